@@ -1,0 +1,118 @@
+"""Seeded synthetic inputs shared by the golden generator and the tests
+(fixed seeds, tie-free scores, boxes inside a 600x1000 image).
+
+Large tensors (features, weights) are regenerated from the seed instead of being
+stored in the fixtures; only the reference-side OUTPUTS are committed as .npz.
+"""
+import numpy as np
+
+F32 = np.float32
+IM_H, IM_W = 600, 1000
+
+
+def random_boxes(n, seed, im_h=IM_H, im_w=IM_W, min_size=16, max_size=400):
+    """n boxes (x1,y1,x2,y2) fp32, integer-free uniform, clipped to the image."""
+    rng = np.random.default_rng(seed)
+    x1 = rng.uniform(0, im_w - min_size - 1, n)
+    y1 = rng.uniform(0, im_h - min_size - 1, n)
+    w = rng.uniform(min_size, max_size, n)
+    h = rng.uniform(min_size, max_size, n)
+    x2 = np.minimum(x1 + w, im_w - 1)
+    y2 = np.minimum(y1 + h, im_h - 1)
+    return np.stack((x1, y1, x2, y2), axis=1).astype(F32)
+
+
+def relation_case(n, m, seed, std, feat_dim=1024, dim=(1024, 1024, 1024), fc_dim=16, emb=64,
+                  index=1, prefix=''):
+    """boxes [n,4], feat [n,feat_dim], relation weights N(0,std) (biases small non-zero so
+    bias handling is exercised; the reference initialises them to 0 but trains them)."""
+    rng = np.random.default_rng(seed)
+    boxes = random_boxes(n, seed + 1000)
+    feat = rng.normal(0, 1, (n, feat_dim)).astype(F32)
+    p = {}
+    def nrm(*shape, s=std):
+        return rng.normal(0.0, s, size=shape).astype(F32)
+    p['%spair_pos_fc1_%d_weight' % (prefix, index)] = nrm(fc_dim, emb)
+    p['%spair_pos_fc1_%d_bias' % (prefix, index)] = nrm(fc_dim, s=std)
+    p['%squery_%d_weight' % (prefix, index)] = nrm(dim[0], feat_dim)
+    p['%squery_%d_bias' % (prefix, index)] = nrm(dim[0], s=std)
+    p['%skey_%d_weight' % (prefix, index)] = nrm(dim[1], feat_dim)
+    p['%skey_%d_bias' % (prefix, index)] = nrm(dim[1], s=std)
+    p['%slinear_out_%d_weight' % (prefix, index)] = nrm(dim[2], feat_dim, 1, 1)
+    p['%slinear_out_%d_bias' % (prefix, index)] = nrm(dim[2], s=std)
+    return boxes, feat, p
+
+
+RELATION_CASES = {
+    # name: (n, m, seed, std)
+    'rel_n48_m48_std01': (48, 48, 11, 0.01),
+    'rel_n40_m32_std05': (40, 32, 12, 0.05),     # keys = first 32 rois (nongt_dim < N)
+}
+
+
+def learn_nms_case(n, num_fg, seed, std=0.05):
+    """Inputs of the learn_nms operator (operator_py/learn_nms.py:437-441 argument order)."""
+    rng = np.random.default_rng(seed)
+    boxes = random_boxes(n, seed + 2000)
+    rois = np.hstack((np.zeros((n, 1), F32), boxes)).astype(F32)
+    cls_score = rng.normal(0, 2.0, (n, num_fg + 1)).astype(F32)
+    bbox_pred = rng.normal(0, 0.1, (n, 8)).astype(F32)
+    im_info = np.array([[IM_H, IM_W, 1.0]], dtype=F32)
+    feat = np.maximum(rng.normal(0, 1, (n, 1024)), 0).astype(F32)
+    def nrm(*shape, s=std):
+        return rng.normal(0.0, s, size=shape).astype(F32)
+    p = {
+        'nms_rank_weight': nrm(128, 1024), 'nms_rank_bias': nrm(128),
+        'roi_feat_embedding_weight': nrm(128, 1024), 'roi_feat_embedding_bias': nrm(128),
+        'nms_pair_pos_fc1_1_weight': nrm(16, 64), 'nms_pair_pos_fc1_1_bias': nrm(16),
+        'nms_query_1_weight': nrm(1024, 128), 'nms_query_1_bias': nrm(1024),
+        'nms_key_1_weight': nrm(1024, 128), 'nms_key_1_bias': nrm(1024),
+        'nms_linear_out_1_weight': nrm(128, 128, 1, 1), 'nms_linear_out_1_bias': nrm(128),
+        'nms_logit_weight': nrm(5, 128), 'nms_logit_bias': np.full(5, -3.0, F32),
+    }
+    return cls_score, bbox_pred, rois, im_info, feat, p
+
+
+LEARN_NMS_ARG_ORDER = ['nms_rank_weight', 'nms_rank_bias', 'roi_feat_embedding_weight',
+                       'roi_feat_embedding_bias', 'nms_pair_pos_fc1_1_weight',
+                       'nms_pair_pos_fc1_1_bias', 'nms_query_1_weight', 'nms_query_1_bias',
+                       'nms_key_1_weight', 'nms_key_1_bias', 'nms_linear_out_1_weight',
+                       'nms_linear_out_1_bias', 'nms_logit_weight', 'nms_logit_bias']
+
+LEARN_NMS_CASES = {
+    # name: (n_rois, num_fg_classes, first_n, seed)
+    'lnms_n60_c6_f20': (60, 6, 20, 21),
+}
+
+
+def dets_case(n, seed):
+    """[n,5] fp32 detections with distinct scores for NMS tests."""
+    rng = np.random.default_rng(seed)
+    boxes = random_boxes(n, seed + 3000, max_size=300)
+    scores = rng.permutation(n).astype(np.float64)
+    scores = (scores + rng.uniform(0.1, 0.9, n)) / n       # distinct, in (0,1)
+    return np.hstack((boxes, scores[:, None].astype(F32))).astype(F32)
+
+
+def rpn_case(seed, height=38, width=63, num_anchors=12, score_sigma=2.0, delta_sigma=0.5):
+    """cls_prob [1,2A,H,W] (softmax pairs), bbox_pred [1,4A,H,W]; fg scores tie-free."""
+    rng = np.random.default_rng(seed)
+    logit = rng.normal(0, score_sigma, (1, num_anchors, height, width))
+    fg = 1.0 / (1.0 + np.exp(-logit))
+    fg = fg.astype(F32)
+    flat = fg.ravel()
+    # break exact fp32 ties deterministically
+    order = np.argsort(flat, kind='stable')
+    s = flat[order]
+    for _ in range(4):
+        dup = np.where(s[1:] <= s[:-1])[0]
+        if dup.size == 0:
+            break
+        for d in dup:
+            s[d + 1] = np.nextafter(s[d], F32(2.0), dtype=F32)
+    flat[order] = s
+    fg = flat.reshape(fg.shape)
+    cls_prob = np.concatenate((F32(1) - fg, fg), axis=1).astype(F32)
+    deltas = rng.normal(0, delta_sigma, (1, 4 * num_anchors, height, width)).astype(F32)
+    im_info = np.array([[IM_H, IM_W, 1.0]], dtype=F32)
+    return cls_prob, deltas, im_info

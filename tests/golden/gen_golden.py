@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by EXECUTING THE REFERENCE'S OWN PYTHON.
+
+Run in the build container only (needs /root/reference; the GPU box has neither the
+reference nor a need for this script -- tests read the committed .npz files):
+
+    python tests/golden/gen_golden.py [--ref /root/reference]
+
+What runs from the reference, unchanged, imported from where it lies:
+  lib/rpn/generate_anchor.py            generate_anchors
+  lib/bbox/bbox_transform.py            bbox_pred (nonlinear_pred), clip_boxes,
+                                        nonlinear_transform, bbox_overlaps_py
+  lib/nms/nms.py                        nms, soft_nms
+  relation_rcnn/symbols/resnet_v1_101_rcnn_attention_1024_pairwise_position_multi_head_16.py
+                                        extract_position_matrix, extract_position_embedding,
+                                        attention_module_multi_head
+  relation_rcnn/operator_py/learn_nms.py  LearnNmsOperator.forward (+ its nd helpers)
+
+Shims needed because the reference is Python-2 / numpy-1 / MXNet-1.1.0 code (none of
+them edits a reference file): `xrange`, `np.float`/`np.int` aliases, `cPickle`, stub
+modules for the compiled Cython/CUDA extensions (`bbox`, `cpu_nms`, `gpu_nms`) and for
+the three operator_py files with Python-2 print statements, and the numpy MXNet
+stand-in in tests/golden/refshim (its docstring says what that does and does not pin).
+"""
+import argparse
+import builtins
+import importlib.util
+import os
+import pickle
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import cases  # noqa: E402
+
+F32 = np.float32
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def setup_reference(ref):
+    builtins.xrange = range
+    if not hasattr(np, 'float'):
+        np.float = float
+    if not hasattr(np, 'int'):
+        np.int = int
+    sys.modules['cPickle'] = pickle
+    sys.path.insert(0, os.path.join(HERE, 'refshim'))
+    import mxnet  # noqa: F401  (the numpy stand-in)
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    def _no_ext(*a, **k):
+        raise RuntimeError("compiled reference extension is not available")
+
+    stub('bbox', bbox_overlaps_cython=_no_ext)
+    stub('cpu_nms', cpu_nms=_no_ext)
+    stub('gpu_nms', gpu_nms=_no_ext)
+    op = stub('operator_py')
+    op.__path__ = []
+    for sub in ('proposal', 'proposal_target', 'box_annotator_ohem'):
+        stub('operator_py.' + sub)
+    sys.path.insert(0, os.path.join(ref, 'lib'))            # utils.symbol
+    ga = _load('ref_generate_anchor', os.path.join(ref, 'lib/rpn/generate_anchor.py'))
+    bt = _load('ref_bbox_transform', os.path.join(ref, 'lib/bbox/bbox_transform.py'))
+    nm = _load('ref_nms', os.path.join(ref, 'lib/nms/nms.py'))
+    sym_dir = os.path.join(ref, 'relation_rcnn/symbols')
+    _load('resnet_v1_101_rcnn_base', os.path.join(sym_dir, 'resnet_v1_101_rcnn_base.py'))
+    rel = _load('ref_sym_rel', os.path.join(
+        sym_dir, 'resnet_v1_101_rcnn_attention_1024_pairwise_position_multi_head_16.py'))
+    lnms = _load('ref_learn_nms', os.path.join(ref, 'relation_rcnn/operator_py/learn_nms.py'))
+    return ga, bt, nm, rel, lnms
+
+
+def gen_boxes(ga, bt, out):
+    d = {}
+    d['anchors_default'] = ga.generate_anchors()
+    d['anchors_cfg'] = ga.generate_anchors(base_size=16, ratios=np.array([0.5, 1, 2]),
+                                           scales=np.array([4, 8, 16, 32]))
+    rng = np.random.default_rng(5)
+    boxes = cases.random_boxes(200, 6)
+    deltas = rng.normal(0, 0.5, (200, 8)).astype(F32)
+    pred = bt.nonlinear_pred(boxes, deltas)
+    d['pred_boxes_in'] = boxes
+    d['pred_deltas_in'] = deltas
+    d['pred_out'] = pred
+    d['pred_out_f64deltas'] = bt.nonlinear_pred(boxes, deltas.astype(np.float64))
+    d['clip_out'] = bt.clip_boxes(pred.copy(), (cases.IM_H, cases.IM_W))
+    gt = cases.random_boxes(200, 7)
+    d['transform_gt_in'] = gt
+    d['transform_out'] = bt.nonlinear_transform(boxes.astype(np.float64), gt.astype(np.float64))
+    d['overlaps_out'] = bt.bbox_overlaps_py(boxes[:20].astype(np.float64), gt[:15].astype(np.float64))
+    np.savez_compressed(os.path.join(out, 'boxes.npz'), **d)
+
+
+def gen_nms(nm, out):
+    d = {}
+    for name, (n, seed) in {'a': (300, 31), 'b': (1000, 32)}.items():
+        dets = cases.dets_case(n, seed)
+        for t in (0.3, 0.5, 0.7):
+            d['nms_%s_%d' % (name, int(t * 10))] = np.asarray(nm.nms(dets.copy(), t), dtype=np.int64)
+        d['softnms_%s' % name] = nm.soft_nms(dets.copy(), 0.6, -1)
+        d['softnms_%s_max100' % name] = nm.soft_nms(dets.copy(), 0.6, 100)
+    np.savez_compressed(os.path.join(out, 'nms.npz'), **d)
+
+
+def gen_relation(rel, out):
+    import mxnet as mx
+    cls = rel.resnet_v1_101_rcnn_attention_1024_pairwise_position_multi_head_16
+    net = cls()
+    d = {}
+    for name, (n, m, seed, std) in cases.RELATION_CASES.items():
+        boxes, feat, p = cases.relation_case(n, m, seed, std)
+        mx.PARAMS.clear(); mx.TRACE.clear()
+        mx.PARAMS.update({k: mx.NDArray(v) for k, v in p.items()})
+        pm = net.extract_position_matrix(mx.NDArray(boxes), nongt_dim=m)
+        pe = net.extract_position_embedding(pm, feat_dim=64)
+        y = net.attention_module_multi_head(mx.NDArray(feat), pe, nongt_dim=m, fc_dim=16,
+                                            feat_dim=1024, index=1, group=16,
+                                            dim=(1024, 1024, 1024))
+        logits, soft = mx.TRACE['softmax_1']
+        d[name + '/position_matrix'] = pm.asnumpy()
+        d[name + '/position_embedding'] = pe.asnumpy()
+        d[name + '/logits'] = logits                      # weighted_aff [N, 16, M]
+        d[name + '/softmax'] = soft
+        d[name + '/output'] = y.asnumpy()
+    np.savez_compressed(os.path.join(out, 'relation.npz'), **d)
+
+
+def gen_learn_nms(lnms, out):
+    import mxnet as mx
+    d = {}
+    for name, (n, c, first_n, seed) in cases.LEARN_NMS_CASES.items():
+        cls_score, bbox_pred, rois, im_info, feat, p = cases.learn_nms_case(n, c, seed)
+        op = lnms.LearnNmsOperator(num_fg_classes=c, bbox_means=None, bbox_stds=None,
+                                   first_n=first_n, class_agnostic=True, num_thresh=5,
+                                   class_thresh=0.01, nongt_dim=n, has_non_gt_index=False)
+        in_data = [mx.NDArray(x) for x in (cls_score, bbox_pred, rois, im_info, feat)]
+        in_data += [mx.NDArray(p[k]) for k in cases.LEARN_NMS_ARG_ORDER]
+        outs = [mx.nd.zeros((first_n, c, 5)), mx.nd.zeros((first_n, c, 4)), mx.nd.zeros((first_n, c))]
+        mx.TRACE.clear()
+        op.forward(False, ['write'] * 3, in_data, outs, [])
+        d[name + '/nms_multi_score'] = outs[0].asnumpy()
+        d[name + '/sorted_bbox'] = outs[1].asnumpy()
+        d[name + '/sorted_score'] = outs[2].asnumpy()
+        d[name + '/logits'] = mx.TRACE['nms_softmax_1'][0]
+    np.savez_compressed(os.path.join(out, 'learn_nms.npz'), **d)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--ref', default='/root/reference')
+    ap.add_argument('--out', default=HERE)
+    a = ap.parse_args()
+    ga, bt, nm, rel, lnms = setup_reference(a.ref)
+    gen_boxes(ga, bt, a.out)
+    gen_nms(nm, a.out)
+    gen_relation(rel, a.out)
+    gen_learn_nms(lnms, a.out)
+    for f in sorted(os.listdir(a.out)):
+        if f.endswith('.npz'):
+            print(f, os.path.getsize(os.path.join(a.out, f)), 'bytes')
+
+
+if __name__ == '__main__':
+    main()

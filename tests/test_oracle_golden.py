@@ -1,0 +1,119 @@
+"""The CPU oracle against golden vectors produced by the reference's own python
+(tests/golden/gen_golden.py) plus hand-checkable known answers."""
+import numpy as np
+
+import cases
+from oracle import boxes as OB
+from oracle import nms as ON
+from oracle import relation as OR
+from oracle import learn_nms as OL
+
+
+def test_anchor_known_answers():
+    # classic py-faster-rcnn table (ratios .5,1,2 x scales 8,16,32)
+    want = np.array([[-84, -40, 99, 55], [-176, -88, 191, 103], [-360, -184, 375, 199],
+                     [-56, -56, 71, 71], [-120, -120, 135, 135], [-248, -248, 263, 263],
+                     [-36, -80, 51, 95], [-80, -168, 95, 183], [-168, -344, 183, 359]], dtype=np.float64)
+    assert np.array_equal(OB.generate_anchors(), want)
+    cfg = OB.generate_anchors(16, (0.5, 1, 2), (4, 8, 16, 32))
+    assert cfg.shape == (12, 4)
+    assert np.array_equal(cfg[[0, 4, 8]], [[-38, -16, 53, 31], [-24, -24, 39, 39], [-14, -36, 29, 51]])
+
+
+def test_anchors_match_reference(golden):
+    g = golden['boxes']
+    assert np.array_equal(OB.generate_anchors(), g['anchors_default'])
+    assert np.array_equal(OB.generate_anchors(16, (0.5, 1, 2), (4, 8, 16, 32)), g['anchors_cfg'])
+
+
+def test_box_decode_clip_transform_match_reference(golden):
+    g = golden['boxes']
+    # float64 deltas: every op is IEEE float64 in both -> bit exact
+    p64 = OB.bbox_pred(g['pred_boxes_in'], g['pred_deltas_in'].astype(np.float64))
+    assert p64.dtype == np.float64 and np.array_equal(p64, g['pred_out_f64deltas'])
+    # float32 deltas: the reference calls numpy's float32 exp (a SIMD approximation that
+    # differs between numpy builds); the oracle pins the correctly rounded fp32 exp, so
+    # agreement is to 1 ulp of that exp (relative 2^-23 on the box extent).
+    pred = OB.bbox_pred(g['pred_boxes_in'], g['pred_deltas_in'])
+    ext = np.abs(g['pred_out'][:, 2::4] - g['pred_out'][:, 0::4]).max()
+    assert np.abs(pred - g['pred_out']).max() <= 2.0 ** -23 * ext
+    pred = g['pred_out']
+    assert np.array_equal(OB.clip_boxes(pred, (cases.IM_H, cases.IM_W)), g['clip_out'])
+    t = OB.bbox_transform(g['pred_boxes_in'], g['transform_gt_in'])
+    assert np.array_equal(t, g['transform_out'])
+    ov = OB.bbox_overlaps(g['pred_boxes_in'][:20], g['transform_gt_in'][:15])
+    assert np.array_equal(ov, g['overlaps_out'])
+
+
+def test_iou_micro_cases():
+    a = np.array([0, 0, 9, 9], np.float32)
+    b = np.array([[0, 0, 9, 9], [5, 0, 14, 9], [10, 10, 19, 19], [9, 9, 18, 18]], np.float32)
+    iou = ON.iou_f32(a, b)
+    # +1 pixel extents: areas 100; overlaps 100, 50, 0, 1
+    np.testing.assert_allclose(iou, [1.0, 50 / 150., 0.0, 1 / 199.], rtol=1e-6)
+
+
+def test_nms_and_softnms_match_reference(golden):
+    g = golden['nms']
+    for name, (n, seed) in {'a': (300, 31), 'b': (1000, 32)}.items():
+        dets = cases.dets_case(n, seed)
+        for t in (0.3, 0.5, 0.7):
+            want = g['nms_%s_%d' % (name, int(t * 10))]
+            assert np.array_equal(np.asarray(ON.py_nms(dets, t)), want)
+            # the CUDA-order variant (fp32 IoU, strict >) selects the same boxes here
+            assert np.array_equal(np.asarray(ON.gpu_nms(dets, t)), want)
+        assert np.array_equal(ON.soft_nms(dets, 0.6, -1), g['softnms_%s' % name])
+        assert np.array_equal(ON.soft_nms(dets, 0.6, 100), g['softnms_%s_max100' % name])
+
+
+def test_nms_three_box_order():
+    dets = np.array([[0, 0, 10, 10, 0.5], [1, 1, 11, 11, 0.9], [50, 50, 60, 60, 0.1]], np.float32)
+    assert ON.gpu_nms(dets, 0.5) == [1, 2]
+    assert ON.py_nms(dets, 0.5) == [1, 2]
+
+
+def test_relation_module_matches_reference_graph(golden):
+    g = golden['relation']
+    for name, (n, m, seed, std) in cases.RELATION_CASES.items():
+        boxes, feat, p = cases.relation_case(n, m, seed, std)
+        pm = OR.position_matrix(boxes, m)
+        pe = OR.position_embedding(pm)
+        assert np.array_equal(pm, g[name + '/position_matrix'])
+        assert np.array_equal(pe, g[name + '/position_embedding'])
+        r = OR.relation_module(feat, pe, p, index=1, nongt_dim=m, return_intermediates=True)
+        np.testing.assert_allclose(r['logits'], g[name + '/logits'], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(r['softmax'], g[name + '/softmax'], rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(r['output'], g[name + '/output'], rtol=1e-5, atol=1e-6)
+
+
+def test_logit_conditioning_is_what_design_md_says():
+    """DESIGN.md "tolerances": the fp32 graph multiplies the log-geometry by 100 before
+    sin/cos and takes log(relu(.)) afterwards, so a 1-ulp change of the position matrix
+    moves some logits by far more than 1e-4 although the module output barely moves.
+    Hence the HIP path reproduces the position matrix bit-exactly (same IEEE ops,
+    correctly rounded log) and the logit bound is conditioning-aware."""
+    name, (n, m, seed, std) = next(iter(cases.RELATION_CASES.items()))
+    boxes, feat, p = cases.relation_case(n, m, seed, std)
+    pm = OR.position_matrix(boxes, m)
+    r = OR.relation_module(feat, OR.position_embedding(pm), p, 1, m, return_intermediates=True)
+    pm_ulp = np.nextafter(pm, np.float32(100))
+    r2 = OR.relation_module(feat, OR.position_embedding(pm_ulp), p, 1, m, return_intermediates=True)
+    dl = np.abs(r['logits'] - r2['logits'])
+    assert dl.max() > 1e-3                       # ill-conditioned entries exist
+    assert np.abs(r['output'] - r2['output']).max() < 1e-4
+    # a 1-ulp change of the sin/cos values, by contrast, is harmless where G >= 1e-3
+    r3 = OR.relation_module(feat, np.nextafter(OR.position_embedding(pm), np.float32(2)), p, 1, m,
+                            return_intermediates=True)
+    well = r['aff_weight'] >= 1e-3
+    assert np.abs(r['logits'] - r3['logits'])[well].max() < 1e-4
+
+
+def test_learn_nms_matches_reference_operator(golden):
+    g = golden['learn_nms']
+    for name, (n, c, first_n, seed) in cases.LEARN_NMS_CASES.items():
+        cls_score, bbox_pred, rois, im_info, feat, p = cases.learn_nms_case(n, c, seed)
+        multi, sbox, sscore = OL.learn_nms(cls_score, bbox_pred, rois, im_info, feat, p,
+                                           num_fg_classes=c, first_n=first_n, nongt_dim=n)
+        np.testing.assert_allclose(sscore, g[name + '/sorted_score'], rtol=1e-6, atol=0)
+        np.testing.assert_allclose(sbox, g[name + '/sorted_bbox'], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(multi, g[name + '/nms_multi_score'], rtol=2e-5, atol=1e-7)
