@@ -1,0 +1,51 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the relation-network
+// detection hot path.  gfx950 only: 64-wide wavefronts, MFMA 32x32x16 bf16 / 32x32x2 f32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace relnet {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;    // 8 bf16 = MFMA A/B fragment
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int kWave = 64;
+
+// float -> bf16 bits, round to nearest even (inputs are finite on this path).
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  unsigned int u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) {
+  return __uint_as_float(((unsigned int)h) << 16);
+}
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+}
+
+// Row index inside a 32x32 MFMA C/D tile held by this lane in accumulator register r:
+//   col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)      (guide section 3)
+__device__ __forceinline__ int mfma32_row(int r, int lane) {
+  return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+
+}  // namespace relnet
+
+// Error plumbing of the C-ABI: every entry point returns 0 or a negative code and
+// records a message retrievable with relnet_last_error().
+extern "C" const char* relnet_last_error(void);
+namespace relnet {
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+}  // namespace relnet
+
+#define RELNET_REQUIRE(cond, ...)            \
+  do {                                       \
+    if (!(cond)) {                           \
+      relnet::set_error(__VA_ARGS__);        \
+      return -1;                             \
+    }                                        \
+  } while (0)

@@ -1,0 +1,358 @@
+// Object-relation module kernels (reference: relation_rcnn/symbols/
+// resnet_v1_101_rcnn_attention_1024_pairwise_position_multi_head_16.py = SYM_REL).
+//
+//  geometry_bias_kernel   SYM_REL:46-83 (extract_position_matrix) + :29-44
+//                         (extract_position_embedding) + :109-116 (pair_pos_fc1 + ReLU) +
+//                         the log(max(.,1e-6)) of :139, fused: the [N,M,64] embedding
+//                         (23 MB / image in the reference) never exists in HBM; the same
+//                         sin/cos values feed every relation module that shares the boxes.
+//  relation_attention_kernel  SYM_REL:132-150: logits = bias + QK^T/8, softmax over keys,
+//                         value aggregation and the grouped 1x1 `linear_out`.
+//                         linear_out is re-associated: Y_h = S_h (F_K Wout_h^T); the
+//                         [M,64] product F_K Wout_h^T ("VW") comes from the GEMM kernel as
+//                         VW^T[h*64+dv][key], so the kernel is a flash-style attention
+//                         with d_k = d_v = 64 (executed FLOPs 4.4x below the graph as
+//                         written; DESIGN.md reports both).
+#include "common.h"
+
+namespace relnet {
+
+// ---------------------------------------------------------------------------------------
+// geometry bias: one thread per (query i, key j) pair, all heads x modules.
+// ---------------------------------------------------------------------------------------
+struct GeomArgs {
+  const float* boxes;      // [B, N, box_stride] (x1,y1,x2,y2 at +box_off)
+  int box_stride, box_off;
+  const float* wp;         // [64, NMOD*FC]  pair_pos_fc1 weights, embedding-index major
+  const float* bp;         // [NMOD, FC]
+  float divisors[8];       // wave_length^(k/8), fp32 (host computes them like the graph)
+  float* bias;             // [NMOD, B, FC, N, Mpad]   log(max(relu(E Wp^T + bp), 1e-6))
+  float* pos_mat;          // optional [B, N, M, 4]
+  float* pos_emb;          // optional [B, N, M, 64]
+  int B, N, M, Mpad, nmod;
+};
+
+#pragma clang fp contract(off)
+__device__ __forceinline__ void position_features(float4 bi, float4 bj, float (&p)[4]) {
+  // bit-for-bit the fp32 op sequence of SYM_REL:59-77; log is correctly rounded (fp64
+  // evaluation) because a 1-ulp log difference is amplified x100 before sin/cos.
+  const float wi = bi.z - bi.x + 1.f, hi = bi.w - bi.y + 1.f;
+  const float wj = bj.z - bj.x + 1.f, hj = bj.w - bj.y + 1.f;
+  const float cxi = 0.5f * (bi.x + bi.z), cyi = 0.5f * (bi.y + bi.w);
+  const float cxj = 0.5f * (bj.x + bj.z), cyj = 0.5f * (bj.y + bj.w);
+  const float dx = fmaxf(fabsf((cxi - cxj) / wi), 1e-3f);
+  const float dy = fmaxf(fabsf((cyi - cyj) / hi), 1e-3f);
+  p[0] = (float)log((double)dx);
+  p[1] = (float)log((double)dy);
+  p[2] = (float)log((double)(wi / wj));
+  p[3] = (float)log((double)(hi / hj));
+}
+
+template <int FC, int NMOD>
+__global__ __launch_bounds__(256) void geometry_bias_kernel(GeomArgs g) {
+  const long pair = (long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (pair >= (long)g.N * g.M) return;
+  const int i = (int)(pair / g.M), j = (int)(pair % g.M);
+  const float* bx = g.boxes + (long)b * g.N * g.box_stride + g.box_off;
+  const float* pi = bx + (long)i * g.box_stride;
+  const float* pj = bx + (long)j * g.box_stride;
+  const float4 bi = make_float4(pi[0], pi[1], pi[2], pi[3]);
+  const float4 bj = make_float4(pj[0], pj[1], pj[2], pj[3]);
+  float p[4];
+  position_features(bi, bj, p);
+  if (g.pos_mat) *(float4*)(g.pos_mat + (((long)b * g.N + i) * g.M + j) * 4) = make_float4(p[0], p[1], p[2], p[3]);
+
+  constexpr int NO = NMOD * FC;                  // outputs per pair
+  float acc[NO];
+#pragma unroll
+  for (int o = 0; o < NO; ++o) acc[o] = g.bp[o];
+
+#pragma unroll 1
+  for (int c = 0; c < 4; ++c) {
+    const float pc = c == 0 ? p[0] : c == 1 ? p[1] : c == 2 ? p[2] : p[3];
+    const float x100 = 100.0f * pc;
+    float e[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float arg = x100 / g.divisors[k];
+      sincosf(arg, &e[k], &e[8 + k]);
+    }
+    if (g.pos_emb) {
+      float* pe = g.pos_emb + (((long)b * g.N + i) * g.M + j) * 64 + c * 16;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) pe[k] = e[k];
+    }
+    // wp_t is [64][NO] (embedding index major): the NO weights of one embedding element
+    // are contiguous and wave-uniform -> s_load_dwordx16 + v_fmac with an SGPR operand.
+    const float* w = g.wp + (long)(c * 16) * NO;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+      for (int o = 0; o < NO; ++o) acc[o] = fmaf(e[k], w[k * NO + o], acc[o]);
+  }
+#pragma unroll
+  for (int m = 0; m < NMOD; ++m)
+#pragma unroll
+    for (int h = 0; h < FC; ++h) {
+      const float gw = fmaxf(fmaxf(acc[m * FC + h], 0.f), 1e-6f);
+      g.bias[((((long)m * g.B + b) * FC + h) * g.N + i) * g.Mpad + j] = logf(gw);
+    }
+}
+#pragma clang fp contract(fast)
+
+// ---------------------------------------------------------------------------------------
+// relation attention.  One wave = 32 queries of one (image, head); key tiles of 32.
+// S^T = K Q^T is computed "swapped" so every lane owns one query column: the row max /
+// row sum are in-lane plus one lane^32 exchange, and the per-query rescale is a per-lane
+// scalar.  P^T feeds the second MFMA directly from the accumulator registers: the
+// contraction (key) index is permuted identically in P^T and in the VW^T fragment loads,
+// so no cross-lane shuffle or LDS round trip is needed between the two products.
+// ---------------------------------------------------------------------------------------
+struct AttnArgs {
+  const void* q; long q_ld, q_bs;        // [B][N][.. h*64+d ..]
+  const void* k; long k_ld, k_bs;        // [B][M][.. h*64+d ..]
+  const void* vwt; long vwt_ld, vwt_bs;  // [B][H*64][Mpad]   (VW^T, keys contiguous)
+  const float* bias; long bias_bs;       // [B][H][N][Mpad] fp32
+  const float* bout;                     // [H*64] linear_out bias or nullptr
+  const void* resid; long resid_ld, resid_bs;   // optional residual (same dtype as out)
+  void* out; long out_ld, out_bs;        // Y = attention output (nullptr to skip)
+  void* out_act; long act_ld, act_bs;    // relu(resid + Y)      (nullptr to skip)
+  float* logits;                         // optional [B][N][H][M] fp32 (weighted_aff)
+  int B, H, N, M, Mpad;
+  float scale;
+};
+
+template <typename T, typename TOUT>
+__global__ __launch_bounds__(256) void relation_attention_kernel(AttnArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int qt = blockIdx.x * 4 + wave;
+  const int h = blockIdx.y, b = blockIdx.z;
+  if (qt * 32 >= a.N) return;
+  const int q = qt * 32 + l31;
+  const int qc = q < a.N ? q : a.N - 1;                 // clamped row for loads
+  constexpr bool kBF = sizeof(T) == 2;
+
+  const T* Q = (const T*)a.q + (long)b * a.q_bs + (long)qc * a.q_ld + h * 64;
+  const T* Kb = (const T*)a.k + (long)b * a.k_bs + h * 64;
+  const T* Vb = (const T*)a.vwt + (long)b * a.vwt_bs + (long)(h * 64) * a.vwt_ld;
+  const float* Bq = a.bias + (long)b * a.bias_bs + ((long)h * a.N + qc) * a.Mpad;
+
+  // Q fragments (B operand of S^T = K Q^T): 64 d-values per query.
+  bf16x8 qf[4];
+  float qs[32];
+  if constexpr (kBF) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(Q + 16 * kk + 8 * half);
+  } else {
+#pragma unroll
+    for (int s = 0; s < 32; s += 4) {
+      const float4 v = *(const float4*)(Q + half * 32 + s);
+      qs[s] = v.x; qs[s + 1] = v.y; qs[s + 2] = v.z; qs[s + 3] = v.w;
+    }
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nkt = (a.M + 31) / 32;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int key0 = kt * 32;
+    int kr = key0 + l31; kr = kr < a.M ? kr : a.M - 1;
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    if constexpr (kBF) {
+      const T* Kr = Kb + (long)kr * a.k_ld;
+      bf16x8 kf[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) kf[kk] = *(const bf16x8*)(Kr + 16 * kk + 8 * half);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], s, 0, 0, 0);
+    } else {
+      const float* Kr = (const float*)Kb + (long)kr * a.k_ld + half * 32;
+#pragma unroll
+      for (int c4 = 0; c4 < 8; ++c4) {
+        const float4 v = *(const float4*)(Kr + 4 * c4);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, qs[4 * c4 + 0], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, qs[4 * c4 + 1], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, qs[4 * c4 + 2], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, qs[4 * c4 + 3], s, 0, 0, 0);
+      }
+    }
+    // logits for this lane's query: keys key0 + 8g + 4*half + (0..3), g = r >> 2
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int kbase = key0 + 8 * gq + 4 * half;
+      const float4 bv = *(const float4*)(Bq + kbase);
+      const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * gq + e;
+        float v = a.scale * s[r];
+        v = bb[e] + v;                                   // weighted_aff (SYM_REL:139)
+        v = (kbase + e < a.M) ? v : -INFINITY;
+        s[r] = v;
+        tmax = fmaxf(tmax, v);
+      }
+      if (a.logits && q < a.N) {
+        float* lp = a.logits + (((long)b * a.N + q) * a.H + h) * a.M + kbase;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (kbase + e < a.M) lp[e] = s[4 * gq + e];
+      }
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = kBF ? __expf(m_run - m_new) : expf(m_run - m_new);   // first tile: exp(-inf) = 0
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = kBF ? __expf(s[r] - m_new) : expf(s[r] - m_new);
+      s[r] = pv;
+      psum += pv;
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+
+    // O^T[dv][q] += VW^T[dv][key] P^T[key][q]; key slot t of k-step ks is
+    // key0 + 16 ks + 8 (t >> 2) + 4 half + (t & 3) for BOTH operands.
+    if constexpr (kBF) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 pf;
+        unsigned int* pw = (unsigned int*)&pf;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) pw[t] = pack_bf16x2(s[8 * ks + 2 * t], s[8 * ks + 2 * t + 1]);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const T* Vr = Vb + (long)(32 * d + l31) * a.vwt_ld + key0 + 16 * ks + 4 * half;
+          bf16x8 vf;
+          *(uint2*)&vf = *(const uint2*)(Vr);
+          *((uint2*)&vf + 1) = *(const uint2*)(Vr + 8);
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const float* Vr = (const float*)Vb + (long)(32 * d + l31) * a.vwt_ld + key0 + 4 * half;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const float4 v = *(const float4*)(Vr + 8 * gq);
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, s[4 * gq + 0], o[d], 0, 0, 0);
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, s[4 * gq + 1], o[d], 0, 0, 0);
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, s[4 * gq + 2], o[d], 0, 0, 0);
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, s[4 * gq + 3], o[d], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (q >= a.N) return;
+  TOUT* Y = a.out ? (TOUT*)a.out + (long)b * a.out_bs + (long)q * a.out_ld + h * 64 : nullptr;
+  TOUT* Z = a.out_act ? (TOUT*)a.out_act + (long)b * a.act_bs + (long)q * a.act_ld + h * 64 : nullptr;
+  const TOUT* R = a.resid ? (const TOUT*)a.resid + (long)b * a.resid_bs + (long)q * a.resid_ld + h * 64 : nullptr;
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int dv = 32 * d + 8 * gq + 4 * half;
+      float y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        y[e] = o[d][4 * gq + e] * inv;
+        if (a.bout) y[e] += a.bout[h * 64 + dv + e];
+      }
+      if constexpr (sizeof(TOUT) == 4) {
+        if (Y) *(float4*)((float*)Y + dv) = make_float4(y[0], y[1], y[2], y[3]);
+        if (Z) {
+          float4 rv = R ? *(const float4*)((const float*)R + dv) : make_float4(0, 0, 0, 0);
+          *(float4*)((float*)Z + dv) = make_float4(fmaxf(rv.x + y[0], 0.f), fmaxf(rv.y + y[1], 0.f),
+                                                    fmaxf(rv.z + y[2], 0.f), fmaxf(rv.w + y[3], 0.f));
+        }
+      } else {
+        if (Y) *(uint2*)((unsigned short*)Y + dv) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+        if (Z) {
+          float rr[4] = {0, 0, 0, 0};
+          if (R) {
+            const uint2 rv = *(const uint2*)((const unsigned short*)R + dv);
+            rr[0] = bf2f(rv.x & 0xffff); rr[1] = bf2f(rv.x >> 16);
+            rr[2] = bf2f(rv.y & 0xffff); rr[3] = bf2f(rv.y >> 16);
+          }
+          *(uint2*)((unsigned short*)Z + dv) =
+              make_uint2(pack_bf16x2(fmaxf(rr[0] + y[0], 0.f), fmaxf(rr[1] + y[1], 0.f)),
+                         pack_bf16x2(fmaxf(rr[2] + y[2], 0.f), fmaxf(rr[3] + y[3], 0.f)));
+        }
+      }
+    }
+}
+
+}  // namespace relnet
+
+using namespace relnet;
+enum { RELNET_F32 = 0, RELNET_BF16 = 1 };
+
+extern "C" int relnet_geometry_bias(const float* boxes, int box_stride, int box_off,
+                                    const float* wp, const float* bp, const float* divisors8,
+                                    float* bias, float* pos_mat, float* pos_emb, int B, int N,
+                                    int M, int Mpad, int fc_dim, int nmod, void* stream) {
+  RELNET_REQUIRE(boxes && wp && bp && divisors8 && bias, "relnet_geometry_bias: null operand");
+  RELNET_REQUIRE(fc_dim == 16, "relnet_geometry_bias: fc_dim %d unsupported (16 only)", fc_dim);
+  RELNET_REQUIRE(nmod == 1 || nmod == 2, "relnet_geometry_bias: nmod %d unsupported (1 or 2)", nmod);
+  RELNET_REQUIRE(B > 0 && N > 0 && M > 0 && M <= N && Mpad >= M && Mpad % 32 == 0,
+                 "relnet_geometry_bias: bad shape B=%d N=%d M=%d Mpad=%d", B, N, M, Mpad);
+  GeomArgs g;
+  g.boxes = boxes; g.box_stride = box_stride; g.box_off = box_off; g.wp = wp; g.bp = bp;
+  for (int k = 0; k < 8; ++k) g.divisors[k] = divisors8[k];
+  g.bias = bias; g.pos_mat = pos_mat; g.pos_emb = pos_emb;
+  g.B = B; g.N = N; g.M = M; g.Mpad = Mpad; g.nmod = nmod;
+  dim3 grid((unsigned)(((long)N * M + 255) / 256), B);
+  hipStream_t s = (hipStream_t)stream;
+  if (nmod == 1) geometry_bias_kernel<16, 1><<<grid, 256, 0, s>>>(g);
+  else geometry_bias_kernel<16, 2><<<grid, 256, 0, s>>>(g);
+  return check_launch("relnet_geometry_bias");
+}
+
+extern "C" int relnet_relation_attention(
+    const void* q, long q_ld, long q_bs, const void* k, long k_ld, long k_bs, const void* vwt,
+    long vwt_ld, long vwt_bs, const float* bias, long bias_bs, const float* bout,
+    const void* resid, long resid_ld, long resid_bs, void* out, long out_ld, long out_bs,
+    void* out_act, long act_ld, long act_bs, float* logits, int B, int H, int N, int M, int Mpad,
+    float scale, int in_dtype, int out_dtype, void* stream) {
+  RELNET_REQUIRE(q && k && vwt && bias, "relnet_relation_attention: null operand");
+  RELNET_REQUIRE(out || out_act, "relnet_relation_attention: no output requested");
+  RELNET_REQUIRE(B > 0 && H > 0 && N > 0 && M > 0 && Mpad >= M && Mpad % 32 == 0,
+                 "relnet_relation_attention: bad shape B=%d H=%d N=%d M=%d Mpad=%d", B, H, N, M, Mpad);
+  RELNET_REQUIRE(in_dtype == out_dtype, "relnet_relation_attention: in/out dtype must match (%d vs %d)", in_dtype, out_dtype);
+  AttnArgs a;
+  a.q = q; a.q_ld = q_ld; a.q_bs = q_bs; a.k = k; a.k_ld = k_ld; a.k_bs = k_bs;
+  a.vwt = vwt; a.vwt_ld = vwt_ld; a.vwt_bs = vwt_bs; a.bias = bias; a.bias_bs = bias_bs;
+  a.bout = bout; a.resid = resid; a.resid_ld = resid_ld; a.resid_bs = resid_bs;
+  a.out = out; a.out_ld = out_ld; a.out_bs = out_bs; a.out_act = out_act; a.act_ld = act_ld;
+  a.act_bs = act_bs; a.logits = logits; a.B = B; a.H = H; a.N = N; a.M = M; a.Mpad = Mpad;
+  a.scale = scale;
+  dim3 grid((unsigned)(((N + 31) / 32 + 3) / 4), H, B);
+  hipStream_t s = (hipStream_t)stream;
+  if (in_dtype == RELNET_BF16) {
+    RELNET_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && vwt_ld % 4 == 0, "relnet_relation_attention(bf16): row strides must be 16-byte (q,k) / 8-byte (vwt) aligned");
+    relation_attention_kernel<unsigned short, unsigned short><<<grid, 256, 0, s>>>(a);
+  } else if (in_dtype == RELNET_F32) {
+    RELNET_REQUIRE(q_ld % 4 == 0 && k_ld % 4 == 0 && vwt_ld % 4 == 0, "relnet_relation_attention(f32): row strides must be 16-byte aligned");
+    relation_attention_kernel<float, float><<<grid, 256, 0, s>>>(a);
+  } else {
+    RELNET_REQUIRE(false, "relnet_relation_attention: unknown dtype %d", in_dtype);
+  }
+  return check_launch("relnet_relation_attention");
+}

@@ -1,0 +1,63 @@
+"""ctypes binding of librelnet_hip.so -- the C-ABI declared in include/relnet_hip.h.
+
+The library is the product: there is no CPU or PyTorch fallback.  Importing this module
+when the library is missing raises, and every wrapper raises `RelnetError` on a non-zero
+return code with the message recorded by the library.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'librelnet_hip.so')
+
+F32, BF16 = 0, 1
+
+
+class RelnetError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+_SIGNATURES = {
+    'relnet_version': (C.c_int, []),
+    'relnet_last_error': (C.c_char_p, []),
+    'relnet_gemm_nt': (C.c_int, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _i, _vp, _i,
+                                 _i, _i, _i, _i, _i, _i, _vp]),
+    'relnet_geometry_bias': (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
+                                       _i, _i, _vp]),
+    'relnet_relation_attention': (C.c_int, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _vp,
+                                            _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp,
+                                            _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+}
+
+
+def load():
+    """dlopen the library (once) and attach argument types to every exported symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RelnetError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no fallback path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so is stale -> loud
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RelnetError("%s failed (%d): %s" % (name, rc, lib.relnet_last_error().decode()))

@@ -1,0 +1,127 @@
+"""Torch-tensor front ends of the C-ABI kernels (device memory + streams are torch's;
+all arithmetic happens in librelnet_hip.so).  Every function requires CUDA(HIP) tensors
+and raises otherwise -- there is no CPU or eager fallback.
+"""
+import math
+
+import torch
+
+from . import lib as _lib
+
+F32, BF16 = _lib.F32, _lib.BF16
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("unsupported dtype %s (float32 or bfloat16)" % t.dtype)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is not None:
+            if not t.is_cuda:
+                raise _lib.RelnetError("relnet ops need GPU tensors (HIP kernels only; no CPU fallback)")
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pad32(m):
+    return (m + 31) // 32 * 32
+
+
+def gemm_nt(a, w, bias=None, bias_mode=1, resid=None, relu=False, out=None, out_dtype=None,
+            n_cols=None):
+    """out = a @ w^T (+bias) (+resid) (relu).  a [M,K] or [batch,M,K] (a 2-D `a` with a
+    3-D `w` is broadcast over the batch and vice versa); w [N,K]; rows K-contiguous.
+    `out` may be a wider pre-allocated buffer ([.., M, ldc]); n_cols limits N."""
+    _chk(a, w, bias, resid, out)
+    batch = 1
+    if a.dim() == 3:
+        batch = a.shape[0]
+    if w.dim() == 3:
+        batch = max(batch, w.shape[0])
+    M, K = a.shape[-2], a.shape[-1]
+    N = w.shape[-2] if n_cols is None else n_cols
+    assert w.shape[-1] == K, (a.shape, w.shape)
+    assert a.stride(-1) == 1 and w.stride(-1) == 1
+    sa = a.stride(0) if a.dim() == 3 else 0
+    sw = w.stride(0) if w.dim() == 3 else 0
+    odt = out_dtype or (out.dtype if out is not None else a.dtype)
+    if out is None:
+        shape = (batch, M, N) if batch > 1 or a.dim() == 3 or w.dim() == 3 else (M, N)
+        out = torch.empty(shape, device=a.device, dtype=odt)
+    assert out.stride(-1) == 1
+    sc = out.stride(0) if out.dim() == 3 else 0
+    if resid is not None:
+        assert resid.dtype == out.dtype and resid.stride() == out.stride()
+    _lib.call('relnet_gemm_nt', a.data_ptr(), a.stride(-2), sa, w.data_ptr(), w.stride(-2), sw,
+              out.data_ptr(), out.stride(-2), sc, _ptr(bias), bias_mode if bias is not None else 0,
+              _ptr(resid), int(relu), M, N, K, batch, _dt(a), _dt(out), _stream())
+    return out
+
+
+def embedding_divisors(feat_dim=64, wave_length=1000.0):
+    """fp32 dim_mat of the reference graph (SYM_REL:32-35): wave_length ** ((8/feat_dim) k),
+    evaluated in float32 like MXNet's arange / broadcast_power."""
+    k = torch.arange(0, feat_dim // 8, dtype=torch.float32)
+    return torch.pow(torch.tensor(float(wave_length), dtype=torch.float32),
+                     torch.tensor(8.0 / feat_dim, dtype=torch.float32) * k)
+
+
+def geometry_bias(boxes, wp_t, bp, M=None, divisors=None, debug=False):
+    """boxes [B,N,4|5] fp32 (xyxy, or batch_idx + xyxy); wp_t [64, nmod*16]; bp [nmod*16]
+    -> bias [nmod, B, 16, N, Mpad] fp32 = log(max(relu(E Wp^T + bp), 1e-6)).
+    debug=True also returns (position_matrix [B,N,M,4], position_embedding [B,N,M,64])."""
+    _chk(boxes, wp_t, bp)
+    assert boxes.dtype == torch.float32 and boxes.is_contiguous()
+    B, N, bs = boxes.shape
+    off = 1 if bs == 5 else 0
+    M = N if M is None else M
+    Mpad = pad32(M)
+    nmod = wp_t.shape[1] // 16
+    assert wp_t.shape == (64, nmod * 16) and wp_t.is_contiguous() and wp_t.dtype == torch.float32
+    div = (divisors if divisors is not None else embedding_divisors()).to('cpu', torch.float32).contiguous()
+    bias = torch.empty((nmod, B, 16, N, Mpad), device=boxes.device, dtype=torch.float32)
+    pm = pe = None
+    if debug:
+        pm = torch.empty((B, N, M, 4), device=boxes.device, dtype=torch.float32)
+        pe = torch.empty((B, N, M, 64), device=boxes.device, dtype=torch.float32)
+    _lib.call('relnet_geometry_bias', boxes.data_ptr(), bs, off, wp_t.data_ptr(), bp.data_ptr(),
+              div.data_ptr(), bias.data_ptr(), _ptr(pm), _ptr(pe), B, N, M, Mpad, 16, nmod, _stream())
+    if debug:
+        return bias, pm, pe
+    return bias
+
+
+def relation_attention(q, k, vwt, bias, bout=None, resid=None, M=None, want_out=True,
+                       want_act=False, want_logits=False, heads=16):
+    """q [B,N,>=H*64] (row stride free), k [B,>=M,..], vwt [B,H*64,Mpad] (zero padded),
+    bias [B,H,N,Mpad] fp32 -> (out [B,N,H*64] | None, relu(resid+out) | None, logits | None)."""
+    _chk(q, k, vwt, bias, bout, resid)
+    B, N = q.shape[0], q.shape[1]
+    H = heads
+    Mpad = vwt.shape[-1]
+    M = k.shape[1] if M is None else M
+    assert bias.shape == (B, H, N, Mpad) and bias.is_contiguous() and bias.dtype == torch.float32
+    assert vwt.shape[1] == H * 64 and vwt.stride(-1) == 1 and q.stride(-1) == 1 and k.stride(-1) == 1
+    dt = q.dtype
+    out = torch.empty((B, N, H * 64), device=q.device, dtype=dt) if want_out else None
+    act = torch.empty((B, N, H * 64), device=q.device, dtype=dt) if want_act else None
+    logits = torch.empty((B, N, H, M), device=q.device, dtype=torch.float32) if want_logits else None
+    rs = (resid.stride(1), resid.stride(0)) if resid is not None else (0, 0)
+    _lib.call('relnet_relation_attention',
+              q.data_ptr(), q.stride(1), q.stride(0), k.data_ptr(), k.stride(1), k.stride(0),
+              vwt.data_ptr(), vwt.stride(1), vwt.stride(0), bias.data_ptr(), bias.stride(0),
+              _ptr(bout), _ptr(resid), rs[0], rs[1],
+              _ptr(out), H * 64, N * H * 64, _ptr(act), H * 64, N * H * 64, _ptr(logits),
+              B, H, N, M, Mpad, 1.0 / math.sqrt(64.0), _dt(q), _dt(q), _stream())
+    return out, act, logits

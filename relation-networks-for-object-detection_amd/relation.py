@@ -1,0 +1,127 @@
+"""Host side of the object-relation module and the 2FC relation head.
+
+Mirrors the reference's symbol-level interface for this path
+(relation_rcnn/symbols/resnet_v1_101_rcnn_attention_1024_pairwise_position_multi_head_16.py):
+`attention_module_multi_head(roi_feat, position_embedding, nongt_dim, fc_dim, feat_dim, dim,
+group, index)` (:85-151) and the fc_new_1 -> relation -> fc_new_2 -> relation -> cls/bbox head
+(:254-280), with parameters under the reference's names (`query_1_weight`, ...).  The
+[N, M, 64] position embedding is never materialised: the geometry kernel consumes the ROI
+boxes directly, so `position_embedding` is replaced by the rois themselves.
+"""
+import torch
+
+from . import ops
+
+
+class RelationParams(object):
+    """Relation-module weights packed once for the kernels (all device tensors).
+
+    wqk  [2048, F]  = [query_i_weight; key_i_weight]     bqk [2048]
+    wout [dim2, F]  = linear_out_i_weight[:, :, 0, 0]     bout [dim2]
+    wp_t/bp are shared across the modules that see the same boxes (see RelationHead)."""
+
+    def __init__(self, params, index, dtype, device, prefix=''):
+        g = lambda n: params['%s%s_%d_%s' % (prefix, n.rsplit('_', 1)[0], index, n.rsplit('_', 1)[1])]
+        t = lambda x, dt: torch.as_tensor(x).to(device=device, dtype=dt).contiguous()
+        self.wqk = t(torch.cat([torch.as_tensor(g('query_weight')), torch.as_tensor(g('key_weight'))], 0), dtype)
+        self.bqk = t(torch.cat([torch.as_tensor(g('query_bias')), torch.as_tensor(g('key_bias'))], 0), torch.float32)
+        wo = torch.as_tensor(g('linear_out_weight'))
+        self.wout = t(wo.reshape(wo.shape[0], wo.shape[1]), dtype)
+        self.bout = t(g('linear_out_bias'), torch.float32)
+        self.wp = torch.as_tensor(g('pair_pos_fc1_weight')).to(torch.float32)      # [16, 64]
+        self.bp = torch.as_tensor(g('pair_pos_fc1_bias')).to(torch.float32)
+
+
+def pack_pair_pos(mods, device):
+    """[16,64] pair_pos_fc1 weights of the modules -> wp_t [64, nmod*16], bp [nmod*16]."""
+    wp_t = torch.cat([m.wp for m in mods], 0).t().contiguous().to(device)
+    bp = torch.cat([m.bp for m in mods], 0).contiguous().to(device)
+    return wp_t, bp
+
+
+def attention_module_multi_head(roi_feat, rois, params, nongt_dim=None, fc_dim=16, feat_dim=1024,
+                                dim=(1024, 1024, 1024), group=16, index=1, dtype=None,
+                                return_logits=False, packed=None, bias=None):
+    """Drop-in for SYM_REL.attention_module_multi_head (:85-151) on device tensors.
+
+    roi_feat [N, feat_dim] or [B, N, feat_dim]; `rois` [.., N, 4|5] takes the place of the
+    reference's `position_embedding` argument (the embedding is computed inside the kernel);
+    returns the module output [.., N, dim[2]] (and the logits `weighted_aff` [.., N, 16, M])."""
+    assert fc_dim == 16 and group == 16 and dim == (1024, 1024, 1024) and feat_dim == 1024, \
+        "the HIP kernels are specialised to the reference configuration (16 heads x 64)"
+    squeeze = roi_feat.dim() == 2
+    f = roi_feat[None] if squeeze else roi_feat
+    bx = rois[None] if rois.dim() == 2 else rois
+    dtype = dtype or f.dtype
+    f = f.to(dtype).contiguous()
+    B, N, _ = f.shape
+    M = N if nongt_dim is None else nongt_dim
+    mod = packed or RelationParams(params, index, dtype, f.device)
+    if bias is None:
+        wp_t, bp = pack_pair_pos([mod], f.device)
+        bias = ops.geometry_bias(bx.to(torch.float32).contiguous(), wp_t, bp, M)[0]
+    y, _, logits = _module_forward(f, mod, bias, M, want_out=True, want_act=False,
+                                   want_logits=return_logits)
+    if squeeze:
+        y = y[0]
+        logits = logits[0] if logits is not None else None
+    return (y, logits) if return_logits else y
+
+
+def _module_forward(f, mod, bias, M, want_out, want_act, want_logits, vwt_buf=None):
+    B, N, F = f.shape
+    qk = ops.gemm_nt(f.reshape(B * N, F), mod.wqk, mod.bqk).reshape(B, N, -1)
+    Mpad = bias.shape[-1]
+    if vwt_buf is None:
+        vwt_buf = torch.zeros((B, mod.wout.shape[0], Mpad), device=f.device, dtype=f.dtype)
+    # VW^T[b] = Wout F_b[:M]^T  (linear_out re-associated in front of the softmax sum)
+    ops.gemm_nt(mod.wout, f[:, :M, :], out=vwt_buf, n_cols=M)
+    d = mod.wqk.shape[0] // 2
+    return ops.relation_attention(qk[:, :, :d], qk[:, :M, d:], vwt_buf, bias, bout=mod.bout,
+                                  resid=f if want_act else None, M=M, want_out=want_out,
+                                  want_act=want_act, want_logits=want_logits)
+
+
+class RelationHead(object):
+    """fc_new_1 -> relation_1 -> ReLU -> fc_new_2 -> relation_2 -> ReLU -> cls_score / bbox_pred
+    (SYM_REL:254-280).  `dtype` bf16 is the throughput path, float32 the parity path."""
+
+    def __init__(self, params, dtype=torch.bfloat16, device='cuda', fc1_perm=None):
+        t = lambda x, dt: torch.as_tensor(x).to(device=device, dtype=dt).contiguous()
+        self.dtype, self.device = dtype, device
+        w1 = torch.as_tensor(params['fc_new_1_weight'])
+        if fc1_perm is not None:            # (C,7,7) -> (7,7,C) input order for channels-last pooling
+            w1 = w1[:, fc1_perm]
+        self.w1, self.b1 = t(w1, dtype), t(params['fc_new_1_bias'], torch.float32)
+        self.w2, self.b2 = t(params['fc_new_2_weight'], dtype), t(params['fc_new_2_bias'], torch.float32)
+        wcb = torch.cat([torch.as_tensor(params['cls_score_weight']), torch.as_tensor(params['bbox_pred_weight'])], 0)
+        bcb = torch.cat([torch.as_tensor(params['cls_score_bias']), torch.as_tensor(params['bbox_pred_bias'])], 0)
+        self.num_classes = int(params['cls_score_weight'].shape[0])
+        self.wcb, self.bcb = t(wcb, dtype), t(bcb, torch.float32)
+        self.mods = [RelationParams(params, i, dtype, device) for i in (1, 2)]
+        self.wp_t, self.bp = pack_pair_pos(self.mods, device)
+        self._vwt = {}
+
+    def _vwt_buf(self, B, Mpad):
+        key = (B, Mpad)
+        if key not in self._vwt:      # pad columns stay zero: the GEMM only writes [:, :, :M]
+            self._vwt[key] = [torch.zeros((B, 1024, Mpad), device=self.device, dtype=self.dtype) for _ in range(2)]
+        return self._vwt[key]
+
+    def forward(self, pooled, rois, nongt_dim=None, return_intermediates=False):
+        """pooled [B, N, 12544] (dtype), rois [B, N, 5] fp32 -> cls_score [B,N,C], bbox_pred [B,N,8]
+        (fp32 logits; softmax / decoding live in postprocess)."""
+        B, N, K = pooled.shape
+        M = N if nongt_dim is None else nongt_dim
+        bias = ops.geometry_bias(rois, self.wp_t, self.bp, M)            # [2, B, 16, N, Mpad]
+        vw = self._vwt_buf(B, bias.shape[-1])
+        f1 = ops.gemm_nt(pooled.reshape(B * N, K), self.w1, self.b1).reshape(B, N, -1)
+        y1, x1, _ = _module_forward(f1, self.mods[0], bias[0], M, return_intermediates, True, False, vw[0])
+        f2 = ops.gemm_nt(x1.reshape(B * N, -1), self.w2, self.b2).reshape(B, N, -1)
+        y2, x2, _ = _module_forward(f2, self.mods[1], bias[1], M, return_intermediates, True, False, vw[1])
+        cb = ops.gemm_nt(x2.reshape(B * N, -1), self.wcb, self.bcb, out_dtype=torch.float32).reshape(B, N, -1)
+        cls_score, bbox_pred = cb[:, :, :self.num_classes], cb[:, :, self.num_classes:]
+        if return_intermediates:
+            return dict(fc_new_1=f1, attention_1=y1, fc_all_1_relu=x1, fc_new_2=f2, attention_2=y2,
+                        fc_all_2_relu=x2, cls_score=cls_score, bbox_pred=bbox_pred)
+        return cls_score, bbox_pred, x2
