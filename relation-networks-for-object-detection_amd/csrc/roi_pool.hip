@@ -1,0 +1,115 @@
+// Max ROIPooling forward/backward (reference: mx.symbol.ROIPooling(pooled_size=(7,7),
+// spatial_scale=1/16), SYM_REL:252-253; semantics of MXNet v1.1.0 src/operator/roi_pooling.cu).
+// Element strides are explicit so the same kernel serves NCHW fp32 (the reference layout,
+// parity tests) and channels-last bf16 (the throughput path, where the 256 channels of a
+// bin are contiguous and a wavefront reads 64 consecutive channels per pixel).
+#include "common.h"
+#include <float.h>
+
+namespace relnet {
+
+struct RoiArgs {
+  const void* data; long ds_b, ds_c, ds_h, ds_w;     // element strides of [B, C, H, W]
+  const float* rois;                                  // [R, 5] batch_idx, x1, y1, x2, y2
+  void* out; long os_r, os_c, os_ph, os_pw;           // element strides of [R, C, PH, PW]
+  int* argmax;                                        // same strides as out, or nullptr
+  int R, C, H, W, PH, PW, batch_index_base;
+  float scale;
+};
+
+template <typename T> __device__ __forceinline__ float ld(const T* p);
+template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld<unsigned short>(const unsigned short* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void st(T* p, float v);
+template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st<unsigned short>(unsigned short* p, float v) { *p = f2bf(v); }
+
+#pragma clang fp contract(off)
+// grid.x = R * PH * PW bins, threads stride over channels
+template <typename T>
+__global__ __launch_bounds__(256) void roi_pool_fwd_kernel(RoiArgs g) {
+  const int bin = blockIdx.x;
+  const int pw = bin % g.PW, ph = (bin / g.PW) % g.PH, r = bin / (g.PW * g.PH);
+  const float* roi = g.rois + (long)r * 5;
+  const int b = (int)roi[0] - g.batch_index_base;
+  const int rs_w = (int)roundf(roi[1] * g.scale), rs_h = (int)roundf(roi[2] * g.scale);
+  const int re_w = (int)roundf(roi[3] * g.scale), re_h = (int)roundf(roi[4] * g.scale);
+  const int rw = max(re_w - rs_w + 1, 1), rh = max(re_h - rs_h + 1, 1);   // malformed -> 1x1
+  const float bin_h = (float)rh / (float)g.PH, bin_w = (float)rw / (float)g.PW;
+  int hs = (int)floorf((float)ph * bin_h), he = (int)ceilf((float)(ph + 1) * bin_h);
+  int ws = (int)floorf((float)pw * bin_w), we = (int)ceilf((float)(pw + 1) * bin_w);
+  hs = min(max(hs + rs_h, 0), g.H); he = min(max(he + rs_h, 0), g.H);
+  ws = min(max(ws + rs_w, 0), g.W); we = min(max(we + rs_w, 0), g.W);
+  const bool empty = (he <= hs) || (we <= ws);
+  const T* base = (const T*)g.data + (long)b * g.ds_b;
+  for (int c = threadIdx.x; c < g.C; c += 256) {
+    float best = empty ? 0.f : -FLT_MAX;
+    int bi = -1;
+    const T* pc = base + (long)c * g.ds_c;
+    for (int y = hs; y < he; ++y)
+      for (int x = ws; x < we; ++x) {
+        const float v = ld<T>(pc + (long)y * g.ds_h + (long)x * g.ds_w);
+        if (v > best) { best = v; bi = y * g.W + x; }
+      }
+    const long o = (long)r * g.os_r + (long)c * g.os_c + (long)ph * g.os_ph + (long)pw * g.os_pw;
+    st<T>((T*)g.out + o, best);
+    if (g.argmax) g.argmax[o] = bi;
+  }
+}
+#pragma clang fp contract(fast)
+
+struct RoiBwdArgs {
+  const void* grad_out; const int* argmax; long os_r, os_c, os_ph, os_pw;
+  const float* rois;
+  float* grad_in; long ds_b, ds_c;          // fp32 [B, C, H*W] accumulation buffer (pre-zeroed)
+  int R, C, W, PH, PW, batch_index_base;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_pool_bwd_kernel(RoiBwdArgs g) {
+  const int bin = blockIdx.x;
+  const int pw = bin % g.PW, ph = (bin / g.PW) % g.PH, r = bin / (g.PW * g.PH);
+  const int b = (int)g.rois[(long)r * 5] - g.batch_index_base;
+  for (int c = threadIdx.x; c < g.C; c += 256) {
+    const long o = (long)r * g.os_r + (long)c * g.os_c + (long)ph * g.os_ph + (long)pw * g.os_pw;
+    const int a = g.argmax[o];
+    if (a >= 0) atomicAdd(g.grad_in + (long)b * g.ds_b + (long)c * g.ds_c + a, ld<T>((const T*)g.grad_out + o));
+  }
+}
+
+}  // namespace relnet
+
+using namespace relnet;
+enum { RELNET_F32 = 0, RELNET_BF16 = 1 };
+
+extern "C" int relnet_roi_pool_fwd(const void* data, const long* data_strides4, const float* rois,
+                                   void* out, const long* out_strides4, int* argmax, int R, int C,
+                                   int H, int W, int PH, int PW, float spatial_scale,
+                                   int batch_index_base, int dtype, void* stream) {
+  RELNET_REQUIRE(data && rois && out && data_strides4 && out_strides4, "relnet_roi_pool_fwd: null operand");
+  RELNET_REQUIRE(R > 0 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0, "relnet_roi_pool_fwd: bad shape");
+  RoiArgs g;
+  g.data = data; g.ds_b = data_strides4[0]; g.ds_c = data_strides4[1]; g.ds_h = data_strides4[2]; g.ds_w = data_strides4[3];
+  g.rois = rois; g.out = out; g.os_r = out_strides4[0]; g.os_c = out_strides4[1]; g.os_ph = out_strides4[2]; g.os_pw = out_strides4[3];
+  g.argmax = argmax; g.R = R; g.C = C; g.H = H; g.W = W; g.PH = PH; g.PW = PW; g.scale = spatial_scale;
+  g.batch_index_base = batch_index_base;
+  dim3 grid((unsigned)((long)R * PH * PW));
+  if (dtype == RELNET_F32) roi_pool_fwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(g);
+  else if (dtype == RELNET_BF16) roi_pool_fwd_kernel<unsigned short><<<grid, 256, 0, (hipStream_t)stream>>>(g);
+  else RELNET_REQUIRE(false, "relnet_roi_pool_fwd: unknown dtype %d", dtype);
+  return check_launch("relnet_roi_pool_fwd");
+}
+
+extern "C" int relnet_roi_pool_bwd(const void* grad_out, const int* argmax, const long* out_strides4,
+                                   const float* rois, float* grad_in, long gs_b, long gs_c, int R,
+                                   int C, int W, int PH, int PW, int batch_index_base, int dtype,
+                                   void* stream) {
+  RELNET_REQUIRE(grad_out && argmax && rois && grad_in, "relnet_roi_pool_bwd: null operand");
+  RoiBwdArgs g{grad_out, argmax, out_strides4[0], out_strides4[1], out_strides4[2], out_strides4[3],
+               rois, grad_in, gs_b, gs_c, R, C, W, PH, PW, batch_index_base};
+  dim3 grid((unsigned)((long)R * PH * PW));
+  if (dtype == RELNET_F32) roi_pool_bwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(g);
+  else if (dtype == RELNET_BF16) roi_pool_bwd_kernel<unsigned short><<<grid, 256, 0, (hipStream_t)stream>>>(g);
+  else RELNET_REQUIRE(false, "relnet_roi_pool_bwd: unknown dtype %d", dtype);
+  return check_launch("relnet_roi_pool_bwd");
+}

@@ -125,3 +125,85 @@ def relation_attention(q, k, vwt, bias, bout=None, resid=None, M=None, want_out=
               _ptr(out), H * 64, N * H * 64, _ptr(act), H * 64, N * H * 64, _ptr(logits),
               B, H, N, M, Mpad, 1.0 / math.sqrt(64.0), _dt(q), _dt(q), _stream())
     return out, act, logits
+
+
+# ---------------------------------------------------------------------------------------
+# RPN proposal path
+# ---------------------------------------------------------------------------------------
+def _strides4(t):
+    import ctypes
+    return (ctypes.c_long * 4)(*[int(s) for s in t.stride()])
+
+
+def proposal_decode(cls_prob, bbox_deltas, im_info, base_anchors, feat_stride=16, min_size=0):
+    """cls_prob [B,2A,H,W], bbox_deltas [B,4A,H,W] fp32 (any strides), im_info [B,3],
+    base_anchors float64 [A,4] -> boxes [B,n,4] fp32, scores [B,n] fp32 in (y,x,a) order over
+    the cropped grid int(im_h/stride) x int(im_w/stride) (proposal.py:85)."""
+    _chk(cls_prob, bbox_deltas, im_info, base_anchors)
+    assert cls_prob.dtype == torch.float32 and bbox_deltas.dtype == torch.float32
+    assert base_anchors.dtype == torch.float64 and im_info.dtype == torch.float32
+    B = cls_prob.shape[0]
+    A = base_anchors.shape[0]
+    info = im_info.detach().cpu()
+    h, w = int(info[0, 0].item() / feat_stride), int(info[0, 1].item() / feat_stride)
+    assert bool((info[:, :2] == info[0, :2]).all()), "one (h, w) per batch"
+    h, w = min(h, cls_prob.shape[2]), min(w, cls_prob.shape[3])
+    n = h * w * A
+    boxes = torch.empty((B, n, 4), device=cls_prob.device, dtype=torch.float32)
+    scores = torch.empty((B, n), device=cls_prob.device, dtype=torch.float32)
+    _lib.call('relnet_proposal_decode', cls_prob.data_ptr(), _strides4(cls_prob), bbox_deltas.data_ptr(),
+              _strides4(bbox_deltas), im_info.data_ptr(), base_anchors.data_ptr(), boxes.data_ptr(),
+              scores.data_ptr(), B, A, h, w, feat_stride, int(min_size), _stream())
+    return boxes, scores
+
+
+def topk_sort(scores, boxes, K):
+    """Descending top-K: -> det [B,K,5] (x1,y1,x2,y2,score), index [B,K] int32, count [B]."""
+    _chk(scores, boxes)
+    B, n = scores.shape
+    K = min(K, n)
+    det = torch.empty((B, K, 5), device=scores.device, dtype=torch.float32)
+    index = torch.empty((B, K), device=scores.device, dtype=torch.int32)
+    count = torch.empty((B,), device=scores.device, dtype=torch.int32)
+    _lib.call('relnet_topk_sort', scores.data_ptr(), boxes.data_ptr(), det.data_ptr(), index.data_ptr(),
+              count.data_ptr(), B, n, K, _stream())
+    return det, index, count
+
+
+def nms_sorted(det, thresh, post=0, counts=None, max_keep=None, want_keep=False, batch_index_base=0):
+    """det [B,n,5] sorted by score.  Returns dict(rois [B,post,5], scores [B,post],
+    keep [B,max_keep] int32, num_keep [B])."""
+    _chk(det, counts)
+    B, n, _ = det.shape
+    cb = (n + 63) // 64
+    mask = torch.empty((B, n, cb), device=det.device, dtype=torch.int64)
+    _lib.call('relnet_nms_mask', det.data_ptr(), _ptr(counts), mask.data_ptr(), B, n, n, float(thresh), _stream())
+    max_keep = max_keep or (post if post > 0 else n)
+    rois = torch.zeros((B, post, 5), device=det.device, dtype=torch.float32) if post > 0 else None
+    rscores = torch.zeros((B, post), device=det.device, dtype=torch.float32) if post > 0 else None
+    keep = torch.full((B, max_keep), -1, device=det.device, dtype=torch.int32) if want_keep else None
+    num = torch.empty((B,), device=det.device, dtype=torch.int32)
+    _lib.call('relnet_nms_scan', mask.data_ptr(), det.data_ptr(), _ptr(counts), _ptr(rois), _ptr(rscores),
+              _ptr(keep), num.data_ptr(), B, n, n, post, max_keep, batch_index_base, _stream())
+    return dict(rois=rois, scores=rscores, keep=keep, num_keep=num)
+
+
+def roi_pool(data, rois, pooled=(7, 7), spatial_scale=0.0625, channels_last_out=False,
+             want_argmax=False, batch_index_base=0):
+    """data: logical [B,C,H,W] tensor of any strides (NCHW or channels_last memory format);
+    rois [R,5].  Output logical [R,C,PH,PW]; memory order (R,PH,PW,C) when
+    channels_last_out (then `.permute(0,2,3,1)` is contiguous)."""
+    _chk(data, rois)
+    assert rois.dtype == torch.float32 and rois.is_contiguous()
+    B, Cc, H, W = data.shape
+    R = rois.shape[0]
+    PH, PW = pooled
+    if channels_last_out:
+        out = torch.empty((R, PH, PW, Cc), device=data.device, dtype=data.dtype).permute(0, 3, 1, 2)
+    else:
+        out = torch.empty((R, Cc, PH, PW), device=data.device, dtype=data.dtype)
+    arg = torch.empty_strided(out.shape, out.stride(), device=data.device, dtype=torch.int32) if want_argmax else None
+    _lib.call('relnet_roi_pool_fwd', data.data_ptr(), _strides4(data), rois.data_ptr(), out.data_ptr(),
+              _strides4(out), _ptr(arg), R, Cc, H, W, PH, PW, float(spatial_scale), batch_index_base,
+              _dt(data), _stream())
+    return (out, arg) if want_argmax else out

@@ -46,13 +46,13 @@ def test_gemm_nt(rn, M, N, K, batch, dtype):
     ref = torch.relu(a.double() @ w.double().t() + bias.double() + res.double())
     scale = ref.abs().max().item()
     err = (out.double() - ref).abs().max().item() / scale
-    assert err < (2e-6 if dtype == 'f32' else 1e-2), err
+    assert err < (1e-6 + 1e-7 * np.sqrt(K) if dtype == 'f32' else 1e-2), err   # fp32 accumulation ~ eps*sqrt(K)
     # plain product, per-row bias, fp32 output from bf16 inputs
     rb = _dev(rng.normal(0, 1, M).astype(np.float32))
     out2 = ops.gemm_nt(a, w, rb, bias_mode=2, out_dtype=torch.float32)
     ref2 = a.double() @ w.double().t() + rb.double()[None, :, None]
     err2 = (out2.double() - ref2).abs().max().item() / ref2.abs().max().item()
-    assert err2 < (2e-6 if dtype == 'f32' else 2e-5 * np.sqrt(K)), err2
+    assert err2 < (1e-6 + 1e-7 * np.sqrt(K) if dtype == 'f32' else 2e-5 * np.sqrt(K)), err2
 
 
 def test_geometry_matches_reference_graph(rn, golden):
