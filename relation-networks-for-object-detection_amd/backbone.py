@@ -1,0 +1,137 @@
+"""ResNet-101 conv1..conv5 + RPN head + conv_new_1 of the reference graph
+(relation_rcnn/symbols/resnet_v1_101_rcnn_base.py:29-693, SYM_REL:249-250).
+
+Dense convolutions are plain library calls (MIOpen through torch.nn.functional.conv2d) in
+channels-last memory; what this module owns is the graph itself: the Caffe-style ResNet
+(stride on the FIRST 1x1 of a stage, :99,103), conv5 dilated 2 with stride 1 (:632-633),
+ceil-mode pool1 (pooling_convention='full', :35-36) and the frozen BatchNorm
+(use_global_stats=True, eps=1e-5, :32) folded into the preceding convolution at load time.
+Parameter names are the reference's (`res4b7_branch2a_weight`, `bn4b7_branch2a_gamma`, ...).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+UNITS = (3, 4, 23, 3)
+FILTERS = (256, 512, 1024, 2048)
+EPS = 1e-5
+
+
+def unit_names():
+    """[(stage, unit_name, in_ch, mid_ch, out_ch, stride, dilate, has_proj)] in graph order."""
+    out = []
+    in_ch = 64
+    for si, (n, oc) in enumerate(zip(UNITS, FILTERS)):
+        stage = si + 2
+        for u in range(n):
+            if n <= 3 or stage == 2 or stage == 5:
+                name = 'abc'[u]
+            else:
+                name = 'a' if u == 0 else 'b%d' % u
+            stride = 2 if (u == 0 and stage in (3, 4)) else 1
+            dilate = 2 if stage == 5 else 1
+            out.append((stage, '%d%s' % (stage, name), in_ch, oc // 4, oc, stride, dilate, u == 0))
+            in_ch = oc
+    return out
+
+
+def conv_bn_names():
+    """[(conv_name, bn_name, out_ch, in_ch, k)] for every conv+BN pair of the backbone."""
+    layers = [('conv1', 'bn_conv1', 64, 3, 7)]
+    for stage, nm, ic, mc, oc, stride, dil, proj in unit_names():
+        if proj:
+            layers.append(('res%s_branch1' % nm, 'bn%s_branch1' % nm, oc, ic, 1))
+        layers.append(('res%s_branch2a' % nm, 'bn%s_branch2a' % nm, mc, ic, 1))
+        layers.append(('res%s_branch2b' % nm, 'bn%s_branch2b' % nm, mc, mc, 3))
+        layers.append(('res%s_branch2c' % nm, 'bn%s_branch2c' % nm, oc, mc, 1))
+    return layers
+
+
+def init_params(seed=1, num_anchors=12, num_classes=81, num_reg_classes=2, generator=None):
+    """Random-init parameters of the relation test graph under the reference's names.
+    New layers N(0, 0.01)/0 as init_weight (SYM_REL:327-362); the backbone has no pretrained
+    weights offline: He-normal convs, BN gamma=1 (0.25 on the residual branch output so the
+    34 residual adds keep activations O(1)), beta=0, mean=0, var=1."""
+    g = generator or torch.Generator().manual_seed(seed)
+    p = {}
+
+    def nrm(std, *shape):
+        return torch.randn(*shape, generator=g) * std
+
+    for conv, bn, oc, ic, k in conv_bn_names():
+        p[conv + '_weight'] = nrm(math.sqrt(2.0 / (ic * k * k)), oc, ic, k, k)
+        p[bn + '_gamma'] = torch.full((oc,), 0.25 if conv.endswith('branch2c') else 1.0)
+        p[bn + '_beta'] = torch.zeros(oc)
+        p[bn + '_moving_mean'] = torch.zeros(oc)
+        p[bn + '_moving_var'] = torch.ones(oc)
+    p['rpn_conv_3x3_weight'] = nrm(0.01, 512, 1024, 3, 3); p['rpn_conv_3x3_bias'] = torch.zeros(512)
+    p['rpn_cls_score_weight'] = nrm(0.01, 2 * num_anchors, 512, 1, 1); p['rpn_cls_score_bias'] = torch.zeros(2 * num_anchors)
+    p['rpn_bbox_pred_weight'] = nrm(0.01, 4 * num_anchors, 512, 1, 1); p['rpn_bbox_pred_bias'] = torch.zeros(4 * num_anchors)
+    p['conv_new_1_weight'] = nrm(0.01, 256, 2048, 1, 1); p['conv_new_1_bias'] = torch.zeros(256)
+    p['fc_new_1_weight'] = nrm(0.01, 1024, 256 * 49); p['fc_new_1_bias'] = torch.zeros(1024)
+    p['fc_new_2_weight'] = nrm(0.01, 1024, 1024); p['fc_new_2_bias'] = torch.zeros(1024)
+    p['cls_score_weight'] = nrm(0.01, num_classes, 1024); p['cls_score_bias'] = torch.zeros(num_classes)
+    p['bbox_pred_weight'] = nrm(0.01, 4 * num_reg_classes, 1024); p['bbox_pred_bias'] = torch.zeros(4 * num_reg_classes)
+    for i in (1, 2):
+        p['pair_pos_fc1_%d_weight' % i] = nrm(0.01, 16, 64); p['pair_pos_fc1_%d_bias' % i] = torch.zeros(16)
+        p['query_%d_weight' % i] = nrm(0.01, 1024, 1024); p['query_%d_bias' % i] = torch.zeros(1024)
+        p['key_%d_weight' % i] = nrm(0.01, 1024, 1024); p['key_%d_bias' % i] = torch.zeros(1024)
+        p['linear_out_%d_weight' % i] = nrm(0.01, 1024, 1024, 1, 1); p['linear_out_%d_bias' % i] = torch.zeros(1024)
+    return p
+
+
+def fold_bn(w, gamma, beta, mean, var, eps=EPS):
+    """BatchNorm(use_global_stats=True, fix_gamma=False): y = (x-mean)/sqrt(var+eps)*gamma+beta."""
+    s = gamma.double() / torch.sqrt(var.double() + eps)
+    return (w.double() * s.view(-1, 1, 1, 1)).float(), (beta.double() - mean.double() * s).float()
+
+
+class Backbone(object):
+    """Folded, device-resident backbone + RPN head + conv_new_1."""
+
+    def __init__(self, params, dtype=torch.bfloat16, device='cuda', channels_last=True):
+        self.dtype, self.device = dtype, device
+        self.mf = torch.channels_last if channels_last else torch.contiguous_format
+        self.w = {}
+        for conv, bn, oc, ic, k in conv_bn_names():
+            w, b = fold_bn(params[conv + '_weight'], params[bn + '_gamma'], params[bn + '_beta'],
+                           params[bn + '_moving_mean'], params[bn + '_moving_var'])
+            self._put(conv, w, b)
+        for name in ('rpn_conv_3x3', 'rpn_cls_score', 'rpn_bbox_pred', 'conv_new_1'):
+            self._put(name, params[name + '_weight'], params[name + '_bias'])
+        # both 1x1 RPN outputs in one convolution: 24 score + 48 delta channels
+        self._put('rpn_out', torch.cat([params['rpn_cls_score_weight'], params['rpn_bbox_pred_weight']], 0),
+                  torch.cat([params['rpn_cls_score_bias'], params['rpn_bbox_pred_bias']], 0))
+        self.units = unit_names()
+
+    def _put(self, name, w, b):
+        self.w[name] = (w.to(self.device, self.dtype).contiguous(memory_format=self.mf),
+                        b.to(self.device, self.dtype))
+
+    def _conv(self, x, name, stride=1, pad=0, dil=1, relu=False):
+        w, b = self.w[name]
+        y = F.conv2d(x, w, b, stride=stride, padding=pad, dilation=dil)
+        return F.relu_(y) if relu else y
+
+    def forward(self, data):
+        """data [B,3,H,W] -> dict(conv4, conv5, conv_new_1_relu, rpn_cls_score, rpn_bbox_pred)."""
+        x = data.to(self.dtype).contiguous(memory_format=self.mf)
+        x = self._conv(x, 'conv1', stride=2, pad=3, relu=True)
+        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=0, ceil_mode=True)
+        conv4 = None
+        for stage, nm, ic, mc, oc, stride, dil, proj in self.units:
+            if stage == 5 and conv4 is None:
+                conv4 = x
+            sc = self._conv(x, 'res%s_branch1' % nm, stride=stride) if proj else x
+            y = self._conv(x, 'res%s_branch2a' % nm, stride=stride, relu=True)
+            y = self._conv(y, 'res%s_branch2b' % nm, pad=dil, dil=dil, relu=True)
+            y = self._conv(y, 'res%s_branch2c' % nm)
+            x = F.relu_(y.add_(sc))
+        conv5 = x
+        feat = self._conv(conv5, 'conv_new_1', relu=True)
+        r = self._conv(conv4, 'rpn_conv_3x3', pad=1, relu=True)
+        rpn = self._conv(r, 'rpn_out')
+        na2 = self.w['rpn_cls_score'][0].shape[0]
+        return dict(conv4=conv4, conv5=conv5, conv_new_1_relu=feat,
+                    rpn_cls_score=rpn[:, :na2], rpn_bbox_pred=rpn[:, na2:])

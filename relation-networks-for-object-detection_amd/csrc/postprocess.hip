@@ -1,0 +1,267 @@
+// Detection post-processing on device (reference: relation_rcnn/core/tester.py:148-156
+// im_detect decode, :244-268 per-class NMS / soft-NMS, :270-277 max_per_image; lib/nms/nms.py:
+// 45-82 `nms`, :85-141 `soft_nms`).  The reference runs this part in numpy float64 on one host
+// core (25 / 59 ms per image in its README); here every (image, class) pair is one wavefront.
+//
+//   detect_head_kernel      softmax over classes (SoftmaxActivation) + class-agnostic box
+//                           decode (bbox_transform.py:103-140, float64) + clip + 1/scale.
+//   class_nms_kernel        per (image, class): candidates with prob > thresh, then Gaussian
+//                           soft-NMS (score *= exp(-iou^2/sigma), re-pick the max each step) or
+//                           greedy NMS (drop iou > thresh); all arithmetic float64 like numpy.
+//   image_topk_kernel       image-level score threshold = max_per_image-th largest score.
+#include "common.h"
+
+namespace relnet {
+
+struct HeadArgs {
+  const float* cls_score; long cs_ld;     // [R, C] logits
+  const float* bbox_pred; long bp_ld;     // [R, 4*num_reg]; class-agnostic fg deltas at +4
+  const float* rois;                      // [R, 5]
+  const float* im_info;                   // [B, 3]
+  float* cls_prob;                        // [R, C]
+  double* boxes;                          // [R, 4] decoded, clipped, divided by im scale
+  int R, C, rois_per_image, delta_off;
+};
+
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(64) void detect_head_kernel(HeadArgs g) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const float* z = g.cls_score + (long)r * g.cs_ld;
+  float m = -INFINITY;
+  for (int c = lane; c < g.C; c += 64) m = fmaxf(m, z[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float s = 0.f;
+  for (int c = lane; c < g.C; c += 64) s += expf(z[c] - m);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  for (int c = lane; c < g.C; c += 64) g.cls_prob[(long)r * g.C + c] = expf(z[c] - m) / s;
+  if (lane == 0) {
+    const float* roi = g.rois + (long)r * 5;
+    const float* d = g.bbox_pred + (long)r * g.bp_ld + g.delta_off;
+    const float* info = g.im_info + (long)(r / g.rois_per_image) * 3;
+    const double x1 = roi[1], y1 = roi[2], x2 = roi[3], y2 = roi[4];
+    const double w = x2 - x1 + 1.0, h = y2 - y1 + 1.0;
+    const double cx = x1 + 0.5 * (w - 1.0), cy = y1 + 0.5 * (h - 1.0);
+    const double pcx = (double)d[0] * w + cx, pcy = (double)d[1] * h + cy;
+    const double pw = (double)(float)exp((double)d[2]) * w, ph = (double)(float)exp((double)d[3]) * h;
+    const double mx = (double)info[1] - 1.0, my = (double)info[0] - 1.0, sc = (double)info[2];
+    double o[4] = {pcx - 0.5 * (pw - 1.0), pcy - 0.5 * (ph - 1.0), pcx + 0.5 * (pw - 1.0), pcy + 0.5 * (ph - 1.0)};
+    o[0] = fmax(fmin(o[0], mx), 0.0); o[1] = fmax(fmin(o[1], my), 0.0);
+    o[2] = fmax(fmin(o[2], mx), 0.0); o[3] = fmax(fmin(o[3], my), 0.0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) g.boxes[(long)r * 4 + c] = o[c] / sc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+struct ClsNmsArgs {
+  const float* cls_prob;     // [B, N, C]
+  const double* boxes;       // [B, N, 4]
+  double* dets;              // [B, C-1, N, 5]  x1,y1,x2,y2,score in pick order
+  int* counts;               // [B, C-1]
+  int N, C;
+  float score_thresh;        // 1e-3 (tester.py:245)
+  double nms_param;          // sigma (soft) or IoU threshold (hard)
+  int soft;
+};
+
+constexpr int kPerLane = 8;   // up to 512 candidates per (image, class)
+
+__global__ __launch_bounds__(64) void class_nms_kernel(ClsNmsArgs g) {
+  const int cls = blockIdx.x + 1, b = blockIdx.y, lane = threadIdx.x;
+  const float* prob = g.cls_prob + (long)b * g.N * g.C;
+  const double* bx = g.boxes + (long)b * g.N * 4;
+  double x1[kPerLane], y1[kPerLane], x2[kPerLane], y2[kPerLane], area[kPerLane], sc[kPerLane];
+  // candidate slot s of lane l is roi index s*64 + l; sc < 0 marks "absent/picked"
+  int n = 0;
+#pragma unroll
+  for (int s = 0; s < kPerLane; ++s) {
+    const int i = s * 64 + lane;
+    sc[s] = -1.0;
+    x1[s] = y1[s] = x2[s] = y2[s] = area[s] = 0.0;
+    if (i < g.N) {
+      const float p = prob[(long)i * g.C + cls];
+      if (p > g.score_thresh) {
+        sc[s] = (double)p;
+        x1[s] = bx[i * 4 + 0]; y1[s] = bx[i * 4 + 1]; x2[s] = bx[i * 4 + 2]; y2[s] = bx[i * 4 + 3];
+        area[s] = (x2[s] - x1[s] + 1) * (y2[s] - y1[s] + 1);
+        ++n;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+  double* out = g.dets + (((long)b * (g.C - 1) + (cls - 1)) * g.N) * 5;
+  int picked = 0;
+  for (int it = 0; it < n; ++it) {
+    // arg-max over remaining; ties -> larger roi index (argsort()[::-1] convention)
+    double best = -1.0; int bi = -1;
+#pragma unroll
+    for (int s = 0; s < kPerLane; ++s)
+      if (sc[s] > best || (sc[s] == best && sc[s] >= 0.0)) { best = sc[s]; bi = s * 64 + lane; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ob = __shfl_xor(best, o);
+      const int oi = __shfl_xor(bi, o);
+      if (ob > best || (ob == best && oi > bi)) { best = ob; bi = oi; }
+    }
+    if (best < 0.0) break;                     // everything suppressed (hard NMS)
+    const int bl = bi & 63, bs = bi >> 6;
+    double px1 = 0, py1 = 0, px2 = 0, py2 = 0, pa = 0;
+#pragma unroll
+    for (int s = 0; s < kPerLane; ++s)
+      if (s == bs) { px1 = x1[s]; py1 = y1[s]; px2 = x2[s]; py2 = y2[s]; pa = area[s]; }
+    px1 = __shfl(px1, bl); py1 = __shfl(py1, bl); px2 = __shfl(px2, bl); py2 = __shfl(py2, bl); pa = __shfl(pa, bl);
+    if (lane == 0) {
+      double* o = out + (long)picked * 5;
+      o[0] = px1; o[1] = py1; o[2] = px2; o[3] = py2; o[4] = best;
+    }
+    ++picked;
+#pragma unroll
+    for (int s = 0; s < kPerLane; ++s) {
+      if (s * 64 + lane == bi) { sc[s] = -1.0; continue; }
+      if (sc[s] < 0.0) continue;
+      const double w = fmax(0.0, fmin(px2, x2[s]) - fmax(px1, x1[s]) + 1);
+      const double h = fmax(0.0, fmin(py2, y2[s]) - fmax(py1, y1[s]) + 1);
+      const double inter = w * h;
+      const double ovr = inter / (pa + area[s] - inter);
+      if (g.soft) sc[s] = sc[s] * exp(-(ovr * ovr) / g.nms_param);     // nms.py:92
+      else if (!(ovr <= g.nms_param)) sc[s] = -1.0;                     // nms.py:79
+    }
+  }
+  if (lane == 0) g.counts[(long)b * (g.C - 1) + (cls - 1)] = picked;
+}
+#pragma clang fp contract(fast)
+
+// ---------------------------------------------------------------------------------------
+struct ImgTopkArgs {
+  const double* dets;   // [B, NC, N, 5]
+  const int* counts;    // [B, NC]
+  double* thresh;       // [B] image score threshold (-inf when total <= max_per_image)
+  int* total;           // [B]
+  float* out;           // [B, max_out, 6] class, score, x1,y1,x2,y2 (class-major, pick order)
+  int* out_count;       // [B]
+  int NC, N, max_per_image, max_out;
+};
+
+__device__ __forceinline__ unsigned long long dkey(double d) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(d);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+__global__ __launch_bounds__(1024) void image_topk_kernel(ImgTopkArgs g) {
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned long long s_prefix;
+  __shared__ int s_remaining, s_total, s_out;
+  __shared__ int s_off[128];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int* cnt = g.counts + (long)b * g.NC;
+  const double* dets = g.dets + (long)b * g.NC * g.N * 5;
+  if (tid == 0) {
+    int t = 0;
+    for (int c = 0; c < g.NC; ++c) t += cnt[c];
+    s_total = t; s_out = 0;
+  }
+  __syncthreads();
+  const int total = s_total;
+  const long slots = (long)g.NC * g.N;
+  unsigned long long kth = 0ull;
+  if (total > g.max_per_image) {
+    if (tid == 0) { s_prefix = 0ull; s_remaining = g.max_per_image; }
+    __syncthreads();
+    for (int pass = 7; pass >= 0; --pass) {
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      const unsigned long long prefix = s_prefix;
+      const int shift = pass * 8;
+      for (long i = tid; i < slots; i += 1024) {
+        const int c = (int)(i / g.N), k = (int)(i % g.N);
+        if (k >= cnt[c]) continue;
+        const unsigned long long key = dkey(dets[i * 5 + 4]);
+        if (pass == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 0xff], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int rem = s_remaining, d = 255;
+        for (; d > 0; --d) { if ((int)hist[d] >= rem) break; rem -= hist[d]; }
+        s_remaining = rem;
+        s_prefix = prefix | ((unsigned long long)d << shift);
+      }
+      __syncthreads();
+    }
+    kth = s_prefix;
+  }
+  // keep score >= threshold, class-major / pick order (tester.py:273-277)
+  if (tid == 0) {
+    g.total[b] = total;
+    double th = -INFINITY;
+    if (total > g.max_per_image) {
+      const unsigned long long u = (kth >> 63) ? (kth & 0x7fffffffffffffffull) : ~kth;
+      th = __longlong_as_double((long long)u);
+    }
+    g.thresh[b] = th;
+  }
+  // per-class kept counts -> offsets (keeps are a prefix of each pick-ordered class list)
+  for (int c = tid; c < g.NC; c += 1024) {
+    int kc = 0;
+    for (int k = 0; k < cnt[c]; ++k) kc += (dkey(dets[((long)c * g.N + k) * 5 + 4]) >= kth) ? 1 : 0;
+    s_off[c] = kc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int c = 0; c < g.NC; ++c) { const int kc = s_off[c]; s_off[c] = acc; acc += kc; }
+    s_out = acc;
+  }
+  __syncthreads();
+  for (int c = tid; c < g.NC; c += 1024) {
+    int pos = s_off[c];
+    for (int k = 0; k < cnt[c]; ++k) {
+      const double* d = dets + ((long)c * g.N + k) * 5;
+      if (dkey(d[4]) >= kth) {
+        if (pos < g.max_out) {
+          float* o = g.out + ((long)b * g.max_out + pos) * 6;
+          o[0] = (float)(c + 1); o[1] = (float)d[4]; o[2] = (float)d[0]; o[3] = (float)d[1]; o[4] = (float)d[2]; o[5] = (float)d[3];
+        }
+        ++pos;
+      }
+    }
+  }
+  if (tid == 0) g.out_count[b] = s_out < g.max_out ? s_out : g.max_out;
+}
+
+}  // namespace relnet
+
+using namespace relnet;
+
+extern "C" int relnet_detect_head(const float* cls_score, long cs_ld, const float* bbox_pred, long bp_ld,
+                                  const float* rois, const float* im_info, float* cls_prob, double* boxes,
+                                  int R, int C, int rois_per_image, int delta_off, void* stream) {
+  RELNET_REQUIRE(cls_score && bbox_pred && rois && im_info && cls_prob && boxes, "relnet_detect_head: null operand");
+  RELNET_REQUIRE(R > 0 && C > 1 && rois_per_image > 0, "relnet_detect_head: bad shape");
+  HeadArgs g{cls_score, cs_ld, bbox_pred, bp_ld, rois, im_info, cls_prob, boxes, R, C, rois_per_image, delta_off};
+  detect_head_kernel<<<R, 64, 0, (hipStream_t)stream>>>(g);
+  return check_launch("relnet_detect_head");
+}
+
+extern "C" int relnet_class_nms(const float* cls_prob, const double* boxes, double* dets, int* counts,
+                                int B, int N, int C, float score_thresh, double nms_param, int soft,
+                                void* stream) {
+  RELNET_REQUIRE(cls_prob && boxes && dets && counts, "relnet_class_nms: null operand");
+  RELNET_REQUIRE(B > 0 && N > 0 && N <= 64 * kPerLane && C > 1, "relnet_class_nms: need 0 < N <= %d (N=%d)", 64 * kPerLane, N);
+  ClsNmsArgs g{cls_prob, boxes, dets, counts, N, C, score_thresh, nms_param, soft};
+  dim3 grid(C - 1, B);
+  class_nms_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(g);
+  return check_launch("relnet_class_nms");
+}
+
+extern "C" int relnet_image_topk(const double* dets, const int* counts, double* thresh, int* total,
+                                 float* out, int* out_count, int B, int NC, int N, int max_per_image,
+                                 int max_out, void* stream) {
+  RELNET_REQUIRE(dets && counts && thresh && total && out && out_count, "relnet_image_topk: null operand");
+  RELNET_REQUIRE(B > 0 && NC > 0 && NC <= 128 && N > 0 && max_per_image > 0 && max_out >= max_per_image, "relnet_image_topk: bad shape");
+  ImgTopkArgs g{dets, counts, thresh, total, out, out_count, NC, N, max_per_image, max_out};
+  image_topk_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(g);
+  return check_launch("relnet_image_topk");
+}

@@ -25,6 +25,7 @@ struct DecodeArgs {
   float* boxes;           // [B, n, 4] n = h*w*A (cropped grid)
   float* scores;          // [B, n]    (-inf when filtered by min_size)
   int A, h, w, feat_stride, min_size;
+  int softmax_pairs;      // 1: cls_prob holds raw rpn_cls_score, fg prob = softmax over {bg=a, fg=A+a}
 };
 
 #pragma clang fp contract(off)
@@ -35,7 +36,13 @@ __global__ __launch_bounds__(256) void proposal_decode_kernel(DecodeArgs g) {
   if (idx >= n) return;
   const int a = idx % g.A, x = (idx / g.A) % g.w, y = idx / (g.A * g.w);
   const float* info = g.im_info + b * 3;
-  const float score = g.cls_prob[b * g.cs_b + (long)(g.A + a) * g.cs_c + y * g.cs_h + x * g.cs_w];
+  float score = g.cls_prob[b * g.cs_b + (long)(g.A + a) * g.cs_c + y * g.cs_h + x * g.cs_w];
+  if (g.softmax_pairs) {   // SoftmaxActivation(mode='channel') on the (0,2,-1,0) reshape, SYM_REL:218-221
+    const float bg = g.cls_prob[b * g.cs_b + (long)a * g.cs_c + y * g.cs_h + x * g.cs_w];
+    const float m = fmaxf(bg, score);
+    const float eb = expf(bg - m), ef = expf(score - m);
+    score = ef / (eb + ef);
+  }
   const float* dp = g.deltas + b * g.ds_b + (long)(4 * a) * g.ds_c + y * g.ds_h + x * g.ds_w;
   const float dx = dp[0], dy = dp[g.ds_c], dw = dp[2 * g.ds_c], dh = dp[3 * g.ds_c];
   const double sx = (double)(x * g.feat_stride), sy = (double)(y * g.feat_stride);
@@ -309,14 +316,14 @@ extern "C" int relnet_proposal_decode(const float* cls_prob, const long* cls_str
                                       const float* deltas, const long* delta_strides4,
                                       const float* im_info, const double* base_anchors, float* boxes,
                                       float* scores, int B, int A, int h, int w, int feat_stride,
-                                      int min_size, void* stream) {
+                                      int min_size, int softmax_pairs, void* stream) {
   RELNET_REQUIRE(cls_prob && deltas && im_info && base_anchors && boxes && scores, "relnet_proposal_decode: null operand");
   RELNET_REQUIRE(B > 0 && A > 0 && h > 0 && w > 0 && (long)h * w * A < 65536, "relnet_proposal_decode: bad grid B=%d A=%d h=%d w=%d (h*w*A must be < 65536)", B, A, h, w);
   DecodeArgs g;
   g.cls_prob = cls_prob; g.cs_b = cls_strides4[0]; g.cs_c = cls_strides4[1]; g.cs_h = cls_strides4[2]; g.cs_w = cls_strides4[3];
   g.deltas = deltas; g.ds_b = delta_strides4[0]; g.ds_c = delta_strides4[1]; g.ds_h = delta_strides4[2]; g.ds_w = delta_strides4[3];
   g.im_info = im_info; g.anchors = base_anchors; g.boxes = boxes; g.scores = scores;
-  g.A = A; g.h = h; g.w = w; g.feat_stride = feat_stride; g.min_size = min_size;
+  g.A = A; g.h = h; g.w = w; g.feat_stride = feat_stride; g.min_size = min_size; g.softmax_pairs = softmax_pairs;
   dim3 grid((h * w * A + 255) / 256, B);
   proposal_decode_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g);
   return check_launch("relnet_proposal_decode");

@@ -6,8 +6,6 @@ single-image protocol, proposal.py:54-56); forward() runs decode -> top-K sort -
 -> greedy scan entirely on the GPU (the reference does four device<->host round trips and a
 numpy scan).  `propose_batch` is the batched (B images per launch) entry the detector uses.
 """
-from distutils.util import strtobool  # noqa: F401  (kept for interface fidelity)
-
 import numpy as np
 import torch
 
@@ -45,10 +43,11 @@ def _parse_tuple(s):
 
 
 def propose_batch(cls_prob, bbox_pred, im_info, anchors, feat_stride, pre_nms_top_n, post_nms_top_n,
-                  threshold, min_size, want_debug=False):
+                  threshold, min_size, want_debug=False, im_hw=None, softmax_pairs=False):
     """Batched proposal: cls_prob [B,2A,H,W], bbox_pred [B,4A,H,W], im_info [B,3] ->
     rois [B, post, 5] (column 0 = image index in the batch), scores [B, post]."""
-    boxes, scores = ops.proposal_decode(cls_prob, bbox_pred, im_info, anchors, feat_stride, min_size)
+    boxes, scores = ops.proposal_decode(cls_prob, bbox_pred, im_info, anchors, feat_stride, min_size,
+                                        im_hw=im_hw, softmax_pairs=softmax_pairs)
     n = scores.shape[1]
     k = min(pre_nms_top_n, n) if pre_nms_top_n > 0 else n
     det, index, count = ops.topk_sort(scores, boxes, k)

@@ -135,7 +135,8 @@ def _strides4(t):
     return (ctypes.c_long * 4)(*[int(s) for s in t.stride()])
 
 
-def proposal_decode(cls_prob, bbox_deltas, im_info, base_anchors, feat_stride=16, min_size=0):
+def proposal_decode(cls_prob, bbox_deltas, im_info, base_anchors, feat_stride=16, min_size=0,
+                    im_hw=None, softmax_pairs=False):
     """cls_prob [B,2A,H,W], bbox_deltas [B,4A,H,W] fp32 (any strides), im_info [B,3],
     base_anchors float64 [A,4] -> boxes [B,n,4] fp32, scores [B,n] fp32 in (y,x,a) order over
     the cropped grid int(im_h/stride) x int(im_w/stride) (proposal.py:85)."""
@@ -144,16 +145,18 @@ def proposal_decode(cls_prob, bbox_deltas, im_info, base_anchors, feat_stride=16
     assert base_anchors.dtype == torch.float64 and im_info.dtype == torch.float32
     B = cls_prob.shape[0]
     A = base_anchors.shape[0]
-    info = im_info.detach().cpu()
-    h, w = int(info[0, 0].item() / feat_stride), int(info[0, 1].item() / feat_stride)
-    assert bool((info[:, :2] == info[0, :2]).all()), "one (h, w) per batch"
+    if im_hw is None:                      # reads im_info on the host (a device sync)
+        info = im_info.detach().cpu()
+        assert bool((info[:, :2] == info[0, :2]).all()), "one (h, w) per batch"
+        im_hw = (info[0, 0].item(), info[0, 1].item())
+    h, w = int(im_hw[0] / feat_stride), int(im_hw[1] / feat_stride)
     h, w = min(h, cls_prob.shape[2]), min(w, cls_prob.shape[3])
     n = h * w * A
     boxes = torch.empty((B, n, 4), device=cls_prob.device, dtype=torch.float32)
     scores = torch.empty((B, n), device=cls_prob.device, dtype=torch.float32)
     _lib.call('relnet_proposal_decode', cls_prob.data_ptr(), _strides4(cls_prob), bbox_deltas.data_ptr(),
               _strides4(bbox_deltas), im_info.data_ptr(), base_anchors.data_ptr(), boxes.data_ptr(),
-              scores.data_ptr(), B, A, h, w, feat_stride, int(min_size), _stream())
+              scores.data_ptr(), B, A, h, w, feat_stride, int(min_size), int(softmax_pairs), _stream())
     return boxes, scores
 
 
@@ -207,3 +210,48 @@ def roi_pool(data, rois, pooled=(7, 7), spatial_scale=0.0625, channels_last_out=
               _strides4(out), _ptr(arg), R, Cc, H, W, PH, PW, float(spatial_scale), batch_index_base,
               _dt(data), _stream())
     return (out, arg) if want_argmax else out
+
+
+# ---------------------------------------------------------------------------------------
+# detection post-processing
+# ---------------------------------------------------------------------------------------
+def detect_head(cls_score, bbox_pred, rois, im_info, rois_per_image, delta_off=4):
+    """cls_score [R,C] fp32 logits, bbox_pred [R,4*num_reg] fp32, rois [R,5], im_info [B,3]
+    -> cls_prob [R,C] fp32, boxes [R,4] float64 (decoded class-agnostic fg box / im scale)."""
+    _chk(cls_score, bbox_pred, rois, im_info)
+    R, Cn = cls_score.shape
+    assert cls_score.dtype == torch.float32 and bbox_pred.dtype == torch.float32
+    assert cls_score.stride(1) == 1 and bbox_pred.stride(1) == 1 and rois.is_contiguous()
+    prob = torch.empty((R, Cn), device=cls_score.device, dtype=torch.float32)
+    boxes = torch.empty((R, 4), device=cls_score.device, dtype=torch.float64)
+    _lib.call('relnet_detect_head', cls_score.data_ptr(), cls_score.stride(0), bbox_pred.data_ptr(),
+              bbox_pred.stride(0), rois.data_ptr(), im_info.data_ptr(), prob.data_ptr(), boxes.data_ptr(),
+              R, Cn, rois_per_image, delta_off, _stream())
+    return prob, boxes
+
+
+def class_nms(cls_prob, boxes, score_thresh=1e-3, nms_param=0.6, soft=True):
+    """cls_prob [B,N,C] fp32, boxes [B,N,4] float64 -> dets [B,C-1,N,5] float64 (pick order),
+    counts [B,C-1] int32."""
+    _chk(cls_prob, boxes)
+    B, N, Cn = cls_prob.shape
+    assert cls_prob.is_contiguous() and boxes.is_contiguous() and boxes.dtype == torch.float64
+    dets = torch.zeros((B, Cn - 1, N, 5), device=cls_prob.device, dtype=torch.float64)
+    counts = torch.empty((B, Cn - 1), device=cls_prob.device, dtype=torch.int32)
+    _lib.call('relnet_class_nms', cls_prob.data_ptr(), boxes.data_ptr(), dets.data_ptr(), counts.data_ptr(),
+              B, N, Cn, float(score_thresh), float(nms_param), int(soft), _stream())
+    return dets, counts
+
+
+def image_topk(dets, counts, max_per_image=100, max_out=None):
+    """-> out [B,max_out,6] (class, score, x1,y1,x2,y2), out_count [B], thresh [B] float64, total [B]."""
+    _chk(dets, counts)
+    B, NC, N, _ = dets.shape
+    max_out = max_out or (max_per_image + 28)
+    thresh = torch.empty((B,), device=dets.device, dtype=torch.float64)
+    total = torch.empty((B,), device=dets.device, dtype=torch.int32)
+    out = torch.zeros((B, max_out, 6), device=dets.device, dtype=torch.float32)
+    out_count = torch.empty((B,), device=dets.device, dtype=torch.int32)
+    _lib.call('relnet_image_topk', dets.data_ptr(), counts.data_ptr(), thresh.data_ptr(), total.data_ptr(),
+              out.data_ptr(), out_count.data_ptr(), B, NC, N, max_per_image, max_out, _stream())
+    return out, out_count, thresh, total

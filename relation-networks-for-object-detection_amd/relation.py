@@ -86,7 +86,7 @@ class RelationHead(object):
     """fc_new_1 -> relation_1 -> ReLU -> fc_new_2 -> relation_2 -> ReLU -> cls_score / bbox_pred
     (SYM_REL:254-280).  `dtype` bf16 is the throughput path, float32 the parity path."""
 
-    def __init__(self, params, dtype=torch.bfloat16, device='cuda', fc1_perm=None):
+    def __init__(self, params, dtype=torch.bfloat16, device='cuda', fc1_perm=None, use_relation=True):
         t = lambda x, dt: torch.as_tensor(x).to(device=device, dtype=dt).contiguous()
         self.dtype, self.device = dtype, device
         w1 = torch.as_tensor(params['fc_new_1_weight'])
@@ -98,8 +98,10 @@ class RelationHead(object):
         bcb = torch.cat([torch.as_tensor(params['cls_score_bias']), torch.as_tensor(params['bbox_pred_bias'])], 0)
         self.num_classes = int(params['cls_score_weight'].shape[0])
         self.wcb, self.bcb = t(wcb, dtype), t(bcb, torch.float32)
-        self.mods = [RelationParams(params, i, dtype, device) for i in (1, 2)]
-        self.wp_t, self.bp = pack_pair_pos(self.mods, device)
+        self.use_relation = use_relation
+        if use_relation:
+            self.mods = [RelationParams(params, i, dtype, device) for i in (1, 2)]
+            self.wp_t, self.bp = pack_pair_pos(self.mods, device)
         self._vwt = {}
 
     def _vwt_buf(self, B, Mpad):
@@ -112,6 +114,11 @@ class RelationHead(object):
         """pooled [B, N, 12544] (dtype), rois [B, N, 5] fp32 -> cls_score [B,N,C], bbox_pred [B,N,8]
         (fp32 logits; softmax / decoding live in postprocess)."""
         B, N, K = pooled.shape
+        if not self.use_relation:        # plain 2FC head, resnet_v1_101_rcnn.py:125-134
+            x1 = ops.gemm_nt(pooled.reshape(B * N, K), self.w1, self.b1, relu=True)
+            x2 = ops.gemm_nt(x1, self.w2, self.b2, relu=True).reshape(B, N, -1)
+            cb = ops.gemm_nt(x2.reshape(B * N, -1), self.wcb, self.bcb, out_dtype=torch.float32).reshape(B, N, -1)
+            return cb[:, :, :self.num_classes], cb[:, :, self.num_classes:], x2
         M = N if nongt_dim is None else nongt_dim
         bias = ops.geometry_bias(rois, self.wp_t, self.bp, M)            # [2, B, 16, N, Mpad]
         vw = self._vwt_buf(B, bias.shape[-1])

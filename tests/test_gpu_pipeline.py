@@ -1,0 +1,130 @@
+"""GPU parity of the remaining hot-path rows, stage by stage ("teacher forced": each HIP stage
+is checked against the oracle applied to the SAME inputs, so a 1e-6 difference in one stage
+cannot flip a discrete decision (sort order, NMS) in the next and hide a real error)."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import network as ON
+from oracle import proposal as OP
+from oracle import roi_pooling as ORP
+from oracle import relation as OR
+from oracle import postprocess as OPP
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def rn():
+    import relnet_amd  # noqa: F401
+    from relnet_amd import ops, lib, backbone, detector
+    lib.load()
+    return ops, backbone, detector
+
+
+def _np(t):
+    return t.detach().float().cpu().numpy()
+
+
+def test_postprocess_softnms_and_nms(rn):
+    ops, _, _ = rn
+    rng = np.random.default_rng(77)
+    B, N, C = 2, 120, 9
+    rois = np.stack([np.hstack((np.full((N, 1), b, np.float32), cases.random_boxes(N, 80 + b))) for b in range(B)])
+    cls_score = rng.normal(0, 2.5, (B, N, C)).astype(np.float32)
+    bbox = rng.normal(0, 0.2, (B, N, 8)).astype(np.float32)
+    im_info = np.array([[600, 1000, 1.5], [600, 1000, 1.0]], np.float32)
+    d = lambda x: torch.as_tensor(x).cuda()
+    prob, boxes = ops.detect_head(d(cls_score.reshape(B * N, C)), d(bbox.reshape(B * N, 8)), d(rois.reshape(B * N, 5)), d(im_info), N)
+    prob, boxes = prob.view(B, N, C), boxes.view(B, N, 4)
+    for soft, param in ((True, 0.6), (False, 0.5)):
+        dets, counts = ops.class_nms(prob, boxes, 1e-3, param, soft)
+        out, out_count, thresh, total = ops.image_topk(dets, counts, 100)
+        for b in range(B):
+            want_prob = OPP.softmax_rows(cls_score[b])
+            np.testing.assert_allclose(_np(prob[b]), want_prob, rtol=2e-6, atol=1e-9)
+            _, wboxes = OPP.im_detect(rois[b], want_prob, bbox[b], im_info[b])
+            np.testing.assert_allclose(boxes[b].cpu().numpy(), wboxes[:, 4:8], rtol=1e-12, atol=1e-9)
+            # NMS stages on the GPU's own probabilities / boxes
+            full = np.zeros((N, 8)); full[:, 4:8] = boxes[b].cpu().numpy()
+            want = OPP.detections(_np(prob[b]), full, C, 1e-3, param, soft, 100)
+            raw = OPP.detections(_np(prob[b]), full, C, 1e-3, param, soft, -1)
+            for c in range(C - 1):
+                k = int(counts[b, c])
+                assert k == len(raw[c])
+                np.testing.assert_allclose(dets[b, c, :k].cpu().numpy(), raw[c], rtol=1e-10, atol=1e-12)
+            got = out[b, :int(out_count[b])].cpu().numpy()
+            flat = np.concatenate([np.hstack((np.full((len(w), 1), c + 1.0), w[:, 4:5], w[:, :4])) for c, w in enumerate(want)])
+            assert got.shape == flat.shape
+            np.testing.assert_allclose(got, flat.astype(np.float32), rtol=1e-6)
+
+
+@pytest.mark.parametrize('relation', [True, False])
+def test_detector_fp32_stagewise(rn, relation):
+    ops, backbone, detector = rn
+    H, W = 192, 256
+    torch.manual_seed(0)
+    p = backbone.init_params(seed=3)
+    # make the small-image RPN interesting: larger rpn/cls weights than the N(0,0.01) init
+    g = torch.Generator().manual_seed(5)
+    for k in ('rpn_cls_score_weight', 'rpn_bbox_pred_weight', 'cls_score_weight', 'bbox_pred_weight'):
+        p[k] = torch.randn(p[k].shape, generator=g) * 0.05
+    data = torch.randn(1, 3, H, W, generator=g) * 50
+    im_info = torch.tensor([[H, W, 1.0]])
+    cfg = detector.Config()
+    cfg.rpn_post_nms_top_n = 100
+    det = detector.Detector(p, dtype=torch.float32, relation=relation, im_hw=(H, W), cfg=cfg)
+    f = det.backbone.forward(data.cuda())
+    out = det.forward(data.cuda(), im_info.cuda())
+    # A1/A2: backbone + RPN head vs torch-CPU fp32 restatement
+    with torch.no_grad():
+        c4, c5 = ON.backbone(data, p)
+        cls, box, feat = ON.rpn_and_feat(c4, c5, p)
+    for got, want in ((f['conv4'], c4), (f['conv5'], c5), (f['conv_new_1_relu'], feat),
+                      (f['rpn_cls_score'], cls), (f['rpn_bbox_pred'], box)):
+        err = (got.float().cpu() - want).abs().max().item() / want.abs().max().item()
+        assert err < 2e-4, err
+    # A3: proposal on the GPU's RPN maps -> bit exact rois
+    prob = ON.rpn_softmax(_np(f['rpn_cls_score']))
+    rois_o, _, dbg = OP.proposal(prob, _np(f['rpn_bbox_pred']), im_info.numpy(), 16, cfg.anchor_scales,
+                                 cfg.anchor_ratios, 6000, 100, 0.7, 0, return_debug=True)
+    assert dbg['n_kept'] >= 100
+    rois = _np(out['rois'][0])
+    # fp32 softmax of two logits: the GPU expf may differ by an ulp from numpy -> compare decisions
+    assert np.array_equal(rois, rois_o) or np.abs(rois - rois_o).max() < 1e-3
+    # A4: ROIPooling of the GPU feature map -> bit exact
+    pooled_o = ORP.roi_pooling(_np(f['conv_new_1_relu']), rois)
+    pooled = ops.roi_pool(f['conv_new_1_relu'], out['rois'].view(-1, 5), channels_last_out=True)
+    assert np.array_equal(_np(pooled), pooled_o)
+    # A6/A7: head on those pooled features
+    pn = {k: v.numpy() for k, v in p.items()}
+    if relation:
+        r = OR.relation_head(pooled_o, rois, pn, return_intermediates=True)
+        cs, bp = r['cls_score'], r['bbox_pred']
+    else:
+        cs, bp, _ = ON.plain_head(pooled_o, pn)
+    assert np.abs(_np(out['cls_score'][0]) - cs).max() <= 2e-4 * np.abs(cs).max()
+    assert np.abs(_np(out['bbox_pred'][0]) - bp).max() <= 2e-4 * max(np.abs(bp).max(), 1e-3)
+    # A9: post-processing of the GPU's probabilities / boxes
+    full = np.zeros((rois.shape[0], 8)); full[:, 4:8] = out['pred_boxes'][0].cpu().numpy()
+    want = OPP.detections(_np(out['cls_prob'][0]), full, 81, 1e-3, 0.6, True, 100)
+    n = int(out['num_detections'][0])
+    flat = np.concatenate([np.hstack((np.full((len(w), 1), c + 1.0), w[:, 4:5], w[:, :4])) for c, w in enumerate(want)])
+    assert n == len(flat)
+    np.testing.assert_allclose(_np(out['detections'][0, :n]), flat.astype(np.float32), rtol=1e-5)
+
+
+def test_detector_bf16_batch_runs_and_is_close(rn):
+    """bf16 throughput path at a reduced image size: same graph, finite outputs, rois valid."""
+    ops, backbone, detector = rn
+    H, W = 192, 256
+    p = backbone.init_params(seed=4)
+    g = torch.Generator().manual_seed(6)
+    data = torch.randn(2, 3, H, W, generator=g) * 50
+    im_info = torch.tensor([[H, W, 1.0], [H, W, 1.0]])
+    cfg = detector.Config(); cfg.rpn_post_nms_top_n = 64
+    out = detector.Detector(p, dtype=torch.bfloat16, im_hw=(H, W), cfg=cfg).forward(data.cuda(), im_info.cuda())
+    assert torch.isfinite(out['cls_prob']).all() and torch.isfinite(out['pred_boxes']).all()
+    assert out['rois'].shape == (2, 64, 5) and (out['rois'][1, :, 0] == 1).all()
+    assert (out['num_detections'] > 0).all()

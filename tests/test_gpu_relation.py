@@ -2,9 +2,12 @@
 vectors produced by the reference's own python.  Tolerances (DESIGN.md "tolerances"):
   position matrix               bit exact
   position embedding (sin/cos)  <= 4 ulp of 1.0 (2.4e-7 abs)
-  attention logits, fp32 path   |dL| <= 1e-4 where the geometry weight G >= 1e-3
-                                (north_star bar), and <= 1e-4 + 4e-7/G elsewhere
-                                (log(G) amplifies a 1e-7 absolute error in G)
+  attention logits, fp32 path   |dL| <= 1e-4 (north_star bar) wherever the geometry weight
+                                G = relu(E.w_h + b_h) is >= 2e-3 * ||w_h||_1 (= 1e-3 for the
+                                reference's N(0, 0.01) init), and <= 1e-4 + 8e-7 ||w_h||_1 / G
+                                elsewhere: L contains log(G), which turns the unavoidable
+                                ~1e-7 * ||w_h||_1 absolute error of G (2-ulp sin/cos, fp32
+                                accumulation) into a relative one
   module output, fp32 path      <= 1e-4 relative to the output scale
   module output, bf16 path      <= 2e-2 relative to the output scale
 """
@@ -16,6 +19,16 @@ import cases
 from oracle import relation as OR
 
 pytestmark = pytest.mark.gpu
+
+
+def check_logits(logits, want, gw, wp):
+    """gw: oracle geometry weight [N, H, M]; wp: pair_pos_fc1 weight [H, 64]."""
+    s = np.abs(wp).sum(axis=1)[None, :, None]
+    dl = np.abs(logits - want)
+    well = gw >= 2e-3 * s
+    assert well.mean() > 0.3
+    assert dl[well].max() <= 1e-4, dl[well].max()
+    assert (dl <= 1e-4 + 8e-7 * s / np.maximum(gw, 1e-6)).all()
 
 
 def _dev(x, dtype=None):
@@ -70,7 +83,7 @@ def test_geometry_matches_reference_graph(rn, golden):
         gw = r['aff_weight']                                   # [N, 16, M]
         want = np.log(np.maximum(gw.astype(np.float64), 1e-6))
         got = bias[0, 0, :, :, :m].permute(1, 0, 2).cpu().numpy()      # [N, 16, M]
-        tol = 2e-6 + 4e-7 / np.maximum(gw, 1e-6)
+        tol = 2e-6 + 8e-7 * np.abs(p['pair_pos_fc1_1_weight']).sum(axis=1)[None, :, None] / np.maximum(gw, 1e-6)
         assert (np.abs(got - want) <= tol).all()
 
 
@@ -85,9 +98,7 @@ def test_relation_module_fp32_vs_golden_and_oracle(rn, golden, name):
                                                      dtype=torch.float32, return_logits=True)
     y, logits = y.cpu().numpy(), logits.cpu().numpy()
     gw = OR.relation_module(feat, g[name + '/position_embedding'], p, 1, m, return_intermediates=True)['aff_weight']
-    dl = np.abs(logits - g[name + '/logits'])
-    assert dl[gw >= 1e-3].max() <= 1e-4, dl[gw >= 1e-3].max()
-    assert (dl <= 1e-4 + 4e-7 / np.maximum(gw, 1e-6)).all()
+    check_logits(logits, g[name + '/logits'], gw, p['pair_pos_fc1_1_weight'])
     want = g[name + '/output']
     assert np.abs(y - want).max() <= 1e-4 * np.abs(want).max()
 
@@ -102,10 +113,7 @@ def test_relation_module_full_size(rn, n, m, seed, std):
     r = OR.relation_module(feat, pe, p, 1, m, return_intermediates=True)
     y, logits = relation.attention_module_multi_head(_dev(feat), _dev(boxes), pt, nongt_dim=m,
                                                      dtype=torch.float32, return_logits=True)
-    gw = r['aff_weight']
-    dl = np.abs(logits.cpu().numpy() - r['logits'])
-    assert dl[gw >= 1e-3].max() <= 1e-4
-    assert (dl <= 1e-4 + 4e-7 / np.maximum(gw, 1e-6)).all()
+    check_logits(logits.cpu().numpy(), r['logits'], r['aff_weight'], p['pair_pos_fc1_1_weight'])
     scale = np.abs(r['output']).max()
     assert np.abs(y.cpu().numpy() - r['output']).max() <= 1e-4 * scale
     # bf16 throughput path: same module, bf16 operands, fp32 softmax/accumulate
