@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/s of the relation-network detector forward pass.
+
+  python bench.py --gpus N --steps K --warmup W         (N>1: launched by torch.distributed.run)
+
+One step = one pass of the hot path over a batch of `--batch` synthetic 600x1000 images per
+GPU: ResNet-101 conv1..conv5 + RPN -> proposal (300 rois) -> ROIPooling -> 2FC + 2 relation
+modules (16 heads, d=1024) -> cls/bbox -> decode -> per-class soft-NMS -> top-100
+(BASELINE.json configs[1], bf16).  Inputs are resident in HBM before the timed region.
+Images are independent units: ranks share nothing on the data path (weak scaling, no
+collective); the barrier + max-over-ranks timing is the only communication.
+
+The JSON line also carries
+  roofline      the relation-attention kernel (north_star's named kernel): algorithmic FLOPs of
+                the graph as written (3.13 GFLOP per module-image) / measured
+                launch duration (HIP events on the launching stream, inside the timed steps);
+                `executed` = FLOPs the re-associated kernel really performs.
+  cpu_baseline  the CPU oracle (numpy + torch-CPU fp32 restatement of the same graph) timed on
+                a bounded sample of the same workload on this host's cores.
+"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_GFLOP_PER_MODULE_IMAGE = (2 * 16 * 300 * 300 * 64 + 2 * 16 * 300 * 300 * 1024) / 1e9    # 3.1334
+EXEC_GFLOP_PER_MODULE_IMAGE = (2 * 16 * 300 * 300 * 64 * 2) / 1e9                           # 0.3686
+PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+class KernelTimer(object):
+    """HIP-event brackets around every C-ABI launch (events recorded on torch's current
+    stream, which is the stream the kernels are launched on)."""
+
+    def __init__(self):
+        self.events = {}
+
+    @contextlib.contextmanager
+    def __call__(self, name):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        yield
+        e.record()
+        self.events.setdefault(name, []).append((s, e))
+
+    def summary(self):
+        out = {}
+        for name, evs in self.events.items():
+            ms = [s.elapsed_time(e) for s, e in evs]
+            out[name] = dict(calls=len(ms), avg_ms=sum(ms) / len(ms), total_ms=sum(ms))
+        return out
+
+
+def cpu_baseline(params, relation=True, soft=True, images=2, seed=123):
+    """Oracle (oracle/network.py) on `images` synthetic 600x1000 images; returns the dict."""
+    import numpy as np
+    from oracle import network as ON
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(seed)
+    im_info = np.array([[600, 1000, 1.0]], np.float32)
+    t_img = []
+    for i in range(images + 1):                       # first image = warm-up (thread pools, caches)
+        data = torch.randn(1, 3, 600, 1000, generator=g)
+        t0 = time.time()
+        ON.detect(data, im_info, params, relation=relation, soft=soft)
+        if i > 0:
+            t_img.append(time.time() - t0)
+    per = sum(t_img) / len(t_img)
+    return dict(value=1.0 / per, unit='images/s', cores=cores, kind='port',
+                sample='%d synthetic 600x1000 images through oracle/network.py:detect (torch-CPU fp32 convs on '
+                       '%d threads + numpy proposal/ROI/relation/soft-NMS), %.1f s/image' % (images, cores, per))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-relation', action='store_true', help='plain 2FC head (config 1 graph)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-images', type=int, default=2)
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == a.gpus or world == 1, "WORLD_SIZE=%d but --gpus %d" % (world, a.gpus)
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    import __graft_entry__ as ge
+    ge.build()
+    import relnet_amd  # noqa: F401
+    from relnet_amd import lib, backbone, detector
+
+    tdt = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
+    params = backbone.init_params(seed=1)
+    det = detector.Detector(params, dtype=tdt, device='cuda', relation=not a.no_relation)
+    g = torch.Generator().manual_seed(1000 + rank)
+    # unit-variance synthetic pixels: with random-init weights (no checkpoints offline) this gives
+    # O(1) RPN logits/deltas, i.e. several hundred distinct proposals survive NMS per image; N(0,50)
+    # pixels would push every delta past exp overflow and degenerate all rois to the full image.
+    data = torch.randn(a.batch, 3, 600, 1000, generator=g).cuda().to(tdt).contiguous(memory_format=torch.channels_last)
+    im_info = torch.tensor([[600.0, 1000.0, 1.0]] * a.batch).cuda()
+    torch.backends.cudnn.benchmark = True
+
+    def step():
+        return det.forward(data, im_info)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            out = step()
+        timer = None if a.no_kernel_timing else KernelTimer()
+        lib.timing_hook = timer
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        lib.timing_hook = None
+    if dist is not None:
+        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_det = int(out['num_detections'].sum().item())
+    assert n_det > 0 and bool(torch.isfinite(out['cls_prob']).all())
+
+    if rank == 0:
+        images = world * a.batch * a.steps
+        res = {
+            'metric': 'images/sec (1000x600, 300 ROIs)', 'value': images / elapsed, 'unit': 'images/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype,
+            'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: ResNet-101 Faster-RCNN + %s + soft-NMS(0.6) + top-100, '
+                                   '600x1000 images, 300 proposals, random-init weights'
+                                   % ('2 relation modules (N=300, 16 heads, d=1024)' if not a.no_relation else 'plain 2FC head'),
+                       'images_per_gpu_per_step': a.batch, 'parallelism': 'replicas x%d (no data-path collective)' % world},
+        }
+        if timer is not None:
+            ks = timer.summary()
+            res['kernels_ms'] = {k: round(v['avg_ms'], 5) for k, v in sorted(ks.items())}
+            att = ks.get('relnet_relation_attention')
+            if att:
+                sec = att['avg_ms'] * 1e-3
+                algo = ALGO_GFLOP_PER_MODULE_IMAGE * a.batch / 1e3 / sec          # TFLOP/s
+                peak = PEAK_TFLOPS[a.dtype]
+                traffic = None
+                pmc = os.path.join(ROOT, 'profiles', 'attention_pmc.json')
+                if os.path.exists(pmc):
+                    traffic = json.load(open(pmc)).get('hbm_bytes_per_launch_at_batch', {}).get(str(a.batch))
+                res['roofline'] = {
+                    'kernel': 'relation_attention_kernel (csrc/relation.hip)', 'bound': 'mfma',
+                    'achieved': algo, 'peak': peak, 'unit': 'TFLOP/s', 'frac': algo / peak, 'traffic': traffic,
+                    'executed': EXEC_GFLOP_PER_MODULE_IMAGE * a.batch / 1e3 / sec,
+                    'launch_ms': att['avg_ms'], 'launches': att['calls'],
+                    'algorithmic_gflop_per_launch': ALGO_GFLOP_PER_MODULE_IMAGE * a.batch,
+                }
+        if world == 1 and not a.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(params, relation=not a.no_relation, images=a.cpu_images)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -66,8 +66,17 @@ def exported_symbols():
     return sorted(_SIGNATURES)
 
 
+#: optional per-launch timing: set to a callable(name) -> context manager (bench.py brackets
+#: every C-ABI launch with HIP events on the launching stream); None = no overhead.
+timing_hook = None
+
+
 def call(name, *args):
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if timing_hook is not None:
+        with timing_hook(name):
+            rc = getattr(lib, name)(*args)
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RelnetError("%s failed (%d): %s" % (name, rc, lib.relnet_last_error().decode()))

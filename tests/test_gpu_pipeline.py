@@ -66,11 +66,11 @@ def test_detector_fp32_stagewise(rn, relation):
     H, W = 192, 256
     torch.manual_seed(0)
     p = backbone.init_params(seed=3)
-    # make the small-image RPN interesting: larger rpn/cls weights than the N(0,0.01) init
+    # spread the class scores / box deltas more than the N(0,0.01) init does
     g = torch.Generator().manual_seed(5)
-    for k in ('rpn_cls_score_weight', 'rpn_bbox_pred_weight', 'cls_score_weight', 'bbox_pred_weight'):
+    for k in ('cls_score_weight', 'bbox_pred_weight'):
         p[k] = torch.randn(p[k].shape, generator=g) * 0.05
-    data = torch.randn(1, 3, H, W, generator=g) * 50
+    data = torch.randn(1, 3, H, W, generator=g)      # unit-variance pixels: O(1) RPN deltas
     im_info = torch.tensor([[H, W, 1.0]])
     cfg = detector.Config()
     cfg.rpn_post_nms_top_n = 100
@@ -121,7 +121,7 @@ def test_detector_bf16_batch_runs_and_is_close(rn):
     H, W = 192, 256
     p = backbone.init_params(seed=4)
     g = torch.Generator().manual_seed(6)
-    data = torch.randn(2, 3, H, W, generator=g) * 50
+    data = torch.randn(2, 3, H, W, generator=g)
     im_info = torch.tensor([[H, W, 1.0], [H, W, 1.0]])
     cfg = detector.Config(); cfg.rpn_post_nms_top_n = 64
     out = detector.Detector(p, dtype=torch.bfloat16, im_hw=(H, W), cfg=cfg).forward(data.cuda(), im_info.cuda())
