@@ -13,6 +13,8 @@ import math
 import torch
 import torch.nn.functional as F
 
+from . import ops
+
 UNITS = (3, 4, 23, 3)
 FILTERS = (256, 512, 1024, 2048)
 EPS = 1e-5
@@ -88,12 +90,21 @@ def fold_bn(w, gamma, beta, mean, var, eps=EPS):
 
 
 class Backbone(object):
-    """Folded, device-resident backbone + RPN head + conv_new_1."""
+    """Folded, device-resident backbone + RPN head + conv_new_1.
 
-    def __init__(self, params, dtype=torch.bfloat16, device='cuda', channels_last=True):
+    impl='hip' (bf16 only): every convolution except the 7x7/Cin=3 stem runs on the implicit-GEMM
+    MFMA kernel of csrc/gemm.hip over NHWC activations, with bias + ReLU and the bottleneck's
+    residual add + ReLU fused into the GEMM epilogue (the library path spends as long in separate
+    bias / add / clamp passes as in the convolutions themselves).  impl='miopen' keeps every conv
+    in torch.nn.functional.conv2d (used for the float32 parity path)."""
+
+    def __init__(self, params, dtype=torch.bfloat16, device='cuda', channels_last=True, impl=None):
         self.dtype, self.device = dtype, device
+        self.impl = impl or ('hip' if dtype == torch.bfloat16 else 'miopen')
+        assert self.impl in ('hip', 'miopen') and (self.impl == 'miopen' or dtype == torch.bfloat16)
         self.mf = torch.channels_last if channels_last else torch.contiguous_format
         self.w = {}
+        self.wp = {}
         for conv, bn, oc, ic, k in conv_bn_names():
             w, b = fold_bn(params[conv + '_weight'], params[bn + '_gamma'], params[bn + '_beta'],
                            params[bn + '_moving_mean'], params[bn + '_moving_var'])
@@ -108,6 +119,36 @@ class Backbone(object):
     def _put(self, name, w, b):
         self.w[name] = (w.to(self.device, self.dtype).contiguous(memory_format=self.mf),
                         b.to(self.device, self.dtype))
+        if self.impl == 'hip' and w.shape[1] % 64 == 0:
+            self.wp[name] = (ops.pack_conv_weight(w, self.dtype, self.device),
+                             b.to(self.device, torch.float32).contiguous(), int(w.shape[2]))
+
+    def _hconv(self, x, name, stride=1, pad=0, dil=1, relu=False, resid=None, out_dtype=None):
+        w, b, k = self.wp[name]
+        return ops.conv2d_nhwc(x, w, b, ksize=k, stride=stride, pad=pad, dil=dil, relu=relu, resid=resid,
+                               out_dtype=out_dtype)
+
+    def _forward_hip(self, data):
+        x = data.to(self.dtype).contiguous(memory_format=self.mf)
+        x = self._conv(x, 'conv1', stride=2, pad=3, relu=True)
+        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=0, ceil_mode=True)
+        x = x.permute(0, 2, 3, 1)                       # NHWC view of the channels-last tensor
+        conv4 = None
+        for stage, nm, ic, mc, oc, stride, dil, proj in self.units:
+            if stage == 5 and conv4 is None:
+                conv4 = x
+            sc = self._hconv(x, 'res%s_branch1' % nm, stride=stride) if proj else x
+            y = self._hconv(x, 'res%s_branch2a' % nm, stride=stride, relu=True)
+            y = self._hconv(y, 'res%s_branch2b' % nm, pad=dil, dil=dil, relu=True)
+            x = self._hconv(y, 'res%s_branch2c' % nm, relu=True, resid=sc)     # relu(bn(conv) + shortcut)
+        conv5 = x
+        feat = self._hconv(conv5, 'conv_new_1', relu=True)
+        r = self._hconv(conv4, 'rpn_conv_3x3', pad=1, relu=True)
+        rpn = self._hconv(r, 'rpn_out', out_dtype=torch.float32)
+        na2 = self.w['rpn_cls_score'][0].shape[0]
+        nchw = lambda t: t.permute(0, 3, 1, 2)
+        return dict(conv4=nchw(conv4), conv5=nchw(conv5), conv_new_1_relu=nchw(feat),
+                    rpn_cls_score=nchw(rpn[..., :na2]), rpn_bbox_pred=nchw(rpn[..., na2:]))
 
     def _conv(self, x, name, stride=1, pad=0, dil=1, relu=False):
         w, b = self.w[name]
@@ -115,7 +156,10 @@ class Backbone(object):
         return F.relu_(y) if relu else y
 
     def forward(self, data):
-        """data [B,3,H,W] -> dict(conv4, conv5, conv_new_1_relu, rpn_cls_score, rpn_bbox_pred)."""
+        """data [B,3,H,W] -> dict(conv4, conv5, conv_new_1_relu, rpn_cls_score, rpn_bbox_pred)
+        (logical NCHW tensors; channels-last memory)."""
+        if self.impl == 'hip':
+            return self._forward_hip(data)
         x = data.to(self.dtype).contiguous(memory_format=self.mf)
         x = self._conv(x, 'conv1', stride=2, pad=3, relu=True)
         x = F.max_pool2d(x, kernel_size=3, stride=2, padding=0, ceil_mode=True)

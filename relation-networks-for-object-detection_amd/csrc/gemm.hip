@@ -23,6 +23,10 @@ struct GemmArgs {
   int M, N, K;
   int bias_mode;           // 0 none, 1 per output column (N), 2 per output row (M)
   int relu;
+  // implicit-GEMM convolution (CONV kernels only): A is an NHWC image batch, row m of the
+  // GEMM is output pixel (b, oy, ox), k = (r*S + s)*Cin + ic; W is [Cout][R][S][Cin].
+  int cH, cW, cCin, cHout, cWout, cR, cS, cStride, cDil, cPad;
+  long cPix, cImg;         // element strides between pixels / images of the input
 };
 
 template <typename TOUT> __device__ __forceinline__ void store_out(TOUT* p, float v);
@@ -54,7 +58,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& g, TOUT* C, const 
 // ---------------------------------------------------------------------------------------
 // bf16 in, fp32 accumulate.  BM x BN workgroup tile, TM x TN MFMA tiles per wave.
 // ---------------------------------------------------------------------------------------
-template <int BM, int BN, typename TOUT>
+template <int BM, int BN, typename TOUT, bool CONV>
 __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
   constexpr int BK = 64;
   constexpr int TM = BM / 64, TN = BN / 64;           // 32x32 tiles per wave per dim
@@ -73,13 +77,40 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
   const TOUT* R = g.resid ? (const TOUT*)g.resid + (long)blockIdx.z * g.strideC : nullptr;
 
   uint4 ra[A_CHUNKS], rb[B_CHUNKS];
+  // implicit im2col: per-thread output-pixel coordinates of its A rows (fixed over k)
+  const unsigned short* cbase[A_CHUNKS];
+  int ciy[A_CHUNKS], cix[A_CHUNKS];
+  if constexpr (CONV) {
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i) {
+      const int gr = m0 + ((tid + 256 * i) >> 3);
+      const int hw = g.cHout * g.cWout;
+      const int b = gr / hw, rem = gr - b * hw;
+      const int oy = rem / g.cWout, ox = rem - oy * g.cWout;
+      cbase[i] = A + (long)b * g.cImg;
+      ciy[i] = (gr < g.M) ? oy * g.cStride - g.cPad : -(1 << 28);      // row >= M: never in bounds
+      cix[i] = ox * g.cStride - g.cPad;
+    }
+  }
   auto gload = [&](int kt) {
     const int k0 = kt * BK;
+    int tr = 0, ts = 0, ic0 = k0;
+    if constexpr (CONV) {
+      const int tap = k0 / g.cCin;
+      ic0 = k0 - tap * g.cCin;
+      tr = tap / g.cS; ts = tap - tr * g.cS;
+    }
 #pragma unroll
     for (int i = 0; i < A_CHUNKS; ++i) {
       const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
-      const int gr = m0 + row;
-      ra[i] = (gr < g.M) ? *(const uint4*)(A + (long)gr * g.lda + k0 + ch * 8) : make_uint4(0, 0, 0, 0);
+      if constexpr (CONV) {
+        const int iy = ciy[i] + tr * g.cDil, ix = cix[i] + ts * g.cDil;
+        const bool ok = (iy >= 0) && (iy < g.cH) && (ix >= 0) && (ix < g.cW);
+        ra[i] = ok ? *(const uint4*)(cbase[i] + ((long)iy * g.cW + ix) * g.cPix + ic0 + ch * 8) : make_uint4(0, 0, 0, 0);
+      } else {
+        const int gr = m0 + row;
+        ra[i] = (gr < g.M) ? *(const uint4*)(A + (long)gr * g.lda + k0 + ch * 8) : make_uint4(0, 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_CHUNKS; ++i) {
@@ -228,6 +259,25 @@ using namespace relnet;
 // dtype codes shared by the whole C-ABI
 enum { RELNET_F32 = 0, RELNET_BF16 = 1 };
 
+template <bool CONV>
+static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t s) {
+  const int M = g.M, N = g.N;
+  const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+  if (N <= 64) {
+    dim3 grid((N + 63) / 64, (M + 127) / 128, batch);
+    if (out_dtype == RELNET_BF16) gemm_nt_bf16_kernel<128, 64, unsigned short, CONV><<<grid, 256, 0, s>>>(g);
+    else gemm_nt_bf16_kernel<128, 64, float, CONV><<<grid, 256, 0, s>>>(g);
+  } else if (tiles128 >= 200) {
+    dim3 grid((N + 127) / 128, (M + 127) / 128, batch);
+    if (out_dtype == RELNET_BF16) gemm_nt_bf16_kernel<128, 128, unsigned short, CONV><<<grid, 256, 0, s>>>(g);
+    else gemm_nt_bf16_kernel<128, 128, float, CONV><<<grid, 256, 0, s>>>(g);
+  } else {
+    dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
+    if (out_dtype == RELNET_BF16) gemm_nt_bf16_kernel<64, 64, unsigned short, CONV><<<grid, 256, 0, s>>>(g);
+    else gemm_nt_bf16_kernel<64, 64, float, CONV><<<grid, 256, 0, s>>>(g);
+  }
+}
+
 extern "C" int relnet_gemm_nt(const void* A, long lda, long strideA, const void* W, long ldw,
                               long strideW, void* C, long ldc, long strideC, const float* bias,
                               int bias_mode, const void* resid, int relu, int M, int N, int K,
@@ -235,20 +285,13 @@ extern "C" int relnet_gemm_nt(const void* A, long lda, long strideA, const void*
   RELNET_REQUIRE(A && W && C, "relnet_gemm_nt: null operand");
   RELNET_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "relnet_gemm_nt: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
   RELNET_REQUIRE(bias_mode == 0 || bias, "relnet_gemm_nt: bias_mode=%d needs a bias vector", bias_mode);
-  GemmArgs g{A, lda, strideA, W, ldw, strideW, C, ldc, strideC, bias, resid, M, N, K, bias_mode, relu};
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.strideA = strideA; g.W = W; g.ldw = ldw; g.strideW = strideW; g.C = C; g.ldc = ldc;
+  g.strideC = strideC; g.bias = bias; g.resid = resid; g.M = M; g.N = N; g.K = K; g.bias_mode = bias_mode; g.relu = relu;
   hipStream_t s = (hipStream_t)stream;
   if (in_dtype == RELNET_BF16) {
     RELNET_REQUIRE(K % 64 == 0 && lda % 8 == 0 && ldw % 8 == 0, "relnet_gemm_nt(bf16): K %% 64 and ld %% 8 required (K=%d lda=%ld ldw=%ld)", K, lda, ldw);
-    const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
-    if (tiles128 >= 200) {
-      dim3 grid((N + 127) / 128, (M + 127) / 128, batch);
-      if (out_dtype == RELNET_BF16) gemm_nt_bf16_kernel<128, 128, unsigned short><<<grid, 256, 0, s>>>(g);
-      else gemm_nt_bf16_kernel<128, 128, float><<<grid, 256, 0, s>>>(g);
-    } else {
-      dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
-      if (out_dtype == RELNET_BF16) gemm_nt_bf16_kernel<64, 64, unsigned short><<<grid, 256, 0, s>>>(g);
-      else gemm_nt_bf16_kernel<64, 64, float><<<grid, 256, 0, s>>>(g);
-    }
+    launch_bf16<false>(g, batch, out_dtype, s);
   } else if (in_dtype == RELNET_F32) {
     RELNET_REQUIRE(K % 16 == 0 && lda % 4 == 0 && ldw % 4 == 0, "relnet_gemm_nt(f32): K %% 16 and ld %% 4 required (K=%d)", K);
     dim3 grid((N + 127) / 128, (M + 127) / 128, batch);
@@ -258,4 +301,30 @@ extern "C" int relnet_gemm_nt(const void* A, long lda, long strideA, const void*
     RELNET_REQUIRE(false, "relnet_gemm_nt: unknown in_dtype %d", in_dtype);
   }
   return check_launch("relnet_gemm_nt");
+}
+
+// NHWC convolution as an implicit GEMM on the bf16 MFMA kernel (reference: the Convolution
+// + BatchNorm(use_global_stats) + Activation triples of resnet_v1_101_rcnn_base.py:29-693, BN
+// folded into weight/bias at load time; `resid` fuses the bottleneck's broadcast_add + ReLU).
+//   in  [B, H, W, >=Cin] bf16 (pixel stride in_pix, image stride in_img, elements)
+//   w   [Cout, R*S*Cin] bf16, k = (r*S + s)*Cin + ic
+//   out [B*Hout*Wout, ldc] (bf16 or f32), resid same layout/dtype as out
+extern "C" int relnet_conv2d_nhwc(const void* in, long in_pix, long in_img, const void* w,
+                                  const float* bias, const void* resid, int relu, void* out, long ldc,
+                                  int B, int H, int W, int Cin, int Cout, int R, int S, int stride,
+                                  int dil, int pad, int out_dtype, void* stream) {
+  RELNET_REQUIRE(in && w && out, "relnet_conv2d_nhwc: null operand");
+  RELNET_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && dil > 0 && pad >= 0, "relnet_conv2d_nhwc: bad geometry");
+  RELNET_REQUIRE(Cin % 64 == 0 && in_pix % 8 == 0 && in_img % 8 == 0, "relnet_conv2d_nhwc: Cin %% 64 == 0 and 16-byte aligned strides required (Cin=%d)", Cin);
+  const int Hout = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1;
+  const int Wout = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
+  RELNET_REQUIRE(Hout > 0 && Wout > 0 && (long)B * Hout * Wout < (1L << 31), "relnet_conv2d_nhwc: empty or too large output");
+  GemmArgs g{};
+  g.A = in; g.lda = in_pix; g.strideA = 0; g.W = w; g.ldw = (long)R * S * Cin; g.strideW = 0;
+  g.C = out; g.ldc = ldc; g.strideC = 0; g.bias = bias; g.resid = resid;
+  g.M = B * Hout * Wout; g.N = Cout; g.K = R * S * Cin; g.bias_mode = bias ? 1 : 0; g.relu = relu;
+  g.cH = H; g.cW = W; g.cCin = Cin; g.cHout = Hout; g.cWout = Wout; g.cR = R; g.cS = S;
+  g.cStride = stride; g.cDil = dil; g.cPad = pad; g.cPix = in_pix; g.cImg = in_img;
+  launch_bf16<true>(g, 1, out_dtype, (hipStream_t)stream);
+  return check_launch("relnet_conv2d_nhwc");
 }

@@ -64,10 +64,13 @@ struct ClsNmsArgs {
   float score_thresh;        // 1e-3 (tester.py:245)
   double nms_param;          // sigma (soft) or IoU threshold (hard)
   int soft;
+  int max_picks;             // stop after this many picks per class (picks come out in
+                             // non-increasing score order, so the first max_per_image picks of a
+                             // class are the only ones that can survive tester.py:270-277)
 };
 
-constexpr int kPerLane = 8;   // up to 512 candidates per (image, class)
-
+// kPerLane * 64 >= N candidates per (image, class)
+template <int kPerLane>
 __global__ __launch_bounds__(64) void class_nms_kernel(ClsNmsArgs g) {
   const int cls = blockIdx.x + 1, b = blockIdx.y, lane = threadIdx.x;
   const float* prob = g.cls_prob + (long)b * g.N * g.C;
@@ -94,7 +97,8 @@ __global__ __launch_bounds__(64) void class_nms_kernel(ClsNmsArgs g) {
   for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
   double* out = g.dets + (((long)b * (g.C - 1) + (cls - 1)) * g.N) * 5;
   int picked = 0;
-  for (int it = 0; it < n; ++it) {
+  const int n_it = n < g.max_picks ? n : g.max_picks;
+  for (int it = 0; it < n_it; ++it) {
     // arg-max over remaining; ties -> larger roi index (argsort()[::-1] convention)
     double best = -1.0; int bi = -1;
 #pragma unroll
@@ -247,12 +251,15 @@ extern "C" int relnet_detect_head(const float* cls_score, long cs_ld, const floa
 
 extern "C" int relnet_class_nms(const float* cls_prob, const double* boxes, double* dets, int* counts,
                                 int B, int N, int C, float score_thresh, double nms_param, int soft,
-                                void* stream) {
+                                int max_picks, void* stream) {
   RELNET_REQUIRE(cls_prob && boxes && dets && counts, "relnet_class_nms: null operand");
-  RELNET_REQUIRE(B > 0 && N > 0 && N <= 64 * kPerLane && C > 1, "relnet_class_nms: need 0 < N <= %d (N=%d)", 64 * kPerLane, N);
-  ClsNmsArgs g{cls_prob, boxes, dets, counts, N, C, score_thresh, nms_param, soft};
+  RELNET_REQUIRE(B > 0 && N > 0 && N <= 1024 && C > 1, "relnet_class_nms: need 0 < N <= 1024 (N=%d)", N);
+  ClsNmsArgs g{cls_prob, boxes, dets, counts, N, C, score_thresh, nms_param, soft, max_picks > 0 ? max_picks : N};
   dim3 grid(C - 1, B);
-  class_nms_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(g);
+  hipStream_t s = (hipStream_t)stream;
+  if (N <= 320) class_nms_kernel<5><<<grid, 64, 0, s>>>(g);
+  else if (N <= 512) class_nms_kernel<8><<<grid, 64, 0, s>>>(g);
+  else class_nms_kernel<16><<<grid, 64, 0, s>>>(g);
   return check_launch("relnet_class_nms");
 }
 

@@ -67,7 +67,8 @@ class Detector(object):
                                       rois.view(B * N, 5), im_info, N)
         out['cls_prob'], out['pred_boxes'] = prob.view(B, N, -1), boxes.view(B, N, 4)
         if post:
-            dets, counts = ops.class_nms(out['cls_prob'], out['pred_boxes'], c.score_thresh, c.nms, c.softnms)
+            dets, counts = ops.class_nms(out['cls_prob'], out['pred_boxes'], c.score_thresh, c.nms, c.softnms,
+                                         max_picks=c.max_per_image)
             det, det_count, thresh, total = ops.image_topk(dets, counts, c.max_per_image)
             out.update(class_dets=dets, class_counts=counts, detections=det, num_detections=det_count,
                        image_thresh=thresh)

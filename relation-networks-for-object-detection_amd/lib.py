@@ -39,8 +39,9 @@ _SIGNATURES = {
     'relnet_roi_pool_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     'relnet_roi_pool_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_detect_head': (C.c_int, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'relnet_class_nms': (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, C.c_double, _i, _vp]),
+    'relnet_class_nms': (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, C.c_double, _i, _i, _vp]),
     'relnet_image_topk': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'relnet_conv2d_nhwc': (C.c_int, [_vp, _l, _l, _vp, _vp, _vp, _i, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
 }
 
 

@@ -230,16 +230,17 @@ def detect_head(cls_score, bbox_pred, rois, im_info, rois_per_image, delta_off=4
     return prob, boxes
 
 
-def class_nms(cls_prob, boxes, score_thresh=1e-3, nms_param=0.6, soft=True):
+def class_nms(cls_prob, boxes, score_thresh=1e-3, nms_param=0.6, soft=True, max_picks=0):
     """cls_prob [B,N,C] fp32, boxes [B,N,4] float64 -> dets [B,C-1,N,5] float64 (pick order),
-    counts [B,C-1] int32."""
+    counts [B,C-1] int32.  max_picks > 0 truncates every class list after that many picks
+    (exactly the rows that can survive the image-level max_per_image cut)."""
     _chk(cls_prob, boxes)
     B, N, Cn = cls_prob.shape
     assert cls_prob.is_contiguous() and boxes.is_contiguous() and boxes.dtype == torch.float64
     dets = torch.zeros((B, Cn - 1, N, 5), device=cls_prob.device, dtype=torch.float64)
     counts = torch.empty((B, Cn - 1), device=cls_prob.device, dtype=torch.int32)
     _lib.call('relnet_class_nms', cls_prob.data_ptr(), boxes.data_ptr(), dets.data_ptr(), counts.data_ptr(),
-              B, N, Cn, float(score_thresh), float(nms_param), int(soft), _stream())
+              B, N, Cn, float(score_thresh), float(nms_param), int(soft), int(max_picks), _stream())
     return dets, counts
 
 
@@ -255,3 +256,36 @@ def image_topk(dets, counts, max_per_image=100, max_out=None):
     _lib.call('relnet_image_topk', dets.data_ptr(), counts.data_ptr(), thresh.data_ptr(), total.data_ptr(),
               out.data_ptr(), out_count.data_ptr(), B, NC, N, max_per_image, max_out, _stream())
     return out, out_count, thresh, total
+
+
+# ---------------------------------------------------------------------------------------
+# NHWC convolution (implicit GEMM on the bf16 MFMA kernel)
+# ---------------------------------------------------------------------------------------
+def pack_conv_weight(w_oihw, dtype=torch.bfloat16, device='cuda'):
+    """[Cout, Cin, R, S] -> [Cout, R*S*Cin] (k = (r*S+s)*Cin + ic)."""
+    return w_oihw.permute(0, 2, 3, 1).reshape(w_oihw.shape[0], -1).to(device=device, dtype=dtype).contiguous()
+
+
+def conv2d_nhwc(x, w_packed, bias, ksize=1, stride=1, pad=0, dil=1, relu=False, resid=None, out=None,
+                out_dtype=None):
+    """x [B,H,W,Cin] bf16 (last dim contiguous; pixel/image strides free), w_packed
+    [Cout, k*k*Cin], bias fp32 [Cout] -> [B,Hout,Wout,Cout]; optional fused residual + ReLU."""
+    _chk(x, w_packed, bias, resid, out)
+    assert x.dtype == torch.bfloat16 and w_packed.dtype == torch.bfloat16 and x.stride(3) == 1
+    B, H, W, Cin = x.shape
+    assert x.stride(1) == W * x.stride(2), "rows of an image must be dense in W"
+    Cout = w_packed.shape[0]
+    assert w_packed.shape[1] == ksize * ksize * Cin and w_packed.is_contiguous()
+    Hout = (H + 2 * pad - dil * (ksize - 1) - 1) // stride + 1
+    Wout = (W + 2 * pad - dil * (ksize - 1) - 1) // stride + 1
+    odt = out_dtype or (out.dtype if out is not None else x.dtype)
+    if out is None:
+        out = torch.empty((B, Hout, Wout, Cout), device=x.device, dtype=odt)
+    assert out.shape == (B, Hout, Wout, Cout) and out.stride(3) == 1
+    assert out.stride(1) == Wout * out.stride(2) and out.stride(0) == Hout * out.stride(1)
+    if resid is not None:
+        assert resid.dtype == out.dtype and resid.stride() == out.stride()
+    _lib.call('relnet_conv2d_nhwc', x.data_ptr(), x.stride(2), x.stride(0), w_packed.data_ptr(), _ptr(bias),
+              _ptr(resid), int(relu), out.data_ptr(), out.stride(2), B, H, W, Cin, Cout, ksize, ksize,
+              stride, dil, pad, _dt(out), _stream())
+    return out

@@ -70,6 +70,9 @@ def test_detector_fp32_stagewise(rn, relation):
     g = torch.Generator().manual_seed(5)
     for k in ('cls_score_weight', 'bbox_pred_weight'):
         p[k] = torch.randn(p[k].shape, generator=g) * 0.05
+    # exact score ties (identical all-zero pooled features) are order-unspecified in the reference
+    # (unstable argsort, nms.py:108,133): keep the feature map strictly positive so none occur
+    p['conv_new_1_bias'] = torch.rand(256, generator=g) * 0.1 + 0.05
     data = torch.randn(1, 3, H, W, generator=g)      # unit-variance pixels: O(1) RPN deltas
     im_info = torch.tensor([[H, W, 1.0]])
     cfg = detector.Config()
@@ -108,11 +111,23 @@ def test_detector_fp32_stagewise(rn, relation):
     assert np.abs(_np(out['bbox_pred'][0]) - bp).max() <= 2e-4 * max(np.abs(bp).max(), 1e-3)
     # A9: post-processing of the GPU's probabilities / boxes
     full = np.zeros((rois.shape[0], 8)); full[:, 4:8] = out['pred_boxes'][0].cpu().numpy()
-    want = OPP.detections(_np(out['cls_prob'][0]), full, 81, 1e-3, 0.6, True, 100)
+    prob0 = _np(out['cls_prob'][0])
+    want = OPP.detections(prob0, full, 81, 1e-3, 0.6, True, 100)
     n = int(out['num_detections'][0])
     flat = np.concatenate([np.hstack((np.full((len(w), 1), c + 1.0), w[:, 4:5], w[:, :4])) for c, w in enumerate(want)])
+    got = _np(out['detections'][0, :n])
     assert n == len(flat)
-    np.testing.assert_allclose(_np(out['detections'][0, :n]), flat.astype(np.float32), rtol=1e-5)
+    # (class, score) sequence always matches; boxes too unless two rois tie EXACTLY (rois that
+    # quantise to the same pooling bins give bit-identical features in the plain 2FC head; the
+    # reference's unstable argsort leaves the order of such ties unspecified)
+    np.testing.assert_allclose(got[:, :2], flat[:, :2].astype(np.float32), rtol=1e-5)
+    uniq = np.array([np.sum(np.isclose(flat[:, 1], sc, rtol=0, atol=0) & (flat[:, 0] == c)) == 1 for c, sc in flat[:, :2]])
+    has_tie = any(len(np.unique(prob0[:, j])) < len(prob0) for j in range(1, 81))
+    if not has_tie:
+        np.testing.assert_allclose(got, flat.astype(np.float32), rtol=1e-5)
+    else:
+        assert not relation, "the relation head should separate co-quantised rois"
+        np.testing.assert_allclose(got[uniq][:, 1], flat[uniq][:, 1].astype(np.float32), rtol=1e-5)
 
 
 def test_detector_bf16_batch_runs_and_is_close(rn):
@@ -128,3 +143,42 @@ def test_detector_bf16_batch_runs_and_is_close(rn):
     assert torch.isfinite(out['cls_prob']).all() and torch.isfinite(out['pred_boxes']).all()
     assert out['rois'].shape == (2, 64, 5) and (out['rois'][1, :, 0] == 1).all()
     assert (out['num_detections'] > 0).all()
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,dil,hw', [(64, 64, 1, 1, 1, (37, 50)), (256, 128, 1, 2, 1, (38, 51)),
+                                                      (128, 128, 3, 1, 1, (19, 33)), (512, 512, 3, 1, 2, (13, 21)),
+                                                      (1024, 72, 1, 1, 1, (12, 16)), (64, 256, 1, 1, 1, (75, 64))])
+def test_conv2d_nhwc_implicit_gemm(rn, cin, cout, k, stride, dil, hw):
+    """Implicit-GEMM NHWC convolution (+bias, +residual, ReLU) vs torch conv2d in float64."""
+    ops, _, _ = rn
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(cin + cout + k)
+    B, (H, W) = 3, hw
+    x = torch.randn(B, H, W, cin, generator=g).cuda().to(torch.bfloat16)
+    w = (torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5).cuda().to(torch.bfloat16)
+    b = torch.randn(cout, generator=g).cuda()
+    pad = dil * (k // 2)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=stride, padding=pad, dilation=dil)
+    res = torch.randn(ref.shape, generator=g).cuda().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
+    want = torch.relu(ref.permute(0, 2, 3, 1) + res.double())
+    got = ops.conv2d_nhwc(x, ops.pack_conv_weight(w), b, ksize=k, stride=stride, pad=pad, dil=dil, relu=True, resid=res)
+    assert got.shape == want.shape
+    err = (got.double() - want).abs().max().item() / want.abs().max().item()
+    assert err < 1e-2, err
+    got32 = ops.conv2d_nhwc(x, ops.pack_conv_weight(w), b, ksize=k, stride=stride, pad=pad, dil=dil, out_dtype=torch.float32)
+    err32 = (got32.double() - ref.permute(0, 2, 3, 1)).abs().max().item() / ref.abs().max().item()
+    assert err32 < 2e-5 * (cin * k * k) ** 0.5, err32
+
+
+def test_backbone_hip_matches_library_path(rn):
+    """bf16 backbone on the implicit-GEMM kernels vs the same folded weights through MIOpen."""
+    ops, backbone, _ = rn
+    p = backbone.init_params(seed=8)
+    g = torch.Generator().manual_seed(9)
+    data = torch.randn(2, 3, 160, 224, generator=g).cuda()
+    a = backbone.Backbone(p, torch.bfloat16, impl='hip').forward(data)
+    b = backbone.Backbone(p, torch.float32, impl='miopen').forward(data)
+    for k in ('conv4', 'conv5', 'conv_new_1_relu', 'rpn_cls_score', 'rpn_bbox_pred'):
+        assert a[k].shape == b[k].shape, k
+        err = (a[k].float() - b[k]).abs().max().item() / b[k].abs().max().item()
+        assert err < 6e-2, (k, err)          # ~100 bf16 layers deep
