@@ -55,20 +55,83 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& g, TOUT* C, const 
   }
 }
 
+// Epilogue for accumulators computed with SWAPPED MFMA operands (D = W_frag x A_frag): lane
+// owns output row m = row0 + (lane & 31) and, per register group gq, four CONSECUTIVE output
+// columns col0 + 8 gq + 4 (lane >> 5) + 0..3 -> 8-byte (bf16) / 16-byte (f32) stores and
+// residual loads instead of one 2-byte element per lane.
+template <typename TOUT>
+__device__ __forceinline__ void epilogue_tile_t(const GemmArgs& g, TOUT* C, const TOUT* R,
+                                                const f32x16& acc, int row0, int col0, int lane) {
+  const int m = row0 + (lane & 31);
+  if (m >= g.M) return;
+  const float brow = (g.bias_mode == 2) ? g.bias[m] : 0.f;
+  const bool vec_ok = (g.ldc & 3) == 0;
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const int n = col0 + 8 * gq + 4 * (lane >> 5);
+    if (n >= g.N) continue;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = acc[4 * gq + e] + brow;
+    TOUT* cp = C + (long)m * g.ldc + n;
+    const TOUT* rp = R ? R + (long)m * g.ldc + n : nullptr;
+    if (vec_ok && n + 3 < g.N) {
+      if (g.bias_mode == 1) {
+        const float4 bv = *(const float4*)(g.bias + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+      }
+      if constexpr (sizeof(TOUT) == 2) {
+        if (rp) {
+          const uint2 rv = *(const uint2*)rp;
+          v[0] += bf2f(rv.x & 0xffff); v[1] += bf2f(rv.x >> 16); v[2] += bf2f(rv.y & 0xffff); v[3] += bf2f(rv.y >> 16);
+        }
+        if (g.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        *(uint2*)cp = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      } else {
+        if (rp) {
+          const float4 rv = *(const float4*)rp;
+          v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+        }
+        if (g.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e < g.N) {
+          float x = v[e];
+          if (g.bias_mode == 1) x += g.bias[n + e];
+          if (rp) x += load_out<TOUT>(rp + e);
+          if (g.relu) x = fmaxf(x, 0.f);
+          store_out<TOUT>(cp + e, x);
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // bf16 in, fp32 accumulate.  BM x BN workgroup tile, TM x TN MFMA tiles per wave.
 // ---------------------------------------------------------------------------------------
+// 16 zero bytes: source of out-of-range rows / padded convolution taps for the LDS-direct loads
+__device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+typedef const __attribute__((address_space(1))) void* gas_ptr;
+typedef __attribute__((address_space(3))) void* las_ptr;
+
 template <int BM, int BN, typename TOUT, bool CONV>
 __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
   constexpr int BK = 64;
-  constexpr int TM = BM / 64, TN = BN / 64;           // 32x32 tiles per wave per dim
-  constexpr int A_CHUNKS = BM * 8 / 256, B_CHUNKS = BN * 8 / 256;   // 16-B chunks per thread
+  constexpr int TM = BM / 64, TN = BN / 64;           // 32x32 MFMA tiles per wave per dim
+  constexpr int A_GROUPS = BM / 32, B_GROUPS = BN / 32;   // 8-row groups (1 KiB) per wave
   constexpr int STAGE = (BM + BN) * BK * 2;            // bytes per pipeline stage
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
-  auto ldsA = [&](int buf) { return lds + buf * STAGE; };
-  auto ldsB = [&](int buf) { return lds + buf * STAGE + BM * BK * 2; };
+  constexpr int CLD = BN + 4;                          // padded fp32 row of the epilogue tile
+  constexpr int LDS_BYTES = (2 * STAGE > BM * CLD * 4) ? 2 * STAGE : BM * CLD * 4;
+  // ONE shared array (a second __shared__ object makes hipcc drain vmcnt before every ds_read)
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const unsigned short* A = (const unsigned short*)g.A + (long)blockIdx.z * g.strideA;
@@ -76,23 +139,33 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
   TOUT* C = (TOUT*)g.C + (long)blockIdx.z * g.strideC;
   const TOUT* R = g.resid ? (const TOUT*)g.resid + (long)blockIdx.z * g.strideC : nullptr;
 
-  uint4 ra[A_CHUNKS], rb[B_CHUNKS];
-  // implicit im2col: per-thread output-pixel coordinates of its A rows (fixed over k)
-  const unsigned short* cbase[A_CHUNKS];
-  int ciy[A_CHUNKS], cix[A_CHUNKS];
-  if constexpr (CONV) {
+  // LDS-direct staging (global_load_lds, 16 B per lane): one instruction fills 8 rows x 128 B,
+  // lane l -> LDS (row l>>3, slot l&7).  The bank-conflict swizzle slot = chunk ^ (row & 7) is
+  // applied on the SOURCE side: lane l fetches global chunk (l&7) ^ (l>>3) of its row.
+  const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);
+  const unsigned short* arow[A_GROUPS];
+  const unsigned short* brow[B_GROUPS];
+  int ciy[A_GROUPS], cix[A_GROUPS];
 #pragma unroll
-    for (int i = 0; i < A_CHUNKS; ++i) {
-      const int gr = m0 + ((tid + 256 * i) >> 3);
+  for (int j = 0; j < A_GROUPS; ++j) {
+    const int gr = m0 + (wave * A_GROUPS + j) * 8 + lrow;
+    if constexpr (CONV) {
       const int hw = g.cHout * g.cWout;
       const int b = gr / hw, rem = gr - b * hw;
       const int oy = rem / g.cWout, ox = rem - oy * g.cWout;
-      cbase[i] = A + (long)b * g.cImg;
-      ciy[i] = (gr < g.M) ? oy * g.cStride - g.cPad : -(1 << 28);      // row >= M: never in bounds
-      cix[i] = ox * g.cStride - g.cPad;
+      arow[j] = A + (long)b * g.cImg + lchunk * 8;
+      ciy[j] = (gr < g.M) ? oy * g.cStride - g.cPad : -(1 << 28);     // row >= M: never in bounds
+      cix[j] = ox * g.cStride - g.cPad;
+    } else {
+      arow[j] = (gr < g.M) ? A + (long)gr * g.lda + lchunk * 8 : nullptr;
     }
   }
-  auto gload = [&](int kt) {
+#pragma unroll
+  for (int j = 0; j < B_GROUPS; ++j) {
+    const int gr = n0 + (wave * B_GROUPS + j) * 8 + lrow;
+    brow[j] = (gr < g.N) ? W + (long)gr * g.ldw + lchunk * 8 : nullptr;
+  }
+  auto stage = [&](int kt, int buf) {
     const int k0 = kt * BK;
     int tr = 0, ts = 0, ic0 = k0;
     if constexpr (CONV) {
@@ -100,35 +173,24 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
       ic0 = k0 - tap * g.cCin;
       tr = tap / g.cS; ts = tap - tr * g.cS;
     }
+    unsigned char* la = lds + buf * STAGE + wave * (A_GROUPS * 1024);
+    unsigned char* lb = lds + buf * STAGE + BM * BK * 2 + wave * (B_GROUPS * 1024);
 #pragma unroll
-    for (int i = 0; i < A_CHUNKS; ++i) {
-      const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+    for (int j = 0; j < A_GROUPS; ++j) {
+      const void* src;
       if constexpr (CONV) {
-        const int iy = ciy[i] + tr * g.cDil, ix = cix[i] + ts * g.cDil;
+        const int iy = ciy[j] + tr * g.cDil, ix = cix[j] + ts * g.cDil;
         const bool ok = (iy >= 0) && (iy < g.cH) && (ix >= 0) && (ix < g.cW);
-        ra[i] = ok ? *(const uint4*)(cbase[i] + ((long)iy * g.cW + ix) * g.cPix + ic0 + ch * 8) : make_uint4(0, 0, 0, 0);
+        src = ok ? (const void*)(arow[j] + ((long)iy * g.cW + ix) * g.cPix + ic0) : (const void*)g_zero16;
       } else {
-        const int gr = m0 + row;
-        ra[i] = (gr < g.M) ? *(const uint4*)(A + (long)gr * g.lda + k0 + ch * 8) : make_uint4(0, 0, 0, 0);
+        src = arow[j] ? (const void*)(arow[j] + k0) : (const void*)g_zero16;
       }
+      __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(la + j * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < B_CHUNKS; ++i) {
-      const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
-      const int gr = n0 + row;
-      rb[i] = (gr < g.N) ? *(const uint4*)(W + (long)gr * g.ldw + k0 + ch * 8) : make_uint4(0, 0, 0, 0);
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < A_CHUNKS; ++i) {
-      const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
-      *(uint4*)(ldsA(buf) + row * 128 + ((ch ^ (row & 7)) << 4)) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < B_CHUNKS; ++i) {
-      const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
-      *(uint4*)(ldsB(buf) + row * 128 + ((ch ^ (row & 7)) << 4)) = rb[i];
+    for (int j = 0; j < B_GROUPS; ++j) {
+      const void* src = brow[j] ? (const void*)(brow[j] + k0) : (const void*)g_zero16;
+      __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(lb + j * 1024), 16, 0, 0);
     }
   };
 
@@ -141,12 +203,13 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = g.K / BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
+  stage(0, 0);
+  __syncthreads();                                   // (drains the LDS-direct loads: vmcnt(0))
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+    if (kt + 1 < nk) stage(kt + 1, buf ^ 1);         // async: lands while this tile is multiplied
+    const unsigned char* la = lds + buf * STAGE;
+    const unsigned char* lb = la + BM * BK * 2;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       bf16x8 af[TM], bfr[TN];
@@ -154,27 +217,96 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row = wr * (BM / 2) + i * 32 + (lane & 31);
-        af[i] = *(const bf16x8*)(ldsA(buf) + row * 128 + ((ch ^ (row & 7)) << 4));
+        af[i] = *(const bf16x8*)(la + row * 128 + ((ch ^ (row & 7)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int row = wc * (BN / 2) + j * 32 + (lane & 31);
-        bfr[j] = *(const bf16x8*)(ldsB(buf) + row * 128 + ((ch ^ (row & 7)) << 4));
+        bfr[j] = *(const bf16x8*)(lb + row * 128 + ((ch ^ (row & 7)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // D = W x A: lane <-> output row
     }
-    if (kt + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
   }
+  // ---- epilogue: accumulators -> LDS (fp32, padded rows) -> coalesced 16-byte stores ------
+  // (the loop's trailing barrier has retired every read of the staging buffers)
+  float* ct = (float*)lds;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      epilogue_tile<TOUT>(g, C, R, acc[i][j], m0 + wr * (BM / 2) + i * 32, n0 + wc * (BN / 2) + j * 32, lane);
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int row = wr * (BM / 2) + i * 32 + (lane & 31);
+        const int col = wc * (BN / 2) + j * 32 + 8 * gq + 4 * (lane >> 5);
+        *(float4*)(ct + row * CLD + col) = make_float4(acc[i][j][4 * gq], acc[i][j][4 * gq + 1],
+                                                       acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]);
+      }
+  __syncthreads();
+  constexpr int VEC = 16 / sizeof(TOUT);               // output elements per 16-byte store
+  constexpr int TPR = BN / VEC;                        // threads per tile row
+  constexpr int RPP = 256 / TPR;                       // rows per pass
+  const int tcol = (tid % TPR) * VEC, trow = tid / TPR;
+  const int n = n0 + tcol;
+  const bool vec_ok = ((g.ldc % VEC) == 0) && ((((size_t)C) & 15) == 0) && (!R || (((size_t)R) & 15) == 0);
+  float bv[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) bv[e] = (g.bias_mode == 1 && n + e < g.N) ? g.bias[n + e] : 0.f;
+#pragma unroll 4
+  for (int p = 0; p < BM / RPP; ++p) {
+    const int row = p * RPP + trow, m = m0 + row;
+    if (m >= g.M || n >= g.N) continue;
+    float v[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q) {
+      const float4 x = *(const float4*)(ct + row * CLD + tcol + 4 * q);
+      v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+    }
+    const float brow = (g.bias_mode == 2) ? g.bias[m] : 0.f;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] += bv[e] + brow;
+    TOUT* cp = C + (long)m * g.ldc + n;
+    const TOUT* rp = R ? R + (long)m * g.ldc + n : nullptr;
+    if (vec_ok && n + VEC <= g.N) {
+      if constexpr (sizeof(TOUT) == 2) {
+        if (rp) {
+          const uint4 rv = *(const uint4*)rp;
+          const unsigned int rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f(rw[e] & 0xffff); v[2 * e + 1] += bf2f(rw[e] >> 16); }
+        }
+        if (g.relu) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *(uint4*)cp = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+      } else {
+        if (rp) {
+          const float4 rv = *(const float4*)rp;
+          v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+        }
+        if (g.relu) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        if (n + e < g.N) {
+          float x = v[e];
+          if (rp) x += load_out<TOUT>(rp + e);
+          if (g.relu) x = fmaxf(x, 0.f);
+          store_out<TOUT>(cp + e, x);
+        }
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -259,11 +391,18 @@ using namespace relnet;
 // dtype codes shared by the whole C-ABI
 enum { RELNET_F32 = 0, RELNET_BF16 = 1 };
 
+static int g_force_tile = 0;     // tuning knob: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64
+extern "C" void relnet_gemm_force_tile(int t) { g_force_tile = t; }
+
 template <bool CONV>
 static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t s) {
   const int M = g.M, N = g.N;
-  const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
-  if (N <= 64) {
+  long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+  int n_small = N <= 64;
+  if (g_force_tile == 1) { n_small = 0; tiles128 = 1000; }
+  if (g_force_tile == 2) { n_small = 1; }
+  if (g_force_tile == 3) { n_small = 0; tiles128 = 0; }
+  if (n_small) {
     dim3 grid((N + 63) / 64, (M + 127) / 128, batch);
     if (out_dtype == RELNET_BF16) gemm_nt_bf16_kernel<128, 64, unsigned short, CONV><<<grid, 256, 0, s>>>(g);
     else gemm_nt_bf16_kernel<128, 64, float, CONV><<<grid, 256, 0, s>>>(g);
