@@ -50,11 +50,15 @@ class KernelTimer(object):
         e.record()
         self.events.setdefault(name, []).append((s, e))
 
-    def summary(self):
+    def summary(self, by_tag=False):
         out = {}
         for name, evs in self.events.items():
             ms = [s.elapsed_time(e) for s, e in evs]
-            out[name] = dict(calls=len(ms), avg_ms=sum(ms) / len(ms), total_ms=sum(ms))
+            key = name if by_tag else name.split(':')[0]
+            d = out.setdefault(key, dict(calls=0, total_ms=0.0))
+            d['calls'] += len(ms); d['total_ms'] += sum(ms)
+        for d in out.values():
+            d['avg_ms'] = d['total_ms'] / d['calls']
         return out
 
 
@@ -90,6 +94,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=2)
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of hipGraph replays')
+    ap.add_argument('--shapes', action='store_true', help='print per-shape GEMM/conv times to stderr')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -131,15 +137,33 @@ def main():
     with torch.no_grad():
         for _ in range(a.warmup):
             out = step()
-        timer = None if a.no_kernel_timing else KernelTimer()
-        lib.timing_hook = timer
+        graph = None
+        if not a.no_graph:
+            # the whole step (~190 launches, no host synchronisation inside) as ONE hipGraph:
+            # the Python/ctypes launch path costs ~50 us per kernel, i.e. ~10 ms per step eager
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = step()
+            graph.replay()
         fence()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            out = step()
+            if graph is not None:
+                graph.replay()
+            else:
+                out = step()
         fence()
         elapsed = time.perf_counter() - t0
-        lib.timing_hook = None
+        # per-kernel durations: the same step launched eagerly with HIP events around every C-ABI
+        # launch (events cannot be timed inside a captured graph); same inputs, same stream
+        timer = None if a.no_kernel_timing else KernelTimer()
+        if timer is not None:
+            lib.timing_hook = timer
+            for _ in range(min(a.steps, 5)):
+                step()
+            torch.cuda.synchronize()
+            lib.timing_hook = None
     if dist is not None:
         t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -157,10 +181,14 @@ def main():
             'config': {'workload': 'BASELINE configs[1]: ResNet-101 Faster-RCNN + %s + soft-NMS(0.6) + top-100, '
                                    '600x1000 images, 300 proposals, random-init weights'
                                    % ('2 relation modules (N=300, 16 heads, d=1024)' if not a.no_relation else 'plain 2FC head'),
-                       'images_per_gpu_per_step': a.batch, 'parallelism': 'replicas x%d (no data-path collective)' % world},
+                       'images_per_gpu_per_step': a.batch, 'launch': 'eager' if a.no_graph else 'hipGraph replay', 'parallelism': 'replicas x%d (no data-path collective)' % world},
         }
         if timer is not None:
             ks = timer.summary()
+            if a.shapes:
+                for k, v in sorted(timer.summary(by_tag=True).items(), key=lambda kv: -kv[1]['total_ms']):
+                    sys.stderr.write('%-60s calls/step %5.1f avg %8.1f us  per-step %8.3f ms\n' % (
+                        k, v['calls'] / min(a.steps, 5), v['avg_ms'] * 1e3, v['total_ms'] / min(a.steps, 5)))
             res['kernels_ms'] = {k: round(v['avg_ms'], 5) for k, v in sorted(ks.items())}
             att = ks.get('relnet_relation_attention')
             if att:

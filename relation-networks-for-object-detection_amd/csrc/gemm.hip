@@ -119,20 +119,25 @@ __device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u
 typedef const __attribute__((address_space(1))) void* gas_ptr;
 typedef __attribute__((address_space(3))) void* las_ptr;
 
-template <int BM, int BN, typename TOUT, bool CONV>
-__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
+// BM x BN workgroup tile, WM x WN waves (each wave: TM x TN MFMA tiles of 32x32), BK = 64,
+// two LDS stages filled by global_load_lds.
+template <int BM, int BN, int WM, int WN, typename TOUT, bool CONV>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) {
   constexpr int BK = 64;
-  constexpr int TM = BM / 64, TN = BN / 64;           // 32x32 MFMA tiles per wave per dim
-  constexpr int A_GROUPS = BM / 32, B_GROUPS = BN / 32;   // 8-row groups (1 KiB) per wave
+  constexpr int NW = WM * WN, NT = 64 * NW;
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr int A_GROUPS = BM / (8 * NW), B_GROUPS = BN / (8 * NW);   // 8-row (1 KiB) groups per wave
+  static_assert(TM >= 1 && TN >= 1 && A_GROUPS >= 1 && B_GROUPS >= 1, "tile too small for the wave grid");
   constexpr int STAGE = (BM + BN) * BK * 2;            // bytes per pipeline stage
-  constexpr int CLD = BN + 4;                          // padded fp32 row of the epilogue tile
-  constexpr int LDS_BYTES = (2 * STAGE > BM * CLD * 4) ? 2 * STAGE : BM * CLD * 4;
+  constexpr int CLD = BN + 4;                          // padded fp32 row of the epilogue band
+  constexpr int BAND = 32 * WM;                        // rows written per epilogue pass
+  constexpr int LDS_BYTES = (2 * STAGE > BAND * CLD * 4) ? 2 * STAGE : BAND * CLD * 4;
   // ONE shared array (a second __shared__ object makes hipcc drain vmcnt before every ds_read)
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const unsigned short* A = (const unsigned short*)g.A + (long)blockIdx.z * g.strideA;
   const unsigned short* W = (const unsigned short*)g.W + (long)blockIdx.z * g.strideW;
@@ -216,12 +221,12 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
       const int ch = 2 * kk + (lane >> 5);
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int row = wr * (BM / 2) + i * 32 + (lane & 31);
+        const int row = wr * (BM / WM) + i * 32 + (lane & 31);
         af[i] = *(const bf16x8*)(la + row * 128 + ((ch ^ (row & 7)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int row = wc * (BN / 2) + j * 32 + (lane & 31);
+        const int row = wc * (BN / WN) + j * 32 + (lane & 31);
         bfr[j] = *(const bf16x8*)(lb + row * 128 + ((ch ^ (row & 7)) << 4));
       }
 #pragma unroll
@@ -232,77 +237,82 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
     }
     __syncthreads();
   }
-  // ---- epilogue: accumulators -> LDS (fp32, padded rows) -> coalesced 16-byte stores ------
-  // (the loop's trailing barrier has retired every read of the staging buffers)
+
+  // ---- epilogue: per band of 32 rows per wave-row: accumulators -> LDS (fp32, padded rows) ->
+  // coalesced 16-byte stores with bias / residual / ReLU applied on the way out -------------
   float* ct = (float*)lds;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int row = wr * (BM / 2) + i * 32 + (lane & 31);
-        const int col = wc * (BN / 2) + j * 32 + 8 * gq + 4 * (lane >> 5);
-        *(float4*)(ct + row * CLD + col) = make_float4(acc[i][j][4 * gq], acc[i][j][4 * gq + 1],
-                                                       acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]);
-      }
-  __syncthreads();
   constexpr int VEC = 16 / sizeof(TOUT);               // output elements per 16-byte store
-  constexpr int TPR = BN / VEC;                        // threads per tile row
-  constexpr int RPP = 256 / TPR;                       // rows per pass
+  constexpr int TPR = BN / VEC;                        // threads per band row
+  constexpr int RPP = NT / TPR;                        // rows per copy pass
   const int tcol = (tid % TPR) * VEC, trow = tid / TPR;
   const int n = n0 + tcol;
   const bool vec_ok = ((g.ldc % VEC) == 0) && ((((size_t)C) & 15) == 0) && (!R || (((size_t)R) & 15) == 0);
   float bv[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) bv[e] = (g.bias_mode == 1 && n + e < g.N) ? g.bias[n + e] : 0.f;
-#pragma unroll 4
-  for (int p = 0; p < BM / RPP; ++p) {
-    const int row = p * RPP + trow, m = m0 + row;
-    if (m >= g.M || n >= g.N) continue;
-    float v[VEC];
 #pragma unroll
-    for (int q = 0; q < VEC / 4; ++q) {
-      const float4 x = *(const float4*)(ct + row * CLD + tcol + 4 * q);
-      v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
-    }
-    const float brow = (g.bias_mode == 2) ? g.bias[m] : 0.f;
+  for (int i = 0; i < TM; ++i) {
+    if (i > 0) __syncthreads();                        // previous band fully copied out
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) v[e] += bv[e] + brow;
-    TOUT* cp = C + (long)m * g.ldc + n;
-    const TOUT* rp = R ? R + (long)m * g.ldc + n : nullptr;
-    if (vec_ok && n + VEC <= g.N) {
-      if constexpr (sizeof(TOUT) == 2) {
-        if (rp) {
-          const uint4 rv = *(const uint4*)rp;
-          const unsigned int rw[4] = {rv.x, rv.y, rv.z, rv.w};
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f(rw[e] & 0xffff); v[2 * e + 1] += bf2f(rw[e] >> 16); }
-        }
-        if (g.relu) {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        *(uint4*)cp = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-      } else {
-        if (rp) {
-          const float4 rv = *(const float4*)rp;
-          v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-        }
-        if (g.relu) {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+      for (int gq = 0; gq < 4; ++gq) {
+        const int row = wr * 32 + (lane & 31);
+        const int col = wc * (BN / WN) + j * 32 + 8 * gq + 4 * (lane >> 5);
+        *(float4*)(ct + row * CLD + col) = make_float4(acc[i][j][4 * gq], acc[i][j][4 * gq + 1],
+                                                       acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]);
       }
-    } else {
+    __syncthreads();
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        if (n + e < g.N) {
-          float x = v[e];
-          if (rp) x += load_out<TOUT>(rp + e);
-          if (g.relu) x = fmaxf(x, 0.f);
-          store_out<TOUT>(cp + e, x);
+    for (int p = 0; p < (BAND + RPP - 1) / RPP; ++p) {
+      const int brow_i = p * RPP + trow;               // row inside the band
+      if (brow_i >= BAND) continue;
+      const int m = m0 + (brow_i >> 5) * (BM / WM) + i * 32 + (brow_i & 31);
+      if (m >= g.M || n >= g.N) continue;
+      float v[VEC];
+#pragma unroll
+      for (int q = 0; q < VEC / 4; ++q) {
+        const float4 x = *(const float4*)(ct + brow_i * CLD + tcol + 4 * q);
+        v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+      }
+      const float brow = (g.bias_mode == 2) ? g.bias[m] : 0.f;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] += bv[e] + brow;
+      TOUT* cp = C + (long)m * g.ldc + n;
+      const TOUT* rp = R ? R + (long)m * g.ldc + n : nullptr;
+      if (vec_ok && n + VEC <= g.N) {
+        if constexpr (sizeof(TOUT) == 2) {
+          if (rp) {
+            const uint4 rv = *(const uint4*)rp;
+            const unsigned int rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f(rw[e] & 0xffff); v[2 * e + 1] += bf2f(rw[e] >> 16); }
+          }
+          if (g.relu) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          *(uint4*)cp = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        } else {
+          if (rp) {
+            const float4 rv = *(const float4*)rp;
+            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+          }
+          if (g.relu) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          if (n + e < g.N) {
+            float x = v[e];
+            if (rp) x += load_out<TOUT>(rp + e);
+            if (g.relu) x = fmaxf(x, 0.f);
+            store_out<TOUT>(cp + e, x);
+          }
         }
       }
     }
@@ -391,29 +401,40 @@ using namespace relnet;
 // dtype codes shared by the whole C-ABI
 enum { RELNET_F32 = 0, RELNET_BF16 = 1 };
 
-static int g_force_tile = 0;     // tuning knob: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64
+static int g_force_tile = 0;     // tuning knob: 0 auto, else index into the config list below
 extern "C" void relnet_gemm_force_tile(int t) { g_force_tile = t; }
 
+template <int BM, int BN, int WM, int WN, bool CONV>
+static void launch_cfg(const GemmArgs& g, int batch, int out_dtype, hipStream_t s) {
+  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
+  if (out_dtype == RELNET_BF16) gemm_nt_bf16_kernel<BM, BN, WM, WN, unsigned short, CONV><<<grid, 64 * WM * WN, 0, s>>>(g);
+  else gemm_nt_bf16_kernel<BM, BN, WM, WN, float, CONV><<<grid, 64 * WM * WN, 0, s>>>(g);
+}
+
+// configs: 1 = 256x256 (8 waves) 2 = 256x128 (8 waves) 3 = 128x128 (4 waves) 4 = 128x64 5 = 64x64
 template <bool CONV>
 static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t s) {
-  const int M = g.M, N = g.N;
-  long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
-  int n_small = N <= 64;
-  if (g_force_tile == 1) { n_small = 0; tiles128 = 1000; }
-  if (g_force_tile == 2) { n_small = 1; }
-  if (g_force_tile == 3) { n_small = 0; tiles128 = 0; }
-  if (n_small) {
-    dim3 grid((N + 63) / 64, (M + 127) / 128, batch);
-    if (out_dtype == RELNET_BF16) gemm_nt_bf16_kernel<128, 64, unsigned short, CONV><<<grid, 256, 0, s>>>(g);
-    else gemm_nt_bf16_kernel<128, 64, float, CONV><<<grid, 256, 0, s>>>(g);
-  } else if (tiles128 >= 200) {
-    dim3 grid((N + 127) / 128, (M + 127) / 128, batch);
-    if (out_dtype == RELNET_BF16) gemm_nt_bf16_kernel<128, 128, unsigned short, CONV><<<grid, 256, 0, s>>>(g);
-    else gemm_nt_bf16_kernel<128, 128, float, CONV><<<grid, 256, 0, s>>>(g);
-  } else {
-    dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
-    if (out_dtype == RELNET_BF16) gemm_nt_bf16_kernel<64, 64, unsigned short, CONV><<<grid, 256, 0, s>>>(g);
-    else gemm_nt_bf16_kernel<64, 64, float, CONV><<<grid, 256, 0, s>>>(g);
+  const long M = g.M, N = g.N;
+  int cfg = g_force_tile;
+  if (cfg == 0) {
+    // Picked from on-device timings of every GEMM / convolution shape of the detector at 16
+    // images per launch (tests/_bench_gemm.py; table in DESIGN.md): wide tiles cut the
+    // L2 -> LDS fill traffic of the compute-bound 3x3 / large-K layers, 128-row tiles keep more
+    // workgroups resident for the short-K, store-bound expand convolutions.
+    const long K = g.K;
+    if (N <= 64) cfg = 4;
+    else if (M * batch <= 8192) cfg = (N >= 256 ? 4 : 5);
+    else if (N <= 128) cfg = 3;
+    else if (K <= 256) cfg = (N >= 1024 ? 4 : 1);
+    else if (N % 256 != 0) cfg = 3;
+    else cfg = (N == 512 && K < 4096) ? 3 : 1;
+  }
+  switch (cfg) {
+    case 1: launch_cfg<256, 256, 2, 4, CONV>(g, batch, out_dtype, s); break;
+    case 2: launch_cfg<256, 128, 4, 2, CONV>(g, batch, out_dtype, s); break;
+    case 3: launch_cfg<128, 128, 2, 2, CONV>(g, batch, out_dtype, s); break;
+    case 4: launch_cfg<128, 64, 2, 2, CONV>(g, batch, out_dtype, s); break;
+    default: launch_cfg<64, 64, 2, 2, CONV>(g, batch, out_dtype, s); break;
   }
 }
 

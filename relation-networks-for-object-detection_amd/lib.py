@@ -73,10 +73,10 @@ def exported_symbols():
 timing_hook = None
 
 
-def call(name, *args):
+def call(name, *args, tag=None):
     lib = load()
     if timing_hook is not None:
-        with timing_hook(name):
+        with timing_hook(name if tag is None else name + ':' + tag):
             rc = getattr(lib, name)(*args)
     else:
         rc = getattr(lib, name)(*args)

@@ -65,7 +65,8 @@ def gemm_nt(a, w, bias=None, bias_mode=1, resid=None, relu=False, out=None, out_
         assert resid.dtype == out.dtype and resid.stride() == out.stride()
     _lib.call('relnet_gemm_nt', a.data_ptr(), a.stride(-2), sa, w.data_ptr(), w.stride(-2), sw,
               out.data_ptr(), out.stride(-2), sc, _ptr(bias), bias_mode if bias is not None else 0,
-              _ptr(resid), int(relu), M, N, K, batch, _dt(a), _dt(out), _stream())
+              _ptr(resid), int(relu), M, N, K, batch, _dt(a), _dt(out), _stream(),
+              tag='M%d_N%d_K%d_b%d' % (M, N, K, batch))
     return out
 
 
@@ -287,5 +288,6 @@ def conv2d_nhwc(x, w_packed, bias, ksize=1, stride=1, pad=0, dil=1, relu=False, 
         assert resid.dtype == out.dtype and resid.stride() == out.stride()
     _lib.call('relnet_conv2d_nhwc', x.data_ptr(), x.stride(2), x.stride(0), w_packed.data_ptr(), _ptr(bias),
               _ptr(resid), int(relu), out.data_ptr(), out.stride(2), B, H, W, Cin, Cout, ksize, ksize,
-              stride, dil, pad, _dt(out), _stream())
+              stride, dil, pad, _dt(out), _stream(),
+              tag='M%d_N%d_K%d_k%d' % (B * Hout * Wout, Cout, ksize * ksize * Cin, ksize))
     return out

@@ -36,5 +36,5 @@ for (M, N, K) in [(P4, 256, 1024), (P4, 1024, 256), (P4, 256, 2304), (P4, 512, 1
                   (B * 75 * 125, 128, 512), (B * 75 * 125, 512, 128), (B * 75 * 125, 128, 1152),
                   (B * 150 * 250, 64, 256), (B * 150 * 250, 256, 64), (B * 150 * 250, 64, 576),
                   (B * 300, 1024, 12544), (B * 300, 2048, 1024), (B * 300, 1024, 1024), (4096, 4096, 4096), (8192, 8192, 8192)]:
-    for t in (1, 2, 3):
+    for t in (1, 2, 3, 4, 5):
         bench(M, N, K, tile=t)
