@@ -98,21 +98,16 @@ def main():
     ap.add_argument('--shapes', action='store_true', help='print per-shape GEMM/conv times to stderr')
     a = ap.parse_args()
 
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == a.gpus or world == 1, "WORLD_SIZE=%d but --gpus %d" % (world, a.gpus)
-    torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
-
     import __graft_entry__ as ge
     ge.build()
     import relnet_amd  # noqa: F401
     from relnet_amd import lib, backbone, detector
+    from relnet_amd import dist as D
+
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    rank, world, local = D.init(backend='nccl')          # 'nccl' = RCCL over xGMI
+    assert world == a.gpus or world == 1, "WORLD_SIZE=%d but --gpus %d" % (world, a.gpus)
 
     tdt = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
     params = backbone.init_params(seed=1)
@@ -129,10 +124,7 @@ def main():
         return det.forward(data, im_info)
 
     def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+        D.fence(device='cuda')
 
     with torch.no_grad():
         for _ in range(a.warmup):
@@ -164,10 +156,7 @@ def main():
                 step()
             torch.cuda.synchronize()
             lib.timing_hook = None
-    if dist is not None:
-        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = D.max_over_ranks(elapsed, device='cuda')
     n_det = int(out['num_detections'].sum().item())
     assert n_det > 0 and bool(torch.isfinite(out['cls_prob']).all())
 
@@ -209,9 +198,9 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(params, relation=not a.no_relation, images=a.cpu_images)
         print(json.dumps(res))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

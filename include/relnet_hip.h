@@ -1,0 +1,123 @@
+/* relnet_hip.h -- C-ABI of librelnet_hip.so: the MI355X (gfx950) hot path of
+ * msracver/Relation-Networks-for-Object-Detection.
+ *
+ * Plain pointers and sizes only (no torch / MXNet types).  Unless a function says "host", every
+ * pointer is DEVICE memory and the work is enqueued on `stream` (a hipStream_t passed as void*;
+ * NULL = the default stream) without any host synchronisation, so every entry point can be
+ * captured in a hipGraph.  Return value: 0 on success, negative on error; the message of the
+ * last error on the calling thread is relnet_last_error().  dtype codes: RELNET_F32 = 0,
+ * RELNET_BF16 = 1 (bf16 operands, fp32 accumulation).
+ *
+ * Citations are file:line in the reference repository (the interface or code each entry point
+ * replaces).  SYM_REL = relation_rcnn/symbols/
+ * resnet_v1_101_rcnn_attention_1024_pairwise_position_multi_head_16.py.
+ */
+#ifndef RELNET_HIP_H
+#define RELNET_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { RELNET_F32 = 0, RELNET_BF16 = 1 };
+
+int relnet_version(void);                 /* 100 = 0.1.0 */
+const char* relnet_last_error(void);
+
+/* ---- lib/nms/gpu_nms.hpp:1-2 (the reference's own C prototype, bound by gpu_nms.pyx:15-16) -----
+ * HOST pointers.  boxes_host: boxes_num rows [x1,y1,x2,y2,score] pre-sorted by score (descending);
+ * keep_out[boxes_num] receives the kept row indices in ascending order, *num_out their count.
+ * Suppression rule of nms_kernel.cu:24-32,71: IoU with +1 pixel extents, strictly greater than
+ * nms_overlap_thresh.  On a HIP error *num_out = -1 (the reference only prints CUDA errors).     */
+void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+          float nms_overlap_thresh, int device_id);
+
+/* ---- operator_py/proposal.py:51-168 (ProposalOperator.forward), split in four device stages ----
+ * decode: anchors in (y, x, a) order over the h x w cropped grid (:85,113-123), float64 decode of
+ * lib/bbox/bbox_transform.py:103-140, clip (:45-60), min-size filter (:133-135, score := -inf).
+ * strides4 = element strides (b, c, y, x) of the [B,2A,H,W] / [B,4A,H,W] maps (host arrays of 4 longs).
+ * softmax_pairs != 0: cls_prob holds raw rpn_cls_score and the 2-way softmax of SYM_REL:218-223 is
+ * applied on the fly.                                                                            */
+int relnet_proposal_decode(const float* cls_prob, const long* cls_strides4, const float* deltas,
+                           const long* delta_strides4, const float* im_info, const double* base_anchors,
+                           float* boxes /*[B,n,4]*/, float* scores /*[B,n]*/, int B, int A, int h, int w,
+                           int feat_stride, int min_size, int softmax_pairs, void* stream);
+/* descending top-K (proposal.py:140-144): out_boxes5 [B,K,5] = the float32 `det` of :149,
+ * out_index [B,K] anchor indices, out_count [B] entries with finite score.  n < 65536, K <= 8192.
+ * Equal scores are ordered by descending index (the reference's argsort is unstable).            */
+int relnet_topk_sort(const float* scores, const float* boxes, float* out_boxes5, int* out_index,
+                     int* out_count, int B, int n, int K, void* stream);
+/* nms_kernel.cu:34-78 (bitmask, upper triangle only); mask [B, n, ceil(n/64)] uint64              */
+int relnet_nms_mask(const float* boxes5, const int* counts /*[B] or NULL*/, unsigned long long* mask,
+                    int B, int n, int n_stride, float thresh, void* stream);
+/* nms_kernel.cu:118-140 (greedy scan) on device + proposal.py:151-168 (first `post` kept boxes, pad,
+ * batch index column).  rois [B,post,5], roi_scores [B,post], keep [B,max_keep] (any may be NULL). */
+int relnet_nms_scan(const unsigned long long* mask, const float* boxes5, const int* counts, float* rois,
+                    float* roi_scores, int* keep, int* num_keep, int B, int n, int n_stride, int post,
+                    int max_keep, int batch_index_base, void* stream);
+
+/* ---- mx.symbol.ROIPooling(pooled_size=(7,7), spatial_scale=1/16), SYM_REL:252-253 ---------------
+ * data/out described by element strides (b|r, c, y, x) so NCHW and channels-last both work.       */
+int relnet_roi_pool_fwd(const void* data, const long* data_strides4, const float* rois /*[R,5]*/, void* out,
+                        const long* out_strides4, int* argmax /*or NULL*/, int R, int C, int H, int W, int PH,
+                        int PW, float spatial_scale, int batch_index_base, int dtype, void* stream);
+int relnet_roi_pool_bwd(const void* grad_out, const int* argmax, const long* out_strides4, const float* rois,
+                        float* grad_in /*fp32, pre-zeroed*/, long gs_b, long gs_c, int R, int C, int W, int PH,
+                        int PW, int batch_index_base, int dtype, void* stream);
+
+/* ---- mx.symbol.FullyConnected (fc_new_1/2, cls_score, bbox_pred, query_i, key_i: SYM_REL:254-280,
+ * 120-129) and the grouped linear_out_i product (:146-150): C = A W^T (+bias)(+resid)(ReLU).
+ * A [batch][M,K] (lda, strideA), W [batch][N,K], C [batch][M,N]; bias_mode 0 none / 1 per column /
+ * 2 per row; resid has C's layout and dtype.  bf16: K % 64 == 0; f32 (exact fp32 MFMA): K % 16 == 0. */
+int relnet_gemm_nt(const void* A, long lda, long strideA, const void* W, long ldw, long strideW, void* C,
+                   long ldc, long strideC, const float* bias, int bias_mode, const void* resid, int relu,
+                   int M, int N, int K, int batch, int in_dtype, int out_dtype, void* stream);
+void relnet_gemm_force_tile(int cfg);     /* tuning knob: 0 = auto, 1..5 = fixed tile configuration */
+
+/* ---- mx.symbol.Convolution + BatchNorm(use_global_stats) + Activation of
+ * relation_rcnn/symbols/resnet_v1_101_rcnn_base.py:29-693 as an NHWC implicit GEMM (BN folded by the
+ * caller); `resid` fuses the bottleneck's broadcast_add + ReLU.  in [B,H,W,>=Cin] bf16 with pixel /
+ * image strides in elements, w [Cout, R*S*Cin] (k = (r*S+s)*Cin + ic), out rows of ldc elements.    */
+int relnet_conv2d_nhwc(const void* in, long in_pix, long in_img, const void* w, const float* bias,
+                       const void* resid, int relu, void* out, long ldc, int B, int H, int W, int Cin, int Cout,
+                       int R, int S, int stride, int dil, int pad, int out_dtype, void* stream);
+
+/* ---- SYM_REL:46-83 extract_position_matrix + :29-44 extract_position_embedding + :109-116
+ * pair_pos_fc1 + ReLU + the log(max(.,1e-6)) of :139, fused (the [N,M,64] embedding is never stored).
+ * boxes [B,N,box_stride] with x1 at +box_off; wp_t [64, nmod*16] (embedding-index major), bp [nmod*16];
+ * divisors8: HOST array, wave_length^(k/8) in fp32; bias [nmod,B,16,N,Mpad] fp32.
+ * pos_mat [B,N,M,4] / pos_emb [B,N,M,64]: optional debug outputs (NULL to skip).                   */
+int relnet_geometry_bias(const float* boxes, int box_stride, int box_off, const float* wp_t, const float* bp,
+                         const float* divisors8, float* bias, float* pos_mat, float* pos_emb, int B, int N,
+                         int M, int Mpad, int fc_dim, int nmod, void* stream);
+
+/* ---- SYM_REL:132-150: logits = bias + scale * Q K^T (`weighted_aff`), softmax over keys, value sum
+ * and grouped linear_out (re-associated: vwt = (F_K Wout^T)^T, [B][H*64][Mpad], zero padded).
+ * q/k rows of 64-wide heads at column h*64; out / out_act [B][N][H*64]; out_act = relu(resid + out)
+ * (SYM_REL:267-268); logits [B][N][H][M] fp32 optional.  Any of out/out_act/logits may be NULL.     */
+int relnet_relation_attention(const void* q, long q_ld, long q_bs, const void* k, long k_ld, long k_bs,
+                              const void* vwt, long vwt_ld, long vwt_bs, const float* bias, long bias_bs,
+                              const float* bout, const void* resid, long resid_ld, long resid_bs, void* out,
+                              long out_ld, long out_bs, void* out_act, long act_ld, long act_bs, float* logits,
+                              int B, int H, int N, int M, int Mpad, float scale, int in_dtype, int out_dtype,
+                              void* stream);
+
+/* ---- relation_rcnn/core/tester.py:148-156 (im_detect) + :244-277 (per-class NMS, max_per_image) ----
+ * detect_head: SoftmaxActivation over classes + class-agnostic decode (bbox_transform.py:103-140,
+ * float64) + clip + 1/scale; boxes [R,4] float64.                                                   */
+int relnet_detect_head(const float* cls_score, long cs_ld, const float* bbox_pred, long bp_ld, const float* rois,
+                       const float* im_info, float* cls_prob, double* boxes, int R, int C, int rois_per_image,
+                       int delta_off, void* stream);
+/* lib/nms/nms.py:85-141 soft_nms (soft != 0, nms_param = sigma) or :45-82 nms (nms_param = IoU
+ * threshold), float64 like numpy; dets [B,C-1,N,5] in pick order, counts [B,C-1].                    */
+int relnet_class_nms(const float* cls_prob, const double* boxes, double* dets, int* counts, int B, int N, int C,
+                     float score_thresh, double nms_param, int soft, int max_picks, void* stream);
+/* tester.py:270-277: image threshold = max_per_image-th largest score; out [B,max_out,6] =
+ * (class, score, x1, y1, x2, y2), class-major in pick order.                                        */
+int relnet_image_topk(const double* dets, const int* counts, double* thresh, int* total, float* out,
+                      int* out_count, int B, int NC, int N, int max_per_image, int max_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RELNET_HIP_H */

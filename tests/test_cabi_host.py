@@ -1,0 +1,110 @@
+"""CPU-side checks (no GPU, no compute calls): the C-ABI library loads and exports exactly what
+include/relnet_hip.h declares; host-side logic of the operator mirror and the detector config."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    import __graft_entry__ as ge
+    ge.build()
+    import relnet_amd  # noqa: F401
+    from relnet_amd import lib
+    return lib
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, 'include', 'relnet_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    return sorted(set(re.findall(r'\b(relnet_\w+|_nms)\s*\(', hdr)))
+
+
+def test_header_and_library_agree(pkg):
+    declared = _declared()
+    assert '_nms' in declared and 'relnet_relation_attention' in declared
+    lib = ctypes.CDLL(pkg.LIB_PATH)
+    for sym in declared:
+        assert hasattr(lib, sym), "declared in include/relnet_hip.h but not exported: %s" % sym
+    assert sorted(pkg.exported_symbols()) == declared     # the Python binding covers all of it
+
+
+def test_version_and_error_channel(pkg):
+    lib = pkg.load()
+    assert lib.relnet_version() == 100
+    # argument validation happens before any HIP call -> usable without a GPU
+    rc = lib.relnet_gemm_nt(None, 0, 0, None, 0, 0, None, 0, 0, None, 0, None, 0, 1, 1, 64, 1, 1, 1, None)
+    assert rc != 0 and b'null operand' in lib.relnet_last_error()
+    rc = lib.relnet_nms_mask(None, None, None, 1, 64, 64, 0.7, None)
+    assert rc != 0 and b'relnet_nms_mask' in lib.relnet_last_error()
+
+
+def test_no_cpu_fallback():
+    import relnet_amd  # noqa: F401
+    from relnet_amd import ops, lib
+    with pytest.raises(lib.RelnetError):
+        ops.gemm_nt(torch.zeros(4, 64), torch.zeros(4, 64))           # CPU tensors are refused
+
+
+def test_product_does_not_import_oracle():
+    pkg_dir = os.path.join(ROOT, 'relation-networks-for-object-detection_amd')
+    for dp, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dp, f)).read()
+                assert 'import oracle' not in src and 'from oracle' not in src, f
+
+
+def test_proposal_prop_protocol():
+    import relnet_amd  # noqa: F401
+    from relnet_amd import operator_py
+    from relnet_amd.operator_py import proposal as P
+    prop = operator_py.get_prop('proposal')(feat_stride='16', scales='(4, 8, 16, 32)', ratios='(0.5, 1, 2)',
+                                            output_score='True', rpn_pre_nms_top_n='6000',
+                                            rpn_post_nms_top_n='300', threshold='0.7', rpn_min_size='0')
+    assert prop.list_arguments() == ['cls_prob', 'bbox_pred', 'im_info']
+    assert prop.list_outputs() == ['output', 'score']
+    ins, outs = prop.infer_shape([(1, 24, 38, 63), (1, 48, 38, 63), (1, 3)])
+    assert outs == [(300, 5), (300, 1)] and ins[2] == (1, 3)
+    assert prop.declare_backward_dependency([], [], []) == []
+    op = prop.create_operator(None, None, None)
+    assert op._num_anchors == 12
+    from oracle.boxes import generate_anchors
+    assert np.array_equal(P.generate_anchors(16, (0.5, 1, 2), (4, 8, 16, 32)),
+                          generate_anchors(16, (0.5, 1, 2), (4, 8, 16, 32)))
+    with pytest.raises(KeyError):
+        operator_py.get_prop('no_such_op')
+
+
+def test_backbone_graph_matches_reference_names():
+    import relnet_amd  # noqa: F401
+    from relnet_amd import backbone, detector
+    names = [c for c, _, _, _, _ in backbone.conv_bn_names()]
+    assert len(names) == 104 and names[0] == 'conv1' and 'res4b22_branch2c' in names and 'res3b3_branch2a' in names
+    units = backbone.unit_names()
+    assert [u[5] for u in units if u[7]] == [1, 2, 2, 1]           # strides of res2a/3a/4a/5a
+    assert all(u[6] == 2 for u in units if u[0] == 5)               # conv5 dilated
+    perm = detector.fc1_channels_last_perm(4, 2, 2)
+    # new column (s*C + c) takes reference column (c*S + s)
+    assert perm.tolist() == [0, 4, 8, 12, 1, 5, 9, 13, 2, 6, 10, 14, 3, 7, 11, 15]
+    w, b = backbone.fold_bn(torch.ones(2, 1, 1, 1), torch.tensor([2.0, 1.0]), torch.tensor([0.5, 0.0]),
+                            torch.tensor([1.0, 0.0]), torch.tensor([3.0, 0.0]))
+    assert torch.allclose(w.flatten(), torch.tensor([2 / (3 + 1e-5) ** 0.5, 1 / (1e-5) ** 0.5]), rtol=1e-6)
+    assert torch.allclose(b, torch.tensor([0.5 - 2 / (3 + 1e-5) ** 0.5, 0.0]), rtol=1e-6)
+
+
+def test_oracle_roi_pooling_micro_case():
+    from oracle.roi_pooling import roi_pooling
+    data = np.arange(2 * 6 * 8, dtype=np.float32).reshape(1, 2, 6, 8)
+    rois = np.array([[0, 0, 0, 127, 95], [0, 16, 16, 47, 47]], dtype=np.float32)      # /16 -> (0..8, 0..6), (1..3)
+    out, arg = roi_pooling(data, rois, pooled_size=(2, 2), spatial_scale=1 / 16., return_argmax=True)
+    # roi 0 spans x 0..8 -> clipped to the 8-wide map; bins are 4.5 x 3.5 -> floor/ceil windows
+    assert out[0, 0].tolist() == [[28.0, 31.0], [44.0, 47.0]]
+    assert out[1, 0].tolist() == [[18.0, 19.0], [26.0, 27.0]]
+    assert arg[1, 0].tolist() == [[18, 19], [26, 27]]

@@ -1,0 +1,54 @@
+"""N>1 path on CPU: two gloo ranks run the sharding / barrier / max-over-ranks protocol that
+bench.py uses on RCCL (images are independent units; there is no data-path collective)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import relnet_amd  # noqa: F401
+    from relnet_amd import dist as D
+    r, w, _ = D.init(backend='gloo')
+    lo, hi = D.shard_images(37, r, w)
+    D.fence()
+    elapsed = 0.5 + 0.25 * r                       # rank 1 is the slow one
+    thr = D.throughput(hi - lo, elapsed)
+    q.put((r, lo, hi, thr, D.max_over_ranks(elapsed)))
+    D.fence()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_protocol():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, thr0, mx0), (r1, lo1, hi1, thr1, mx1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 19, 19, 37)             # disjoint, covering, balanced
+    assert mx0 == mx1 == 0.75
+    assert abs(thr0 - 37 / 0.75) < 1e-9 and thr0 == thr1       # whole-job rate / slowest rank
+
+
+def test_shard_edges():
+    import relnet_amd  # noqa: F401
+    from relnet_amd.dist import shard_images
+    assert [shard_images(5, r, 8) for r in range(8)] == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 5), (5, 5), (5, 5)]
+    assert shard_images(16, 3, 4) == (12, 16)
