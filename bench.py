@@ -88,7 +88,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=16, help='images per GPU per step')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-relation', action='store_true', help='plain 2FC head (config 1 graph)')
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -88,16 +88,17 @@ int relnet_conv2d_nhwc(const void* in, long in_pix, long in_img, const void* w, 
  * divisors8: HOST array, wave_length^(k/8) in fp32; bias [nmod,B,16,N,Mpad] fp32.
  * pos_mat [B,N,M,4] / pos_emb [B,N,M,64]: optional debug outputs (NULL to skip).                   */
 int relnet_geometry_bias(const float* boxes, int box_stride, int box_off, const float* wp_t, const float* bp,
-                         const float* divisors8, float* bias, float* pos_mat, float* pos_emb, int B, int N,
-                         int M, int Mpad, int fc_dim, int nmod, void* stream);
+                         const float* divisors8, void* bias, int bias_half /*1: fp16 output*/, float* pos_mat,
+                         float* pos_emb, int B, int N, int M, int Mpad, int fc_dim, int nmod, void* stream);
 
 /* ---- SYM_REL:132-150: logits = bias + scale * Q K^T (`weighted_aff`), softmax over keys, value sum
  * and grouped linear_out (re-associated: vwt = (F_K Wout^T)^T, [B][H*64][Mpad], zero padded).
  * q/k rows of 64-wide heads at column h*64; out / out_act [B][N][H*64]; out_act = relu(resid + out)
- * (SYM_REL:267-268); logits [B][N][H][M] fp32 optional.  Any of out/out_act/logits may be NULL.     */
+ * (SYM_REL:267-268); logits [B][N][H][M] fp32 optional.  Any of out/out_act/logits may be NULL.
+ * bf16 + fp16 bias (bias_half = 1) selects the LDS-shared throughput kernel (no logits output).     */
 int relnet_relation_attention(const void* q, long q_ld, long q_bs, const void* k, long k_ld, long k_bs,
-                              const void* vwt, long vwt_ld, long vwt_bs, const float* bias, long bias_bs,
-                              const float* bout, const void* resid, long resid_ld, long resid_bs, void* out,
+                              const void* vwt, long vwt_ld, long vwt_bs, const void* bias, int bias_half,
+                              long bias_bs, const float* bout, const void* resid, long resid_ld, long resid_bs, void* out,
                               long out_ld, long out_bs, void* out_act, long act_ld, long act_bs, float* logits,
                               int B, int H, int N, int M, int Mpad, float scale, int in_dtype, int out_dtype,
                               void* stream);

@@ -14,6 +14,7 @@
 //                         with d_k = d_v = 64 (executed FLOPs 4.4x below the graph as
 //                         written; DESIGN.md reports both).
 #include "common.h"
+#include <hip/hip_fp16.h>
 
 namespace relnet {
 
@@ -26,7 +27,7 @@ struct GeomArgs {
   const float* wp;         // [64, NMOD*FC]  pair_pos_fc1 weights, embedding-index major
   const float* bp;         // [NMOD, FC]
   float divisors[8];       // wave_length^(k/8), fp32 (host computes them like the graph)
-  float* bias;             // [NMOD, B, FC, N, Mpad]   log(max(relu(E Wp^T + bp), 1e-6))
+  void* bias;              // [NMOD, B, FC, N, Mpad]   log(max(relu(E Wp^T + bp), 1e-6)), float or half
   float* pos_mat;          // optional [B, N, M, 4]
   float* pos_emb;          // optional [B, N, M, 64]
   int B, N, M, Mpad, nmod;
@@ -48,7 +49,7 @@ __device__ __forceinline__ void position_features(float4 bi, float4 bj, float (&
   p[3] = (float)log((double)(hi / hj));
 }
 
-template <int FC, int NMOD>
+template <int FC, int NMOD, typename TB>
 __global__ __launch_bounds__(256) void geometry_bias_kernel(GeomArgs g) {
   const long pair = (long)blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void geometry_bias_kernel(GeomArgs g) {
 #pragma unroll
     for (int h = 0; h < FC; ++h) {
       const float gw = fmaxf(fmaxf(acc[m * FC + h], 0.f), 1e-6f);
-      g.bias[((((long)m * g.B + b) * FC + h) * g.N + i) * g.Mpad + j] = logf(gw);
+      ((TB*)g.bias)[((((long)m * g.B + b) * FC + h) * g.N + i) * g.Mpad + j] = (TB)logf(gw);
     }
 }
 #pragma clang fp contract(fast)
@@ -113,7 +114,7 @@ struct AttnArgs {
   const void* q; long q_ld, q_bs;        // [B][N][.. h*64+d ..]
   const void* k; long k_ld, k_bs;        // [B][M][.. h*64+d ..]
   const void* vwt; long vwt_ld, vwt_bs;  // [B][H*64][Mpad]   (VW^T, keys contiguous)
-  const float* bias; long bias_bs;       // [B][H][N][Mpad] fp32
+  const void* bias; long bias_bs;        // [B][H][N][Mpad] fp32 (or fp16 for the LDS kernel)
   const float* bout;                     // [H*64] linear_out bias or nullptr
   const void* resid; long resid_ld, resid_bs;   // optional residual (same dtype as out)
   void* out; long out_ld, out_bs;        // Y = attention output (nullptr to skip)
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void relation_attention_kernel(AttnArgs a) {
   const T* Q = (const T*)a.q + (long)b * a.q_bs + (long)qc * a.q_ld + h * 64;
   const T* Kb = (const T*)a.k + (long)b * a.k_bs + h * 64;
   const T* Vb = (const T*)a.vwt + (long)b * a.vwt_bs + (long)(h * 64) * a.vwt_ld;
-  const float* Bq = a.bias + (long)b * a.bias_bs + ((long)h * a.N + qc) * a.Mpad;
+  const float* Bq = (const float*)a.bias + (long)b * a.bias_bs + ((long)h * a.N + qc) * a.Mpad;
 
   // Q fragments (B operand of S^T = K Q^T): 64 d-values per query.
   bf16x8 qf[4];
@@ -299,6 +300,178 @@ __global__ __launch_bounds__(256) void relation_attention_kernel(AttnArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// bf16 throughput kernel: one WORKGROUP = all query tiles of one (image, head) (up to 16
+// wavefronts, 32 queries each).  The head's K rows and VW^T columns are staged ONCE per key
+// chunk of 320 keys in LDS and shared by every wavefront (the v1 kernel above re-reads them
+// from L2 per wavefront and is latency bound: 3.7 % MFMA utilisation in profiles/r01).  The
+// geometry bias arrives as fp16; the epilogue transposes O^T through LDS so that the output,
+// residual and activation rows move as 16-byte coalesced accesses.
+// ---------------------------------------------------------------------------------------
+constexpr int kKC = 320;                    // keys per LDS chunk
+constexpr int kVLD = kKC + 4;               // VW^T row stride in LDS (bf16): conflict-free b64 reads
+constexpr int kOLD = 68;                    // epilogue row stride (fp32)
+
+__global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sK = smem;                              // [kKC][64] bf16, 16-B chunks XOR-swizzled
+  unsigned short* sV = (unsigned short*)(smem + kKC * 128);   // [64][kVLD] bf16
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qt = blockIdx.x * nwave + wave;
+  const bool wave_on = qt * 32 < a.N;
+  const int q = qt * 32 + l31;
+  const int qc = q < a.N ? q : a.N - 1;
+  typedef unsigned short T;
+  const T* Q = (const T*)a.q + (long)b * a.q_bs + (long)qc * a.q_ld + h * 64;
+  const T* Kb = (const T*)a.k + (long)b * a.k_bs + h * 64;
+  const T* Vb = (const T*)a.vwt + (long)b * a.vwt_bs + (long)(h * 64) * a.vwt_ld;
+  const __half* Bq = (const __half*)a.bias + (long)b * a.bias_bs + ((long)h * a.N + qc) * a.Mpad;
+
+  bf16x8 qf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(Q + 16 * kk + 8 * half);
+  f32x16 o[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int kc0 = 0; kc0 < a.M; kc0 += kKC) {
+    if (kc0 > 0) __syncthreads();
+    // ---- stage K rows [kc0, kc0+kKC) and VW^T columns of this head -----------------------
+    for (int c = tid; c < kKC * 8; c += nthr) {
+      const int row = c >> 3, ch = c & 7, key = kc0 + row;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (key < a.M) v = *(const uint4*)(Kb + (long)key * a.k_ld + ch * 8);
+      *(uint4*)(sK + row * 128 + ((ch ^ (row & 7)) << 4)) = v;
+    }
+    for (int c = tid; c < 64 * (kKC / 4); c += nthr) {
+      const int row = c / (kKC / 4), c4 = c - row * (kKC / 4), key = kc0 + 4 * c4;
+      uint2 v = make_uint2(0, 0);
+      if (key < a.Mpad) v = *(const uint2*)(Vb + (long)row * a.vwt_ld + key);     // pad columns are zero
+      *(uint2*)(sV + row * kVLD + 4 * c4) = v;
+    }
+    __syncthreads();
+    if (wave_on) {
+      const int ntile = (min(a.M - kc0, kKC) + 31) / 32;
+      for (int kt = 0; kt < ntile; ++kt) {
+        const int key0 = kc0 + kt * 32;
+        // bias for this lane's query: keys key0 + 8g + 4 half + (0..3)
+        uint2 braw[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) braw[gq] = *(const uint2*)(Bq + key0 + 8 * gq + 4 * half);
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        {
+          const int row = kt * 32 + l31;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 kf = *(const bf16x8*)(sK + row * 128 + (((2 * kk + half) ^ (row & 7)) << 4));
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
+          }
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int kbase = key0 + 8 * gq + 4 * half;
+          const __half2 b01 = *(const __half2*)&braw[gq].x, b23 = *(const __half2*)&braw[gq].y;
+          const float bb[4] = {__low2float(b01), __high2float(b01), __low2float(b23), __high2float(b23)};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * gq + e;
+            float v = bb[e] + a.scale * s[r];
+            v = (kbase + e < a.M) ? v : -INFINITY;
+            s[r] = v;
+            tmax = fmaxf(tmax, v);
+          }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __expf(s[r] - m_new);
+          s[r] = pv;
+          psum += pv;
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 pf;
+          unsigned int* pw = (unsigned int*)&pf;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) pw[t] = pack_bf16x2(s[8 * ks + 2 * t], s[8 * ks + 2 * t + 1]);
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const unsigned short* vr = sV + (32 * d + l31) * kVLD + kt * 32 + 16 * ks + 4 * half;
+            bf16x8 vf;
+            *(uint2*)&vf = *(const uint2*)vr;
+            *((uint2*)&vf + 1) = *(const uint2*)(vr + 8);
+            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // ---- epilogue: O^T -> LDS [q][dv] fp32 -> 16-byte coalesced rows ---------------------------
+  __syncthreads();
+  float* so = (float*)smem + wave * (32 * kOLD);
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (wave_on) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        *(float4*)(so + l31 * kOLD + 32 * d + 8 * gq + 4 * half) =
+            make_float4(o[d][4 * gq] * inv, o[d][4 * gq + 1] * inv, o[d][4 * gq + 2] * inv, o[d][4 * gq + 3] * inv);
+    // same wave reads back what it wrote: no workgroup barrier needed, only LDS completion
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    unsigned short* Y = a.out ? (unsigned short*)a.out + (long)b * a.out_bs + h * 64 : nullptr;
+    unsigned short* Z = a.out_act ? (unsigned short*)a.out_act + (long)b * a.act_bs + h * 64 : nullptr;
+    const unsigned short* R = a.resid ? (const unsigned short*)a.resid + (long)b * a.resid_bs + h * 64 : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = lane + 64 * i, qq = idx >> 3, c8 = (idx & 7) * 8;
+      const int qrow = qt * 32 + qq;
+      if (qrow >= a.N) continue;
+      const float4 x0 = *(const float4*)(so + qq * kOLD + c8), x1 = *(const float4*)(so + qq * kOLD + c8 + 4);
+      float y[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      if (a.bout) {
+        const float4 b0 = *(const float4*)(a.bout + h * 64 + c8), b1 = *(const float4*)(a.bout + h * 64 + c8 + 4);
+        y[0] += b0.x; y[1] += b0.y; y[2] += b0.z; y[3] += b0.w; y[4] += b1.x; y[5] += b1.y; y[6] += b1.z; y[7] += b1.w;
+      }
+      if (Y) *(uint4*)(Y + (long)qrow * a.out_ld + c8) =
+          make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7]));
+      if (Z) {
+        if (R) {
+          const uint4 rv = *(const uint4*)(R + (long)qrow * a.resid_ld + c8);
+          const unsigned int rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { y[2 * e] += bf2f(rw[e] & 0xffff); y[2 * e + 1] += bf2f(rw[e] >> 16); }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = fmaxf(y[e], 0.f);
+        *(uint4*)(Z + (long)qrow * a.act_ld + c8) =
+            make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7]));
+      }
+    }
+  }
+}
+
 }  // namespace relnet
 
 using namespace relnet;
@@ -306,7 +479,7 @@ enum { RELNET_F32 = 0, RELNET_BF16 = 1 };
 
 extern "C" int relnet_geometry_bias(const float* boxes, int box_stride, int box_off,
                                     const float* wp, const float* bp, const float* divisors8,
-                                    float* bias, float* pos_mat, float* pos_emb, int B, int N,
+                                    void* bias, int bias_half, float* pos_mat, float* pos_emb, int B, int N,
                                     int M, int Mpad, int fc_dim, int nmod, void* stream) {
   RELNET_REQUIRE(boxes && wp && bp && divisors8 && bias, "relnet_geometry_bias: null operand");
   RELNET_REQUIRE(fc_dim == 16, "relnet_geometry_bias: fc_dim %d unsupported (16 only)", fc_dim);
@@ -320,14 +493,19 @@ extern "C" int relnet_geometry_bias(const float* boxes, int box_stride, int box_
   g.B = B; g.N = N; g.M = M; g.Mpad = Mpad; g.nmod = nmod;
   dim3 grid((unsigned)(((long)N * M + 255) / 256), B);
   hipStream_t s = (hipStream_t)stream;
-  if (nmod == 1) geometry_bias_kernel<16, 1><<<grid, 256, 0, s>>>(g);
-  else geometry_bias_kernel<16, 2><<<grid, 256, 0, s>>>(g);
+  if (bias_half) {
+    if (nmod == 1) geometry_bias_kernel<16, 1, __half><<<grid, 256, 0, s>>>(g);
+    else geometry_bias_kernel<16, 2, __half><<<grid, 256, 0, s>>>(g);
+  } else {
+    if (nmod == 1) geometry_bias_kernel<16, 1, float><<<grid, 256, 0, s>>>(g);
+    else geometry_bias_kernel<16, 2, float><<<grid, 256, 0, s>>>(g);
+  }
   return check_launch("relnet_geometry_bias");
 }
 
 extern "C" int relnet_relation_attention(
     const void* q, long q_ld, long q_bs, const void* k, long k_ld, long k_bs, const void* vwt,
-    long vwt_ld, long vwt_bs, const float* bias, long bias_bs, const float* bout,
+    long vwt_ld, long vwt_bs, const void* bias, int bias_half, long bias_bs, const float* bout,
     const void* resid, long resid_ld, long resid_bs, void* out, long out_ld, long out_bs,
     void* out_act, long act_ld, long act_bs, float* logits, int B, int H, int N, int M, int Mpad,
     float scale, int in_dtype, int out_dtype, void* stream) {
@@ -345,10 +523,27 @@ extern "C" int relnet_relation_attention(
   a.scale = scale;
   dim3 grid((unsigned)(((N + 31) / 32 + 3) / 4), H, B);
   hipStream_t s = (hipStream_t)stream;
-  if (in_dtype == RELNET_BF16) {
+  if (in_dtype == RELNET_BF16 && bias_half) {
+    // LDS kernel: fp16 bias, no logits output; one workgroup per (image, head, <=16 query tiles)
+    RELNET_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && vwt_ld % 4 == 0 && Mpad % 4 == 0, "relnet_relation_attention(bf16): row strides must be 16-byte (q,k) / 8-byte (vwt) aligned");
+    RELNET_REQUIRE(!logits, "relnet_relation_attention: logits output needs the fp32-bias kernel (bias_half = 0)");
+    RELNET_REQUIRE(out_ld % 8 == 0 && act_ld % 8 == 0 && resid_ld % 8 == 0, "relnet_relation_attention(bf16): output rows must be 16-byte aligned");
+    const int qtiles = (N + 31) / 32;
+    const int nwave = qtiles < 16 ? qtiles : 16;
+    const size_t kv = (size_t)kKC * 128 + (size_t)64 * kVLD * 2, ep = (size_t)nwave * 32 * kOLD * 4;
+    const size_t lds = kv > ep ? kv : ep;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute((const void*)relation_attention_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    dim3 g2((unsigned)((qtiles + nwave - 1) / nwave), H, B);
+    relation_attention_lds_kernel<<<g2, nwave * 64, lds, s>>>(a);
+  } else if (in_dtype == RELNET_BF16) {
     RELNET_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && vwt_ld % 4 == 0, "relnet_relation_attention(bf16): row strides must be 16-byte (q,k) / 8-byte (vwt) aligned");
     relation_attention_kernel<unsigned short, unsigned short><<<grid, 256, 0, s>>>(a);
   } else if (in_dtype == RELNET_F32) {
+    RELNET_REQUIRE(!bias_half, "relnet_relation_attention(f32): fp32 bias required");
     RELNET_REQUIRE(q_ld % 4 == 0 && k_ld % 4 == 0 && vwt_ld % 4 == 0, "relnet_relation_attention(f32): row strides must be 16-byte aligned");
     relation_attention_kernel<float, float><<<grid, 256, 0, s>>>(a);
   } else {

@@ -26,9 +26,9 @@ _SIGNATURES = {
     'relnet_last_error': (C.c_char_p, []),
     'relnet_gemm_nt': (C.c_int, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _i, _vp, _i,
                                  _i, _i, _i, _i, _i, _i, _vp]),
-    'relnet_geometry_bias': (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
+    'relnet_geometry_bias': (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i,
                                        _i, _i, _vp]),
-    'relnet_relation_attention': (C.c_int, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _vp,
+    'relnet_relation_attention': (C.c_int, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _i, _l, _vp,
                                             _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp,
                                             _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     'relnet_proposal_decode': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -78,7 +78,7 @@ def embedding_divisors(feat_dim=64, wave_length=1000.0):
                      torch.tensor(8.0 / feat_dim, dtype=torch.float32) * k)
 
 
-def geometry_bias(boxes, wp_t, bp, M=None, divisors=None, debug=False):
+def geometry_bias(boxes, wp_t, bp, M=None, divisors=None, debug=False, half=False):
     """boxes [B,N,4|5] fp32 (xyxy, or batch_idx + xyxy); wp_t [64, nmod*16]; bp [nmod*16]
     -> bias [nmod, B, 16, N, Mpad] fp32 = log(max(relu(E Wp^T + bp), 1e-6)).
     debug=True also returns (position_matrix [B,N,M,4], position_embedding [B,N,M,64])."""
@@ -91,13 +91,13 @@ def geometry_bias(boxes, wp_t, bp, M=None, divisors=None, debug=False):
     nmod = wp_t.shape[1] // 16
     assert wp_t.shape == (64, nmod * 16) and wp_t.is_contiguous() and wp_t.dtype == torch.float32
     div = (divisors if divisors is not None else embedding_divisors()).to('cpu', torch.float32).contiguous()
-    bias = torch.empty((nmod, B, 16, N, Mpad), device=boxes.device, dtype=torch.float32)
+    bias = torch.empty((nmod, B, 16, N, Mpad), device=boxes.device, dtype=torch.float16 if half else torch.float32)
     pm = pe = None
     if debug:
         pm = torch.empty((B, N, M, 4), device=boxes.device, dtype=torch.float32)
         pe = torch.empty((B, N, M, 64), device=boxes.device, dtype=torch.float32)
     _lib.call('relnet_geometry_bias', boxes.data_ptr(), bs, off, wp_t.data_ptr(), bp.data_ptr(),
-              div.data_ptr(), bias.data_ptr(), _ptr(pm), _ptr(pe), B, N, M, Mpad, 16, nmod, _stream())
+              div.data_ptr(), bias.data_ptr(), int(half), _ptr(pm), _ptr(pe), B, N, M, Mpad, 16, nmod, _stream())
     if debug:
         return bias, pm, pe
     return bias
@@ -112,7 +112,7 @@ def relation_attention(q, k, vwt, bias, bout=None, resid=None, M=None, want_out=
     H = heads
     Mpad = vwt.shape[-1]
     M = k.shape[1] if M is None else M
-    assert bias.shape == (B, H, N, Mpad) and bias.is_contiguous() and bias.dtype == torch.float32
+    assert bias.shape == (B, H, N, Mpad) and bias.is_contiguous() and bias.dtype in (torch.float32, torch.float16)
     assert vwt.shape[1] == H * 64 and vwt.stride(-1) == 1 and q.stride(-1) == 1 and k.stride(-1) == 1
     dt = q.dtype
     out = torch.empty((B, N, H * 64), device=q.device, dtype=dt) if want_out else None
@@ -121,7 +121,7 @@ def relation_attention(q, k, vwt, bias, bout=None, resid=None, M=None, want_out=
     rs = (resid.stride(1), resid.stride(0)) if resid is not None else (0, 0)
     _lib.call('relnet_relation_attention',
               q.data_ptr(), q.stride(1), q.stride(0), k.data_ptr(), k.stride(1), k.stride(0),
-              vwt.data_ptr(), vwt.stride(1), vwt.stride(0), bias.data_ptr(), bias.stride(0),
+              vwt.data_ptr(), vwt.stride(1), vwt.stride(0), bias.data_ptr(), int(bias.dtype == torch.float16), bias.stride(0),
               _ptr(bout), _ptr(resid), rs[0], rs[1],
               _ptr(out), H * 64, N * H * 64, _ptr(act), H * 64, N * H * 64, _ptr(logits),
               B, H, N, M, Mpad, 1.0 / math.sqrt(64.0), _dt(q), _dt(q), _stream())

@@ -59,7 +59,8 @@ def attention_module_multi_head(roi_feat, rois, params, nongt_dim=None, fc_dim=1
     mod = packed or RelationParams(params, index, dtype, f.device)
     if bias is None:
         wp_t, bp = pack_pair_pos([mod], f.device)
-        bias = ops.geometry_bias(bx.to(torch.float32).contiguous(), wp_t, bp, M)[0]
+        bias = ops.geometry_bias(bx.to(torch.float32).contiguous(), wp_t, bp, M,
+                                 half=(dtype == torch.bfloat16 and not return_logits))[0]
     y, _, logits = _module_forward(f, mod, bias, M, want_out=True, want_act=False,
                                    want_logits=return_logits)
     if squeeze:
@@ -120,7 +121,7 @@ class RelationHead(object):
             cb = ops.gemm_nt(x2.reshape(B * N, -1), self.wcb, self.bcb, out_dtype=torch.float32).reshape(B, N, -1)
             return cb[:, :, :self.num_classes], cb[:, :, self.num_classes:], x2
         M = N if nongt_dim is None else nongt_dim
-        bias = ops.geometry_bias(rois, self.wp_t, self.bp, M)            # [2, B, 16, N, Mpad]
+        bias = ops.geometry_bias(rois, self.wp_t, self.bp, M, half=self.dtype == torch.bfloat16)   # [2,B,16,N,Mpad]
         vw = self._vwt_buf(B, bias.shape[-1])
         f1 = ops.gemm_nt(pooled.reshape(B * N, K), self.w1, self.b1).reshape(B, N, -1)
         y1, x1, _ = _module_forward(f1, self.mods[0], bias[0], M, return_intermediates, True, False, vw[0])

@@ -137,3 +137,23 @@ def test_relation_batched_equals_single(rn):
     for i in range(3):
         yi = relation.attention_module_multi_head(_dev(feats[i]), _dev(boxes_l[i]), pt, dtype=torch.float32)
         assert torch.equal(yb[i], yi)
+
+
+def test_attention_lds_kernel_matches_streaming_kernel(rn):
+    """bf16: the LDS-shared kernel (fp16 bias) vs the per-wave streaming kernel (fp32 bias)."""
+    ops, relation = rn
+    boxes, feat, p = cases.relation_case(300, 300, 44, 0.02)
+    pt = {k: torch.as_tensor(v) for k, v in p.items()}
+    mod = relation.RelationParams(pt, 1, torch.bfloat16, 'cuda')
+    wp_t, bp = relation.pack_pair_pos([mod], 'cuda')
+    f = torch.stack([_dev(feat), _dev(feat[::-1].copy())]).to(torch.bfloat16)
+    bx = torch.stack([_dev(boxes), _dev(boxes[::-1].copy())])
+    outs = []
+    for half in (False, True):
+        bias = ops.geometry_bias(bx, wp_t, bp, 300, half=half)[0]
+        y, act, _ = relation._module_forward(f, mod, bias, 300, True, True, False)
+        outs.append((y.float(), act.float()))
+    scale = outs[0][0].abs().max().item()
+    assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-2 * scale
+    assert (outs[0][1] - outs[1][1]).abs().max().item() <= 1e-2 * outs[0][1].abs().max().item()
+    assert torch.equal(outs[1][1], torch.relu(outs[1][1]))
