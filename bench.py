@@ -62,11 +62,13 @@ class KernelTimer(object):
         return out
 
 
-def cpu_baseline(params, relation=True, soft=True, images=2, seed=123):
+def cpu_baseline(params, relation=True, soft=True, images=4, seed=123, threads=32):
     """Oracle (oracle/network.py) on `images` synthetic 600x1000 images; returns the dict."""
     import numpy as np
     from oracle import network as ON
-    cores = os.cpu_count() or 1
+    # 32 threads: the torch-CPU convolutions stop scaling there on the GPU box's host (0.74 s
+    # backbone at 16-32 threads, 1.4 s at 64, ~100 s at all 256 hardware threads)
+    cores = max(1, min(os.cpu_count() or 1, threads))
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(seed)
     im_info = np.array([[600, 1000, 1.0]], np.float32)
@@ -80,7 +82,7 @@ def cpu_baseline(params, relation=True, soft=True, images=2, seed=123):
     per = sum(t_img) / len(t_img)
     return dict(value=1.0 / per, unit='images/s', cores=cores, kind='port',
                 sample='%d synthetic 600x1000 images through oracle/network.py:detect (torch-CPU fp32 convs on '
-                       '%d threads + numpy proposal/ROI/relation/soft-NMS), %.1f s/image' % (images, cores, per))
+                       '%d threads + numpy proposal/ROI/relation/soft-NMS), %.2f s/image' % (images, cores, per))
 
 
 def main():
@@ -92,7 +94,8 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-relation', action='store_true', help='plain 2FC head (config 1 graph)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-images', type=int, default=2)
+    ap.add_argument('--cpu-images', type=int, default=4)
+    ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of hipGraph replays')
     ap.add_argument('--shapes', action='store_true', help='print per-shape GEMM/conv times to stderr')
@@ -196,7 +199,7 @@ def main():
                     'algorithmic_gflop_per_launch': ALGO_GFLOP_PER_MODULE_IMAGE * a.batch,
                 }
         if world == 1 and not a.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(params, relation=not a.no_relation, images=a.cpu_images)
+            res['cpu_baseline'] = cpu_baseline(params, relation=not a.no_relation, images=a.cpu_images, threads=a.cpu_threads)
         print(json.dumps(res))
     if world > 1:
         torch.distributed.barrier()
