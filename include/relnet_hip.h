@@ -56,6 +56,13 @@ int relnet_nms_scan(const unsigned long long* mask, const float* boxes5, const i
                     float* roi_scores, int* keep, int* num_keep, int B, int n, int n_stride, int post,
                     int max_keep, int batch_index_base, void* stream);
 
+/* nms_kernel.cu:24-32,118-140 + proposal.py:151-153 fused: greedy NMS that keeps only the first
+ * `post` (<= 2048) boxes, testing each 64-box block against the kept list instead of building the
+ * n x n bitmask; identical keep list to relnet_nms_mask + relnet_nms_scan(post).                    */
+int relnet_nms_greedy(const float* boxes5, const int* counts, float* rois, float* roi_scores, int* keep,
+                      int* num_keep, int B, int n, int n_stride, int post, float thresh,
+                      int batch_index_base, void* stream);
+
 /* ---- mx.symbol.ROIPooling(pooled_size=(7,7), spatial_scale=1/16), SYM_REL:252-253 ---------------
  * data/out described by element strides (b|r, c, y, x) so NCHW and channels-last both work.       */
 int relnet_roi_pool_fwd(const void* data, const long* data_strides4, const float* rois /*[R,5]*/, void* out,

@@ -308,6 +308,117 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(ScanArgs g) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Greedy NMS with a bounded keep list, fused: instead of the full n x n suppression bitmask
+// (18 M IoUs + 4.5 MB of mask per image at n = 6000) each 64-candidate block is tested
+// against the <= max_keep boxes kept so far and against itself, and the scan stops as soon as
+// `post` boxes are kept -- the only rows proposal.py:151-153 uses.  Same IoU arithmetic and
+// the same greedy order as nms_mask_kernel + nms_scan_kernel, hence the same keep list.
+// ---------------------------------------------------------------------------------------
+constexpr int kMaxKeep = 2048;
+
+struct GreedyArgs {
+  const float* boxes;      // [B, n_stride, 5] sorted by score
+  const int* counts;       // [B] or nullptr
+  float* rois;             // [B, post, 5] or nullptr
+  float* roi_scores;       // [B, post] or nullptr
+  int* keep;               // [B, post] kept positions or nullptr
+  int* num_keep;           // [B]
+  int n, n_stride, post, batch_index_base;
+  float thresh;
+};
+
+constexpr int kGreedyWaves = 16;
+
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(64 * kGreedyWaves) void nms_greedy_kernel(GreedyArgs g) {
+  __shared__ float kb[kMaxKeep * 4];
+  __shared__ unsigned long long s_sup[kGreedyWaves];
+  __shared__ unsigned long long s_diag[64];
+  __shared__ int s_total;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  const int n = g.counts ? min(g.counts[b], g.n) : g.n;
+  const float* bx = g.boxes + (long)b * g.n_stride * 5;
+  if (tid == 0) s_total = 0;
+  __syncthreads();
+  const int nblk = (n + 63) / 64;
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int i = blk * 64 + lane;
+    const int bsize = min(n - blk * 64, 64);
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c[k] = bx[(long)i * 5 + k];
+    }
+    const int total = s_total;
+    if (tid < 64) s_diag[tid] = 0ull;
+    // ---- phase 1: candidates vs boxes already kept (the waves split the kept list) ---------
+    bool sup = false;
+    for (int k = wave; k < total; k += kGreedyWaves) sup = sup || (dev_iou(kb + 4 * k, c) > g.thresh);
+    const unsigned long long ball = __ballot(sup);
+    if (lane == 0) s_sup[wave] = ball;
+    __syncthreads();
+    // ---- phase 2: order inside the block: bits j > lane with IoU(lane, j) > thresh; each wave
+    // covers 4 of the 64 rotation offsets -----------------------------------------------------
+    unsigned long long part = 0ull;
+#pragma unroll
+    for (int jj = 0; jj < 64 / kGreedyWaves; ++jj) {
+      const int off = wave * (64 / kGreedyWaves) + jj;
+      const int src = (lane + off) & 63;
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = __shfl(c[k], src);
+      if (off != 0 && src > lane && src < bsize && dev_iou(c, o) > g.thresh) part |= 1ull << src;
+    }
+    if (part) atomicOr(&s_diag[lane], part);
+    __syncthreads();
+    if (wave == 0) {
+      unsigned long long alive = 0ull;
+#pragma unroll
+      for (int w = 0; w < kGreedyWaves; ++w) alive |= s_sup[w];
+      alive = ~alive;
+      if (bsize < 64) alive &= (1ull << bsize) - 1ull;
+      const unsigned long long diag = s_diag[lane];
+      unsigned long long cur = alive, km = 0ull;
+      int tot = total;
+      while (cur != 0ull && tot < g.post) {
+        const int t0 = __builtin_ctzll(cur);
+        km |= 1ull << t0;
+        ++tot;
+        const unsigned long long d0 = __shfl(diag, t0);
+        cur &= ~d0;
+        cur &= ~(1ull << t0);
+      }
+      if ((km >> lane) & 1ull) {
+        const int pos = total + __builtin_popcountll(km & ((1ull << lane) - 1ull));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) kb[4 * pos + k] = c[k];
+        if (g.keep) g.keep[(long)b * g.post + pos] = i;
+        if (g.rois) {
+          float* r = g.rois + ((long)b * g.post + pos) * 5;
+          r[0] = (float)(g.batch_index_base + b); r[1] = c[0]; r[2] = c[1]; r[3] = c[2]; r[4] = c[3];
+          if (g.roi_scores) g.roi_scores[(long)b * g.post + pos] = bx[(long)i * 5 + 4];
+        }
+      }
+      if (lane == 0) s_total = tot;
+    }
+    __syncthreads();
+    if (s_total >= g.post) break;
+  }
+  const int total = s_total;
+  if (tid == 0) g.num_keep[b] = total;
+  if (g.rois && total < g.post && total > 0) {         // deterministic padding (see nms_scan_kernel)
+    for (int pos = total + tid; pos < g.post; pos += 64 * kGreedyWaves) {
+      const float* src = g.rois + ((long)b * g.post + (pos % total)) * 5;
+      float* dst = g.rois + ((long)b * g.post + pos) * 5;
+      for (int k = 0; k < 5; ++k) dst[k] = src[k];
+      if (g.roi_scores) g.roi_scores[(long)b * g.post + pos] = g.roi_scores[(long)b * g.post + (pos % total)];
+    }
+  }
+}
+#pragma clang fp contract(fast)
+
 }  // namespace relnet
 
 using namespace relnet;
@@ -392,4 +503,17 @@ extern "C" void _nms(int* keep_out, int* num_out, const float* boxes_host, int b
   }
   if (e != hipSuccess) set_error("_nms: %s", hipGetErrorString(e));
   hipFree(d_boxes); hipFree(d_mask); hipFree(d_keep); hipFree(d_num);
+}
+
+// Fused greedy NMS keeping the first `post` (<= 2048) boxes: rois [B,post,5], roi_scores [B,post],
+// keep [B,post] positions into the sorted boxes, num_keep [B].  Same result as relnet_nms_mask +
+// relnet_nms_scan(post) without materialising the mask.
+extern "C" int relnet_nms_greedy(const float* boxes5, const int* counts, float* rois, float* roi_scores,
+                                 int* keep, int* num_keep, int B, int n, int n_stride, int post,
+                                 float thresh, int batch_index_base, void* stream) {
+  RELNET_REQUIRE(boxes5 && num_keep && B > 0 && n > 0 && n_stride >= n, "relnet_nms_greedy: bad arguments");
+  RELNET_REQUIRE(post > 0 && post <= kMaxKeep, "relnet_nms_greedy: need 0 < post <= %d (post=%d)", kMaxKeep, post);
+  GreedyArgs g{boxes5, counts, rois, roi_scores, keep, num_keep, n, n_stride, post, batch_index_base, thresh};
+  nms_greedy_kernel<<<B, 64 * kGreedyWaves, 0, (hipStream_t)stream>>>(g);
+  return check_launch("relnet_nms_greedy");
 }

@@ -51,6 +51,7 @@ __device__ __forceinline__ void position_features(float4 bi, float4 bj, float (&
 
 template <int FC, int NMOD, typename TB>
 __global__ __launch_bounds__(256) void geometry_bias_kernel(GeomArgs g) {
+  constexpr bool kFast = sizeof(TB) == 2;    // fp16 bias = bf16 throughput path: hardware sin/cos
   const long pair = (long)blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   if (pair >= (long)g.N * g.M) return;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void geometry_bias_kernel(GeomArgs g) {
   constexpr int NO = NMOD * FC;                  // outputs per pair
   float acc[NO];
 #pragma unroll
-  for (int o = 0; o < NO; ++o) acc[o] = g.bp[o];
+  for (int o = 0; o < NO; ++o) acc[o] = ((const float __attribute__((address_space(4))) *)(unsigned long long)g.bp)[o];
 
 #pragma unroll 1
   for (int c = 0; c < 4; ++c) {
@@ -77,7 +78,11 @@ __global__ __launch_bounds__(256) void geometry_bias_kernel(GeomArgs g) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float arg = x100 / g.divisors[k];
-      sincosf(arg, &e[k], &e[8 + k]);
+      if constexpr (kFast) {       // v_sin/v_cos (|arg| <= 700 rad is inside their range); abs err ~1e-5
+        e[k] = __sinf(arg); e[8 + k] = __cosf(arg);
+      } else {
+        sincosf(arg, &e[k], &e[8 + k]);
+      }
     }
     if (g.pos_emb) {
       float* pe = g.pos_emb + (((long)b * g.N + i) * g.M + j) * 64 + c * 16;
@@ -86,7 +91,11 @@ __global__ __launch_bounds__(256) void geometry_bias_kernel(GeomArgs g) {
     }
     // wp_t is [64][NO] (embedding index major): the NO weights of one embedding element
     // are contiguous and wave-uniform -> s_load_dwordx16 + v_fmac with an SGPR operand.
-    const float* w = g.wp + (long)(c * 16) * NO;
+    // constant address space => s_load_dwordx8/16 into SGPRs (a plain pointer gives per-lane
+    // global_load_dwordx4 of the same address: hipcc cannot prove the weights are not aliased
+    // by the bias stores)
+    typedef const float __attribute__((address_space(4))) * cfloat_p;
+    cfloat_p w = (cfloat_p)(unsigned long long)(g.wp + (long)(c * 16) * NO);
 #pragma unroll
     for (int k = 0; k < 16; ++k)
 #pragma unroll

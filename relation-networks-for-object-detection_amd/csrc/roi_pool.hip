@@ -56,6 +56,51 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(RoiArgs g) {
     if (g.argmax) g.argmax[o] = bi;
   }
 }
+// Channels-last bf16 fast path: thread = (bin, 8-channel group); 16-byte loads, the 8 running
+// maxima stay in registers.  Requires C % 8 == 0, ds_c == 1, os_c == 1 (bf16).
+__global__ __launch_bounds__(256) void roi_pool_fwd_cl_kernel(RoiArgs g) {
+  const int groups = g.C >> 3;                           // 8-channel groups per bin
+  const int bins_per_blk = 256 / groups;                 // groups divides 256 (checked on the host)
+  const int r = blockIdx.y;
+  const int bin = blockIdx.x * bins_per_blk + threadIdx.x / groups;
+  const int cg = threadIdx.x % groups;
+  if (bin >= g.PH * g.PW) return;
+  const int pw = bin % g.PW, ph = bin / g.PW;
+  const float* roi = g.rois + (long)r * 5;
+  const int b = (int)roi[0] - g.batch_index_base;
+  const int rs_w = (int)roundf(roi[1] * g.scale), rs_h = (int)roundf(roi[2] * g.scale);
+  const int re_w = (int)roundf(roi[3] * g.scale), re_h = (int)roundf(roi[4] * g.scale);
+  const int rw = max(re_w - rs_w + 1, 1), rh = max(re_h - rs_h + 1, 1);
+  const float bin_h = (float)rh / (float)g.PH, bin_w = (float)rw / (float)g.PW;
+  int hs = (int)floorf((float)ph * bin_h), he = (int)ceilf((float)(ph + 1) * bin_h);
+  int ws = (int)floorf((float)pw * bin_w), we = (int)ceilf((float)(pw + 1) * bin_w);
+  hs = min(max(hs + rs_h, 0), g.H); he = min(max(he + rs_h, 0), g.H);
+  ws = min(max(ws + rs_w, 0), g.W); we = min(max(we + rs_w, 0), g.W);
+  const bool empty = (he <= hs) || (we <= ws);
+  float best[8];
+  int bi[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { best[e] = empty ? 0.f : -FLT_MAX; bi[e] = -1; }
+  const unsigned short* base = (const unsigned short*)g.data + (long)b * g.ds_b + cg * 8;
+  for (int y = hs; y < he; ++y)
+    for (int x = ws; x < we; ++x) {
+      const uint4 v = *(const uint4*)(base + (long)y * g.ds_h + (long)x * g.ds_w);
+      const unsigned int w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = bf2f(w4[e] & 0xffff), hi = bf2f(w4[e] >> 16);
+        if (lo > best[2 * e]) { best[2 * e] = lo; bi[2 * e] = y * g.W + x; }
+        if (hi > best[2 * e + 1]) { best[2 * e + 1] = hi; bi[2 * e + 1] = y * g.W + x; }
+      }
+    }
+  const long o = (long)r * g.os_r + (long)ph * g.os_ph + (long)pw * g.os_pw + cg * 8;
+  *(uint4*)((unsigned short*)g.out + o) = make_uint4(pack_bf16x2(best[0], best[1]), pack_bf16x2(best[2], best[3]),
+                                                     pack_bf16x2(best[4], best[5]), pack_bf16x2(best[6], best[7]));
+  if (g.argmax) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g.argmax[o + e] = bi[e];
+  }
+}
 #pragma clang fp contract(fast)
 
 struct RoiBwdArgs {
@@ -94,6 +139,14 @@ extern "C" int relnet_roi_pool_fwd(const void* data, const long* data_strides4, 
   g.argmax = argmax; g.R = R; g.C = C; g.H = H; g.W = W; g.PH = PH; g.PW = PW; g.scale = spatial_scale;
   g.batch_index_base = batch_index_base;
   dim3 grid((unsigned)((long)R * PH * PW));
+  const int groups = C / 8;
+  if (dtype == RELNET_BF16 && C % 8 == 0 && groups <= 256 && 256 % groups == 0 && g.ds_c == 1 && g.os_c == 1 &&
+      g.ds_h % 8 == 0 && g.ds_w % 8 == 0 && g.ds_b % 8 == 0 && g.os_r % 8 == 0 && g.os_ph % 8 == 0 && g.os_pw % 8 == 0) {
+    const int bins_per_blk = 256 / groups;
+    dim3 g2((PH * PW + bins_per_blk - 1) / bins_per_blk, R);
+    roi_pool_fwd_cl_kernel<<<g2, 256, 0, (hipStream_t)stream>>>(g);
+    return check_launch("relnet_roi_pool_fwd");
+  }
   if (dtype == RELNET_F32) roi_pool_fwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(g);
   else if (dtype == RELNET_BF16) roi_pool_fwd_kernel<unsigned short><<<grid, 256, 0, (hipStream_t)stream>>>(g);
   else RELNET_REQUIRE(false, "relnet_roi_pool_fwd: unknown dtype %d", dtype);

@@ -51,7 +51,10 @@ def propose_batch(cls_prob, bbox_pred, im_info, anchors, feat_stride, pre_nms_to
     n = scores.shape[1]
     k = min(pre_nms_top_n, n) if pre_nms_top_n > 0 else n
     det, index, count = ops.topk_sort(scores, boxes, k)
-    r = ops.nms_sorted(det, threshold, post=post_nms_top_n, counts=count, want_keep=want_debug)
+    if 0 < post_nms_top_n <= 2048:      # fused greedy NMS: no n x n bitmask, stops at post_nms_top_n keeps
+        r = ops.nms_greedy(det, threshold, post_nms_top_n, counts=count, want_keep=want_debug)
+    else:
+        r = ops.nms_sorted(det, threshold, post=post_nms_top_n, counts=count, want_keep=want_debug)
     if want_debug:
         return r['rois'], r['scores'], dict(det=det, order=index, keep=r['keep'], num_keep=r['num_keep'])
     return r['rois'], r['scores']

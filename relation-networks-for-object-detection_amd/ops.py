@@ -192,6 +192,20 @@ def nms_sorted(det, thresh, post=0, counts=None, max_keep=None, want_keep=False,
     return dict(rois=rois, scores=rscores, keep=keep, num_keep=num)
 
 
+def nms_greedy(det, thresh, post, counts=None, want_keep=False, batch_index_base=0):
+    """Fused greedy NMS (no bitmask) keeping the first `post` boxes: same outputs as
+    nms_sorted(det, thresh, post=post)."""
+    _chk(det, counts)
+    B, n, _ = det.shape
+    rois = torch.zeros((B, post, 5), device=det.device, dtype=torch.float32)
+    rscores = torch.zeros((B, post), device=det.device, dtype=torch.float32)
+    keep = torch.full((B, post), -1, device=det.device, dtype=torch.int32) if want_keep else None
+    num = torch.empty((B,), device=det.device, dtype=torch.int32)
+    _lib.call('relnet_nms_greedy', det.data_ptr(), _ptr(counts), rois.data_ptr(), rscores.data_ptr(), _ptr(keep),
+              num.data_ptr(), B, n, n, post, float(thresh), batch_index_base, _stream())
+    return dict(rois=rois, scores=rscores, keep=keep, num_keep=num)
+
+
 def roi_pool(data, rois, pooled=(7, 7), spatial_scale=0.0625, channels_last_out=False,
              want_argmax=False, batch_index_base=0):
     """data: logical [B,C,H,W] tensor of any strides (NCHW or channels_last memory format);

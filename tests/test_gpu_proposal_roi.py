@@ -148,3 +148,19 @@ def test_roi_pooling_channels_last_bf16(rn):
     out = ops.roi_pool(cl, _dev(rois), channels_last_out=True)
     assert out.permute(0, 2, 3, 1).is_contiguous()
     assert np.array_equal(out.float().cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('n,seed,thresh,post', [(6000, 51, 0.7, 300), (1000, 52, 0.3, 100), (700, 53, 0.5, 2048)])
+def test_fused_greedy_nms_equals_mask_scan(rn, n, seed, thresh, post):
+    ops, _, _ = rn
+    dets = cases.dets_case(n, seed)
+    order = ON.argsort_desc(dets[:, 4])
+    det = _dev(np.stack([dets[order], dets[order][::-1][np.argsort(-dets[order][::-1][:, 4], kind='stable')]]))
+    a = ops.nms_sorted(det, thresh, post=post, want_keep=True)
+    b = ops.nms_greedy(det, thresh, post, want_keep=True)
+    assert torch.equal(a['num_keep'].clamp(max=post), b['num_keep'])
+    assert torch.equal(a['rois'], b['rois']) and torch.equal(a['scores'], b['scores'])
+    k = int(b['num_keep'][0])
+    assert torch.equal(a['keep'][:, :k], b['keep'][:, :k])
+    want = ON.nms_sorted_f32(dets[order][:, :4], thresh, max_keep=post)
+    assert np.array_equal(b['keep'][0, :len(want)].cpu().numpy(), want)
