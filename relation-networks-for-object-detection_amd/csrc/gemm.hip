@@ -207,6 +207,34 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // epilogue thread mapping (needed up front to prefetch the residual rows)
+  constexpr int VEC = 16 / sizeof(TOUT);               // output elements per 16-byte store
+  constexpr int TPR = BN / VEC;                        // threads per band row
+  constexpr int RPP = NT / TPR;                        // rows per copy pass
+  constexpr int NP = (BAND + RPP - 1) / RPP;           // copy passes per band
+  const int tcol = (tid % TPR) * VEC, trow = tid / TPR;
+  const int n = n0 + tcol;
+  const bool vec_ok = ((g.ldc % VEC) == 0) && ((((size_t)C) & 15) == 0) && (!R || (((size_t)R) & 15) == 0);
+  auto out_row = [&](int i, int p) {                   // global row of (band i, pass p) or -1
+    const int brow_i = p * RPP + trow;
+    if (brow_i >= BAND) return -1;
+    const int m = m0 + (brow_i >> 5) * (BM / WM) + i * 32 + (brow_i & 31);
+    return (m < g.M && n < g.N) ? m : -1;
+  };
+  // The residual tile is fetched NOW (16 B per thread per pass) so that its latency hides behind
+  // the main loop; fetched inside the epilogue it serialises one HBM round trip per copy pass,
+  // which made the residual-add 1x1 convolutions run at 1.8-2.5 TB/s.
+  uint4 rpre[TM][NP];
+  if (R && vec_ok) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int m = out_row(i, p);
+        rpre[i][p] = (m >= 0 && n + VEC <= g.N) ? *(const uint4*)(R + (long)m * g.ldc + n) : make_uint4(0, 0, 0, 0);
+      }
+  }
+
   const int nk = g.K / BK;
   stage(0, 0);
   __syncthreads();                                   // (drains the LDS-direct loads: vmcnt(0))
@@ -241,12 +269,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
   // ---- epilogue: per band of 32 rows per wave-row: accumulators -> LDS (fp32, padded rows) ->
   // coalesced 16-byte stores with bias / residual / ReLU applied on the way out -------------
   float* ct = (float*)lds;
-  constexpr int VEC = 16 / sizeof(TOUT);               // output elements per 16-byte store
-  constexpr int TPR = BN / VEC;                        // threads per band row
-  constexpr int RPP = NT / TPR;                        // rows per copy pass
-  const int tcol = (tid % TPR) * VEC, trow = tid / TPR;
-  const int n = n0 + tcol;
-  const bool vec_ok = ((g.ldc % VEC) == 0) && ((((size_t)C) & 15) == 0) && (!R || (((size_t)R) & 15) == 0);
   float bv[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) bv[e] = (g.bias_mode == 1 && n + e < g.N) ? g.bias[n + e] : 0.f;
@@ -264,11 +286,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
       }
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < (BAND + RPP - 1) / RPP; ++p) {
-      const int brow_i = p * RPP + trow;               // row inside the band
-      if (brow_i >= BAND) continue;
-      const int m = m0 + (brow_i >> 5) * (BM / WM) + i * 32 + (brow_i & 31);
-      if (m >= g.M || n >= g.N) continue;
+    for (int p = 0; p < NP; ++p) {
+      const int m = out_row(i, p);
+      if (m < 0) continue;
+      const int brow_i = p * RPP + trow;
       float v[VEC];
 #pragma unroll
       for (int q = 0; q < VEC / 4; ++q) {
@@ -279,12 +300,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
 #pragma unroll
       for (int e = 0; e < VEC; ++e) v[e] += bv[e] + brow;
       TOUT* cp = C + (long)m * g.ldc + n;
-      const TOUT* rp = R ? R + (long)m * g.ldc + n : nullptr;
       if (vec_ok && n + VEC <= g.N) {
         if constexpr (sizeof(TOUT) == 2) {
-          if (rp) {
-            const uint4 rv = *(const uint4*)rp;
-            const unsigned int rw[4] = {rv.x, rv.y, rv.z, rv.w};
+          if (R) {
+            const unsigned int rw[4] = {rpre[i][p].x, rpre[i][p].y, rpre[i][p].z, rpre[i][p].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f(rw[e] & 0xffff); v[2 * e + 1] += bf2f(rw[e] >> 16); }
           }
@@ -294,9 +313,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
           }
           *(uint4*)cp = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
         } else {
-          if (rp) {
-            const float4 rv = *(const float4*)rp;
-            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+          if (R) {
+            v[0] += __uint_as_float(rpre[i][p].x); v[1] += __uint_as_float(rpre[i][p].y);
+            v[2] += __uint_as_float(rpre[i][p].z); v[3] += __uint_as_float(rpre[i][p].w);
           }
           if (g.relu) {
 #pragma unroll
@@ -305,6 +324,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
           *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
         }
       } else {
+        const TOUT* rp = R ? R + (long)m * g.ldc + n : nullptr;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           if (n + e < g.N) {
@@ -425,9 +445,9 @@ static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t
     if (N <= 64) cfg = 4;
     else if (M * batch <= 8192) cfg = (N >= 256 ? 4 : 5);
     else if (N <= 128) cfg = 3;
-    else if (K <= 256) cfg = (N >= 1024 ? 4 : 1);
+    else if (K <= 128) cfg = 4;
     else if (N % 256 != 0) cfg = 3;
-    else cfg = (N == 512 && K < 4096) ? 3 : 1;
+    else cfg = 1;
   }
   switch (cfg) {
     case 1: launch_cfg<256, 256, 2, 4, CONV>(g, batch, out_dtype, s); break;
