@@ -89,6 +89,11 @@ int relnet_conv2d_nhwc(const void* in, long in_pix, long in_img, const void* w, 
                        const void* resid, int relu, void* out, long ldc, int B, int H, int W, int Cin, int Cout,
                        int R, int S, int stride, int dil, int pad, int out_dtype, void* stream);
 
+/* ---- bn_conv1 (folded) + conv1_relu + pool1 (3x3/2, pooling_convention='full'), resnet_v1_101_rcnn_base.py:
+ * 30-36, fused into one pass over the NHWC stem output: out = relu(maxpool_ceil(in) + bias).        */
+int relnet_stem_bias_relu_pool(const void* in, const float* bias, void* out, int B, int H, int W, int C,
+                               int ksize, int stride, void* stream);
+
 /* ---- SYM_REL:46-83 extract_position_matrix + :29-44 extract_position_embedding + :109-116
  * pair_pos_fc1 + ReLU + the log(max(.,1e-6)) of :139, fused (the [N,M,64] embedding is never stored).
  * boxes [B,N,box_stride] with x1 at +box_off; wp_t [64, nmod*16] (embedding-index major), bp [nmod*16];

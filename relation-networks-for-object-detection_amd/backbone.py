@@ -105,6 +105,7 @@ class Backbone(object):
         self.mf = torch.channels_last if channels_last else torch.contiguous_format
         self.w = {}
         self.wp = {}
+        self.b32 = {}
         for conv, bn, oc, ic, k in conv_bn_names():
             w, b = fold_bn(params[conv + '_weight'], params[bn + '_gamma'], params[bn + '_beta'],
                            params[bn + '_moving_mean'], params[bn + '_moving_var'])
@@ -119,6 +120,8 @@ class Backbone(object):
     def _put(self, name, w, b):
         self.w[name] = (w.to(self.device, self.dtype).contiguous(memory_format=self.mf),
                         b.to(self.device, self.dtype))
+        if self.impl == 'hip':
+            self.b32[name] = b.to(self.device, torch.float32).contiguous()
         if self.impl == 'hip' and w.shape[1] % 64 == 0:
             self.wp[name] = (ops.pack_conv_weight(w, self.dtype, self.device),
                              b.to(self.device, torch.float32).contiguous(), int(w.shape[2]))
@@ -130,9 +133,9 @@ class Backbone(object):
 
     def _forward_hip(self, data):
         x = data.to(self.dtype).contiguous(memory_format=self.mf)
-        x = self._conv(x, 'conv1', stride=2, pad=3, relu=True)
-        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=0, ceil_mode=True)
-        x = x.permute(0, 2, 3, 1)                       # NHWC view of the channels-last tensor
+        # 7x7 / Cin = 3 stem: library convolution (no bias), then ONE kernel for bias + ReLU + pool1
+        x = F.conv2d(x, self.w['conv1'][0], None, stride=2, padding=3)
+        x = ops.stem_bias_relu_pool(x.permute(0, 2, 3, 1), self.b32['conv1'])
         conv4 = None
         for stage, nm, ic, mc, oc, stride, dil, proj in self.units:
             if stage == 5 and conv4 is None:

@@ -305,3 +305,20 @@ def conv2d_nhwc(x, w_packed, bias, ksize=1, stride=1, pad=0, dil=1, relu=False, 
               stride, dil, pad, _dt(out), _stream(),
               tag='M%d_N%d_K%d_k%d' % (B * Hout * Wout, Cout, ksize * ksize * Cin, ksize))
     return out
+
+
+def stem_bias_relu_pool(x_nhwc, bias, ksize=3, stride=2):
+    """x [B,H,W,C] bf16 contiguous (conv output without bias) -> relu(maxpool_ceil(x) + bias) [B,Ho,Wo,C]."""
+    _chk(x_nhwc, bias)
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and bias.dtype == torch.float32
+    B, H, W, Cc = x_nhwc.shape
+    Ho = -(-(H - ksize) // stride) + 1
+    Wo = -(-(W - ksize) // stride) + 1
+    if (Ho - 1) * stride >= H:
+        Ho -= 1
+    if (Wo - 1) * stride >= W:
+        Wo -= 1
+    out = torch.empty((B, Ho, Wo, Cc), device=x_nhwc.device, dtype=torch.bfloat16)
+    _lib.call('relnet_stem_bias_relu_pool', x_nhwc.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, Cc,
+              ksize, stride, _stream())
+    return out
