@@ -93,6 +93,7 @@ def main():
     ap.add_argument('--batch', type=int, default=16, help='images per GPU per step')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-relation', action='store_true', help='plain 2FC head (config 1 graph)')
+    ap.add_argument('--learn-nms', action='store_true', help='learned duplicate removal instead of soft-NMS (config 3 graph, inference)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=4)
     ap.add_argument('--cpu-threads', type=int, default=32)
@@ -114,7 +115,9 @@ def main():
 
     tdt = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
     params = backbone.init_params(seed=1)
-    det = detector.Detector(params, dtype=tdt, device='cuda', relation=not a.no_relation)
+    cfg = detector.Config()
+    cfg.learn_nms = a.learn_nms
+    det = detector.Detector(params, dtype=tdt, device='cuda', relation=not a.no_relation, cfg=cfg)
     g = torch.Generator().manual_seed(1000 + rank)
     # unit-variance synthetic pixels: with random-init weights (no checkpoints offline) this gives
     # O(1) RPN logits/deltas, i.e. several hundred distinct proposals survive NMS per image; N(0,50)
@@ -161,7 +164,7 @@ def main():
             lib.timing_hook = None
     elapsed = D.max_over_ranks(elapsed, device='cuda')
     n_det = int(out['num_detections'].sum().item())
-    assert n_det > 0 and bool(torch.isfinite(out['cls_prob']).all())
+    assert n_det > 0 and bool(torch.isfinite(out['cls_score']).all())
 
     if rank == 0:
         images = world * a.batch * a.steps
@@ -170,7 +173,7 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype,
             'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: ResNet-101 Faster-RCNN + %s + soft-NMS(0.6) + top-100, '
+            'config': {'workload': 'BASELINE configs[1]: ResNet-101 Faster-RCNN + %s + ' + ('learn-NMS (first_n 100, 80 classes)' if a.learn_nms else 'soft-NMS(0.6)') + ' + top-100, '
                                    '600x1000 images, 300 proposals, random-init weights'
                                    % ('2 relation modules (N=300, 16 heads, d=1024)' if not a.no_relation else 'plain 2FC head'),
                        'images_per_gpu_per_step': a.batch, 'launch': 'eager' if a.no_graph else 'hipGraph replay', 'parallelism': 'replicas x%d (no data-path collective)' % world},

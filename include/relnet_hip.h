@@ -130,6 +130,29 @@ int relnet_class_nms(const float* cls_prob, const double* boxes, double* dets, i
 int relnet_image_topk(const double* dets, const int* counts, double* thresh, int* total, float* out,
                       int* out_count, int B, int NC, int N, int max_per_image, int max_out, void* stream);
 
+/* ---- relation_rcnn/operator_py/learn_nms.py:238-401 (LearnNmsOperator.forward), device stages ------
+ * prepare: softmax over classes (background dropped) + refine_bbox_nd (:175-217, float32) + clip.
+ * means4 / stds4: HOST arrays of 4 floats or NULL (the test graph passes None, :420-421).           */
+int relnet_lnms_prepare(const float* cls_score, long cs_ld, const float* bbox_pred, long bp_ld, const float* rois,
+                        const float* im_info, float* prob /*[B,N,C-1]*/, float* boxes /*[B,N,4]*/, int B, int N,
+                        int C, int delta_off, const float* means4, const float* stds4, void* stream);
+/* :289-308: per (image, class) descending sort, first_n ranks; rank_idx [B,NC,F], sorted_score [B,F,NC],
+ * sorted_bbox [B,F,NC,4], class_boxes [B,NC,F,4], class_max [B,NC].  Ties: smaller roi index first.  */
+int relnet_lnms_sort(const float* prob, const float* boxes, int* rank_idx, float* sorted_score, float* sorted_bbox,
+                     float* class_boxes, float* class_max, int B, int N, int NC, int first_n, void* stream);
+/* :335-344: x[b,c,r,:] = roi_feat_embedding[b, rank_idx[b,c,r], :] + rank_feat[r, :]                    */
+int relnet_lnms_embed(const void* roi_emb, const float* rank_feat, const int* rank_idx, void* x, int B, int N,
+                      int NC, int first_n, int D, int dtype, void* stream);
+/* :349-381 + symbols/..._learn_nms.py:553-560 + core/tester.py:231-242: relu(x + attention), logit FC,
+ * sigmoid, x sorted_score (0 for classes failing the valid-class rule :293-302), merge over the T
+ * thresholds (merge = -1 mean, -2 max, k >= 0 slice), compaction of score > score_thresh into
+ * dets [B,NC,F,5] float64 (boxes / im scale) + counts [B,NC] (NULL to skip).                          */
+int relnet_lnms_score(const void* x, const void* att, const float* w_logit, const float* b_logit,
+                      const float* sorted_score, const float* sorted_bbox, const float* class_max,
+                      const float* im_info, float* multi, float* final_score, double* dets, int* counts, int B,
+                      int NC, int first_n, int D, int T, int H, int dv, int att_hstride, int merge,
+                      float class_thresh, float score_thresh, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

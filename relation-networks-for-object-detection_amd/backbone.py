@@ -80,6 +80,14 @@ def init_params(seed=1, num_anchors=12, num_classes=81, num_reg_classes=2, gener
         p['query_%d_weight' % i] = nrm(0.01, 1024, 1024); p['query_%d_bias' % i] = torch.zeros(1024)
         p['key_%d_weight' % i] = nrm(0.01, 1024, 1024); p['key_%d_bias' % i] = torch.zeros(1024)
         p['linear_out_%d_weight' % i] = nrm(0.01, 1024, 1024, 1, 1); p['linear_out_%d_bias' % i] = torch.zeros(1024)
+    # learn-NMS head, init_weight_nms (symbols/..._learn_nms.py:571-600): N(0,0.01) / 0, logit bias -3
+    p['nms_rank_weight'] = nrm(0.01, 128, 1024); p['nms_rank_bias'] = torch.zeros(128)
+    p['roi_feat_embedding_weight'] = nrm(0.01, 128, 1024); p['roi_feat_embedding_bias'] = torch.zeros(128)
+    p['nms_pair_pos_fc1_1_weight'] = nrm(0.01, 16, 64); p['nms_pair_pos_fc1_1_bias'] = torch.zeros(16)
+    p['nms_query_1_weight'] = nrm(0.01, 1024, 128); p['nms_query_1_bias'] = torch.zeros(1024)
+    p['nms_key_1_weight'] = nrm(0.01, 1024, 128); p['nms_key_1_bias'] = torch.zeros(1024)
+    p['nms_linear_out_1_weight'] = nrm(0.01, 128, 128, 1, 1); p['nms_linear_out_1_bias'] = torch.zeros(128)
+    p['nms_logit_weight'] = nrm(0.01, 5, 128); p['nms_logit_bias'] = torch.full((5,), -3.0)
     return p
 
 

@@ -12,6 +12,7 @@ import torch
 from . import ops
 from .backbone import Backbone
 from .relation import RelationHead
+from .learn_nms import LearnNMS
 from .operator_py.proposal import generate_anchors, propose_batch
 
 
@@ -28,6 +29,11 @@ class Config(object):
     softnms = True            # TEST.SOFTNMS
     score_thresh = 1e-3       # tester.py:175
     max_per_image = 100
+    learn_nms = False         # TEST.LEARN_NMS: learned duplicate removal instead of (soft-)NMS
+    first_n = 100             # TEST.FIRST_N
+    learn_nms_class_thresh = 0.01   # TEST.LEARN_NMS_CLASS_SCORE_TH
+    nms_target_thresh = (0.5, 0.6, 0.7, 0.8, 0.9)   # network.NMS_TARGET_THRESH
+    merge_method = -1         # TEST.MERGE_METHOD (mean over thresholds)
 
 
 def fc1_channels_last_perm(c=256, ph=7, pw=7):
@@ -46,6 +52,11 @@ class Detector(object):
         self.backbone = Backbone(params, dtype, device)
         self.head = RelationHead(params, dtype, device, fc1_perm=fc1_channels_last_perm(),
                                  use_relation=relation)
+        self.lnms = None
+        if self.cfg.learn_nms:
+            self.lnms = LearnNMS(params, self.cfg.num_classes - 1, self.cfg.first_n, len(self.cfg.nms_target_thresh),
+                                 self.cfg.learn_nms_class_thresh, None, None, self.cfg.merge_method,
+                                 self.cfg.score_thresh, self.cfg.max_per_image, dtype=dtype, device=device)
         self.anchors = torch.as_tensor(generate_anchors(self.cfg.feat_stride, self.cfg.anchor_ratios,
                                                         self.cfg.anchor_scales), dtype=torch.float64, device=device)
 
@@ -63,6 +74,9 @@ class Detector(object):
         pooled = pooled.permute(0, 2, 3, 1).reshape(B, N, -1)              # (ph, pw, c) order, no copy
         cls_score, bbox_pred, feat = self.head.forward(pooled, rois)
         out = dict(rois=rois, cls_score=cls_score, bbox_pred=bbox_pred, fc_all_2_relu=feat)
+        if self.lnms is not None and post:                 # symbols/..._learn_nms.py:518-565 + tester.py:231-242
+            out.update(self.lnms.forward(cls_score.contiguous(), bbox_pred.contiguous(), rois, im_info, feat))
+            return out
         prob, boxes = ops.detect_head(cls_score.reshape(B * N, -1), bbox_pred.reshape(B * N, -1),
                                       rois.view(B * N, 5), im_info, N)
         out['cls_prob'], out['pred_boxes'] = prob.view(B, N, -1), boxes.view(B, N, 4)

@@ -45,6 +45,11 @@ _SIGNATURES = {
     'relnet_gemm_force_tile': (None, [_i]),
     'relnet_nms_greedy': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     'relnet_stem_bias_relu_pool': (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'relnet_lnms_prepare': (C.c_int, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'relnet_lnms_sort': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'relnet_lnms_embed': (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'relnet_lnms_score': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp]),
 }
 
 

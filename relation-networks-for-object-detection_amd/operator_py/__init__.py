@@ -89,4 +89,5 @@ def Custom(*args, **kwargs):
     return out_data[0] if len(out_data) == 1 else out_data
 
 
-from . import proposal  # noqa: E402,F401  (registers 'proposal')
+from . import proposal  # noqa: E402,F401  (registers "proposal")
+from . import learn_nms  # noqa: E402,F401  (registers "learn_nms")

@@ -1,0 +1,74 @@
+"""GPU parity of the learn-NMS head (A8) against the golden vectors produced by the reference's own
+operator_py/learn_nms.py and against the oracle at the full configuration."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import learn_nms as OL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def rn():
+    import relnet_amd  # noqa: F401
+    from relnet_amd import learn_nms, operator_py, lib
+    lib.load()
+    return learn_nms, operator_py
+
+
+def _d(x):
+    return torch.as_tensor(np.ascontiguousarray(x)).cuda()
+
+
+def test_learn_nms_matches_reference_operator(rn, golden):
+    learn_nms, operator_py = rn
+    g = golden['learn_nms']
+    for name, (n, c, first_n, seed) in cases.LEARN_NMS_CASES.items():
+        cls_score, bbox_pred, rois, im_info, feat, p = cases.learn_nms_case(n, c, seed)
+        # through the mirrored CustomOp protocol, exactly the reference's call (symbols/..._learn_nms.py:518-534)
+        kw = dict(cls_score=_d(cls_score), bbox_pred=_d(bbox_pred), rois=_d(rois), im_info=_d(im_info), fc_all_2_relu=_d(feat))
+        kw.update({k: _d(p[k]) for k in cases.LEARN_NMS_ARG_ORDER})
+        multi, sbox, sscore = operator_py.Custom(op_type='learn_nms', name='nms_multi_score', num_fg_classes=c,
+                                                 bbox_means='None', bbox_stds='None', first_n=first_n,
+                                                 class_agnostic=True, num_thresh=5, class_thresh=0.01,
+                                                 nongt_dim=n, has_non_gt_index=False, **kw)
+        np.testing.assert_array_equal(sscore.cpu().numpy().shape, (first_n, c))
+        np.testing.assert_allclose(sscore.cpu().numpy(), g[name + '/sorted_score'], rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(sbox.cpu().numpy(), g[name + '/sorted_bbox'], rtol=0, atol=1e-4)
+        want = g[name + '/nms_multi_score']
+        np.testing.assert_allclose(multi.cpu().numpy(), want, rtol=1e-3, atol=1e-5 * np.abs(want).max())
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-3), (torch.bfloat16, 4e-2)])
+def test_learn_nms_full_config_vs_oracle(rn, dtype, tol):
+    learn_nms, _ = rn
+    n, c, first_n = 300, 80, 100
+    cls_score, bbox_pred, rois, im_info, feat, p = cases.learn_nms_case(n, c, 77)
+    # make a third of the classes fail the valid-class rule (max prob < 0.01)
+    cls_score[:, 1 + np.arange(0, c, 3)] -= 12.0
+    want_multi, want_box, want_score, dbg = OL.learn_nms(cls_score, bbox_pred, rois, im_info, feat, p, c, first_n,
+                                                         nongt_dim=n, return_intermediates=True)
+    assert 0 < len(dbg['valid']) < c
+    m = learn_nms.LearnNMS({k: torch.as_tensor(v) for k, v in p.items()}, c, first_n, dtype=dtype)
+    B = 2
+    r = m.forward(_d(np.stack([cls_score] * B)), _d(np.stack([bbox_pred] * B)), _d(np.stack([rois] * B)),
+                  _d(np.concatenate([im_info] * B)), _d(np.stack([feat] * B)).to(dtype))
+    for b in range(B):
+        np.testing.assert_allclose(r['sorted_score'][b].cpu().numpy(), want_score, rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(r['sorted_bbox'][b].cpu().numpy(), want_box, rtol=0, atol=1e-4)
+        got = r['nms_multi_score'][b].cpu().numpy()
+        assert np.abs(got - want_multi).max() <= tol * np.abs(want_multi).max()
+        invalid = np.setdiff1d(np.arange(c), dbg['valid'])
+        assert (got[:, invalid, :] == 0).all()
+        fin = OL.merge_thresholds(want_multi)
+        assert np.abs(r['nms_final_score'][b].cpu().numpy() - fin).max() <= tol * np.abs(fin).max()
+    # detections: score > 1e-3, top-100 (tester.py:231-242, 270-277) on the GPU's own final scores
+    fin_gpu = r['nms_final_score'][0].cpu().numpy()
+    nd = int(r['num_detections'][0])
+    flat = np.sort(fin_gpu[fin_gpu > 1e-3])[::-1]
+    k = min(100, len(flat))
+    assert nd >= k
+    got_scores = np.sort(r['detections'][0, :nd, 1].cpu().numpy())[::-1]
+    np.testing.assert_allclose(got_scores[:k], flat[:k].astype(np.float32), rtol=1e-6)

@@ -182,3 +182,20 @@ def test_backbone_hip_matches_library_path(rn):
         assert a[k].shape == b[k].shape, k
         err = (a[k].float() - b[k]).abs().max().item() / b[k].abs().max().item()
         assert err < 6e-2, (k, err)          # ~100 bf16 layers deep
+
+
+def test_detector_learn_nms_runs(rn):
+    """config-3 inference graph: relation head + learn-NMS head, bf16, batch of 2."""
+    ops, backbone, detector = rn
+    H, W = 192, 256
+    p = backbone.init_params(seed=4)
+    g = torch.Generator().manual_seed(6)
+    data = torch.randn(2, 3, H, W, generator=g)
+    im_info = torch.tensor([[H, W, 1.0], [H, W, 1.0]])
+    cfg = detector.Config(); cfg.rpn_post_nms_top_n = 128; cfg.learn_nms = True; cfg.first_n = 50
+    out = detector.Detector(p, dtype=torch.bfloat16, im_hw=(H, W), cfg=cfg).forward(data.cuda(), im_info.cuda())
+    assert out['nms_final_score'].shape == (2, 50, 80) and out['sorted_bbox'].shape == (2, 50, 80, 4)
+    assert torch.isfinite(out['nms_multi_score']).all() and (out['nms_multi_score'] >= 0).all()
+    assert (out['num_detections'] > 0).all()
+    s = out['sorted_score']
+    assert (s[:, :-1] >= s[:, 1:]).all()                  # ranks are in descending score order
