@@ -164,7 +164,8 @@ def main():
             lib.timing_hook = None
     elapsed = D.max_over_ranks(elapsed, device='cuda')
     n_det = int(out['num_detections'].sum().item())
-    assert n_det > 0 and bool(torch.isfinite(out['cls_score']).all())
+    # (random-init learn-NMS logits start at sigmoid(-3) x ~1/81 < 1e-3: zero detections is expected there)
+    assert (n_det > 0 or a.learn_nms) and bool(torch.isfinite(out['cls_score']).all())
 
     if rank == 0:
         images = world * a.batch * a.steps
@@ -173,9 +174,10 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype,
             'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: ResNet-101 Faster-RCNN + %s + ' + ('learn-NMS (first_n 100, 80 classes)' if a.learn_nms else 'soft-NMS(0.6)') + ' + top-100, '
-                                   '600x1000 images, 300 proposals, random-init weights'
-                                   % ('2 relation modules (N=300, 16 heads, d=1024)' if not a.no_relation else 'plain 2FC head'),
+            'config': {'workload': 'BASELINE configs[1]: ResNet-101 Faster-RCNN + %s + %s + top-100, 600x1000 images, '
+                                   '300 proposals, random-init weights'
+                                   % ('2 relation modules (N=300, 16 heads, d=1024)' if not a.no_relation else 'plain 2FC head',
+                                      'learn-NMS (first_n 100, 80 classes)' if a.learn_nms else 'soft-NMS(0.6)'),
                        'images_per_gpu_per_step': a.batch, 'launch': 'eager' if a.no_graph else 'hipGraph replay', 'parallelism': 'replicas x%d (no data-path collective)' % world},
         }
         if timer is not None:
