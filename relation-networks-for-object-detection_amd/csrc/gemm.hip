@@ -27,6 +27,7 @@ struct GemmArgs {
   // GEMM is output pixel (b, oy, ox), k = (r*S + s)*Cin + ic; W is [Cout][R][S][Cin].
   int cH, cW, cCin, cHout, cWout, cR, cS, cStride, cDil, cPad;
   long cPix, cImg;         // element strides between pixels / images of the input
+  int n_loop;              // column tiles walked by one workgroup (row-panel mode), >= 1
 };
 
 template <typename TOUT> __device__ __forceinline__ void store_out(TOUT* p, float v);
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM;
   const unsigned short* A = (const unsigned short*)g.A + (long)blockIdx.z * g.strideA;
   const unsigned short* W = (const unsigned short*)g.W + (long)blockIdx.z * g.strideW;
   TOUT* C = (TOUT*)g.C + (long)blockIdx.z * g.strideC;
@@ -165,6 +166,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
       arow[j] = (gr < g.M) ? A + (long)gr * g.lda + lchunk * 8 : nullptr;
     }
   }
+  // Row-panel mode (n_loop > 1): this workgroup walks n_loop consecutive column tiles of its row
+  // tile, so its output rows are written as long contiguous runs and the A rows are re-read
+  // from its own XCD's L2 instead of by workgroups scattered over the chip.
+  for (int nt = 0; nt < g.n_loop; ++nt) {
+  const int n0 = (blockIdx.x * g.n_loop + nt) * BN;
+  if (n0 >= g.N) break;
+  if (nt > 0) __syncthreads();                         // previous tile's epilogue band fully read
 #pragma unroll
   for (int j = 0; j < B_GROUPS; ++j) {
     const int gr = n0 + (wave * B_GROUPS + j) * 8 + lrow;
@@ -337,6 +345,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
       }
     }
   }
+  }   // nt (row-panel loop)
 }
 
 // ---------------------------------------------------------------------------------------
@@ -422,11 +431,18 @@ using namespace relnet;
 enum { RELNET_F32 = 0, RELNET_BF16 = 1 };
 
 static int g_force_tile = 0;     // tuning knob: 0 auto, else index into the config list below
+static int g_force_nloop = 0;    // tuning knob: 0 auto, else column tiles per workgroup
 extern "C" void relnet_gemm_force_tile(int t) { g_force_tile = t; }
+extern "C" void relnet_gemm_force_nloop(int n) { g_force_nloop = n; }
 
 template <int BM, int BN, int WM, int WN, bool CONV>
-static void launch_cfg(const GemmArgs& g, int batch, int out_dtype, hipStream_t s) {
-  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
+static void launch_cfg(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
+  const int ntile = (g.N + BN - 1) / BN;
+  int nloop = g_force_nloop > 0 ? g_force_nloop : g.n_loop;
+  if (nloop < 1) nloop = 1;
+  if (nloop > ntile) nloop = ntile;
+  g.n_loop = nloop;
+  dim3 grid((ntile + nloop - 1) / nloop, (g.M + BM - 1) / BM, batch);
   if (out_dtype == RELNET_BF16) gemm_nt_bf16_kernel<BM, BN, WM, WN, unsigned short, CONV><<<grid, 64 * WM * WN, 0, s>>>(g);
   else gemm_nt_bf16_kernel<BM, BN, WM, WN, float, CONV><<<grid, 64 * WM * WN, 0, s>>>(g);
 }
