@@ -90,6 +90,14 @@ int relnet_conv2d_nhwc(const void* in, long in_pix, long in_img, const void* w, 
                        const void* resid, int relu, void* out, long ldc, int B, int H, int W, int Cin, int Cout,
                        int R, int S, int stride, int dil, int pad, int out_dtype, void* stream);
 
+/* ---- conv1 7x7/2 pad 3, Cin = 3 (resnet_v1_101_rcnn_base.py:30-31) on the MFMA kernel: pack the
+ * [B,3,H,W] image (fp32 or bf16) into zero-padded NHWC4 bf16 [B,Hp,Wp,4], then the implicit GEMM with
+ * w256 [Cout][256], k = ty*32 + tx*4 + c (ops.pack_stem_weight), bias + ReLU fused.                  */
+int relnet_stem_pack_input(const void* in, void* out, int B, int H, int W, int Hp, int Wp, int pad, int in_dtype,
+                           void* stream);
+int relnet_stem_conv7(const void* packed, const void* w256, const float* bias, int relu, void* out, long ldc,
+                      int B, int Hp, int Wp, int Hout, int Wout, int Cout, int out_dtype, void* stream);
+
 /* ---- bn_conv1 (folded) + conv1_relu + pool1 (3x3/2, pooling_convention='full'), resnet_v1_101_rcnn_base.py:
  * 30-36, fused into one pass over the NHWC stem output: out = relu(maxpool_ceil(in) + bias).        */
 int relnet_stem_bias_relu_pool(const void* in, const float* bias, void* out, int B, int H, int W, int C,

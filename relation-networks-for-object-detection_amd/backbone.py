@@ -106,9 +106,10 @@ class Backbone(object):
     bias / add / clamp passes as in the convolutions themselves).  impl='miopen' keeps every conv
     in torch.nn.functional.conv2d (used for the float32 parity path)."""
 
-    def __init__(self, params, dtype=torch.bfloat16, device='cuda', channels_last=True, impl=None):
+    def __init__(self, params, dtype=torch.bfloat16, device='cuda', channels_last=True, impl=None, stem='hip'):
         self.dtype, self.device = dtype, device
         self.impl = impl or ('hip' if dtype == torch.bfloat16 else 'miopen')
+        self.stem = stem
         assert self.impl in ('hip', 'miopen') and (self.impl == 'miopen' or dtype == torch.bfloat16)
         self.mf = torch.channels_last if channels_last else torch.contiguous_format
         self.w = {}
@@ -124,6 +125,11 @@ class Backbone(object):
         self._put('rpn_out', torch.cat([params['rpn_cls_score_weight'], params['rpn_bbox_pred_weight']], 0),
                   torch.cat([params['rpn_cls_score_bias'], params['rpn_bbox_pred_bias']], 0))
         self.units = unit_names()
+        if self.impl == 'hip':
+            w1, b1 = fold_bn(params['conv1_weight'], params['bn_conv1_gamma'], params['bn_conv1_beta'],
+                             params['bn_conv1_moving_mean'], params['bn_conv1_moving_var'])
+            self.w_stem = ops.pack_stem_weight(w1, self.dtype, self.device)
+            self.zero_bias64 = torch.zeros(64, device=self.device, dtype=torch.float32)
 
     def _put(self, name, w, b):
         self.w[name] = (w.to(self.device, self.dtype).contiguous(memory_format=self.mf),
@@ -140,10 +146,15 @@ class Backbone(object):
                                out_dtype=out_dtype)
 
     def _forward_hip(self, data):
-        x = data.to(self.dtype).contiguous(memory_format=self.mf)
-        # 7x7 / Cin = 3 stem: library convolution (no bias), then ONE kernel for bias + ReLU + pool1
-        x = F.conv2d(x, self.w['conv1'][0], None, stride=2, padding=3)
-        x = ops.stem_bias_relu_pool(x.permute(0, 2, 3, 1), self.b32['conv1'])
+        if self.stem == 'hip':
+            # repack to padded NHWC4, 7x7/2 conv + bias + ReLU on the MFMA kernel, then pool1
+            x = ops.stem_conv7(data, self.w_stem, self.b32['conv1'], relu=True)
+            x = ops.stem_bias_relu_pool(x, self.zero_bias64)
+        else:
+            # library 7x7 convolution (no bias), then ONE kernel for bias + ReLU + pool1
+            x = data.to(self.dtype).contiguous(memory_format=self.mf)
+            x = F.conv2d(x, self.w['conv1'][0], None, stride=2, padding=3)
+            x = ops.stem_bias_relu_pool(x.permute(0, 2, 3, 1), self.b32['conv1'])
         conv4 = None
         for stage, nm, ic, mc, oc, stride, dil, proj in self.units:
             if stage == 5 and conv4 is None:

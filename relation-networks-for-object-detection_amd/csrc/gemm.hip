@@ -122,8 +122,10 @@ typedef __attribute__((address_space(3))) void* las_ptr;
 
 // BM x BN workgroup tile, WM x WN waves (each wave: TM x TN MFMA tiles of 32x32), BK = 64,
 // two LDS stages filled by global_load_lds.
-template <int BM, int BN, int WM, int WN, typename TOUT, bool CONV>
+template <int BM, int BN, int WM, int WN, typename TOUT, int MODE>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) {
+  constexpr bool CONV = MODE == 1;       // NHWC implicit GEMM, Cin % 64 == 0
+  constexpr bool STEM = MODE == 2;       // 7x7/2 stem on a zero-padded NHWC4 image (see relnet_stem_conv7)
   constexpr int BK = 64;
   constexpr int NW = WM * WN, NT = 64 * NW;
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
@@ -162,6 +164,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
       arow[j] = A + (long)b * g.cImg + lchunk * 8;
       ciy[j] = (gr < g.M) ? oy * g.cStride - g.cPad : -(1 << 28);     // row >= M: never in bounds
       cix[j] = ox * g.cStride - g.cPad;
+    } else if constexpr (STEM) {
+      // padded image [B][Hp][Wp][4]: output (oy, ox) reads rows 2oy..2oy+7, 32 contiguous elements
+      // (8 pixels x 4 ch) from pixel 2ox; k-tile kt covers tap rows 2kt, 2kt+1; chunk c of the tile
+      // = tap row 2kt + (c >> 2), elements 8 (c & 3)...
+      const int hw = g.cHout * g.cWout;
+      const int gr2 = gr < g.M ? gr : g.M - 1;
+      const int b = gr2 / hw, rem = gr2 - b * hw;
+      const int oy = rem / g.cWout, ox = rem - oy * g.cWout;
+      arow[j] = A + (long)b * g.cImg + ((long)(2 * oy + (lchunk >> 2)) * g.cW + 2 * ox) * 4 + (lchunk & 3) * 8;
+      ciy[j] = 0; cix[j] = 0;
     } else {
       arow[j] = (gr < g.M) ? A + (long)gr * g.lda + lchunk * 8 : nullptr;
     }
@@ -195,6 +207,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
         const int iy = ciy[j] + tr * g.cDil, ix = cix[j] + ts * g.cDil;
         const bool ok = (iy >= 0) && (iy < g.cH) && (ix >= 0) && (ix < g.cW);
         src = ok ? (const void*)(arow[j] + ((long)iy * g.cW + ix) * g.cPix + ic0) : (const void*)g_zero16;
+      } else if constexpr (STEM) {
+        src = (const void*)(arow[j] + (long)(2 * kt) * g.cW * 4);
       } else {
         src = arow[j] ? (const void*)(arow[j] + k0) : (const void*)g_zero16;
       }
@@ -435,7 +449,7 @@ static int g_force_nloop = 0;    // tuning knob: 0 auto, else column tiles per w
 extern "C" void relnet_gemm_force_tile(int t) { g_force_tile = t; }
 extern "C" void relnet_gemm_force_nloop(int n) { g_force_nloop = n; }
 
-template <int BM, int BN, int WM, int WN, bool CONV>
+template <int BM, int BN, int WM, int WN, int CONV>
 static void launch_cfg(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
   const int ntile = (g.N + BN - 1) / BN;
   int nloop = g_force_nloop > 0 ? g_force_nloop : g.n_loop;
@@ -448,7 +462,7 @@ static void launch_cfg(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
 }
 
 // configs: 1 = 256x256 (8 waves) 2 = 256x128 (8 waves) 3 = 128x128 (4 waves) 4 = 128x64 5 = 64x64
-template <bool CONV>
+template <int CONV>
 static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t s) {
   const long M = g.M, N = g.N;
   int cfg = g_force_tile;
@@ -487,7 +501,7 @@ extern "C" int relnet_gemm_nt(const void* A, long lda, long strideA, const void*
   hipStream_t s = (hipStream_t)stream;
   if (in_dtype == RELNET_BF16) {
     RELNET_REQUIRE(K % 64 == 0 && lda % 8 == 0 && ldw % 8 == 0, "relnet_gemm_nt(bf16): K %% 64 and ld %% 8 required (K=%d lda=%ld ldw=%ld)", K, lda, ldw);
-    launch_bf16<false>(g, batch, out_dtype, s);
+    launch_bf16<0>(g, batch, out_dtype, s);
   } else if (in_dtype == RELNET_F32) {
     RELNET_REQUIRE(K % 16 == 0 && lda % 4 == 0 && ldw % 4 == 0, "relnet_gemm_nt(f32): K %% 16 and ld %% 4 required (K=%d)", K);
     dim3 grid((N + 127) / 128, (M + 127) / 128, batch);
@@ -521,6 +535,63 @@ extern "C" int relnet_conv2d_nhwc(const void* in, long in_pix, long in_img, cons
   g.M = B * Hout * Wout; g.N = Cout; g.K = R * S * Cin; g.bias_mode = bias ? 1 : 0; g.relu = relu;
   g.cH = H; g.cW = W; g.cCin = Cin; g.cHout = Hout; g.cWout = Wout; g.cR = R; g.cS = S;
   g.cStride = stride; g.cDil = dil; g.cPad = pad; g.cPix = in_pix; g.cImg = in_img;
-  launch_bf16<true>(g, 1, out_dtype, (hipStream_t)stream);
+  launch_bf16<1>(g, 1, out_dtype, (hipStream_t)stream);
   return check_launch("relnet_conv2d_nhwc");
+}
+
+// ---------------------------------------------------------------------------------------
+// Stem: conv1 7x7 / stride 2 / pad 3, Cin = 3 (resnet_v1_101_rcnn_base.py:30-31) as an implicit GEMM
+// on the same MFMA kernel.  Cin = 3 cannot feed 16-byte fragment loads, so the image is first
+// repacked (relnet_stem_pack_input) to zero-padded NHWC4 bf16 [B][H+6 (+1)][W+8][4]: every 7-tap row
+// of a window is then 28 contiguous elements (padded to 32 with the next pixel, whose weights are
+// zero) at an 8-byte aligned address and no bounds checks are needed.  K = 8 tap rows x 32 = 256
+// (row 7 and channel 3 carry zero weights): w [Cout][256], k = ty*32 + tx*4 + c.
+// ---------------------------------------------------------------------------------------
+namespace relnet {
+struct PackArgs {
+  const void* in;            // [B, 3, H, W] fp32 or bf16 (NCHW, contiguous)
+  unsigned short* out;       // [B, Hp, Wp, 4] bf16
+  int B, H, W, Hp, Wp, pad, in_bf16;
+};
+__global__ __launch_bounds__(256) void stem_pack_kernel(PackArgs g) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)g.B * g.Hp * g.Wp;
+  if (t >= total) return;
+  const int xp = (int)(t % g.Wp);
+  const int yp = (int)((t / g.Wp) % g.Hp);
+  const int b = (int)(t / ((long)g.Wp * g.Hp));
+  const int x = xp - g.pad, y = yp - g.pad;
+  float v[3] = {0.f, 0.f, 0.f};
+  if (x >= 0 && x < g.W && y >= 0 && y < g.H) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const long o = (((long)b * 3 + c) * g.H + y) * g.W + x;
+      v[c] = g.in_bf16 ? bf2f(((const unsigned short*)g.in)[o]) : ((const float*)g.in)[o];
+    }
+  }
+  *(uint2*)(g.out + t * 4) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], 0.f));
+}
+}  // namespace relnet
+
+extern "C" int relnet_stem_pack_input(const void* in, void* out, int B, int H, int W, int Hp, int Wp, int pad,
+                                      int in_dtype, void* stream) {
+  RELNET_REQUIRE(in && out && B > 0 && Hp >= H + 2 * pad && Wp >= W + 2 * pad, "relnet_stem_pack_input: bad arguments");
+  PackArgs g{in, (unsigned short*)out, B, H, W, Hp, Wp, pad, in_dtype == RELNET_BF16};
+  const long total = (long)B * Hp * Wp;
+  stem_pack_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(g);
+  return check_launch("relnet_stem_pack_input");
+}
+
+// packed [B][Hp][Wp][4] -> out [B*Hout*Wout, ldc] = relu?(conv7x7/2 + bias); Hout = (H+6-7)/2+1 etc.
+extern "C" int relnet_stem_conv7(const void* packed, const void* w256, const float* bias, int relu, void* out,
+                                 long ldc, int B, int Hp, int Wp, int Hout, int Wout, int Cout, int out_dtype,
+                                 void* stream) {
+  RELNET_REQUIRE(packed && w256 && out, "relnet_stem_conv7: null operand");
+  RELNET_REQUIRE(2 * (Hout - 1) + 8 <= Hp && 2 * (Wout - 1) + 8 <= Wp && Wp % 2 == 0, "relnet_stem_conv7: padded image too small (Hp=%d Wp=%d)", Hp, Wp);
+  GemmArgs g{};
+  g.A = packed; g.W = w256; g.ldw = 256; g.C = out; g.ldc = ldc; g.bias = bias; g.bias_mode = bias ? 1 : 0; g.relu = relu;
+  g.M = B * Hout * Wout; g.N = Cout; g.K = 256;
+  g.cHout = Hout; g.cWout = Wout; g.cW = Wp; g.cImg = (long)Hp * Wp * 4;
+  launch_bf16<2>(g, 1, out_dtype, (hipStream_t)stream);
+  return check_launch("relnet_stem_conv7");
 }

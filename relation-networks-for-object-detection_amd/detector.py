@@ -46,10 +46,10 @@ def fc1_channels_last_perm(c=256, ph=7, pw=7):
 
 class Detector(object):
     def __init__(self, params, dtype=torch.bfloat16, device='cuda', cfg=None, relation=True,
-                 im_hw=(600, 1000)):
+                 im_hw=(600, 1000), stem='hip'):
         self.cfg = cfg or Config()
         self.dtype, self.device, self.relation, self.im_hw = dtype, device, relation, im_hw
-        self.backbone = Backbone(params, dtype, device)
+        self.backbone = Backbone(params, dtype, device, stem=stem)
         self.head = RelationHead(params, dtype, device, fc1_perm=fc1_channels_last_perm(),
                                  use_relation=relation)
         self.lnms = None

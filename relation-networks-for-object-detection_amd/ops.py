@@ -322,3 +322,29 @@ def stem_bias_relu_pool(x_nhwc, bias, ksize=3, stride=2):
     _lib.call('relnet_stem_bias_relu_pool', x_nhwc.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, Cc,
               ksize, stride, _stream())
     return out
+
+
+def pack_stem_weight(w_oihw, dtype=torch.bfloat16, device='cuda'):
+    """[Cout, 3, 7, 7] -> [Cout, 256] with k = ty*32 + tx*4 + c (zeros for ty = 7, tx = 7, c = 3)."""
+    co = w_oihw.shape[0]
+    w = torch.zeros(co, 8, 8, 4, dtype=torch.float32)
+    w[:, :7, :7, :3] = w_oihw.detach().cpu().float().permute(0, 2, 3, 1)
+    return w.reshape(co, 256).to(device=device, dtype=dtype).contiguous()
+
+
+def stem_conv7(data, w256, bias, relu=True):
+    """data [B,3,H,W] fp32/bf16 NCHW contiguous -> relu(conv 7x7 / 2, pad 3) as NHWC bf16 [B,Ho,Wo,Cout]."""
+    _chk(data, w256, bias)
+    data = data.contiguous()
+    B, Cin, H, W = data.shape
+    assert Cin == 3
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    Hp, Wp = 2 * (Ho - 1) + 8, 2 * (Wo - 1) + 8
+    Hp, Wp = max(Hp, H + 6), max(Wp + (Wp & 1), W + 6 + ((W + 6) & 1))
+    packed = torch.empty((B, Hp, Wp, 4), device=data.device, dtype=torch.bfloat16)
+    _lib.call('relnet_stem_pack_input', data.data_ptr(), packed.data_ptr(), B, H, W, Hp, Wp, 3, _dt(data), _stream())
+    Cout = w256.shape[0]
+    out = torch.empty((B, Ho, Wo, Cout), device=data.device, dtype=torch.bfloat16)
+    _lib.call('relnet_stem_conv7', packed.data_ptr(), w256.data_ptr(), _ptr(bias), int(relu), out.data_ptr(), Cout,
+              B, Hp, Wp, Ho, Wo, Cout, _dt(out), _stream())
+    return out

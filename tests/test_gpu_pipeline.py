@@ -201,3 +201,22 @@ def test_detector_learn_nms_runs(rn):
     assert (out['num_detections'] >= want).all()          # >= : ties at the 100th score are all kept
     s = out['sorted_score']
     assert (s[:, :-1] >= s[:, 1:]).all()                  # ranks are in descending score order
+
+
+def test_stem_conv7_matches_torch(rn):
+    """conv1 7x7/2 pad 3 (Cin = 3) on the MFMA kernel via the padded NHWC4 repack vs torch conv2d."""
+    ops, _, _ = rn
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(21)
+    for (H, W) in ((37, 52), (120, 200)):
+        x = torch.randn(2, 3, H, W, generator=g).cuda()
+        w = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).cuda()
+        b = torch.randn(64, generator=g).cuda()
+        xb, wb = x.to(torch.bfloat16), w.to(torch.bfloat16)
+        want = torch.relu(F.conv2d(xb.double(), wb.double(), b.double(), stride=2, padding=3)).permute(0, 2, 3, 1)
+        got = ops.stem_conv7(x, ops.pack_stem_weight(w), b, relu=True)
+        assert got.shape == want.shape
+        assert (got.double() - want).abs().max().item() <= 1e-2 * want.abs().max().item()
+        pooled = ops.stem_bias_relu_pool(got, torch.zeros(64, device='cuda'))
+        ref = F.max_pool2d(got.permute(0, 3, 1, 2).float(), 3, 2, 0, ceil_mode=True).permute(0, 2, 3, 1)
+        assert torch.equal(pooled.float(), ref)
