@@ -116,3 +116,38 @@ def rpn_case(seed, height=38, width=63, num_anchors=12, score_sigma=2.0, delta_s
     deltas = rng.normal(0, delta_sigma, (1, 4 * num_anchors, height, width)).astype(F32)
     im_info = np.array([[IM_H, IM_W, 1.0]], dtype=F32)
     return cls_prob, deltas, im_info
+
+
+def targets_case(n, g, seed, num_fg=80):
+    """Training-target inputs: rois [n,5], gt_boxes [g,5] (class ids 1..num_fg), and head outputs."""
+    rng = np.random.default_rng(seed)
+    gt = random_boxes(g, seed + 4000, min_size=32)
+    gt_cls = rng.integers(1, num_fg + 1, g).astype(F32)
+    gt_boxes = np.hstack((gt, gt_cls[:, None])).astype(F32)
+    rois = random_boxes(n, seed + 4001)
+    # a third of the rois are jittered copies of gt boxes so that positives exist
+    k = n // 3
+    src = rng.integers(0, g, k)
+    rois[:k] = np.clip(gt[src] + rng.normal(0, 6, (k, 4)).astype(F32), 0, [IM_W - 1, IM_H - 1, IM_W - 1, IM_H - 1])
+    rois[:k, 2:] = np.maximum(rois[:k, 2:], rois[:k, :2] + 4)
+    rois = np.hstack((np.zeros((n, 1), F32), rois)).astype(F32)
+    cls_score = rng.normal(0, 2, (n + g, num_fg + 1)).astype(F32)
+    bbox_pred = rng.normal(0, 0.5, (n + g, 8)).astype(F32)
+    return rois, gt_boxes, cls_score, bbox_pred
+
+
+def nms_target_case(first_n, num_fg, g, seed):
+    """bbox [F,C,4], gt_box [1,G,5], score [F,C] (descending per class, like sorted_score)."""
+    rng = np.random.default_rng(seed)
+    gt = random_boxes(g, seed + 5000, min_size=40)
+    gt_cls = rng.integers(1, min(num_fg, 4) + 1, g).astype(F32)      # few classes -> several gts per class
+    gt_box = np.hstack((gt, gt_cls[:, None])).astype(F32)[None]
+    bbox = np.zeros((first_n, num_fg, 4), F32)
+    for c in range(num_fg):
+        b = random_boxes(first_n, seed + 6000 + c)
+        src = rng.integers(0, g, first_n // 2)
+        b[:first_n // 2] = np.clip(gt[src] + rng.normal(0, 8, (first_n // 2, 4)).astype(F32), 0, [IM_W - 1, IM_H - 1, IM_W - 1, IM_H - 1])
+        b[:, 2:] = np.maximum(b[:, 2:], b[:, :2] + 4)
+        bbox[:, c] = b[rng.permutation(first_n)]
+    score = np.sort(rng.random((first_n, num_fg)).astype(F32), axis=0)[::-1].copy()
+    return bbox, gt_box, score

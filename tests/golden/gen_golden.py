@@ -34,6 +34,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))      # repo root (oracle package)
 import cases  # noqa: E402
 
 F32 = np.float32
@@ -82,6 +83,21 @@ def setup_reference(ref):
     rel = _load('ref_sym_rel', os.path.join(
         sym_dir, 'resnet_v1_101_rcnn_attention_1024_pairwise_position_multi_head_16.py'))
     lnms = _load('ref_learn_nms', os.path.join(ref, 'relation_rcnn/operator_py/learn_nms.py'))
+    # training-target operators: the compiled `bbox_overlaps_cython` is replaced by the reference's
+    # own pure-python twin bbox_overlaps_py (bbox_transform.py:22-42)
+    bt.bbox_overlaps = bt.bbox_overlaps_py
+    pk = stub('bbox')
+    pk.__path__ = []
+    pk.bbox_overlaps_cython = _no_ext
+    sys.modules['bbox.bbox_transform'] = bt
+    import oracle.targets as OT                     # bbox_regression.py has Python-2 prints: restated
+    stub('bbox.bbox_regression', expand_bbox_regression_targets=lambda d, n, cfg: OT.expand_bbox_regression_targets(
+        d, n, cfg.CLASS_AGNOSTIC, cfg.TRAIN.BBOX_WEIGHTS))
+    stub('utils.image', get_image=_no_ext, tensor_vstack=_no_ext)
+    ohem = _load('ref_ohem', os.path.join(ref, 'relation_rcnn/operator_py/box_annotator_ohem.py'))
+    nmt = _load('ref_nms_multi_target', os.path.join(ref, 'relation_rcnn/operator_py/nms_multi_target.py'))
+    rcnn = _load('ref_rcnn', os.path.join(ref, 'relation_rcnn/core/rcnn.py'))
+    setup_reference.extra = (ohem, nmt, rcnn)
     return ga, bt, nm, rel, lnms
 
 
@@ -160,6 +176,38 @@ def gen_learn_nms(lnms, out):
     np.savez_compressed(os.path.join(out, 'learn_nms.npz'), **d)
 
 
+def gen_targets(out):
+    import mxnet as mx
+    ohem, nmt, rcnn = setup_reference.extra
+
+    class _NS(object):
+        pass
+    cfg = _NS(); cfg.TRAIN = _NS()
+    cfg.CLASS_AGNOSTIC = True
+    cfg.TRAIN.BG_THRESH_HI = 0.5
+    cfg.TRAIN.BBOX_NORMALIZATION_PRECOMPUTED = True
+    cfg.TRAIN.BBOX_MEANS = (0.0, 0.0, 0.0, 0.0)
+    cfg.TRAIN.BBOX_STDS = (0.1, 0.1, 0.2, 0.2)
+    cfg.TRAIN.BBOX_WEIGHTS = np.array([1.0, 1.0, 1.0, 1.0])
+    d = {}
+    rois, gt_boxes, cls_score, bbox_pred = cases.targets_case(90, 7, 61)
+    # proposal_target.py:64-67 (restated glue) + the reference's sample_rois_v2
+    all_rois = np.vstack((rois, np.hstack((np.zeros((gt_boxes.shape[0], 1), F32), gt_boxes[:, :-1]))))
+    r, lab, bt_, bw = rcnn.sample_rois_v2(all_rois, 81, cfg, gt_boxes=gt_boxes)
+    d['pt/rois'] = r; d['pt/label'] = lab; d['pt/bbox_target'] = bt_; d['pt/bbox_weight'] = bw
+    op = ohem.BoxAnnotatorOHEMOperator(81, 2, 32)
+    ins = [mx.NDArray(x) for x in (cls_score, bbox_pred, lab, bt_, bw)]
+    outs = [mx.nd.zeros(lab.shape), mx.nd.zeros(bw.shape)]
+    op.forward(True, ['write'] * 2, ins, outs, [])
+    d['ohem/labels'] = outs[0].asnumpy(); d['ohem/bbox_weights'] = outs[1].asnumpy()
+    bbox, gt_box, score = cases.nms_target_case(40, 6, 9, 62)
+    op = nmt.NmsMultiTargetOp(np.array([0.5, 0.6, 0.7, 0.8, 0.9]))
+    outs = [mx.nd.zeros((40, 6, 5))]
+    op.forward(True, ['write'], [mx.NDArray(bbox), mx.NDArray(gt_box), mx.NDArray(score)], outs, [])
+    d['nmt/target'] = outs[0].asnumpy()
+    np.savez_compressed(os.path.join(out, 'targets.npz'), **d)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -170,6 +218,7 @@ def main():
     gen_nms(nm, a.out)
     gen_relation(rel, a.out)
     gen_learn_nms(lnms, a.out)
+    gen_targets(a.out)
     for f in sorted(os.listdir(a.out)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(a.out, f)), 'bytes')

@@ -321,6 +321,20 @@ def softmax(*a, **kw):
     return out
 
 
+def SoftmaxActivation(*a, **kw):
+    return softmax(_first(a, kw, 'data'), axis=1)
+
+
+def smooth_l1(*a, **kw):
+    x = _np(_first(a, kw, 'data'))
+    s2 = F32(kw.get('scalar', 1.0)) ** 2
+    return NDArray(np.where(np.abs(x) < F32(1.0) / s2, F32(0.5) * s2 * x * x, np.abs(x) - F32(0.5) / s2))
+
+
+def sum(*a, **kw):
+    return NDArray(_np(_first(a, kw, 'data')).astype(np.float64).sum(axis=kw.get('axis')))
+
+
 def sort(*a, **kw):
     x = _np(_first(a, kw, 'data'))
     axis = kw.get('axis', -1)

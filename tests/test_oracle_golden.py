@@ -117,3 +117,22 @@ def test_learn_nms_matches_reference_operator(golden):
         np.testing.assert_allclose(sscore, g[name + '/sorted_score'], rtol=1e-6, atol=0)
         np.testing.assert_allclose(sbox, g[name + '/sorted_bbox'], rtol=0, atol=1e-4)
         np.testing.assert_allclose(multi, g[name + '/nms_multi_score'], rtol=2e-5, atol=1e-7)
+
+
+def test_training_targets_match_reference(golden):
+    """proposal_target (sample_rois_v2), BoxAnnotatorOHEM, nms_multi_target vs the reference's own code."""
+    from oracle import targets as OT
+    g = golden['targets']
+    rois, gt_boxes, cls_score, bbox_pred = cases.targets_case(90, 7, 61)
+    r, lab, bt, bw = OT.proposal_target(rois, gt_boxes)
+    assert np.array_equal(r, g['pt/rois']) and np.array_equal(lab, g['pt/label'])
+    assert (lab > 0).sum() >= 10 and (lab == 0).sum() >= 10
+    assert np.array_equal(bw, g['pt/bbox_weight'])
+    # numpy's float32 log in the reference run vs the correctly rounded log of the oracle: 1 ulp
+    np.testing.assert_allclose(bt, g['pt/bbox_target'], rtol=3e-7, atol=1e-6)
+    lo, wo, _ = OT.box_annotator_ohem(cls_score, bbox_pred, g['pt/label'], g['pt/bbox_target'], g['pt/bbox_weight'], 32)
+    assert np.array_equal(lo, g['ohem/labels']) and np.array_equal(wo, g['ohem/bbox_weights'])
+    assert (lo >= 0).sum() == 32
+    bbox, gt_box, score = cases.nms_target_case(40, 6, 9, 62)
+    t = OT.nms_multi_target(bbox, gt_box, score)
+    assert np.array_equal(t, g['nmt/target']) and t.sum() > 0
