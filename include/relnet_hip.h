@@ -162,6 +162,26 @@ int relnet_lnms_score(const void* x, const void* att, const float* w_logit, cons
                       int NC, int first_n, int D, int T, int H, int dv, int att_hstride, int merge,
                       float class_thresh, float score_thresh, int dtype, void* stream);
 
+/* ---- training-target operators (A10), no host round trip ---------------------------------------
+ * operator_py/proposal_target.py:44-93 with BATCH_ROIS = -1 -> core/rcnn.py:288-325 (sample_rois_v2),
+ * lib/bbox/bbox.pyx:33-55 (float64 IoU), bbox_transform.py:74-100, bbox_regression.py:120-140.
+ * rois [B,N,5], gt [B,Gmax,5], num_gt [B]; outputs have N+Gmax rows (rows past N+num_gt[b]: label -1).
+ * means4/stds4/weights4: HOST double[4].                                                           */
+int relnet_proposal_target(const float* rois, const float* gt, const int* num_gt, float* rois_out, float* label,
+                           float* bbox_target, float* bbox_weight, int B, int N, int Gmax, int num_reg,
+                           int class_agnostic, float bg_thresh_hi, const double* means4, const double* stds4,
+                           const double* weights4, void* stream);
+/* operator_py/box_annotator_ohem.py:26-53: per-roi loss (-log softmax[label] + sum w*smooth_l1), keep the
+ * roi_per_img largest; others get label -1 / zero weights.  R <= 2048.  loss [B,R] optional.           */
+int relnet_box_annotator_ohem(const float* cls_score, const float* bbox_pred, const float* labels,
+                              const float* bbox_targets, const float* bbox_weights, float* labels_ohem,
+                              float* weights_ohem, float* loss, int B, int R, int C, int D, int roi_per_img,
+                              void* stream);
+/* operator_py/nms_multi_target.py:24-74: per class and IoU threshold, the highest-scoring box among those
+ * whose arg-max gt is g and IoU > t gets target 1.  thresh: HOST double[T], T <= 8; first_n <= 256.      */
+int relnet_nms_multi_target(const float* bbox, const float* gt, const int* num_gt, const float* score, float* out,
+                            int B, int F, int C, int Gmax, const double* thresh, int T, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,9 @@ _SIGNATURES = {
                                     _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp]),
     'relnet_stem_pack_input': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_stem_conv7': (C.c_int, [_vp, _vp, _vp, _i, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'relnet_proposal_target': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    'relnet_box_annotator_ohem': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'relnet_nms_multi_target': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
 }
 
 

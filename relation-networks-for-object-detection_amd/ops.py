@@ -348,3 +348,63 @@ def stem_conv7(data, w256, bias, relu=True):
     _lib.call('relnet_stem_conv7', packed.data_ptr(), w256.data_ptr(), _ptr(bias), int(relu), out.data_ptr(), Cout,
               B, Hp, Wp, Ho, Wo, Cout, _dt(out), _stream())
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# training-target operators
+# ---------------------------------------------------------------------------------------
+def _d4(v):
+    import ctypes
+    return (ctypes.c_double * 4)(*[float(x) for x in v])
+
+
+def proposal_target(rois, gt_boxes, num_gt=None, num_reg=2, class_agnostic=True, bg_thresh_hi=0.5,
+                    means=(0.0, 0.0, 0.0, 0.0), stds=(0.1, 0.1, 0.2, 0.2), weights=(1.0, 1.0, 1.0, 1.0)):
+    """rois [B,N,5], gt_boxes [B,Gmax,5] (x1,y1,x2,y2,cls), num_gt [B] int32 (default: all Gmax valid)
+    -> rois_out [B,N+Gmax,5], label [B,N+Gmax], bbox_target / bbox_weight [B,N+Gmax,4*num_reg]
+    (BATCH_ROIS = -1 semantics; rows past N + num_gt[b] carry label -1 and zero weights)."""
+    _chk(rois, gt_boxes, num_gt)
+    B, N, _ = rois.shape
+    G = gt_boxes.shape[1]
+    dev = rois.device
+    if num_gt is None:
+        num_gt = torch.full((B,), G, device=dev, dtype=torch.int32)
+    R = N + G
+    ro = torch.empty((B, R, 5), device=dev, dtype=torch.float32)
+    lab = torch.empty((B, R), device=dev, dtype=torch.float32)
+    bt = torch.empty((B, R, 4 * num_reg), device=dev, dtype=torch.float32)
+    bw = torch.empty((B, R, 4 * num_reg), device=dev, dtype=torch.float32)
+    _lib.call('relnet_proposal_target', rois.contiguous().data_ptr(), gt_boxes.contiguous().data_ptr(), num_gt.data_ptr(),
+              ro.data_ptr(), lab.data_ptr(), bt.data_ptr(), bw.data_ptr(), B, N, G, num_reg, int(class_agnostic),
+              float(bg_thresh_hi), _d4(means), _d4(stds), _d4(weights), _stream())
+    return ro, lab, bt, bw
+
+
+def box_annotator_ohem(cls_score, bbox_pred, labels, bbox_targets, bbox_weights, roi_per_img=128, want_loss=False):
+    """[B,R,C], [B,R,D], [B,R], [B,R,D], [B,R,D] -> labels_ohem [B,R], bbox_weights_ohem [B,R,D]."""
+    _chk(cls_score, bbox_pred, labels, bbox_targets, bbox_weights)
+    B, R, Cn = cls_score.shape
+    D = bbox_pred.shape[2]
+    lo = torch.empty_like(labels)
+    wo = torch.empty_like(bbox_weights)
+    loss = torch.empty((B, R), device=labels.device, dtype=torch.float32) if want_loss else None
+    _lib.call('relnet_box_annotator_ohem', cls_score.contiguous().data_ptr(), bbox_pred.contiguous().data_ptr(),
+              labels.contiguous().data_ptr(), bbox_targets.contiguous().data_ptr(), bbox_weights.contiguous().data_ptr(),
+              lo.data_ptr(), wo.data_ptr(), _ptr(loss), B, R, Cn, D, int(roi_per_img), _stream())
+    return (lo, wo, loss) if want_loss else (lo, wo)
+
+
+def nms_multi_target(bbox, gt_boxes, score, num_gt=None, target_thresh=(0.5, 0.6, 0.7, 0.8, 0.9)):
+    """bbox [B,F,C,4], gt_boxes [B,Gmax,5], score [B,F,C] -> nms_multi_target [B,F,C,T]."""
+    _chk(bbox, gt_boxes, score, num_gt)
+    import ctypes
+    B, F, Cn, _ = bbox.shape
+    G = gt_boxes.shape[1]
+    if num_gt is None:
+        num_gt = torch.full((B,), G, device=bbox.device, dtype=torch.int32)
+    T = len(target_thresh)
+    out = torch.empty((B, F, Cn, T), device=bbox.device, dtype=torch.float32)
+    th = (ctypes.c_double * T)(*[float(t) for t in target_thresh])
+    _lib.call('relnet_nms_multi_target', bbox.contiguous().data_ptr(), gt_boxes.contiguous().data_ptr(), num_gt.data_ptr(),
+              score.contiguous().data_ptr(), out.data_ptr(), B, F, Cn, G, th, T, _stream())
+    return out
