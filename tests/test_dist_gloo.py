@@ -52,3 +52,40 @@ def test_shard_edges():
     from relnet_amd.dist import shard_images
     assert [shard_images(5, r, 8) for r in range(8)] == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 5), (5, 5), (5, 5)]
     assert shard_images(16, 3, 4) == (12, 16)
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import relnet_amd  # noqa: F401
+    from relnet_amd import dist as D
+    D.init(backend='gloo')
+    shapes = [('conv1_weight', (64, 3, 7, 7)), ('res2a_branch2a_weight', (64, 64, 1, 1)), ('bn4b3_branch2a_gamma', (256,)),
+              ('res4b3_branch2a_weight', (256, 1024, 1, 1)), ('fc_new_1_weight', (8, 50)), ('query_1_bias', (7,))]
+    b = D.GradientBucket(shapes)
+    for i, n in enumerate(b.names):
+        b.view(n).fill_(float(rank + 1) * (i + 1))
+    b.all_reduce()
+    q.put((rank, b.names, [float(b.view(n).flatten()[0]) for n in b.names], int(b.flat.numel())))
+    torch.distributed.destroy_process_group()
+
+
+def test_gradient_bucket_sum_allreduce():
+    """A13: frozen-by-substring rule + one flat SUM all-reduce (rescale_grad = 1 semantics)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, names, vals, numel in res:
+        assert names == ['res4b3_branch2a_weight', 'fc_new_1_weight', 'query_1_bias']   # conv1/res2/gamma frozen
+        assert vals == [3.0, 6.0, 9.0]                                                 # (1 + 2) * (i + 1): SUM, not mean
+        assert numel == 256 * 1024 + 448 + 64                                          # 64-element aligned slices
