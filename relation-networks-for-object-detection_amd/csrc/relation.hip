@@ -319,13 +319,14 @@ __global__ __launch_bounds__(256) void relation_attention_kernel(AttnArgs a) {
 // residual and activation rows move as 16-byte coalesced accesses.
 // ---------------------------------------------------------------------------------------
 constexpr int kKC = 320;                    // keys per LDS chunk
-constexpr int kVLD = kKC + 4;               // VW^T row stride in LDS (bf16): conflict-free b64 reads
-constexpr int kOLD = 68;                    // epilogue row stride (fp32)
+constexpr int kOLD = 72;                    // epilogue row stride (bf16): 64 + 8 pad
 
-__global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a) {
+// lds layout: sK [kc_rows][64] bf16 (16-B chunks XOR-swizzled), sV [64][vld] bf16 (+ slack); the
+// epilogue reuses the start of the buffer as [nwave][32][kOLD] bf16.
+__global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a, int kc_rows, int vld) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sK = smem;                              // [kKC][64] bf16, 16-B chunks XOR-swizzled
-  unsigned short* sV = (unsigned short*)(smem + kKC * 128);   // [64][kVLD] bf16
+  unsigned char* sK = smem;
+  unsigned short* sV = (unsigned short*)(smem + kc_rows * 128);
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -352,33 +353,47 @@ __global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a
 
   for (int kc0 = 0; kc0 < a.M; kc0 += kKC) {
     if (kc0 > 0) __syncthreads();
-    // ---- stage K rows [kc0, kc0+kKC) and VW^T columns of this head -----------------------
-    for (int c = tid; c < kKC * 8; c += nthr) {
-      const int row = c >> 3, ch = c & 7, key = kc0 + row;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (key < a.M) v = *(const uint4*)(Kb + (long)key * a.k_ld + ch * 8);
-      *(uint4*)(sK + row * 128 + ((ch ^ (row & 7)) << 4)) = v;
+    const int clen = min(a.M - kc0, kKC);             // valid keys of this chunk
+    // bias of the first tile: issued before the staging so that its latency overlaps it
+    uint2 bcur[4];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) bcur[gq] = *(const uint2*)(Bq + kc0 + 8 * gq + 4 * half);
+    // ---- stage K rows [kc0, kc0+clen) and VW^T columns of this head --------------------------
+    for (int c = tid; c < clen * 8; c += nthr) {
+      const int row = c >> 3, ch = c & 7;
+      *(uint4*)(sK + row * 128 + ((ch ^ (row & 7)) << 4)) = *(const uint4*)(Kb + (long)(kc0 + row) * a.k_ld + ch * 8);
     }
-    for (int c = tid; c < 64 * (kKC / 4); c += nthr) {
-      const int row = c / (kKC / 4), c4 = c - row * (kKC / 4), key = kc0 + 4 * c4;
-      uint2 v = make_uint2(0, 0);
-      if (key < a.Mpad) v = *(const uint2*)(Vb + (long)row * a.vwt_ld + key);     // pad columns are zero
-      *(uint2*)(sV + row * kVLD + 4 * c4) = v;
+    const int v4 = (clen + 3) >> 2;                   // 4-key groups per row
+    // zero what the masked tail of the last tile may touch (P is 0 there, but 0 x NaN is not)
+    if (kc0 == 0) {
+      for (int c = tid; c < 64 * ((vld >> 2) - v4); c += nthr) {
+        const int row = c / ((vld >> 2) - v4), c4 = v4 + c % ((vld >> 2) - v4);
+        *(uint2*)(sV + row * vld + 4 * c4) = make_uint2(0, 0);
+      }
+      if (tid < 16) *(uint2*)(sV + 64 * vld + 4 * tid) = make_uint2(0, 0);
+    }
+    for (int c = tid; c < 64 * v4; c += nthr) {
+      const int row = c / v4, c4 = c - row * v4;
+      *(uint2*)(sV + row * vld + 4 * c4) = *(const uint2*)(Vb + (long)row * a.vwt_ld + kc0 + 4 * c4);   // pad cols are 0
     }
     __syncthreads();
     if (wave_on) {
-      const int ntile = (min(a.M - kc0, kKC) + 31) / 32;
+      const int ntile = (clen + 31) / 32;
       for (int kt = 0; kt < ntile; ++kt) {
         const int key0 = kc0 + kt * 32;
-        // bias for this lane's query: keys key0 + 8g + 4 half + (0..3)
-        uint2 braw[4];
+        // prefetch the next tile's bias (clamped: the last prefetch re-reads a valid address)
+        uint2 bnext[4];
+        {
+          const int kn = (kt + 1 < ntile) ? key0 + 32 : key0;
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) braw[gq] = *(const uint2*)(Bq + key0 + 8 * gq + 4 * half);
+          for (int gq = 0; gq < 4; ++gq) bnext[gq] = *(const uint2*)(Bq + kn + 8 * gq + 4 * half);
+        }
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
         {
-          const int row = kt * 32 + l31;
+          int row = kt * 32 + l31;
+          row = row < clen ? row : clen - 1;          // keys past M: any valid row, masked below
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
             const bf16x8 kf = *(const bf16x8*)(sK + row * 128 + (((2 * kk + half) ^ (row & 7)) << 4));
@@ -389,7 +404,7 @@ __global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const int kbase = key0 + 8 * gq + 4 * half;
-          const __half2 b01 = *(const __half2*)&braw[gq].x, b23 = *(const __half2*)&braw[gq].y;
+          const __half2 b01 = *(const __half2*)&bcur[gq].x, b23 = *(const __half2*)&bcur[gq].y;
           const float bb[4] = {__low2float(b01), __high2float(b01), __low2float(b23), __high2float(b23)};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -424,28 +439,35 @@ __global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a
           for (int t = 0; t < 4; ++t) pw[t] = pack_bf16x2(s[8 * ks + 2 * t], s[8 * ks + 2 * t + 1]);
 #pragma unroll
           for (int d = 0; d < 2; ++d) {
-            const unsigned short* vr = sV + (32 * d + l31) * kVLD + kt * 32 + 16 * ks + 4 * half;
+            // columns past the chunk hold finite data of the next row (or the slack): P is 0 there
+            const unsigned short* vr = sV + (32 * d + l31) * vld + kt * 32 + 16 * ks + 4 * half;
             bf16x8 vf;
             *(uint2*)&vf = *(const uint2*)vr;
             *((uint2*)&vf + 1) = *(const uint2*)(vr + 8);
             o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
           }
         }
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) bcur[gq] = bnext[gq];
       }
     }
   }
-  // ---- epilogue: O^T -> LDS [q][dv] fp32 -> 16-byte coalesced rows ---------------------------
+  // ---- epilogue: (O^T / l + bout) -> bf16 -> LDS [q][dv] -> 16-byte coalesced rows -------------
   __syncthreads();
-  float* so = (float*)smem + wave * (32 * kOLD);
+  unsigned short* so = (unsigned short*)smem + wave * (32 * kOLD);
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
   if (wave_on) {
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq)
-        *(float4*)(so + l31 * kOLD + 32 * d + 8 * gq + 4 * half) =
-            make_float4(o[d][4 * gq] * inv, o[d][4 * gq + 1] * inv, o[d][4 * gq + 2] * inv, o[d][4 * gq + 3] * inv);
+      for (int gq = 0; gq < 4; ++gq) {
+        const int dv = 32 * d + 8 * gq + 4 * half;
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = o[d][4 * gq + e] * inv + (a.bout ? a.bout[h * 64 + dv + e] : 0.f);
+        *(uint2*)(so + l31 * kOLD + dv) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+      }
     // same wave reads back what it wrote: no workgroup barrier needed, only LDS completion
     __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
@@ -457,25 +479,22 @@ __global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a
       const int idx = lane + 64 * i, qq = idx >> 3, c8 = (idx & 7) * 8;
       const int qrow = qt * 32 + qq;
       if (qrow >= a.N) continue;
-      const float4 x0 = *(const float4*)(so + qq * kOLD + c8), x1 = *(const float4*)(so + qq * kOLD + c8 + 4);
-      float y[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-      if (a.bout) {
-        const float4 b0 = *(const float4*)(a.bout + h * 64 + c8), b1 = *(const float4*)(a.bout + h * 64 + c8 + 4);
-        y[0] += b0.x; y[1] += b0.y; y[2] += b0.z; y[3] += b0.w; y[4] += b1.x; y[5] += b1.y; y[6] += b1.z; y[7] += b1.w;
-      }
-      if (Y) *(uint4*)(Y + (long)qrow * a.out_ld + c8) =
-          make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7]));
+      const uint4 yv = *(const uint4*)(so + qq * kOLD + c8);
+      if (Y) *(uint4*)(Y + (long)qrow * a.out_ld + c8) = yv;
       if (Z) {
+        // relu(resid + Y) on the bf16 attention output, i.e. exactly the unfused bf16 graph
+        const unsigned int yw[4] = {yv.x, yv.y, yv.z, yv.w};
+        unsigned int rw[4] = {0u, 0u, 0u, 0u};
         if (R) {
           const uint4 rv = *(const uint4*)(R + (long)qrow * a.resid_ld + c8);
-          const unsigned int rw[4] = {rv.x, rv.y, rv.z, rv.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { y[2 * e] += bf2f(rw[e] & 0xffff); y[2 * e + 1] += bf2f(rw[e] >> 16); }
+          rw[0] = rv.x; rw[1] = rv.y; rw[2] = rv.z; rw[3] = rv.w;
         }
+        unsigned int zw[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] = fmaxf(y[e], 0.f);
-        *(uint4*)(Z + (long)qrow * a.act_ld + c8) =
-            make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7]));
+        for (int e = 0; e < 4; ++e)
+          zw[e] = pack_bf16x2(fmaxf(bf2f(yw[e] & 0xffff) + bf2f(rw[e] & 0xffff), 0.f),
+                              fmaxf(bf2f(yw[e] >> 16) + bf2f(rw[e] >> 16), 0.f));
+        *(uint4*)(Z + (long)qrow * a.act_ld + c8) = make_uint4(zw[0], zw[1], zw[2], zw[3]);
       }
     }
   }
@@ -539,7 +558,12 @@ extern "C" int relnet_relation_attention(
     RELNET_REQUIRE(out_ld % 8 == 0 && act_ld % 8 == 0 && resid_ld % 8 == 0, "relnet_relation_attention(bf16): output rows must be 16-byte aligned");
     const int qtiles = (N + 31) / 32;
     const int nwave = qtiles < 16 ? qtiles : 16;
-    const size_t kv = (size_t)kKC * 128 + (size_t)64 * kVLD * 2, ep = (size_t)nwave * 32 * kOLD * 4;
+    const int kc_rows = M < kKC ? M : kKC;                         // K rows staged per chunk
+    int vk = (kc_rows + 3) / 4 + 1;                                 // VW^T row stride (bf16) = 4 * odd:
+    if ((vk & 1) == 0) ++vk;                                        // 32 rows x 8-byte reads hit 32 distinct bank pairs
+    const int vld = 4 * vk;
+    const size_t kv = (size_t)kc_rows * 128 + (size_t)64 * vld * 2 + 128 /* slack for the masked tail */;
+    const size_t ep = (size_t)nwave * 32 * kOLD * 2;
     const size_t lds = kv > ep ? kv : ep;
     static bool attr_set = false;
     if (!attr_set) {
@@ -547,7 +571,7 @@ extern "C" int relnet_relation_attention(
       attr_set = true;
     }
     dim3 g2((unsigned)((qtiles + nwave - 1) / nwave), H, B);
-    relation_attention_lds_kernel<<<g2, nwave * 64, lds, s>>>(a);
+    relation_attention_lds_kernel<<<g2, nwave * 64, lds, s>>>(a, kc_rows, vld);
   } else if (in_dtype == RELNET_BF16) {
     RELNET_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && vwt_ld % 4 == 0, "relnet_relation_attention(bf16): row strides must be 16-byte (q,k) / 8-byte (vwt) aligned");
     relation_attention_kernel<unsigned short, unsigned short><<<grid, 256, 0, s>>>(a);
