@@ -22,8 +22,13 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 __device__ __forceinline__ float bf2f(unsigned short h) {
   return __uint_as_float(((unsigned int)h) << 16);
 }
+// two floats -> packed bf16x2 (round to nearest even): one v_cvt_pk_bf16_f32 on gfx950
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+  const hw_f32x2 v = {lo, hi};
+  const hw_bf16x2 b = __builtin_convertvector(v, hw_bf16x2);
+  return *(const unsigned int*)&b;
 }
 
 // Row index inside a 32x32 MFMA C/D tile held by this lane in accumulator register r:

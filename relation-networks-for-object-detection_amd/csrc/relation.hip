@@ -15,6 +15,7 @@
 //                         written; DESIGN.md reports both).
 #include "common.h"
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 namespace relnet {
 
@@ -27,7 +28,7 @@ struct GeomArgs {
   const float* wp;         // [64, NMOD*FC]  pair_pos_fc1 weights, embedding-index major
   const float* bp;         // [NMOD, FC]
   float divisors[8];       // wave_length^(k/8), fp32 (host computes them like the graph)
-  void* bias;              // [NMOD, B, FC, N, Mpad]   log(max(relu(E Wp^T + bp), 1e-6)), float or half
+  void* bias;              // [NMOD, B, FC, N, Mpad]   log(max(relu(E Wp^T + bp), 1e-6)) float, or log2(.) half
   float* pos_mat;          // optional [B, N, M, 4]
   float* pos_emb;          // optional [B, N, M, 64]
   int B, N, M, Mpad, nmod;
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(256) void geometry_bias_kernel(GeomArgs g) {
 #pragma unroll
     for (int h = 0; h < FC; ++h) {
       const float gw = fmaxf(fmaxf(acc[m * FC + h], 0.f), 1e-6f);
-      ((TB*)g.bias)[((((long)m * g.B + b) * FC + h) * g.N + i) * g.Mpad + j] = (TB)logf(gw);
+      // fp16 bias feeds the exp2-based LDS attention kernel: store log2(G) (v_log_f32 is log2)
+      ((TB*)g.bias)[((((long)m * g.B + b) * FC + h) * g.N + i) * g.Mpad + j] = (TB)(kFast ? __log2f(gw) : logf(gw));
     }
 }
 #pragma clang fp contract(fast)
@@ -350,6 +352,7 @@ __global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  const float scale2 = a.scale * 1.44269504088896340736f;
 
   for (int kc0 = 0; kc0 < a.M; kc0 += kKC) {
     if (kc0 > 0) __syncthreads();
@@ -400,37 +403,48 @@ __global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
           }
         }
+        // logits in the log2 domain: v = log2(G) + (scale * log2 e) * (q . k)
         float tmax = -INFINITY;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-          const int kbase = key0 + 8 * gq + 4 * half;
           const __half2 b01 = *(const __half2*)&bcur[gq].x, b23 = *(const __half2*)&bcur[gq].y;
           const float bb[4] = {__low2float(b01), __high2float(b01), __low2float(b23), __high2float(b23)};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * gq + e;
-            float v = bb[e] + a.scale * s[r];
-            v = (kbase + e < a.M) ? v : -INFINITY;
-            s[r] = v;
-            tmax = fmaxf(tmax, v);
+            s[r] = fmaf(s[r], scale2, bb[e]);
           }
         }
+        if (key0 + 32 > a.M) {                           // only the last tile has keys past M
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (key0 + 8 * gq + 4 * half + e >= a.M) s[4 * gq + e] = -INFINITY;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __expf(m_run - m_new);
+        // deferred rescale: the running maximum only moves when some query's tile maximum exceeds it
+        // by more than 2^8; P is then bounded by 256 instead of 1 (exact after the final 1/l)
+        if (__any(tmax > m_run + 8.0f)) {
+          const float m_new = fmaxf(m_run, tmax);
+          const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // first tile: exp2(-inf) = 0
+          l_run *= alpha;
+          m_run = m_new;
+#pragma unroll
+          for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        }
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float pv = __expf(s[r] - m_new);
+          const float pv = __builtin_amdgcn_exp2f(s[r] - m_run);
           s[r] = pv;
           psum += pv;
         }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        l_run += psum;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           bf16x8 pf;
@@ -557,7 +571,10 @@ extern "C" int relnet_relation_attention(
     RELNET_REQUIRE(!logits, "relnet_relation_attention: logits output needs the fp32-bias kernel (bias_half = 0)");
     RELNET_REQUIRE(out_ld % 8 == 0 && act_ld % 8 == 0 && resid_ld % 8 == 0, "relnet_relation_attention(bf16): output rows must be 16-byte aligned");
     const int qtiles = (N + 31) / 32;
-    const int nwave = qtiles < 16 ? qtiles : 16;
+    // one workgroup = all query tiles of the (image, head) (measured: splitting it in two to overlap
+    // staging with compute loses more to the duplicated K / VW^T staging than it gains)
+    int nwave = qtiles < 16 ? qtiles : 16;
+    if (const char* e = getenv("RELNET_ATTN_WAVES")) nwave = atoi(e) > 0 && atoi(e) <= 16 ? atoi(e) : nwave;
     const int kc_rows = M < kKC ? M : kKC;                         // K rows staged per chunk
     int vk = (kc_rows + 3) / 4 + 1;                                 // VW^T row stride (bf16) = 4 * odd:
     if ((vk & 1) == 0) ++vk;                                        // 32 rows x 8-byte reads hit 32 distinct bank pairs
