@@ -17,6 +17,6 @@ f = torch.randn(B, 300, 1024, device='cuda').to(torch.bfloat16)
 bx = torch.as_tensor(boxes).cuda()[None].repeat(B, 1, 1).contiguous()
 bias = ops.geometry_bias(bx, wp_t, bp, 300, half=True)[0]   # fp16 bias -> the LDS throughput kernel
 for _ in range(iters):
-    relation._module_forward(f, mod, bias, 300, True, True, False)
+    relation._module_forward(f, mod, bias, 300, False, True, False)   # as in the pipeline: ReLU(out + resid) only
 torch.cuda.synchronize()
 print('done')
