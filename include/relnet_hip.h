@@ -182,6 +182,28 @@ int relnet_box_annotator_ohem(const float* cls_score, const float* bbox_pred, co
 int relnet_nms_multi_target(const float* bbox, const float* gt, const int* num_gt, const float* score, float* out,
                             int B, int F, int C, int Gmax, const double* thresh, int T, void* stream);
 
+/* ---- DCN configuration -------------------------------------------------
+ * relation_rcnn/operator_cxx/deformable_convolution-inl.h:91-143 (DeformableConvolutionOp::Forward) =
+ * relnet_deformable_im2col (nn/deformable_im2col.cuh:215-262, bilinear :76-113) followed by
+ * relnet_gemm_nt on the column matrix.  data: logical [B,C,H,W] with element strides (NCHW fp32 or
+ * channels-last bf16); offset: fp32 logical [B, 2*KH*KW*num_deformable_group, Ho, Wo] with element
+ * strides; col: [B*Ho*Wo][col_ld] with column index (i*KW + j)*C + c  -- multiply by weights packed
+ * [Cout][KH][KW][Cin].  Samples outside [0,H)x[0,W) contribute 0 (:247).                              */
+int relnet_deformable_im2col(const void* data, const long* data_strides4, const float* offset,
+                             const long* offset_strides4, void* col, long col_ld, int B, int C, int H, int W,
+                             int KH, int KW, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
+                             int dil_w, int num_deformable_group, int data_dtype, int col_dtype, void* stream);
+
+/* relation_rcnn/operator_cxx/deformable_psroi_pooling.cu:51-138 (DeformablePSROIPoolForwardKernel, called
+ * from deformable_psroi_pooling-inl.h:64-95).  data logical [B, output_dim*group_size^2, H, W]; rois [R,5];
+ * trans fp32 contiguous [R, 2*num_classes, part, part] or NULL (= no_trans); out / top_count logical
+ * [R, output_dim, P, P] with element strides (top_count fp32, may be NULL).  part_size 0 = pooled_size. */
+int relnet_deformable_psroi_pool_fwd(const void* data, const long* data_strides4, const float* rois,
+                                     const float* trans, void* out, const long* out_strides4, float* top_count,
+                                     int R, int C, int H, int W, int output_dim, int group_size, int pooled_size,
+                                     int part_size, int sample_per_part, float spatial_scale, float trans_std,
+                                     int num_classes, int batch_index_base, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,178 @@
+"""CPU restatement of the reference's deformable operators (TEST INFRASTRUCTURE ONLY: imported by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product path).
+
+Follows, operation by operation in float32 (DType = float in the reference):
+  * deformable_im2col_gpu_kernel + deformable_im2col_bilinear
+        relation_rcnn/operator_cxx/nn/deformable_im2col.cuh:76-113, 215-262
+  * DeformableConvolutionOp::Forward (im2col -> per-image GEMM -> + bias)
+        relation_rcnn/operator_cxx/deformable_convolution-inl.h:91-143
+  * DeformablePSROIPoolForwardKernel + bilinear_interp
+        relation_rcnn/operator_cxx/deformable_psroi_pooling.cu:29-138
+
+PARITY UNPINNED: the reference implementation is CUDA-only (no CPU kernel, no tests, no golden
+vectors) and cannot be executed here.  Two things are therefore modelled, not measured:
+  * nvcc contracts `a*b + c` into fma by default; this restatement uses separately rounded fp32
+    multiplies and adds (the difference is <= 1 ulp of a sampling coordinate / blend);
+  * the GEMM summation order of cuBLAS is unknown: convolution outputs are compared with a tolerance.
+The vectorised functions here are themselves checked against line-by-line scalar twins in
+tests/test_oracle_deform.py and against torch conv2d for zero / integer offsets.
+"""
+import numpy as np
+
+F32 = np.float32
+
+
+def _f(x):
+    return np.asarray(x, dtype=F32)
+
+
+def deformable_im2col(data, offset, kernel, pad, stride, dilate, num_deformable_group):
+    """data [C,H,W] f32, offset [2*kh*kw*dg, Ho, Wo] f32 -> col [C*kh*kw, Ho, Wo] f32
+    (row index c*kh*kw + i*kw + j, deformable_im2col.cuh:232,237-259)."""
+    data = _f(data); offset = _f(offset)
+    C, H, W = data.shape
+    kh, kw = kernel
+    Ho = (H + 2 * pad[0] - (dilate[0] * (kh - 1) + 1)) // stride[0] + 1
+    Wo = (W + 2 * pad[1] - (dilate[1] * (kw - 1) + 1)) // stride[1] + 1
+    assert offset.shape == (2 * kh * kw * num_deformable_group, Ho, Wo), (offset.shape, Ho, Wo)
+    cpg = C // num_deformable_group
+    h_in = (np.arange(Ho) * stride[0] - pad[0])[:, None]            # [Ho,1] int
+    w_in = (np.arange(Wo) * stride[1] - pad[1])[None, :]            # [1,Wo] int
+    col = np.zeros((C, kh * kw, Ho, Wo), F32)
+    for g in range(num_deformable_group):
+        d = data[g * cpg:(g + 1) * cpg]
+        for i in range(kh):
+            for j in range(kw):
+                t = i * kw + j
+                off_h = offset[g * 2 * kh * kw + 2 * t]
+                off_w = offset[g * 2 * kh * kw + 2 * t + 1]
+                h_im = (h_in + i * dilate[0]).astype(F32) + off_h              # :245
+                w_im = (w_in + j * dilate[1]).astype(F32) + off_w
+                inside = (h_im >= 0) & (w_im >= 0) & (h_im < H) & (w_im < W)   # :247
+                map_h = np.broadcast_to(F32(i * dilate[0]) + off_h, (Ho, Wo)).copy()   # :248
+                map_w = np.broadcast_to(F32(j * dilate[1]) + off_w, (Ho, Wo)).copy()
+                cur_h = np.broadcast_to(H - h_in, (Ho, Wo))                    # :250
+                cur_w = np.broadcast_to(W - w_in, (Ho, Wo))
+                # deformable_im2col_bilinear, :76-113 (coordinates relative to (h_in, w_in))
+                h_low = np.floor(map_h).astype(np.int64)
+                w_low = np.floor(map_w).astype(np.int64)
+                ch = h_low >= cur_h - 1
+                cw = w_low >= cur_w - 1
+                h_low = np.where(ch, cur_h - 1, h_low); h_high = np.where(ch, h_low, h_low + 1)
+                w_low = np.where(cw, cur_w - 1, w_low); w_high = np.where(cw, w_low, w_low + 1)
+                hh_ = np.where(ch, h_low.astype(F32), map_h)
+                ww_ = np.where(cw, w_low.astype(F32), map_w)
+                lh = (hh_ - h_low.astype(F32)).astype(F32)
+                lw = (ww_ - w_low.astype(F32)).astype(F32)
+                hh = (F32(1) - lh).astype(F32); hw = (F32(1) - lw).astype(F32)
+                w1 = hh * hw; w2 = hh * lw; w3 = lh * hw; w4 = lh * lw
+                # absolute rows / columns (only used where `inside`)
+                ya = np.clip(h_in + h_low, 0, H - 1); yb = np.clip(h_in + h_high, 0, H - 1)
+                xa = np.clip(w_in + w_low, 0, W - 1); xb = np.clip(w_in + w_high, 0, W - 1)
+                v1 = d[:, ya, xa]; v2 = d[:, ya, xb]; v3 = d[:, yb, xa]; v4 = d[:, yb, xb]
+                val = (((w1 * v1).astype(F32) + (w2 * v2).astype(F32)).astype(F32)
+                       + (w3 * v3).astype(F32)).astype(F32) + (w4 * v4).astype(F32)
+                col[g * cpg:(g + 1) * cpg, t] = np.where(inside, val.astype(F32), F32(0))
+    return col.reshape(C * kh * kw, Ho, Wo)
+
+
+def deformable_convolution(data, offset, weight, bias=None, kernel=(3, 3), stride=(1, 1), dilate=(1, 1),
+                           pad=(0, 0), num_deformable_group=1, num_group=1):
+    """data [N,C,H,W], offset [N,2*kh*kw*dg,Ho,Wo], weight [Co,C/group,kh,kw] -> [N,Co,Ho,Wo] f32."""
+    data = _f(data); offset = _f(offset); weight = _f(weight)
+    N, C = data.shape[:2]
+    Co = weight.shape[0]
+    outs = []
+    for n in range(N):
+        col = deformable_im2col(data[n], offset[n], kernel, pad, stride, dilate, num_deformable_group)
+        K, Ho, Wo = col.shape
+        kg = K // num_group
+        mg = Co // num_group
+        out = np.empty((Co, Ho * Wo), F32)
+        colm = col.reshape(K, Ho * Wo)
+        for g in range(num_group):
+            out[g * mg:(g + 1) * mg] = weight[g * mg:(g + 1) * mg].reshape(mg, kg) @ colm[g * kg:(g + 1) * kg]
+        outs.append(out.reshape(Co, Ho, Wo))
+    out = np.stack(outs)
+    if bias is not None:
+        out = (out + _f(bias)[None, :, None, None]).astype(F32)
+    return out
+
+
+def _round_half_away(x):
+    """CUDA round(float): halfway cases away from zero."""
+    x = _f(x)
+    return (np.sign(x) * np.floor(np.abs(x) + F32(0.5))).astype(F32)
+
+
+def deformable_psroi_pooling(data, rois, trans=None, spatial_scale=0.0625, output_dim=256, group_size=1,
+                             pooled_size=7, part_size=0, sample_per_part=1, trans_std=0.0, no_trans=False):
+    """data [B, output_dim*group_size^2, H, W], rois [R,5], trans [R, 2*num_classes, part, part]
+    -> (out [R, output_dim, P, P], top_count same shape), deformable_psroi_pooling.cu:51-138."""
+    data = _f(data); rois = _f(rois)
+    B, Cc, H, W = data.shape
+    R = rois.shape[0]
+    P = pooled_size
+    part = part_size if part_size else P
+    scale = F32(spatial_scale); tstd = F32(trans_std)
+    if no_trans:
+        num_classes = 1
+    else:
+        trans = _f(trans)
+        num_classes = trans.shape[1] // 2
+    ch_each = output_dim if no_trans else output_dim // num_classes
+    out = np.zeros((R, output_dim, P, P), F32)
+    cnt = np.zeros((R, output_dim, P, P), F32)
+    half = F32(0.5)
+    ph = np.arange(P)
+    # part / group indices: fp32 divisions exactly as written (:92-93, :108-111)
+    part_idx = np.floor((ph.astype(F32) / F32(P)).astype(F32) * F32(part)).astype(np.int64)
+    g_idx = np.clip(np.floor((ph.astype(F32) * F32(group_size)).astype(F32) / F32(P)).astype(np.int64), 0, group_size - 1)
+    ctop = np.arange(output_dim)
+    class_id = ctop // ch_each
+    for n in range(R):
+        b = int(rois[n, 0])
+        rs_w = (_round_half_away(rois[n, 1]) * scale).astype(F32) - half
+        rs_h = (_round_half_away(rois[n, 2]) * scale).astype(F32) - half
+        re_w = ((_round_half_away(rois[n, 3]) + F32(1)).astype(F32) * scale).astype(F32) - half
+        re_h = ((_round_half_away(rois[n, 4]) + F32(1)).astype(F32) * scale).astype(F32) - half
+        rw = np.maximum((re_w - rs_w).astype(F32), F32(0.1))
+        rh = np.maximum((re_h - rs_h).astype(F32), F32(0.1))
+        bin_h = (rh / F32(P)).astype(F32); bin_w = (rw / F32(P)).astype(F32)
+        sub_h = (bin_h / F32(sample_per_part)).astype(F32); sub_w = (bin_w / F32(sample_per_part)).astype(F32)
+        if no_trans:
+            tx = np.zeros((output_dim, P, P), F32); ty = np.zeros((output_dim, P, P), F32)
+        else:
+            t = trans[n].reshape(num_classes, 2, part, part)
+            tx = (t[class_id, 0][:, part_idx][:, :, part_idx] * tstd).astype(F32)      # [ctop, ph, pw]
+            ty = (t[class_id, 1][:, part_idx][:, :, part_idx] * tstd).astype(F32)
+        wstart = ((ph.astype(F32) * bin_w).astype(F32) + rs_w).astype(F32)[None, None, :]     # over pw
+        hstart = ((ph.astype(F32) * bin_h).astype(F32) + rs_h).astype(F32)[None, :, None]     # over ph
+        wstart = (wstart + (tx * rw).astype(F32)).astype(F32)
+        hstart = (hstart + (ty * rh).astype(F32)).astype(F32)
+        c = (ctop[:, None, None] * group_size + g_idx[None, :, None]) * group_size + g_idx[None, None, :]
+        d = data[b]
+        s = np.zeros((output_dim, P, P), F32)
+        k = np.zeros((output_dim, P, P), np.int64)
+        for ih in range(sample_per_part):
+            for iw in range(sample_per_part):
+                w = (wstart + (F32(iw) * sub_w).astype(F32)).astype(F32)
+                h = (hstart + (F32(ih) * sub_h).astype(F32)).astype(F32)
+                ok = ~((w < -0.5) | (w > W - 0.5) | (h < -0.5) | (h > H - 0.5))
+                w = np.minimum(np.maximum(w, F32(0)), F32(W - 1)).astype(F32)
+                h = np.minimum(np.maximum(h, F32(0)), F32(H - 1)).astype(F32)
+                x1 = np.floor(w).astype(np.int64); x2 = np.ceil(w).astype(np.int64)
+                y1 = np.floor(h).astype(np.int64); y2 = np.ceil(h).astype(np.int64)
+                dx = (w - x1.astype(F32)).astype(F32); dy = (h - y1.astype(F32)).astype(F32)
+                v11 = d[c, y1, x1]; v12 = d[c, y2, x1]
+                v21 = d[c, y1, x2]; v22 = d[c, y2, x2]
+                one = F32(1)
+                val = ((((one - dx) * (one - dy)).astype(F32) * v11).astype(F32)
+                       + (((one - dx) * dy).astype(F32) * v12).astype(F32)).astype(F32)
+                val = (val + ((dx * (one - dy)).astype(F32) * v21).astype(F32)).astype(F32)
+                val = (val + ((dx * dy).astype(F32) * v22).astype(F32)).astype(F32)
+                s = np.where(ok, (s + val).astype(F32), s)
+                k = k + ok
+        out[n] = np.where(k == 0, F32(0), (s / np.maximum(k, 1).astype(F32)).astype(F32))
+        cnt[n] = k.astype(F32)
+    return out, cnt

@@ -1,0 +1,359 @@
+// Deformable operators of the DCN configuration.
+//
+//  * relnet_deformable_im2col : the sampling half of DeformableConvolutionOp::Forward
+//      (relation_rcnn/operator_cxx/deformable_convolution-inl.h:91-143, kernel
+//       nn/deformable_im2col.cuh:215-262 with deformable_im2col_bilinear :76-113).
+//      The GEMM half is relnet_gemm_nt on the column matrix, with BN / bias / ReLU fused there.
+//  * relnet_deformable_psroi_pool_fwd : DeformablePSROIPoolForwardKernel
+//      (relation_rcnn/operator_cxx/deformable_psroi_pooling.cu:51-138).
+//
+// Layout: element strides are explicit, so the same entry points serve the reference's NCHW fp32
+// tensors (parity) and channels-last bf16 (throughput; 8 channels = 16 bytes per lane).  The column
+// matrix is [B*Ho*Wo][KH*KW*C] with K ordered (tap, channel) -- the K order of the packed conv weights
+// [Cout][KH][KW][Cin], so the GEMM needs no transposes.
+//
+// All coordinate arithmetic is separately rounded fp32 (contract off) in the order the reference writes
+// it; oracle/deform.py is the matching CPU restatement.
+#include "common.h"
+
+namespace relnet {
+
+enum { RELNET_F32 = 0, RELNET_BF16 = 1 };
+
+struct DeformColArgs {
+  const void* data; long ds_b, ds_c, ds_h, ds_w;        // [B,C,H,W] element strides
+  const float* offset; long fs_b, fs_c, fs_h, fs_w;     // [B, 2*KH*KW*DG, Ho, Wo]
+  void* col; long col_ld;                               // [B*Ho*Wo][col_ld], K = KH*KW*C used
+  int B, C, H, W, Ho, Wo, KH, KW, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, DG;
+};
+
+template <typename T> __device__ __forceinline__ float dld(const T* p);
+template <> __device__ __forceinline__ float dld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float dld<unsigned short>(const unsigned short* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void dst(T* p, float v);
+template <> __device__ __forceinline__ void dst<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void dst<unsigned short>(unsigned short* p, float v) { *p = f2bf(v); }
+
+#pragma clang fp contract(off)
+
+// Bilinear taps of one (output pixel, kernel tap, deformable group): deformable_im2col.cuh:241-252 + :76-113.
+struct Taps {
+  bool inside;
+  int ya, yb, xa, xb;        // absolute rows / columns of the 4 corners
+  float w1, w2, w3, w4;
+};
+__device__ __forceinline__ Taps deform_taps(const DeformColArgs& g, int b, int ho, int wo, int i, int j, int dgi) {
+  Taps t;
+  const int tap = i * g.KW + j;
+  const float* po = g.offset + (long)b * g.fs_b + (long)ho * g.fs_h + (long)wo * g.fs_w +
+                    (long)(dgi * 2 * g.KH * g.KW + 2 * tap) * g.fs_c;
+  const float off_h = po[0], off_w = po[g.fs_c];
+  const int h_in = ho * g.stride_h - g.pad_h, w_in = wo * g.stride_w - g.pad_w;
+  const float h_im = (float)(h_in + i * g.dil_h) + off_h;
+  const float w_im = (float)(w_in + j * g.dil_w) + off_w;
+  t.inside = (h_im >= 0.f) && (w_im >= 0.f) && (h_im < (float)g.H) && (w_im < (float)g.W);
+  float mh = (float)(i * g.dil_h) + off_h, mw = (float)(j * g.dil_w) + off_w;
+  const int cur_h = g.H - h_in, cur_w = g.W - w_in;
+  int h_low = (int)floorf(mh), w_low = (int)floorf(mw), h_high, w_high;
+  if (h_low >= cur_h - 1) { h_high = h_low = cur_h - 1; mh = (float)h_low; } else h_high = h_low + 1;
+  if (w_low >= cur_w - 1) { w_high = w_low = cur_w - 1; mw = (float)w_low; } else w_high = w_low + 1;
+  const float lh = mh - (float)h_low, lw = mw - (float)w_low;
+  const float hh = 1.f - lh, hw = 1.f - lw;
+  t.w1 = hh * hw; t.w2 = hh * lw; t.w3 = lh * hw; t.w4 = lh * lw;
+  t.ya = min(max(h_in + h_low, 0), g.H - 1); t.yb = min(max(h_in + h_high, 0), g.H - 1);
+  t.xa = min(max(w_in + w_low, 0), g.W - 1); t.xb = min(max(w_in + w_high, 0), g.W - 1);
+  return t;
+}
+
+// Generic strides: one thread per (pixel, tap, channel), channel fastest.
+template <typename TIN, typename TCOL>
+__global__ __launch_bounds__(256) void deformable_im2col_kernel(DeformColArgs g) {
+  const long total = (long)g.B * g.Ho * g.Wo * g.KH * g.KW * g.C;
+  const int cpg = g.C / g.DG;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % g.C);
+    long r = idx / g.C;
+    const int tap = (int)(r % (g.KH * g.KW)); r /= (g.KH * g.KW);
+    const int wo = (int)(r % g.Wo); r /= g.Wo;
+    const int ho = (int)(r % g.Ho);
+    const int b = (int)(r / g.Ho);
+    const Taps t = deform_taps(g, b, ho, wo, tap / g.KW, tap % g.KW, c / cpg);
+    float val = 0.f;
+    if (t.inside) {
+      const TIN* p = (const TIN*)g.data + (long)b * g.ds_b + (long)c * g.ds_c;
+      const float v1 = dld<TIN>(p + (long)t.ya * g.ds_h + (long)t.xa * g.ds_w);
+      const float v2 = dld<TIN>(p + (long)t.ya * g.ds_h + (long)t.xb * g.ds_w);
+      const float v3 = dld<TIN>(p + (long)t.yb * g.ds_h + (long)t.xa * g.ds_w);
+      const float v4 = dld<TIN>(p + (long)t.yb * g.ds_h + (long)t.xb * g.ds_w);
+      val = t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4;
+    }
+    const long row = ((long)b * g.Ho + ho) * g.Wo + wo;
+    dst<TCOL>((TCOL*)g.col + row * g.col_ld + (long)tap * g.C + c, val);
+  }
+}
+
+// Channels-last bf16: one thread per (pixel, tap, 8-channel chunk); four 16-byte corner loads, one
+// 16-byte store.  Requires ds_c == 1, C % 8 == 0, (C / DG) % 8 == 0 and 16-byte aligned strides.
+__global__ __launch_bounds__(256) void deformable_im2col_cl_kernel(DeformColArgs g) {
+  const int chunks = g.C / 8;
+  const long total = (long)g.B * g.Ho * g.Wo * g.KH * g.KW * chunks;
+  const int cpg = g.C / g.DG;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int cc = (int)(idx % chunks);
+    long r = idx / chunks;
+    const int tap = (int)(r % (g.KH * g.KW)); r /= (g.KH * g.KW);
+    const int wo = (int)(r % g.Wo); r /= g.Wo;
+    const int ho = (int)(r % g.Ho);
+    const int b = (int)(r / g.Ho);
+    const int c = cc * 8;
+    const Taps t = deform_taps(g, b, ho, wo, tap / g.KW, tap % g.KW, c / cpg);
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (t.inside) {
+      const unsigned short* p = (const unsigned short*)g.data + (long)b * g.ds_b + c;
+      const uint4 q1 = *(const uint4*)(p + (long)t.ya * g.ds_h + (long)t.xa * g.ds_w);
+      const uint4 q2 = *(const uint4*)(p + (long)t.ya * g.ds_h + (long)t.xb * g.ds_w);
+      const uint4 q3 = *(const uint4*)(p + (long)t.yb * g.ds_h + (long)t.xa * g.ds_w);
+      const uint4 q4 = *(const uint4*)(p + (long)t.yb * g.ds_h + (long)t.xb * g.ds_w);
+      const unsigned int* a1 = (const unsigned int*)&q1; const unsigned int* a2 = (const unsigned int*)&q2;
+      const unsigned int* a3 = (const unsigned int*)&q3; const unsigned int* a4 = (const unsigned int*)&q4;
+      unsigned int* po = (unsigned int*)&o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float lo = t.w1 * __uint_as_float(a1[k] << 16) + t.w2 * __uint_as_float(a2[k] << 16) +
+                         t.w3 * __uint_as_float(a3[k] << 16) + t.w4 * __uint_as_float(a4[k] << 16);
+        const float hi = t.w1 * __uint_as_float(a1[k] & 0xffff0000u) + t.w2 * __uint_as_float(a2[k] & 0xffff0000u) +
+                         t.w3 * __uint_as_float(a3[k] & 0xffff0000u) + t.w4 * __uint_as_float(a4[k] & 0xffff0000u);
+        po[k] = pack_bf16x2(lo, hi);
+      }
+    }
+    const long row = ((long)b * g.Ho + ho) * g.Wo + wo;
+    *(uint4*)((unsigned short*)g.col + row * g.col_ld + (long)tap * g.C + c) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct PsroiArgs {
+  const void* data; long ds_b, ds_c, ds_h, ds_w;       // [B, output_dim*group^2, H, W]
+  const float* rois;                                   // [R,5]
+  const float* trans;                                  // [R, 2*num_classes, part, part] or nullptr (no_trans)
+  void* out; long os_r, os_c, os_ph, os_pw;            // [R, output_dim, P, P]
+  float* top_count;                                    // same strides as out, or nullptr
+  int R, H, W, output_dim, group, P, part, spp, num_classes, ch_each, batch_index_base;
+  float scale, trans_std;
+};
+
+struct RoiGeom { float start_w, start_h, roi_w, roi_h, bin_w, bin_h, sub_w, sub_h; int b; };
+__device__ __forceinline__ RoiGeom psroi_geom(const PsroiArgs& g, int n) {
+  const float* roi = g.rois + (long)n * 5;
+  RoiGeom q;
+  q.b = (int)roi[0] - g.batch_index_base;
+  q.start_w = roundf(roi[1]) * g.scale - 0.5f;                  // :67-70
+  q.start_h = roundf(roi[2]) * g.scale - 0.5f;
+  const float end_w = (roundf(roi[3]) + 1.f) * g.scale - 0.5f;
+  const float end_h = (roundf(roi[4]) + 1.f) * g.scale - 0.5f;
+  q.roi_w = fmaxf(end_w - q.start_w, 0.1f);                     // :73-74
+  q.roi_h = fmaxf(end_h - q.start_h, 0.1f);
+  q.bin_h = q.roi_h / (float)g.P; q.bin_w = q.roi_w / (float)g.P;
+  q.sub_h = q.bin_h / (float)g.spp; q.sub_w = q.bin_w / (float)g.spp;
+  return q;
+}
+
+// One thread per (roi, ph, pw, ctop), ctop fastest.
+template <typename T>
+__global__ __launch_bounds__(256) void deformable_psroi_pool_fwd_kernel(PsroiArgs g) {
+  const long total = (long)g.R * g.P * g.P * g.output_dim;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int ctop = (int)(idx % g.output_dim);
+    long r = idx / g.output_dim;
+    const int pw = (int)(r % g.P); r /= g.P;
+    const int ph = (int)(r % g.P);
+    const int n = (int)(r / g.P);
+    const RoiGeom q = psroi_geom(g, n);
+    const int part_h = (int)floorf((float)ph / (float)g.P * (float)g.part);       // :92-93
+    const int part_w = (int)floorf((float)pw / (float)g.P * (float)g.part);
+    float tx = 0.f, ty = 0.f;
+    if (g.trans) {
+      const int cls = ctop / g.ch_each;
+      const float* pt = g.trans + ((((long)n * g.num_classes + cls) * 2) * g.part + part_h) * g.part + part_w;
+      tx = pt[0] * g.trans_std;
+      ty = pt[(long)g.part * g.part] * g.trans_std;
+    }
+    float wstart = (float)pw * q.bin_w + q.start_w; wstart = wstart + tx * q.roi_w;    // :100-105
+    float hstart = (float)ph * q.bin_h + q.start_h; hstart = hstart + ty * q.roi_h;
+    int gw = (int)floorf((float)pw * (float)g.group / (float)g.P);
+    int gh = (int)floorf((float)ph * (float)g.group / (float)g.P);
+    gw = min(max(gw, 0), g.group - 1); gh = min(max(gh, 0), g.group - 1);
+    const int c = (ctop * g.group + gh) * g.group + gw;
+    const T* pc = (const T*)g.data + (long)q.b * g.ds_b + (long)c * g.ds_c;
+    float sum = 0.f; int count = 0;
+    for (int ih = 0; ih < g.spp; ++ih)
+      for (int iw = 0; iw < g.spp; ++iw) {
+        float w = wstart + (float)iw * q.sub_w;
+        float h = hstart + (float)ih * q.sub_h;
+        if (w < -0.5f || w > (float)g.W - 0.5f || h < -0.5f || h > (float)g.H - 0.5f) continue;
+        w = fminf(fmaxf(w, 0.f), (float)g.W - 1.f);
+        h = fminf(fmaxf(h, 0.f), (float)g.H - 1.f);
+        const int x1 = (int)floorf(w), x2 = (int)ceilf(w), y1 = (int)floorf(h), y2 = (int)ceilf(h);
+        const float dx = w - (float)x1, dy = h - (float)y1;
+        const float v11 = dld<T>(pc + (long)y1 * g.ds_h + (long)x1 * g.ds_w);
+        const float v12 = dld<T>(pc + (long)y2 * g.ds_h + (long)x1 * g.ds_w);
+        const float v21 = dld<T>(pc + (long)y1 * g.ds_h + (long)x2 * g.ds_w);
+        const float v22 = dld<T>(pc + (long)y2 * g.ds_h + (long)x2 * g.ds_w);
+        const float val = (1.f - dx) * (1.f - dy) * v11 + (1.f - dx) * dy * v12 + dx * (1.f - dy) * v21 + dx * dy * v22;
+        sum = sum + val;
+        ++count;
+      }
+    const long o = (long)n * g.os_r + (long)ctop * g.os_c + (long)ph * g.os_ph + (long)pw * g.os_pw;
+    dst<T>((T*)g.out + o, count == 0 ? 0.f : sum / (float)count);
+    if (g.top_count) g.top_count[o] = (float)count;
+  }
+}
+
+// Channels-last bf16, group_size 1, one class of offsets: thread = (roi, bin, 8-channel chunk).
+__global__ __launch_bounds__(256) void deformable_psroi_pool_fwd_cl_kernel(PsroiArgs g) {
+  const int chunks = g.output_dim / 8;
+  const long total = (long)g.R * g.P * g.P * chunks;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int cc = (int)(idx % chunks);
+    long r = idx / chunks;
+    const int pw = (int)(r % g.P); r /= g.P;
+    const int ph = (int)(r % g.P);
+    const int n = (int)(r / g.P);
+    const RoiGeom q = psroi_geom(g, n);
+    const int part_h = (int)floorf((float)ph / (float)g.P * (float)g.part);
+    const int part_w = (int)floorf((float)pw / (float)g.P * (float)g.part);
+    float tx = 0.f, ty = 0.f;
+    if (g.trans) {
+      const float* pt = g.trans + (((long)n * 2) * g.part + part_h) * g.part + part_w;
+      tx = pt[0] * g.trans_std;
+      ty = pt[(long)g.part * g.part] * g.trans_std;
+    }
+    float wstart = (float)pw * q.bin_w + q.start_w; wstart = wstart + tx * q.roi_w;
+    float hstart = (float)ph * q.bin_h + q.start_h; hstart = hstart + ty * q.roi_h;
+    const unsigned short* pc = (const unsigned short*)g.data + (long)q.b * g.ds_b + cc * 8;
+    float sum[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum[k] = 0.f;
+    int count = 0;
+    for (int ih = 0; ih < g.spp; ++ih)
+      for (int iw = 0; iw < g.spp; ++iw) {
+        float w = wstart + (float)iw * q.sub_w;
+        float h = hstart + (float)ih * q.sub_h;
+        if (w < -0.5f || w > (float)g.W - 0.5f || h < -0.5f || h > (float)g.H - 0.5f) continue;
+        w = fminf(fmaxf(w, 0.f), (float)g.W - 1.f);
+        h = fminf(fmaxf(h, 0.f), (float)g.H - 1.f);
+        const int x1 = (int)floorf(w), x2 = (int)ceilf(w), y1 = (int)floorf(h), y2 = (int)ceilf(h);
+        const float dx = w - (float)x1, dy = h - (float)y1;
+        const float c11 = (1.f - dx) * (1.f - dy), c12 = (1.f - dx) * dy, c21 = dx * (1.f - dy), c22 = dx * dy;
+        const uint4 q11 = *(const uint4*)(pc + (long)y1 * g.ds_h + (long)x1 * g.ds_w);
+        const uint4 q12 = *(const uint4*)(pc + (long)y2 * g.ds_h + (long)x1 * g.ds_w);
+        const uint4 q21 = *(const uint4*)(pc + (long)y1 * g.ds_h + (long)x2 * g.ds_w);
+        const uint4 q22 = *(const uint4*)(pc + (long)y2 * g.ds_h + (long)x2 * g.ds_w);
+        const unsigned int* a = (const unsigned int*)&q11; const unsigned int* bq = (const unsigned int*)&q12;
+        const unsigned int* cq = (const unsigned int*)&q21; const unsigned int* d = (const unsigned int*)&q22;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float lo = c11 * __uint_as_float(a[k] << 16) + c12 * __uint_as_float(bq[k] << 16) +
+                           c21 * __uint_as_float(cq[k] << 16) + c22 * __uint_as_float(d[k] << 16);
+          const float hi = c11 * __uint_as_float(a[k] & 0xffff0000u) + c12 * __uint_as_float(bq[k] & 0xffff0000u) +
+                           c21 * __uint_as_float(cq[k] & 0xffff0000u) + c22 * __uint_as_float(d[k] & 0xffff0000u);
+          sum[2 * k] = sum[2 * k] + lo;
+          sum[2 * k + 1] = sum[2 * k + 1] + hi;
+        }
+        ++count;
+      }
+    uint4 o4;
+    unsigned int* po = (unsigned int*)&o4;
+    const float fc = (float)max(count, 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      po[k] = pack_bf16x2(count == 0 ? 0.f : sum[2 * k] / fc, count == 0 ? 0.f : sum[2 * k + 1] / fc);
+    const long o = (long)n * g.os_r + (long)cc * 8 + (long)ph * g.os_ph + (long)pw * g.os_pw;
+    *(uint4*)((unsigned short*)g.out + o) = o4;
+  }
+}
+
+static inline unsigned grid_for(long total) {
+  long blocks = (total + 255) / 256;
+  const long cap = 256L * 64;              // grid-stride beyond 64 blocks per CU
+  return (unsigned)(blocks < cap ? blocks : cap);
+}
+
+}  // namespace relnet
+
+using namespace relnet;
+
+extern "C" int relnet_deformable_im2col(const void* data, const long* data_strides4, const float* offset,
+                                        const long* offset_strides4, void* col, long col_ld, int B, int C,
+                                        int H, int W, int KH, int KW, int pad_h, int pad_w, int stride_h,
+                                        int stride_w, int dil_h, int dil_w, int num_deformable_group,
+                                        int data_dtype, int col_dtype, void* stream) {
+  RELNET_REQUIRE(data && offset && col && data_strides4 && offset_strides4, "relnet_deformable_im2col: null operand");
+  RELNET_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride_h > 0 && stride_w > 0 &&
+                 dil_h > 0 && dil_w > 0 && pad_h >= 0 && pad_w >= 0, "relnet_deformable_im2col: bad shape");
+  RELNET_REQUIRE(num_deformable_group > 0 && C % num_deformable_group == 0,
+                 "relnet_deformable_im2col: input channels %d must divide deformable group size %d", C, num_deformable_group);
+  DeformColArgs g;
+  g.data = data; g.ds_b = data_strides4[0]; g.ds_c = data_strides4[1]; g.ds_h = data_strides4[2]; g.ds_w = data_strides4[3];
+  g.offset = offset; g.fs_b = offset_strides4[0]; g.fs_c = offset_strides4[1]; g.fs_h = offset_strides4[2]; g.fs_w = offset_strides4[3];
+  g.col = col; g.col_ld = col_ld;
+  g.B = B; g.C = C; g.H = H; g.W = W; g.KH = KH; g.KW = KW; g.pad_h = pad_h; g.pad_w = pad_w;
+  g.stride_h = stride_h; g.stride_w = stride_w; g.dil_h = dil_h; g.dil_w = dil_w; g.DG = num_deformable_group;
+  g.Ho = (H + 2 * pad_h - (dil_h * (KH - 1) + 1)) / stride_h + 1;
+  g.Wo = (W + 2 * pad_w - (dil_w * (KW - 1) + 1)) / stride_w + 1;
+  RELNET_REQUIRE(g.Ho > 0 && g.Wo > 0, "relnet_deformable_im2col: empty output");
+  RELNET_REQUIRE(col_ld >= (long)KH * KW * C, "relnet_deformable_im2col: col_ld %ld < K %ld", col_ld, (long)KH * KW * C);
+  hipStream_t s = (hipStream_t)stream;
+  const long pixels = (long)B * g.Ho * g.Wo * KH * KW;
+  if (data_dtype == RELNET_BF16 && col_dtype == RELNET_BF16 && g.ds_c == 1 && C % 8 == 0 &&
+      (C / num_deformable_group) % 8 == 0 && g.ds_h % 8 == 0 && g.ds_w % 8 == 0 && g.ds_b % 8 == 0 && col_ld % 8 == 0 &&
+      ((uintptr_t)data & 15) == 0 && ((uintptr_t)col & 15) == 0) {
+    deformable_im2col_cl_kernel<<<grid_for(pixels * (C / 8)), 256, 0, s>>>(g);
+    return check_launch("relnet_deformable_im2col");
+  }
+  const unsigned grid = grid_for(pixels * C);
+  if (data_dtype == RELNET_F32 && col_dtype == RELNET_F32) deformable_im2col_kernel<float, float><<<grid, 256, 0, s>>>(g);
+  else if (data_dtype == RELNET_F32 && col_dtype == RELNET_BF16) deformable_im2col_kernel<float, unsigned short><<<grid, 256, 0, s>>>(g);
+  else if (data_dtype == RELNET_BF16 && col_dtype == RELNET_BF16) deformable_im2col_kernel<unsigned short, unsigned short><<<grid, 256, 0, s>>>(g);
+  else if (data_dtype == RELNET_BF16 && col_dtype == RELNET_F32) deformable_im2col_kernel<unsigned short, float><<<grid, 256, 0, s>>>(g);
+  else RELNET_REQUIRE(false, "relnet_deformable_im2col: unknown dtype %d/%d", data_dtype, col_dtype);
+  return check_launch("relnet_deformable_im2col");
+}
+
+extern "C" int relnet_deformable_psroi_pool_fwd(const void* data, const long* data_strides4, const float* rois,
+                                                const float* trans, void* out, const long* out_strides4,
+                                                float* top_count, int R, int C, int H, int W, int output_dim,
+                                                int group_size, int pooled_size, int part_size,
+                                                int sample_per_part, float spatial_scale, float trans_std,
+                                                int num_classes, int batch_index_base, int dtype, void* stream) {
+  RELNET_REQUIRE(data && rois && out && data_strides4 && out_strides4, "relnet_deformable_psroi_pool_fwd: null operand");
+  RELNET_REQUIRE(R > 0 && C > 0 && H > 0 && W > 0 && output_dim > 0 && group_size > 0 && pooled_size > 0 &&
+                 sample_per_part > 0, "relnet_deformable_psroi_pool_fwd: bad shape");
+  RELNET_REQUIRE(C == output_dim * group_size * group_size,
+                 "relnet_deformable_psroi_pool_fwd: data channels %d != output_dim*group_size^2 = %d", C,
+                 output_dim * group_size * group_size);
+  const bool no_trans = (trans == nullptr);
+  RELNET_REQUIRE(no_trans || (num_classes > 0 && output_dim % num_classes == 0),
+                 "relnet_deformable_psroi_pool_fwd: output_dim %d not divisible by num_classes %d", output_dim, num_classes);
+  PsroiArgs g;
+  g.data = data; g.ds_b = data_strides4[0]; g.ds_c = data_strides4[1]; g.ds_h = data_strides4[2]; g.ds_w = data_strides4[3];
+  g.rois = rois; g.trans = trans; g.out = out;
+  g.os_r = out_strides4[0]; g.os_c = out_strides4[1]; g.os_ph = out_strides4[2]; g.os_pw = out_strides4[3];
+  g.top_count = top_count; g.R = R; g.H = H; g.W = W; g.output_dim = output_dim; g.group = group_size;
+  g.P = pooled_size; g.part = part_size > 0 ? part_size : pooled_size; g.spp = sample_per_part;
+  g.num_classes = no_trans ? 1 : num_classes; g.ch_each = no_trans ? output_dim : output_dim / num_classes;
+  g.batch_index_base = batch_index_base; g.scale = spatial_scale; g.trans_std = trans_std;
+  hipStream_t s = (hipStream_t)stream;
+  const long bins = (long)R * pooled_size * pooled_size;
+  if (dtype == RELNET_BF16 && !top_count && group_size == 1 && g.num_classes == 1 && output_dim % 8 == 0 && g.ds_c == 1 &&
+      g.os_c == 1 && g.ds_h % 8 == 0 && g.ds_w % 8 == 0 && g.ds_b % 8 == 0 && g.os_r % 8 == 0 && g.os_ph % 8 == 0 &&
+      g.os_pw % 8 == 0 && ((uintptr_t)data & 15) == 0 && ((uintptr_t)out & 15) == 0) {
+    deformable_psroi_pool_fwd_cl_kernel<<<grid_for(bins * (output_dim / 8)), 256, 0, s>>>(g);
+    return check_launch("relnet_deformable_psroi_pool_fwd");
+  }
+  const unsigned grid = grid_for(bins * output_dim);
+  if (dtype == RELNET_F32) deformable_psroi_pool_fwd_kernel<float><<<grid, 256, 0, s>>>(g);
+  else if (dtype == RELNET_BF16) deformable_psroi_pool_fwd_kernel<unsigned short><<<grid, 256, 0, s>>>(g);
+  else RELNET_REQUIRE(false, "relnet_deformable_psroi_pool_fwd: unknown dtype %d", dtype);
+  return check_launch("relnet_deformable_psroi_pool_fwd");
+}

@@ -408,3 +408,75 @@ def nms_multi_target(bbox, gt_boxes, score, num_gt=None, target_thresh=(0.5, 0.6
     _lib.call('relnet_nms_multi_target', bbox.contiguous().data_ptr(), gt_boxes.contiguous().data_ptr(), num_gt.data_ptr(),
               score.contiguous().data_ptr(), out.data_ptr(), B, F, Cn, G, th, T, _stream())
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# DCN configuration
+# ---------------------------------------------------------------------------------------
+def _pair(v):
+    return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+def deformable_im2col(data, offset, kernel=(3, 3), stride=(1, 1), dilate=(1, 1), pad=(0, 0),
+                      num_deformable_group=1, col_dtype=None, col=None):
+    """data: logical [B,C,H,W] of any strides (NCHW fp32 or channels_last bf16); offset: fp32 logical
+    [B, 2*kh*kw*dg, Ho, Wo] of any strides -> col [B*Ho*Wo, kh*kw*C] (column (i*kw+j)*C + c);
+    nn/deformable_im2col.cuh:215-262."""
+    _chk(data, offset, col)
+    assert offset.dtype == torch.float32
+    kh, kw = _pair(kernel); sh, sw = _pair(stride); dh, dw = _pair(dilate); ph, pw = _pair(pad)
+    B, Cc, H, W = data.shape
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    if tuple(offset.shape) != (B, 2 * kh * kw * num_deformable_group, Ho, Wo):
+        raise ValueError("offset shape %s, expected %s (output size and 2*kh*kw*num_deformable_group channels, "
+                         "deformable_convolution-inl.h:389-396)" % (tuple(offset.shape), (B, 2 * kh * kw * num_deformable_group, Ho, Wo)))
+    cdt = col_dtype or (col.dtype if col is not None else data.dtype)
+    if col is None:
+        col = torch.empty((B * Ho * Wo, kh * kw * Cc), device=data.device, dtype=cdt)
+    assert col.stride(1) == 1 and col.shape[0] == B * Ho * Wo
+    _lib.call('relnet_deformable_im2col', data.data_ptr(), _strides4(data), offset.data_ptr(), _strides4(offset),
+              col.data_ptr(), col.stride(0), B, Cc, H, W, kh, kw, ph, pw, sh, sw, dh, dw, num_deformable_group,
+              _dt(data), _dt(col), _stream(), tag='B%d_C%d_%dx%d' % (B, Cc, Ho, Wo))
+    return col, (Ho, Wo)
+
+
+def deformable_conv(data, offset, w_packed, bias=None, kernel=(3, 3), stride=(1, 1), dilate=(1, 1), pad=(0, 0),
+                    num_deformable_group=1, relu=False, out_dtype=None):
+    """DeformableConvolutionOp::Forward (deformable_convolution-inl.h:91-143): sampling kernel + GEMM with
+    the bias (or folded BatchNorm) and ReLU fused.  w_packed [Cout, kh*kw*Cin] (pack_conv_weight order).
+    Returns logical [B, Cout, Ho, Wo] in channels-last memory ([B,Ho,Wo,Cout] contiguous)."""
+    col, (Ho, Wo) = deformable_im2col(data, offset, kernel, stride, dilate, pad, num_deformable_group,
+                                      col_dtype=w_packed.dtype)
+    y = gemm_nt(col, w_packed, bias, relu=relu, out_dtype=out_dtype)
+    return y.view(data.shape[0], Ho, Wo, w_packed.shape[0]).permute(0, 3, 1, 2)
+
+
+def deformable_psroi_pool(data, rois, trans=None, spatial_scale=0.0625, output_dim=256, group_size=1,
+                          pooled_size=7, part_size=0, sample_per_part=1, trans_std=0.0, no_trans=False,
+                          channels_last_out=False, want_top_count=False, batch_index_base=0):
+    """DeformablePSROIPooling forward (deformable_psroi_pooling.cu:51-138).  data logical
+    [B, output_dim*group_size^2, H, W] (any strides); rois [R,5]; trans [R, 2*num_classes, part, part]
+    fp32 unless no_trans.  Output logical [R, output_dim, P, P] (memory (R,P,P,C) when channels_last_out)."""
+    _chk(data, rois, trans)
+    assert rois.dtype == torch.float32 and rois.is_contiguous()
+    B, Cc, H, W = data.shape
+    R, P = rois.shape[0], int(pooled_size)
+    num_classes = 0
+    if not no_trans:
+        if trans is None:
+            raise ValueError("DeformablePSROIPooling: trans is required unless no_trans (deformable_psroi_pooling-inl.h:70-72)")
+        assert trans.dtype == torch.float32 and trans.is_contiguous()
+        part = part_size or P
+        num_classes = trans.shape[1] // 2
+        assert tuple(trans.shape) == (R, 2 * num_classes, part, part), trans.shape
+    if channels_last_out:
+        out = torch.empty((R, P, P, output_dim), device=data.device, dtype=data.dtype).permute(0, 3, 1, 2)
+    else:
+        out = torch.empty((R, output_dim, P, P), device=data.device, dtype=data.dtype)
+    cnt = torch.empty_strided(out.shape, out.stride(), device=data.device, dtype=torch.float32) if want_top_count else None
+    _lib.call('relnet_deformable_psroi_pool_fwd', data.data_ptr(), _strides4(data), rois.data_ptr(),
+              0 if no_trans else trans.data_ptr(), out.data_ptr(), _strides4(out), _ptr(cnt), R, Cc, H, W,
+              int(output_dim), int(group_size), P, int(part_size), int(sample_per_part), float(spatial_scale),
+              float(trans_std), num_classes, batch_index_base, _dt(data), _stream())
+    return (out, cnt) if want_top_count else out

@@ -108,3 +108,32 @@ def test_oracle_roi_pooling_micro_case():
     assert out[0, 0].tolist() == [[28.0, 31.0], [44.0, 47.0]]
     assert out[1, 0].tolist() == [[18.0, 19.0], [26.0, 27.0]]
     assert arg[1, 0].tolist() == [[18, 19], [26, 27]]
+
+
+def test_operator_cxx_property_shapes():
+    """operator_cxx mirror: parameter defaults, argument lists and InferShape rules of the reference's
+    DeformableConvolutionProp / DeformablePSROIPoolingProp (deformable_convolution-inl.h:294-400,
+    deformable_psroi_pooling-inl.h:153-230) -- host logic only."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import operator_cxx as cxx
+    p = cxx.DeformableConvolutionProp(kernel='(3, 3)', num_filter='512', pad='(2, 2)', dilate='(2, 2)',
+                                      num_deformable_group='4', no_bias='True')
+    assert p.ListArguments() == ['data', 'offset', 'weight'] and p.param_.stride == (1, 1)
+    shapes, (out,) = p.InferShape([(1, 512, 38, 63), (1, 72, 38, 63), None])
+    assert out == (1, 512, 38, 63) and shapes[2] == (512, 512, 3, 3)
+    q = cxx.DeformableConvolutionProp(kernel=(3, 3), num_filter=8)
+    assert q.ListArguments() == ['data', 'offset', 'weight', 'bias']
+    assert q.InferShape([(2, 4, 9, 9), (2, 18, 7, 7), None, None])[1] == [(2, 8, 7, 7)]
+    import pytest
+    with pytest.raises(ValueError):
+        q.InferShape([(2, 4, 9, 9), (2, 18, 9, 9), None, None])          # offset map size != output size
+    with pytest.raises(ValueError):
+        q.InferShape([(2, 4, 9, 9), (2, 36, 7, 7), None, None])          # offset channels vs deformable groups
+    with pytest.raises(ValueError):
+        q.InferShape([(2, 4, 9, 9), (2, 18, 7, 7), None])                # bias missing
+    r = cxx.DeformablePSROIPoolingProp(spatial_scale='0.0625', output_dim='256', group_size='1', pooled_size='7',
+                                      part_size='7', sample_per_part='4', trans_std='0.1')
+    assert r.ListArguments() == ['data', 'rois', 'trans'] and r.NumVisibleOutputs() == 1
+    assert r.InferShape([(1, 256, 38, 63), (300, 5), (300, 2, 7, 7)])[1] == [(300, 256, 7, 7)] * 2
+    with pytest.raises(ValueError):
+        cxx.DeformablePSROIPoolingParam(spatial_scale=2.0, output_dim=1, group_size=1, pooled_size=7)

@@ -1,0 +1,204 @@
+"""GPU parity of the DCN operators against oracle/deform.py.
+
+Tolerances: sampling (column matrix, pooled bins, top_count) is bit-exact -- the device code and the
+oracle execute the same separately rounded fp32 operations; convolution outputs (a GEMM over K = kh*kw*C)
+are compared at 1e-5 * sqrt(K) relative to the output scale (summation order differs)."""
+import os
+import sys
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import deform  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def _mods():
+    import relnet_amd
+    from relnet_amd import ops, operator_cxx
+    return ops, operator_cxx
+
+
+def _bf16_round(x):
+    return torch.as_tensor(x).to(torch.bfloat16).float().numpy()
+
+
+def _col_to_oracle_layout(col, B, C, Ho, Wo, kk):
+    """[B*Ho*Wo, kk*C] (tap, c) -> [B, C*kk, Ho, Wo] with row c*kk + tap."""
+    return col.reshape(B, Ho, Wo, kk, C).transpose(0, 4, 3, 1, 2).reshape(B, C * kk, Ho, Wo)
+
+
+CASES = [
+    # B, C, H, W, k, pad, stride, dil, dg, offset sigma
+    (2, 16, 13, 17, 3, 2, 1, 2, 4, 2.0),
+    (1, 8, 12, 9, 3, 1, 2, 1, 1, 4.0),
+    (1, 32, 38, 63, 3, 2, 1, 2, 4, 1.0),        # res5 geometry, fewer channels
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_im2col_fp32_nchw_bit_exact(case):
+    ops, _ = _mods()
+    B, C, H, W, k, pad, st, dil, dg, sig = case
+    rng = np.random.default_rng(7)
+    data = rng.normal(0, 1, (B, C, H, W)).astype(F)
+    Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // st + 1
+    Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // st + 1
+    off = rng.normal(0, sig, (B, 2 * k * k * dg, Ho, Wo)).astype(F)
+    col, (ho, wo) = ops.deformable_im2col(torch.as_tensor(data).cuda(), torch.as_tensor(off).cuda(), k, st, dil, pad, dg)
+    assert (ho, wo) == (Ho, Wo)
+    got = _col_to_oracle_layout(col.cpu().numpy(), B, C, Ho, Wo, k * k)
+    want = np.stack([deform.deformable_im2col(data[b], off[b], (k, k), (pad, pad), (st, st), (dil, dil), dg) for b in range(B)])
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_im2col_bf16_channels_last_bit_exact(case):
+    """Throughput layout: channels-last bf16 activations, vector kernel; fp32 blend rounded once to bf16."""
+    ops, _ = _mods()
+    B, C, H, W, k, pad, st, dil, dg, sig = case
+    rng = np.random.default_rng(8)
+    data = _bf16_round(rng.normal(0, 1, (B, C, H, W)).astype(F))
+    Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // st + 1
+    Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // st + 1
+    off = rng.normal(0, sig, (B, 2 * k * k * dg, Ho, Wo)).astype(F)
+    x = torch.as_tensor(data).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    o = torch.as_tensor(off).cuda().contiguous(memory_format=torch.channels_last)      # offsets channels-last too
+    col, _ = ops.deformable_im2col(x, o, k, st, dil, pad, dg)
+    assert col.dtype == torch.bfloat16
+    got = _col_to_oracle_layout(col.float().cpu().numpy(), B, C, Ho, Wo, k * k)
+    want = np.stack([deform.deformable_im2col(data[b], off[b], (k, k), (pad, pad), (st, st), (dil, dil), dg) for b in range(B)])
+    assert np.array_equal(got, _bf16_round(want))
+    # the generic-stride kernel (NCHW bf16) gives the same bits
+    col2, _ = ops.deformable_im2col(torch.as_tensor(data).cuda().to(torch.bfloat16), torch.as_tensor(off).cuda(), k, st, dil, pad, dg)
+    assert torch.equal(col, col2)
+
+
+def test_deformable_convolution_operator_fp32():
+    """`mx.contrib.sym.DeformableConvolution` call surface, fp32 NCHW, against the oracle."""
+    _, cxx = _mods()
+    rng = np.random.default_rng(9)
+    B, C, H, W, Co, k, pad, dil, dg = 2, 64, 19, 23, 48, 3, 2, 2, 4
+    data = rng.normal(0, 1, (B, C, H, W)).astype(F)
+    off = rng.normal(0, 1.5, (B, 2 * k * k * dg, H, W)).astype(F)
+    wgt = rng.normal(0, 0.05, (Co, C, k, k)).astype(F)
+    bias = rng.normal(0, 0.1, Co).astype(F)
+    t = lambda a: torch.as_tensor(a).cuda()
+    out = cxx.contrib.DeformableConvolution(data=t(data), offset=t(off), weight=t(wgt), bias=t(bias), num_filter=Co,
+                                            pad=(pad, pad), kernel=(k, k), num_deformable_group=dg, stride=(1, 1),
+                                            dilate=(dil, dil))
+    want = deform.deformable_convolution(data, off, wgt, bias, (k, k), (1, 1), (dil, dil), (pad, pad), dg)
+    assert out.shape == want.shape
+    tol = 1e-5 * np.sqrt(k * k * C) * np.abs(want).max()
+    assert np.abs(out.cpu().numpy() - want).max() <= tol
+    out2 = cxx.contrib.DeformableConvolution(data=t(data), offset=t(off), weight=t(wgt), num_filter=Co, pad=(pad, pad),
+                                             kernel=(k, k), num_deformable_group=dg, dilate=(dil, dil), no_bias=True)
+    assert np.abs(out2.cpu().numpy() + bias[None, :, None, None] - want).max() <= 2 * tol
+
+
+def test_deformable_convolution_errors():
+    _, cxx = _mods()
+    z = lambda *s: torch.zeros(s, device='cuda')
+    with pytest.raises(ValueError):          # offset map of the wrong size
+        cxx.contrib.DeformableConvolution(data=z(1, 8, 10, 10), offset=z(1, 18, 9, 10), weight=z(4, 8, 3, 3), num_filter=4,
+                                          pad=(1, 1), kernel=(3, 3), no_bias=True)
+    with pytest.raises(ValueError):          # offset channels do not match num_deformable_group
+        cxx.contrib.DeformableConvolution(data=z(1, 8, 10, 10), offset=z(1, 18, 10, 10), weight=z(4, 8, 3, 3), num_filter=4,
+                                          pad=(1, 1), kernel=(3, 3), num_deformable_group=2, no_bias=True)
+    with pytest.raises(ValueError):          # bias missing
+        cxx.contrib.DeformableConvolution(data=z(1, 8, 10, 10), offset=z(1, 18, 10, 10), weight=z(4, 8, 3, 3), num_filter=4,
+                                          pad=(1, 1), kernel=(3, 3))
+
+
+def test_zero_offsets_equal_own_convolution_full_size():
+    """Full res5 size (512 channels, 38x63, dilation 2), bf16: with zero offsets the deformable path must
+    reproduce the implicit-GEMM convolution kernel bit for bit up to GEMM tiling (same products, fp32 sums)."""
+    ops, _ = _mods()
+    torch.manual_seed(3)
+    B, C, H, W, Co = 2, 512, 38, 63, 512
+    x = torch.randn(B, H, W, C, device='cuda').to(torch.bfloat16)
+    w = (torch.randn(Co, C, 3, 3, device='cuda') * 0.02)
+    wp = ops.pack_conv_weight(w)
+    bias = torch.randn(Co, device='cuda') * 0.1
+    ref = ops.conv2d_nhwc(x, wp, bias, ksize=3, stride=1, pad=2, dil=2, relu=True)
+    off = torch.zeros(B, H, W, 72, device='cuda').permute(0, 3, 1, 2)
+    out = ops.deformable_conv(x.permute(0, 3, 1, 2), off, wp, bias, 3, 1, 2, 2, 4, relu=True)
+    assert out.shape == (B, Co, H, W)
+    d = (out.permute(0, 2, 3, 1).float() - ref.float()).abs().max().item()
+    assert d <= 2e-2 * ref.float().abs().max().item()
+
+
+PSROI_CASES = [
+    # group, no_trans, num_classes, output_dim, spp, trans_std
+    (1, True, 1, 16, 4, 0.0),
+    (1, False, 1, 16, 4, 0.1),
+    (3, False, 2, 8, 2, 0.1),
+]
+
+
+def _rois(rng, R, B, W, H):
+    x1 = rng.uniform(-40, W * 16 - 40, R); y1 = rng.uniform(-40, H * 16 - 40, R)
+    w = rng.uniform(1, 500, R); h = rng.uniform(1, 400, R)
+    r = np.stack([rng.integers(0, B, R).astype(F), x1, y1, x1 + w, y1 + h], 1).astype(F)
+    r[0, 1:] = [50.5, 60.5, 50.5, 60.5]            # degenerate roi; .5 exercises round-half-away
+    return r
+
+
+@pytest.mark.parametrize("case", PSROI_CASES)
+def test_psroi_fp32_bit_exact(case):
+    ops, _ = _mods()
+    group, no_trans, ncls, od, spp, tstd = case
+    rng = np.random.default_rng(11)
+    B, H, W, P, R = 2, 20, 31, 7, 40
+    data = rng.normal(0, 1, (B, od * group * group, H, W)).astype(F)
+    rois = _rois(rng, R, B, W, H)
+    trans = None if no_trans else rng.normal(0, 1.0, (R, 2 * ncls, P, P)).astype(F)
+    out, cnt = ops.deformable_psroi_pool(torch.as_tensor(data).cuda(), torch.as_tensor(rois).cuda(),
+                                         None if no_trans else torch.as_tensor(trans).cuda(), 0.0625, od, group, P, P, spp,
+                                         tstd, no_trans, want_top_count=True)
+    want, wcnt = deform.deformable_psroi_pooling(data, rois, trans, 0.0625, od, group, P, P, spp, tstd, no_trans)
+    assert np.array_equal(cnt.cpu().numpy(), wcnt)
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert (wcnt < spp * spp).any()                # border clipping is exercised
+
+
+def test_psroi_bf16_channels_last_bit_exact_full_size():
+    """Pipeline layout at full size: conv_new_1 map [B,38,63,256] bf16 channels-last, 300 rois per image,
+    learned offsets; output [R,7,7,256] feeding fc_new_1 (weight columns permuted)."""
+    ops, _ = _mods()
+    rng = np.random.default_rng(12)
+    B, C, H, W, P, R = 2, 256, 38, 63, 7, 600
+    data = _bf16_round(np.maximum(rng.normal(0, 1, (B, C, H, W)), 0).astype(F))
+    rois = _rois(rng, R, B, W, H)
+    trans = rng.normal(0, 1.0, (R, 2, P, P)).astype(F)
+    x = torch.as_tensor(data).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    out = ops.deformable_psroi_pool(x, torch.as_tensor(rois).cuda(), torch.as_tensor(trans).cuda(), 0.0625, C, 1, P, P, 4,
+                                    0.1, False, channels_last_out=True)
+    assert out.permute(0, 2, 3, 1).is_contiguous()
+    want, _ = deform.deformable_psroi_pooling(data, rois, trans, 0.0625, C, 1, P, P, 4, 0.1, False)
+    assert np.array_equal(out.float().cpu().numpy(), _bf16_round(want))
+    # offset branch of the graph: no_trans pooling (SYM_DCN_RELNMS:1073-1074)
+    out0 = ops.deformable_psroi_pool(x, torch.as_tensor(rois).cuda(), None, 0.0625, C, 1, P, P, 4, 0.0, True, channels_last_out=True)
+    want0, _ = deform.deformable_psroi_pooling(data, rois, None, 0.0625, C, 1, P, P, 4, 0.0, True)
+    assert np.array_equal(out0.float().cpu().numpy(), _bf16_round(want0))
+
+
+def test_psroi_operator_surface():
+    _, cxx = _mods()
+    rng = np.random.default_rng(13)
+    data = rng.normal(0, 1, (1, 8, 12, 15)).astype(F)
+    rois = _rois(rng, 9, 1, 15, 12)
+    trans = rng.normal(0, 1, (9, 2, 7, 7)).astype(F)
+    t = lambda a: torch.as_tensor(a).cuda()
+    out = cxx.contrib.DeformablePSROIPooling(data=t(data), rois=t(rois), trans=t(trans), group_size=1, pooled_size=7,
+                                             sample_per_part=4, no_trans=False, part_size=7, output_dim=8, spatial_scale=0.0625,
+                                             trans_std=0.1)
+    want, _ = deform.deformable_psroi_pooling(data, rois, trans, 0.0625, 8, 1, 7, 7, 4, 0.1, False)
+    assert np.array_equal(out.cpu().numpy(), want)
+    prop = cxx.DeformablePSROIPoolingProp(spatial_scale=0.0625, output_dim=8, group_size=1, pooled_size=7, no_trans='True')
+    assert prop.ListArguments() == ['data', 'rois'] and prop.ListOutputs() == ['output', 'top_count']
+    with pytest.raises(ValueError):
+        prop.InferShape([(1, 8, 12, 15), (9, 4)])
