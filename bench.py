@@ -94,6 +94,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-relation', action='store_true', help='plain 2FC head (config 1 graph)')
     ap.add_argument('--learn-nms', action='store_true', help='learned duplicate removal instead of soft-NMS (config 3 graph, inference)')
+    ap.add_argument('--dcn', action='store_true', help='deformable res5 + deformable PSROI pooling (config 4 graph, inference)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=4)
     ap.add_argument('--cpu-threads', type=int, default=32)
@@ -115,9 +116,10 @@ def main():
     assert world == a.gpus or world == 1, "WORLD_SIZE=%d but --gpus %d" % (world, a.gpus)
 
     tdt = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
-    params = backbone.init_params(seed=1)
+    params = backbone.init_params(seed=1, dcn_offset_std=0.01 if a.dcn else 0.0)
     cfg = detector.Config()
     cfg.learn_nms = a.learn_nms
+    cfg.dcn = a.dcn
     det = detector.Detector(params, dtype=tdt, device='cuda', relation=not a.no_relation, cfg=cfg, stem=a.stem)
     g = torch.Generator().manual_seed(1000 + rank)
     # unit-variance synthetic pixels: with random-init weights (no checkpoints offline) this gives
@@ -176,9 +178,11 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype,
             'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: ResNet-101 Faster-RCNN + %s + %s + top-100, 600x1000 images, '
+            'config': {'workload': '%sResNet-101 Faster-RCNN + %s + %s + top-100, 600x1000 images, '
                                    '300 proposals, random-init weights'
-                                   % ('2 relation modules (N=300, 16 heads, d=1024)' if not a.no_relation else 'plain 2FC head',
+                                   % ('BASELINE configs[1]: ' if not (a.dcn or a.learn_nms or a.no_relation) else
+                                      ('inference graph of BASELINE configs[3] (DCN): deformable ' if a.dcn else ''),
+                                      '2 relation modules (N=300, 16 heads, d=1024)' if not a.no_relation else 'plain 2FC head',
                                       'learn-NMS (first_n 100, 80 classes)' if a.learn_nms else 'soft-NMS(0.6)'),
                        'images_per_gpu_per_step': a.batch, 'launch': 'eager' if a.no_graph else 'hipGraph replay', 'parallelism': 'replicas x%d (no data-path collective)' % world},
         }
@@ -205,7 +209,7 @@ def main():
                     'launch_ms': att['avg_ms'], 'launches': att['calls'],
                     'algorithmic_gflop_per_launch': ALGO_GFLOP_PER_MODULE_IMAGE * a.batch,
                 }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not a.dcn:      # the CPU port of the DCN graph is parity-only (slow)
             res['cpu_baseline'] = cpu_baseline(params, relation=not a.no_relation, images=a.cpu_images, threads=a.cpu_threads)
         print(json.dumps(res))
     if world > 1:

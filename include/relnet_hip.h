@@ -204,6 +204,29 @@ int relnet_deformable_psroi_pool_fwd(const void* data, const long* data_strides4
                                      int part_size, int sample_per_part, float spatial_scale, float trans_std,
                                      int num_classes, int batch_index_base, int dtype, void* stream);
 
+/* ---- FPN configuration -------------------------------------------------
+ * relation_rcnn/core/rcnn.py:53-74 (cfg.network.ROIDispatch, host numpy in the reference): pyramid level
+ * feat_id = clip(floor(2 + log2(sqrt(w*h)/224)), 0, 3) per roi and the stable regrouping by level in which
+ * symbols/resnet_v1_101_rcnn_fpn_..._learn_nms.py:1108-1121 concatenates rois_0..rois_3.  rois: [B,N,box_stride]
+ * fp32 with x1,y1,x2,y2 at box_off.  Outputs: rois_out [B,N,5] (image index + base, box) level-sorted,
+ * level_out [B,N], perm [B,N] (original row of each sorted row), counts [B,4].  The reference's all-zero dummy
+ * roi for an empty level (rcnn.py:61-71) is NOT appended: counts tells the caller.                          */
+int relnet_fpn_roi_dispatch(const float* rois, int box_stride, int box_off, float* rois_out, int* level_out,
+                            int* perm, int* counts, int B, int N, int batch_index_base, void* stream);
+
+/* The four mx.symbol.ROIPooling calls at 1/4, 1/8, 1/16, 1/32 + Concat(dim=0) (symbols/...fpn...:1108-1119)
+ * as ONE launch: roi r pools from level roi_level[r].  data_levels / heights / widths / spatial_scales are
+ * HOST arrays of num_levels entries (device pointers inside data_levels); data_strides4_levels is
+ * [num_levels][4] element strides (b, c, y, x); all levels share C.                  */
+int relnet_roi_pool_fpn_fwd(const void* const* data_levels, const long* data_strides4_levels, const int* heights,
+                            const int* widths, const float* spatial_scales, int num_levels, const float* rois,
+                            const int* roi_level, void* out, const long* out_strides4, int* argmax /*or NULL*/,
+                            int R, int C, int PH, int PW, int batch_index_base, int dtype, void* stream);
+
+/* mx.symbol.UpSampling(scale=2, sample_type='nearest') + mx.sym.ElementWiseSum of the FPN top-down pathway
+ * (symbols/...fpn...:817-829): lateral[b,y,x,c] += top[b,y/2,x/2,c], NHWC contiguous, in place.             */
+int relnet_upsample2x_add(const void* top, void* lateral, int B, int H, int W, int C, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@ from . import proposal as OP
 from . import roi_pooling as ORP
 from . import relation as OR
 from . import postprocess as OPP
+from . import deform as OD
 
 EPS = 1e-5
 UNITS = (3, 4, 23, 3)
@@ -40,15 +41,60 @@ def _unit_name(stage, u, n):
     return '%d%s' % (stage, 'a' if u == 0 else 'b%d' % u)
 
 
-def backbone(data, p):
-    """data [B,3,H,W] -> (conv4 [B,1024,h,w], conv5 [B,2048,h,w])."""
+def _bn(y, p, bn):
+    g, b = _t(p[bn + '_gamma']), _t(p[bn + '_beta'])
+    m, v = _t(p[bn + '_moving_mean']), _t(p[bn + '_moving_var'])
+    return (y - m.view(1, -1, 1, 1)) / torch.sqrt(v.view(1, -1, 1, 1) + EPS) * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+
+
+def deformable_2b(y, p, nm):
+    """res5x_branch2b of the DCN graphs (symbols/resnet_v1_101_rcnn_dcn_..._learn_nms.py:700-707): 72-channel
+    offset conv (3x3, pad 2, dilate 2, bias) -> DeformableConvolution(num_deformable_group=4, no_bias) -> BN -> ReLU."""
+    name = 'res%s_branch2b' % nm
+    off = F.conv2d(y, _t(p[name + '_offset_weight']), _t(p[name + '_offset_bias']), padding=2, dilation=2)
+    z = OD.deformable_convolution(y.numpy(), off.numpy(), _t(p[name + '_weight']).numpy(), None, (3, 3), (1, 1), (2, 2), (2, 2), 4)
+    return F.relu(_bn(torch.as_tensor(z), p, 'bn%s_branch2b' % nm))
+
+
+def res5(conv4, p, dcn=False, fpn=False):
+    """conv4 [B,1024,h,w] -> conv5 [B,2048,h,w] (get_resnet_v1_conv5, dilate 2, stride 1); fpn: stride 2 on
+    the first 1x1s and no dilation (symbols/resnet_v1_101_rcnn_fpn_..._learn_nms.py:707-720)."""
+    x = conv4
+    for u in range(3):
+        nm = '5' + 'abc'[u]
+        st = 2 if (fpn and u == 0) else 1
+        dil = 1 if fpn else 2
+        sc = _conv_bn(x, p, 'res%s_branch1' % nm, 'bn%s_branch1' % nm, stride=st) if u == 0 else x
+        y = _conv_bn(x, p, 'res%s_branch2a' % nm, 'bn%s_branch2a' % nm, stride=st, relu=True)
+        if dcn:
+            y = deformable_2b(y, p, nm)
+        else:
+            y = _conv_bn(y, p, 'res%s_branch2b' % nm, 'bn%s_branch2b' % nm, pad=dil, dil=dil, relu=True)
+        y = _conv_bn(y, p, 'res%s_branch2c' % nm, 'bn%s_branch2c' % nm)
+        x = F.relu(sc + y)
+    return x
+
+
+def dcn_pool(feat, rois, p, sample_per_part=4, trans_std=0.1):
+    """offset_t -> FC `offset` -> reshape (-1,2,7,7) -> deformable_roi_pool (SYM_DCN_RELNMS:1073-1080)."""
+    feat = np.asarray(feat, np.float32)
+    t0, _ = OD.deformable_psroi_pooling(feat, rois, None, 0.0625, feat.shape[1], 1, 7, 7, sample_per_part, 0.0, True)
+    off = OR.fc(t0.reshape(t0.shape[0], -1), np.asarray(p['offset_weight']), np.asarray(p['offset_bias']))
+    trans = off.reshape(-1, 2, 7, 7).astype(np.float32)
+    out, _ = OD.deformable_psroi_pooling(feat, rois, trans, 0.0625, feat.shape[1], 1, 7, 7, sample_per_part, trans_std, False)
+    return out, trans
+
+
+def backbone(data, p, dcn=False, fpn=False):
+    """data [B,3,H,W] -> (conv4 [B,1024,h,w], conv5 [B,2048,h,w]); fpn: (res2c, res3b3, res4b22, res5c)."""
     x = _conv_bn(_t(data), p, 'conv1', 'bn_conv1', stride=2, pad=3, relu=True)
     x = F.max_pool2d(x, 3, 2, 0, ceil_mode=True)             # pooling_convention='full'
-    conv4 = None
+    ends = {}
     for si, n in enumerate(UNITS):
         stage = si + 2
         if stage == 5:
-            conv4 = x
+            c5 = res5(x, p, dcn, fpn)
+            return (ends[2], ends[3], x, c5) if fpn else (x, c5)
         for u in range(n):
             nm = _unit_name(stage, u, n)
             stride = 2 if (u == 0 and stage in (3, 4)) else 1     # stride on the first 1x1
@@ -58,7 +104,7 @@ def backbone(data, p):
             y = _conv_bn(y, p, 'res%s_branch2b' % nm, 'bn%s_branch2b' % nm, pad=dil, dil=dil, relu=True)
             y = _conv_bn(y, p, 'res%s_branch2c' % nm, 'bn%s_branch2c' % nm)
             x = F.relu(sc + y)
-    return conv4, x
+        ends[stage] = x
 
 
 def rpn_and_feat(conv4, conv5, p):

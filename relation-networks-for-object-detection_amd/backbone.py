@@ -20,8 +20,9 @@ FILTERS = (256, 512, 1024, 2048)
 EPS = 1e-5
 
 
-def unit_names():
-    """[(stage, unit_name, in_ch, mid_ch, out_ch, stride, dilate, has_proj)] in graph order."""
+def unit_names(fpn=False):
+    """[(stage, unit_name, in_ch, mid_ch, out_ch, stride, dilate, has_proj)] in graph order.  fpn: res5 has
+    stride 2 and no dilation (symbols/resnet_v1_101_rcnn_fpn_..._learn_nms.py:707-720)."""
     out = []
     in_ch = 64
     for si, (n, oc) in enumerate(zip(UNITS, FILTERS)):
@@ -31,8 +32,8 @@ def unit_names():
                 name = 'abc'[u]
             else:
                 name = 'a' if u == 0 else 'b%d' % u
-            stride = 2 if (u == 0 and stage in (3, 4)) else 1
-            dilate = 2 if stage == 5 else 1
+            stride = 2 if (u == 0 and (stage in (3, 4) or (fpn and stage == 5))) else 1
+            dilate = 2 if (stage == 5 and not fpn) else 1
             out.append((stage, '%d%s' % (stage, name), in_ch, oc // 4, oc, stride, dilate, u == 0))
             in_ch = oc
     return out
@@ -50,7 +51,7 @@ def conv_bn_names():
     return layers
 
 
-def init_params(seed=1, num_anchors=12, num_classes=81, num_reg_classes=2, generator=None):
+def init_params(seed=1, num_anchors=12, num_classes=81, num_reg_classes=2, generator=None, dcn_offset_std=0.0, fpn=False):
     """Random-init parameters of the relation test graph under the reference's names.
     New layers N(0, 0.01)/0 as init_weight (SYM_REL:327-362); the backbone has no pretrained
     weights offline: He-normal convs, BN gamma=1 (0.25 on the residual branch output so the
@@ -88,6 +89,20 @@ def init_params(seed=1, num_anchors=12, num_classes=81, num_reg_classes=2, gener
     p['nms_key_1_weight'] = nrm(0.01, 1024, 128); p['nms_key_1_bias'] = torch.zeros(1024)
     p['nms_linear_out_1_weight'] = nrm(0.01, 128, 128, 1, 1); p['nms_linear_out_1_bias'] = torch.zeros(128)
     p['nms_logit_weight'] = nrm(0.01, 5, 128); p['nms_logit_bias'] = torch.full((5,), -3.0)
+    # DCN configuration (symbols/resnet_v1_101_rcnn_dcn_..._learn_nms.py:700-746,1075).  The reference
+    # initialises every offset predictor to ZERO (:1525-1535); `dcn_offset_std` > 0 gives non-trivial offsets
+    # for tests / benches that have no trained weights.
+    for u in 'abc':
+        p['res5%s_branch2b_offset_weight' % u] = nrm(dcn_offset_std, 72, 512, 3, 3)
+        p['res5%s_branch2b_offset_bias' % u] = torch.zeros(72)
+    p['offset_weight'] = nrm(dcn_offset_std, 98, 256 * 49); p['offset_bias'] = torch.zeros(98)
+    if fpn:     # symbols/...fpn...:1450-1470, 1508-1511: N(0, 0.01) / 0
+        for lvl, cin in ((32, 2048), (16, 1024), (8, 512), (4, 256)):
+            p['fpn_ft%d_1x1_weight' % lvl] = nrm(0.01, 256, cin, 1, 1); p['fpn_ft%d_1x1_bias' % lvl] = torch.zeros(256)
+            p['fpn_ft%d_3x3_weight' % lvl] = nrm(0.01, 256, 256, 3, 3); p['fpn_ft%d_3x3_bias' % lvl] = torch.zeros(256)
+        p['fpn_ft64_3x3_weight'] = nrm(0.01, 256, 256, 3, 3); p['fpn_ft64_3x3_bias'] = torch.zeros(256)
+        p['roi_pool_fc1_weight'] = nrm(0.01, 1024, 256 * 49); p['roi_pool_fc1_bias'] = torch.zeros(1024)
+        p['roi_pool_fc2_weight'] = nrm(0.01, 1024, 1024); p['roi_pool_fc2_bias'] = torch.zeros(1024)
     return p
 
 
@@ -106,8 +121,9 @@ class Backbone(object):
     bias / add / clamp passes as in the convolutions themselves).  impl='miopen' keeps every conv
     in torch.nn.functional.conv2d (used for the float32 parity path)."""
 
-    def __init__(self, params, dtype=torch.bfloat16, device='cuda', channels_last=True, impl=None, stem='hip'):
-        self.dtype, self.device = dtype, device
+    def __init__(self, params, dtype=torch.bfloat16, device='cuda', channels_last=True, impl=None, stem='hip', dcn=False,
+                 fpn=False):
+        self.dtype, self.device, self.dcn, self.fpn = dtype, device, dcn, fpn
         self.impl = impl or ('hip' if dtype == torch.bfloat16 else 'miopen')
         self.stem = stem
         assert self.impl in ('hip', 'miopen') and (self.impl == 'miopen' or dtype == torch.bfloat16)
@@ -119,12 +135,26 @@ class Backbone(object):
             w, b = fold_bn(params[conv + '_weight'], params[bn + '_gamma'], params[bn + '_beta'],
                            params[bn + '_moving_mean'], params[bn + '_moving_var'])
             self._put(conv, w, b)
-        for name in ('rpn_conv_3x3', 'rpn_cls_score', 'rpn_bbox_pred', 'conv_new_1'):
-            self._put(name, params[name + '_weight'], params[name + '_bias'])
-        # both 1x1 RPN outputs in one convolution: 24 score + 48 delta channels
-        self._put('rpn_out', torch.cat([params['rpn_cls_score_weight'], params['rpn_bbox_pred_weight']], 0),
-                  torch.cat([params['rpn_cls_score_bias'], params['rpn_bbox_pred_bias']], 0))
-        self.units = unit_names()
+        if fpn:     # FPN neck instead of the RPN head / conv_new_1 (HAS_RPN: false in the FPN relation configs)
+            for lvl in (32, 16, 8, 4):
+                for k in ('1x1', '3x3'):
+                    name = 'fpn_ft%d_%s' % (lvl, k)
+                    self._put(name, params[name + '_weight'], params[name + '_bias'])
+        else:
+            for name in ('rpn_conv_3x3', 'rpn_cls_score', 'rpn_bbox_pred', 'conv_new_1'):
+                self._put(name, params[name + '_weight'], params[name + '_bias'])
+            # both 1x1 RPN outputs in one convolution: 24 score + 48 delta channels
+            self._put('rpn_out', torch.cat([params['rpn_cls_score_weight'], params['rpn_bbox_pred_weight']], 0),
+                      torch.cat([params['rpn_cls_score_bias'], params['rpn_bbox_pred_bias']], 0))
+        self.units = unit_names(fpn)
+        self.wp_dcn = {}
+        if dcn:     # res5{a,b,c}_branch2b become DeformableConvolution(num_deformable_group=4) fed by a 72-channel offset conv
+            for u in 'abc':
+                name = 'res5%s_branch2b' % u
+                self._put(name + '_offset', params[name + '_offset_weight'], params[name + '_offset_bias'])
+                w, b = fold_bn(params[name + '_weight'], params['bn5%s_branch2b_gamma' % u], params['bn5%s_branch2b_beta' % u],
+                               params['bn5%s_branch2b_moving_mean' % u], params['bn5%s_branch2b_moving_var' % u])
+                self.wp_dcn[name] = (ops.pack_conv_weight(w, self.dtype, self.device), b.to(self.device, torch.float32).contiguous())
         if self.impl == 'hip':
             w1, b1 = fold_bn(params['conv1_weight'], params['bn_conv1_gamma'], params['bn_conv1_beta'],
                              params['bn_conv1_moving_mean'], params['bn_conv1_moving_var'])
@@ -156,21 +186,43 @@ class Backbone(object):
             x = F.conv2d(x, self.w['conv1'][0], None, stride=2, padding=3)
             x = ops.stem_bias_relu_pool(x.permute(0, 2, 3, 1), self.b32['conv1'])
         conv4 = None
+        ends = {}
         for stage, nm, ic, mc, oc, stride, dil, proj in self.units:
             if stage == 5 and conv4 is None:
                 conv4 = x
+            if proj and stage > 2:
+                ends[stage - 1] = x
             sc = self._hconv(x, 'res%s_branch1' % nm, stride=stride) if proj else x
             y = self._hconv(x, 'res%s_branch2a' % nm, stride=stride, relu=True)
-            y = self._hconv(y, 'res%s_branch2b' % nm, pad=dil, dil=dil, relu=True)
+            if self.dcn and stage == 5:
+                y = self._deform_2b(y.permute(0, 3, 1, 2), 'res%s_branch2b' % nm,
+                                    self._hconv(y, 'res%s_branch2b_offset' % nm, pad=2, dil=2, out_dtype=torch.float32).permute(0, 3, 1, 2))
+                y = y.permute(0, 2, 3, 1)
+            else:
+                y = self._hconv(y, 'res%s_branch2b' % nm, pad=dil, dil=dil, relu=True)
             x = self._hconv(y, 'res%s_branch2c' % nm, relu=True, resid=sc)     # relu(bn(conv) + shortcut)
         conv5 = x
+        nchw = lambda t: t.permute(0, 3, 1, 2)
+        if self.fpn:
+            # top-down pathway: 1x1 laterals, nearest 2x upsampling + sum (one in-place kernel), 3x3 output convs
+            tops = {32: self._hconv(conv5, 'fpn_ft32_1x1')}
+            for lvl, src in ((16, ends[4]), (8, ends[3]), (4, ends[2])):
+                tops[lvl] = ops.upsample2x_add_(self._hconv(src, 'fpn_ft%d_1x1' % lvl), tops[lvl * 2])
+            out = {'fpn_ft%d' % lvl: nchw(self._hconv(tops[lvl], 'fpn_ft%d_3x3' % lvl, pad=1)) for lvl in (4, 8, 16, 32)}
+            out.update(conv4=nchw(conv4), conv5=nchw(conv5))
+            return out
         feat = self._hconv(conv5, 'conv_new_1', relu=True)
         r = self._hconv(conv4, 'rpn_conv_3x3', pad=1, relu=True)
         rpn = self._hconv(r, 'rpn_out', out_dtype=torch.float32)
         na2 = self.w['rpn_cls_score'][0].shape[0]
-        nchw = lambda t: t.permute(0, 3, 1, 2)
         return dict(conv4=nchw(conv4), conv5=nchw(conv5), conv_new_1_relu=nchw(feat),
                     rpn_cls_score=nchw(rpn[..., :na2]), rpn_bbox_pred=nchw(rpn[..., na2:]))
+
+    def _deform_2b(self, y, name, offset):
+        """DeformableConvolution(kernel 3x3, pad 2, dilate 2, num_deformable_group 4, no_bias) + BN + ReLU
+        (SYM_DCN_RELNMS:700-707); y / offset logical NCHW."""
+        w, b = self.wp_dcn[name]
+        return ops.deformable_conv(y, offset, w, b, 3, 1, 2, 2, 4, relu=True)
 
     def _conv(self, x, name, stride=1, pad=0, dil=1, relu=False):
         w, b = self.w[name]
@@ -186,15 +238,29 @@ class Backbone(object):
         x = self._conv(x, 'conv1', stride=2, pad=3, relu=True)
         x = F.max_pool2d(x, kernel_size=3, stride=2, padding=0, ceil_mode=True)
         conv4 = None
+        ends = {}
         for stage, nm, ic, mc, oc, stride, dil, proj in self.units:
             if stage == 5 and conv4 is None:
                 conv4 = x
+            if proj and stage > 2:
+                ends[stage - 1] = x
             sc = self._conv(x, 'res%s_branch1' % nm, stride=stride) if proj else x
             y = self._conv(x, 'res%s_branch2a' % nm, stride=stride, relu=True)
-            y = self._conv(y, 'res%s_branch2b' % nm, pad=dil, dil=dil, relu=True)
+            if self.dcn and stage == 5:
+                off = self._conv(y, 'res%s_branch2b_offset' % nm, pad=2, dil=2).float()
+                y = self._deform_2b(y, 'res%s_branch2b' % nm, off).contiguous(memory_format=self.mf)
+            else:
+                y = self._conv(y, 'res%s_branch2b' % nm, pad=dil, dil=dil, relu=True)
             y = self._conv(y, 'res%s_branch2c' % nm)
             x = F.relu_(y.add_(sc))
         conv5 = x
+        if self.fpn:
+            tops = {32: self._conv(conv5, 'fpn_ft32_1x1')}
+            for lvl, src in ((16, ends[4]), (8, ends[3]), (4, ends[2])):
+                tops[lvl] = F.interpolate(tops[lvl * 2], scale_factor=2, mode='nearest') + self._conv(src, 'fpn_ft%d_1x1' % lvl)
+            out = {'fpn_ft%d' % lvl: self._conv(tops[lvl], 'fpn_ft%d_3x3' % lvl, pad=1) for lvl in (4, 8, 16, 32)}
+            out.update(conv4=conv4, conv5=conv5)
+            return out
         feat = self._conv(conv5, 'conv_new_1', relu=True)
         r = self._conv(conv4, 'rpn_conv_3x3', pad=1, relu=True)
         rpn = self._conv(r, 'rpn_out')

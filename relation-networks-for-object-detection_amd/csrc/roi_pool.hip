@@ -15,7 +15,18 @@ struct RoiArgs {
   int* argmax;                                        // same strides as out, or nullptr
   int R, C, H, W, PH, PW, batch_index_base;
   float scale;
+  // FPN (relnet_roi_pool_fpn_fwd): roi r pools from pyramid level level[r]; nullptr = single map above
+  const int* level;
+  struct Level { const void* data; long ds_b, ds_c, ds_h, ds_w; int H, W; float scale; } lv[4];
 };
+
+// Select the feature map of roi r (rois are level-sorted, so a workgroup rarely mixes levels).
+__device__ __forceinline__ void roi_level(RoiArgs& g, int r) {
+  if (g.level) {
+    const RoiArgs::Level& L = g.lv[g.level[r] & 3];
+    g.data = L.data; g.ds_b = L.ds_b; g.ds_c = L.ds_c; g.ds_h = L.ds_h; g.ds_w = L.ds_w; g.H = L.H; g.W = L.W; g.scale = L.scale;
+  }
+}
 
 template <typename T> __device__ __forceinline__ float ld(const T* p);
 template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
@@ -30,6 +41,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(RoiArgs g) {
   const int bin = blockIdx.x;
   const int pw = bin % g.PW, ph = (bin / g.PW) % g.PH, r = bin / (g.PW * g.PH);
+  roi_level(g, r);
   const float* roi = g.rois + (long)r * 5;
   const int b = (int)roi[0] - g.batch_index_base;
   const int rs_w = (int)roundf(roi[1] * g.scale), rs_h = (int)roundf(roi[2] * g.scale);
@@ -66,6 +78,7 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_cl_kernel(RoiArgs g) {
   const int cg = threadIdx.x % groups;
   if (bin >= g.PH * g.PW) return;
   const int pw = bin % g.PW, ph = bin / g.PW;
+  roi_level(g, r);
   const float* roi = g.rois + (long)r * 5;
   const int b = (int)roi[0] - g.batch_index_base;
   const int rs_w = (int)roundf(roi[1] * g.scale), rs_h = (int)roundf(roi[2] * g.scale);
@@ -127,6 +140,22 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_kernel(RoiBwdArgs g) {
 using namespace relnet;
 enum { RELNET_F32 = 0, RELNET_BF16 = 1 };
 
+static int launch_roi_pool(const RoiArgs& g, int dtype, bool aligned, void* stream, const char* what) {
+  dim3 grid((unsigned)((long)g.R * g.PH * g.PW));
+  const int groups = g.C / 8;
+  if (dtype == RELNET_BF16 && g.C % 8 == 0 && groups <= 256 && 256 % groups == 0 && g.ds_c == 1 && g.os_c == 1 && aligned &&
+      g.os_r % 8 == 0 && g.os_ph % 8 == 0 && g.os_pw % 8 == 0) {
+    const int bins_per_blk = 256 / groups;
+    dim3 g2((g.PH * g.PW + bins_per_blk - 1) / bins_per_blk, g.R);
+    roi_pool_fwd_cl_kernel<<<g2, 256, 0, (hipStream_t)stream>>>(g);
+    return check_launch(what);
+  }
+  if (dtype == RELNET_F32) roi_pool_fwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(g);
+  else if (dtype == RELNET_BF16) roi_pool_fwd_kernel<unsigned short><<<grid, 256, 0, (hipStream_t)stream>>>(g);
+  else RELNET_REQUIRE(false, "%s: unknown dtype %d", what, dtype);
+  return check_launch(what);
+}
+
 extern "C" int relnet_roi_pool_fwd(const void* data, const long* data_strides4, const float* rois,
                                    void* out, const long* out_strides4, int* argmax, int R, int C,
                                    int H, int W, int PH, int PW, float spatial_scale,
@@ -138,19 +167,34 @@ extern "C" int relnet_roi_pool_fwd(const void* data, const long* data_strides4, 
   g.rois = rois; g.out = out; g.os_r = out_strides4[0]; g.os_c = out_strides4[1]; g.os_ph = out_strides4[2]; g.os_pw = out_strides4[3];
   g.argmax = argmax; g.R = R; g.C = C; g.H = H; g.W = W; g.PH = PH; g.PW = PW; g.scale = spatial_scale;
   g.batch_index_base = batch_index_base;
-  dim3 grid((unsigned)((long)R * PH * PW));
-  const int groups = C / 8;
-  if (dtype == RELNET_BF16 && C % 8 == 0 && groups <= 256 && 256 % groups == 0 && g.ds_c == 1 && g.os_c == 1 &&
-      g.ds_h % 8 == 0 && g.ds_w % 8 == 0 && g.ds_b % 8 == 0 && g.os_r % 8 == 0 && g.os_ph % 8 == 0 && g.os_pw % 8 == 0) {
-    const int bins_per_blk = 256 / groups;
-    dim3 g2((PH * PW + bins_per_blk - 1) / bins_per_blk, R);
-    roi_pool_fwd_cl_kernel<<<g2, 256, 0, (hipStream_t)stream>>>(g);
-    return check_launch("relnet_roi_pool_fwd");
+  g.level = nullptr;
+  return launch_roi_pool(g, dtype, g.ds_h % 8 == 0 && g.ds_w % 8 == 0 && g.ds_b % 8 == 0, stream, "relnet_roi_pool_fwd");
+}
+
+extern "C" int relnet_roi_pool_fpn_fwd(const void* const* data_levels, const long* data_strides4_levels,
+                                       const int* heights, const int* widths, const float* spatial_scales,
+                                       int num_levels, const float* rois, const int* roi_level, void* out,
+                                       const long* out_strides4, int* argmax, int R, int C, int PH, int PW,
+                                       int batch_index_base, int dtype, void* stream) {
+  RELNET_REQUIRE(data_levels && data_strides4_levels && heights && widths && spatial_scales && rois && roi_level && out &&
+                 out_strides4, "relnet_roi_pool_fpn_fwd: null operand");
+  RELNET_REQUIRE(num_levels >= 1 && num_levels <= 4, "relnet_roi_pool_fpn_fwd: 1..4 pyramid levels, got %d", num_levels);
+  RELNET_REQUIRE(R > 0 && C > 0 && PH > 0 && PW > 0, "relnet_roi_pool_fpn_fwd: bad shape");
+  RoiArgs g;
+  bool aligned = true;
+  for (int l = 0; l < 4; ++l) {
+    const int s = l < num_levels ? l : num_levels - 1;
+    RELNET_REQUIRE(data_levels[s] && heights[s] > 0 && widths[s] > 0, "relnet_roi_pool_fpn_fwd: bad level %d", s);
+    g.lv[l].data = data_levels[s]; g.lv[l].ds_b = data_strides4_levels[4 * s]; g.lv[l].ds_c = data_strides4_levels[4 * s + 1];
+    g.lv[l].ds_h = data_strides4_levels[4 * s + 2];
+    g.lv[l].ds_w = data_strides4_levels[4 * s + 3]; g.lv[l].H = heights[s]; g.lv[l].W = widths[s]; g.lv[l].scale = spatial_scales[s];
+    aligned = aligned && g.lv[l].ds_c == 1 && g.lv[l].ds_b % 8 == 0 && g.lv[l].ds_h % 8 == 0 && g.lv[l].ds_w % 8 == 0;
   }
-  if (dtype == RELNET_F32) roi_pool_fwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(g);
-  else if (dtype == RELNET_BF16) roi_pool_fwd_kernel<unsigned short><<<grid, 256, 0, (hipStream_t)stream>>>(g);
-  else RELNET_REQUIRE(false, "relnet_roi_pool_fwd: unknown dtype %d", dtype);
-  return check_launch("relnet_roi_pool_fwd");
+  g.data = g.lv[0].data; g.ds_b = g.lv[0].ds_b; g.ds_c = data_strides4_levels[1]; g.ds_h = g.lv[0].ds_h; g.ds_w = g.lv[0].ds_w;
+  g.H = g.lv[0].H; g.W = g.lv[0].W; g.scale = g.lv[0].scale;
+  g.rois = rois; g.out = out; g.os_r = out_strides4[0]; g.os_c = out_strides4[1]; g.os_ph = out_strides4[2]; g.os_pw = out_strides4[3];
+  g.argmax = argmax; g.R = R; g.C = C; g.PH = PH; g.PW = PW; g.batch_index_base = batch_index_base; g.level = roi_level;
+  return launch_roi_pool(g, dtype, aligned, stream, "relnet_roi_pool_fpn_fwd");
 }
 
 extern "C" int relnet_roi_pool_bwd(const void* grad_out, const int* argmax, const long* out_strides4,

@@ -34,6 +34,9 @@ class Config(object):
     learn_nms_class_thresh = 0.01   # TEST.LEARN_NMS_CLASS_SCORE_TH
     nms_target_thresh = (0.5, 0.6, 0.7, 0.8, 0.9)   # network.NMS_TARGET_THRESH
     merge_method = -1         # TEST.MERGE_METHOD (mean over thresholds)
+    dcn = False               # deformable res5 + DeformablePSROIPooling (symbols/..._dcn_...py)
+    dcn_sample_per_part = 4
+    dcn_trans_std = 0.1
 
 
 def fc1_channels_last_perm(c=256, ph=7, pw=7):
@@ -49,7 +52,10 @@ class Detector(object):
                  im_hw=(600, 1000), stem='hip'):
         self.cfg = cfg or Config()
         self.dtype, self.device, self.relation, self.im_hw = dtype, device, relation, im_hw
-        self.backbone = Backbone(params, dtype, device, stem=stem)
+        self.backbone = Backbone(params, dtype, device, stem=stem, dcn=self.cfg.dcn)
+        if self.cfg.dcn:          # FC 12544 -> 2*7*7 offsets (SYM_DCN_RELNMS:1075), columns in (ph, pw, c) order
+            self.w_offset = params['offset_weight'][:, fc1_channels_last_perm()].to(device, dtype).contiguous()
+            self.b_offset = params['offset_bias'].to(device, torch.float32).contiguous()
         self.head = RelationHead(params, dtype, device, fc1_perm=fc1_channels_last_perm(),
                                  use_relation=relation)
         self.lnms = None
@@ -69,8 +75,17 @@ class Detector(object):
                                          self.anchors, c.feat_stride, c.rpn_pre_nms_top_n, c.rpn_post_nms_top_n,
                                          c.rpn_nms_thresh, c.rpn_min_size, im_hw=self.im_hw, softmax_pairs=True)
         N = rois.shape[1]
-        pooled = ops.roi_pool(f['conv_new_1_relu'], rois.view(B * N, 5), (7, 7), 1.0 / c.feat_stride,
-                              channels_last_out=True)
+        if c.dcn:                 # SYM_DCN_RELNMS:1073-1080
+            feat, r5, sc = f['conv_new_1_relu'], rois.view(B * N, 5), 1.0 / c.feat_stride
+            t0 = ops.deformable_psroi_pool(feat, r5, None, sc, feat.shape[1], 1, 7, 7, c.dcn_sample_per_part, 0.0, True,
+                                           channels_last_out=True)
+            trans = ops.gemm_nt(t0.permute(0, 2, 3, 1).reshape(B * N, -1), self.w_offset, self.b_offset,
+                                out_dtype=torch.float32).view(B * N, 2, 7, 7)
+            pooled = ops.deformable_psroi_pool(feat, r5, trans, sc, feat.shape[1], 1, 7, 7, c.dcn_sample_per_part,
+                                               c.dcn_trans_std, False, channels_last_out=True)
+        else:
+            pooled = ops.roi_pool(f['conv_new_1_relu'], rois.view(B * N, 5), (7, 7), 1.0 / c.feat_stride,
+                                  channels_last_out=True)
         pooled = pooled.permute(0, 2, 3, 1).reshape(B, N, -1)              # (ph, pw, c) order, no copy
         cls_score, bbox_pred, feat = self.head.forward(pooled, rois)
         out = dict(rois=rois, cls_score=cls_score, bbox_pred=bbox_pred, fc_all_2_relu=feat)
@@ -86,4 +101,58 @@ class Detector(object):
             det, det_count, thresh, total = ops.image_topk(dets, counts, c.max_per_image)
             out.update(class_dets=dets, class_counts=counts, detections=det, num_detections=det_count,
                        image_thresh=thresh)
+        return out
+
+
+class FPNDetector(object):
+    """Test graph of the FPN relation configuration (symbols/resnet_v1_101_rcnn_fpn_attention_1024_pairwise_position_
+    multi_head_16.py / ..._learn_nms.py, get_symbol_rcnn test branch :1085-1200): proposals are an INPUT
+    (HAS_RPN: false, TOP_ROIS 1000), dispatched to pyramid levels (core/rcnn.py:53-74), pooled from
+    fpn_ft4..fpn_ft32, then roi_pool_fc1/fc2 with two relation modules over all N proposals.
+
+    Rows of every per-roi output are in the reference's level-major order; `perm` maps them back to the input
+    order.  Images must be padded to a multiple of 32 (IMAGE_STRIDE) like the reference's loader does."""
+
+    scales = (1 / 4.0, 1 / 8.0, 1 / 16.0, 1 / 32.0)
+
+    def __init__(self, params, dtype=torch.bfloat16, device='cuda', cfg=None, relation=True, stem='hip'):
+        self.cfg = cfg or Config()
+        self.dtype, self.device = dtype, device
+        self.backbone = Backbone(params, dtype, device, stem=stem, fpn=True)
+        self.head = RelationHead(params, dtype, device, fc1_perm=fc1_channels_last_perm(), use_relation=relation,
+                                 fc_names=('roi_pool_fc1', 'roi_pool_fc2'))
+        self.lnms = None
+        if self.cfg.learn_nms:
+            self.lnms = LearnNMS(params, self.cfg.num_classes - 1, self.cfg.first_n, len(self.cfg.nms_target_thresh),
+                                 self.cfg.learn_nms_class_thresh, None, None, self.cfg.merge_method,
+                                 self.cfg.score_thresh, self.cfg.max_per_image, dtype=dtype, device=device)
+
+    def forward(self, data, proposals, im_info, post=True, check_levels=False):
+        """data [B,3,H,W] (H, W multiples of 32); proposals [B,N,4] fp32 xyxy; im_info [B,3]."""
+        c = self.cfg
+        B, N = proposals.shape[:2]
+        if data.shape[2] % 32 or data.shape[3] % 32:
+            raise ValueError("FPN images must be padded to IMAGE_STRIDE 32, got %s" % (tuple(data.shape),))
+        f = self.backbone.forward(data)
+        rois, level, perm, counts = ops.fpn_roi_dispatch(proposals.contiguous())
+        if check_levels and bool((counts == 0).any()):       # host sync: debugging aid only
+            raise ValueError("a pyramid level received no roi: the reference appends an all-zero dummy roi there "
+                             "(core/rcnn.py:61-71), which this path does not reproduce")
+        pooled = ops.roi_pool_fpn([f['fpn_ft4'], f['fpn_ft8'], f['fpn_ft16'], f['fpn_ft32']], self.scales,
+                                  rois.view(B * N, 5), level.view(-1), (7, 7), channels_last_out=True)
+        pooled = pooled.permute(0, 2, 3, 1).reshape(B, N, -1)
+        cls_score, bbox_pred, feat = self.head.forward(pooled, rois)
+        out = dict(rois=rois, roi_level=level, perm=perm, level_counts=counts, cls_score=cls_score, bbox_pred=bbox_pred,
+                   fc_all_2_relu=feat)
+        if self.lnms is not None and post:
+            out.update(self.lnms.forward(cls_score.contiguous(), bbox_pred.contiguous(), rois, im_info, feat))
+            return out
+        prob, boxes = ops.detect_head(cls_score.reshape(B * N, -1), bbox_pred.reshape(B * N, -1),
+                                      rois.view(B * N, 5), im_info, N)
+        out['cls_prob'], out['pred_boxes'] = prob.view(B, N, -1), boxes.view(B, N, 4)
+        if post:
+            dets, cnts = ops.class_nms(out['cls_prob'], out['pred_boxes'], c.score_thresh, c.nms, c.softnms,
+                                       max_picks=c.max_per_image)
+            det, det_count, thresh, total = ops.image_topk(dets, cnts, c.max_per_image)
+            out.update(class_dets=dets, class_counts=cnts, detections=det, num_detections=det_count, image_thresh=thresh)
         return out

@@ -44,6 +44,9 @@ _SIGNATURES = {
     'relnet_conv2d_nhwc': (C.c_int, [_vp, _l, _l, _vp, _vp, _vp, _i, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_deformable_im2col': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l] + [_i] * 15 + [_vp]),
     'relnet_deformable_psroi_pool_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_f, _f, _i, _i, _i, _vp]),
+    'relnet_roi_pool_fpn_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'relnet_fpn_roi_dispatch': (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'relnet_upsample2x_add': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'relnet_gemm_force_tile': (None, [_i]),
     'relnet_gemm_force_nloop': (None, [_i]),
     'relnet_nms_greedy': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),

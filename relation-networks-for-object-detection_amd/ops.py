@@ -480,3 +480,60 @@ def deformable_psroi_pool(data, rois, trans=None, spatial_scale=0.0625, output_d
               int(output_dim), int(group_size), P, int(part_size), int(sample_per_part), float(spatial_scale),
               float(trans_std), num_classes, batch_index_base, _dt(data), _stream())
     return (out, cnt) if want_top_count else out
+
+
+# ---------------------------------------------------------------------------------------
+# FPN configuration
+# ---------------------------------------------------------------------------------------
+def fpn_roi_dispatch(rois, batch_index_base=0):
+    """rois [B,N,4] (xyxy) or [B,N,5] (idx + xyxy) fp32 -> (rois_sorted [B,N,5], level [B,N] int32,
+    perm [B,N] int32, counts [B,4] int32); core/rcnn.py:53-74 on the device."""
+    _chk(rois)
+    assert rois.dtype == torch.float32 and rois.is_contiguous() and rois.dim() == 3
+    B, N, bs = rois.shape
+    out = torch.empty((B, N, 5), device=rois.device, dtype=torch.float32)
+    level = torch.empty((B, N), device=rois.device, dtype=torch.int32)
+    perm = torch.empty((B, N), device=rois.device, dtype=torch.int32)
+    counts = torch.empty((B, 4), device=rois.device, dtype=torch.int32)
+    _lib.call('relnet_fpn_roi_dispatch', rois.data_ptr(), bs, bs - 4, out.data_ptr(), level.data_ptr(),
+              perm.data_ptr(), counts.data_ptr(), B, N, batch_index_base, _stream())
+    return out, level, perm, counts
+
+
+def roi_pool_fpn(levels, scales, rois, roi_level, pooled=(7, 7), channels_last_out=False, batch_index_base=0):
+    """levels: list of logical [B,C,H_l,W_l] maps (any strides, same C / dtype); rois [R,5]; roi_level [R] int32
+    -> [R,C,PH,PW] (memory (R,PH,PW,C) when channels_last_out): 4 x ROIPooling + Concat in one launch."""
+    import ctypes
+    _chk(rois, roi_level, *levels)
+    assert rois.dtype == torch.float32 and rois.is_contiguous() and roi_level.dtype == torch.int32
+    nl = len(levels)
+    Cc = levels[0].shape[1]
+    R = rois.shape[0]
+    PH, PW = pooled
+    ptrs = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in levels])
+    strides = (ctypes.c_long * (4 * nl))(*[int(s) for t in levels for s in t.stride()])
+    hs = (ctypes.c_int * nl)(*[int(t.shape[2]) for t in levels])
+    ws = (ctypes.c_int * nl)(*[int(t.shape[3]) for t in levels])
+    sc = (ctypes.c_float * nl)(*[float(x) for x in scales])
+    dt = levels[0].dtype
+    assert all(t.dtype == dt and t.shape[1] == Cc for t in levels)
+    if channels_last_out:
+        out = torch.empty((R, PH, PW, Cc), device=rois.device, dtype=dt).permute(0, 3, 1, 2)
+    else:
+        out = torch.empty((R, Cc, PH, PW), device=rois.device, dtype=dt)
+    _lib.call('relnet_roi_pool_fpn_fwd', ctypes.addressof(ptrs), ctypes.addressof(strides), ctypes.addressof(hs),
+              ctypes.addressof(ws), ctypes.addressof(sc), nl, rois.data_ptr(), roi_level.data_ptr(), out.data_ptr(),
+              _strides4(out), 0, R, Cc, PH, PW, batch_index_base, _dt(levels[0]), _stream())
+    return out
+
+
+def upsample2x_add_(lateral, top):
+    """lateral [B,H,W,C] += nearest-upsampled top [B,H/2,W/2,C] (both NHWC contiguous), in place."""
+    _chk(lateral, top)
+    assert lateral.is_contiguous() and top.is_contiguous() and lateral.dtype == top.dtype
+    B, H, W, Cc = lateral.shape
+    if tuple(top.shape) != (B, H // 2, W // 2, Cc) or H % 2 or W % 2:
+        raise ValueError("upsample2x_add: lateral %s is not exactly twice top %s (pad images to IMAGE_STRIDE 32)"
+                         % (tuple(lateral.shape), tuple(top.shape)))
+    _lib.call('relnet_upsample2x_add', top.data_ptr(), lateral.data_ptr(), B, H, W, Cc, _dt(lateral), _stream())
+    return lateral

@@ -87,14 +87,16 @@ class RelationHead(object):
     """fc_new_1 -> relation_1 -> ReLU -> fc_new_2 -> relation_2 -> ReLU -> cls_score / bbox_pred
     (SYM_REL:254-280).  `dtype` bf16 is the throughput path, float32 the parity path."""
 
-    def __init__(self, params, dtype=torch.bfloat16, device='cuda', fc1_perm=None, use_relation=True):
+    def __init__(self, params, dtype=torch.bfloat16, device='cuda', fc1_perm=None, use_relation=True,
+                 fc_names=('fc_new_1', 'fc_new_2')):
         t = lambda x, dt: torch.as_tensor(x).to(device=device, dtype=dt).contiguous()
         self.dtype, self.device = dtype, device
-        w1 = torch.as_tensor(params['fc_new_1_weight'])
+        n1, n2 = fc_names          # ('roi_pool_fc1', 'roi_pool_fc2') in the FPN graphs
+        w1 = torch.as_tensor(params[n1 + '_weight'])
         if fc1_perm is not None:            # (C,7,7) -> (7,7,C) input order for channels-last pooling
             w1 = w1[:, fc1_perm]
-        self.w1, self.b1 = t(w1, dtype), t(params['fc_new_1_bias'], torch.float32)
-        self.w2, self.b2 = t(params['fc_new_2_weight'], dtype), t(params['fc_new_2_bias'], torch.float32)
+        self.w1, self.b1 = t(w1, dtype), t(params[n1 + '_bias'], torch.float32)
+        self.w2, self.b2 = t(params[n2 + '_weight'], dtype), t(params[n2 + '_bias'], torch.float32)
         wcb = torch.cat([torch.as_tensor(params['cls_score_weight']), torch.as_tensor(params['bbox_pred_weight'])], 0)
         bcb = torch.cat([torch.as_tensor(params['cls_score_bias']), torch.as_tensor(params['bbox_pred_bias'])], 0)
         self.num_classes = int(params['cls_score_weight'].shape[0])

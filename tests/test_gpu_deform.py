@@ -202,3 +202,51 @@ def test_psroi_operator_surface():
     assert prop.ListArguments() == ['data', 'rois'] and prop.ListOutputs() == ['output', 'top_count']
     with pytest.raises(ValueError):
         prop.InferShape([(1, 8, 12, 15), (9, 4)])
+
+
+def test_dcn_detector_stagewise_fp32_and_bf16():
+    """Config-4 graph (deformable res5 + deformable PSROI pooling), teacher forced: fp32 backbone vs the
+    torch-CPU/numpy restatement, pooling stage on the GPU's own feature map and rois, then the bf16 MFMA path
+    against the fp32 path."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import backbone, detector, ops
+    from oracle import network as ON
+    H, W = 160, 224
+    p = backbone.init_params(seed=11, dcn_offset_std=0.02)
+    g = torch.Generator().manual_seed(12)
+    p['conv_new_1_bias'] = torch.rand(256, generator=g) * 0.1 + 0.05
+    p['offset_weight'] = torch.randn(98, 256 * 49, generator=g) * 0.05      # |trans| up to a few units
+    data = torch.randn(1, 3, H, W, generator=g)
+    im_info = torch.tensor([[H, W, 1.0]])
+    cfg = detector.Config(); cfg.rpn_post_nms_top_n = 64; cfg.dcn = True
+    det = detector.Detector(p, dtype=torch.float32, im_hw=(H, W), cfg=cfg)
+    f = det.backbone.forward(data.cuda())
+    with torch.no_grad():
+        c4, c5 = ON.backbone(data, p, dcn=True)
+        c5_plain = ON.res5(c4, p, dcn=False)
+    assert (c5 - c5_plain).abs().max() > 1e-2 * c5.abs().max()          # the offsets really deform the sampling
+    for got, want in ((f['conv4'], c4), (f['conv5'], c5)):
+        err = (got.float().cpu() - want).abs().max().item() / want.abs().max().item()
+        assert err < 3e-4, err
+    out = det.forward(data.cuda(), im_info.cuda())
+    rois = out['rois'][0].cpu().numpy()
+    feat = f['conv_new_1_relu'].float().cpu().numpy()
+    pn = {k: v.numpy() for k, v in p.items()}
+    pooled_o, trans_o = ON.dcn_pool(feat, rois, pn)
+    # device: same two poolings + FC on the same feature map
+    r5 = out['rois'].view(-1, 5)
+    t0 = ops.deformable_psroi_pool(f['conv_new_1_relu'], r5, None, 0.0625, 256, 1, 7, 7, 4, 0.0, True, channels_last_out=True)
+    trans = ops.gemm_nt(t0.permute(0, 2, 3, 1).reshape(r5.shape[0], -1), det.w_offset, det.b_offset).view(-1, 2, 7, 7)
+    assert np.abs(trans.cpu().numpy() - trans_o).max() <= 1e-4 * max(np.abs(trans_o).max(), 1.0)
+    assert np.abs(trans_o).max() > 0.5
+    pooled = ops.deformable_psroi_pool(f['conv_new_1_relu'], r5, torch.as_tensor(trans_o).cuda(), 0.0625, 256, 1, 7, 7, 4, 0.1, False)
+    assert np.array_equal(pooled.cpu().numpy(), pooled_o)                # teacher-forced offsets -> bit exact
+    assert torch.isfinite(out['cls_score']).all() and out['num_detections'].shape == (1,)
+    # bf16 throughput path, batch of 2
+    det16 = detector.Detector(p, dtype=torch.bfloat16, im_hw=(H, W), cfg=cfg)
+    data2 = torch.cat([data, torch.randn(1, 3, H, W, generator=g)]).cuda()
+    f16 = det16.backbone.forward(data2)
+    err = (f16['conv5'][0].float() - f['conv5'][0]).abs().max().item() / f['conv5'].abs().max().item()
+    assert err < 6e-2, err
+    o16 = det16.forward(data2, torch.tensor([[H, W, 1.0]] * 2).cuda())
+    assert torch.isfinite(o16['cls_score']).all() and o16['rois'].shape == (2, 64, 5)

@@ -1,0 +1,150 @@
+"""GPU parity of the FPN configuration's pieces against oracle/fpn.py.
+
+Integer work (level assignment, regrouping, max pooling) is bit-exact; convolution stacks are compared at the
+tolerances written next to each assertion."""
+import os
+import sys
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+import cases  # noqa: E402
+from oracle import fpn as OF  # noqa: E402
+from oracle import network as ON  # noqa: E402
+from oracle import relation as OR  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def _mods():
+    import relnet_amd  # noqa: F401
+    from relnet_amd import ops, backbone, detector
+    return ops, backbone, detector
+
+
+def _proposals(n, seed, im_h=800, im_w=1024):
+    """n boxes spanning all four pyramid levels, with some exactly ON the level boundaries
+    (sqrt(w*h) = 112, 224, 448: log2 = -1, 0, 1 exactly)."""
+    rng = np.random.default_rng(seed)
+    side = np.exp(rng.uniform(np.log(12), np.log(700), n))
+    ar = np.exp(rng.uniform(-0.7, 0.7, n))
+    w = np.minimum(side * ar, im_w - 2); h = np.minimum(side / ar, im_h - 2)
+    x1 = rng.uniform(0, im_w - 1 - w); y1 = rng.uniform(0, im_h - 1 - h)
+    b = np.stack([x1, y1, x1 + w, y1 + h], 1).astype(F)
+    for i, s in enumerate((112, 224, 448)):
+        b[i] = [10, 20, 10 + s - 1, 20 + s - 1]                 # w = h = s exactly
+        b[3 + i] = [5, 5, 5 + 2 * s - 1, 5 + s / 2 - 1]         # w*h = s^2 with w != h
+    return b
+
+
+def test_roi_dispatch_bit_exact():
+    ops, _, _ = _mods()
+    B, N = 3, 1000
+    boxes = np.stack([_proposals(N, 100 + b) for b in range(B)])
+    boxes[2, :, :] = _proposals(N, 7)                            # third image: forced empty level 0
+    small = OF.roi_levels(boxes[2]) == 0
+    boxes[2, small] = [100, 100, 400, 400]
+    rois, level, perm, counts = ops.fpn_roi_dispatch(torch.as_tensor(boxes).cuda())
+    for b in range(B):
+        wr, wl, wp, wc = OF.roi_dispatch(boxes[b], dummy_for_empty=False)
+        wr[:, 0] = b
+        assert np.array_equal(counts[b].cpu().numpy(), wc)
+        assert np.array_equal(level[b].cpu().numpy(), wl)
+        assert np.array_equal(perm[b].cpu().numpy(), wp)
+        assert np.array_equal(rois[b].cpu().numpy(), wr)
+    assert int(counts[2, 0]) == 0 and (counts[:2] > 0).all()
+    # boundary boxes land in the upper level (floor of an exact integer)
+    lv = OF.roi_levels(boxes[0][:6])
+    assert lv.tolist() == [1, 2, 3, 1, 2, 3]
+    # 5-column input (batch index + box) gives the same grouping
+    b5 = torch.cat([torch.zeros(B, N, 1), torch.as_tensor(boxes)], 2).cuda()
+    r2 = ops.fpn_roi_dispatch(b5)
+    assert torch.equal(r2[0], rois) and torch.equal(r2[2], perm)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_upsample2x_add(dtype):
+    ops, _, _ = _mods()
+    torch.manual_seed(1)
+    top = torch.randn(2, 25, 32, 256, device='cuda').to(dtype)
+    lat = torch.randn(2, 50, 64, 256, device='cuda').to(dtype)
+    want = (lat.float() + top.float().repeat_interleave(2, 1).repeat_interleave(2, 2)).to(dtype)
+    got = ops.upsample2x_add_(lat.clone(), top)
+    assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        ops.upsample2x_add_(torch.zeros(1, 51, 64, 8, device='cuda').to(dtype), torch.zeros(1, 25, 32, 8, device='cuda').to(dtype))
+
+
+def test_roi_pool_fpn_bit_exact():
+    ops, _, _ = _mods()
+    rng = np.random.default_rng(5)
+    B, C, N = 2, 16, 300
+    H, W = 256, 320
+    feats = [rng.normal(0, 1, (B, C, H // s, W // s)).astype(F) for s in (4, 8, 16, 32)]
+    boxes = np.stack([_proposals(N, 30 + b, H, W) for b in range(B)])
+    rois, level, perm, counts = ops.fpn_roi_dispatch(torch.as_tensor(boxes).cuda())
+    out = ops.roi_pool_fpn([torch.as_tensor(f).cuda() for f in feats], (1 / 4.0, 1 / 8.0, 1 / 16.0, 1 / 32.0),
+                           rois.view(-1, 5), level.view(-1))
+    r = rois.cpu().numpy(); lv = level.cpu().numpy()
+    for b in range(B):
+        want = OF.pool_levels(feats, r[b], lv[b])
+        assert np.array_equal(out[b * N:(b + 1) * N].cpu().numpy(), want)
+    # bf16 channels-last maps, channels-last output (the pipeline layout)
+    f16 = [torch.as_tensor(f).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for f in feats]
+    o16 = ops.roi_pool_fpn(f16, (1 / 4.0, 1 / 8.0, 1 / 16.0, 1 / 32.0), rois.view(-1, 5), level.view(-1), channels_last_out=True)
+    fr = [t.float().cpu().numpy() for t in f16]
+    want = np.concatenate([OF.pool_levels(fr, r[b], lv[b]) for b in range(B)])
+    assert np.array_equal(o16.float().cpu().numpy(), want)
+
+
+def test_fpn_detector_stagewise():
+    ops, backbone, detector = _mods()
+    H, W, N = 160, 224, 200
+    p = backbone.init_params(seed=21, fpn=True)
+    g = torch.Generator().manual_seed(22)
+    for k in ('cls_score_weight', 'bbox_pred_weight'):
+        p[k] = torch.randn(p[k].shape, generator=g) * 0.05
+    for lvl in (4, 8, 16, 32):                         # O(1) pyramid features instead of the N(0, 0.01) init's ~1e-3
+        p['fpn_ft%d_1x1_weight' % lvl] = p['fpn_ft%d_1x1_weight' % lvl] * 5
+        p['fpn_ft%d_3x3_weight' % lvl] = p['fpn_ft%d_3x3_weight' % lvl] * 5
+        p['fpn_ft%d_3x3_bias' % lvl] = torch.rand(256, generator=g) * 0.1
+    data = torch.randn(1, 3, H, W, generator=g)
+    boxes = _proposals(N, 23, H, W)[None]
+    im_info = torch.tensor([[H, W, 1.0]])
+    det = detector.FPNDetector(p, dtype=torch.float32)
+    f = det.backbone.forward(data.cuda())
+    with torch.no_grad():
+        c2, c3, c4, c5 = ON.backbone(data, p, fpn=True)
+        want = OF.fpn_neck(c2, c3, c4, c5, p)
+    assert c5.shape[2:] == (H // 32, W // 32)
+    for name, w in zip(('fpn_ft4', 'fpn_ft8', 'fpn_ft16', 'fpn_ft32'), want):
+        got = f[name].float().cpu()
+        assert got.shape == w.shape
+        err = (got - w).abs().max().item() / w.abs().max().item()
+        assert err < 3e-4, (name, err)               # fp32 conv stacks, different summation orders
+    out = det.forward(data.cuda(), torch.as_tensor(boxes).cuda(), im_info.cuda(), check_levels=True)
+    rois = out['rois'][0].cpu().numpy(); lv = out['roi_level'][0].cpu().numpy()
+    feats = [f[n].float().cpu().numpy() for n in ('fpn_ft4', 'fpn_ft8', 'fpn_ft16', 'fpn_ft32')]
+    pooled_o = OF.pool_levels(feats, rois, lv)
+    pn = {k: v.numpy() for k, v in p.items()}
+    pn['fc_new_1_weight'], pn['fc_new_1_bias'] = pn['roi_pool_fc1_weight'], pn['roi_pool_fc1_bias']
+    pn['fc_new_2_weight'], pn['fc_new_2_bias'] = pn['roi_pool_fc2_weight'], pn['roi_pool_fc2_bias']
+    r = OR.relation_head(pooled_o, rois, pn, return_intermediates=True)
+    cs, bp = r['cls_score'], r['bbox_pred']
+    assert np.abs(out['cls_score'][0].cpu().numpy() - cs).max() <= 2e-4 * np.abs(cs).max()
+    assert np.abs(out['bbox_pred'][0].cpu().numpy() - bp).max() <= 2e-4 * max(np.abs(bp).max(), 1e-3)
+    assert int(out['num_detections'][0]) > 0
+    # bf16 MFMA path, batch 2, same graph
+    det16 = detector.FPNDetector(p, dtype=torch.bfloat16)
+    data2 = torch.cat([data, torch.randn(1, 3, H, W, generator=g)]).cuda()
+    boxes2 = torch.as_tensor(np.stack([boxes[0], _proposals(N, 24, H, W)])).cuda()
+    f16 = det16.backbone.forward(data2)
+    for name in ('fpn_ft4', 'fpn_ft32'):
+        err = (f16[name][0].float() - f[name][0]).abs().max().item() / f[name].abs().max().item()
+        assert err < 6e-2, (name, err)
+    o16 = det16.forward(data2, boxes2, torch.tensor([[H, W, 1.0]] * 2).cuda())
+    assert torch.isfinite(o16['cls_score']).all() and o16['cls_score'].shape == (2, N, 81)
+    assert torch.equal(o16['rois'][0], out['rois'][0])          # dispatch does not depend on the dtype

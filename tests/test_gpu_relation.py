@@ -103,7 +103,8 @@ def test_relation_module_fp32_vs_golden_and_oracle(rn, golden, name):
     assert np.abs(y - want).max() <= 1e-4 * np.abs(want).max()
 
 
-@pytest.mark.parametrize('n,m,seed,std', [(300, 300, 41, 0.01), (300, 300, 42, 0.05), (333, 300, 43, 0.02)])
+@pytest.mark.parametrize('n,m,seed,std', [(300, 300, 41, 0.01), (300, 300, 42, 0.05), (333, 300, 43, 0.02),
+                                          (1000, 1000, 45, 0.02)])     # last: FPN configuration (TOP_ROIS 1000)
 def test_relation_module_full_size(rn, n, m, seed, std):
     """N=M=300 (BASELINE config) and N = 300 + gt rows with keys = first 300 (training shape)."""
     ops, relation = rn
