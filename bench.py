@@ -21,6 +21,7 @@ The JSON line also carries
 import argparse
 import contextlib
 import json
+import math
 import os
 import sys
 import time
@@ -95,6 +96,7 @@ def main():
     ap.add_argument('--no-relation', action='store_true', help='plain 2FC head (config 1 graph)')
     ap.add_argument('--learn-nms', action='store_true', help='learned duplicate removal instead of soft-NMS (config 3 graph, inference)')
     ap.add_argument('--dcn', action='store_true', help='deformable res5 + deformable PSROI pooling (config 4 graph, inference)')
+    ap.add_argument('--fpn', action='store_true', help='FPN graph, 800x1024 images, 1000 given proposals (inference graph of config 5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=4)
     ap.add_argument('--cpu-threads', type=int, default=32)
@@ -116,21 +118,34 @@ def main():
     assert world == a.gpus or world == 1, "WORLD_SIZE=%d but --gpus %d" % (world, a.gpus)
 
     tdt = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
-    params = backbone.init_params(seed=1, dcn_offset_std=0.01 if a.dcn else 0.0)
+    params = backbone.init_params(seed=1, dcn_offset_std=0.01 if a.dcn else 0.0, fpn=a.fpn)
     cfg = detector.Config()
     cfg.learn_nms = a.learn_nms
     cfg.dcn = a.dcn
-    det = detector.Detector(params, dtype=tdt, device='cuda', relation=not a.no_relation, cfg=cfg, stem=a.stem)
+    if a.fpn:
+        det = detector.FPNDetector(params, dtype=tdt, device='cuda', relation=not a.no_relation, cfg=cfg, stem=a.stem)
+    else:
+        det = detector.Detector(params, dtype=tdt, device='cuda', relation=not a.no_relation, cfg=cfg, stem=a.stem)
     g = torch.Generator().manual_seed(1000 + rank)
     # unit-variance synthetic pixels: with random-init weights (no checkpoints offline) this gives
     # O(1) RPN logits/deltas, i.e. several hundred distinct proposals survive NMS per image; N(0,50)
     # pixels would push every delta past exp overflow and degenerate all rois to the full image.
     # the step starts from the raw fp32 NCHW image batch (dtype/layout conversion is part of the step)
-    data = torch.randn(a.batch, 3, 600, 1000, generator=g).cuda()
-    im_info = torch.tensor([[600.0, 1000.0, 1.0]] * a.batch).cuda()
+    im_h, im_w, n_rois = (800, 1024, 1000) if a.fpn else (600, 1000, 300)
+    data = torch.randn(a.batch, 3, im_h, im_w, generator=g).cuda()
+    im_info = torch.tensor([[float(im_h), float(im_w), 1.0]] * a.batch).cuda()
     torch.backends.cudnn.benchmark = True
+    if a.fpn:      # proposals are an input of the FPN graphs (HAS_RPN: false): log-uniform sizes over all levels
+        side = torch.exp(torch.empty(a.batch, n_rois).uniform_(math.log(16), math.log(640), generator=g))
+        ar = torch.exp(torch.empty(a.batch, n_rois).uniform_(-0.7, 0.7, generator=g))
+        bw, bh = (side * ar).clamp(max=im_w - 2), (side / ar).clamp(max=im_h - 2)
+        x1 = torch.rand(a.batch, n_rois, generator=g) * (im_w - 1 - bw)
+        y1 = torch.rand(a.batch, n_rois, generator=g) * (im_h - 1 - bh)
+        proposals = torch.stack([x1, y1, x1 + bw, y1 + bh], 2).cuda()
 
     def step():
+        if a.fpn:
+            return det.forward(data, proposals, im_info)
         return det.forward(data, im_info)
 
     def fence():
@@ -180,8 +195,9 @@ def main():
             'data': 'synthetic',
             'config': {'workload': '%sResNet-101 Faster-RCNN + %s + %s + top-100, 600x1000 images, '
                                    '300 proposals, random-init weights'
-                                   % ('BASELINE configs[1]: ' if not (a.dcn or a.learn_nms or a.no_relation) else
-                                      ('inference graph of BASELINE configs[3] (DCN): deformable ' if a.dcn else ''),
+                                   % ('BASELINE configs[1]: ' if not (a.dcn or a.learn_nms or a.no_relation or a.fpn) else
+                                      ('inference graph of BASELINE configs[3] (DCN): deformable ' if a.dcn else
+                                       'inference graph of BASELINE configs[4] (FPN, 800x1024 images, 1000 given proposals): ' if a.fpn else ''),
                                       '2 relation modules (N=300, 16 heads, d=1024)' if not a.no_relation else 'plain 2FC head',
                                       'learn-NMS (first_n 100, 80 classes)' if a.learn_nms else 'soft-NMS(0.6)'),
                        'images_per_gpu_per_step': a.batch, 'launch': 'eager' if a.no_graph else 'hipGraph replay', 'parallelism': 'replicas x%d (no data-path collective)' % world},
@@ -196,7 +212,8 @@ def main():
             att = ks.get('relnet_relation_attention')
             if att:
                 sec = att['avg_ms'] * 1e-3
-                algo = ALGO_GFLOP_PER_MODULE_IMAGE * a.batch / 1e3 / sec          # TFLOP/s
+                rs = (n_rois / 300.0) ** 2                                         # N = M = n_rois keys and queries
+                algo = ALGO_GFLOP_PER_MODULE_IMAGE * rs * a.batch / 1e3 / sec     # TFLOP/s
                 peak = PEAK_TFLOPS[a.dtype]
                 traffic = None
                 pmc = os.path.join(ROOT, 'profiles', 'attention_pmc.json')
@@ -205,11 +222,11 @@ def main():
                 res['roofline'] = {
                     'kernel': 'relation_attention_kernel (csrc/relation.hip)', 'bound': 'mfma',
                     'achieved': algo, 'peak': peak, 'unit': 'TFLOP/s', 'frac': algo / peak, 'traffic': traffic,
-                    'executed': EXEC_GFLOP_PER_MODULE_IMAGE * a.batch / 1e3 / sec,
+                    'executed': EXEC_GFLOP_PER_MODULE_IMAGE * rs * a.batch / 1e3 / sec,
                     'launch_ms': att['avg_ms'], 'launches': att['calls'],
                     'algorithmic_gflop_per_launch': ALGO_GFLOP_PER_MODULE_IMAGE * a.batch,
                 }
-        if world == 1 and not a.no_cpu_baseline and not a.dcn:      # the CPU port of the DCN graph is parity-only (slow)
+        if world == 1 and not a.no_cpu_baseline and not a.dcn and not a.fpn:      # the CPU port of the DCN graph is parity-only (slow)
             res['cpu_baseline'] = cpu_baseline(params, relation=not a.no_relation, images=a.cpu_images, threads=a.cpu_threads)
         print(json.dumps(res))
     if world > 1:

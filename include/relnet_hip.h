@@ -227,6 +227,28 @@ int relnet_roi_pool_fpn_fwd(const void* const* data_levels, const long* data_str
  * (symbols/...fpn...:817-829): lateral[b,y,x,c] += top[b,y/2,x/2,c], NHWC contiguous, in place.             */
 int relnet_upsample2x_add(const void* top, void* lateral, int B, int H, int W, int C, int dtype, void* stream);
 
+/* ---- Training losses ---------------------------------------------------
+ * mx.sym.SoftmaxOutput(normalization='valid', use_ignore, ignore_label=-1[, multi_output], grad_scale):
+ * rpn_cls_prob / cls_prob (symbols/resnet_v1_101_rcnn_attention_1024_pairwise_position_multi_head_16_learn_nms.py
+ * :272-273, :372-373, :379).  data / prob / grad: logical [outer, C, inner] (softmax over C; inner = 1 for the
+ * [rois, classes] head, inner = A*H*W for the RPN's Reshape(0,2,-1,0)); label [outer, inner] float class ids.
+ * grad (may be NULL) = (prob - onehot) * grad_scale / max(#labels != ignore, 1), 0 where ignored.
+ * valid_count_scratch: one device int.                                                                    */
+int relnet_softmax_output(const float* data, const float* label, float* prob, float* grad, int* valid_count_scratch,
+                          long outer, int C, long inner, int use_ignore, float ignore_label, float grad_scale,
+                          void* stream);
+
+/* weight * mx.sym.smooth_l1(scalar=sigma, data=pred - target) inside mx.sym.MakeLoss(grad_scale) (:276-278,
+ * :374-377): loss (may be NULL) = w * f(pred - target), grad (may be NULL) = grad_scale * w * f'(pred - target);
+ * f(x) = 0.5 (sigma x)^2 if |x| < 1/sigma^2 else |x| - 0.5/sigma^2.  weight NULL = 1.                        */
+int relnet_smooth_l1_loss(const float* pred, const float* target, const float* weight, float* loss, float* grad,
+                          long n, float sigma, float grad_scale, void* stream);
+
+/* nms_pos_loss / nms_neg_loss (:536-551): pos = -k t log(s + eps), neg = -k (1 - t) log(1 - s + eps),
+ * k = nms_loss_scale / (first_n * num_thresh); grad = d(pos_scale * pos + neg) / ds.                         */
+int relnet_nms_loss(const float* score, const float* target, float* pos_loss, float* neg_loss, float* grad, long n,
+                    float eps, float loss_scale_over_normalizer, float pos_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

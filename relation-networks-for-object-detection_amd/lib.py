@@ -47,6 +47,9 @@ _SIGNATURES = {
     'relnet_roi_pool_fpn_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_fpn_roi_dispatch': (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'relnet_upsample2x_add': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'relnet_softmax_output': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _i, _l, _i, _f, _f, _vp]),
+    'relnet_smooth_l1_loss': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _vp]),
+    'relnet_nms_loss': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _vp]),
     'relnet_gemm_force_tile': (None, [_i]),
     'relnet_gemm_force_nloop': (None, [_i]),
     'relnet_nms_greedy': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
