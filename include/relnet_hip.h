@@ -249,6 +249,31 @@ int relnet_smooth_l1_loss(const float* pred, const float* target, const float* w
 int relnet_nms_loss(const float* score, const float* target, float* pos_loss, float* neg_loss, float* grad, long n,
                     float eps, float loss_scale_over_normalizer, float pos_scale, void* stream);
 
+/* ---- Backward of the relation module (training; adjoint of relnet_geometry_bias / relnet_relation_attention,
+ * i.e. of symbols/resnet_v1_101_rcnn_attention_1024_pairwise_position_multi_head_16.py:85-151 -- MXNet derives it
+ * by autograd, the reference has no backward source).  All gradients fp32.
+ * relnet_transpose_2d: out[c][r] = in[r][c] per batch item (operand layouts below).                          */
+int relnet_transpose_2d(const void* in, long in_ld, long in_bs, void* out, long out_ld, long out_bs, int rows,
+                        int cols, int batch, int dtype, void* stream);
+
+/* q [B][N][..], k [B][M][..] as in the forward; kt = K^T [B][H*64][>=Mpad] and qt = Q^T, dyt = dY^T
+ * [B][H*64][>=Npad] zero padded; vw = F_K Wout^T [B][M][H*64] (not transposed); bias = fp32 log G of the forward;
+ * dy / y = gradient / value of the module output [B][N][H*64] (y includes bout).  Writes prob (softmax) and dlog
+ * (d loss / d logits) [B][H][N][Mpad], dq [B][N][H*64], dk and dvw [B][M][H*64].                              */
+int relnet_relation_attention_bwd(const void* q, long q_ld, long q_bs, const void* k, long k_ld, long k_bs,
+                                  const void* kt, long kt_ld, long kt_bs, const void* vw, long vw_ld, long vw_bs,
+                                  const float* bias, long bias_bs, const void* dy, long dy_ld, long dy_bs,
+                                  const void* y, long y_ld, long y_bs, const float* bout, const void* qt, long qt_ld,
+                                  long qt_bs, const void* dyt, long dyt_ld, long dyt_bs, float* prob, float* dlog,
+                                  float* dq, float* dk, float* dvw, int B, int H, int N, int M, int Mpad, int Npad,
+                                  float scale, int dtype, void* stream);
+
+/* d pair_pos_fc1_{weight [16][64], bias [16]} += from dlog and the forward's fp32 bias (= log max(G,1e-6)):
+ * dpre = dlog / G where G > 1e-6; the 64-d embedding is recomputed from the boxes (SYM_REL:29-83).            */
+int relnet_geometry_bias_bwd(const float* boxes, int box_stride, int box_off, const float* bias, const float* dlog,
+                             const float* divisors8, float* dwp, float* dbp, int B, int N, int M, int Mpad,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

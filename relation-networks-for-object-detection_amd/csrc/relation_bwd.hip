@@ -1,0 +1,446 @@
+// Backward of the object-relation module (training: SURVEY.md section 8 rows A7 / A10 / A13 -- MXNet derives
+// it by autograd from symbols/resnet_v1_101_rcnn_attention_1024_pairwise_position_multi_head_16.py:85-151;
+// there is no backward source in the reference to follow, the math is the adjoint of the forward kernels).
+//
+// Forward (per image b, head h):  L = log(max(G,1e-6)) + s Q K^T,  S = softmax_keys(L),  Y = S VW + bout,
+//                                 VW = F_K Wout_h^T,  G = relu(E Wp^T + bp)
+// Backward, given dY:
+//   D_i   = sum_d dY[i,d] (Y[i,d] - bout[d])                 (= sum_m S dS)
+//   dS    = dY VW^T,   dL = S * (dS - D)
+//   dQ    = s dL K,    dK = s dL^T Q,    dVW = S^T dY
+//   dpre  = dL / G  where G > 1e-6 (else 0);  dWp = dpre^T E,  dbp = sum dpre       (geometry kernel)
+//
+//  relation_attention_bwd_q_kernel   one wavefront = 32 queries of one (image, head): recomputes the logits
+//        (two passes over the keys: row statistics, then probabilities), writes S and dL ([B,H,N,Mpad] fp32)
+//        and dQ.  Same swapped-MFMA layout as the forward kernel: a lane owns one query column.
+//  relation_attention_bwd_kv_kernel  one wavefront = 32 keys of one (image, head): dVW = S^T dY and
+//        dK = s dL^T Q as two more MFMA products over the stored S / dL; the A operands are the transposed
+//        copies dY^T / Q^T ([B][H*64][Npad], queries contiguous).
+//  geometry_bias_bwd_kernel          one wavefront = one query row: E is recomputed on the fly (one sin or cos
+//        per lane), dpre comes from dL and the forward's log G, dWp accumulates in a 32x32x2 fp32 MFMA tile.
+//  transpose_2d_kernel               [rows][cols] -> [cols][rows] through an LDS tile (operand layouts above).
+#include "common.h"
+
+namespace relnet {
+
+enum { RELNET_F32 = 0, RELNET_BF16 = 1 };
+
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_2d_kernel(const T* in, long in_ld, long in_bs, T* out, long out_ld,
+                                                           long out_bs, int rows, int cols) {
+  __shared__ T tile[64][65];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const T* src = in + (long)b * in_bs;
+  T* dst = out + (long)b * out_bs;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 x 4
+  for (int r = ty; r < 64; r += 4)
+    if (r0 + r < rows && c0 + tx < cols) tile[r][tx] = src[(long)(r0 + r) * in_ld + c0 + tx];
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4)
+    if (c0 + c < cols && r0 + tx < rows) dst[(long)(c0 + c) * out_ld + r0 + tx] = tile[tx][c];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct AttnBwdArgs {
+  const void* q; long q_ld, q_bs;          // [B][N][.. h*64+d ..]
+  const void* k; long k_ld, k_bs;          // [B][M][.. h*64+d ..]
+  const void* kt; long kt_ld, kt_bs;       // K^T  [B][H*64][Mpad] (keys contiguous, zero padded)
+  const void* vw; long vw_ld, vw_bs;       // VW   [B][M][H*64]    (NOT transposed)
+  const float* bias; long bias_bs;         // [B][H][N][Mpad] fp32 log G
+  const void* dy; long dy_ld, dy_bs;       // [B][N][H*64] gradient of the module output
+  const void* y; long y_ld, y_bs;          // [B][N][H*64] forward output (incl. bout)
+  const float* bout;                       // [H*64] or nullptr
+  const void* qt; long qt_ld, qt_bs;       // Q^T  [B][H*64][Npad] (queries contiguous, zero padded)
+  const void* dyt; long dyt_ld, dyt_bs;    // dY^T [B][H*64][Npad]
+  float* prob; float* dlog;                // [B][H][N][Mpad] fp32 (written by the q kernel, read by the others)
+  float* dq; float* dk; float* dvw;        // fp32 [B][N][H*64], [B][M][H*64], [B][M][H*64]
+  int B, H, N, M, Mpad;
+  float scale;
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<unsigned short> {           // 64 contraction values of one row as 4 bf16x8 fragments
+  bf16x8 f[4];
+  __device__ __forceinline__ void load(const unsigned short* row, int half) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) f[kk] = *(const bf16x8*)(row + 16 * kk + 8 * half);
+  }
+  __device__ __forceinline__ float get(int kk, int j) const { return bf2f((unsigned short)f[kk][j]); }
+};
+template <> struct Frag<float> {                    // fp32: this half-wave's 32 of the 64 values
+  float f[32];
+  __device__ __forceinline__ void load(const float* row, int half) {
+#pragma unroll
+    for (int s = 0; s < 32; s += 4) {
+      const float4 v = *(const float4*)(row + half * 32 + s);
+      f[s] = v.x; f[s + 1] = v.y; f[s + 2] = v.z; f[s + 3] = v.w;
+    }
+  }
+};
+
+// C^T[row][col=this lane's column] over 64 contraction values: A = `arow` (row l31 of the A matrix), B = frag
+template <typename T>
+__device__ __forceinline__ f32x16 dot64(const T* arow, const Frag<T>& bf, int half) {
+  f32x16 s;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s[r] = 0.f;
+  if constexpr (sizeof(T) == 2) {
+    bf16x8 af[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) af[kk] = *(const bf16x8*)(arow + 16 * kk + 8 * half);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk], bf.f[kk], s, 0, 0, 0);
+  } else {
+    const float* ar = (const float*)arow + half * 32;
+#pragma unroll
+    for (int c4 = 0; c4 < 8; ++c4) {
+      const float4 v = *(const float4*)(ar + 4 * c4);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, bf.f[4 * c4 + 0], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, bf.f[4 * c4 + 1], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, bf.f[4 * c4 + 2], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, bf.f[4 * c4 + 3], s, 0, 0, 0);
+    }
+  }
+  return s;
+}
+
+// o[d] += A[32 d + l31][x0 ...] * p   where p holds this lane's 16 entries (slot r <-> x0 + 8 (r>>2) + 4 half + (r&3)),
+// `abase` = A + x0 + 4 * half for row 0 of the 64-row block, `ald` its row stride (the forward's PV product).
+template <typename T>
+__device__ __forceinline__ void acc_pv(f32x16 (&o)[2], const T* abase, long ald, int l31, const f32x16& p) {
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 pf;
+      unsigned int* pw = (unsigned int*)&pf;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) pw[t] = pack_bf16x2(p[8 * ks + 2 * t], p[8 * ks + 2 * t + 1]);
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const unsigned short* ar = (const unsigned short*)abase + (long)(32 * d + l31) * ald + 16 * ks;
+        bf16x8 af;
+        *(uint2*)&af = *(const uint2*)(ar);
+        *((uint2*)&af + 1) = *(const uint2*)(ar + 8);
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf, o[d], 0, 0, 0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const float* ar = (const float*)abase + (long)(32 * d + l31) * ald;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const float4 v = *(const float4*)(ar + 8 * gq);
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, p[4 * gq + 0], o[d], 0, 0, 0);
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, p[4 * gq + 1], o[d], 0, 0, 0);
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, p[4 * gq + 2], o[d], 0, 0, 0);
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, p[4 * gq + 3], o[d], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// store o (rows = 64 channels of head h, col = this lane's row index) * mul into out[row_index][h*64 + ...] fp32
+__device__ __forceinline__ void store_rows(float* orow, const f32x16 (&o)[2], int half, float mul) {
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int dv = 32 * d + 8 * gq + 4 * half;
+      *(float4*)(orow + dv) = make_float4(o[d][4 * gq] * mul, o[d][4 * gq + 1] * mul, o[d][4 * gq + 2] * mul, o[d][4 * gq + 3] * mul);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void relation_attention_bwd_q_kernel(AttnBwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int qt = blockIdx.x * 4 + wave;
+  const int h = blockIdx.y, b = blockIdx.z;
+  if (qt * 32 >= a.N) return;
+  const int q = qt * 32 + l31;
+  const int qc = q < a.N ? q : a.N - 1;
+
+  const T* Qr = (const T*)a.q + (long)b * a.q_bs + (long)qc * a.q_ld + h * 64;
+  const T* dYr = (const T*)a.dy + (long)b * a.dy_bs + (long)qc * a.dy_ld + h * 64;
+  const T* Yr = (const T*)a.y + (long)b * a.y_bs + (long)qc * a.y_ld + h * 64;
+  const T* Kb = (const T*)a.k + (long)b * a.k_bs + h * 64;
+  const T* VWb = (const T*)a.vw + (long)b * a.vw_bs + h * 64;
+  const T* KTb = (const T*)a.kt + (long)b * a.kt_bs + (long)(h * 64) * a.kt_ld;
+  const float* Bq = a.bias + (long)b * a.bias_bs + ((long)h * a.N + qc) * a.Mpad;
+  float* Pq = a.prob + (((long)b * a.H + h) * a.N + qc) * a.Mpad;
+  float* Lq = a.dlog + (((long)b * a.H + h) * a.N + qc) * a.Mpad;
+
+  Frag<T> qf, dyf;
+  qf.load(Qr, half);
+  dyf.load(dYr, half);
+  // D = sum_d dY (Y - bout) over this lane's half of the 64 channels, then across the two halves
+  float D = 0.f;
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bf16x8 yv = *(const bf16x8*)((const unsigned short*)Yr + 16 * kk + 8 * half);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int d = 16 * kk + 8 * half + j;
+        D += dyf.get(kk, j) * (bf2f((unsigned short)yv[j]) - (a.bout ? a.bout[h * 64 + d] : 0.f));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const int d = half * 32 + s;
+      D += dyf.f[s] * (((const float*)Yr)[d] - (a.bout ? a.bout[h * 64 + d] : 0.f));
+    }
+  }
+  D += __shfl_xor(D, 32);
+
+  const int nkt = (a.M + 31) / 32;
+  // pass 1: row maximum and normaliser
+  float m_run = -INFINITY, l_run = 0.f;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int key0 = kt * 32;
+    int kr = key0 + l31; kr = kr < a.M ? kr : a.M - 1;
+    f32x16 s = dot64<T>(Kb + (long)kr * a.k_ld, qf, half);
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int kbase = key0 + 8 * gq + 4 * half;
+      const float4 bv = *(const float4*)(Bq + kbase);
+      const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = bb[e] + a.scale * s[4 * gq + e];
+        v = (kbase + e < a.M) ? v : -INFINITY;
+        s[4 * gq + e] = v;
+        tmax = fmaxf(tmax, v);
+      }
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) psum += expf(s[r] - m_new);
+    l_run = l_run * expf(m_run - m_new) + psum;
+    m_run = m_new;
+  }
+  const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+
+  // pass 2: S, dS, dL, dQ
+  f32x16 o[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int key0 = kt * 32;
+    int kr = key0 + l31; kr = kr < a.M ? kr : a.M - 1;
+    f32x16 s = dot64<T>(Kb + (long)kr * a.k_ld, qf, half);
+    const f32x16 ds = dot64<T>(VWb + (long)kr * a.vw_ld, dyf, half);
+    f32x16 dl;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int kbase = key0 + 8 * gq + 4 * half;
+      const float4 bv = *(const float4*)(Bq + kbase);
+      const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+      float pv[4], lv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * gq + e;
+        const float v = bb[e] + a.scale * s[r];
+        pv[e] = (kbase + e < a.M) ? expf(v - m_run) * inv : 0.f;
+        lv[e] = pv[e] * (ds[r] - D);
+        dl[r] = lv[e];
+      }
+      if (q < a.N) {
+        *(float4*)(Pq + kbase) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+        *(float4*)(Lq + kbase) = make_float4(lv[0], lv[1], lv[2], lv[3]);
+      }
+    }
+    acc_pv<T>(o, KTb + key0 + 4 * half, a.kt_ld, l31, dl);
+  }
+  if (q < a.N) store_rows(a.dq + ((long)b * a.N + q) * (a.H * 64) + h * 64, o, half, a.scale);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void relation_attention_bwd_kv_kernel(AttnBwdArgs a, int Npad) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int kt = blockIdx.x * 4 + wave;
+  const int h = blockIdx.y, b = blockIdx.z;
+  if (kt * 32 >= a.M) return;
+  const int key = kt * 32 + l31;                       // < Mpad: the S / dL rows are padded
+  const float* Pb = a.prob + (((long)b * a.H + h) * a.N) * a.Mpad + key;
+  const float* Lb = a.dlog + (((long)b * a.H + h) * a.N) * a.Mpad + key;
+  const T* DYT = (const T*)a.dyt + (long)b * a.dyt_bs + (long)(h * 64) * a.dyt_ld;
+  const T* QT = (const T*)a.qt + (long)b * a.qt_bs + (long)(h * 64) * a.qt_ld;
+  f32x16 ov[2], ok[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ov[d][r] = 0.f; ok[d][r] = 0.f; }
+  const int nqt = (a.N + 31) / 32;
+  for (int t = 0; t < nqt; ++t) {
+    const int q0 = t * 32;
+    f32x16 p, dl;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qq = q0 + 8 * (r >> 2) + 4 * half + (r & 3);
+      const bool okq = qq < a.N;
+      p[r] = okq ? Pb[(long)qq * a.Mpad] : 0.f;
+      dl[r] = okq ? Lb[(long)qq * a.Mpad] : 0.f;
+    }
+    acc_pv<T>(ov, DYT + q0 + 4 * half, a.dyt_ld, l31, p);
+    acc_pv<T>(ok, QT + q0 + 4 * half, a.qt_ld, l31, dl);
+  }
+  if (key < a.M) {
+    store_rows(a.dvw + ((long)b * a.M + key) * (a.H * 64) + h * 64, ov, half, 1.0f);
+    store_rows(a.dk + ((long)b * a.M + key) * (a.H * 64) + h * 64, ok, half, a.scale);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct GeomBwdArgs {
+  const float* boxes; int box_stride, box_off;   // [B, N, box_stride]
+  const float* bias;                              // [B][16][N][Mpad] fp32 log(max(G, 1e-6)) of this module
+  const float* dlog;                              // [B][16][N][Mpad] fp32 dL
+  float divisors[8];
+  float* dwp;                                     // [16][64] (+=, atomics)
+  float* dbp;                                     // [16]     (+=, atomics)
+  int B, N, M, Mpad;
+};
+
+#pragma clang fp contract(off)
+__device__ __forceinline__ float position_feature_1(float4 bi, float4 bj, int comp) {
+  // relation.hip:position_features, one component
+  const float wi = bi.z - bi.x + 1.f, hi = bi.w - bi.y + 1.f;
+  const float wj = bj.z - bj.x + 1.f, hj = bj.w - bj.y + 1.f;
+  const float cxi = 0.5f * (bi.x + bi.z), cyi = 0.5f * (bi.y + bi.w);
+  const float cxj = 0.5f * (bj.x + bj.z), cyj = 0.5f * (bj.y + bj.w);
+  float v;
+  if (comp == 0) v = fmaxf(fabsf((cxi - cxj) / wi), 1e-3f);
+  else if (comp == 1) v = fmaxf(fabsf((cyi - cyj) / hi), 1e-3f);
+  else if (comp == 2) v = wi / wj;
+  else v = hi / hj;
+  return (float)log((double)v);
+}
+__device__ __forceinline__ float embed_value(float p, int sc, float divisor) {
+  const float arg = (100.0f * p) / divisor;
+  return sc ? cosf(arg) : sinf(arg);
+}
+#pragma clang fp contract(fast)
+
+// one wavefront per (image, query i); MFMA k = pairs (two per instruction, one per half-wave)
+__global__ __launch_bounds__(256) void geometry_bias_bwd_kernel(GeomBwdArgs g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int i = blockIdx.x * 4 + wave, b = blockIdx.y;
+  if (i >= g.N) return;
+  const float* bx = g.boxes + (long)b * g.N * g.box_stride + g.box_off;
+  const float* pi = bx + (long)i * g.box_stride;
+  const float4 bi = make_float4(pi[0], pi[1], pi[2], pi[3]);
+  // this lane's two embedding columns: c = 32 blk + l31 -> component c >> 4, sin/cos (c >> 3) & 1, frequency c & 7
+  const int comp0 = l31 >> 4, comp1 = 2 + (l31 >> 4), sc = (l31 >> 3) & 1;
+  const float div = g.divisors[l31 & 7];
+  const int hh = l31 & 15;                       // head row supplied by this lane (rows >= 16 are zero)
+  const float* Brow = g.bias + (((long)b * 16 + hh) * g.N + i) * g.Mpad;
+  const float* Lrow = g.dlog + (((long)b * 16 + hh) * g.N + i) * g.Mpad;
+  const float kLogFloor = logf(1e-6f);
+  f32x16 c0, c1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+  float bsum = 0.f;
+  for (int j0 = 0; j0 < g.M; j0 += 2) {
+    const int j = j0 + half;
+    const bool okj = j < g.M;
+    const int jc = okj ? j : g.M - 1;
+    const float* pj = bx + (long)jc * g.box_stride;
+    const float4 bj = make_float4(pj[0], pj[1], pj[2], pj[3]);
+    float dpre = 0.f;
+    if (okj && l31 < 16) {
+      const float lg = Brow[j];
+      dpre = lg > kLogFloor ? Lrow[j] * expf(-lg) : 0.f;          // dL / G, zero on the clamped branch
+    }
+    bsum += dpre;
+    const float e0 = okj ? embed_value(position_feature_1(bi, bj, comp0), sc, div) : 0.f;
+    const float e1 = okj ? embed_value(position_feature_1(bi, bj, comp1), sc, div) : 0.f;
+    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(dpre, e0, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dpre, e1, c1, 0, 0, 0);
+  }
+  // rows h = (r & 3) + 8 (r >> 2) + 4 half < 16  <=>  r < 8 ; col = l31
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int hrow = (r & 3) + 8 * (r >> 2) + 4 * half;
+    atomicAdd(g.dwp + hrow * 64 + l31, c0[r]);
+    atomicAdd(g.dwp + hrow * 64 + 32 + l31, c1[r]);
+  }
+  bsum += __shfl_xor(bsum, 32);
+  if (lane < 16) atomicAdd(g.dbp + lane, bsum);
+}
+
+}  // namespace relnet
+
+using namespace relnet;
+
+extern "C" int relnet_transpose_2d(const void* in, long in_ld, long in_bs, void* out, long out_ld, long out_bs,
+                                   int rows, int cols, int batch, int dtype, void* stream) {
+  RELNET_REQUIRE(in && out, "relnet_transpose_2d: null operand");
+  RELNET_REQUIRE(rows > 0 && cols > 0 && batch > 0 && in_ld >= cols && out_ld >= rows, "relnet_transpose_2d: bad shape");
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64, batch);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == RELNET_F32) transpose_2d_kernel<float><<<grid, 256, 0, s>>>((const float*)in, in_ld, in_bs, (float*)out, out_ld, out_bs, rows, cols);
+  else if (dtype == RELNET_BF16) transpose_2d_kernel<unsigned short><<<grid, 256, 0, s>>>((const unsigned short*)in, in_ld, in_bs, (unsigned short*)out, out_ld, out_bs, rows, cols);
+  else RELNET_REQUIRE(false, "relnet_transpose_2d: unknown dtype %d", dtype);
+  return check_launch("relnet_transpose_2d");
+}
+
+extern "C" int relnet_relation_attention_bwd(
+    const void* q, long q_ld, long q_bs, const void* k, long k_ld, long k_bs, const void* kt, long kt_ld, long kt_bs,
+    const void* vw, long vw_ld, long vw_bs, const float* bias, long bias_bs, const void* dy, long dy_ld, long dy_bs,
+    const void* y, long y_ld, long y_bs, const float* bout, const void* qt, long qt_ld, long qt_bs, const void* dyt,
+    long dyt_ld, long dyt_bs, float* prob, float* dlog, float* dq, float* dk, float* dvw, int B, int H, int N, int M,
+    int Mpad, int Npad, float scale, int dtype, void* stream) {
+  RELNET_REQUIRE(q && k && kt && vw && bias && dy && y && qt && dyt && prob && dlog && dq && dk && dvw,
+                 "relnet_relation_attention_bwd: null operand");
+  RELNET_REQUIRE(B > 0 && H > 0 && N > 0 && M > 0 && M <= N && Mpad >= M && Mpad % 32 == 0 && Npad >= N && Npad % 32 == 0,
+                 "relnet_relation_attention_bwd: bad shape (N=%d M=%d Mpad=%d Npad=%d)", N, M, Mpad, Npad);
+  RELNET_REQUIRE(kt_ld >= Mpad && qt_ld >= Npad && dyt_ld >= Npad, "relnet_relation_attention_bwd: transposed operands must be padded");
+  AttnBwdArgs a;
+  a.q = q; a.q_ld = q_ld; a.q_bs = q_bs; a.k = k; a.k_ld = k_ld; a.k_bs = k_bs; a.kt = kt; a.kt_ld = kt_ld; a.kt_bs = kt_bs;
+  a.vw = vw; a.vw_ld = vw_ld; a.vw_bs = vw_bs; a.bias = bias; a.bias_bs = bias_bs; a.dy = dy; a.dy_ld = dy_ld; a.dy_bs = dy_bs;
+  a.y = y; a.y_ld = y_ld; a.y_bs = y_bs; a.bout = bout; a.qt = qt; a.qt_ld = qt_ld; a.qt_bs = qt_bs;
+  a.dyt = dyt; a.dyt_ld = dyt_ld; a.dyt_bs = dyt_bs; a.prob = prob; a.dlog = dlog; a.dq = dq; a.dk = dk; a.dvw = dvw;
+  a.B = B; a.H = H; a.N = N; a.M = M; a.Mpad = Mpad; a.scale = scale;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 gq((unsigned)(((N + 31) / 32 + 3) / 4), H, B), gk((unsigned)(((M + 31) / 32 + 3) / 4), H, B);
+  if (dtype == RELNET_F32) {
+    RELNET_REQUIRE(q_ld % 4 == 0 && k_ld % 4 == 0 && kt_ld % 4 == 0 && vw_ld % 4 == 0 && dy_ld % 4 == 0 && qt_ld % 4 == 0 && dyt_ld % 4 == 0,
+                   "relnet_relation_attention_bwd(f32): rows must be 16-byte aligned");
+    relation_attention_bwd_q_kernel<float><<<gq, 256, 0, s>>>(a);
+    relation_attention_bwd_kv_kernel<float><<<gk, 256, 0, s>>>(a, Npad);
+  } else if (dtype == RELNET_BF16) {
+    RELNET_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && kt_ld % 4 == 0 && vw_ld % 8 == 0 && dy_ld % 8 == 0 && y_ld % 8 == 0 && qt_ld % 4 == 0 && dyt_ld % 4 == 0,
+                   "relnet_relation_attention_bwd(bf16): rows must be 16-byte (8-byte for the transposed operands) aligned");
+    relation_attention_bwd_q_kernel<unsigned short><<<gq, 256, 0, s>>>(a);
+    relation_attention_bwd_kv_kernel<unsigned short><<<gk, 256, 0, s>>>(a, Npad);
+  } else {
+    RELNET_REQUIRE(false, "relnet_relation_attention_bwd: unknown dtype %d", dtype);
+  }
+  return check_launch("relnet_relation_attention_bwd");
+}
+
+extern "C" int relnet_geometry_bias_bwd(const float* boxes, int box_stride, int box_off, const float* bias,
+                                        const float* dlog, const float* divisors8, float* dwp, float* dbp, int B,
+                                        int N, int M, int Mpad, void* stream) {
+  RELNET_REQUIRE(boxes && bias && dlog && divisors8 && dwp && dbp, "relnet_geometry_bias_bwd: null operand");
+  RELNET_REQUIRE(B > 0 && N > 0 && M > 0 && Mpad >= M, "relnet_geometry_bias_bwd: bad shape");
+  GeomBwdArgs g;
+  g.boxes = boxes; g.box_stride = box_stride; g.box_off = box_off; g.bias = bias; g.dlog = dlog;
+  for (int k = 0; k < 8; ++k) g.divisors[k] = divisors8[k];
+  g.dwp = dwp; g.dbp = dbp; g.B = B; g.N = N; g.M = M; g.Mpad = Mpad;
+  dim3 grid((unsigned)((N + 3) / 4), B);
+  geometry_bias_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g);
+  return check_launch("relnet_geometry_bias_bwd");
+}

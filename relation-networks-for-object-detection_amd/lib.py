@@ -50,6 +50,11 @@ _SIGNATURES = {
     'relnet_softmax_output': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _i, _l, _i, _f, _f, _vp]),
     'relnet_smooth_l1_loss': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _vp]),
     'relnet_nms_loss': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _vp]),
+    'relnet_transpose_2d': (C.c_int, [_vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _vp]),
+    'relnet_relation_attention_bwd': (C.c_int, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _vp, _l, _l,
+                                                _vp, _l, _l, _vp, _vp, _l, _l, _vp, _l, _l, _vp, _vp, _vp, _vp, _vp,
+                                                _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    'relnet_geometry_bias_bwd': (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'relnet_gemm_force_tile': (None, [_i]),
     'relnet_gemm_force_nloop': (None, [_i]),
     'relnet_nms_greedy': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),

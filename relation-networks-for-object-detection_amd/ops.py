@@ -537,3 +537,64 @@ def upsample2x_add_(lateral, top):
                          % (tuple(lateral.shape), tuple(top.shape)))
     _lib.call('relnet_upsample2x_add', top.data_ptr(), lateral.data_ptr(), B, H, W, Cc, _dt(lateral), _stream())
     return lateral
+
+
+# ---------------------------------------------------------------------------------------
+# relation module backward (training)
+# ---------------------------------------------------------------------------------------
+def pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def transpose_2d(x, out=None, pad_cols_to=1):
+    """x [rows, cols] or [batch, rows, cols] (last dim contiguous) -> [.., cols, pad(rows)] (zero padded)."""
+    _chk(x, out)
+    assert x.stride(-1) == 1
+    batch = x.shape[0] if x.dim() == 3 else 1
+    rows, cols = x.shape[-2], x.shape[-1]
+    rp = pad_to(rows, pad_cols_to)
+    if out is None:
+        shape = (batch, cols, rp) if x.dim() == 3 else (cols, rp)
+        out = (torch.zeros if rp != rows else torch.empty)(shape, device=x.device, dtype=x.dtype)
+    assert out.stride(-1) == 1 and out.shape[-2] == cols and out.shape[-1] >= rows
+    _lib.call('relnet_transpose_2d', x.data_ptr(), x.stride(-2), x.stride(0) if x.dim() == 3 else 0, out.data_ptr(),
+              out.stride(-2), out.stride(0) if out.dim() == 3 else 0, rows, cols, batch, _dt(x), _stream())
+    return out
+
+
+def relation_attention_bwd(q, k, kt, vw, bias, dy, y, bout, qt, dyt, M, heads=16):
+    """Adjoint of relation_attention: -> (dq [B,N,H*64], dk [B,M,H*64], dvw [B,M,H*64], prob, dlog [B,H,N,Mpad]), fp32."""
+    _chk(q, k, kt, vw, bias, dy, y, bout, qt, dyt)
+    B, N = q.shape[0], q.shape[1]
+    H = heads
+    Mpad, Npad = bias.shape[-1], qt.shape[-1]
+    assert bias.dtype == torch.float32 and bias.shape == (B, H, N, Mpad) and bias.is_contiguous()
+    assert kt.shape[1] == H * 64 and kt.shape[2] >= Mpad and dyt.shape == qt.shape and qt.shape[1] == H * 64
+    dev = q.device
+    prob = torch.empty((B, H, N, Mpad), device=dev, dtype=torch.float32)
+    dlog = torch.empty((B, H, N, Mpad), device=dev, dtype=torch.float32)
+    dq = torch.empty((B, N, H * 64), device=dev, dtype=torch.float32)
+    dk = torch.empty((B, M, H * 64), device=dev, dtype=torch.float32)
+    dvw = torch.empty((B, M, H * 64), device=dev, dtype=torch.float32)
+    _lib.call('relnet_relation_attention_bwd',
+              q.data_ptr(), q.stride(1), q.stride(0), k.data_ptr(), k.stride(1), k.stride(0),
+              kt.data_ptr(), kt.stride(1), kt.stride(0), vw.data_ptr(), vw.stride(1), vw.stride(0),
+              bias.data_ptr(), bias.stride(0), dy.data_ptr(), dy.stride(1), dy.stride(0),
+              y.data_ptr(), y.stride(1), y.stride(0), _ptr(bout), qt.data_ptr(), qt.stride(1), qt.stride(0),
+              dyt.data_ptr(), dyt.stride(1), dyt.stride(0), prob.data_ptr(), dlog.data_ptr(), dq.data_ptr(),
+              dk.data_ptr(), dvw.data_ptr(), B, H, N, M, Mpad, Npad, 1.0 / math.sqrt(64.0), _dt(q), _stream())
+    return dq, dk, dvw, prob, dlog
+
+
+def geometry_bias_bwd(boxes, bias, dlog, M, divisors=None):
+    """boxes [B,N,4|5]; bias / dlog [B,16,N,Mpad] fp32 -> (d pair_pos_fc1 weight [16,64], d bias [16]) fp32."""
+    _chk(boxes, bias, dlog)
+    assert boxes.dtype == torch.float32 and boxes.is_contiguous()
+    B, N, bs = boxes.shape
+    assert bias.shape == dlog.shape and bias.shape[:3] == (B, 16, N) and bias.is_contiguous() and dlog.is_contiguous()
+    div = (embedding_divisors() if divisors is None else divisors).to(torch.float32).cpu().contiguous()
+    dwp = torch.zeros((16, 64), device=boxes.device, dtype=torch.float32)
+    dbp = torch.zeros((16,), device=boxes.device, dtype=torch.float32)
+    _lib.call('relnet_geometry_bias_bwd', boxes.data_ptr(), bs, 1 if bs == 5 else 0, bias.data_ptr(), dlog.data_ptr(),
+              div.data_ptr(), dwp.data_ptr(), dbp.data_ptr(), B, N, M, bias.shape[-1], _stream())
+    return dwp, dbp

@@ -135,3 +135,73 @@ class RelationHead(object):
             return dict(fc_new_1=f1, attention_1=y1, fc_all_1_relu=x1, fc_new_2=f2, attention_2=y2,
                         fc_all_2_relu=x2, cls_score=cls_score, bbox_pred=bbox_pred)
         return cls_score, bbox_pred, x2
+
+
+def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, index=1, dtype=None, packed=None):
+    """Gradient of `attention_module_multi_head` (the adjoint MXNet's autograd derives from SYM_REL:85-151).
+
+    roi_feat [B,N,1024] (or [N,1024]), rois [..,N,4|5], d_out = d loss / d module output, same shape.
+    Returns dict: d_roi_feat [B,N,1024] and the parameter gradients under the reference's names
+    (`query_i_weight`, `key_i_bias`, `linear_out_i_weight` [1024,1024,1,1], `pair_pos_fc1_i_weight`, ...), all fp32.
+
+    Every contraction runs on the GEMM / attention kernels: weight gradients are A^T B products, formed as
+    gemm_nt over transposed copies (relnet_transpose_2d); the forward is recomputed from roi_feat (nothing but
+    the inputs has to be kept alive between forward and backward)."""
+    squeeze = roi_feat.dim() == 2
+    f = roi_feat[None] if squeeze else roi_feat
+    bx = (rois[None] if rois.dim() == 2 else rois).to(torch.float32).contiguous()
+    dY = d_out[None] if squeeze else d_out
+    dtype = dtype or f.dtype
+    f = f.to(dtype).contiguous()
+    dY = dY.to(dtype).contiguous()
+    B, N, Fd = f.shape
+    M = N if nongt_dim is None else nongt_dim
+    mod = packed or RelationParams(params, index, dtype, f.device)
+    wp_t, bp = pack_pair_pos([mod], f.device)
+    bias = ops.geometry_bias(bx, wp_t, bp, M)[0]                       # fp32 log G  [B,16,N,Mpad]
+    Mpad = bias.shape[-1]
+    d = mod.wqk.shape[0] // 2
+    kpad = 64 if dtype == torch.bfloat16 else 16                        # GEMM K granularity
+    # ---- forward recompute
+    qk = ops.gemm_nt(f.reshape(B * N, Fd), mod.wqk, mod.bqk).reshape(B, N, 2 * d)
+    q, k = qk[:, :, :d], qk[:, :M, d:]
+    vwt = torch.zeros((B, d, Mpad), device=f.device, dtype=dtype)
+    ops.gemm_nt(mod.wout, f[:, :M, :], out=vwt, n_cols=M)
+    y, _, _ = ops.relation_attention(q, k, vwt, bias, bout=mod.bout, M=M, want_out=True)
+    # ---- operand layouts of the backward kernels
+    vw = ops.gemm_nt(f[:, :M, :].reshape(B * M, Fd) if M == N else f[:, :M, :].contiguous().reshape(B * M, Fd),
+                     mod.wout).reshape(B, M, d)                          # F_K Wout^T, not transposed
+    kt = torch.zeros((B, d, Mpad), device=f.device, dtype=dtype)
+    ops.transpose_2d(k, out=kt)
+    qt = ops.transpose_2d(q, pad_cols_to=32)
+    dyt = ops.transpose_2d(dY, pad_cols_to=32)
+    dq, dk, dvw, prob, dlog = ops.relation_attention_bwd(q, k, kt, vw, bias, dY, y, mod.bout, qt, dyt, M)
+    dwp, dbp = ops.geometry_bias_bwd(bx, bias, dlog, M)
+    # ---- projections: Q|K = F [Wq;Wk]^T + b,  VW = F_K Wout^T
+    dqk = torch.zeros((B, N, 2 * d), device=f.device, dtype=dtype)
+    dqk[:, :, :d] = dq
+    dqk[:, :M, d:] = dk
+    dvw_t = dvw.to(dtype)
+    wqk_t = ops.transpose_2d(mod.wqk)                                    # [Fd, 2d]
+    wout_t = ops.transpose_2d(mod.wout)                                  # [Fd, d]
+    d_f = ops.gemm_nt(dqk.reshape(B * N, 2 * d), wqk_t, out_dtype=torch.float32).reshape(B, N, Fd)
+    d_fk = ops.gemm_nt(dvw_t.reshape(B * M, d), wout_t, out_dtype=torch.float32).reshape(B, M, Fd)
+    d_f[:, :M] += d_fk
+    # weight gradients: dW[out, in] = sum_rows dOut[row, out] X[row, in]
+    f_t = ops.transpose_2d(f.reshape(B * N, Fd), pad_cols_to=kpad)       # [Fd, pad(B N)]
+    dqk_t = ops.transpose_2d(dqk.reshape(B * N, 2 * d), pad_cols_to=kpad)
+    d_wqk = ops.gemm_nt(dqk_t, f_t, out_dtype=torch.float32)             # [2d, Fd]
+    fk = f[:, :M, :].contiguous().reshape(B * M, Fd)
+    fk_t = ops.transpose_2d(fk, pad_cols_to=kpad)
+    dvw_tt = ops.transpose_2d(dvw_t.reshape(B * M, d), pad_cols_to=kpad)
+    d_wout = ops.gemm_nt(dvw_tt, fk_t, out_dtype=torch.float32)          # [d, Fd]
+    i = index
+    grads = {
+        'd_roi_feat': d_f[0] if squeeze else d_f,
+        'query_%d_weight' % i: d_wqk[:d], 'key_%d_weight' % i: d_wqk[d:],
+        'query_%d_bias' % i: dq.sum((0, 1)), 'key_%d_bias' % i: dk.sum((0, 1)),
+        'linear_out_%d_weight' % i: d_wout.reshape(d, Fd, 1, 1),
+        'linear_out_%d_bias' % i: dY.float().sum((0, 1)),
+        'pair_pos_fc1_%d_weight' % i: dwp, 'pair_pos_fc1_%d_bias' % i: dbp,
+    }
+    return grads

@@ -1,0 +1,93 @@
+"""GPU parity of the relation-module backward (csrc/relation_bwd.hip + GEMM composition) against torch-CPU float64
+autograd of the restated module (oracle/relation_torch.py).  fp32 path: every gradient within 2e-4 of its own
+max-abs (fp32 accumulation over up to 300 x 1024 terms); bf16 path: 4e-2."""
+import os
+import sys
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+import cases  # noqa: E402
+from oracle import relation_torch as ORT  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _autograd(feat, boxes, p, m, d_out):
+    ft = torch.tensor(feat.astype(np.float64), requires_grad=True)
+    pt = {k: torch.tensor(v.astype(np.float64), requires_grad=True) for k, v in p.items()}
+    y = ORT.relation_module(ft, boxes, pt, 1, m)
+    (y * torch.as_tensor(d_out.astype(np.float64))).sum().backward()
+    g = {k: v.grad.numpy() for k, v in pt.items()}
+    g['d_roi_feat'] = ft.grad.numpy()
+    return g
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_transpose_2d(dtype):
+    import relnet_amd  # noqa: F401
+    from relnet_amd import ops
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    x = torch.randn(3, 300, 1024, device='cuda').to(dt)
+    y = ops.transpose_2d(x[:, :, 64:640], pad_cols_to=32)              # strided rows, padded output
+    assert y.shape == (3, 576, 320)
+    assert torch.equal(y[:, :, :300], x[:, :, 64:640].transpose(1, 2)) and float(y[:, :, 300:].abs().max()) == 0
+    z = ops.transpose_2d(x[0, :77, :130])
+    assert torch.equal(z, x[0, :77, :130].t())
+
+
+@pytest.mark.parametrize('n,m,seed,std', [(48, 48, 11, 0.03), (40, 32, 12, 0.05), (300, 300, 41, 0.02), (333, 300, 43, 0.02)])
+def test_relation_module_backward_fp32(n, m, seed, std):
+    import relnet_amd  # noqa: F401
+    from relnet_amd import relation
+    boxes, feat, p = cases.relation_case(n, m, seed, std)
+    rng = np.random.default_rng(seed + 500)
+    d_out = rng.normal(0, 1, (n, 1024)).astype(np.float32)
+    want = _autograd(feat, boxes, p, m, d_out)
+    pt = {k: torch.as_tensor(v) for k, v in p.items()}
+    got = relation.attention_module_backward(torch.as_tensor(feat).cuda(), torch.as_tensor(boxes).cuda(), pt,
+                                             torch.as_tensor(d_out).cuda(), nongt_dim=m, dtype=torch.float32)
+    assert set(got) == set(want)
+    for k in sorted(want):
+        g = got[k].cpu().numpy().reshape(want[k].shape)
+        if k == 'key_1_bias':      # exactly zero in exact arithmetic (softmax is invariant to a shift of all keys)
+            assert np.abs(want[k]).max() < 1e-12 and np.abs(g).max() <= 1e-5 * np.abs(want['query_1_bias']).max()
+            continue
+        # pair_pos_fc1 gradients are DISCONTINUOUS at the 1e-6 floor of log(max(G, 1e-6)): a pair whose G rounds to
+        # the other side of the floor in fp32 moves a term of size dL / 1e-6, so they get a wider bar
+        tol = 2e-3 if k.startswith('pair_pos') else 2e-4
+        assert _rel(g, want[k]) <= tol, (k, _rel(g, want[k]))
+    # the clamp / ReLU branches are exercised: some geometry weights sit on the 1e-6 floor
+    assert np.abs(want['pair_pos_fc1_1_weight']).max() > 0
+
+
+def test_relation_module_backward_batched_bf16():
+    """bf16 operands (MFMA 32x32x16), batch of 2 images with shared weights: parameter gradients sum over images."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import relation
+    n, m = 300, 300
+    boxes0, feat0, p = cases.relation_case(n, m, 41, 0.02)
+    boxes1 = cases.random_boxes(n, 777)
+    rng = np.random.default_rng(9)
+    feat1 = rng.normal(0, 1, feat0.shape).astype(np.float32)
+    d_out = rng.normal(0, 1, (2, n, 1024)).astype(np.float32)
+    r = lambda a: torch.as_tensor(a).to(torch.bfloat16).float().numpy()          # operands as the kernel sees them
+    w0 = _autograd(r(feat0), boxes0, {k: (r(v) if 'pair_pos' not in k and 'bias' not in k else v) for k, v in p.items()}, m, r(d_out[0]))
+    w1 = _autograd(r(feat1), boxes1, {k: (r(v) if 'pair_pos' not in k and 'bias' not in k else v) for k, v in p.items()}, m, r(d_out[1]))
+    pt = {k: torch.as_tensor(v) for k, v in p.items()}
+    got = relation.attention_module_backward(torch.as_tensor(np.stack([feat0, feat1])).cuda(),
+                                             torch.as_tensor(np.stack([boxes0, boxes1])).cuda(), pt,
+                                             torch.as_tensor(d_out).cuda(), nongt_dim=m, dtype=torch.bfloat16)
+    for k in sorted(w0):
+        want = np.stack([w0[k], w1[k]]) if k == 'd_roi_feat' else w0[k] + w1[k]
+        g = got[k].cpu().numpy().reshape(want.shape)
+        if k == 'key_1_bias':
+            assert np.abs(g).max() <= 1e-2 * np.abs(w0['query_1_bias'] + w1['query_1_bias']).max()
+            continue
+        assert _rel(g, want) <= 4e-2, (k, _rel(g, want))

@@ -136,3 +136,17 @@ def test_training_targets_match_reference(golden):
     bbox, gt_box, score = cases.nms_target_case(40, 6, 9, 62)
     t = OT.nms_multi_target(bbox, gt_box, score)
     assert np.array_equal(t, g['nmt/target']) and t.sum() > 0
+
+
+def test_torch_relation_matches_numpy_oracle():
+    """oracle/relation_torch.py (the autograd checker of the backward kernels) computes the same forward as the
+    numpy oracle that is pinned to the reference's Python above."""
+    import torch
+    from oracle import relation as OR, relation_torch as ORT
+    for n, m, seed, std in ((40, 32, 12, 0.05), (48, 48, 11, 0.01)):
+        boxes, feat, p = cases.relation_case(n, m, seed, std)
+        pe = OR.position_embedding(OR.position_matrix(boxes, m))
+        want = OR.relation_module(feat, pe, p, 1, m)
+        pt = {k: torch.as_tensor(v.astype(np.float64)) for k, v in p.items()}
+        got = ORT.relation_module(torch.as_tensor(feat.astype(np.float64)), boxes, pt, 1, m).numpy()
+        assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
