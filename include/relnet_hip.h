@@ -274,6 +274,17 @@ int relnet_geometry_bias_bwd(const float* boxes, int box_stride, int box_off, co
                              const float* divisors8, float* dwp, float* dbp, int B, int N, int M, int Mpad,
                              void* stream);
 
+/* ---- Elementwise pieces of the training step ------------------------------
+ * Gradient through Activation(relu) and the fused conv(+residual)+ReLU epilogues: dx = dy * (y > 0) (+ add).  */
+int relnet_relu_bwd(const void* dy, const void* y, const void* add /*or NULL*/, void* dx, long n, int dtype,
+                    void* stream);
+
+/* mx.optimizer.SGD as set up in relation_rcnn/train_end2end.py:163-168 (momentum, wd, rescale_grad 1.0, no
+ * clipping): mom = momentum*mom - lr*(rescale*grad + wd*w); w += mom.  fp32 master weights; w_bf16 (may be
+ * NULL) receives the rounded copy the MFMA kernels read.                                                    */
+int relnet_sgd_update(float* w, float* mom, const float* grad, void* w_bf16, long n, float lr, float momentum,
+                      float wd, float rescale_grad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

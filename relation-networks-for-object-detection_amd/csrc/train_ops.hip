@@ -1,0 +1,92 @@
+// Elementwise pieces of the training step:
+//  * relnet_relu_bwd    gradient through mx.symbol.Activation(act_type='relu') (and through the fused
+//                       conv + bias + [residual] + ReLU epilogues of the forward kernels): dx = dy * (y > 0),
+//                       optionally + an accumulated second gradient (the bottleneck's shortcut branch).
+//  * relnet_sgd_update  mx.optimizer.SGD as configured by relation_rcnn/train_end2end.py:163-168
+//                       (momentum 0.9, wd 5e-4, rescale_grad 1.0, no gradient clipping):
+//                         mom = momentum * mom - lr * (rescale * grad + wd * w);  w += mom
+//                       on fp32 master weights, optionally refreshing a bf16 copy for the MFMA kernels.
+#include "common.h"
+
+namespace relnet {
+enum { RELNET_F32 = 0, RELNET_BF16 = 1 };
+
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const T* dy, const T* y, const T* add, T* dx, long n) {
+  constexpr int V = 16 / sizeof(T);
+  const long nv = n / V;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+    const uint4 g = *((const uint4*)dy + i), o = *((const uint4*)y + i);
+    uint4 a = make_uint4(0, 0, 0, 0);
+    if (add) a = *((const uint4*)add + i);
+    uint4 r;
+    if constexpr (sizeof(T) == 4) {
+      const float* fg = (const float*)&g; const float* fo = (const float*)&o; const float* fa = (const float*)&a;
+      float* fr = (float*)&r;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) fr[k] = (fo[k] > 0.f ? fg[k] : 0.f) + (add ? fa[k] : 0.f);
+    } else {
+      const unsigned int* ug = (const unsigned int*)&g; const unsigned int* uo = (const unsigned int*)&o;
+      const unsigned int* ua = (const unsigned int*)&a; unsigned int* ur = (unsigned int*)&r;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float glo = __uint_as_float(ug[k] << 16), ghi = __uint_as_float(ug[k] & 0xffff0000u);
+        const float olo = __uint_as_float(uo[k] << 16), ohi = __uint_as_float(uo[k] & 0xffff0000u);
+        const float alo = add ? __uint_as_float(ua[k] << 16) : 0.f, ahi = add ? __uint_as_float(ua[k] & 0xffff0000u) : 0.f;
+        ur[k] = pack_bf16x2((olo > 0.f ? glo : 0.f) + alo, (ohi > 0.f ? ghi : 0.f) + ahi);
+      }
+    }
+    *((uint4*)dx + i) = r;
+  }
+  // tail (n not a multiple of the vector width)
+  if (blockIdx.x == 0) {
+    for (long i = nv * V + threadIdx.x; i < n; i += 256) {
+      float g, o, a = 0.f;
+      if constexpr (sizeof(T) == 4) { g = dy[i]; o = y[i]; if (add) a = add[i]; dx[i] = (o > 0.f ? g : 0.f) + a; }
+      else { g = bf2f(dy[i]); o = bf2f(y[i]); if (add) a = bf2f(add[i]); dx[i] = f2bf((o > 0.f ? g : 0.f) + a); }
+    }
+  }
+}
+
+struct SgdArgs {
+  float* w; float* mom; const float* grad; unsigned short* w_bf16;
+  long n;
+  float lr, momentum, wd, rescale;
+};
+
+__global__ __launch_bounds__(256) void sgd_update_kernel(SgdArgs g) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < g.n; i += (long)gridDim.x * 256) {
+    const float w = g.w[i];
+    const float m = g.momentum * g.mom[i] - g.lr * (g.rescale * g.grad[i] + g.wd * w);
+    const float wn = w + m;
+    g.mom[i] = m;
+    g.w[i] = wn;
+    if (g.w_bf16) g.w_bf16[i] = f2bf(wn);
+  }
+}
+
+}  // namespace relnet
+
+using namespace relnet;
+
+extern "C" int relnet_relu_bwd(const void* dy, const void* y, const void* add, void* dx, long n, int dtype, void* stream) {
+  RELNET_REQUIRE(dy && y && dx && n > 0, "relnet_relu_bwd: bad operand");
+  RELNET_REQUIRE((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)add) & 15) == 0, "relnet_relu_bwd: operands must be 16-byte aligned");
+  long blocks = (n / 8 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == RELNET_F32) relu_bwd_kernel<float><<<(unsigned)blocks, 256, 0, s>>>((const float*)dy, (const float*)y, (const float*)add, (float*)dx, n);
+  else if (dtype == RELNET_BF16) relu_bwd_kernel<unsigned short><<<(unsigned)blocks, 256, 0, s>>>((const unsigned short*)dy, (const unsigned short*)y, (const unsigned short*)add, (unsigned short*)dx, n);
+  else RELNET_REQUIRE(false, "relnet_relu_bwd: unknown dtype %d", dtype);
+  return check_launch("relnet_relu_bwd");
+}
+
+extern "C" int relnet_sgd_update(float* w, float* mom, const float* grad, void* w_bf16, long n, float lr, float momentum,
+                                 float wd, float rescale_grad, void* stream) {
+  RELNET_REQUIRE(w && mom && grad && n > 0, "relnet_sgd_update: bad operand");
+  SgdArgs g{w, mom, grad, (unsigned short*)w_bf16, n, lr, momentum, wd, rescale_grad};
+  long blocks = (n + 255) / 256;
+  blocks = blocks > 8192 ? 8192 : blocks;
+  sgd_update_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(g);
+  return check_launch("relnet_sgd_update");
+}

@@ -55,6 +55,8 @@ _SIGNATURES = {
                                                 _vp, _l, _l, _vp, _vp, _l, _l, _vp, _l, _l, _vp, _vp, _vp, _vp, _vp,
                                                 _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     'relnet_geometry_bias_bwd': (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'relnet_relu_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _l, _i, _vp]),
+    'relnet_sgd_update': (C.c_int, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _vp]),
     'relnet_gemm_force_tile': (None, [_i]),
     'relnet_gemm_force_nloop': (None, [_i]),
     'relnet_nms_greedy': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),

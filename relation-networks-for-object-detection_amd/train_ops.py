@@ -1,0 +1,122 @@
+"""Backward building blocks of the training step, composed from the HIP kernels:
+
+  linear_bwd / conv1x1_bwd / conv3x3_bwd   data gradient  = GEMM / implicit-GEMM conv with transposed (and, for
+                                           3x3, tap-flipped) weights;
+                                           weight gradient = dY^T X as a split-K gemm_nt over transposed copies
+                                           (relnet_transpose_2d), K = pixels, partial sums reduced in fp32
+  relu_bwd                                 gradient through the fused (+residual)+ReLU epilogues
+  sgd_update                               mx.optimizer.SGD (train_end2end.py:163-168)
+
+MXNet derives these by autograd from the symbols; there is no backward source in the reference to follow.  Layout
+is the forward's: NHWC bf16 activations, weights packed [Cout][R][S][Cin].
+"""
+import torch
+
+from . import lib as _lib
+from . import ops
+from .ops import _chk, _dt, _ptr, _stream, pad_to
+
+
+def relu_bwd(dy, y, add=None, out=None):
+    """dx = dy * (y > 0) (+ add); y is the saved forward output of the ReLU."""
+    _chk(dy, y, add, out)
+    assert dy.is_contiguous() and y.is_contiguous() and dy.shape == y.shape and dy.dtype == y.dtype
+    if add is not None:
+        assert add.is_contiguous() and add.shape == dy.shape and add.dtype == dy.dtype
+    out = torch.empty_like(dy) if out is None else out
+    _lib.call('relnet_relu_bwd', dy.data_ptr(), y.data_ptr(), _ptr(add), out.data_ptr(), dy.numel(), _dt(dy), _stream())
+    return out
+
+
+def sgd_update(w, mom, grad, lr, momentum=0.9, wd=0.0005, rescale_grad=1.0, w_bf16=None):
+    """In place on fp32 `w` / `mom`; optional bf16 copy refreshed in the same pass."""
+    _chk(w, mom, grad, w_bf16)
+    assert w.dtype == torch.float32 and mom.dtype == torch.float32 and grad.dtype == torch.float32
+    assert w.is_contiguous() and mom.is_contiguous() and grad.is_contiguous() and grad.numel() == w.numel()
+    if w_bf16 is not None:
+        assert w_bf16.dtype == torch.bfloat16 and w_bf16.is_contiguous() and w_bf16.numel() == w.numel()
+    _lib.call('relnet_sgd_update', w.data_ptr(), mom.data_ptr(), grad.data_ptr(), _ptr(w_bf16), w.numel(), float(lr),
+              float(momentum), float(wd), float(rescale_grad), _stream())
+
+
+def _splits_for(m, n, k):
+    """split-K factor of a weight-gradient GEMM [m, n] with a long contraction k: enough tiles to fill 256 CUs."""
+    tiles = ((m + 255) // 256) * ((n + 255) // 256)
+    s = max(1, min(512 // max(tiles, 1), k // 512))
+    return s
+
+
+def wgrad(dy2d, x2d):
+    """dW [Cout, K] = dY^T X for dY [P, Cout], X [P, K] (bf16 or fp32, rows = pixels / rois); fp32 result."""
+    P, Cout = dy2d.shape
+    K = x2d.shape[1]
+    gran = 64 if dy2d.dtype == torch.bfloat16 else 16
+    s = _splits_for(Cout, K, P)
+    Pp = pad_to(P, gran * s)
+    dyt = ops.transpose_2d(dy2d, pad_cols_to=gran * s)                 # [Cout, Pp], zero padded
+    xt = ops.transpose_2d(x2d, pad_cols_to=gran * s)                   # [K, Pp]
+    ks = Pp // s
+    a3 = dyt.as_strided((s, Cout, ks), (ks, dyt.stride(0), 1))
+    w3 = xt.as_strided((s, K, ks), (ks, xt.stride(0), 1))
+    part = ops.gemm_nt(a3, w3, out_dtype=torch.float32)                 # [s, Cout, K] partial sums
+    return part.sum(0) if s > 1 else part[0]
+
+
+def linear_bwd(x2d, w, dy2d, need_dx=True, w_t=None):
+    """y = x W^T + b  ->  (dx [P,K] in x's dtype | None, dW [N,K] fp32, db [N] fp32)."""
+    dx = None
+    if need_dx:
+        gran = 64 if dy2d.dtype == torch.bfloat16 else 16
+        N = dy2d.shape[1]
+        w_t = ops.transpose_2d(w, pad_cols_to=gran) if w_t is None else w_t      # [K, pad(N)], zero padded
+        dyp = dy2d
+        if N % gran:                              # e.g. the 81 + 8 outputs of cls_score | bbox_pred
+            dyp = torch.zeros((dy2d.shape[0], w_t.shape[1]), device=dy2d.device, dtype=dy2d.dtype)
+            dyp[:, :N] = dy2d
+        dx = ops.gemm_nt(dyp, w_t)
+    return dx, wgrad(dy2d, x2d), dy2d.float().sum(0)
+
+
+def pack_conv_dgrad_weight(w_oihw, dtype=torch.bfloat16, device='cuda'):
+    """[Cout, Cin, R, S] -> [Cin, R*S*Cout] with the taps flipped: the data gradient of a stride-1 'same'
+    convolution is the convolution of dY with this kernel (same padding / dilation)."""
+    w = torch.flip(w_oihw, dims=(2, 3)).permute(1, 2, 3, 0)          # [Cin, R, S, Cout]
+    return w.reshape(w.shape[0], -1).to(device=device, dtype=dtype).contiguous()
+
+
+def conv1x1_bwd(x, w_packed, dy, stride=1, need_dx=True, w_t=None, dx_add=None):
+    """x [B,H,W,Cin], dy [B,Ho,Wo,Cout] NHWC; w_packed [Cout,Cin].  -> (dx [B,H,W,Cin] | None, dW fp32).
+    dx_add (stride 1 only): a second gradient of x's shape added in the GEMM epilogue (the shortcut branch)."""
+    B, H, W, Cin = x.shape
+    Cout = w_packed.shape[0]
+    xs = x if stride == 1 else x[:, ::stride, ::stride, :].contiguous()
+    P = dy.shape[0] * dy.shape[1] * dy.shape[2]
+    dy2 = dy.reshape(P, Cout)
+    dx = None
+    if need_dx:
+        w_t = ops.transpose_2d(w_packed) if w_t is None else w_t       # [Cin, Cout]
+        if stride == 1:
+            dx = ops.gemm_nt(dy2, w_t, resid=None if dx_add is None else dx_add.reshape(P, Cin)).reshape(B, H, W, Cin)
+        else:
+            assert dx_add is None
+            dx = torch.zeros_like(x)
+            dx[:, ::stride, ::stride, :] = ops.gemm_nt(dy2, w_t).reshape(xs.shape)
+    return dx, wgrad(dy2, xs.reshape(P, Cin))
+
+
+_ZERO_OFF = {}
+
+
+def conv3x3_bwd(x, w_dgrad_packed, dy, dil=1, need_dx=True):
+    """3x3, stride 1, pad = dil.  x [B,H,W,Cin], dy [B,H,W,Cout]; w_dgrad_packed from pack_conv_dgrad_weight.
+    -> (dx | None, dW [Cout, 9*Cin] fp32 in pack_conv_weight order)."""
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    dx = None
+    if need_dx:
+        dx = ops.conv2d_nhwc(dy, w_dgrad_packed, None, ksize=3, stride=1, pad=dil, dil=dil)
+    key = (B, H, W, x.device)
+    if key not in _ZERO_OFF:
+        _ZERO_OFF[key] = torch.zeros((B, H, W, 18), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
+    col, _ = ops.deformable_im2col(x.permute(0, 3, 1, 2), _ZERO_OFF[key], 3, 1, dil, dil, 1)    # [P, 9*Cin] patches
+    return dx, wgrad(dy.reshape(B * H * W, Cout), col)
