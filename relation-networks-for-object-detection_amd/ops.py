@@ -227,6 +227,19 @@ def roi_pool(data, rois, pooled=(7, 7), spatial_scale=0.0625, channels_last_out=
     return (out, arg) if want_argmax else out
 
 
+def roi_pool_bwd(grad_out, argmax, rois, in_shape, batch_index_base=0):
+    """Adjoint of roi_pool: grad_out / argmax logical [R,C,PH,PW] with IDENTICAL strides (as returned by
+    roi_pool(want_argmax=True)); in_shape (B,C,H,W) -> fp32 gradient of the feature map [B,C,H,W] (NCHW)."""
+    _chk(grad_out, argmax, rois)
+    assert argmax.dtype == torch.int32 and tuple(grad_out.stride()) == tuple(argmax.stride()) and grad_out.shape == argmax.shape
+    B, Cc, H, W = in_shape
+    R, _, PH, PW = grad_out.shape
+    gin = torch.zeros((B, Cc, H, W), device=grad_out.device, dtype=torch.float32)
+    _lib.call('relnet_roi_pool_bwd', grad_out.data_ptr(), argmax.data_ptr(), _strides4(grad_out), rois.data_ptr(),
+              gin.data_ptr(), gin.stride(0), gin.stride(1), R, Cc, W, PH, PW, batch_index_base, _dt(grad_out), _stream())
+    return gin
+
+
 # ---------------------------------------------------------------------------------------
 # detection post-processing
 # ---------------------------------------------------------------------------------------

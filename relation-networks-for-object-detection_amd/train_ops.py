@@ -94,13 +94,18 @@ def conv1x1_bwd(x, w_packed, dy, stride=1, need_dx=True, w_t=None, dx_add=None):
     dy2 = dy.reshape(P, Cout)
     dx = None
     if need_dx:
-        w_t = ops.transpose_2d(w_packed) if w_t is None else w_t       # [Cin, Cout]
+        gran = 64 if dy.dtype == torch.bfloat16 else 16
+        w_t = ops.transpose_2d(w_packed, pad_cols_to=gran) if w_t is None else w_t       # [Cin, pad(Cout)]
+        dyp = dy2
+        if Cout % gran:                           # e.g. the RPN's 24 + 48 output channels
+            dyp = torch.zeros((P, w_t.shape[1]), device=dy.device, dtype=dy.dtype)
+            dyp[:, :Cout] = dy2
         if stride == 1:
-            dx = ops.gemm_nt(dy2, w_t, resid=None if dx_add is None else dx_add.reshape(P, Cin)).reshape(B, H, W, Cin)
+            dx = ops.gemm_nt(dyp, w_t, resid=None if dx_add is None else dx_add.reshape(P, Cin)).reshape(B, H, W, Cin)
         else:
             assert dx_add is None
             dx = torch.zeros_like(x)
-            dx[:, ::stride, ::stride, :] = ops.gemm_nt(dy2, w_t).reshape(xs.shape)
+            dx[:, ::stride, ::stride, :] = ops.gemm_nt(dyp, w_t).reshape(xs.shape)
     return dx, wgrad(dy2, xs.reshape(P, Cin))
 
 
