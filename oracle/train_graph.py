@@ -1,0 +1,70 @@
+"""Differentiable torch-CPU restatement of the relation end2end TRAIN graph (TEST INFRASTRUCTURE ONLY) -- the checker
+of relnet_amd.train.Trainer's gradients.
+
+Graph: symbols/resnet_v1_101_rcnn_attention_1024_pairwise_position_multi_head_16.py:176-322 (train branch).  The
+non-differentiable decisions (proposals + gt rows, OHEM labels / weights, RPN anchor labels) are INPUTS here
+("teacher forced" from the run under test); everything differentiable is recomputed in float64 and differentiated by
+torch autograd.  The scalar is the sum of the four loss heads with MXNet's scalings:
+  SoftmaxOutput(normalization='valid', use_ignore)  -> sum CE over labels != -1  / #valid        (rpn_cls_prob, cls_prob)
+  MakeLoss(w * smooth_l1(.), grad_scale)            -> grad_scale * sum(.)   (1/RPN_BATCH_SIZE, 1/BATCH_ROIS_OHEM)
+MXNet built-ins restated from v1.1.0 semantics: PARITY UNPINNED.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import network as ON
+from . import roi_pooling as ORP
+from . import relation_torch as ORT
+from .losses import smooth_l1
+
+
+def total_loss(data, p, rois, labels_ohem, bbox_target, bbox_weight_ohem, rpn_label, rpn_bbox_target, rpn_bbox_weight,
+               nongt_dim, rpn_batch_size=256, batch_rois_ohem=128):
+    """One image.  p: name -> torch float64 tensors (requires_grad on the trainable ones).  rois [R,5] numpy;
+    labels_ohem [R]; bbox_target / bbox_weight_ohem [R,8]; rpn_label [A*h*w]; rpn_bbox_target / weight [4A,h,w]."""
+    pd = {k: (v.double() if torch.is_tensor(v) else torch.as_tensor(np.asarray(v), dtype=torch.float64)) for k, v in p.items()}
+
+    class _P(dict):
+        pass
+    # oracle/network casts with .float(): run it in float64 by monkey-free re-implementation of the cast
+    old = ON._t
+    ON._t = lambda x: x.double() if torch.is_tensor(x) else torch.as_tensor(np.asarray(x), dtype=torch.float64)
+    try:
+        conv4, conv5 = ON.backbone(torch.as_tensor(np.asarray(data), dtype=torch.float64), pd)
+        cls, box, feat = ON.rpn_and_feat(conv4, conv5, pd)
+    finally:
+        ON._t = old
+    # RPN losses
+    A2 = cls.shape[1]
+    logits = cls.reshape(1, 2, -1)[0].t()                                  # [A*h*w, 2]  (Reshape(0,2,-1,0))
+    lab = torch.as_tensor(np.asarray(rpn_label, np.int64))
+    valid = lab >= 0
+    logp = torch.log_softmax(logits, dim=1)
+    l_rpn_cls = -(logp[torch.arange(len(lab)), lab.clamp(min=0)] * valid.double()).sum() / max(int(valid.sum()), 1)
+    l_rpn_box = (torch.as_tensor(np.asarray(rpn_bbox_weight), dtype=torch.float64)
+                 * smooth_l1(box[0] - torch.as_tensor(np.asarray(rpn_bbox_target), dtype=torch.float64), 3.0)).sum() / rpn_batch_size
+    # ROIPooling (max; argmax from the numpy oracle on the same feature values)
+    rois = np.asarray(rois, np.float32)
+    _, arg = ORP.roi_pooling(feat.detach().numpy().astype(np.float32), rois, return_argmax=True)
+    R, C = arg.shape[:2]
+    flat = feat[0].reshape(C, -1)
+    idx = torch.as_tensor(arg.astype(np.int64))
+    g = torch.gather(flat, 1, idx.clamp(min=0).permute(1, 0, 2, 3).reshape(C, -1)).reshape(C, R, 7, 7).permute(1, 0, 2, 3)
+    pooled = g * (idx >= 0).double()
+    # head
+    x = pooled.reshape(R, -1)
+    f1 = x @ pd['fc_new_1_weight'].t() + pd['fc_new_1_bias']
+    x1 = torch.relu(f1 + ORT.relation_module(f1, rois[:, 1:5], pd, 1, nongt_dim))
+    f2 = x1 @ pd['fc_new_2_weight'].t() + pd['fc_new_2_bias']
+    x2 = torch.relu(f2 + ORT.relation_module(f2, rois[:, 1:5], pd, 2, nongt_dim))
+    cls_score = x2 @ pd['cls_score_weight'].t() + pd['cls_score_bias']
+    bbox_pred = x2 @ pd['bbox_pred_weight'].t() + pd['bbox_pred_bias']
+    lo = torch.as_tensor(np.asarray(labels_ohem, np.int64))
+    v = lo >= 0
+    lp = torch.log_softmax(cls_score, dim=1)
+    l_cls = -(lp[torch.arange(R), lo.clamp(min=0)] * v.double()).sum() / max(int(v.sum()), 1)
+    l_box = (torch.as_tensor(np.asarray(bbox_weight_ohem), dtype=torch.float64)
+             * smooth_l1(bbox_pred - torch.as_tensor(np.asarray(bbox_target), dtype=torch.float64), 1.0)).sum() / batch_rois_ohem
+    return l_rpn_cls + l_rpn_box + l_cls + l_box, dict(rpn_cls=l_rpn_cls, rpn_box=l_rpn_box, cls=l_cls, box=l_box,
+                                                        cls_score=cls_score.detach(), feat=feat.detach())

@@ -276,6 +276,8 @@ class Trainer(object):
                 self._add_wgrad(na, dw, self.bn_scale[na])
         out['rois'] = rois_t
         out['label'] = labels_ohem
+        out['bbox_target'], out['bbox_weight'] = bbox_target, weights_ohem
+        out['bbox_pred'] = bbox_pred
         out['cls_score'] = cls_score
         return out
 
