@@ -86,17 +86,87 @@ def cpu_baseline(params, relation=True, soft=True, images=4, seed=123, threads=3
                        '%d threads + numpy proposal/ROI/relation/soft-NMS), %.2f s/image' % (images, cores, per))
 
 
+def bench_train(a, rank, world, D):
+    """Training throughput of the relation end2end graph (reference config ..._end2end_relation_8epoch.yaml): one step =
+    forward + backward over `batch` images per GPU, ONE summed all-reduce of the 67.7 M trainable gradients, SGD."""
+    import numpy as np
+    from relnet_amd import backbone, train
+    H, W, G = 600, 1000, 8
+    B = a.batch
+    params = backbone.init_params(seed=1)
+    cfg = train.TrainConfig()
+    tr = train.Trainer(params, cfg, im_hw=(H, W))
+    g = torch.Generator().manual_seed(1000 + rank)
+    data = torch.randn(B, 3, H, W, generator=g).cuda()
+    im_info = torch.tensor([[float(H), float(W), 1.0]] * B).cuda()
+    rng = np.random.default_rng(2 + rank)
+    gt = np.zeros((B, G, 5), np.float32)
+    labs, tgts, wgts = [], [], []
+    for b in range(B):                      # SURVEY 8d: 8 gt boxes, w,h in [32,400], classes uniform in 1..80
+        bw, bh = rng.uniform(32, 400, G), rng.uniform(32, 400, G)
+        x1, y1 = rng.uniform(0, W - 1 - bw), rng.uniform(0, H - 1 - bh)
+        gt[b] = np.stack([x1, y1, x1 + bw, y1 + bh, rng.integers(1, 81, G)], 1)
+        L, Tg, Wg = train.assign_anchor((38, 63), gt[b], (H, W), cfg, seed=b)      # host loader work, outside the step
+        labs.append(L); tgts.append(Tg); wgts.append(Wg)
+    batch = (data, im_info, torch.as_tensor(gt).cuda(), torch.as_tensor(np.stack(labs)).cuda(),
+             torch.as_tensor(np.stack(tgts)).cuda(), torch.as_tensor(np.stack(wgts)).cuda())
+
+    def fence():
+        D.fence(device='cuda')
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            out = tr.step(*batch)
+        graph = None
+        if not a.no_graph:                  # forward + backward as one hipGraph; the collective and SGD stay eager
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = tr.forward_backward(*batch)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            if graph is not None:
+                graph.replay()
+            else:
+                out = tr.forward_backward(*batch)
+            tr.all_reduce()
+            tr.update()
+        fence()
+        elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(elapsed, device='cuda')
+    ok = bool(torch.isfinite(tr.W.master).all())
+    assert ok, "non-finite weights after training steps"
+    if rank == 0:
+        images = world * B * a.steps
+        print(json.dumps({
+            'metric': 'images/sec (1000x600, 300 ROIs)', 'value': images / elapsed, 'unit': 'images/s', 'n_gpus': world,
+            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'TRAINING step of ResNet-101 Faster-RCNN + 2 relation modules end2end (reference config '
+                                   '..._rcnn_end2end_relation_8epoch.yaml; the learn-NMS head of BASELINE configs[2] is not '
+                                   'trained yet): forward + backward + summed all-reduce of %d gradients + SGD, 600x1000 '
+                                   'images, 300 proposals + 8 gt rows, OHEM 128, random-init weights' % tr.num_trainable(),
+                       'images_per_gpu_per_step': B, 'launch': 'eager' if a.no_graph else 'hipGraph replay (forward+backward)',
+                       'parallelism': 'dp%d (RCCL all-reduce SUM)' % world},
+            'losses': {k: float(out[k]) for k in ('bbox_loss', 'rpn_bbox_loss')}}))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=54, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (default 54; 4 with --train)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-relation', action='store_true', help='plain 2FC head (config 1 graph)')
     ap.add_argument('--learn-nms', action='store_true', help='learned duplicate removal instead of soft-NMS (config 3 graph, inference)')
     ap.add_argument('--dcn', action='store_true', help='deformable res5 + deformable PSROI pooling (config 4 graph, inference)')
     ap.add_argument('--fpn', action='store_true', help='FPN graph, 800x1024 images, 1000 given proposals (inference graph of config 5)')
+    ap.add_argument('--train', action='store_true', help='training step (relation end2end graph): forward + backward + summed all-reduce + SGD')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=4)
     ap.add_argument('--cpu-threads', type=int, default=32)
@@ -105,6 +175,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of hipGraph replays')
     ap.add_argument('--shapes', action='store_true', help='print per-shape GEMM/conv times to stderr')
     a = ap.parse_args()
+    if a.batch is None:
+        a.batch = 4 if a.train else 54
 
     import __graft_entry__ as ge
     ge.build()
@@ -117,6 +189,8 @@ def main():
     rank, world, local = D.init(backend='nccl')          # 'nccl' = RCCL over xGMI
     assert world == a.gpus or world == 1, "WORLD_SIZE=%d but --gpus %d" % (world, a.gpus)
 
+    if a.train:
+        return bench_train(a, rank, world, D)
     tdt = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
     params = backbone.init_params(seed=1, dcn_offset_std=0.01 if a.dcn else 0.0, fpn=a.fpn)
     cfg = detector.Config()

@@ -42,6 +42,38 @@ __global__ __launch_bounds__(256) void transpose_2d_kernel(const T* in, long in_
     if (c0 + c < cols && r0 + tx < rows) dst[(long)(c0 + c) * out_ld + r0 + tx] = tile[tx][c];
 }
 
+// bf16 fast path: 16-byte global loads and stores (8 elements per lane); requires 16-byte aligned rows on both
+// sides.  Tile 64 x 64; the LDS image is [row][col] with a 66-element pitch (33 words: conflict-free column reads).
+__global__ __launch_bounds__(256) void transpose_2d_bf16_vec_kernel(const unsigned short* in, long in_ld, long in_bs,
+                                                                    unsigned short* out, long out_ld, long out_bs,
+                                                                    int rows, int cols) {
+  __shared__ unsigned short tile[64][66];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const unsigned short* src = in + (long)b * in_bs;
+  unsigned short* dst = out + (long)b * out_bs;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int r = pass * 32 + (t >> 3), cc = (t & 7) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < rows && c0 + cc < cols) v = *(const uint4*)(src + (long)(r0 + r) * in_ld + c0 + cc);   // cols % 8 == 0
+    unsigned int* p = (unsigned int*)&tile[r][cc];
+    p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int c = pass * 32 + (t >> 3), rr = (t & 7) * 8;          // output row = input column c, 8 input rows rr..rr+7
+    if (c0 + c < cols && r0 + rr < rows) {
+      unsigned int w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = (unsigned int)tile[rr + 2 * k][c] | ((unsigned int)tile[rr + 2 * k + 1][c] << 16);
+      *(uint4*)(dst + (long)(c0 + c) * out_ld + r0 + rr) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 struct AttnBwdArgs {
   const void* q; long q_ld, q_bs;          // [B][N][.. h*64+d ..]
@@ -391,7 +423,14 @@ extern "C" int relnet_transpose_2d(const void* in, long in_ld, long in_bs, void*
   dim3 grid((cols + 63) / 64, (rows + 63) / 64, batch);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == RELNET_F32) transpose_2d_kernel<float><<<grid, 256, 0, s>>>((const float*)in, in_ld, in_bs, (float*)out, out_ld, out_bs, rows, cols);
-  else if (dtype == RELNET_BF16) transpose_2d_kernel<unsigned short><<<grid, 256, 0, s>>>((const unsigned short*)in, in_ld, in_bs, (unsigned short*)out, out_ld, out_bs, rows, cols);
+  else if (dtype == RELNET_BF16) {
+    // vector path: whole 8-element groups on both sides (the destination rows are padded by the caller, so writing a
+    // group that extends past `rows` up to out_ld is allowed only when it stays inside the row: rows rounded to 8 <= out_ld)
+    const bool vec = cols % 8 == 0 && in_ld % 8 == 0 && in_bs % 8 == 0 && out_ld % 8 == 0 && out_bs % 8 == 0 &&
+                     ((rows + 7) / 8) * 8 <= out_ld && (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    if (vec) transpose_2d_bf16_vec_kernel<<<grid, 256, 0, s>>>((const unsigned short*)in, in_ld, in_bs, (unsigned short*)out, out_ld, out_bs, rows, cols);
+    else transpose_2d_kernel<unsigned short><<<grid, 256, 0, s>>>((const unsigned short*)in, in_ld, in_bs, (unsigned short*)out, out_ld, out_bs, rows, cols);
+  }
   else RELNET_REQUIRE(false, "relnet_transpose_2d: unknown dtype %d", dtype);
   return check_launch("relnet_transpose_2d");
 }

@@ -568,7 +568,9 @@ def transpose_2d(x, out=None, pad_cols_to=1):
     rp = pad_to(rows, pad_cols_to)
     if out is None:
         shape = (batch, cols, rp) if x.dim() == 3 else (cols, rp)
-        out = (torch.zeros if rp != rows else torch.empty)(shape, device=x.device, dtype=x.dtype)
+        out = torch.empty(shape, device=x.device, dtype=x.dtype)
+        if rp != rows:
+            out[..., rows:].zero_()                       # only the padding columns need clearing
     assert out.stride(-1) == 1 and out.shape[-2] == cols and out.shape[-1] >= rows
     _lib.call('relnet_transpose_2d', x.data_ptr(), x.stride(-2), x.stride(0) if x.dim() == 3 else 0, out.data_ptr(),
               out.stride(-2), out.stride(0) if out.dim() == 3 else 0, rows, cols, batch, _dt(x), _stream())
