@@ -95,6 +95,7 @@ def bench_train(a, rank, world, D):
     B = a.batch
     params = backbone.init_params(seed=1)
     cfg = train.TrainConfig()
+    cfg.learn_nms = a.learn_nms
     tr = train.Trainer(params, cfg, im_hw=(H, W))
     g = torch.Generator().manual_seed(1000 + rank)
     data = torch.randn(B, 3, H, W, generator=g).cuda()
@@ -143,13 +144,15 @@ def bench_train(a, rank, world, D):
             'metric': 'images/sec (1000x600, 300 ROIs)', 'value': images / elapsed, 'unit': 'images/s', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'TRAINING step of ResNet-101 Faster-RCNN + 2 relation modules end2end (reference config '
-                                   '..._rcnn_end2end_relation_8epoch.yaml; the learn-NMS head of BASELINE configs[2] is not '
-                                   'trained yet): forward + backward + summed all-reduce of %d gradients + SGD, 600x1000 '
-                                   'images, 300 proposals + 8 gt rows, OHEM 128, random-init weights' % tr.num_trainable(),
+            'config': {'workload': ('BASELINE configs[2]: TRAINING step of ResNet-101 Faster-RCNN + 2 relation modules + learn-NMS '
+                                    'head end2end (..._rcnn_end2end_relation_learn_nms_8epoch.yaml)' if a.learn_nms else
+                                    'TRAINING step of ResNet-101 Faster-RCNN + 2 relation modules end2end '
+                                    '(..._rcnn_end2end_relation_8epoch.yaml)') +
+                                   ': forward + backward + summed all-reduce of %d gradients + SGD, 600x1000 images, '
+                                   '300 proposals + 8 gt rows, OHEM 128, random-init weights' % tr.num_trainable(),
                        'images_per_gpu_per_step': B, 'launch': 'eager' if a.no_graph else 'hipGraph replay (forward+backward)',
                        'parallelism': 'dp%d (RCCL all-reduce SUM)' % world},
-            'losses': {k: float(out[k]) for k in ('bbox_loss', 'rpn_bbox_loss')}}))
+            'losses': {k: float(out[k]) for k in ('bbox_loss', 'rpn_bbox_loss', 'nms_pos_loss', 'nms_neg_loss') if k in out}}))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -19,8 +19,39 @@ from . import relation_torch as ORT
 from .losses import smooth_l1
 
 
+def learn_nms_loss(cls_score, fc_all_2_relu, pd, rank_idx, class_boxes, target, first_n, nms_loss_scale=1.0, nms_pos_scale=4.0,
+                   eps=1e-8):
+    """Train branch of the learn-NMS head (symbols/..._learn_nms.py:424-551) on one image.  cls_score [N,81] and
+    fc_all_2_relu [N,1024] are torch float64 (differentiable); rank_idx [C,F] (per-class descending order), class_boxes
+    [C,F,4] (sorted refined boxes; BlockGrad in the reference) and target [F,C,T] are taken from the run under test."""
+    from .learn_nms import rank_embedding as _rank_embedding_np
+    N, C1 = cls_score.shape
+    C, Fn = C1 - 1, first_n
+    T = target.shape[2]
+    prob = torch.softmax(cls_score, dim=1)[:, 1:]                                    # [N,C]
+    idx = torch.as_tensor(np.asarray(rank_idx, np.int64))                            # [C,F]
+    sorted_score = prob.t().gather(1, idx).t()                                       # [F,C]
+    rank_emb = torch.as_tensor(np.asarray(_rank_embedding_np(Fn, 1024), np.float64))
+    rank_feat = rank_emb @ pd['nms_rank_weight'].t() + pd['nms_rank_bias']           # [F,128]
+    roi_emb = fc_all_2_relu @ pd['roi_feat_embedding_weight'].t() + pd['roi_feat_embedding_bias']
+    pn = {k[4:]: v for k, v in pd.items() if k.startswith('nms_')}                    # nms_query_1_weight -> query_1_weight ...
+    cond = []
+    for c in range(C):
+        emb = roi_emb[idx[c]] + rank_feat                                            # [F,128]
+        att = ORT.relation_module(emb, np.asarray(class_boxes[c], np.float32), pn, 1, Fn)
+        allf = torch.relu(emb + att)
+        cond.append(torch.sigmoid(allf @ pd['nms_logit_weight'].t() + pd['nms_logit_bias']))      # [F,T]
+    cond = torch.stack(cond, 1)                                                      # [F,C,T]
+    multi = sorted_score.unsqueeze(2) * cond
+    t = torch.as_tensor(np.asarray(target, np.float64))
+    k = nms_loss_scale / float(Fn * T)
+    pos = k * (-(t * torch.log(multi + eps))).sum()
+    neg = k * (-((1.0 - t) * torch.log(1.0 - multi + eps))).sum()
+    return nms_pos_scale * pos + neg, multi
+
+
 def total_loss(data, p, rois, labels_ohem, bbox_target, bbox_weight_ohem, rpn_label, rpn_bbox_target, rpn_bbox_weight,
-               nongt_dim, rpn_batch_size=256, batch_rois_ohem=128):
+               nongt_dim, rpn_batch_size=256, batch_rois_ohem=128, lnms=None):
     """One image.  p: name -> torch float64 tensors (requires_grad on the trainable ones).  rois [R,5] numpy;
     labels_ohem [R]; bbox_target / bbox_weight_ohem [R,8]; rpn_label [A*h*w]; rpn_bbox_target / weight [4A,h,w]."""
     pd = {k: (v.double() if torch.is_tensor(v) else torch.as_tensor(np.asarray(v), dtype=torch.float64)) for k, v in p.items()}
@@ -66,5 +97,10 @@ def total_loss(data, p, rois, labels_ohem, bbox_target, bbox_weight_ohem, rpn_la
     l_cls = -(lp[torch.arange(R), lo.clamp(min=0)] * v.double()).sum() / max(int(v.sum()), 1)
     l_box = (torch.as_tensor(np.asarray(bbox_weight_ohem), dtype=torch.float64)
              * smooth_l1(bbox_pred - torch.as_tensor(np.asarray(bbox_target), dtype=torch.float64), 1.0)).sum() / batch_rois_ohem
-    return l_rpn_cls + l_rpn_box + l_cls + l_box, dict(rpn_cls=l_rpn_cls, rpn_box=l_rpn_box, cls=l_cls, box=l_box,
+    l_nms = 0.0
+    multi = None
+    if lnms is not None:       # dict(rank_idx, class_boxes, target, first_n)
+        l_nms, multi = learn_nms_loss(cls_score[:nongt_dim], x2[:nongt_dim], pd, lnms['rank_idx'], lnms['class_boxes'],
+                                      lnms['target'], lnms['first_n'])
+    return l_rpn_cls + l_rpn_box + l_cls + l_box + l_nms, dict(nms_multi=None if multi is None else multi.detach(),rpn_cls=l_rpn_cls, rpn_box=l_rpn_box, cls=l_cls, box=l_box,
                                                         cls_score=cls_score.detach(), feat=feat.detach())

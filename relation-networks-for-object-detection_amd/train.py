@@ -7,7 +7,9 @@ ROIPooling -> fc_new_1 -> relation_1 -> fc_new_2 -> relation_2 (keys = the first
 -> BoxAnnotatorOHEM (128) -> SoftmaxOutput / smooth_l1 losses; then the adjoint of all of it, ONE summed all-reduce
 of the trainable gradients (core/module.py + kvstore 'device' in the reference, rescale_grad = 1.0) and
 mx.optimizer.SGD (momentum 0.9, wd 5e-4; train_end2end.py:163-168).  Frozen, as cfgs/*.yaml:23-29: conv1, res2 and
-every BatchNorm gamma / beta.  The learn-NMS head's training graph is not built yet.
+every BatchNorm gamma / beta.  With cfg.learn_nms the learn-NMS head's train branch (symbols/..._learn_nms.py:424-551:
+per-class sort, rank + appearance embedding, class-batched relation module, sigmoid x score, pos / neg log losses
+against nms_multi_target) is trained jointly = BASELINE configs[2].
 
 MI355X-first choices:
   * master weights live in ONE flat fp32 buffer already in the kernels' layouts (convs [Cout][R][S][Cin] with the
@@ -37,6 +39,11 @@ class TrainConfig(Config):
     lr = 0.0005
     momentum = 0.9
     wd = 0.0005
+    nms_loss_scale = 1.0          # TRAIN.nms_loss_scale
+    nms_pos_scale = 4.0           # TRAIN.nms_pos_scale
+    nms_eps = 1e-8
+    bbox_means = (0.0, 0.0, 0.0, 0.0)
+    bbox_stds = (0.1, 0.1, 0.2, 0.2)
 
 
 class _Flat(object):
@@ -115,6 +122,15 @@ class Trainer(object):
             biases.append(('linear_out_%d' % i, params['linear_out_%d_bias' % i]))
             weights.append(('pair_pos_fc1_%d' % i, params['pair_pos_fc1_%d_weight' % i]))
             biases.append(('pair_pos_fc1_%d' % i, params['pair_pos_fc1_%d_bias' % i]))
+        if c.learn_nms:     # learn-NMS head (symbols/..._learn_nms.py:424-551), trained end to end with the detector
+            for n in ('nms_rank', 'roi_feat_embedding', 'nms_pair_pos_fc1_1', 'nms_logit'):
+                weights.append((n, params[n + '_weight'])); biases.append((n, params[n + '_bias']))
+            weights.append(('nms_qk_1', torch.cat([params['nms_query_1_weight'], params['nms_key_1_weight']], 0)))
+            biases.append(('nms_qk_1', torch.cat([params['nms_query_1_bias'], params['nms_key_1_bias']], 0)))
+            weights.append(('nms_linear_out_1', params['nms_linear_out_1_weight'].reshape(128, 128)))
+            biases.append(('nms_linear_out_1', params['nms_linear_out_1_bias']))
+            from .learn_nms import rank_embedding
+            self.rank_emb = rank_embedding(c.first_n, 1024).to(dev, torch.bfloat16).contiguous()
         self.W = _Flat(weights, dev)          # weight decay applies
         self.Bv = _Flat(biases, dev)          # biases: wd_mult 0 (MXNet's rule for names not ending in _weight / _gamma)
         self.anchors = torch.as_tensor(generate_anchors(c.feat_stride, c.anchor_ratios, c.anchor_scales), dtype=torch.float64, device=dev)
@@ -227,10 +243,19 @@ class Trainer(object):
         l1, d_bbox = losses.smooth_l1_loss(bbox_pred, bbox_target, weights_ohem, 1.0, 1.0 / c.batch_rois_ohem)
         out['bbox_loss'] = l1.sum() / B
         out['num_ohem'] = (labels_ohem >= 0).sum()
+        d_x2_lnms = None
+        if c.learn_nms:     # the learn-NMS head sees the first N (non-gt) rows; its gradient joins cls_score and fc_all_2_relu
+            d_cls_l, d_x2_lnms, lo = self._lnms_forward_backward(cls_score[:, :N], bbox_pred[:, :N], rois_t[:, :N].contiguous(),
+                                                                 im_info, x2[:, :N], gt_boxes, num_gt)
+            d_cls[:, :N] += d_cls_l
+            out.update(lo)
         # ================= backward =================
         d_cb = torch.cat([d_cls, d_bbox], 2).reshape(B * R, -1).to(bt)
         d_x2, dw, db = T.linear_bwd(x2.reshape(B * R, -1), self.w('cls_bbox'), d_cb)
         self._add_wgrad('cls_bbox', dw); self._add_bgrad('cls_bbox', db)
+        if d_x2_lnms is not None:
+            d_x2 = d_x2.reshape(B, R, -1)
+            d_x2[:, :N] += d_x2_lnms.to(d_x2.dtype)
         d_f2 = self._relation_bwd(2, mods[1], f2, x2, rois_t, d_x2.reshape(B, R, -1), N)
         d_x1, dw, db = T.linear_bwd(x1.reshape(B * R, -1), self.w('fc_new_2'), d_f2.reshape(B * R, -1))
         self._add_wgrad('fc_new_2', dw); self._add_bgrad('fc_new_2', db)
@@ -280,6 +305,98 @@ class Trainer(object):
         out['bbox_pred'] = bbox_pred
         out['cls_score'] = cls_score
         return out
+
+    def _lnms_forward_backward(self, cls_score, bbox_pred, rois, im_info, feat, gt_boxes, num_gt):
+        """Train branch of the learn-NMS head (symbols/..._learn_nms.py:424-551) and its adjoint.
+        cls_score [B,N,81] fp32, bbox_pred [B,N,8] (BlockGrad), rois [B,N,5], feat = fc_all_2_relu[:, :N] bf16.
+        Returns (d cls_score [B,N,81] fp32, d feat [B,N,1024] fp32, losses)."""
+        import ctypes
+        from . import lib as _lib
+        c = self.cfg
+        B, N, C1 = cls_score.shape
+        C, F, Tn = C1 - 1, c.first_n, len(c.nms_target_thresh)
+        dev, bt, s_ = cls_score.device, torch.bfloat16, ops._stream()
+        cs, bp_ = cls_score.contiguous().view(B * N, C1), bbox_pred.contiguous().view(B * N, -1)
+        prob = torch.empty((B, N, C), device=dev, dtype=torch.float32)
+        boxes = torch.empty((B, N, 4), device=dev, dtype=torch.float32)
+        means, stds = (ctypes.c_float * 4)(*c.bbox_means), (ctypes.c_float * 4)(*c.bbox_stds)
+        _lib.call('relnet_lnms_prepare', cs.data_ptr(), cs.stride(0), bp_.data_ptr(), bp_.stride(0), rois.data_ptr(),
+                  im_info.data_ptr(), prob.data_ptr(), boxes.data_ptr(), B, N, C1, 4, means, stds, s_)
+        rank_idx = torch.empty((B, C, F), device=dev, dtype=torch.int32)
+        sorted_score = torch.empty((B, F, C), device=dev, dtype=torch.float32)
+        sorted_bbox = torch.empty((B, F, C, 4), device=dev, dtype=torch.float32)
+        class_boxes = torch.empty((B, C, F, 4), device=dev, dtype=torch.float32)
+        class_max = torch.empty((B, C), device=dev, dtype=torch.float32)
+        _lib.call('relnet_lnms_sort', prob.data_ptr(), boxes.data_ptr(), rank_idx.data_ptr(), sorted_score.data_ptr(),
+                  sorted_bbox.data_ptr(), class_boxes.data_ptr(), class_max.data_ptr(), B, N, C, F, s_)
+        rank_feat = ops.gemm_nt(self.rank_emb, self.w('nms_rank'), self.b('nms_rank'), out_dtype=torch.float32)      # [F,128]
+        feat2 = feat.contiguous().view(B * N, -1)
+        roi_emb = ops.gemm_nt(feat2, self.w('roi_feat_embedding'), self.b('roi_feat_embedding'))
+        x = torch.empty((B, C, F, 128), device=dev, dtype=bt)
+        _lib.call('relnet_lnms_embed', roi_emb.data_ptr(), rank_feat.data_ptr(), rank_idx.data_ptr(), x.data_ptr(),
+                  B, N, C, F, 128, ops._dt(x), s_)
+        BC = B * C
+        xr = x.view(BC, F, 128)
+        # relation module over (image, class): 16 heads x 64 for Q/K, each head's 8 output channels padded to a 64-wide tile
+        class M_(object):
+            pass
+        mod = M_()
+        mod.wqk, mod.bqk = self.w('nms_qk_1'), self.b('nms_qk_1')
+        wo, bo = self.w('nms_linear_out_1'), self.b('nms_linear_out_1')
+        mod.wout = torch.zeros((1024, 128), device=dev, dtype=bt)
+        mod.wout.view(16, 64, 128)[:, :8] = wo.view(16, 8, 128)
+        mod.bout = torch.zeros(1024, device=dev, dtype=torch.float32)
+        mod.bout.view(16, 64)[:, :8] = bo.view(16, 8)
+        mod.wp = self.W.view(self.W.master, 'nms_pair_pos_fc1_1')
+        mod.bp = self.b('nms_pair_pos_fc1_1')
+        wp_t, bp = pack_pair_pos([mod], dev)
+        cb = class_boxes.view(BC, F, 4)
+        bias = ops.geometry_bias(cb, wp_t, bp, F, half=True)[0]
+        att, _, _ = _module_forward(xr, mod, bias, F, True, False, False)                       # [BC,F,1024]
+        att128 = att.view(BC, F, 16, 64)[..., :8].reshape(BC, F, 128)
+        allf = torch.relu(xr + att128).contiguous()
+        w_logit = torch.zeros((64, 128), device=dev, dtype=bt); w_logit[:Tn] = self.w('nms_logit')
+        b_logit = torch.zeros(64, device=dev, dtype=torch.float32); b_logit[:Tn] = self.b('nms_logit')
+        logit = ops.gemm_nt(allf.view(BC * F, 128), w_logit, b_logit, out_dtype=torch.float32)[:, :Tn]
+        cond = torch.sigmoid(logit).view(B, C, F, Tn).permute(0, 2, 1, 3).contiguous()          # [B,F,C,T]
+        multi = sorted_score.unsqueeze(3) * cond
+        target = ops.nms_multi_target(sorted_bbox, gt_boxes, sorted_score, num_gt, c.nms_target_thresh)
+        pos, neg, d_multi = losses.nms_loss(multi, target, F, Tn, c.nms_loss_scale, c.nms_pos_scale, c.nms_eps)
+        lo = dict(nms_pos_loss=pos.sum() / B, nms_neg_loss=neg.sum() / B, nms_multi_score=multi, nms_multi_target=target,
+                  sorted_score=sorted_score, nms_rank_idx=rank_idx, nms_class_boxes=class_boxes)
+        # ---------------- adjoint ----------------
+        d_sorted = (d_multi * cond).sum(3)                                                      # [B,F,C]
+        d_logit = (d_multi * sorted_score.unsqueeze(3) * cond * (1.0 - cond)).permute(0, 2, 1, 3).reshape(BC * F, Tn)
+        d_logit_p = torch.zeros((BC * F, 64), device=dev, dtype=bt); d_logit_p[:, :Tn] = d_logit
+        d_allf, dw, db = T.linear_bwd(allf.view(BC * F, 128), w_logit, d_logit_p, w_t=None)
+        self._add_wgrad('nms_logit', dw[:Tn]); self._add_bgrad('nms_logit', db[:Tn])
+        g = T.relu_bwd(d_allf, allf.view(BC * F, 128))                                          # [BC*F,128] bf16
+        dY = torch.zeros((BC, F, 1024), device=dev, dtype=bt)
+        dY.view(BC, F, 16, 64)[..., :8] = g.view(BC, F, 16, 8)
+        r = attention_module_backward(xr, cb, None, dY, nongt_dim=F, index=1, dtype=bt, packed=mod)
+        self._add_wgrad('nms_qk_1', torch.cat([r['query_1_weight'], r['key_1_weight']], 0))
+        self._add_bgrad('nms_qk_1', torch.cat([r['query_1_bias'], r['key_1_bias']], 0))
+        self._add_wgrad('nms_linear_out_1', r['linear_out_1_weight'].reshape(16, 64, 128)[:, :8].reshape(128, 128))
+        self._add_bgrad('nms_linear_out_1', r['linear_out_1_bias'].view(16, 64)[:, :8].reshape(128))
+        self._add_wgrad('nms_pair_pos_fc1_1', r['pair_pos_fc1_1_weight']); self._add_bgrad('nms_pair_pos_fc1_1', r['pair_pos_fc1_1_bias'])
+        d_x = (r['d_roi_feat'] + g.view(BC, F, 128).float()).view(B, C, F, 128)                 # residual + module
+        d_rank = d_x.sum((0, 1))                                                                # [F,128]
+        self._add_wgrad('nms_rank', T.wgrad(d_rank.to(bt), self.rank_emb)); self._add_bgrad('nms_rank', d_rank.sum(0))
+        flat = (rank_idx.long() + (torch.arange(B, device=dev) * N).view(B, 1, 1)).view(-1)
+        d_emb = torch.zeros((B * N, 128), device=dev, dtype=torch.float32)
+        d_emb.index_add_(0, flat, d_x.reshape(-1, 128))                                         # take() backward
+        d_feat, dw, db = T.linear_bwd(feat2, self.w('roi_feat_embedding'), d_emb.to(bt))
+        self._add_wgrad('roi_feat_embedding', dw); self._add_bgrad('roi_feat_embedding', db)
+        # sort / slice backward -> cls_prob -> softmax backward (background column has no direct gradient)
+        d_prob = torch.zeros((B, N, C), device=dev, dtype=torch.float32)
+        cidx = torch.arange(C, device=dev).view(1, C, 1).expand(B, C, F)
+        bidx = torch.arange(B, device=dev).view(B, 1, 1).expand(B, C, F)
+        d_prob.index_put_((bidx.reshape(-1), rank_idx.long().reshape(-1), cidx.reshape(-1)),
+                          d_sorted.permute(0, 2, 1).reshape(-1), accumulate=True)
+        p_bg = 1.0 - prob.sum(2, keepdim=True)
+        inner = (prob * d_prob).sum(2, keepdim=True)
+        d_cls = torch.cat([-p_bg * inner, prob * (d_prob - inner)], 2)
+        return d_cls, d_feat.float().view(B, N, -1), lo
 
     def _dgrad_w(self, name, cout):
         """[Cout, 9*Cin] packed forward weights -> [Cin, 9*Cout] tap-flipped data-gradient weights."""

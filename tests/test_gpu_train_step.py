@@ -43,20 +43,42 @@ def _setup(H, W, G, seed):
     return p, cfg, data, gt, L, Tg, Wg, train
 
 
-def test_training_step_gradients_match_autograd():
+@pytest.mark.parametrize('learn_nms', [False, True])
+def test_training_step_gradients_match_autograd(learn_nms):
+    """learn_nms=True: BASELINE configs[2] (relation + learn-NMS end2end); False: the relation end2end config."""
     H, W, G = 128, 160, 4
     p, cfg, data, gt, L, Tg, Wg, train = _setup(H, W, G, 31)
+    cfg.learn_nms, cfg.first_n = learn_nms, 24
+    if learn_nms:          # un-saturate the duplicate classifier (init bias -3 -> sigmoid 0.05) so its gradients are not tiny
+        g_ = torch.Generator().manual_seed(77)
+        p['nms_logit_bias'] = torch.zeros(5)
+        for k in ('nms_logit_weight', 'nms_rank_weight', 'roi_feat_embedding_weight', 'nms_query_1_weight', 'nms_key_1_weight',
+                  'nms_linear_out_1_weight', 'nms_pair_pos_fc1_1_weight'):
+            p[k] = torch.randn(p[k].shape, generator=g_) * 0.05
     tr = train.Trainer(p, cfg, im_hw=(H, W))
     d = lambda a: torch.as_tensor(a).cuda()
     out = tr.forward_backward(data.cuda(), torch.tensor([[H, W, 1.0]]).cuda(), d(gt), d(L[None]), d(Tg[None]), d(Wg[None]))
+    if learn_nms:          # put the gt boxes ON some proposals (they do not depend on gt) so that positive NMS targets exist
+        props = out['rois'][0, :cfg.rpn_post_nms_top_n, 1:5].cpu().numpy()
+        gt[0, :, :4] = props[[0, 7, 14, 21]]
+        L, Tg, Wg = train.assign_anchor((_feat_size(H), _feat_size(W)), gt[0], (H, W), cfg, seed=31)
+        out = tr.forward_backward(data.cuda(), torch.tensor([[H, W, 1.0]]).cuda(), d(gt), d(L[None]), d(Tg[None]), d(Wg[None]))
     rois = out['rois'][0].cpu().numpy()
     N = cfg.rpn_post_nms_top_n
     assert rois.shape[0] == N + G and int((out['label'] >= 0).sum()) > 0
     # ---- float64 autograd on the same decisions
     pt = {k: v.double().clone().requires_grad_(not any(f in k for f in ('conv1', 'bn', 'res2'))) for k, v in p.items()}
+    lnms = None
+    if learn_nms:
+        lnms = dict(rank_idx=out['nms_rank_idx'][0].cpu().numpy(), class_boxes=out['nms_class_boxes'][0].cpu().numpy(),
+                    target=out['nms_multi_target'][0].cpu().numpy(), first_n=cfg.first_n)
+        assert out['nms_multi_target'].sum() > 0                       # some duplicates-free positives exist
     loss, parts = OT.total_loss(data.numpy(), pt, rois, out['label'][0].cpu().numpy(), out['bbox_target'][0].cpu().numpy(),
-                                out['bbox_weight'][0].cpu().numpy(), L, Tg, Wg, N)
+                                out['bbox_weight'][0].cpu().numpy(), L, Tg, Wg, N, lnms=lnms)
     loss.backward()
+    if learn_nms:
+        ms = out['nms_multi_score'][0].cpu().double()
+        assert (ms - parts['nms_multi']).abs().max() <= 0.05 * parts['nms_multi'].abs().max()
     # the forward agrees first (bf16 through ~100 layers)
     cs = out['cls_score'][0].cpu().double()
     assert (cs - parts['cls_score']).abs().max() <= 0.08 * parts['cls_score'].abs().max()
@@ -85,6 +107,12 @@ def test_training_step_gradients_match_autograd():
         want['pair_pos_fc1_%d' % i] = pt['pair_pos_fc1_%d_weight' % i].grad
         wb['linear_out_%d' % i] = pt['linear_out_%d_bias' % i].grad
         wb['pair_pos_fc1_%d' % i] = pt['pair_pos_fc1_%d_bias' % i].grad
+    if learn_nms:
+        for n in ('nms_rank', 'roi_feat_embedding', 'nms_pair_pos_fc1_1', 'nms_logit'):
+            want[n] = pt[n + '_weight'].grad; wb[n] = pt[n + '_bias'].grad
+        want['nms_qk_1'] = torch.cat([pt['nms_query_1_weight'].grad, pt['nms_key_1_weight'].grad], 0)
+        want['nms_linear_out_1'] = pt['nms_linear_out_1_weight'].grad.reshape(128, 128)
+        wb['nms_linear_out_1'] = pt['nms_linear_out_1_bias'].grad
     report, bad = [], []
     for name, w in list(want.items()) + [('bias:' + k, v) for k, v in wb.items()]:
         got = (tr.Bv.view(tr.Bv.grad, name[5:]) if name.startswith('bias:') else tr.W.view(tr.W.grad, name)).cpu().double().reshape(w.shape)
