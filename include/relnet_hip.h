@@ -285,6 +285,28 @@ int relnet_relu_bwd(const void* dy, const void* y, const void* add /*or NULL*/, 
 int relnet_sgd_update(float* w, float* mom, const float* grad, void* w_bf16, long n, float lr, float momentum,
                       float wd, float rescale_grad, void* stream);
 
+/* ---- DCN backward (DeformableConvolutionOp::Backward, deformable_convolution-inl.h:145-237) ---------
+ * The column gradient dcol = dY W comes from relnet_gemm_nt; this entry is deformable_col2im
+ * (nn/deformable_im2col.cuh:313-351) + deformable_col2im_coord (:420-470) in one pass: grad_data (fp32, logical
+ * [B,C,H,W], element strides) and grad_offset (fp32, logical [B,2*KH*KW*DG,Ho,Wo], may be NULL) are ACCUMULATED
+ * into (atomics) -- zero them first.  dcol: [B*Ho*Wo][dcol_ld], column (i*KW + j)*C + c, fp32 or bf16.            */
+int relnet_deformable_col2im(const void* dcol, long dcol_ld, int dcol_dtype, const void* data,
+                             const long* data_strides4, int data_dtype, const float* offset,
+                             const long* offset_strides4, float* grad_data, const long* grad_data_strides4,
+                             float* grad_offset, const long* grad_offset_strides4, int B, int C, int H, int W, int KH,
+                             int KW, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w,
+                             int num_deformable_group, void* stream);
+
+/* DeformablePSROIPoolBackwardAccKernel (deformable_psroi_pooling.cu:178-285): grad_data (fp32 logical [B,C,H,W]) and
+ * grad_trans (fp32 [R,2*num_classes,part,part], NULL iff trans is NULL) are accumulated into; top_count is
+ * recomputed from the geometry.                                                                              */
+int relnet_deformable_psroi_pool_bwd(const void* grad_out, const long* grad_out_strides4, const void* data,
+                                     const long* data_strides4, const float* rois, const float* trans,
+                                     float* grad_data, const long* grad_data_strides4, float* grad_trans, int R, int C,
+                                     int H, int W, int output_dim, int group_size, int pooled_size, int part_size,
+                                     int sample_per_part, float spatial_scale, float trans_std, int num_classes,
+                                     int batch_index_base, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -357,3 +357,217 @@ extern "C" int relnet_deformable_psroi_pool_fwd(const void* data, const long* da
   else RELNET_REQUIRE(false, "relnet_deformable_psroi_pool_fwd: unknown dtype %d", dtype);
   return check_launch("relnet_deformable_psroi_pool_fwd");
 }
+
+// =====================================================================================================
+// Backward (training of the DCN configuration).  Reference: DeformableConvolutionOp::Backward
+// (deformable_convolution-inl.h:145-237) = col-gradient GEMM + deformable_col2im (nn/deformable_im2col.cuh:313-351,
+// weights get_gradient_weight :114-158) + deformable_col2im_coord (:420-470, get_coordinate_weight :161-213), and
+// DeformablePSROIPoolBackwardAccKernel (deformable_psroi_pooling.cu:178-285).  Implemented as the exact adjoint of
+// the forward kernels above (same taps, same border rules), which is what the reference's formulas evaluate to
+// wherever the forward is differentiable.
+// =====================================================================================================
+namespace relnet {
+
+struct DeformBwdArgs {
+  DeformColArgs f;                 // forward geometry: data (values, for the offset gradient), offset, shapes
+  const void* dcol; long dcol_ld;  // [B*Ho*Wo][dcol_ld] gradient of the column matrix, column (tap*C + c)
+  float* grad_data; long gs_b, gs_c, gs_h, gs_w;      // fp32, += (atomics), logical [B,C,H,W]
+  float* grad_offset; long os_b, os_c, os_h, os_w;    // fp32, += (atomics), logical [B, 2*KH*KW*DG, Ho, Wo]
+  int dcol_f32;
+};
+
+// one thread per (pixel, tap, channel), channel fastest: a wavefront covers 64 consecutive channels of one
+// (pixel, tap); when they share a deformable group the two offset gradients are reduced in-wave first.
+template <typename TIN>
+__global__ __launch_bounds__(256) void deformable_col2im_kernel(DeformBwdArgs a) {
+  const DeformColArgs& g = a.f;
+  const long total = (long)g.B * g.Ho * g.Wo * g.KH * g.KW * g.C;
+  const int cpg = g.C / g.DG;
+  const bool wave_uniform = (g.C % 64 == 0) && (cpg % 64 == 0);
+  for (long base = (long)blockIdx.x * 256; base < total; base += (long)gridDim.x * 256) {
+    const long idx = base + threadIdx.x;
+    const bool live = idx < total;
+    const long id = live ? idx : total - 1;
+    const int c = (int)(id % g.C);
+    long r = id / g.C;
+    const int tap = (int)(r % (g.KH * g.KW)); r /= (g.KH * g.KW);
+    const int wo = (int)(r % g.Wo); r /= g.Wo;
+    const int ho = (int)(r % g.Ho);
+    const int b = (int)(r / g.Ho);
+    const int dgi = c / cpg;
+    const Taps t = deform_taps(g, b, ho, wo, tap / g.KW, tap % g.KW, dgi);
+    const long row = ((long)b * g.Ho + ho) * g.Wo + wo;
+    float gval = 0.f;
+    if (live) gval = a.dcol_f32 ? ((const float*)a.dcol)[row * a.dcol_ld + (long)tap * g.C + c]
+                                : bf2f(((const unsigned short*)a.dcol)[row * a.dcol_ld + (long)tap * g.C + c]);
+    float doh = 0.f, dow = 0.f;
+    if (live && t.inside) {
+      const TIN* p = (const TIN*)g.data + (long)b * g.ds_b + (long)c * g.ds_c;
+      const float v1 = dld<TIN>(p + (long)t.ya * g.ds_h + (long)t.xa * g.ds_w);
+      const float v2 = dld<TIN>(p + (long)t.ya * g.ds_h + (long)t.xb * g.ds_w);
+      const float v3 = dld<TIN>(p + (long)t.yb * g.ds_h + (long)t.xa * g.ds_w);
+      const float v4 = dld<TIN>(p + (long)t.yb * g.ds_h + (long)t.xb * g.ds_w);
+      // w1 = hh hw, w2 = hh lw, w3 = lh hw, w4 = lh lw with hh = 1 - lh, hw = 1 - lw; lh, lw move with the offsets
+      // (a clamped axis has ya == yb / xa == xb, so its difference below vanishes like the reference's :199-210)
+      const float hw = t.w1 + t.w3, lw = t.w2 + t.w4, hh = t.w1 + t.w2, lh = t.w3 + t.w4;
+      doh = gval * (hw * (v3 - v1) + lw * (v4 - v2));
+      dow = gval * (hh * (v2 - v1) + lh * (v4 - v3));
+      float* gd = a.grad_data + (long)b * a.gs_b + (long)c * a.gs_c;
+      atomicAdd(gd + (long)t.ya * a.gs_h + (long)t.xa * a.gs_w, t.w1 * gval);
+      atomicAdd(gd + (long)t.ya * a.gs_h + (long)t.xb * a.gs_w, t.w2 * gval);
+      atomicAdd(gd + (long)t.yb * a.gs_h + (long)t.xa * a.gs_w, t.w3 * gval);
+      atomicAdd(gd + (long)t.yb * a.gs_h + (long)t.xb * a.gs_w, t.w4 * gval);
+    }
+    if (a.grad_offset) {
+      float* go = a.grad_offset + (long)b * a.os_b + (long)ho * a.os_h + (long)wo * a.os_w +
+                  (long)(dgi * 2 * g.KH * g.KW + 2 * tap) * a.os_c;
+      if (wave_uniform) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { doh += __shfl_xor(doh, o); dow += __shfl_xor(dow, o); }
+        if ((threadIdx.x & 63) == 0 && live) { atomicAdd(go, doh); atomicAdd(go + a.os_c, dow); }
+      } else if (live && t.inside) {
+        atomicAdd(go, doh); atomicAdd(go + a.os_c, dow);
+      }
+    }
+  }
+}
+
+struct PsroiBwdArgs {
+  PsroiArgs f;                       // forward description (data values, rois, trans, shapes); f.out unused
+  const void* grad_out; long go_r, go_c, go_ph, go_pw;   // [R, output_dim, P, P] (strides in elements, dtype of data)
+  float* grad_data; long gs_b, gs_c, gs_h, gs_w;         // fp32 += (atomics)
+  float* grad_trans;                                     // fp32 [R, 2*num_classes, part, part] += or nullptr
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void deformable_psroi_pool_bwd_kernel(PsroiBwdArgs a) {
+  const PsroiArgs& g = a.f;
+  const long total = (long)g.R * g.P * g.P * g.output_dim;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int ctop = (int)(idx % g.output_dim);
+    long r = idx / g.output_dim;
+    const int pw = (int)(r % g.P); r /= g.P;
+    const int ph = (int)(r % g.P);
+    const int n = (int)(r / g.P);
+    const RoiGeom q = psroi_geom(g, n);
+    const int part_h = (int)floorf((float)ph / (float)g.P * (float)g.part);
+    const int part_w = (int)floorf((float)pw / (float)g.P * (float)g.part);
+    const int cls = ctop / g.ch_each;
+    float tx = 0.f, ty = 0.f;
+    long toff = 0;
+    if (g.trans) {
+      toff = ((((long)n * g.num_classes + cls) * 2) * g.part + part_h) * g.part + part_w;
+      tx = g.trans[toff] * g.trans_std;
+      ty = g.trans[toff + (long)g.part * g.part] * g.trans_std;
+    }
+    float wstart = (float)pw * q.bin_w + q.start_w; wstart = wstart + tx * q.roi_w;
+    float hstart = (float)ph * q.bin_h + q.start_h; hstart = hstart + ty * q.roi_h;
+    int gw = (int)floorf((float)pw * (float)g.group / (float)g.P);
+    int gh = (int)floorf((float)ph * (float)g.group / (float)g.P);
+    gw = min(max(gw, 0), g.group - 1); gh = min(max(gh, 0), g.group - 1);
+    const int c = (ctop * g.group + gh) * g.group + gw;
+    // first pass: the forward's sample count (top_count)
+    int count = 0;
+    for (int ih = 0; ih < g.spp; ++ih)
+      for (int iw = 0; iw < g.spp; ++iw) {
+        const float w = wstart + (float)iw * q.sub_w, h = hstart + (float)ih * q.sub_h;
+        if (!(w < -0.5f || w > (float)g.W - 0.5f || h < -0.5f || h > (float)g.H - 0.5f)) ++count;
+      }
+    if (count == 0) continue;
+    const float gout = dld<T>((const T*)a.grad_out + (long)n * a.go_r + (long)ctop * a.go_c + (long)ph * a.go_ph + (long)pw * a.go_pw);
+    const float diff = gout / (float)count;
+    const T* pc = (const T*)g.data + (long)q.b * g.ds_b + (long)c * g.ds_c;
+    float* gd = a.grad_data + (long)q.b * a.gs_b + (long)c * a.gs_c;
+    float dtx = 0.f, dty = 0.f;
+    for (int ih = 0; ih < g.spp; ++ih)
+      for (int iw = 0; iw < g.spp; ++iw) {
+        float w = wstart + (float)iw * q.sub_w, h = hstart + (float)ih * q.sub_h;
+        if (w < -0.5f || w > (float)g.W - 0.5f || h < -0.5f || h > (float)g.H - 0.5f) continue;
+        w = fminf(fmaxf(w, 0.f), (float)g.W - 1.f);
+        h = fminf(fmaxf(h, 0.f), (float)g.H - 1.f);
+        const int x0 = (int)floorf(w), x1 = (int)ceilf(w), y0 = (int)floorf(h), y1 = (int)ceilf(h);
+        const float dx = w - (float)x0, dy = h - (float)y0;
+        atomicAdd(gd + (long)y0 * a.gs_h + (long)x0 * a.gs_w, (1.f - dx) * (1.f - dy) * diff);
+        atomicAdd(gd + (long)y1 * a.gs_h + (long)x0 * a.gs_w, (1.f - dx) * dy * diff);
+        atomicAdd(gd + (long)y0 * a.gs_h + (long)x1 * a.gs_w, dx * (1.f - dy) * diff);
+        atomicAdd(gd + (long)y1 * a.gs_h + (long)x1 * a.gs_w, dx * dy * diff);
+        if (a.grad_trans) {
+          const float u00 = dld<T>(pc + (long)y0 * g.ds_h + (long)x0 * g.ds_w), u01 = dld<T>(pc + (long)y1 * g.ds_h + (long)x0 * g.ds_w);
+          const float u10 = dld<T>(pc + (long)y0 * g.ds_h + (long)x1 * g.ds_w), u11 = dld<T>(pc + (long)y1 * g.ds_h + (long)x1 * g.ds_w);
+          dtx += (u11 * dy + u10 * (1.f - dy) - u01 * dy - u00 * (1.f - dy)) * g.trans_std * diff * q.roi_w;
+          dty += (u11 * dx + u01 * (1.f - dx) - u10 * dx - u00 * (1.f - dx)) * g.trans_std * diff * q.roi_h;
+        }
+      }
+    if (a.grad_trans) {
+      atomicAdd(a.grad_trans + toff, dtx);
+      atomicAdd(a.grad_trans + toff + (long)g.part * g.part, dty);
+    }
+  }
+}
+
+}  // namespace relnet
+
+extern "C" int relnet_deformable_col2im(const void* dcol, long dcol_ld, int dcol_dtype, const void* data,
+                                        const long* data_strides4, int data_dtype, const float* offset,
+                                        const long* offset_strides4, float* grad_data, const long* grad_data_strides4,
+                                        float* grad_offset, const long* grad_offset_strides4, int B, int C, int H, int W,
+                                        int KH, int KW, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
+                                        int dil_w, int num_deformable_group, void* stream) {
+  RELNET_REQUIRE(dcol && data && offset && grad_data && data_strides4 && offset_strides4 && grad_data_strides4,
+                 "relnet_deformable_col2im: null operand");
+  RELNET_REQUIRE(!grad_offset || grad_offset_strides4, "relnet_deformable_col2im: grad_offset needs its strides");
+  RELNET_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && num_deformable_group > 0 && C % num_deformable_group == 0,
+                 "relnet_deformable_col2im: bad shape");
+  DeformBwdArgs a;
+  DeformColArgs& g = a.f;
+  g.data = data; g.ds_b = data_strides4[0]; g.ds_c = data_strides4[1]; g.ds_h = data_strides4[2]; g.ds_w = data_strides4[3];
+  g.offset = offset; g.fs_b = offset_strides4[0]; g.fs_c = offset_strides4[1]; g.fs_h = offset_strides4[2]; g.fs_w = offset_strides4[3];
+  g.col = nullptr; g.col_ld = 0; g.B = B; g.C = C; g.H = H; g.W = W; g.KH = KH; g.KW = KW; g.pad_h = pad_h; g.pad_w = pad_w;
+  g.stride_h = stride_h; g.stride_w = stride_w; g.dil_h = dil_h; g.dil_w = dil_w; g.DG = num_deformable_group;
+  g.Ho = (H + 2 * pad_h - (dil_h * (KH - 1) + 1)) / stride_h + 1;
+  g.Wo = (W + 2 * pad_w - (dil_w * (KW - 1) + 1)) / stride_w + 1;
+  RELNET_REQUIRE(dcol_ld >= (long)KH * KW * C, "relnet_deformable_col2im: dcol_ld too small");
+  a.dcol = dcol; a.dcol_ld = dcol_ld; a.dcol_f32 = dcol_dtype == RELNET_F32;
+  a.grad_data = grad_data; a.gs_b = grad_data_strides4[0]; a.gs_c = grad_data_strides4[1]; a.gs_h = grad_data_strides4[2]; a.gs_w = grad_data_strides4[3];
+  a.grad_offset = grad_offset;
+  if (grad_offset) { a.os_b = grad_offset_strides4[0]; a.os_c = grad_offset_strides4[1]; a.os_h = grad_offset_strides4[2]; a.os_w = grad_offset_strides4[3]; }
+  const unsigned grid = grid_for((long)B * g.Ho * g.Wo * KH * KW * C);
+  hipStream_t s = (hipStream_t)stream;
+  if (data_dtype == RELNET_F32) deformable_col2im_kernel<float><<<grid, 256, 0, s>>>(a);
+  else if (data_dtype == RELNET_BF16) deformable_col2im_kernel<unsigned short><<<grid, 256, 0, s>>>(a);
+  else RELNET_REQUIRE(false, "relnet_deformable_col2im: unknown dtype %d", data_dtype);
+  return check_launch("relnet_deformable_col2im");
+}
+
+extern "C" int relnet_deformable_psroi_pool_bwd(const void* grad_out, const long* grad_out_strides4, const void* data,
+                                                const long* data_strides4, const float* rois, const float* trans,
+                                                float* grad_data, const long* grad_data_strides4, float* grad_trans,
+                                                int R, int C, int H, int W, int output_dim, int group_size,
+                                                int pooled_size, int part_size, int sample_per_part, float spatial_scale,
+                                                float trans_std, int num_classes, int batch_index_base, int dtype,
+                                                void* stream) {
+  RELNET_REQUIRE(grad_out && grad_out_strides4 && data && data_strides4 && rois && grad_data && grad_data_strides4,
+                 "relnet_deformable_psroi_pool_bwd: null operand");
+  RELNET_REQUIRE(R > 0 && C == output_dim * group_size * group_size && pooled_size > 0 && sample_per_part > 0,
+                 "relnet_deformable_psroi_pool_bwd: bad shape");
+  const bool no_trans = (trans == nullptr);
+  RELNET_REQUIRE(no_trans || (num_classes > 0 && output_dim % num_classes == 0), "relnet_deformable_psroi_pool_bwd: bad num_classes");
+  RELNET_REQUIRE(no_trans || grad_trans, "relnet_deformable_psroi_pool_bwd: grad_trans required when trans is given");
+  PsroiBwdArgs a;
+  PsroiArgs& g = a.f;
+  g.data = data; g.ds_b = data_strides4[0]; g.ds_c = data_strides4[1]; g.ds_h = data_strides4[2]; g.ds_w = data_strides4[3];
+  g.rois = rois; g.trans = trans; g.out = nullptr; g.os_r = g.os_c = g.os_ph = g.os_pw = 0; g.top_count = nullptr;
+  g.R = R; g.H = H; g.W = W; g.output_dim = output_dim; g.group = group_size; g.P = pooled_size;
+  g.part = part_size > 0 ? part_size : pooled_size; g.spp = sample_per_part;
+  g.num_classes = no_trans ? 1 : num_classes; g.ch_each = no_trans ? output_dim : output_dim / num_classes;
+  g.batch_index_base = batch_index_base; g.scale = spatial_scale; g.trans_std = trans_std;
+  a.grad_out = grad_out; a.go_r = grad_out_strides4[0]; a.go_c = grad_out_strides4[1]; a.go_ph = grad_out_strides4[2]; a.go_pw = grad_out_strides4[3];
+  a.grad_data = grad_data; a.gs_b = grad_data_strides4[0]; a.gs_c = grad_data_strides4[1]; a.gs_h = grad_data_strides4[2]; a.gs_w = grad_data_strides4[3];
+  a.grad_trans = no_trans ? nullptr : grad_trans;
+  const unsigned grid = grid_for((long)R * pooled_size * pooled_size * output_dim);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == RELNET_F32) deformable_psroi_pool_bwd_kernel<float><<<grid, 256, 0, s>>>(a);
+  else if (dtype == RELNET_BF16) deformable_psroi_pool_bwd_kernel<unsigned short><<<grid, 256, 0, s>>>(a);
+  else RELNET_REQUIRE(false, "relnet_deformable_psroi_pool_bwd: unknown dtype %d", dtype);
+  return check_launch("relnet_deformable_psroi_pool_bwd");
+}

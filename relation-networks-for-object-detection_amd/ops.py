@@ -613,3 +613,55 @@ def geometry_bias_bwd(boxes, bias, dlog, M, divisors=None):
     _lib.call('relnet_geometry_bias_bwd', boxes.data_ptr(), bs, 1 if bs == 5 else 0, bias.data_ptr(), dlog.data_ptr(),
               div.data_ptr(), dwp.data_ptr(), dbp.data_ptr(), B, N, M, bias.shape[-1], _stream())
     return dwp, dbp
+
+
+def deformable_conv_bwd(data, offset, w_packed, dy, kernel=(3, 3), stride=(1, 1), dilate=(1, 1), pad=(0, 0),
+                        num_deformable_group=1):
+    """Adjoint of deformable_conv.  data logical [B,C,H,W], offset fp32 logical [B,2*kh*kw*dg,Ho,Wo], dy logical
+    [B,Cout,Ho,Wo] with channels-last memory ([B,Ho,Wo,Cout] contiguous).
+    -> (grad_data fp32 [B,H,W,C] (NHWC), grad_offset fp32 [B,Ho,Wo,2*kh*kw*dg] (NHWC), grad_weight fp32 [Cout, kh*kw*C])."""
+    from . import train_ops as T
+    _chk(data, offset, w_packed, dy)
+    kh, kw = _pair(kernel); sh, sw = _pair(stride); dh, dw = _pair(dilate); ph, pw = _pair(pad)
+    B, Cc, H, W = data.shape
+    Cout = w_packed.shape[0]
+    dy2 = dy.permute(0, 2, 3, 1).reshape(-1, Cout)
+    assert dy2.stride(1) == 1
+    # column gradient: dcol [P, kh*kw*C] = dY [P, Cout] . W [Cout, kh*kw*C]
+    gran = 64 if dy2.dtype == torch.bfloat16 else 16
+    w_t = transpose_2d(w_packed, pad_cols_to=gran)
+    dyp = dy2
+    if Cout % gran:
+        dyp = torch.zeros((dy2.shape[0], w_t.shape[1]), device=dy2.device, dtype=dy2.dtype)
+        dyp[:, :Cout] = dy2
+    dcol = gemm_nt(dyp, w_t, out_dtype=torch.float32)
+    gdata = torch.zeros((B, H, W, Cc), device=data.device, dtype=torch.float32).permute(0, 3, 1, 2)
+    goff = torch.zeros((B, offset.shape[2], offset.shape[3], offset.shape[1]), device=data.device, dtype=torch.float32).permute(0, 3, 1, 2)
+    _lib.call('relnet_deformable_col2im', dcol.data_ptr(), dcol.stride(0), F32, data.data_ptr(), _strides4(data), _dt(data),
+              offset.data_ptr(), _strides4(offset), gdata.data_ptr(), _strides4(gdata), goff.data_ptr(), _strides4(goff),
+              B, Cc, H, W, kh, kw, ph, pw, sh, sw, dh, dw, num_deformable_group, _stream())
+    col, _ = deformable_im2col(data, offset, kernel, stride, dilate, pad, num_deformable_group, col_dtype=dy2.dtype)
+    gw = T.wgrad(dy2, col)
+    return gdata.permute(0, 2, 3, 1), goff.permute(0, 2, 3, 1), gw
+
+
+def deformable_psroi_pool_bwd(grad_out, data, rois, trans=None, spatial_scale=0.0625, output_dim=256, group_size=1,
+                              pooled_size=7, part_size=0, sample_per_part=1, trans_std=0.0, no_trans=False,
+                              batch_index_base=0):
+    """Adjoint of deformable_psroi_pool: -> (grad_data fp32 logical [B,C,H,W] stored NHWC, grad_trans fp32 | None)."""
+    _chk(grad_out, data, rois, trans)
+    B, Cc, H, W = data.shape
+    R = rois.shape[0]
+    assert grad_out.dtype == data.dtype and rois.dtype == torch.float32 and rois.is_contiguous()
+    num_classes = 0
+    gtrans = None
+    if not no_trans:
+        assert trans is not None and trans.dtype == torch.float32 and trans.is_contiguous()
+        num_classes = trans.shape[1] // 2
+        gtrans = torch.zeros_like(trans)
+    gdata = torch.zeros((B, H, W, Cc), device=data.device, dtype=torch.float32).permute(0, 3, 1, 2)
+    _lib.call('relnet_deformable_psroi_pool_bwd', grad_out.data_ptr(), _strides4(grad_out), data.data_ptr(), _strides4(data),
+              rois.data_ptr(), 0 if no_trans else trans.data_ptr(), gdata.data_ptr(), _strides4(gdata), _ptr(gtrans),
+              R, Cc, H, W, int(output_dim), int(group_size), int(pooled_size), int(part_size), int(sample_per_part),
+              float(spatial_scale), float(trans_std), num_classes, batch_index_base, _dt(data), _stream())
+    return gdata, gtrans

@@ -250,3 +250,63 @@ def test_dcn_detector_stagewise_fp32_and_bf16():
     assert err < 6e-2, err
     o16 = det16.forward(data2, torch.tensor([[H, W, 1.0]] * 2).cuda())
     assert torch.isfinite(o16['cls_score']).all() and o16['rois'].shape == (2, 64, 5)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# backward (DeformableConvolutionOp::Backward, DeformablePSROIPoolBackwardAcc) vs float64 autograd of the restated forward
+# ------------------------------------------------------------------------------------------------------------------
+def _relerr(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_deformable_convolution_backward(dtype):
+    ops, _ = _mods()
+    from oracle import deform_torch as DT
+    rng = np.random.default_rng(21)
+    B, C, H, W, Co, k, pad, dil, dg = 2, 64, 11, 13, 64, 3, 2, 2, 4
+    rnd = _bf16_round if dtype == 'bf16' else (lambda a: a)
+    data = rnd(rng.normal(0, 1, (B, C, H, W)).astype(F))
+    off = rng.normal(0, 1.5, (B, 2 * k * k * dg, H, W)).astype(F)
+    wgt = rnd(rng.normal(0, 0.05, (Co, C, k, k)).astype(F))
+    dy = rnd(rng.normal(0, 1, (B, Co, H, W)).astype(F))
+    td = torch.tensor(data, dtype=torch.float64, requires_grad=True)
+    to = torch.tensor(off, dtype=torch.float64, requires_grad=True)
+    tw = torch.tensor(wgt, dtype=torch.float64, requires_grad=True)
+    y = DT.deformable_convolution(td, to, tw, (k, k), (1, 1), (dil, dil), (pad, pad), dg)
+    (y * torch.as_tensor(dy).double()).sum().backward()
+    tdt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    x = torch.as_tensor(data).cuda().to(tdt).contiguous(memory_format=torch.channels_last)
+    o = torch.as_tensor(off).cuda()
+    g = torch.as_tensor(dy).cuda().to(tdt).contiguous(memory_format=torch.channels_last)
+    wp = ops.pack_conv_weight(torch.as_tensor(wgt), dtype=tdt)
+    gd, go, gw = ops.deformable_conv_bwd(x, o, wp, g, 3, 1, dil, pad, dg)
+    tol = 2e-4 if dtype == 'f32' else 2e-2
+    assert _relerr(gd.permute(0, 3, 1, 2).cpu().numpy(), td.grad.numpy()) <= tol
+    assert _relerr(go.permute(0, 3, 1, 2).cpu().numpy(), to.grad.numpy()) <= tol
+    want_w = tw.grad.permute(0, 2, 3, 1).reshape(Co, -1).numpy()
+    assert _relerr(gw.cpu().numpy(), want_w) <= (2e-4 if dtype == 'f32' else 5e-3)
+
+
+@pytest.mark.parametrize("case", PSROI_CASES)
+def test_psroi_backward(case):
+    ops, _ = _mods()
+    from oracle import deform_torch as DT
+    group, no_trans, ncls, od, spp, tstd = case
+    rng = np.random.default_rng(22)
+    B, H, W, P, R = 2, 14, 17, 7, 12
+    data = rng.normal(0, 1, (B, od * group * group, H, W)).astype(F)
+    rois = _rois(rng, R, B, W, H)
+    trans = None if no_trans else rng.normal(0, 1.0, (R, 2 * ncls, P, P)).astype(F)
+    gout = rng.normal(0, 1, (R, od, P, P)).astype(F)
+    td = torch.tensor(data, dtype=torch.float64, requires_grad=True)
+    tt = None if no_trans else torch.tensor(trans, dtype=torch.float64, requires_grad=True)
+    y = DT.deformable_psroi_pooling(td, rois, tt, 0.0625, od, group, P, P, spp, tstd, no_trans)
+    (y * torch.as_tensor(gout).double()).sum().backward()
+    gd, gt = ops.deformable_psroi_pool_bwd(torch.as_tensor(gout).cuda(), torch.as_tensor(data).cuda(), torch.as_tensor(rois).cuda(),
+                                           None if no_trans else torch.as_tensor(trans).cuda(), 0.0625, od, group, P, P, spp, tstd, no_trans)
+    assert _relerr(gd.cpu().numpy(), td.grad.numpy()) <= 2e-5
+    if not no_trans:
+        assert _relerr(gt.cpu().numpy(), tt.grad.numpy()) <= 2e-4
+    else:
+        assert gt is None

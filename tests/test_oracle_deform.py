@@ -170,3 +170,21 @@ def test_psroi_part_index_uses_fp32_division():
     ph = np.arange(7)
     idx = np.floor((ph.astype(F) / F(7)).astype(F) * F(7)).astype(int)
     assert idx.tolist() == [int(math.floor(F(F(F(p) / F(7)) * F(7)))) for p in range(7)]
+
+
+def test_torch_restatements_match_numpy_oracle():
+    """oracle/deform_torch.py (autograd checker of the backward kernels) == oracle/deform.py on the forward."""
+    from oracle import deform_torch as DT
+    rng = np.random.default_rng(5)
+    C, H, W, k, pad, dil, dg = 8, 9, 11, 3, 2, 2, 2
+    data = rng.normal(0, 1, (C, H, W)).astype(F)
+    off = rng.normal(0, 2.0, (2 * k * k * dg, H, W)).astype(F)
+    a = deform.deformable_im2col(data, off, (k, k), (pad, pad), (1, 1), (dil, dil), dg)
+    b = DT.deformable_im2col(torch.as_tensor(data).double(), torch.as_tensor(off).double(), (k, k), (pad, pad), (1, 1), (dil, dil), dg).numpy()
+    assert np.abs(a - b).max() <= 1e-5
+    rois = np.array([[0, 10.3, 20.7, 90.2, 100.4], [1, -30, -10, 40, 60.5], [0, 100, 80, 400, 300]], F)
+    d4 = rng.normal(0, 1, (2, 8, 9, 11)).astype(F)
+    trans = rng.normal(0, 1.5, (3, 4, 3, 3)).astype(F)
+    a, _ = deform.deformable_psroi_pooling(d4, rois, trans, 0.0625, 2, 2, 3, 3, 2, 0.1, False)
+    b = DT.deformable_psroi_pooling(torch.as_tensor(d4).double(), rois, torch.as_tensor(trans).double(), 0.0625, 2, 2, 3, 3, 2, 0.1, False).numpy()
+    assert np.abs(a - b).max() <= 1e-5
