@@ -93,9 +93,10 @@ def bench_train(a, rank, world, D):
     from relnet_amd import backbone, train
     H, W, G = 600, 1000, 8
     B = a.batch
-    params = backbone.init_params(seed=1)
+    params = backbone.init_params(seed=1, dcn_offset_std=0.005 if a.dcn else 0.0)
     cfg = train.TrainConfig()
     cfg.learn_nms = a.learn_nms
+    cfg.dcn = a.dcn
     tr = train.Trainer(params, cfg, im_hw=(H, W))
     g = torch.Generator().manual_seed(1000 + rank)
     data = torch.randn(B, 3, H, W, generator=g).cuda()
@@ -144,7 +145,8 @@ def bench_train(a, rank, world, D):
             'metric': 'images/sec (1000x600, 300 ROIs)', 'value': images / elapsed, 'unit': 'images/s', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': ('BASELINE configs[2]: TRAINING step of ResNet-101 Faster-RCNN + 2 relation modules + learn-NMS '
+            'config': {'workload': ('BASELINE configs[3] (deformable res5 + deformable PSROI pooling): ' if a.dcn else '') +
+                                   ('BASELINE configs[2]: TRAINING step of ResNet-101 Faster-RCNN + 2 relation modules + learn-NMS '
                                     'head end2end (..._rcnn_end2end_relation_learn_nms_8epoch.yaml)' if a.learn_nms else
                                     'TRAINING step of ResNet-101 Faster-RCNN + 2 relation modules end2end '
                                     '(..._rcnn_end2end_relation_8epoch.yaml)') +

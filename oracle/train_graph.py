@@ -17,6 +17,7 @@ from . import network as ON
 from . import roi_pooling as ORP
 from . import relation_torch as ORT
 from .losses import smooth_l1
+from . import deform_torch as DT
 
 
 def learn_nms_loss(cls_score, fc_all_2_relu, pd, rank_idx, class_boxes, target, first_n, nms_loss_scale=1.0, nms_pos_scale=4.0,
@@ -50,8 +51,24 @@ def learn_nms_loss(cls_score, fc_all_2_relu, pd, rank_idx, class_boxes, target, 
     return nms_pos_scale * pos + neg, multi
 
 
+def res5_dcn(conv4, pd):
+    """res5 of the DCN graphs (symbols/resnet_v1_101_rcnn_dcn_..._learn_nms.py:694-760), differentiable."""
+    x = conv4
+    for u in 'abc':
+        nm = '5' + u
+        sc = ON._conv_bn(x, pd, 'res%s_branch1' % nm, 'bn%s_branch1' % nm) if u == 'a' else x
+        y = ON._conv_bn(x, pd, 'res%s_branch2a' % nm, 'bn%s_branch2a' % nm, relu=True)
+        name = 'res%s_branch2b' % nm
+        off = F.conv2d(y, pd[name + '_offset_weight'], pd[name + '_offset_bias'], padding=2, dilation=2)
+        z = DT.deformable_convolution(y, off, pd[name + '_weight'], (3, 3), (1, 1), (2, 2), (2, 2), 4)
+        y = F.relu(ON._bn(z, pd, 'bn%s_branch2b' % nm))
+        y = ON._conv_bn(y, pd, 'res%s_branch2c' % nm, 'bn%s_branch2c' % nm)
+        x = F.relu(sc + y)
+    return x
+
+
 def total_loss(data, p, rois, labels_ohem, bbox_target, bbox_weight_ohem, rpn_label, rpn_bbox_target, rpn_bbox_weight,
-               nongt_dim, rpn_batch_size=256, batch_rois_ohem=128, lnms=None):
+               nongt_dim, rpn_batch_size=256, batch_rois_ohem=128, lnms=None, dcn=False):
     """One image.  p: name -> torch float64 tensors (requires_grad on the trainable ones).  rois [R,5] numpy;
     labels_ohem [R]; bbox_target / bbox_weight_ohem [R,8]; rpn_label [A*h*w]; rpn_bbox_target / weight [4A,h,w]."""
     pd = {k: (v.double() if torch.is_tensor(v) else torch.as_tensor(np.asarray(v), dtype=torch.float64)) for k, v in p.items()}
@@ -63,6 +80,8 @@ def total_loss(data, p, rois, labels_ohem, bbox_target, bbox_weight_ohem, rpn_la
     ON._t = lambda x: x.double() if torch.is_tensor(x) else torch.as_tensor(np.asarray(x), dtype=torch.float64)
     try:
         conv4, conv5 = ON.backbone(torch.as_tensor(np.asarray(data), dtype=torch.float64), pd)
+        if dcn:
+            conv5 = res5_dcn(conv4, pd)
         cls, box, feat = ON.rpn_and_feat(conv4, conv5, pd)
     finally:
         ON._t = old
@@ -75,14 +94,19 @@ def total_loss(data, p, rois, labels_ohem, bbox_target, bbox_weight_ohem, rpn_la
     l_rpn_cls = -(logp[torch.arange(len(lab)), lab.clamp(min=0)] * valid.double()).sum() / max(int(valid.sum()), 1)
     l_rpn_box = (torch.as_tensor(np.asarray(rpn_bbox_weight), dtype=torch.float64)
                  * smooth_l1(box[0] - torch.as_tensor(np.asarray(rpn_bbox_target), dtype=torch.float64), 3.0)).sum() / rpn_batch_size
-    # ROIPooling (max; argmax from the numpy oracle on the same feature values)
     rois = np.asarray(rois, np.float32)
-    _, arg = ORP.roi_pooling(feat.detach().numpy().astype(np.float32), rois, return_argmax=True)
-    R, C = arg.shape[:2]
-    flat = feat[0].reshape(C, -1)
-    idx = torch.as_tensor(arg.astype(np.int64))
-    g = torch.gather(flat, 1, idx.clamp(min=0).permute(1, 0, 2, 3).reshape(C, -1)).reshape(C, R, 7, 7).permute(1, 0, 2, 3)
-    pooled = g * (idx >= 0).double()
+    if dcn:     # offset_t -> FC `offset` -> deformable_roi_pool (SYM_DCN_RELNMS:1073-1080)
+        R = rois.shape[0]
+        t0 = DT.deformable_psroi_pooling(feat, rois, None, 0.0625, feat.shape[1], 1, 7, 7, 4, 0.0, True)
+        tr = (t0.reshape(R, -1) @ pd['offset_weight'].t() + pd['offset_bias']).reshape(R, 2, 7, 7)
+        pooled = DT.deformable_psroi_pooling(feat, rois, tr, 0.0625, feat.shape[1], 1, 7, 7, 4, 0.1, False)
+    else:       # ROIPooling (max; argmax from the numpy oracle on the same feature values)
+        _, arg = ORP.roi_pooling(feat.detach().numpy().astype(np.float32), rois, return_argmax=True)
+        R, C = arg.shape[:2]
+        flat = feat[0].reshape(C, -1)
+        idx = torch.as_tensor(arg.astype(np.int64))
+        g = torch.gather(flat, 1, idx.clamp(min=0).permute(1, 0, 2, 3).reshape(C, -1)).reshape(C, R, 7, 7).permute(1, 0, 2, 3)
+        pooled = g * (idx >= 0).double()
     # head
     x = pooled.reshape(R, -1)
     f1 = x @ pd['fc_new_1_weight'].t() + pd['fc_new_1_bias']
@@ -102,5 +126,7 @@ def total_loss(data, p, rois, labels_ohem, bbox_target, bbox_weight_ohem, rpn_la
     if lnms is not None:       # dict(rank_idx, class_boxes, target, first_n)
         l_nms, multi = learn_nms_loss(cls_score[:nongt_dim], x2[:nongt_dim], pd, lnms['rank_idx'], lnms['class_boxes'],
                                       lnms['target'], lnms['first_n'])
-    return l_rpn_cls + l_rpn_box + l_cls + l_box + l_nms, dict(nms_multi=None if multi is None else multi.detach(),rpn_cls=l_rpn_cls, rpn_box=l_rpn_box, cls=l_cls, box=l_box,
+    return l_rpn_cls + l_rpn_box + l_cls + l_box + l_nms, dict(nms_multi=None if multi is None else multi.detach(),
+                                                                conv5=conv5.detach(), pooled=pooled.detach(), f1=f1.detach(), x2=x2.detach(),
+                                                                trans=tr.detach() if dcn else None,rpn_cls=l_rpn_cls, rpn_box=l_rpn_box, cls=l_cls, box=l_box,
                                                         cls_score=cls_score.detach(), feat=feat.detach())

@@ -122,6 +122,11 @@ class Trainer(object):
             biases.append(('linear_out_%d' % i, params['linear_out_%d_bias' % i]))
             weights.append(('pair_pos_fc1_%d' % i, params['pair_pos_fc1_%d_weight' % i]))
             biases.append(('pair_pos_fc1_%d' % i, params['pair_pos_fc1_%d_bias' % i]))
+        if c.dcn:           # deformable res5 (offset convs) + deformable PSROI pooling's offset FC (SYM_DCN_RELNMS:700-746,1073-1080)
+            for u in 'abc':
+                n = 'res5%s_branch2b_offset' % u
+                weights.append((n, conv_w(n))); biases.append((n, params[n + '_bias']))
+                self.ksize[n] = 3
         if c.learn_nms:     # learn-NMS head (symbols/..._learn_nms.py:424-551), trained end to end with the detector
             for n in ('nms_rank', 'roi_feat_embedding', 'nms_pair_pos_fc1_1', 'nms_logit'):
                 weights.append((n, params[n + '_weight'])); biases.append((n, params[n + '_bias']))
@@ -131,8 +136,13 @@ class Trainer(object):
             biases.append(('nms_linear_out_1', params['nms_linear_out_1_bias']))
             from .learn_nms import rank_embedding
             self.rank_emb = rank_embedding(c.first_n, 1024).to(dev, torch.bfloat16).contiguous()
+        self.lr_mult_tail = None
+        if c.dcn:           # `offset` FC has lr_mult = 0.01 (SYM_DCN_RELNMS:1075): keep it LAST so it is one tail range
+            weights.append(('offset', params['offset_weight'][:, self.fc1_perm])); biases.append(('offset', params['offset_bias']))
         self.W = _Flat(weights, dev)          # weight decay applies
         self.Bv = _Flat(biases, dev)          # biases: wd_mult 0 (MXNet's rule for names not ending in _weight / _gamma)
+        if c.dcn:
+            self.lr_mult_tail = (self.W.slices['offset'][0], self.Bv.slices['offset'][0], 0.01)
         self.anchors = torch.as_tensor(generate_anchors(c.feat_stride, c.anchor_ratios, c.anchor_scales), dtype=torch.float64, device=dev)
         self.step_count = 0
 
@@ -188,9 +198,15 @@ class Trainer(object):
                 continue
             sc = self._conv(x, n1, stride=stride) if proj else x
             y1 = self._conv(x, na, stride=stride, relu=True)
-            y2 = self._conv(y1, nb, pad=dil, dil=dil, relu=True)
+            off = None
+            if c.dcn and stage == 5:       # 72-channel offset conv -> DeformableConvolution(num_deformable_group=4) + BN + ReLU
+                off = self._conv(y1, nb + '_offset', pad=2, dil=2, bias=self.b(nb + '_offset'), out_dtype=torch.float32)
+                y2 = ops.deformable_conv(y1.permute(0, 3, 1, 2), off.permute(0, 3, 1, 2), self.w(nb), self.conv_bias[nb],
+                                         3, 1, 2, 2, 4, relu=True).permute(0, 2, 3, 1)
+            else:
+                y2 = self._conv(y1, nb, pad=dil, dil=dil, relu=True)
             out = self._conv(y2, nc, relu=True, resid=sc)
-            saved.append((stage, nm, stride, dil, proj, x, y1, y2, out))
+            saved.append((stage, nm, stride, dil, proj, x, y1, y2, out, off))
             x = out
         conv5 = x
         feat = self._conv(conv5, 'conv_new_1', relu=True, bias=self.b('conv_new_1'))
@@ -220,8 +236,18 @@ class Trainer(object):
         N = rois.shape[1]
         rois_t, label, bbox_target, bbox_weight = ops.proposal_target(rois, gt_boxes, num_gt)
         R = rois_t.shape[1]
-        pooled, argmax = ops.roi_pool(nchw(feat), rois_t.view(B * R, 5), (7, 7), 1.0 / c.feat_stride,
-                                      channels_last_out=True, want_argmax=True)
+        r5 = rois_t.view(B * R, 5)
+        if c.dcn:
+            sc_ = 1.0 / c.feat_stride
+            t0 = ops.deformable_psroi_pool(nchw(feat), r5, None, sc_, feat.shape[3], 1, 7, 7, c.dcn_sample_per_part, 0.0, True,
+                                           channels_last_out=True)
+            t0f = t0.permute(0, 2, 3, 1).reshape(B * R, -1)
+            trans = ops.gemm_nt(t0f, self.w('offset'), self.b('offset'), out_dtype=torch.float32).view(B * R, 2, 7, 7)
+            pooled = ops.deformable_psroi_pool(nchw(feat), r5, trans, sc_, feat.shape[3], 1, 7, 7, c.dcn_sample_per_part,
+                                               c.dcn_trans_std, False, channels_last_out=True)
+            argmax = None
+        else:
+            pooled, argmax = ops.roi_pool(nchw(feat), r5, (7, 7), 1.0 / c.feat_stride, channels_last_out=True, want_argmax=True)
         pooled2 = pooled.permute(0, 2, 3, 1).reshape(B * R, -1)
         # -- 2FC head + relation modules (keys = the first N rows of each image)
         bt = torch.bfloat16
@@ -263,9 +289,19 @@ class Trainer(object):
         d_pool, dw, db = T.linear_bwd(pooled2, self.w('fc_new_1'), d_f1.reshape(B * R, -1))
         self._add_wgrad('fc_new_1', dw); self._add_bgrad('fc_new_1', db)
         # ROIPooling backward -> gradient of conv_new_1_relu
-        d_feat = ops.roi_pool_bwd(d_pool.view(B * R, 7, 7, -1).permute(0, 3, 1, 2), argmax, rois_t.view(B * R, 5),
-                                  (B, feat.shape[3], feat.shape[1], feat.shape[2]))
-        d_feat = d_feat.permute(0, 2, 3, 1).to(bt).contiguous()
+        if c.dcn:
+            gp = d_pool.view(B * R, 7, 7, -1).permute(0, 3, 1, 2)
+            gd1, gtrans = ops.deformable_psroi_pool_bwd(gp, nchw(feat), r5, trans, sc_, feat.shape[3], 1, 7, 7,
+                                                        c.dcn_sample_per_part, c.dcn_trans_std, False)
+            d_t0, dw, db = T.linear_bwd(t0f, self.w('offset'), gtrans.view(B * R, -1).to(bt))
+            self._add_wgrad('offset', dw); self._add_bgrad('offset', db)
+            gd2, _ = ops.deformable_psroi_pool_bwd(d_t0.view(B * R, 7, 7, -1).permute(0, 3, 1, 2), nchw(feat), r5, None, sc_,
+                                                   feat.shape[3], 1, 7, 7, c.dcn_sample_per_part, 0.0, True)
+            d_feat = (gd1 + gd2).permute(0, 2, 3, 1).to(bt).contiguous()       # logical NCHW stored NHWC -> NHWC bf16
+        else:
+            d_feat = ops.roi_pool_bwd(d_pool.view(B * R, 7, 7, -1).permute(0, 3, 1, 2), argmax, r5,
+                                      (B, feat.shape[3], feat.shape[1], feat.shape[2]))
+            d_feat = d_feat.permute(0, 2, 3, 1).to(bt).contiguous()
         g = T.relu_bwd(d_feat, feat)
         d_x, dw = T.conv1x1_bwd(conv5, self.w('conv_new_1'), g)
         self._add_wgrad('conv_new_1', dw); self._add_bgrad('conv_new_1', g.float().sum((0, 1, 2)))
@@ -276,7 +312,7 @@ class Trainer(object):
         d_conv4_rpn, dw = T.conv3x3_bwd(conv4, self._dgrad_w('rpn_conv_3x3', 512), g_r, dil=1)
         self._add_wgrad('rpn_conv_3x3', dw); self._add_bgrad('rpn_conv_3x3', g_r.float().sum((0, 1, 2)))
         # trunk: res5 -> res3
-        for stage, nm, stride, dil, proj, x_in, y1, y2, o in reversed(saved):
+        for stage, nm, stride, dil, proj, x_in, y1, y2, o, off in reversed(saved):
             n1, na, nb, nc_ = 'res%s_branch1' % nm, 'res%s_branch2a' % nm, 'res%s_branch2b' % nm, 'res%s_branch2c' % nm
             if stage == 4 and d_conv4_rpn is not None and nm == '4b22':
                 d_x = d_x + d_conv4_rpn          # conv4 = output of res4b22 feeds both res5 and the RPN head
@@ -285,8 +321,21 @@ class Trainer(object):
             d_y2, dw = T.conv1x1_bwd(y2, self.w(nc_), g_out)
             self._add_wgrad(nc_, dw, self.bn_scale[nc_])
             g_y2 = T.relu_bwd(d_y2, y2)
-            d_y1, dw = T.conv3x3_bwd(y1, self._dgrad_w(nb, y2.shape[3]), g_y2, dil=dil)
-            self._add_wgrad(nb, dw, self.bn_scale[nb])
+            if off is not None:            # deformable branch2b: data + offset gradients, then the offset conv's own backward
+                gd, goff, dw = ops.deformable_conv_bwd(y1.permute(0, 3, 1, 2), off.permute(0, 3, 1, 2), self.w(nb),
+                                                       g_y2.permute(0, 3, 1, 2), 3, 1, 2, 2, 4)
+                self._add_wgrad(nb, dw, self.bn_scale[nb])
+                no = nb + '_offset'
+                goff_p = torch.zeros((B, off.shape[1], off.shape[2], 128), device=off.device, dtype=bt)   # 72 -> 128 channels
+                goff_p[..., :72] = goff
+                wd_ = self.w(no).view(72, 3, 3, -1).flip(1, 2).permute(3, 1, 2, 0)                     # [Cin,3,3,72]
+                wdp = torch.zeros((wd_.shape[0], 3, 3, 128), device=off.device, dtype=bt); wdp[..., :72] = wd_
+                d_off_in, dwo = T.conv3x3_bwd(y1, wdp.reshape(wd_.shape[0], -1).contiguous(), goff_p, dil=2)
+                self._add_wgrad(no, dwo[:72]); self._add_bgrad(no, goff.sum((0, 1, 2)))
+                d_y1 = (gd + d_off_in.float()).to(bt).contiguous()
+            else:
+                d_y1, dw = T.conv3x3_bwd(y1, self._dgrad_w(nb, y2.shape[3]), g_y2, dil=dil)
+                self._add_wgrad(nb, dw, self.bn_scale[nb])
             g_y1 = T.relu_bwd(d_y1, y1)
             first = (stage == 3 and proj)         # res3a: its input comes from the frozen res2 -> no data gradient
             if proj:
@@ -301,6 +350,7 @@ class Trainer(object):
                 self._add_wgrad(na, dw, self.bn_scale[na])
         out['rois'] = rois_t
         out['label'] = labels_ohem
+        out['debug'] = dict(feat=feat, conv5=conv5, pooled=pooled2, trans=trans if c.dcn else None, x2=x2, f1=f1)
         out['bbox_target'], out['bbox_weight'] = bbox_target, weights_ohem
         out['bbox_pred'] = bbox_pred
         out['cls_score'] = cls_score
@@ -438,8 +488,16 @@ class Trainer(object):
     def update(self, lr=None):
         c = self.cfg
         lr = c.lr if lr is None else lr
-        T.sgd_update(self.W.master, self.W.mom, self.W.grad, lr, c.momentum, c.wd, 1.0, w_bf16=self.W.work)
-        T.sgd_update(self.Bv.master, self.Bv.mom, self.Bv.grad, lr, c.momentum, 0.0, 1.0)
+        if self.lr_mult_tail is None:
+            T.sgd_update(self.W.master, self.W.mom, self.W.grad, lr, c.momentum, c.wd, 1.0, w_bf16=self.W.work)
+            T.sgd_update(self.Bv.master, self.Bv.mom, self.Bv.grad, lr, c.momentum, 0.0, 1.0)
+        else:                  # parameters with lr_mult != 1 sit at the tail of both flat buffers
+            wo, bo, mult = self.lr_mult_tail
+            W, Bv = self.W, self.Bv
+            T.sgd_update(W.master[:wo], W.mom[:wo], W.grad[:wo], lr, c.momentum, c.wd, 1.0, w_bf16=W.work[:wo])
+            T.sgd_update(W.master[wo:], W.mom[wo:], W.grad[wo:], lr * mult, c.momentum, c.wd, 1.0, w_bf16=W.work[wo:])
+            T.sgd_update(Bv.master[:bo], Bv.mom[:bo], Bv.grad[:bo], lr, c.momentum, 0.0, 1.0)
+            T.sgd_update(Bv.master[bo:], Bv.mom[bo:], Bv.grad[bo:], lr * mult, c.momentum, 0.0, 1.0)
         self.step_count += 1
 
     def step(self, *batch, **kw):

@@ -21,10 +21,15 @@ def _feat_size(n):
     return (n - 1) // 2 + 1
 
 
-def _setup(H, W, G, seed):
+def _setup(H, W, G, seed, dcn=False):
     import relnet_amd  # noqa: F401
     from relnet_amd import backbone, train
-    p = backbone.init_params(seed=seed)
+    # DCN: offsets of ~0.3 px in res5 and |trans| of a few units (x trans_std 0.1 = a fraction of the roi) -- the regime of a
+    # trained network; much larger random offsets make the sampling positions, hence every downstream value, hypersensitive
+    # to bf16 rounding (measured: |trans| = 30 gives 14 % forward error in the pooled features)
+    p = backbone.init_params(seed=seed, dcn_offset_std=0.005 if dcn else 0.0)
+    if dcn:
+        p['offset_weight'] = torch.randn(98, 256 * 49, generator=torch.Generator().manual_seed(seed)) * 0.003
     g = torch.Generator().manual_seed(seed + 1)
     for k in ('cls_score_weight', 'bbox_pred_weight'):
         p[k] = torch.randn(p[k].shape, generator=g) * 0.05
@@ -43,12 +48,13 @@ def _setup(H, W, G, seed):
     return p, cfg, data, gt, L, Tg, Wg, train
 
 
-@pytest.mark.parametrize('learn_nms', [False, True])
-def test_training_step_gradients_match_autograd(learn_nms):
-    """learn_nms=True: BASELINE configs[2] (relation + learn-NMS end2end); False: the relation end2end config."""
+@pytest.mark.parametrize('learn_nms,dcn', [(False, False), (True, False), (True, True)])
+def test_training_step_gradients_match_autograd(learn_nms, dcn):
+    """(True, False): BASELINE configs[2] (relation + learn-NMS end2end); (False, False): the relation end2end config;
+    (True, True): configs[3], deformable res5 + deformable PSROI pooling on top."""
     H, W, G = 128, 160, 4
-    p, cfg, data, gt, L, Tg, Wg, train = _setup(H, W, G, 31)
-    cfg.learn_nms, cfg.first_n = learn_nms, 24
+    p, cfg, data, gt, L, Tg, Wg, train = _setup(H, W, G, 31, dcn)
+    cfg.learn_nms, cfg.first_n, cfg.dcn = learn_nms, 24, dcn
     if learn_nms:          # un-saturate the duplicate classifier (init bias -3 -> sigmoid 0.05) so its gradients are not tiny
         g_ = torch.Generator().manual_seed(77)
         p['nms_logit_bias'] = torch.zeros(5)
@@ -74,14 +80,16 @@ def test_training_step_gradients_match_autograd(learn_nms):
                     target=out['nms_multi_target'][0].cpu().numpy(), first_n=cfg.first_n)
         assert out['nms_multi_target'].sum() > 0                       # some duplicates-free positives exist
     loss, parts = OT.total_loss(data.numpy(), pt, rois, out['label'][0].cpu().numpy(), out['bbox_target'][0].cpu().numpy(),
-                                out['bbox_weight'][0].cpu().numpy(), L, Tg, Wg, N, lnms=lnms)
+                                out['bbox_weight'][0].cpu().numpy(), L, Tg, Wg, N, lnms=lnms, dcn=dcn)
     loss.backward()
     if learn_nms:
         ms = out['nms_multi_score'][0].cpu().double()
-        assert (ms - parts['nms_multi']).abs().max() <= 0.05 * parts['nms_multi'].abs().max()
+        assert (ms - parts['nms_multi']).abs().max() <= (0.15 if dcn else 0.05) * parts['nms_multi'].abs().max()
     # the forward agrees first (bf16 through ~100 layers)
     cs = out['cls_score'][0].cpu().double()
-    assert (cs - parts['cls_score']).abs().max() <= 0.08 * parts['cls_score'].abs().max()
+    e_cs = float((cs - parts['cls_score']).abs().max() / parts['cls_score'].abs().max())
+    assert e_cs <= (0.2 if dcn else 0.08), e_cs
+    print('forward cls_score rel err %.4f' % e_cs)
 
     def packed(name):
         g_ = pt[name + '_weight'].grad
@@ -89,7 +97,7 @@ def test_training_step_gradients_match_autograd(learn_nms):
 
     want = {}
     for name in tr.W.slices:
-        if name.startswith('res'):
+        if name.startswith('res') and not name.endswith('_offset'):
             want[name] = packed(name) * tr.bn_scale[name].cpu().double().view(-1, 1)      # s * dL/dw = s^2 dL/dw'
     want['rpn_conv_3x3'] = packed('rpn_conv_3x3')
     want['rpn_out'] = torch.cat([packed('rpn_cls_score'), packed('rpn_bbox_pred')], 0)
@@ -107,6 +115,11 @@ def test_training_step_gradients_match_autograd(learn_nms):
         want['pair_pos_fc1_%d' % i] = pt['pair_pos_fc1_%d_weight' % i].grad
         wb['linear_out_%d' % i] = pt['linear_out_%d_bias' % i].grad
         wb['pair_pos_fc1_%d' % i] = pt['pair_pos_fc1_%d_bias' % i].grad
+    if dcn:
+        for u in 'abc':
+            n = 'res5%s_branch2b_offset' % u
+            want[n] = packed(n); wb[n] = pt[n + '_bias'].grad
+        want['offset'] = pt['offset_weight'].grad[:, tr.fc1_perm]; wb['offset'] = pt['offset_bias'].grad
     if learn_nms:
         for n in ('nms_rank', 'roi_feat_embedding', 'nms_pair_pos_fc1_1', 'nms_logit'):
             want[n] = pt[n + '_weight'].grad; wb[n] = pt[n + '_bias'].grad
@@ -120,7 +133,16 @@ def test_training_step_gradients_match_autograd(learn_nms):
         cos = float((w * got).sum() / max(nw * ng, 1e-300))
         report.append('%-22s |want| %.3e |got| %.3e cos %.4f' % (name, nw, ng, cos))
         tight = not name.startswith('res') and 'pair_pos' not in name
-        if nw > 1e-9 and (cos < (0.995 if tight else 0.98) or abs(ng / nw - 1) > (0.03 if tight else 0.08)):
+        cmin, nmax = (0.995, 0.03) if tight else (0.98, 0.08)
+        if dcn:
+            # the deformable graph's forward is 2.5x more sensitive to bf16 rounding (sampling positions move with the
+            # features: measured forward error 2.5 % vs 0.9 %), and the offset gradients are sums of DIFFERENCES of
+            # neighbouring feature values, which amplify that noise; the kernels themselves are exact on equal inputs
+            # (test_gpu_deform.py::test_deformable_convolution_backward, ::test_psroi_backward)
+            cmin, nmax = (0.975, 0.06) if tight else (0.95, 0.10)
+            if 'offset' in name:
+                cmin, nmax = 0.85, 0.15
+        if nw > 1e-9 and (cos < cmin or abs(ng / nw - 1) > nmax):
             bad.append(report[-1])
     assert not bad, '\n'.join(bad) + '\n--- all ---\n' + '\n'.join(report)
     assert len(want) == len(tr.W.slices)
