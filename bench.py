@@ -91,13 +91,13 @@ def bench_train(a, rank, world, D):
     forward + backward over `batch` images per GPU, ONE summed all-reduce of the 67.7 M trainable gradients, SGD."""
     import numpy as np
     from relnet_amd import backbone, train
-    H, W, G = 600, 1000, 8
+    H, W, G = (800, 1024, 8) if a.fpn else (600, 1000, 8)
     B = a.batch
-    params = backbone.init_params(seed=1, dcn_offset_std=0.005 if a.dcn else 0.0)
+    params = backbone.init_params(seed=1, dcn_offset_std=0.005 if a.dcn else 0.0, fpn=a.fpn)
     cfg = train.TrainConfig()
     cfg.learn_nms = a.learn_nms
     cfg.dcn = a.dcn
-    tr = train.Trainer(params, cfg, im_hw=(H, W))
+    tr = train.FPNTrainer(params, cfg) if a.fpn else train.Trainer(params, cfg, im_hw=(H, W))
     g = torch.Generator().manual_seed(1000 + rank)
     data = torch.randn(B, 3, H, W, generator=g).cuda()
     im_info = torch.tensor([[float(H), float(W), 1.0]] * B).cuda()
@@ -108,10 +108,19 @@ def bench_train(a, rank, world, D):
         bw, bh = rng.uniform(32, 400, G), rng.uniform(32, 400, G)
         x1, y1 = rng.uniform(0, W - 1 - bw), rng.uniform(0, H - 1 - bh)
         gt[b] = np.stack([x1, y1, x1 + bw, y1 + bh, rng.integers(1, 81, G)], 1)
-        L, Tg, Wg = train.assign_anchor((38, 63), gt[b], (H, W), cfg, seed=b)      # host loader work, outside the step
-        labs.append(L); tgts.append(Tg); wgts.append(Wg)
-    batch = (data, im_info, torch.as_tensor(gt).cuda(), torch.as_tensor(np.stack(labs)).cuda(),
-             torch.as_tensor(np.stack(tgts)).cuda(), torch.as_tensor(np.stack(wgts)).cuda())
+        if not a.fpn:
+            L, Tg, Wg = train.assign_anchor((38, 63), gt[b], (H, W), cfg, seed=b)  # host loader work, outside the step
+            labs.append(L); tgts.append(Tg); wgts.append(Wg)
+    if a.fpn:       # proposals are an input of the FPN graphs (HAS_RPN: false, TOP_ROIS 1000): log-uniform sizes over all levels
+        n_rois = 1000
+        side = torch.exp(torch.empty(B, n_rois).uniform_(math.log(16), math.log(640), generator=g))
+        ar = torch.exp(torch.empty(B, n_rois).uniform_(-0.7, 0.7, generator=g))
+        bw_, bh_ = (side * ar).clamp(max=W - 2), (side / ar).clamp(max=H - 2)
+        x1_ = torch.rand(B, n_rois, generator=g) * (W - 1 - bw_); y1_ = torch.rand(B, n_rois, generator=g) * (H - 1 - bh_)
+        batch = (data, im_info, torch.as_tensor(gt).cuda(), torch.stack([x1_, y1_, x1_ + bw_, y1_ + bh_], 2).cuda())
+    else:
+        batch = (data, im_info, torch.as_tensor(gt).cuda(), torch.as_tensor(np.stack(labs)).cuda(),
+                 torch.as_tensor(np.stack(tgts)).cuda(), torch.as_tensor(np.stack(wgts)).cuda())
 
     def fence():
         D.fence(device='cuda')
@@ -145,7 +154,8 @@ def bench_train(a, rank, world, D):
             'metric': 'images/sec (1000x600, 300 ROIs)', 'value': images / elapsed, 'unit': 'images/s', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': ('BASELINE configs[3] (deformable res5 + deformable PSROI pooling): ' if a.dcn else '') +
+            'config': {'workload': ('BASELINE configs[4] (FPN, 800x1024 images, 1000 given proposals + 8 gt rows): ' if a.fpn else '') +
+                                   ('BASELINE configs[3] (deformable res5 + deformable PSROI pooling): ' if a.dcn else '') +
                                    ('BASELINE configs[2]: TRAINING step of ResNet-101 Faster-RCNN + 2 relation modules + learn-NMS '
                                     'head end2end (..._rcnn_end2end_relation_learn_nms_8epoch.yaml)' if a.learn_nms else
                                     'TRAINING step of ResNet-101 Faster-RCNN + 2 relation modules end2end '

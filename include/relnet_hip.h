@@ -307,6 +307,13 @@ int relnet_deformable_psroi_pool_bwd(const void* grad_out, const long* grad_out_
                                      int sample_per_part, float spatial_scale, float trans_std, int num_classes,
                                      int batch_index_base, int dtype, void* stream);
 
+/* Adjoint of relnet_roi_pool_fpn_fwd (argmax from the forward, same strides as grad_out): roi r scatters into
+ * grad_in_levels[roi_level[r]] (fp32 [B,C,H_l*W_l] with batch / channel strides gs_b / gs_c; host arrays).     */
+int relnet_roi_pool_fpn_bwd(const void* grad_out, const int* argmax, const long* out_strides4, const float* rois,
+                            const int* roi_level, float* const* grad_in_levels, const long* gs_b_levels,
+                            const long* gs_c_levels, int num_levels, int R, int C, int PH, int PW,
+                            int batch_index_base, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,62 @@ def res5_dcn(conv4, pd):
     return x
 
 
+def _head_losses(pooled, rois, pd, labels_ohem, bbox_target, bbox_weight_ohem, nongt_dim, batch_rois_ohem=128,
+                 fc_names=('fc_new_1', 'fc_new_2')):
+    R = pooled.shape[0]
+    n1, n2 = fc_names
+    x = pooled.reshape(R, -1)
+    f1 = x @ pd[n1 + '_weight'].t() + pd[n1 + '_bias']
+    x1 = torch.relu(f1 + ORT.relation_module(f1, rois[:, 1:5], pd, 1, nongt_dim))
+    f2 = x1 @ pd[n2 + '_weight'].t() + pd[n2 + '_bias']
+    x2 = torch.relu(f2 + ORT.relation_module(f2, rois[:, 1:5], pd, 2, nongt_dim))
+    cls_score = x2 @ pd['cls_score_weight'].t() + pd['cls_score_bias']
+    bbox_pred = x2 @ pd['bbox_pred_weight'].t() + pd['bbox_pred_bias']
+    lo = torch.as_tensor(np.asarray(labels_ohem, np.int64))
+    v = lo >= 0
+    lp = torch.log_softmax(cls_score, dim=1)
+    l_cls = -(lp[torch.arange(R), lo.clamp(min=0)] * v.double()).sum() / max(int(v.sum()), 1)
+    l_box = (torch.as_tensor(np.asarray(bbox_weight_ohem), dtype=torch.float64)
+             * smooth_l1(bbox_pred - torch.as_tensor(np.asarray(bbox_target), dtype=torch.float64), 1.0)).sum() / batch_rois_ohem
+    return cls_score, bbox_pred, x2, f1, l_cls, l_box
+
+
+def total_loss_fpn(data, p, rois, level, labels_ohem, bbox_target, bbox_weight_ohem, nongt_dim, batch_rois_ohem=128, lnms=None):
+    """FPN train graph (symbols/resnet_v1_101_rcnn_fpn_..._learn_nms.py:1040-1200) on one image; rois [R,5] with the nongt_dim
+    non-gt rows first, level [R] = pyramid level of each row (both from the run under test)."""
+    from . import fpn as OF
+    pd = {k: (v.double() if torch.is_tensor(v) else torch.as_tensor(np.asarray(v), dtype=torch.float64)) for k, v in p.items()}
+    cast = lambda x: x.double() if torch.is_tensor(x) else torch.as_tensor(np.asarray(x), dtype=torch.float64)
+    old_n, old_f = ON._t, OF._t
+    ON._t = OF._t = cast
+    try:
+        c2, c3, c4, c5 = ON.backbone(torch.as_tensor(np.asarray(data), dtype=torch.float64), pd, fpn=True)
+        feats = OF.fpn_neck(c2, c3, c4, c5, pd)
+    finally:
+        ON._t, OF._t = old_n, old_f
+    rois = np.asarray(rois, np.float32)
+    level = np.asarray(level)
+    R, C = rois.shape[0], feats[0].shape[1]
+    pooled = torch.zeros(R, C, 7, 7, dtype=torch.float64)
+    for l, sc in enumerate((1 / 4.0, 1 / 8.0, 1 / 16.0, 1 / 32.0)):
+        sel = np.where(level == l)[0]
+        if not len(sel):
+            continue
+        _, arg = ORP.roi_pooling(feats[l].detach().numpy().astype(np.float32), rois[sel], (7, 7), sc, return_argmax=True)
+        idx = torch.as_tensor(arg.astype(np.int64))
+        flat = feats[l][0].reshape(C, -1)
+        g = torch.gather(flat, 1, idx.clamp(min=0).permute(1, 0, 2, 3).reshape(C, -1)).reshape(C, len(sel), 7, 7).permute(1, 0, 2, 3)
+        pooled[torch.as_tensor(sel)] = g * (idx >= 0).double()
+    cls_score, bbox_pred, x2, f1, l_cls, l_box = _head_losses(pooled, rois, pd, labels_ohem, bbox_target, bbox_weight_ohem, nongt_dim,
+                                                              batch_rois_ohem, ('roi_pool_fc1', 'roi_pool_fc2'))
+    l_nms, multi = 0.0, None
+    if lnms is not None:
+        l_nms, multi = learn_nms_loss(cls_score[:nongt_dim], x2[:nongt_dim], pd, lnms['rank_idx'], lnms['class_boxes'],
+                                      lnms['target'], lnms['first_n'])
+    return l_cls + l_box + l_nms, dict(cls_score=cls_score.detach(), nms_multi=None if multi is None else multi.detach(),
+                                       feats=[f.detach() for f in feats], pooled=pooled.detach())
+
+
 def total_loss(data, p, rois, labels_ohem, bbox_target, bbox_weight_ohem, rpn_label, rpn_bbox_target, rpn_bbox_weight,
                nongt_dim, rpn_batch_size=256, batch_rois_ohem=128, lnms=None, dcn=False):
     """One image.  p: name -> torch float64 tensors (requires_grad on the trainable ones).  rois [R,5] numpy;
@@ -107,20 +163,8 @@ def total_loss(data, p, rois, labels_ohem, bbox_target, bbox_weight_ohem, rpn_la
         idx = torch.as_tensor(arg.astype(np.int64))
         g = torch.gather(flat, 1, idx.clamp(min=0).permute(1, 0, 2, 3).reshape(C, -1)).reshape(C, R, 7, 7).permute(1, 0, 2, 3)
         pooled = g * (idx >= 0).double()
-    # head
-    x = pooled.reshape(R, -1)
-    f1 = x @ pd['fc_new_1_weight'].t() + pd['fc_new_1_bias']
-    x1 = torch.relu(f1 + ORT.relation_module(f1, rois[:, 1:5], pd, 1, nongt_dim))
-    f2 = x1 @ pd['fc_new_2_weight'].t() + pd['fc_new_2_bias']
-    x2 = torch.relu(f2 + ORT.relation_module(f2, rois[:, 1:5], pd, 2, nongt_dim))
-    cls_score = x2 @ pd['cls_score_weight'].t() + pd['cls_score_bias']
-    bbox_pred = x2 @ pd['bbox_pred_weight'].t() + pd['bbox_pred_bias']
-    lo = torch.as_tensor(np.asarray(labels_ohem, np.int64))
-    v = lo >= 0
-    lp = torch.log_softmax(cls_score, dim=1)
-    l_cls = -(lp[torch.arange(R), lo.clamp(min=0)] * v.double()).sum() / max(int(v.sum()), 1)
-    l_box = (torch.as_tensor(np.asarray(bbox_weight_ohem), dtype=torch.float64)
-             * smooth_l1(bbox_pred - torch.as_tensor(np.asarray(bbox_target), dtype=torch.float64), 1.0)).sum() / batch_rois_ohem
+    cls_score, bbox_pred, x2, f1, l_cls, l_box = _head_losses(pooled, rois, pd, labels_ohem, bbox_target, bbox_weight_ohem, nongt_dim,
+                                                              batch_rois_ohem)
     l_nms = 0.0
     multi = None
     if lnms is not None:       # dict(rank_idx, class_boxes, target, first_n)

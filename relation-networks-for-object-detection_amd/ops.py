@@ -513,7 +513,8 @@ def fpn_roi_dispatch(rois, batch_index_base=0):
     return out, level, perm, counts
 
 
-def roi_pool_fpn(levels, scales, rois, roi_level, pooled=(7, 7), channels_last_out=False, batch_index_base=0):
+def roi_pool_fpn(levels, scales, rois, roi_level, pooled=(7, 7), channels_last_out=False, batch_index_base=0,
+                 want_argmax=False):
     """levels: list of logical [B,C,H_l,W_l] maps (any strides, same C / dtype); rois [R,5]; roi_level [R] int32
     -> [R,C,PH,PW] (memory (R,PH,PW,C) when channels_last_out): 4 x ROIPooling + Concat in one launch."""
     import ctypes
@@ -534,10 +535,28 @@ def roi_pool_fpn(levels, scales, rois, roi_level, pooled=(7, 7), channels_last_o
         out = torch.empty((R, PH, PW, Cc), device=rois.device, dtype=dt).permute(0, 3, 1, 2)
     else:
         out = torch.empty((R, Cc, PH, PW), device=rois.device, dtype=dt)
+    arg = torch.empty_strided(out.shape, out.stride(), device=rois.device, dtype=torch.int32) if want_argmax else None
     _lib.call('relnet_roi_pool_fpn_fwd', ctypes.addressof(ptrs), ctypes.addressof(strides), ctypes.addressof(hs),
               ctypes.addressof(ws), ctypes.addressof(sc), nl, rois.data_ptr(), roi_level.data_ptr(), out.data_ptr(),
-              _strides4(out), 0, R, Cc, PH, PW, batch_index_base, _dt(levels[0]), _stream())
-    return out
+              _strides4(out), _ptr(arg), R, Cc, PH, PW, batch_index_base, _dt(levels[0]), _stream())
+    return (out, arg) if want_argmax else out
+
+
+def roi_pool_fpn_bwd(grad_out, argmax, rois, roi_level, level_shapes, batch_index_base=0):
+    """Adjoint of roi_pool_fpn: level_shapes = [(B,C,H_l,W_l)] -> list of fp32 gradients [B,C,H_l,W_l] (NCHW)."""
+    import ctypes
+    _chk(grad_out, argmax, rois, roi_level)
+    assert argmax.dtype == torch.int32 and tuple(grad_out.stride()) == tuple(argmax.stride())
+    R, Cc, PH, PW = grad_out.shape
+    gins = [torch.zeros(tuple(sh), device=grad_out.device, dtype=torch.float32) for sh in level_shapes]
+    nl = len(gins)
+    ptrs = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in gins])
+    gb = (ctypes.c_long * nl)(*[int(t.stride(0)) for t in gins])
+    gc = (ctypes.c_long * nl)(*[int(t.stride(1)) for t in gins])
+    _lib.call('relnet_roi_pool_fpn_bwd', grad_out.data_ptr(), argmax.data_ptr(), _strides4(grad_out), rois.data_ptr(),
+              roi_level.data_ptr(), ctypes.addressof(ptrs), ctypes.addressof(gb), ctypes.addressof(gc), nl, R, Cc, PH, PW,
+              batch_index_base, _dt(grad_out), _stream())
+    return gins
 
 
 def upsample2x_add_(lateral, top):

@@ -77,7 +77,8 @@ class Trainer(object):
         c = self.cfg
         dev = device
         f32 = lambda t: torch.as_tensor(t).to(dev, torch.float32).contiguous()
-        self.units = unit_names()
+        self.fpn = bool(getattr(c, 'fpn', False))
+        self.units = unit_names(self.fpn)
         # ---- frozen part (conv1, res2): the inference kernels with folded BN
         self.frozen = {}
         w1, b1 = fold_bn(params['conv1_weight'], params['bn_conv1_gamma'], params['bn_conv1_beta'],
@@ -103,14 +104,23 @@ class Trainer(object):
         def conv_w(name):
             w = params[name + '_weight']
             return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
-        weights.append(('rpn_conv_3x3', conv_w('rpn_conv_3x3'))); biases.append(('rpn_conv_3x3', params['rpn_conv_3x3_bias']))
-        self.na2 = params['rpn_cls_score_weight'].shape[0]
-        weights.append(('rpn_out', torch.cat([conv_w('rpn_cls_score'), conv_w('rpn_bbox_pred')], 0)))
-        biases.append(('rpn_out', torch.cat([params['rpn_cls_score_bias'], params['rpn_bbox_pred_bias']], 0)))
-        weights.append(('conv_new_1', conv_w('conv_new_1'))); biases.append(('conv_new_1', params['conv_new_1_bias']))
+        if self.fpn:        # FPN neck (symbols/..._fpn_...:804-840); no RPN in these graphs (HAS_RPN: false)
+            for lvl in (32, 16, 8, 4):
+                for k_, ks in (('1x1', 1), ('3x3', 3)):
+                    n = 'fpn_ft%d_%s' % (lvl, k_)
+                    weights.append((n, conv_w(n))); biases.append((n, params[n + '_bias'])); self.ksize[n] = ks
+            fc1n, fc2n = 'roi_pool_fc1', 'roi_pool_fc2'
+        else:
+            weights.append(('rpn_conv_3x3', conv_w('rpn_conv_3x3'))); biases.append(('rpn_conv_3x3', params['rpn_conv_3x3_bias']))
+            self.na2 = params['rpn_cls_score_weight'].shape[0]
+            weights.append(('rpn_out', torch.cat([conv_w('rpn_cls_score'), conv_w('rpn_bbox_pred')], 0)))
+            biases.append(('rpn_out', torch.cat([params['rpn_cls_score_bias'], params['rpn_bbox_pred_bias']], 0)))
+            weights.append(('conv_new_1', conv_w('conv_new_1'))); biases.append(('conv_new_1', params['conv_new_1_bias']))
+            fc1n, fc2n = 'fc_new_1', 'fc_new_2'
+        self.fc_names = (fc1n, fc2n)
         self.fc1_perm = fc1_channels_last_perm()
-        weights.append(('fc_new_1', params['fc_new_1_weight'][:, self.fc1_perm])); biases.append(('fc_new_1', params['fc_new_1_bias']))
-        weights.append(('fc_new_2', params['fc_new_2_weight'])); biases.append(('fc_new_2', params['fc_new_2_bias']))
+        weights.append(('fc_new_1', params[fc1n + '_weight'][:, self.fc1_perm])); biases.append(('fc_new_1', params[fc1n + '_bias']))
+        weights.append(('fc_new_2', params[fc2n + '_weight'])); biases.append(('fc_new_2', params[fc2n + '_bias']))
         self.num_classes = params['cls_score_weight'].shape[0]
         weights.append(('cls_bbox', torch.cat([params['cls_score_weight'], params['bbox_pred_weight']], 0)))
         biases.append(('cls_bbox', torch.cat([params['cls_score_bias'], params['bbox_pred_bias']], 0)))
@@ -173,22 +183,20 @@ class Trainer(object):
         return ops.conv2d_nhwc(x, w, bias, ksize=self.ksize.get(name, 1), stride=stride, pad=pad, dil=dil, relu=relu,
                                resid=resid, out_dtype=out_dtype)
 
-    def forward_backward(self, data, im_info, gt_boxes, rpn_label, rpn_bbox_target, rpn_bbox_weight, num_gt=None):
-        """data [B,3,H,W] fp32; gt_boxes [B,G,5]; rpn_label [B, A*h*w] ((a,y,x) order), rpn_bbox_target / weight
-        [B, 4A, h, w] (lib/rpn/rpn.py:assign_anchor layouts).  Accumulates gradients into the flat buffers and
-        returns the loss values (reference metric names)."""
+    def _trunk_forward(self, data):
+        """Frozen stem + res2, then res3..res5 keeping every ReLU output.  Returns (conv5, conv4, saved units, stage ends)."""
         c = self.cfg
-        B = data.shape[0]
-        self.W.grad.zero_(); self.Bv.grad.zero_()
-        # -- frozen stem + res2
         x = ops.stem_conv7(data, self.w_stem, self.b_stem, relu=True)
         x = ops.stem_bias_relu_pool(x, self.zero_bias64)
         saved = []
         conv4 = None
+        ends = {}
         for stage, nm, ic, mc, oc, stride, dil, proj in self.units:
             n1, na, nb, nc = 'res%s_branch1' % nm, 'res%s_branch2a' % nm, 'res%s_branch2b' % nm, 'res%s_branch2c' % nm
             if stage == 5 and conv4 is None:
                 conv4 = x
+            if proj and stage > 2:
+                ends[stage - 1] = x
             if stage == 2:
                 fw = lambda n: self.frozen[n]
                 sc = self._conv(x, n1, stride=stride, w=fw(n1)) if proj else x
@@ -208,7 +216,17 @@ class Trainer(object):
             out = self._conv(y2, nc, relu=True, resid=sc)
             saved.append((stage, nm, stride, dil, proj, x, y1, y2, out, off))
             x = out
-        conv5 = x
+        ends[5] = x
+        return x, conv4, saved, ends
+
+    def forward_backward(self, data, im_info, gt_boxes, rpn_label, rpn_bbox_target, rpn_bbox_weight, num_gt=None):
+        """data [B,3,H,W] fp32; gt_boxes [B,G,5]; rpn_label [B, A*h*w] ((a,y,x) order), rpn_bbox_target / weight
+        [B, 4A, h, w] (lib/rpn/rpn.py:assign_anchor layouts).  Accumulates gradients into the flat buffers and
+        returns the loss values (reference metric names)."""
+        c = self.cfg
+        B = data.shape[0]
+        self.W.grad.zero_(); self.Bv.grad.zero_()
+        conv5, conv4, saved, _ = self._trunk_forward(data)
         feat = self._conv(conv5, 'conv_new_1', relu=True, bias=self.b('conv_new_1'))
         r = self._conv(conv4, 'rpn_conv_3x3', pad=1, relu=True, bias=self.b('rpn_conv_3x3'))
         rpn = self._conv(r, 'rpn_out', bias=self.b('rpn_out'), out_dtype=torch.float32)             # [B,h,w,72]
@@ -249,7 +267,89 @@ class Trainer(object):
         else:
             pooled, argmax = ops.roi_pool(nchw(feat), r5, (7, 7), 1.0 / c.feat_stride, channels_last_out=True, want_argmax=True)
         pooled2 = pooled.permute(0, 2, 3, 1).reshape(B * R, -1)
-        # -- 2FC head + relation modules (keys = the first N rows of each image)
+        d_pool, hs = self._head_forward_backward(pooled2, rois_t, N, label, bbox_target, bbox_weight, im_info, gt_boxes, num_gt, out)
+        bt = torch.bfloat16
+        x2, f1, cls_score, bbox_pred, labels_ohem, weights_ohem = hs
+        # ROIPooling backward -> gradient of conv_new_1_relu
+        if c.dcn:
+            gp = d_pool.view(B * R, 7, 7, -1).permute(0, 3, 1, 2)
+            gd1, gtrans = ops.deformable_psroi_pool_bwd(gp, nchw(feat), r5, trans, sc_, feat.shape[3], 1, 7, 7,
+                                                        c.dcn_sample_per_part, c.dcn_trans_std, False)
+            d_t0, dw, db = T.linear_bwd(t0f, self.w('offset'), gtrans.view(B * R, -1).to(bt))
+            self._add_wgrad('offset', dw); self._add_bgrad('offset', db)
+            gd2, _ = ops.deformable_psroi_pool_bwd(d_t0.view(B * R, 7, 7, -1).permute(0, 3, 1, 2), nchw(feat), r5, None, sc_,
+                                                   feat.shape[3], 1, 7, 7, c.dcn_sample_per_part, 0.0, True)
+            d_feat = (gd1 + gd2).permute(0, 2, 3, 1).to(bt).contiguous()       # logical NCHW stored NHWC -> NHWC bf16
+        else:
+            d_feat = ops.roi_pool_bwd(d_pool.view(B * R, 7, 7, -1).permute(0, 3, 1, 2), argmax, r5,
+                                      (B, feat.shape[3], feat.shape[1], feat.shape[2]))
+            d_feat = d_feat.permute(0, 2, 3, 1).to(bt).contiguous()
+        g = T.relu_bwd(d_feat, feat)
+        d_x, dw = T.conv1x1_bwd(conv5, self.w('conv_new_1'), g)
+        self._add_wgrad('conv_new_1', dw); self._add_bgrad('conv_new_1', g.float().sum((0, 1, 2)))
+        # RPN head backward (joins the trunk at conv4)
+        d_r, dw = T.conv1x1_bwd(r, self.w('rpn_out'), d_rpn)
+        self._add_wgrad('rpn_out', dw); self._add_bgrad('rpn_out', d_rpn.float().sum((0, 1, 2)))
+        g_r = T.relu_bwd(d_r, r)
+        d_conv4_rpn, dw = T.conv3x3_bwd(conv4, self._dgrad_w('rpn_conv_3x3', 512), g_r, dil=1)
+        self._add_wgrad('rpn_conv_3x3', dw); self._add_bgrad('rpn_conv_3x3', g_r.float().sum((0, 1, 2)))
+        self._trunk_backward(saved, d_x, {'4b22': d_conv4_rpn})
+        out['rois'] = rois_t
+        out['label'] = labels_ohem
+        out['debug'] = dict(feat=feat, conv5=conv5, pooled=pooled2, trans=trans if c.dcn else None, x2=x2, f1=f1)
+        out['bbox_target'], out['bbox_weight'] = bbox_target, weights_ohem
+        out['bbox_pred'] = bbox_pred
+        out['cls_score'] = cls_score
+        return out
+
+    def _trunk_backward(self, saved, d_x, inject):
+        """res5 -> res3 backward.  d_x = gradient of the last unit's output; inject[unit] = extra gradient of that unit's output."""
+        B = saved[0][5].shape[0]
+        bt = torch.bfloat16
+        # trunk: res5 -> res3
+        for stage, nm, stride, dil, proj, x_in, y1, y2, o, off in reversed(saved):
+            n1, na, nb, nc_ = 'res%s_branch1' % nm, 'res%s_branch2a' % nm, 'res%s_branch2b' % nm, 'res%s_branch2c' % nm
+            if inject.get(nm) is not None:       # a second consumer of this unit's output (RPN head at conv4, FPN laterals)
+                d_x = inject[nm] if d_x is None else d_x + inject[nm]
+            g_out = T.relu_bwd(d_x, o)
+            d_y2, dw = T.conv1x1_bwd(y2, self.w(nc_), g_out)
+            self._add_wgrad(nc_, dw, self.bn_scale[nc_])
+            g_y2 = T.relu_bwd(d_y2, y2)
+            if off is not None:            # deformable branch2b: data + offset gradients, then the offset conv's own backward
+                gd, goff, dw = ops.deformable_conv_bwd(y1.permute(0, 3, 1, 2), off.permute(0, 3, 1, 2), self.w(nb),
+                                                       g_y2.permute(0, 3, 1, 2), 3, 1, 2, 2, 4)
+                self._add_wgrad(nb, dw, self.bn_scale[nb])
+                no = nb + '_offset'
+                goff_p = torch.zeros((B, off.shape[1], off.shape[2], 128), device=off.device, dtype=bt)   # 72 -> 128 channels
+                goff_p[..., :72] = goff
+                wd_ = self.w(no).view(72, 3, 3, -1).flip(1, 2).permute(3, 1, 2, 0)                     # [Cin,3,3,72]
+                wdp = torch.zeros((wd_.shape[0], 3, 3, 128), device=off.device, dtype=bt); wdp[..., :72] = wd_
+                d_off_in, dwo = T.conv3x3_bwd(y1, wdp.reshape(wd_.shape[0], -1).contiguous(), goff_p, dil=2)
+                self._add_wgrad(no, dwo[:72]); self._add_bgrad(no, goff.sum((0, 1, 2)))
+                d_y1 = (gd + d_off_in.float()).to(bt).contiguous()
+            else:
+                d_y1, dw = T.conv3x3_bwd(y1, self._dgrad_w(nb, y2.shape[3]), g_y2, dil=dil)
+                self._add_wgrad(nb, dw, self.bn_scale[nb])
+            g_y1 = T.relu_bwd(d_y1, y1)
+            first = (stage == 3 and proj)         # res3a: its input comes from the frozen res2 -> no data gradient
+            if proj:
+                d_a, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, stride=stride, need_dx=not first)
+                self._add_wgrad(na, dw, self.bn_scale[na])
+                d_s, dw = T.conv1x1_bwd(x_in, self.w(n1), g_out, stride=stride, need_dx=not first,
+                                        dx_add=d_a if (stride == 1 and not first) else None)
+                self._add_wgrad(n1, dw, self.bn_scale[n1])
+                d_x = None if first else (d_s if stride == 1 else d_s + d_a)
+            else:
+                d_x, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, dx_add=g_out)       # identity shortcut
+                self._add_wgrad(na, dw, self.bn_scale[na])
+
+    def _head_forward_backward(self, pooled2, rois_t, N, label, bbox_target, bbox_weight, im_info, gt_boxes, num_gt, out):
+        """2FC head + relation modules + OHEM + losses (+ learn-NMS branch) and their adjoint down to the pooled features.
+        pooled2 [B*R, 12544] bf16 ((ph, pw, c) column order), rois_t [B,R,5] with the N non-gt rows first.
+        Returns (d_pool [B*R,12544] bf16, (x2, f1, cls_score, bbox_pred, labels_ohem, weights_ohem))."""
+        c = self.cfg
+        B, R = rois_t.shape[0], rois_t.shape[1]
+        # keys of both relation modules = the first N rows of each image
         bt = torch.bfloat16
         mods = [self._rel_params(i) for i in (1, 2)]
         wp_t, bp = pack_pair_pos(mods, self.device)
@@ -288,73 +388,7 @@ class Trainer(object):
         d_f1 = self._relation_bwd(1, mods[0], f1, x1, rois_t, d_x1.reshape(B, R, -1), N)
         d_pool, dw, db = T.linear_bwd(pooled2, self.w('fc_new_1'), d_f1.reshape(B * R, -1))
         self._add_wgrad('fc_new_1', dw); self._add_bgrad('fc_new_1', db)
-        # ROIPooling backward -> gradient of conv_new_1_relu
-        if c.dcn:
-            gp = d_pool.view(B * R, 7, 7, -1).permute(0, 3, 1, 2)
-            gd1, gtrans = ops.deformable_psroi_pool_bwd(gp, nchw(feat), r5, trans, sc_, feat.shape[3], 1, 7, 7,
-                                                        c.dcn_sample_per_part, c.dcn_trans_std, False)
-            d_t0, dw, db = T.linear_bwd(t0f, self.w('offset'), gtrans.view(B * R, -1).to(bt))
-            self._add_wgrad('offset', dw); self._add_bgrad('offset', db)
-            gd2, _ = ops.deformable_psroi_pool_bwd(d_t0.view(B * R, 7, 7, -1).permute(0, 3, 1, 2), nchw(feat), r5, None, sc_,
-                                                   feat.shape[3], 1, 7, 7, c.dcn_sample_per_part, 0.0, True)
-            d_feat = (gd1 + gd2).permute(0, 2, 3, 1).to(bt).contiguous()       # logical NCHW stored NHWC -> NHWC bf16
-        else:
-            d_feat = ops.roi_pool_bwd(d_pool.view(B * R, 7, 7, -1).permute(0, 3, 1, 2), argmax, r5,
-                                      (B, feat.shape[3], feat.shape[1], feat.shape[2]))
-            d_feat = d_feat.permute(0, 2, 3, 1).to(bt).contiguous()
-        g = T.relu_bwd(d_feat, feat)
-        d_x, dw = T.conv1x1_bwd(conv5, self.w('conv_new_1'), g)
-        self._add_wgrad('conv_new_1', dw); self._add_bgrad('conv_new_1', g.float().sum((0, 1, 2)))
-        # RPN head backward (joins the trunk at conv4)
-        d_r, dw = T.conv1x1_bwd(r, self.w('rpn_out'), d_rpn)
-        self._add_wgrad('rpn_out', dw); self._add_bgrad('rpn_out', d_rpn.float().sum((0, 1, 2)))
-        g_r = T.relu_bwd(d_r, r)
-        d_conv4_rpn, dw = T.conv3x3_bwd(conv4, self._dgrad_w('rpn_conv_3x3', 512), g_r, dil=1)
-        self._add_wgrad('rpn_conv_3x3', dw); self._add_bgrad('rpn_conv_3x3', g_r.float().sum((0, 1, 2)))
-        # trunk: res5 -> res3
-        for stage, nm, stride, dil, proj, x_in, y1, y2, o, off in reversed(saved):
-            n1, na, nb, nc_ = 'res%s_branch1' % nm, 'res%s_branch2a' % nm, 'res%s_branch2b' % nm, 'res%s_branch2c' % nm
-            if stage == 4 and d_conv4_rpn is not None and nm == '4b22':
-                d_x = d_x + d_conv4_rpn          # conv4 = output of res4b22 feeds both res5 and the RPN head
-                d_conv4_rpn = None
-            g_out = T.relu_bwd(d_x, o)
-            d_y2, dw = T.conv1x1_bwd(y2, self.w(nc_), g_out)
-            self._add_wgrad(nc_, dw, self.bn_scale[nc_])
-            g_y2 = T.relu_bwd(d_y2, y2)
-            if off is not None:            # deformable branch2b: data + offset gradients, then the offset conv's own backward
-                gd, goff, dw = ops.deformable_conv_bwd(y1.permute(0, 3, 1, 2), off.permute(0, 3, 1, 2), self.w(nb),
-                                                       g_y2.permute(0, 3, 1, 2), 3, 1, 2, 2, 4)
-                self._add_wgrad(nb, dw, self.bn_scale[nb])
-                no = nb + '_offset'
-                goff_p = torch.zeros((B, off.shape[1], off.shape[2], 128), device=off.device, dtype=bt)   # 72 -> 128 channels
-                goff_p[..., :72] = goff
-                wd_ = self.w(no).view(72, 3, 3, -1).flip(1, 2).permute(3, 1, 2, 0)                     # [Cin,3,3,72]
-                wdp = torch.zeros((wd_.shape[0], 3, 3, 128), device=off.device, dtype=bt); wdp[..., :72] = wd_
-                d_off_in, dwo = T.conv3x3_bwd(y1, wdp.reshape(wd_.shape[0], -1).contiguous(), goff_p, dil=2)
-                self._add_wgrad(no, dwo[:72]); self._add_bgrad(no, goff.sum((0, 1, 2)))
-                d_y1 = (gd + d_off_in.float()).to(bt).contiguous()
-            else:
-                d_y1, dw = T.conv3x3_bwd(y1, self._dgrad_w(nb, y2.shape[3]), g_y2, dil=dil)
-                self._add_wgrad(nb, dw, self.bn_scale[nb])
-            g_y1 = T.relu_bwd(d_y1, y1)
-            first = (stage == 3 and proj)         # res3a: its input comes from the frozen res2 -> no data gradient
-            if proj:
-                d_a, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, stride=stride, need_dx=not first)
-                self._add_wgrad(na, dw, self.bn_scale[na])
-                d_s, dw = T.conv1x1_bwd(x_in, self.w(n1), g_out, stride=stride, need_dx=not first,
-                                        dx_add=d_a if (stride == 1 and not first) else None)
-                self._add_wgrad(n1, dw, self.bn_scale[n1])
-                d_x = None if first else (d_s if stride == 1 else d_s + d_a)
-            else:
-                d_x, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, dx_add=g_out)       # identity shortcut
-                self._add_wgrad(na, dw, self.bn_scale[na])
-        out['rois'] = rois_t
-        out['label'] = labels_ohem
-        out['debug'] = dict(feat=feat, conv5=conv5, pooled=pooled2, trans=trans if c.dcn else None, x2=x2, f1=f1)
-        out['bbox_target'], out['bbox_weight'] = bbox_target, weights_ohem
-        out['bbox_pred'] = bbox_pred
-        out['cls_score'] = cls_score
-        return out
+        return d_pool, (x2, f1, cls_score, bbox_pred, labels_ohem, weights_ohem)
 
     def _lnms_forward_backward(self, cls_score, bbox_pred, rois, im_info, feat, gt_boxes, num_gt):
         """Train branch of the learn-NMS head (symbols/..._learn_nms.py:424-551) and its adjoint.
@@ -504,6 +538,89 @@ class Trainer(object):
         out = self.forward_backward(*batch, **kw)
         self.all_reduce()
         self.update()
+        return out
+
+
+class FPNTrainer(Trainer):
+    """Training step of the FPN relation graphs (BASELINE configs[4]; symbols/resnet_v1_101_rcnn_fpn_attention_1024_
+    pairwise_position_multi_head_16_learn_nms.py, get_symbol_rcnn train branch :1040-1200): proposals are an input
+    (HAS_RPN: false, TOP_ROIS 1000), their labels / targets come from proposal_target-style sampling with the gt rows
+    appended, rois are dispatched to the pyramid levels (core/rcnn.py:53-74) and pooled from fpn_ft4..ft32.
+
+    Row order: the reference keeps a level-major order over ALL rows and selects the relation keys with `nongt_index`
+    (:881-885, 931); here the non-gt rows are dispatched first and the gt rows after them, so the keys are the first N
+    rows -- the same set of keys, and every per-roi output is mapped back through `perm`."""
+
+    scales = (1 / 4.0, 1 / 8.0, 1 / 16.0, 1 / 32.0)
+
+    def __init__(self, params, cfg=None, device='cuda'):
+        cfg = cfg or TrainConfig()
+        cfg.fpn = True
+        Trainer.__init__(self, params, cfg, device, im_hw=None)
+
+    def forward_backward(self, data, im_info, gt_boxes, proposals, num_gt=None):
+        """data [B,3,H,W] (H, W multiples of 32), proposals [B,N,4] fp32, gt_boxes [B,G,5]."""
+        c = self.cfg
+        B, N = proposals.shape[:2]
+        bt = torch.bfloat16
+        if data.shape[2] % 32 or data.shape[3] % 32:
+            raise ValueError("FPN images must be padded to IMAGE_STRIDE 32, got %s" % (tuple(data.shape),))
+        self.W.grad.zero_(); self.Bv.grad.zero_()
+        out = {}
+        conv5, conv4, saved, ends = self._trunk_forward(data)
+        # ---- neck: 1x1 laterals (+bias), nearest 2x upsampling + sum, 3x3 output convs
+        src = {32: ends[5], 16: ends[4], 8: ends[3], 4: ends[2]}
+        tops = {32: self._conv(src[32], 'fpn_ft32_1x1', bias=self.b('fpn_ft32_1x1'))}
+        for lvl in (16, 8, 4):
+            tops[lvl] = ops.upsample2x_add_(self._conv(src[lvl], 'fpn_ft%d_1x1' % lvl, bias=self.b('fpn_ft%d_1x1' % lvl)), tops[lvl * 2])
+        feats = {lvl: self._conv(tops[lvl], 'fpn_ft%d_3x3' % lvl, pad=1, bias=self.b('fpn_ft%d_3x3' % lvl)) for lvl in (4, 8, 16, 32)}
+        # ---- rois: labels / targets, then level dispatch (non-gt rows first, gt rows after)
+        rois5 = torch.cat([torch.zeros((B, N, 1), device=proposals.device), proposals], 2)
+        rois5[:, :, 0] = torch.arange(B, device=proposals.device, dtype=torch.float32).view(B, 1)
+        rois_t, label, bbox_target, bbox_weight = ops.proposal_target(rois5.contiguous(), gt_boxes, num_gt)
+        R = rois_t.shape[1]
+        ra, la, pa, _ = ops.fpn_roi_dispatch(rois_t[:, :N].contiguous())
+        rb, lb, pb, _ = ops.fpn_roi_dispatch(rois_t[:, N:].contiguous())
+        rois_s = torch.cat([ra, rb], 1).contiguous()
+        level = torch.cat([la, lb], 1).contiguous()
+        perm = torch.cat([pa, pb + N], 1).long()
+        gat = lambda t: torch.gather(t, 1, perm.view(B, R, *([1] * (t.dim() - 2))).expand(B, R, *t.shape[2:]))
+        label, bbox_target, bbox_weight = gat(label), gat(bbox_target).contiguous(), gat(bbox_weight).contiguous()
+        nchw = lambda t: t.permute(0, 3, 1, 2)
+        lv = [nchw(feats[4]), nchw(feats[8]), nchw(feats[16]), nchw(feats[32])]
+        pooled, argmax = ops.roi_pool_fpn(lv, self.scales, rois_s.view(B * R, 5), level.view(-1), (7, 7), channels_last_out=True,
+                                          want_argmax=True)
+        pooled2 = pooled.permute(0, 2, 3, 1).reshape(B * R, -1)
+        d_pool, hs = self._head_forward_backward(pooled2, rois_s, N, label.contiguous(), bbox_target, bbox_weight, im_info,
+                                                 gt_boxes, num_gt, out)
+        x2, f1, cls_score, bbox_pred, labels_ohem, weights_ohem = hs
+        # ---- pooling backward into the four pyramid maps
+        g_lv = ops.roi_pool_fpn_bwd(d_pool.view(B * R, 7, 7, -1).permute(0, 3, 1, 2), argmax, rois_s.view(B * R, 5), level.view(-1),
+                                    [tuple(t.shape) for t in lv])
+        d_feats = {lvl: g.permute(0, 2, 3, 1).to(bt).contiguous() for lvl, g in zip((4, 8, 16, 32), g_lv)}
+        # ---- neck backward (top-down pathway reversed: finest level first, gradients flow up to the coarser tops)
+        d_tops, inject, d_c5 = {}, {}, None
+        for lvl in (4, 8, 16, 32):
+            n3, n1 = 'fpn_ft%d_3x3' % lvl, 'fpn_ft%d_1x1' % lvl
+            d_top, dw = T.conv3x3_bwd(tops[lvl], self._dgrad_w(n3, 256), d_feats[lvl], dil=1)
+            self._add_wgrad(n3, dw); self._add_bgrad(n3, d_feats[lvl].float().sum((0, 1, 2)))
+            if lvl in d_tops:                                    # + the gradient that came down from the finer level
+                d_top = (d_top.float() + d_tops[lvl]).to(bt)
+            if lvl < 32:       # tops[lvl] = lateral + up2x(tops[2 lvl]): adjoint of nearest upsampling = 2x2 block sums
+                Bh, Hh, Wh, Ch = d_top.shape
+                d_tops[lvl * 2] = d_top.float().view(Bh, Hh // 2, 2, Wh // 2, 2, Ch).sum((2, 4))
+            d_src, dw = T.conv1x1_bwd(src[lvl], self.w(n1), d_top.contiguous(), need_dx=(lvl != 4))   # res2c is frozen
+            self._add_wgrad(n1, dw); self._add_bgrad(n1, d_top.float().sum((0, 1, 2)))
+            if lvl == 32:
+                d_c5 = d_src
+            elif lvl == 16:
+                inject['4b22'] = d_src
+            elif lvl == 8:
+                inject['3b3'] = d_src
+        self._trunk_backward(saved, d_c5, inject)
+        out.update(rois=rois_s, perm=perm, roi_level=level, label=labels_ohem, bbox_target=bbox_target, bbox_weight=weights_ohem,
+                   bbox_pred=bbox_pred, cls_score=cls_score)
+        out['debug'] = dict(feats=feats, pooled=pooled2, x2=x2, f1=f1)
         return out
 
 

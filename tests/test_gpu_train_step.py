@@ -165,3 +165,91 @@ def test_training_steps_reduce_the_loss_and_update_only_trainable():
     assert torch.isfinite(tr.W.master).all() and not torch.equal(tr.W.master, w0)
     assert all(torch.equal(tr.frozen[k], frozen_before[k]) for k in frozen_before)
     assert torch.equal(tr.W.work, tr.W.master.to(torch.bfloat16))  # bf16 working copy refreshed by the optimizer kernel
+
+
+def test_fpn_training_step_gradients_match_autograd():
+    """BASELINE configs[4] graph: FPN neck, level-dispatched ROI pooling, relation head over the given proposals (+ gt rows),
+    learn-NMS head; every gradient vs float64 autograd of oracle/train_graph.py:total_loss_fpn."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import backbone, train
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_fpn import _proposals
+    H, W, N, G = 128, 160, 60, 4
+    p = backbone.init_params(seed=41, fpn=True)
+    g = torch.Generator().manual_seed(42)
+    for k in ('cls_score_weight', 'bbox_pred_weight'):
+        p[k] = torch.randn(p[k].shape, generator=g) * 0.05
+    for lvl in (4, 8, 16, 32):                         # pyramid features of ~0.1 instead of the N(0, 0.01) init's ~1e-3 (x5 puts the
+                                                       # relation softmax in a saturated, bf16-hypersensitive regime: 11 % forward error)
+        p['fpn_ft%d_1x1_weight' % lvl] = p['fpn_ft%d_1x1_weight' % lvl] * 2
+        p['fpn_ft%d_3x3_weight' % lvl] = p['fpn_ft%d_3x3_weight' % lvl] * 2
+        p['fpn_ft%d_3x3_bias' % lvl] = torch.rand(256, generator=g) * 0.1
+    p['nms_logit_bias'] = torch.zeros(5)
+    for k in ('nms_logit_weight', 'nms_rank_weight', 'roi_feat_embedding_weight', 'nms_query_1_weight', 'nms_key_1_weight',
+              'nms_linear_out_1_weight', 'nms_pair_pos_fc1_1_weight'):
+        p[k] = torch.randn(p[k].shape, generator=g) * 0.05
+    cfg = train.TrainConfig()
+    cfg.learn_nms, cfg.first_n = True, 24
+    data = torch.randn(1, 3, H, W, generator=g)
+    props = _proposals(N, 43, H, W)[None]
+    gt = np.zeros((1, G, 5), np.float32)
+    gt[0, :, :4] = props[0, [8, 17, 29, 44]]
+    gt[0, :, 4] = [3, 17, 17, 60]
+    tr = train.FPNTrainer(p, cfg)
+    d = lambda a: torch.as_tensor(a).cuda()
+    out = tr.forward_backward(data.cuda(), torch.tensor([[H, W, 1.0]]).cuda(), d(gt), d(props))
+    rois, level = out['rois'][0].cpu().numpy(), out['roi_level'][0].cpu().numpy()
+    assert rois.shape[0] == N + G and np.array_equal(np.sort(out['perm'][0].cpu().numpy()), np.arange(N + G))
+    assert (np.diff(level[:N]) >= 0).all() and int((out['label'] >= 1).sum()) > 0          # level-major non-gt rows; positives exist
+    pt = {k: v.double().clone().requires_grad_(not any(f in k for f in ('conv1', 'bn', 'res2'))) for k, v in p.items()}
+    lnms = dict(rank_idx=out['nms_rank_idx'][0].cpu().numpy(), class_boxes=out['nms_class_boxes'][0].cpu().numpy(),
+                target=out['nms_multi_target'][0].cpu().numpy(), first_n=cfg.first_n)
+    loss, parts = OT.total_loss_fpn(data.numpy(), pt, rois, level, out['label'][0].cpu().numpy(), out['bbox_target'][0].cpu().numpy(),
+                                    out['bbox_weight'][0].cpu().numpy(), N, lnms=lnms)
+    loss.backward()
+    e_cs = float((out['cls_score'][0].cpu().double() - parts['cls_score']).abs().max() / parts['cls_score'].abs().max())
+    print('fpn forward cls_score rel err %.4f' % e_cs)
+    for l_, nm_ in enumerate((4, 8, 16, 32)):
+        a_ = out['debug']['feats'][nm_][0].permute(2, 0, 1).double().cpu(); b_ = parts['feats'][l_][0]
+        print('  fpn_ft%d rel err %.4f' % (nm_, float((a_ - b_).norm() / b_.norm())))
+    po_ = parts['pooled'].permute(0, 2, 3, 1).reshape(rois.shape[0], -1)
+    print('  pooled rel err %.4f' % float((out['debug']['pooled'].double().cpu() - po_).norm() / po_.norm()))
+    assert e_cs <= 0.2, e_cs
+
+    def packed(name):
+        g_ = pt[name + '_weight'].grad
+        return g_.permute(0, 2, 3, 1).reshape(g_.shape[0], -1)
+
+    want, wb = {}, {}
+    for name in tr.W.slices:
+        if name.startswith('res'):
+            want[name] = packed(name) * tr.bn_scale[name].cpu().double().view(-1, 1)
+        elif name.startswith('fpn_'):
+            want[name] = packed(name); wb[name] = pt[name + '_bias'].grad
+    want['fc_new_1'] = pt['roi_pool_fc1_weight'].grad[:, tr.fc1_perm]; wb['fc_new_1'] = pt['roi_pool_fc1_bias'].grad
+    want['fc_new_2'] = pt['roi_pool_fc2_weight'].grad; wb['fc_new_2'] = pt['roi_pool_fc2_bias'].grad
+    want['cls_bbox'] = torch.cat([pt['cls_score_weight'].grad, pt['bbox_pred_weight'].grad], 0)
+    wb['cls_bbox'] = torch.cat([pt['cls_score_bias'].grad, pt['bbox_pred_bias'].grad])
+    for i in (1, 2):
+        want['qk_%d' % i] = torch.cat([pt['query_%d_weight' % i].grad, pt['key_%d_weight' % i].grad], 0)
+        want['linear_out_%d' % i] = pt['linear_out_%d_weight' % i].grad.reshape(1024, 1024)
+        want['pair_pos_fc1_%d' % i] = pt['pair_pos_fc1_%d_weight' % i].grad
+        wb['linear_out_%d' % i] = pt['linear_out_%d_bias' % i].grad
+        wb['pair_pos_fc1_%d' % i] = pt['pair_pos_fc1_%d_bias' % i].grad
+    for n in ('nms_rank', 'roi_feat_embedding', 'nms_pair_pos_fc1_1', 'nms_logit'):
+        want[n] = pt[n + '_weight'].grad; wb[n] = pt[n + '_bias'].grad
+    want['nms_qk_1'] = torch.cat([pt['nms_query_1_weight'].grad, pt['nms_key_1_weight'].grad], 0)
+    want['nms_linear_out_1'] = pt['nms_linear_out_1_weight'].grad.reshape(128, 128)
+    wb['nms_linear_out_1'] = pt['nms_linear_out_1_bias'].grad
+    assert set(want) == set(tr.W.slices)
+    report, bad = [], []
+    for name, w in list(want.items()) + [('bias:' + k, v) for k, v in wb.items()]:
+        got = (tr.Bv.view(tr.Bv.grad, name[5:]) if name.startswith('bias:') else tr.W.view(tr.W.grad, name)).cpu().double().reshape(w.shape)
+        nw, ng = float(w.norm()), float(got.norm())
+        cos = float((w * got).sum() / max(nw * ng, 1e-300))
+        report.append('%-22s |want| %.3e |got| %.3e cos %.4f' % (name, nw, ng, cos))
+        tight = not name.startswith('res') and 'pair_pos' not in name and 'fpn' not in name
+        cmin, nmax = (0.995, 0.03) if tight else (0.97, 0.08)      # trunk: four pyramid levels feed it (more bf16 paths than C4)
+        if nw > 1e-9 and (cos < cmin or abs(ng / nw - 1) > nmax):
+            bad.append(report[-1])
+    assert not bad, '\n'.join(bad) + '\n--- all ---\n' + '\n'.join(report)
