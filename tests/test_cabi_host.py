@@ -137,3 +137,47 @@ def test_operator_cxx_property_shapes():
     assert r.InferShape([(1, 256, 38, 63), (300, 5), (300, 2, 7, 7)])[1] == [(300, 256, 7, 7)] * 2
     with pytest.raises(ValueError):
         cxx.DeformablePSROIPoolingParam(spatial_scale=2.0, output_dim=1, group_size=1, pooled_size=7)
+
+
+def test_assign_anchor_host_port():
+    """train.assign_anchor (host-side RPN label preparation, lib/rpn/rpn.py:80-244): layouts, sampling limits and the
+    definition of positives / negatives; targets invert back to the matched gt box."""
+    import numpy as np
+    import relnet_amd  # noqa: F401
+    from relnet_amd import train
+    from relnet_amd.operator_py.proposal import generate_anchors
+    cfg = train.TrainConfig()
+    H, W, fh, fw = 600, 1000, 38, 63
+    rng = np.random.default_rng(0)
+    G = 6
+    bw, bh = rng.uniform(40, 400, G), rng.uniform(40, 400, G)
+    x1, y1 = rng.uniform(0, W - 1 - bw), rng.uniform(0, H - 1 - bh)
+    gt = np.stack([x1, y1, x1 + bw, y1 + bh, rng.integers(1, 81, G)], 1).astype(np.float32)
+    L, Tg, Wg = train.assign_anchor((fh, fw), gt, (H, W), cfg, seed=3)
+    A = 12
+    assert L.shape == (A * fh * fw,) and Tg.shape == (4 * A, fh, fw) and Wg.shape == (4 * A, fh, fw)
+    assert set(np.unique(L)) <= {-1.0, 0.0, 1.0}
+    nfg, nbg = int((L == 1).sum()), int((L == 0).sum())
+    assert 0 < nfg <= cfg.rpn_batch_size // 2 and nfg + nbg == cfg.rpn_batch_size
+    # weights mark exactly the positive anchors, all four coordinates
+    Lg = L.reshape(A, fh, fw)
+    assert np.array_equal(Wg.reshape(A, 4, fh, fw).sum(1) == 4, Lg == 1) and set(np.unique(Wg)) <= {0.0, 1.0}
+    # decode the targets of the positive anchors: they reproduce a gt box, and that box overlaps the anchor well
+    base = generate_anchors(cfg.feat_stride, cfg.anchor_ratios, cfg.anchor_scales)
+    a_idx, ys, xs = np.where(Lg == 1)
+    anc = base[a_idx] + np.stack([xs, ys, xs, ys], 1) * cfg.feat_stride
+    t = Tg.reshape(A, 4, fh, fw)[a_idx, :, ys, xs]
+    aw, ah = anc[:, 2] - anc[:, 0] + 1, anc[:, 3] - anc[:, 1] + 1
+    cx, cy = anc[:, 0] + 0.5 * (aw - 1) + t[:, 0] * aw, anc[:, 1] + 0.5 * (ah - 1) + t[:, 1] * ah
+    w, h = np.exp(t[:, 2]) * aw, np.exp(t[:, 3]) * ah
+    dec = np.stack([cx - 0.5 * (w - 1), cy - 0.5 * (h - 1), cx + 0.5 * (w - 1), cy + 0.5 * (h - 1)], 1)
+    err = np.abs(dec[:, None, :] - gt[None, :, :4]).max(2).min(1)
+    assert err.max() < 1e-2
+    # anchors crossing the image border are never labelled
+    sx, sy = np.meshgrid(np.arange(fw) * cfg.feat_stride, np.arange(fh) * cfg.feat_stride)          # [fh, fw]
+    ga = base[None, None] + np.stack([sx, sy, sx, sy], -1)[:, :, None, :]                               # [fh, fw, A, 4]
+    inside = (ga[..., 0] >= 0) & (ga[..., 1] >= 0) & (ga[..., 2] < W) & (ga[..., 3] < H)            # [fh, fw, A]
+    assert (Lg.transpose(1, 2, 0)[~inside] == -1).all()
+    # no gt: everything sampled is background
+    L0, _, W0 = train.assign_anchor((fh, fw), np.zeros((0, 5), np.float32), (H, W), cfg, seed=1)
+    assert (L0 == 1).sum() == 0 and (L0 == 0).sum() == cfg.rpn_batch_size and W0.sum() == 0
