@@ -129,9 +129,11 @@ __global__ __launch_bounds__(64) void class_nms_kernel(ClsNmsArgs g) {
       const double w = fmax(0.0, fmin(px2, x2[s]) - fmax(px1, x1[s]) + 1);
       const double h = fmax(0.0, fmin(py2, y2[s]) - fmax(py1, y1[s]) + 1);
       const double inter = w * h;
-      const double ovr = inter / (pa + area[s] - inter);
-      if (g.soft) sc[s] = sc[s] * exp(-(ovr * ovr) / g.nms_param);     // nms.py:92
-      else if (!(ovr <= g.nms_param)) sc[s] = -1.0;                     // nms.py:79
+      if (inter > 0.0) {     // disjoint boxes: ovr = 0 -> weight exp(0) = 1 / never suppressed; skipping them is exact
+        const double ovr = inter / (pa + area[s] - inter);
+        if (g.soft) sc[s] = sc[s] * exp(-(ovr * ovr) / g.nms_param);     // nms.py:92
+        else if (!(ovr <= g.nms_param)) sc[s] = -1.0;                     // nms.py:79
+      }
     }
   }
   if (lane == 0) g.counts[(long)b * (g.C - 1) + (cls - 1)] = picked;

@@ -358,13 +358,28 @@ __device__ __forceinline__ float position_feature_1(float4 bi, float4 bj, int co
   else v = hi / hj;
   return (float)log((double)v);
 }
+__device__ __forceinline__ void position_features(float4 bi, float4 bj, float (&p)[4]) {
+  // identical to relation.hip:position_features (bit-exact fp32 sequence of SYM_REL:59-77, correctly rounded logs)
+  const float wi = bi.z - bi.x + 1.f, hi = bi.w - bi.y + 1.f;
+  const float wj = bj.z - bj.x + 1.f, hj = bj.w - bj.y + 1.f;
+  const float cxi = 0.5f * (bi.x + bi.z), cyi = 0.5f * (bi.y + bi.w);
+  const float cxj = 0.5f * (bj.x + bj.z), cyj = 0.5f * (bj.y + bj.w);
+  const float dx = fmaxf(fabsf((cxi - cxj) / wi), 1e-3f);
+  const float dy = fmaxf(fabsf((cyi - cyj) / hi), 1e-3f);
+  p[0] = (float)log((double)dx);
+  p[1] = (float)log((double)dy);
+  p[2] = (float)log((double)(wi / wj));
+  p[3] = (float)log((double)(hi / hj));
+}
 __device__ __forceinline__ float embed_value(float p, int sc, float divisor) {
   const float arg = (100.0f * p) / divisor;
   return sc ? cosf(arg) : sinf(arg);
 }
 #pragma clang fp contract(fast)
 
-// one wavefront per (image, query i); MFMA k = pairs (two per instruction, one per half-wave)
+// one wavefront per (image, query i); MFMA k = pairs (two per instruction, one per half-wave).  The four fp64 logs of a
+// pair are computed ONCE (lane L of a 64-pair block owns pair j0 + L, like the forward kernel's one-thread-per-pair) and
+// handed to the lanes that need them with ds_bpermute; each lane then evaluates its two embedding columns.
 __global__ __launch_bounds__(256) void geometry_bias_bwd_kernel(GeomBwdArgs g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -374,7 +389,8 @@ __global__ __launch_bounds__(256) void geometry_bias_bwd_kernel(GeomBwdArgs g) {
   const float* pi = bx + (long)i * g.box_stride;
   const float4 bi = make_float4(pi[0], pi[1], pi[2], pi[3]);
   // this lane's two embedding columns: c = 32 blk + l31 -> component c >> 4, sin/cos (c >> 3) & 1, frequency c & 7
-  const int comp0 = l31 >> 4, comp1 = 2 + (l31 >> 4), sc = (l31 >> 3) & 1;
+  const bool hi_comp = (l31 >> 4) != 0;          // column block 0: component 0 or 1; block 1: component 2 or 3
+  const int sc = (l31 >> 3) & 1;
   const float div = g.divisors[l31 & 7];
   const int hh = l31 & 15;                       // head row supplied by this lane (rows >= 16 are zero)
   const float* Brow = g.bias + (((long)b * 16 + hh) * g.N + i) * g.Mpad;
@@ -384,22 +400,29 @@ __global__ __launch_bounds__(256) void geometry_bias_bwd_kernel(GeomBwdArgs g) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
   float bsum = 0.f;
-  for (int j0 = 0; j0 < g.M; j0 += 2) {
-    const int j = j0 + half;
-    const bool okj = j < g.M;
-    const int jc = okj ? j : g.M - 1;
-    const float* pj = bx + (long)jc * g.box_stride;
-    const float4 bj = make_float4(pj[0], pj[1], pj[2], pj[3]);
-    float dpre = 0.f;
-    if (okj && l31 < 16) {
-      const float lg = Brow[j];
-      dpre = lg > kLogFloor ? Lrow[j] * expf(-lg) : 0.f;          // dL / G, zero on the clamped branch
+  for (int j0 = 0; j0 < g.M; j0 += 64) {
+    // features of pair (i, j0 + lane)
+    const int jl = j0 + lane < g.M ? j0 + lane : g.M - 1;
+    const float* pj = bx + (long)jl * g.box_stride;
+    float pf[4];
+    position_features(bi, make_float4(pj[0], pj[1], pj[2], pj[3]), pf);
+    const int nstep = min(32, (g.M - j0 + 1) >> 1);
+    for (int t = 0; t < nstep; ++t) {
+      const int src = 2 * t + half;              // lane that owns this half-wave's pair
+      const int j = j0 + src;
+      const bool okj = j < g.M;
+      const float q0 = __shfl(pf[0], src), q1 = __shfl(pf[1], src), q2 = __shfl(pf[2], src), q3 = __shfl(pf[3], src);
+      float dpre = 0.f;
+      if (okj && l31 < 16) {
+        const float lg = Brow[j];
+        dpre = lg > kLogFloor ? Lrow[j] * expf(-lg) : 0.f;          // dL / G, zero on the clamped branch
+      }
+      bsum += dpre;
+      const float e0 = okj ? embed_value(hi_comp ? q1 : q0, sc, div) : 0.f;
+      const float e1 = okj ? embed_value(hi_comp ? q3 : q2, sc, div) : 0.f;
+      c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(dpre, e0, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dpre, e1, c1, 0, 0, 0);
     }
-    bsum += dpre;
-    const float e0 = okj ? embed_value(position_feature_1(bi, bj, comp0), sc, div) : 0.f;
-    const float e1 = okj ? embed_value(position_feature_1(bi, bj, comp1), sc, div) : 0.f;
-    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(dpre, e0, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dpre, e1, c1, 0, 0, 0);
   }
   // rows h = (r & 3) + 8 (r >> 2) + 4 half < 16  <=>  r < 8 ; col = l31
 #pragma unroll
