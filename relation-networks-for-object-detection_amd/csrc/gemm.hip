@@ -478,6 +478,9 @@ static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t
     else if (K <= 128) cfg = 4;
     else if (N % 256 != 0) cfg = 3;
     else cfg = 1;
+    // fp32 outputs (weight gradients, column gradients): the 256x256 epilogue needs a second fp32 staging tile and
+    // spills ~180 VGPRs; 256x128 holds everything in registers
+    if (cfg == 1 && out_dtype != RELNET_BF16) cfg = 2;
   }
   switch (cfg) {
     case 1: launch_cfg<256, 256, 2, 4, CONV>(g, batch, out_dtype, s); break;

@@ -20,12 +20,21 @@ struct RoiArgs {
   struct Level { const void* data; long ds_b, ds_c, ds_h, ds_w; int H, W; float scale; } lv[4];
 };
 
-// Select the feature map of roi r (rois are level-sorted, so a workgroup rarely mixes levels).
-__device__ __forceinline__ void roi_level(RoiArgs& g, int r) {
-  if (g.level) {
-    const RoiArgs::Level& L = g.lv[g.level[r] & 3];
-    g.data = L.data; g.ds_b = L.ds_b; g.ds_c = L.ds_c; g.ds_h = L.ds_h; g.ds_w = L.ds_w; g.H = L.H; g.W = L.W; g.scale = L.scale;
+// Feature map of roi r as plain scalars (rois are level-sorted and r is uniform per workgroup, so this is a uniform
+// kernarg read; the kernel-argument struct itself is never written -- doing so spills it to scratch, 6x slower).
+struct RoiMap { const void* data; long ds_b, ds_c, ds_h, ds_w; int H, W; float scale; };
+#define RELNET_SEL4(l, f) ((l) == 0 ? g.lv[0].f : (l) == 1 ? g.lv[1].f : (l) == 2 ? g.lv[2].f : g.lv[3].f)
+__device__ __forceinline__ RoiMap roi_map(const RoiArgs& g, int r) {
+  RoiMap m;
+  if (g.level) {         // constant indices only: a dynamic index into the kernarg array forces a scratch copy of the struct
+    const int l = g.level[r] & 3;
+    m.data = RELNET_SEL4(l, data); m.ds_b = RELNET_SEL4(l, ds_b); m.ds_c = RELNET_SEL4(l, ds_c);
+    m.ds_h = RELNET_SEL4(l, ds_h); m.ds_w = RELNET_SEL4(l, ds_w); m.H = RELNET_SEL4(l, H); m.W = RELNET_SEL4(l, W);
+    m.scale = RELNET_SEL4(l, scale);
+  } else {
+    m.data = g.data; m.ds_b = g.ds_b; m.ds_c = g.ds_c; m.ds_h = g.ds_h; m.ds_w = g.ds_w; m.H = g.H; m.W = g.W; m.scale = g.scale;
   }
+  return m;
 }
 
 template <typename T> __device__ __forceinline__ float ld(const T* p);
@@ -41,27 +50,27 @@ template <typename T>
 __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(RoiArgs g) {
   const int bin = blockIdx.x;
   const int pw = bin % g.PW, ph = (bin / g.PW) % g.PH, r = bin / (g.PW * g.PH);
-  roi_level(g, r);
+  const RoiMap m = roi_map(g, r);
   const float* roi = g.rois + (long)r * 5;
   const int b = (int)roi[0] - g.batch_index_base;
-  const int rs_w = (int)roundf(roi[1] * g.scale), rs_h = (int)roundf(roi[2] * g.scale);
-  const int re_w = (int)roundf(roi[3] * g.scale), re_h = (int)roundf(roi[4] * g.scale);
+  const int rs_w = (int)roundf(roi[1] * m.scale), rs_h = (int)roundf(roi[2] * m.scale);
+  const int re_w = (int)roundf(roi[3] * m.scale), re_h = (int)roundf(roi[4] * m.scale);
   const int rw = max(re_w - rs_w + 1, 1), rh = max(re_h - rs_h + 1, 1);   // malformed -> 1x1
   const float bin_h = (float)rh / (float)g.PH, bin_w = (float)rw / (float)g.PW;
   int hs = (int)floorf((float)ph * bin_h), he = (int)ceilf((float)(ph + 1) * bin_h);
   int ws = (int)floorf((float)pw * bin_w), we = (int)ceilf((float)(pw + 1) * bin_w);
-  hs = min(max(hs + rs_h, 0), g.H); he = min(max(he + rs_h, 0), g.H);
-  ws = min(max(ws + rs_w, 0), g.W); we = min(max(we + rs_w, 0), g.W);
+  hs = min(max(hs + rs_h, 0), m.H); he = min(max(he + rs_h, 0), m.H);
+  ws = min(max(ws + rs_w, 0), m.W); we = min(max(we + rs_w, 0), m.W);
   const bool empty = (he <= hs) || (we <= ws);
-  const T* base = (const T*)g.data + (long)b * g.ds_b;
+  const T* base = (const T*)m.data + (long)b * m.ds_b;
   for (int c = threadIdx.x; c < g.C; c += 256) {
     float best = empty ? 0.f : -FLT_MAX;
     int bi = -1;
-    const T* pc = base + (long)c * g.ds_c;
+    const T* pc = base + (long)c * m.ds_c;
     for (int y = hs; y < he; ++y)
       for (int x = ws; x < we; ++x) {
-        const float v = ld<T>(pc + (long)y * g.ds_h + (long)x * g.ds_w);
-        if (v > best) { best = v; bi = y * g.W + x; }
+        const float v = ld<T>(pc + (long)y * m.ds_h + (long)x * m.ds_w);
+        if (v > best) { best = v; bi = y * m.W + x; }
       }
     const long o = (long)r * g.os_r + (long)c * g.os_c + (long)ph * g.os_ph + (long)pw * g.os_pw;
     st<T>((T*)g.out + o, best);
@@ -78,32 +87,32 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_cl_kernel(RoiArgs g) {
   const int cg = threadIdx.x % groups;
   if (bin >= g.PH * g.PW) return;
   const int pw = bin % g.PW, ph = bin / g.PW;
-  roi_level(g, r);
+  const RoiMap m = roi_map(g, r);
   const float* roi = g.rois + (long)r * 5;
   const int b = (int)roi[0] - g.batch_index_base;
-  const int rs_w = (int)roundf(roi[1] * g.scale), rs_h = (int)roundf(roi[2] * g.scale);
-  const int re_w = (int)roundf(roi[3] * g.scale), re_h = (int)roundf(roi[4] * g.scale);
+  const int rs_w = (int)roundf(roi[1] * m.scale), rs_h = (int)roundf(roi[2] * m.scale);
+  const int re_w = (int)roundf(roi[3] * m.scale), re_h = (int)roundf(roi[4] * m.scale);
   const int rw = max(re_w - rs_w + 1, 1), rh = max(re_h - rs_h + 1, 1);
   const float bin_h = (float)rh / (float)g.PH, bin_w = (float)rw / (float)g.PW;
   int hs = (int)floorf((float)ph * bin_h), he = (int)ceilf((float)(ph + 1) * bin_h);
   int ws = (int)floorf((float)pw * bin_w), we = (int)ceilf((float)(pw + 1) * bin_w);
-  hs = min(max(hs + rs_h, 0), g.H); he = min(max(he + rs_h, 0), g.H);
-  ws = min(max(ws + rs_w, 0), g.W); we = min(max(we + rs_w, 0), g.W);
+  hs = min(max(hs + rs_h, 0), m.H); he = min(max(he + rs_h, 0), m.H);
+  ws = min(max(ws + rs_w, 0), m.W); we = min(max(we + rs_w, 0), m.W);
   const bool empty = (he <= hs) || (we <= ws);
   float best[8];
   int bi[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { best[e] = empty ? 0.f : -FLT_MAX; bi[e] = -1; }
-  const unsigned short* base = (const unsigned short*)g.data + (long)b * g.ds_b + cg * 8;
+  const unsigned short* base = (const unsigned short*)m.data + (long)b * m.ds_b + cg * 8;
   for (int y = hs; y < he; ++y)
     for (int x = ws; x < we; ++x) {
-      const uint4 v = *(const uint4*)(base + (long)y * g.ds_h + (long)x * g.ds_w);
+      const uint4 v = *(const uint4*)(base + (long)y * m.ds_h + (long)x * m.ds_w);
       const unsigned int w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float lo = bf2f(w4[e] & 0xffff), hi = bf2f(w4[e] >> 16);
-        if (lo > best[2 * e]) { best[2 * e] = lo; bi[2 * e] = y * g.W + x; }
-        if (hi > best[2 * e + 1]) { best[2 * e + 1] = hi; bi[2 * e + 1] = y * g.W + x; }
+        if (lo > best[2 * e]) { best[2 * e] = lo; bi[2 * e] = y * m.W + x; }
+        if (hi > best[2 * e + 1]) { best[2 * e + 1] = hi; bi[2 * e + 1] = y * m.W + x; }
       }
     }
   const long o = (long)r * g.os_r + (long)ph * g.os_ph + (long)pw * g.os_pw + cg * 8;
@@ -131,7 +140,10 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_kernel(RoiBwdArgs g) {
   const int pw = bin % g.PW, ph = (bin / g.PW) % g.PH, r = bin / (g.PW * g.PH);
   const int b = (int)g.rois[(long)r * 5] - g.batch_index_base;
   float* gin = g.grad_in; long ds_b = g.ds_b, ds_c = g.ds_c;
-  if (g.level) { const RoiBwdArgs::Level& L = g.lv[g.level[r] & 3]; gin = L.grad_in; ds_b = L.ds_b; ds_c = L.ds_c; }
+  if (g.level) {
+    const int l = g.level[r] & 3;
+    gin = RELNET_SEL4(l, grad_in); ds_b = RELNET_SEL4(l, ds_b); ds_c = RELNET_SEL4(l, ds_c);
+  }
   for (int c = threadIdx.x; c < g.C; c += 256) {
     const long o = (long)r * g.os_r + (long)c * g.os_c + (long)ph * g.os_ph + (long)pw * g.os_pw;
     const int a = g.argmax[o];
