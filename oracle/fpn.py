@@ -7,7 +7,9 @@
   * pool_levels       :1108-1121 (four ROIPooling calls at 1/4..1/32 + Concat(dim=0))
 
 rcnn.py is plain numpy: the level formula here IS the reference's expression on float32 boxes, except that
-log2 is evaluated correctly rounded (see oracle/relation.py:cr).  Convolution / UpSampling / ROIPooling are
+log2 is evaluated correctly rounded (see oracle/relation.py:cr).  roi_dispatch is PINNED: tests/golden/fpn.npz holds the
+output of the reference's own get_rcnn_testbatch on seeded float32 proposals (level boundaries, empty level with its
+dummy roi), tests/test_oracle_golden.py::test_fpn_roi_dispatch_matches_reference_loader compares.  Convolution / UpSampling / ROIPooling are
 MXNet built-ins: restated from v1.1.0 semantics, PARITY UNPINNED.
 """
 import numpy as np

@@ -151,3 +151,18 @@ def nms_target_case(first_n, num_fg, g, seed):
         bbox[:, c] = b[rng.permutation(first_n)]
     score = np.sort(rng.random((first_n, num_fg)).astype(F32), axis=0)[::-1].copy()
     return bbox, gt_box, score
+
+
+def fpn_proposals(n, seed, im_h=800, im_w=1024):
+    """n float32 proposals spanning all four pyramid levels; the first six sit exactly ON the level boundaries
+    (sqrt(w*h) = 112, 224, 448 with w = h and with w = 4h)."""
+    rng = np.random.default_rng(seed)
+    side = np.exp(rng.uniform(np.log(12), np.log(700), n))
+    ar = np.exp(rng.uniform(-0.7, 0.7, n))
+    w = np.minimum(side * ar, im_w - 2); h = np.minimum(side / ar, im_h - 2)
+    x1 = rng.uniform(0, im_w - 1 - w); y1 = rng.uniform(0, im_h - 1 - h)
+    b = np.stack([x1, y1, x1 + w, y1 + h], 1).astype(F32)
+    for i, s in enumerate((112, 224, 448)):
+        b[i] = [10, 20, 10 + s - 1, 20 + s - 1]
+        b[3 + i] = [5, 5, 5 + 2 * s - 1, 5 + s / 2 - 1]
+    return b

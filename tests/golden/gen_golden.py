@@ -15,6 +15,7 @@ What runs from the reference, unchanged, imported from where it lies:
                                         extract_position_matrix, extract_position_embedding,
                                         attention_module_multi_head
   relation_rcnn/operator_py/learn_nms.py  LearnNmsOperator.forward (+ its nd helpers)
+  relation_rcnn/core/rcnn.py              get_rcnn_testbatch (ROIDispatch: FPN level assignment + regrouping)
 
 Shims needed because the reference is Python-2 / numpy-1 / MXNet-1.1.0 code (none of
 them edits a reference file): `xrange`, `np.float`/`np.int` aliases, `cPickle`, stub
@@ -208,6 +209,31 @@ def gen_targets(out):
     np.savez_compressed(os.path.join(out, 'targets.npz'), **d)
 
 
+def gen_fpn(out):
+    """ROI -> pyramid-level dispatch of the FPN graphs, by running the reference's own loader code
+    (relation_rcnn/core/rcnn.py:get_rcnn_testbatch, cfg.network.ROIDispatch) on float32 proposals."""
+    rcnn = setup_reference.extra[2]
+    rcnn.get_image = lambda roidb, cfg: ([np.zeros((1, 3, 8, 8), F32) for _ in roidb], roidb)
+
+    class NS(object):
+        pass
+    cfg = NS(); cfg.network = NS(); cfg.TEST = NS()
+    cfg.network.ROIDispatch = True
+    cfg.TEST.LEARN_NMS = False
+    d = {}
+    cases_ = {'all_levels': cases.fpn_proposals(400, 51), 'empty_level0': None}
+    b = cases.fpn_proposals(300, 52)
+    small = (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1) < 112.0 ** 2
+    b[small] = [100, 100, 400, 400]
+    cases_['empty_level0'] = b
+    for name, boxes in cases_.items():
+        data, _, _ = rcnn.get_rcnn_testbatch([{'boxes': boxes, 'im_info': [800, 1024, 1.0]}], cfg)
+        for l in range(4):
+            d['%s/rois_%d' % (name, l)] = np.asarray(data[0]['rois_%d' % l])
+        d['%s/boxes' % name] = boxes
+    np.savez_compressed(os.path.join(out, 'fpn.npz'), **d)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -219,6 +245,7 @@ def main():
     gen_relation(rel, a.out)
     gen_learn_nms(lnms, a.out)
     gen_targets(a.out)
+    gen_fpn(a.out)
     for f in sorted(os.listdir(a.out)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(a.out, f)), 'bytes')

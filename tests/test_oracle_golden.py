@@ -150,3 +150,23 @@ def test_torch_relation_matches_numpy_oracle():
         pt = {k: torch.as_tensor(v.astype(np.float64)) for k, v in p.items()}
         got = ORT.relation_module(torch.as_tensor(feat.astype(np.float64)), boxes, pt, 1, m).numpy()
         assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+
+
+def test_fpn_roi_dispatch_matches_reference_loader(golden):
+    """oracle/fpn.py:roi_dispatch vs the reference's own loader code (core/rcnn.py:get_rcnn_testbatch with
+    ROIDispatch), including boxes exactly on the level boundaries and the all-zero dummy roi of an empty level."""
+    from oracle import fpn as OF
+    g = golden['fpn']
+    for name in ('all_levels', 'empty_level0'):
+        boxes = g[name + '/boxes']
+        assert np.array_equal(boxes, cases.fpn_proposals(400, 51) if name == 'all_levels' else boxes)
+        rois, level, perm, counts = OF.roi_dispatch(boxes, dummy_for_empty=True)
+        off = 0
+        for l in range(4):
+            want = g['%s/rois_%d' % (name, l)]
+            got = rois[off:off + len(want)]
+            assert np.array_equal(got.astype(np.float64), want), (name, l)
+            assert (level[off:off + len(want)] == l).all()
+            off += len(want)
+        assert off == len(rois)
+    assert OF.roi_dispatch(g['empty_level0/boxes'])[3][0] == 0           # level 0 really is empty there
