@@ -166,3 +166,11 @@ def fpn_proposals(n, seed, im_h=800, im_w=1024):
         b[i] = [10, 20, 10 + s - 1, 20 + s - 1]
         b[3 + i] = [5, 5, 5 + 2 * s - 1, 5 + s / 2 - 1]
     return b
+
+
+def rpn_gt_boxes(g, seed, im_h=IM_H, im_w=IM_W):
+    """g gt boxes [g,5] (x1,y1,x2,y2,cls) float32 with sides in [40, 400]."""
+    rng = np.random.default_rng(seed)
+    bw, bh = rng.uniform(40, 400, g), rng.uniform(40, 400, g)
+    x1, y1 = rng.uniform(0, im_w - 1 - bw), rng.uniform(0, im_h - 1 - bh)
+    return np.stack([x1, y1, x1 + bw, y1 + bh, rng.integers(1, 81, g)], 1).astype(F32)

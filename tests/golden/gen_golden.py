@@ -16,6 +16,7 @@ What runs from the reference, unchanged, imported from where it lies:
                                         attention_module_multi_head
   relation_rcnn/operator_py/learn_nms.py  LearnNmsOperator.forward (+ its nd helpers)
   relation_rcnn/core/rcnn.py              get_rcnn_testbatch (ROIDispatch: FPN level assignment + regrouping)
+  lib/rpn/rpn.py                          assign_anchor (print statements rewritten in memory by lib2to3's fix_print)
 
 Shims needed because the reference is Python-2 / numpy-1 / MXNet-1.1.0 code (none of
 them edits a reference file): `xrange`, `np.float`/`np.int` aliases, `cPickle`, stub
@@ -209,6 +210,45 @@ def gen_targets(out):
     np.savez_compressed(os.path.join(out, 'targets.npz'), **d)
 
 
+def _load_py2(name, path):
+    """Import a Python-2 reference file whose only Python-3 problem is the `print` statement: the source is read from
+    where it lies and passed through lib2to3's fix_print IN MEMORY (a mechanical statement -> function rewrite)."""
+    from lib2to3.refactor import RefactoringTool
+    src = open(path).read()
+    src3 = str(RefactoringTool(['lib2to3.fixes.fix_print']).refactor_string(src if src.endswith('\n') else src + '\n', path))
+    mod = types.ModuleType(name)
+    mod.__file__ = path
+    sys.modules[name] = mod
+    exec(compile(src3, path, 'exec'), mod.__dict__)
+    return mod
+
+
+def gen_rpn_targets(ref, out):
+    """RPN anchor labels / regression targets by the reference's own loader code (lib/rpn/rpn.py:assign_anchor),
+    with numpy's global generator seeded (the function subsamples fg / bg with numpy.random.choice)."""
+    sys.modules['generate_anchor'] = sys.modules['ref_generate_anchor']
+    rpn = _load_py2('ref_rpn', os.path.join(ref, 'lib/rpn/rpn.py'))
+
+    class NS(object):
+        pass
+    cfg = NS(); cfg.TRAIN = NS()
+    cfg.TRAIN.RPN_CLOBBER_POSITIVES = False
+    cfg.TRAIN.RPN_NEGATIVE_OVERLAP, cfg.TRAIN.RPN_POSITIVE_OVERLAP = 0.3, 0.7
+    cfg.TRAIN.RPN_FG_FRACTION, cfg.TRAIN.RPN_BATCH_SIZE = 0.5, 256
+    cfg.TRAIN.RPN_BBOX_WEIGHTS = (1.0, 1.0, 1.0, 1.0)
+    d = {}
+    for name, (seed, G) in {'six_gt': (3, 6), 'crowded': (4, 40)}.items():
+        gt = cases.rpn_gt_boxes(G, seed)
+        np.random.seed(seed)
+        lab = rpn.assign_anchor((1, 48, 38, 63), gt, np.array([[600, 1000, 1.0]], F32), cfg, feat_stride=16,
+                                scales=(4, 8, 16, 32), ratios=(0.5, 1, 2), allowed_border=0)
+        d[name + '/gt'] = gt
+        d[name + '/label'] = lab['label']
+        d[name + '/bbox_target'] = lab['bbox_target']
+        d[name + '/bbox_weight'] = lab['bbox_weight']
+    np.savez_compressed(os.path.join(out, 'rpn_targets.npz'), **d)
+
+
 def gen_fpn(out):
     """ROI -> pyramid-level dispatch of the FPN graphs, by running the reference's own loader code
     (relation_rcnn/core/rcnn.py:get_rcnn_testbatch, cfg.network.ROIDispatch) on float32 proposals."""
@@ -246,6 +286,7 @@ def main():
     gen_learn_nms(lnms, a.out)
     gen_targets(a.out)
     gen_fpn(a.out)
+    gen_rpn_targets(a.ref, a.out)
     for f in sorted(os.listdir(a.out)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(a.out, f)), 'bytes')

@@ -181,3 +181,18 @@ def test_assign_anchor_host_port():
     # no gt: everything sampled is background
     L0, _, W0 = train.assign_anchor((fh, fw), np.zeros((0, 5), np.float32), (H, W), cfg, seed=1)
     assert (L0 == 1).sum() == 0 and (L0 == 0).sum() == cfg.rpn_batch_size and W0.sum() == 0
+
+
+def test_assign_anchor_matches_reference_loader():
+    """train.assign_anchor vs tests/golden/rpn_targets.npz = the output of the reference's own lib/rpn/rpn.py:assign_anchor
+    (gen_golden.py), same numpy seed: identical labels (incl. the random fg / bg subsampling) and weights, targets to 2e-6."""
+    import numpy as np
+    import relnet_amd  # noqa: F401
+    from relnet_amd import train
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'rpn_targets.npz'))
+    cfg = train.TrainConfig()
+    for name, seed in (('six_gt', 3), ('crowded', 4)):
+        L, T, W = train.assign_anchor((38, 63), g[name + '/gt'], (600, 1000), cfg, seed=seed)
+        assert np.array_equal(L, g[name + '/label'][0]) and np.array_equal(W, g[name + '/bbox_weight'][0])
+        assert np.abs(T - g[name + '/bbox_target'][0]).max() <= 2e-6
+    assert int((g['crowded/label'] == 1).sum()) == 128          # the fg subsampling branch is exercised
