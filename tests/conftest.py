@@ -33,4 +33,4 @@ def pytest_collection_modifyitems(config, items):
 def golden():
     d = os.path.join(ROOT, 'tests', 'golden')
     return {name: np.load(os.path.join(d, name + '.npz'))
-            for name in ('boxes', 'nms', 'relation', 'learn_nms', 'targets', 'fpn')}
+            for name in ('boxes', 'nms', 'relation', 'learn_nms', 'targets', 'fpn', 'proposal')}

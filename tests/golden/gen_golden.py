@@ -17,6 +17,7 @@ What runs from the reference, unchanged, imported from where it lies:
   relation_rcnn/operator_py/learn_nms.py  LearnNmsOperator.forward (+ its nd helpers)
   relation_rcnn/core/rcnn.py              get_rcnn_testbatch (ROIDispatch: FPN level assignment + regrouping)
   lib/rpn/rpn.py                          assign_anchor (print statements rewritten in memory by lib2to3's fix_print)
+  relation_rcnn/operator_py/proposal.py   ProposalOperator.forward (same print rewrite; gpu_nms -> the reference's py_nms)
 
 Shims needed because the reference is Python-2 / numpy-1 / MXNet-1.1.0 code (none of
 them edits a reference file): `xrange`, `np.float`/`np.int` aliases, `cPickle`, stub
@@ -249,6 +250,30 @@ def gen_rpn_targets(ref, out):
     np.savez_compressed(os.path.join(out, 'rpn_targets.npz'), **d)
 
 
+def gen_proposal(ref, out):
+    """The whole proposal operator by the reference's own operator_py/proposal.py:ProposalOperator.forward under the numpy
+    MXNet stand-in.  Its hard-coded gpu_nms_wrapper (a compiled CUDA extension) is replaced by the reference's own numpy
+    NMS, lib/nms/nms.py:py_nms_wrapper -- identical to nms_kernel.cu except at IoU == thresh exactly (`<=` vs `>`)."""
+    import mxnet as mx
+    ga, nm = sys.modules['ref_generate_anchor'], sys.modules['ref_nms']
+    pk = types.ModuleType('rpn'); pk.__path__ = []; sys.modules['rpn'] = pk
+    sys.modules['rpn.generate_anchor'] = ga
+    pk2 = types.ModuleType('nms'); pk2.__path__ = []; sys.modules['nms'] = pk2
+    sys.modules['nms.nms'] = nm
+    prop = _load_py2('ref_proposal', os.path.join(ref, 'relation_rcnn/operator_py/proposal.py'))
+    prop.gpu_nms_wrapper = lambda thresh, device_id: nm.py_nms_wrapper(thresh)
+    d = {}
+    for name, (seed, pre, post) in {'full': (61, 6000, 300), 'small': (62, 600, 50)}.items():
+        cls_prob, deltas, im_info = cases.rpn_case(seed)
+        op = prop.ProposalOperator(16, '(4, 8, 16, 32)', '(0.5, 1, 2)', True, pre, post, 0.7, 0)
+        outs = [mx.nd.zeros((post, 5)), mx.nd.zeros((post, 1))]
+        np.random.seed(seed)
+        op.forward(False, ['write', 'write'], [mx.NDArray(cls_prob), mx.NDArray(deltas), mx.NDArray(im_info)], outs, [])
+        d[name + '/rois'] = outs[0].asnumpy()
+        d[name + '/score'] = outs[1].asnumpy()
+    np.savez_compressed(os.path.join(out, 'proposal.npz'), **d)
+
+
 def gen_fpn(out):
     """ROI -> pyramid-level dispatch of the FPN graphs, by running the reference's own loader code
     (relation_rcnn/core/rcnn.py:get_rcnn_testbatch, cfg.network.ROIDispatch) on float32 proposals."""
@@ -287,6 +312,7 @@ def main():
     gen_targets(a.out)
     gen_fpn(a.out)
     gen_rpn_targets(a.ref, a.out)
+    gen_proposal(a.ref, a.out)
     for f in sorted(os.listdir(a.out)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(a.out, f)), 'bytes')

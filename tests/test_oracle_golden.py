@@ -170,3 +170,18 @@ def test_fpn_roi_dispatch_matches_reference_loader(golden):
             off += len(want)
         assert off == len(rois)
     assert OF.roi_dispatch(g['empty_level0/boxes'])[3][0] == 0           # level 0 really is empty there
+
+
+def test_proposal_operator_matches_reference_operator(golden):
+    """oracle/proposal.py vs the reference's own ProposalOperator.forward (operator_py/proposal.py:51-168) run under the numpy
+    MXNet stand-in: the same 300 / 50 proposals in the same order (scores bit-identical); boxes within 1 ulp -- numpy's
+    float32 exp in the reference's bbox_pred is not correctly rounded, the oracle's is (oracle/boxes.py)."""
+    from oracle import proposal as OP
+    g = golden['proposal']
+    for name, (seed, pre, post) in {'full': (61, 6000, 300), 'small': (62, 600, 50)}.items():
+        cls_prob, deltas, im_info = cases.rpn_case(seed)
+        rois, scores = OP.proposal(cls_prob, deltas, im_info, 16, (4, 8, 16, 32), (0.5, 1, 2), pre, post, 0.7, 0)
+        want = g[name + '/rois']
+        assert np.array_equal(scores.reshape(-1), g[name + '/score'].reshape(-1))
+        assert rois.shape == want.shape and np.all(np.abs(rois - want) <= np.spacing(np.abs(want).astype(np.float32)))
+        assert np.array_equal(rois[:, 0], want[:, 0])
