@@ -174,7 +174,7 @@ def test_fpn_roi_dispatch_matches_reference_loader(golden):
 
 def test_proposal_operator_matches_reference_operator(golden):
     """oracle/proposal.py vs the reference's own ProposalOperator.forward (operator_py/proposal.py:51-168) run under the numpy
-    MXNet stand-in: the same 300 / 50 proposals in the same order (scores bit-identical); boxes within 2 ulps -- numpy's
+    MXNet stand-in: the same 300 / 50 proposals in the same order (scores bit-identical); boxes within 2 ulps of the box size -- numpy's
     float32 exp in the reference's bbox_pred is not correctly rounded, the oracle's is (oracle/boxes.py)."""
     from oracle import proposal as OP
     g = golden['proposal']
@@ -183,6 +183,6 @@ def test_proposal_operator_matches_reference_operator(golden):
         rois, scores = OP.proposal(cls_prob, deltas, im_info, 16, (4, 8, 16, 32), (0.5, 1, 2), pre, post, 0.7, 0)
         want = g[name + '/rois']
         assert np.array_equal(scores.reshape(-1), g[name + '/score'].reshape(-1))
-        # (a 1-ulp exp error in the width / height propagates to at most 2 ulps of a corner coordinate)
-        assert rois.shape == want.shape and np.all(np.abs(rois - want) <= 2 * np.spacing(np.abs(want).astype(np.float32)))
+        # a 1-ulp exp error in the predicted width / height (up to ~1000 px) moves a corner by up to 2 ulps OF THAT SIZE
+        assert rois.shape == want.shape and np.abs(rois - want).max() <= 2 * np.spacing(np.float32(1000.0))
         assert np.array_equal(rois[:, 0], want[:, 0])
