@@ -21,9 +21,10 @@ What runs from the reference, unchanged, imported from where it lies:
 
 Shims needed because the reference is Python-2 / numpy-1 / MXNet-1.1.0 code (none of
 them edits a reference file): `xrange`, `np.float`/`np.int` aliases, `cPickle`, stub
-modules for the compiled Cython/CUDA extensions (`bbox`, `cpu_nms`, `gpu_nms`) and for
-the three operator_py files with Python-2 print statements, and the numpy MXNet
-stand-in in tests/golden/refshim (its docstring says what that does and does not pin).
+modules for the compiled Cython/CUDA extensions (`bbox`, `cpu_nms`, `gpu_nms`), an in-memory
+lib2to3 `fix_print` pass for the files whose only Python-3 problem is the print statement
+(`_load_py2`), and the numpy MXNet stand-in in tests/golden/refshim (its docstring says what
+that does and does not pin).  No oracle/ code is used to produce any golden value.
 """
 import argparse
 import builtins
@@ -48,6 +49,19 @@ def _load(name, path):
     mod = importlib.util.module_from_spec(spec)
     sys.modules[name] = mod
     spec.loader.exec_module(mod)
+    return mod
+
+
+def _load_py2(name, path):
+    """Import a Python-2 reference file whose only Python-3 problem is the `print` statement: the source is read from
+    where it lies and passed through lib2to3's fix_print IN MEMORY (a mechanical statement -> function rewrite)."""
+    from lib2to3.refactor import RefactoringTool
+    src = open(path).read()
+    src3 = str(RefactoringTool(['lib2to3.fixes.fix_print']).refactor_string(src if src.endswith('\n') else src + '\n', path))
+    mod = types.ModuleType(name)
+    mod.__file__ = path
+    sys.modules[name] = mod
+    exec(compile(src3, path, 'exec'), mod.__dict__)
     return mod
 
 
@@ -93,9 +107,9 @@ def setup_reference(ref):
     pk.__path__ = []
     pk.bbox_overlaps_cython = _no_ext
     sys.modules['bbox.bbox_transform'] = bt
-    import oracle.targets as OT                     # bbox_regression.py has Python-2 prints: restated
-    stub('bbox.bbox_regression', expand_bbox_regression_targets=lambda d, n, cfg: OT.expand_bbox_regression_targets(
-        d, n, cfg.CLASS_AGNOSTIC, cfg.TRAIN.BBOX_WEIGHTS))
+    # lib/bbox/bbox_regression.py has Python-2 print statements: loaded through the in-memory fix_print rewrite
+    sys.modules['bbox_transform'] = bt
+    sys.modules['bbox.bbox_regression'] = _load_py2('ref_bbox_regression', os.path.join(ref, 'lib/bbox/bbox_regression.py'))
     stub('utils.image', get_image=_no_ext, tensor_vstack=_no_ext)
     ohem = _load('ref_ohem', os.path.join(ref, 'relation_rcnn/operator_py/box_annotator_ohem.py'))
     nmt = _load('ref_nms_multi_target', os.path.join(ref, 'relation_rcnn/operator_py/nms_multi_target.py'))
@@ -209,19 +223,6 @@ def gen_targets(out):
     op.forward(True, ['write'], [mx.NDArray(bbox), mx.NDArray(gt_box), mx.NDArray(score)], outs, [])
     d['nmt/target'] = outs[0].asnumpy()
     np.savez_compressed(os.path.join(out, 'targets.npz'), **d)
-
-
-def _load_py2(name, path):
-    """Import a Python-2 reference file whose only Python-3 problem is the `print` statement: the source is read from
-    where it lies and passed through lib2to3's fix_print IN MEMORY (a mechanical statement -> function rewrite)."""
-    from lib2to3.refactor import RefactoringTool
-    src = open(path).read()
-    src3 = str(RefactoringTool(['lib2to3.fixes.fix_print']).refactor_string(src if src.endswith('\n') else src + '\n', path))
-    mod = types.ModuleType(name)
-    mod.__file__ = path
-    sys.modules[name] = mod
-    exec(compile(src3, path, 'exec'), mod.__dict__)
-    return mod
 
 
 def gen_rpn_targets(ref, out):
