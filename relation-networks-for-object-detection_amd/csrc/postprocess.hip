@@ -138,6 +138,97 @@ __global__ __launch_bounds__(64) void class_nms_kernel(ClsNmsArgs g) {
   }
   if (lane == 0) g.counts[(long)b * (g.C - 1) + (cls - 1)] = picked;
 }
+
+// N up to 1024 candidates (FPN graphs, TOP_ROIS 1000): four wavefronts share one (image, class), 4 candidates per
+// thread.  Same arithmetic and tie rule as the single-wave kernel above; the per-pick arg-max crosses the waves
+// through LDS.  (16 candidates per lane in ONE wave needs 6 x 16 doubles per lane and spills thousands of VGPRs.)
+template <int kPerThread>
+__global__ __launch_bounds__(256) void class_nms_block_kernel(ClsNmsArgs g) {
+  constexpr int NT = 256;
+  __shared__ double s_best[4];
+  __shared__ int s_bi[4];
+  __shared__ double s_box[5];
+  __shared__ int s_n;
+  const int cls = blockIdx.x + 1, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* prob = g.cls_prob + (long)b * g.N * g.C;
+  const double* bx = g.boxes + (long)b * g.N * 4;
+  double x1[kPerThread], y1[kPerThread], x2[kPerThread], y2[kPerThread], area[kPerThread], sc[kPerThread];
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  int n = 0;
+#pragma unroll
+  for (int s = 0; s < kPerThread; ++s) {
+    const int i = s * NT + tid;
+    sc[s] = -1.0;
+    x1[s] = y1[s] = x2[s] = y2[s] = area[s] = 0.0;
+    if (i < g.N) {
+      const float p = prob[(long)i * g.C + cls];
+      if (p > g.score_thresh) {
+        sc[s] = (double)p;
+        x1[s] = bx[i * 4 + 0]; y1[s] = bx[i * 4 + 1]; x2[s] = bx[i * 4 + 2]; y2[s] = bx[i * 4 + 3];
+        area[s] = (x2[s] - x1[s] + 1) * (y2[s] - y1[s] + 1);
+        ++n;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+  if (lane == 0) atomicAdd(&s_n, n);
+  __syncthreads();
+  n = s_n;
+  double* out = g.dets + (((long)b * (g.C - 1) + (cls - 1)) * g.N) * 5;
+  int picked = 0;
+  const int n_it = n < g.max_picks ? n : g.max_picks;
+  for (int it = 0; it < n_it; ++it) {
+    double best = -1.0; int bi = -1;
+#pragma unroll
+    for (int s = 0; s < kPerThread; ++s)
+      if (sc[s] > best || (sc[s] == best && sc[s] >= 0.0)) { best = sc[s]; bi = s * NT + tid; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ob = __shfl_xor(best, o);
+      const int oi = __shfl_xor(bi, o);
+      if (ob > best || (ob == best && oi > bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { s_best[wave] = best; s_bi[wave] = bi; }
+    __syncthreads();
+    best = s_best[0]; bi = s_bi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const double ob = s_best[w]; const int oi = s_bi[w];
+      if (ob > best || (ob == best && oi > bi)) { best = ob; bi = oi; }
+    }
+    if (best < 0.0) break;                     // uniform: every thread read the same LDS values
+    if (tid == (bi % NT)) {
+      const int bs = bi / NT;
+#pragma unroll
+      for (int s = 0; s < kPerThread; ++s)
+        if (s == bs) { s_box[0] = x1[s]; s_box[1] = y1[s]; s_box[2] = x2[s]; s_box[3] = y2[s]; s_box[4] = area[s]; }
+    }
+    __syncthreads();
+    const double px1 = s_box[0], py1 = s_box[1], px2 = s_box[2], py2 = s_box[3], pa = s_box[4];
+    if (tid == 0) {
+      double* o = out + (long)picked * 5;
+      o[0] = px1; o[1] = py1; o[2] = px2; o[3] = py2; o[4] = best;
+    }
+    ++picked;
+#pragma unroll
+    for (int s = 0; s < kPerThread; ++s) {
+      if (s * NT + tid == bi) { sc[s] = -1.0; continue; }
+      if (sc[s] < 0.0) continue;
+      const double w = fmax(0.0, fmin(px2, x2[s]) - fmax(px1, x1[s]) + 1);
+      const double h = fmax(0.0, fmin(py2, y2[s]) - fmax(py1, y1[s]) + 1);
+      const double inter = w * h;
+      if (inter > 0.0) {
+        const double ovr = inter / (pa + area[s] - inter);
+        if (g.soft) sc[s] = sc[s] * exp(-(ovr * ovr) / g.nms_param);
+        else if (!(ovr <= g.nms_param)) sc[s] = -1.0;
+      }
+    }
+    __syncthreads();                           // s_best / s_box are rewritten in the next iteration
+  }
+  if (tid == 0) g.counts[(long)b * (g.C - 1) + (cls - 1)] = picked;
+}
 #pragma clang fp contract(fast)
 
 // ---------------------------------------------------------------------------------------
@@ -261,7 +352,7 @@ extern "C" int relnet_class_nms(const float* cls_prob, const double* boxes, doub
   hipStream_t s = (hipStream_t)stream;
   if (N <= 320) class_nms_kernel<5><<<grid, 64, 0, s>>>(g);
   else if (N <= 512) class_nms_kernel<8><<<grid, 64, 0, s>>>(g);
-  else class_nms_kernel<16><<<grid, 64, 0, s>>>(g);
+  else class_nms_block_kernel<4><<<grid, 256, 0, s>>>(g);
   return check_launch("relnet_class_nms");
 }
 

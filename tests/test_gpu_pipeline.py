@@ -27,10 +27,11 @@ def _np(t):
     return t.detach().float().cpu().numpy()
 
 
-def test_postprocess_softnms_and_nms(rn):
+@pytest.mark.parametrize('N', [120, 700])      # 700: the 4-wavefront kernel of the FPN graphs (N up to 1024)
+def test_postprocess_softnms_and_nms(rn, N):
     ops, _, _ = rn
     rng = np.random.default_rng(77)
-    B, N, C = 2, 120, 9
+    B, C = 2, 9
     rois = np.stack([np.hstack((np.full((N, 1), b, np.float32), cases.random_boxes(N, 80 + b))) for b in range(B)])
     cls_score = rng.normal(0, 2.5, (B, N, C)).astype(np.float32)
     bbox = rng.normal(0, 0.2, (B, N, 8)).astype(np.float32)
