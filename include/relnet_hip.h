@@ -314,6 +314,11 @@ int relnet_roi_pool_fpn_bwd(const void* grad_out, const int* argmax, const long*
                             const long* gs_c_levels, int num_levels, int R, int C, int PH, int PW,
                             int batch_index_base, int dtype, void* stream);
 
+/* grad[r,c] += row_scale[r]^2 * sum_s parts[s,r,c]: split-K partial sums of a weight gradient, the folded frozen-BN
+ * factor (NULL = 1) and the accumulation into the flat gradient buffer in one pass.  cols % 4 == 0.             */
+int relnet_wgrad_accumulate(const float* parts, int splits, long rows, int cols, const float* row_scale, float* grad,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

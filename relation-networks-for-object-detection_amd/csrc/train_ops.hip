@@ -65,6 +65,26 @@ __global__ __launch_bounds__(256) void sgd_update_kernel(SgdArgs g) {
   }
 }
 
+// grad[r, c] += scale[r]^2 * sum_s parts[s, r, c]: the split-K partial sums of a weight gradient, the frozen-BatchNorm
+// factor of a folded convolution (w' = w s  =>  dL/dw' enters SGD as s^2 dL/dw') and the accumulation into the flat
+// gradient buffer in ONE pass (instead of torch sum + mul + add_).
+__global__ __launch_bounds__(256) void wgrad_accumulate_kernel(const float* parts, int splits, long per_split, int cols,
+                                                               const float* row_scale, float* grad) {
+  const long nv = per_split / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+    float4 acc = *((const float4*)parts + i);
+    for (int s = 1; s < splits; ++s) {
+      const float4 v = *((const float4*)(parts + (long)s * per_split) + i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float m = 1.f;
+    if (row_scale) { const float sc = row_scale[(i * 4) / cols]; m = sc * sc; }     // cols % 4 == 0: one row per float4
+    float4 g = *((float4*)grad + i);
+    g.x += m * acc.x; g.y += m * acc.y; g.z += m * acc.z; g.w += m * acc.w;
+    *((float4*)grad + i) = g;
+  }
+}
+
 }  // namespace relnet
 
 using namespace relnet;
@@ -89,4 +109,16 @@ extern "C" int relnet_sgd_update(float* w, float* mom, const float* grad, void* 
   blocks = blocks > 8192 ? 8192 : blocks;
   sgd_update_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(g);
   return check_launch("relnet_sgd_update");
+}
+
+extern "C" int relnet_wgrad_accumulate(const float* parts, int splits, long rows, int cols, const float* row_scale,
+                                       float* grad, void* stream) {
+  RELNET_REQUIRE(parts && grad && splits > 0 && rows > 0 && cols > 0, "relnet_wgrad_accumulate: bad operand");
+  RELNET_REQUIRE(cols % 4 == 0 && (((uintptr_t)parts | (uintptr_t)grad) & 15) == 0,
+                 "relnet_wgrad_accumulate: cols %% 4 and 16-byte alignment required (cols=%d)", cols);
+  const long per_split = rows * cols;
+  long blocks = (per_split / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  wgrad_accumulate_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(parts, splits, per_split, cols, row_scale, grad);
+  return check_launch("relnet_wgrad_accumulate");
 }

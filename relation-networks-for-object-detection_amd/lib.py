@@ -60,6 +60,7 @@ _SIGNATURES = {
     'relnet_deformable_col2im': (C.c_int, [_vp, _l, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
     'relnet_deformable_psroi_pool_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_f, _f, _i, _i, _i, _vp]),
     'relnet_roi_pool_fpn_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'relnet_wgrad_accumulate': (C.c_int, [_vp, _i, _l, _i, _vp, _vp, _vp]),
     'relnet_gemm_force_tile': (None, [_i]),
     'relnet_gemm_force_nloop': (None, [_i]),
     'relnet_nms_greedy': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),

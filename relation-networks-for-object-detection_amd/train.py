@@ -167,7 +167,14 @@ class Trainer(object):
         return sum(int(np.prod(s)) for _, s in self.W.slices.values()) + sum(int(np.prod(s)) for _, s in self.Bv.slices.values())
 
     def _add_wgrad(self, name, dw, scale_rows=None):
+        """dw: the gradient [rows, cols], or the split-K partial sums [splits, rows, cols] of train_ops.wgrad(keep_splits=True)
+        (summed, scaled by the folded-BN factor and accumulated by ONE kernel)."""
         g = self.W.view(self.W.grad, name)
+        if dw.dim() == 3 and dw.is_contiguous() and dw.shape[1] * dw.shape[2] == g.numel() and g.shape[-1] % 4 == 0:
+            T.wgrad_accumulate(dw, g, scale_rows)
+            return
+        if dw.dim() == 3:
+            dw = dw.sum(0)
         dw = dw.reshape(g.shape)
         if scale_rows is not None:
             dw = dw * (scale_rows * scale_rows).view(-1, 1)
@@ -275,7 +282,7 @@ class Trainer(object):
             gp = d_pool.view(B * R, 7, 7, -1).permute(0, 3, 1, 2)
             gd1, gtrans = ops.deformable_psroi_pool_bwd(gp, nchw(feat), r5, trans, sc_, feat.shape[3], 1, 7, 7,
                                                         c.dcn_sample_per_part, c.dcn_trans_std, False)
-            d_t0, dw, db = T.linear_bwd(t0f, self.w('offset'), gtrans.view(B * R, -1).to(bt))
+            d_t0, dw, db = T.linear_bwd(t0f, self.w('offset'), gtrans.view(B * R, -1).to(bt), keep_splits=True)
             self._add_wgrad('offset', dw); self._add_bgrad('offset', db)
             gd2, _ = ops.deformable_psroi_pool_bwd(d_t0.view(B * R, 7, 7, -1).permute(0, 3, 1, 2), nchw(feat), r5, None, sc_,
                                                    feat.shape[3], 1, 7, 7, c.dcn_sample_per_part, 0.0, True)
@@ -285,13 +292,13 @@ class Trainer(object):
                                       (B, feat.shape[3], feat.shape[1], feat.shape[2]))
             d_feat = d_feat.permute(0, 2, 3, 1).to(bt).contiguous()
         g = T.relu_bwd(d_feat, feat)
-        d_x, dw = T.conv1x1_bwd(conv5, self.w('conv_new_1'), g)
+        d_x, dw = T.conv1x1_bwd(conv5, self.w('conv_new_1'), g, keep_splits=True)
         self._add_wgrad('conv_new_1', dw); self._add_bgrad('conv_new_1', g.float().sum((0, 1, 2)))
         # RPN head backward (joins the trunk at conv4)
-        d_r, dw = T.conv1x1_bwd(r, self.w('rpn_out'), d_rpn)
+        d_r, dw = T.conv1x1_bwd(r, self.w('rpn_out'), d_rpn, keep_splits=True)
         self._add_wgrad('rpn_out', dw); self._add_bgrad('rpn_out', d_rpn.float().sum((0, 1, 2)))
         g_r = T.relu_bwd(d_r, r)
-        d_conv4_rpn, dw = T.conv3x3_bwd(conv4, self._dgrad_w('rpn_conv_3x3', 512), g_r, dil=1)
+        d_conv4_rpn, dw = T.conv3x3_bwd(conv4, self._dgrad_w('rpn_conv_3x3', 512), g_r, dil=1, keep_splits=True)
         self._add_wgrad('rpn_conv_3x3', dw); self._add_bgrad('rpn_conv_3x3', g_r.float().sum((0, 1, 2)))
         self._trunk_backward(saved, d_x, {'4b22': d_conv4_rpn})
         out['rois'] = rois_t
@@ -312,7 +319,7 @@ class Trainer(object):
             if inject.get(nm) is not None:       # a second consumer of this unit's output (RPN head at conv4, FPN laterals)
                 d_x = inject[nm] if d_x is None else d_x + inject[nm]
             g_out = T.relu_bwd(d_x, o)
-            d_y2, dw = T.conv1x1_bwd(y2, self.w(nc_), g_out)
+            d_y2, dw = T.conv1x1_bwd(y2, self.w(nc_), g_out, keep_splits=True)
             self._add_wgrad(nc_, dw, self.bn_scale[nc_])
             g_y2 = T.relu_bwd(d_y2, y2)
             if off is not None:            # deformable branch2b: data + offset gradients, then the offset conv's own backward
@@ -324,23 +331,23 @@ class Trainer(object):
                 goff_p[..., :72] = goff
                 wd_ = self.w(no).view(72, 3, 3, -1).flip(1, 2).permute(3, 1, 2, 0)                     # [Cin,3,3,72]
                 wdp = torch.zeros((wd_.shape[0], 3, 3, 128), device=off.device, dtype=bt); wdp[..., :72] = wd_
-                d_off_in, dwo = T.conv3x3_bwd(y1, wdp.reshape(wd_.shape[0], -1).contiguous(), goff_p, dil=2)
-                self._add_wgrad(no, dwo[:72]); self._add_bgrad(no, goff.sum((0, 1, 2)))
+                d_off_in, dwo = T.conv3x3_bwd(y1, wdp.reshape(wd_.shape[0], -1).contiguous(), goff_p, dil=2, keep_splits=True)
+                self._add_wgrad(no, dwo.sum(0)[:72]); self._add_bgrad(no, goff.sum((0, 1, 2)))
                 d_y1 = (gd + d_off_in.float()).to(bt).contiguous()
             else:
-                d_y1, dw = T.conv3x3_bwd(y1, self._dgrad_w(nb, y2.shape[3]), g_y2, dil=dil)
+                d_y1, dw = T.conv3x3_bwd(y1, self._dgrad_w(nb, y2.shape[3]), g_y2, dil=dil, keep_splits=True)
                 self._add_wgrad(nb, dw, self.bn_scale[nb])
             g_y1 = T.relu_bwd(d_y1, y1)
             first = (stage == 3 and proj)         # res3a: its input comes from the frozen res2 -> no data gradient
             if proj:
-                d_a, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, stride=stride, need_dx=not first)
+                d_a, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, stride=stride, need_dx=not first, keep_splits=True)
                 self._add_wgrad(na, dw, self.bn_scale[na])
                 d_s, dw = T.conv1x1_bwd(x_in, self.w(n1), g_out, stride=stride, need_dx=not first,
-                                        dx_add=d_a if (stride == 1 and not first) else None)
+                                        dx_add=d_a if (stride == 1 and not first) else None, keep_splits=True)
                 self._add_wgrad(n1, dw, self.bn_scale[n1])
                 d_x = None if first else (d_s if stride == 1 else d_s + d_a)
             else:
-                d_x, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, dx_add=g_out)       # identity shortcut
+                d_x, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, dx_add=g_out, keep_splits=True)       # identity shortcut
                 self._add_wgrad(na, dw, self.bn_scale[na])
 
     def _head_forward_backward(self, pooled2, rois_t, N, label, bbox_target, bbox_weight, im_info, gt_boxes, num_gt, out):
@@ -377,16 +384,16 @@ class Trainer(object):
             out.update(lo)
         # ================= backward =================
         d_cb = torch.cat([d_cls, d_bbox], 2).reshape(B * R, -1).to(bt)
-        d_x2, dw, db = T.linear_bwd(x2.reshape(B * R, -1), self.w('cls_bbox'), d_cb)
+        d_x2, dw, db = T.linear_bwd(x2.reshape(B * R, -1), self.w('cls_bbox'), d_cb, keep_splits=True)
         self._add_wgrad('cls_bbox', dw); self._add_bgrad('cls_bbox', db)
         if d_x2_lnms is not None:
             d_x2 = d_x2.reshape(B, R, -1)
             d_x2[:, :N] += d_x2_lnms.to(d_x2.dtype)
         d_f2 = self._relation_bwd(2, mods[1], f2, x2, rois_t, d_x2.reshape(B, R, -1), N)
-        d_x1, dw, db = T.linear_bwd(x1.reshape(B * R, -1), self.w('fc_new_2'), d_f2.reshape(B * R, -1))
+        d_x1, dw, db = T.linear_bwd(x1.reshape(B * R, -1), self.w('fc_new_2'), d_f2.reshape(B * R, -1), keep_splits=True)
         self._add_wgrad('fc_new_2', dw); self._add_bgrad('fc_new_2', db)
         d_f1 = self._relation_bwd(1, mods[0], f1, x1, rois_t, d_x1.reshape(B, R, -1), N)
-        d_pool, dw, db = T.linear_bwd(pooled2, self.w('fc_new_1'), d_f1.reshape(B * R, -1))
+        d_pool, dw, db = T.linear_bwd(pooled2, self.w('fc_new_1'), d_f1.reshape(B * R, -1), keep_splits=True)
         self._add_wgrad('fc_new_1', dw); self._add_bgrad('fc_new_1', db)
         return d_pool, (x2, f1, cls_score, bbox_pred, labels_ohem, weights_ohem)
 
@@ -452,8 +459,8 @@ class Trainer(object):
         d_sorted = (d_multi * cond).sum(3)                                                      # [B,F,C]
         d_logit = (d_multi * sorted_score.unsqueeze(3) * cond * (1.0 - cond)).permute(0, 2, 1, 3).reshape(BC * F, Tn)
         d_logit_p = torch.zeros((BC * F, 64), device=dev, dtype=bt); d_logit_p[:, :Tn] = d_logit
-        d_allf, dw, db = T.linear_bwd(allf.view(BC * F, 128), w_logit, d_logit_p, w_t=None)
-        self._add_wgrad('nms_logit', dw[:Tn]); self._add_bgrad('nms_logit', db[:Tn])
+        d_allf, dw, db = T.linear_bwd(allf.view(BC * F, 128), w_logit, d_logit_p, w_t=None, keep_splits=True)
+        self._add_wgrad('nms_logit', dw.sum(0)[:Tn]); self._add_bgrad('nms_logit', db[:Tn])
         g = T.relu_bwd(d_allf, allf.view(BC * F, 128))                                          # [BC*F,128] bf16
         dY = torch.zeros((BC, F, 1024), device=dev, dtype=bt)
         dY.view(BC, F, 16, 64)[..., :8] = g.view(BC, F, 16, 8)
@@ -469,7 +476,7 @@ class Trainer(object):
         flat = (rank_idx.long() + (torch.arange(B, device=dev) * N).view(B, 1, 1)).view(-1)
         d_emb = torch.zeros((B * N, 128), device=dev, dtype=torch.float32)
         d_emb.index_add_(0, flat, d_x.reshape(-1, 128))                                         # take() backward
-        d_feat, dw, db = T.linear_bwd(feat2, self.w('roi_feat_embedding'), d_emb.to(bt))
+        d_feat, dw, db = T.linear_bwd(feat2, self.w('roi_feat_embedding'), d_emb.to(bt), keep_splits=True)
         self._add_wgrad('roi_feat_embedding', dw); self._add_bgrad('roi_feat_embedding', db)
         # sort / slice backward -> cls_prob -> softmax backward (background column has no direct gradient)
         d_prob = torch.zeros((B, N, C), device=dev, dtype=torch.float32)
@@ -602,14 +609,14 @@ class FPNTrainer(Trainer):
         d_tops, inject, d_c5 = {}, {}, None
         for lvl in (4, 8, 16, 32):
             n3, n1 = 'fpn_ft%d_3x3' % lvl, 'fpn_ft%d_1x1' % lvl
-            d_top, dw = T.conv3x3_bwd(tops[lvl], self._dgrad_w(n3, 256), d_feats[lvl], dil=1)
+            d_top, dw = T.conv3x3_bwd(tops[lvl], self._dgrad_w(n3, 256), d_feats[lvl], dil=1, keep_splits=True)
             self._add_wgrad(n3, dw); self._add_bgrad(n3, d_feats[lvl].float().sum((0, 1, 2)))
             if lvl in d_tops:                                    # + the gradient that came down from the finer level
                 d_top = (d_top.float() + d_tops[lvl]).to(bt)
             if lvl < 32:       # tops[lvl] = lateral + up2x(tops[2 lvl]): adjoint of nearest upsampling = 2x2 block sums
                 Bh, Hh, Wh, Ch = d_top.shape
                 d_tops[lvl * 2] = d_top.float().view(Bh, Hh // 2, 2, Wh // 2, 2, Ch).sum((2, 4))
-            d_src, dw = T.conv1x1_bwd(src[lvl], self.w(n1), d_top.contiguous(), need_dx=(lvl != 4))   # res2c is frozen
+            d_src, dw = T.conv1x1_bwd(src[lvl], self.w(n1), d_top.contiguous(), need_dx=(lvl != 4), keep_splits=True)   # res2c is frozen
             self._add_wgrad(n1, dw); self._add_bgrad(n1, d_top.float().sum((0, 1, 2)))
             if lvl == 32:
                 d_c5 = d_src

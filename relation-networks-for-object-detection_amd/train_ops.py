@@ -46,8 +46,9 @@ def _splits_for(m, n, k):
     return s
 
 
-def wgrad(dy2d, x2d):
-    """dW [Cout, K] = dY^T X for dY [P, Cout], X [P, K] (bf16 or fp32, rows = pixels / rois); fp32 result."""
+def wgrad(dy2d, x2d, keep_splits=False):
+    """dW [Cout, K] = dY^T X for dY [P, Cout], X [P, K] (bf16 or fp32, rows = pixels / rois); fp32 result.
+    keep_splits: return the [splits, Cout, K] partial sums (for wgrad_accumulate) instead of their sum."""
     P, Cout = dy2d.shape
     K = x2d.shape[1]
     gran = 64 if dy2d.dtype == torch.bfloat16 else 16
@@ -59,10 +60,22 @@ def wgrad(dy2d, x2d):
     a3 = dyt.as_strided((s, Cout, ks), (ks, dyt.stride(0), 1))
     w3 = xt.as_strided((s, K, ks), (ks, xt.stride(0), 1))
     part = ops.gemm_nt(a3, w3, out_dtype=torch.float32)                 # [s, Cout, K] partial sums
+    if keep_splits:
+        return part
     return part.sum(0) if s > 1 else part[0]
 
 
-def linear_bwd(x2d, w, dy2d, need_dx=True, w_t=None):
+def wgrad_accumulate(parts, grad, row_scale=None):
+    """grad [rows, cols] (fp32 view of the flat gradient buffer) += row_scale^2 * parts.sum(0), one kernel."""
+    _chk(parts, grad, row_scale)
+    if parts.dim() == 2:
+        parts = parts[None]
+    S, rows, cols = parts.shape
+    assert parts.is_contiguous() and grad.is_contiguous() and grad.numel() == rows * cols and parts.dtype == torch.float32
+    _lib.call('relnet_wgrad_accumulate', parts.data_ptr(), S, rows, cols, _ptr(row_scale), grad.data_ptr(), _stream())
+
+
+def linear_bwd(x2d, w, dy2d, need_dx=True, w_t=None, keep_splits=False):
     """y = x W^T + b  ->  (dx [P,K] in x's dtype | None, dW [N,K] fp32, db [N] fp32)."""
     dx = None
     if need_dx:
@@ -74,7 +87,7 @@ def linear_bwd(x2d, w, dy2d, need_dx=True, w_t=None):
             dyp = torch.zeros((dy2d.shape[0], w_t.shape[1]), device=dy2d.device, dtype=dy2d.dtype)
             dyp[:, :N] = dy2d
         dx = ops.gemm_nt(dyp, w_t)
-    return dx, wgrad(dy2d, x2d), dy2d.float().sum(0)
+    return dx, wgrad(dy2d, x2d, keep_splits), dy2d.float().sum(0)
 
 
 def pack_conv_dgrad_weight(w_oihw, dtype=torch.bfloat16, device='cuda'):
@@ -84,7 +97,7 @@ def pack_conv_dgrad_weight(w_oihw, dtype=torch.bfloat16, device='cuda'):
     return w.reshape(w.shape[0], -1).to(device=device, dtype=dtype).contiguous()
 
 
-def conv1x1_bwd(x, w_packed, dy, stride=1, need_dx=True, w_t=None, dx_add=None):
+def conv1x1_bwd(x, w_packed, dy, stride=1, need_dx=True, w_t=None, dx_add=None, keep_splits=False):
     """x [B,H,W,Cin], dy [B,Ho,Wo,Cout] NHWC; w_packed [Cout,Cin].  -> (dx [B,H,W,Cin] | None, dW fp32).
     dx_add (stride 1 only): a second gradient of x's shape added in the GEMM epilogue (the shortcut branch)."""
     B, H, W, Cin = x.shape
@@ -106,13 +119,13 @@ def conv1x1_bwd(x, w_packed, dy, stride=1, need_dx=True, w_t=None, dx_add=None):
             assert dx_add is None
             dx = torch.zeros_like(x)
             dx[:, ::stride, ::stride, :] = ops.gemm_nt(dyp, w_t).reshape(xs.shape)
-    return dx, wgrad(dy2, xs.reshape(P, Cin))
+    return dx, wgrad(dy2, xs.reshape(P, Cin), keep_splits)
 
 
 _ZERO_OFF = {}
 
 
-def conv3x3_bwd(x, w_dgrad_packed, dy, dil=1, need_dx=True):
+def conv3x3_bwd(x, w_dgrad_packed, dy, dil=1, need_dx=True, keep_splits=False):
     """3x3, stride 1, pad = dil.  x [B,H,W,Cin], dy [B,H,W,Cout]; w_dgrad_packed from pack_conv_dgrad_weight.
     -> (dx | None, dW [Cout, 9*Cin] fp32 in pack_conv_weight order)."""
     B, H, W, Cin = x.shape
@@ -124,4 +137,4 @@ def conv3x3_bwd(x, w_dgrad_packed, dy, dil=1, need_dx=True):
     if key not in _ZERO_OFF:
         _ZERO_OFF[key] = torch.zeros((B, H, W, 18), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
     col, _ = ops.deformable_im2col(x.permute(0, 3, 1, 2), _ZERO_OFF[key], 3, 1, dil, dil, 1)    # [P, 9*Cin] patches
-    return dx, wgrad(dy.reshape(B * H * W, Cout), col)
+    return dx, wgrad(dy.reshape(B * H * W, Cout), col, keep_splits)
