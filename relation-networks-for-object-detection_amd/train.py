@@ -303,7 +303,6 @@ class Trainer(object):
         self._trunk_backward(saved, d_x, {'4b22': d_conv4_rpn})
         out['rois'] = rois_t
         out['label'] = labels_ohem
-        out['debug'] = dict(feat=feat, conv5=conv5, pooled=pooled2, trans=trans if c.dcn else None, x2=x2, f1=f1)
         out['bbox_target'], out['bbox_weight'] = bbox_target, weights_ohem
         out['bbox_pred'] = bbox_pred
         out['cls_score'] = cls_score
@@ -627,7 +626,7 @@ class FPNTrainer(Trainer):
         self._trunk_backward(saved, d_c5, inject)
         out.update(rois=rois_s, perm=perm, roi_level=level, label=labels_ohem, bbox_target=bbox_target, bbox_weight=weights_ohem,
                    bbox_pred=bbox_pred, cls_score=cls_score)
-        out['debug'] = dict(feats=feats, pooled=pooled2, x2=x2, f1=f1)
+        out['intermediates'] = dict(feats=feats, pooled=pooled2)        # forward values for the stage-wise parity test
         return out
 
 

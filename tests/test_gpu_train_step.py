@@ -208,13 +208,12 @@ def test_fpn_training_step_gradients_match_autograd():
                                     out['bbox_weight'][0].cpu().numpy(), N, lnms=lnms)
     loss.backward()
     e_cs = float((out['cls_score'][0].cpu().double() - parts['cls_score']).abs().max() / parts['cls_score'].abs().max())
-    print('fpn forward cls_score rel err %.4f' % e_cs)
-    for l_, nm_ in enumerate((4, 8, 16, 32)):
-        a_ = out['debug']['feats'][nm_][0].permute(2, 0, 1).double().cpu(); b_ = parts['feats'][l_][0]
-        print('  fpn_ft%d rel err %.4f' % (nm_, float((a_ - b_).norm() / b_.norm())))
+    for l_, nm_ in enumerate((4, 8, 16, 32)):            # forward first: pyramid maps and pooled features (bf16, ~100 layers)
+        a_ = out['intermediates']['feats'][nm_][0].permute(2, 0, 1).double().cpu(); b_ = parts['feats'][l_][0]
+        assert float((a_ - b_).norm() / b_.norm()) <= 0.03, nm_
     po_ = parts['pooled'].permute(0, 2, 3, 1).reshape(rois.shape[0], -1)
-    print('  pooled rel err %.4f' % float((out['debug']['pooled'].double().cpu() - po_).norm() / po_.norm()))
-    assert e_cs <= 0.2, e_cs
+    assert float((out['intermediates']['pooled'].double().cpu() - po_).norm() / po_.norm()) <= 0.03
+    assert e_cs <= 0.08, e_cs
 
     def packed(name):
         g_ = pt[name + '_weight'].grad
