@@ -175,7 +175,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (default 54; 4 with --train)')
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (default 54; 8 with --train)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-relation', action='store_true', help='plain 2FC head (config 1 graph)')
     ap.add_argument('--learn-nms', action='store_true', help='learned duplicate removal instead of soft-NMS (config 3 graph, inference)')
@@ -191,7 +191,7 @@ def main():
     ap.add_argument('--shapes', action='store_true', help='print per-shape GEMM/conv times to stderr')
     a = ap.parse_args()
     if a.batch is None:
-        a.batch = 4 if a.train else 54
+        a.batch = 8 if a.train else 54
 
     import __graft_entry__ as ge
     ge.build()
