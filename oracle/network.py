@@ -148,7 +148,9 @@ def detect(data, im_info, p, relation=True, soft=True, nms=0.6, num_classes=81, 
         cls_score, bbox = r['cls_score'], r['bbox_pred']
     else:
         cls_score, bbox, _ = plain_head(pooled, pn)
+    import time
     cls_prob = OPP.softmax_rows(cls_score)
     scores, boxes = OPP.im_detect(rois, cls_prob, bbox, im_info)
+    t0 = time.time()
     dets = OPP.detections(scores, boxes, num_classes, 1e-3, nms, soft, max_per_image)
-    return dict(rois=rois, cls_prob=cls_prob, bbox_pred=bbox, boxes=boxes, dets=dets)
+    return dict(rois=rois, cls_prob=cls_prob, bbox_pred=bbox, boxes=boxes, dets=dets, post_seconds=time.time() - t0)
