@@ -81,6 +81,7 @@ int relnet_gemm_nt(const void* A, long lda, long strideA, const void* W, long ld
                    int M, int N, int K, int batch, int in_dtype, int out_dtype, void* stream);
 void relnet_gemm_force_tile(int cfg);     /* tuning knob: 0 = auto, 1..5 = fixed tile configuration */
 void relnet_gemm_force_nloop(int n);      /* tuning knob: 0 = auto, n = column tiles per workgroup     */
+void relnet_gemm_set_swizzle(int on);     /* tuning knob: XCD-aware tile order (default 1)               */
 
 /* ---- mx.symbol.Convolution + BatchNorm(use_global_stats) + Activation of
  * relation_rcnn/symbols/resnet_v1_101_rcnn_base.py:29-693 as an NHWC implicit GEMM (BN folded by the

@@ -28,6 +28,7 @@ struct GemmArgs {
   int cH, cW, cCin, cHout, cWout, cR, cS, cStride, cDil, cPad;
   long cPix, cImg;         // element strides between pixels / images of the input
   int n_loop;              // column tiles walked by one workgroup (row-panel mode), >= 1
+  int xcd_swizzle;         // 1: remap the linear workgroup id so that every XCD owns a contiguous run of tiles
 };
 
 template <typename TOUT> __device__ __forceinline__ void store_out(TOUT* p, float v);
@@ -141,7 +142,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
-  const int m0 = blockIdx.y * BM;
+  // Workgroup b runs on XCD b % 8 (observed dispatch rule).  The column tiles of one row panel share the A rows, so they
+  // should sit on ONE XCD (one L2) close together in time: give every XCD a contiguous run of the (row panel, column
+  // group) sequence (bijective for any grid size).  Measured before: the 4 column tiles of the res4 expand convolutions
+  // re-fetched A from the fabric 4x (profiles/conv_pmc.json: 820 MB moved for 596 MB of operands).
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (g.xcd_swizzle) {
+    const int gx = gridDim.x, nwg = gx * gridDim.y;
+    const int id = bx + gx * by, xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    by = t / gx; bx = t - by * gx;
+  }
+  const int m0 = by * BM;
   const unsigned short* A = (const unsigned short*)g.A + (long)blockIdx.z * g.strideA;
   const unsigned short* W = (const unsigned short*)g.W + (long)blockIdx.z * g.strideW;
   TOUT* C = (TOUT*)g.C + (long)blockIdx.z * g.strideC;
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
   // tile, so its output rows are written as long contiguous runs and the A rows are re-read
   // from its own XCD's L2 instead of by workgroups scattered over the chip.
   for (int nt = 0; nt < g.n_loop; ++nt) {
-  const int n0 = (blockIdx.x * g.n_loop + nt) * BN;
+  const int n0 = (bx * g.n_loop + nt) * BN;
   if (n0 >= g.N) break;
   if (nt > 0) __syncthreads();                         // previous tile's epilogue band fully read
 #pragma unroll
@@ -446,17 +458,25 @@ enum { RELNET_F32 = 0, RELNET_BF16 = 1 };
 
 static int g_force_tile = 0;     // tuning knob: 0 auto, else index into the config list below
 static int g_force_nloop = 0;    // tuning knob: 0 auto, else column tiles per workgroup
+static int g_swizzle = 1;        // tuning knob: XCD-aware tile order (0 = plain blockIdx order)
 extern "C" void relnet_gemm_force_tile(int t) { g_force_tile = t; }
 extern "C" void relnet_gemm_force_nloop(int n) { g_force_nloop = n; }
+extern "C" void relnet_gemm_set_swizzle(int on) { g_swizzle = on; }
 
 template <int BM, int BN, int WM, int WN, int CONV>
 static void launch_cfg(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
   const int ntile = (g.N + BN - 1) / BN;
   int nloop = g_force_nloop > 0 ? g_force_nloop : g.n_loop;
+  const bool swz = g_swizzle && batch == 1 && ntile > 1 && (long)ntile * ((g.M + BM - 1) / BM) >= 16;
+  // with the XCD-aware order the column tiles of a row panel run side by side on one XCD and share the A rows through
+  // its L2; walking them serially in one workgroup (row-panel mode) only costs parallelism then (measured, 54 images:
+  // res4 expand 229.9 us plain/auto -> 217.7 us swizzle/n_loop 1; per-step convolution total 23.07 -> 22.36 ms)
+  if (swz && g_force_nloop == 0) nloop = 1;
   if (nloop < 1) nloop = 1;
   if (nloop > ntile) nloop = ntile;
   g.n_loop = nloop;
   dim3 grid((ntile + nloop - 1) / nloop, (g.M + BM - 1) / BM, batch);
+  g.xcd_swizzle = (swz && grid.x > 1) ? 1 : 0;
   if (out_dtype == RELNET_BF16) gemm_nt_bf16_kernel<BM, BN, WM, WN, unsigned short, CONV><<<grid, 64 * WM * WN, 0, s>>>(g);
   else gemm_nt_bf16_kernel<BM, BN, WM, WN, float, CONV><<<grid, 64 * WM * WN, 0, s>>>(g);
 }

@@ -1,0 +1,72 @@
+"""Micro-benchmark (not a test): every convolution shape of the detector at B images, per tile configuration.
+python tests/_bench_tiles.py [B]   -> prints the time of tile configs 0 (auto) / 1 / 2 / 3 / 4 per shape."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import relnet_amd
+from relnet_amd import ops, lib
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 54
+L = lib.load()
+
+
+def timeit(fn, iters=8):
+    for _ in range(2):
+        fn()
+    s, e = torch.cuda.Event(True), torch.cuda.Event(True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+
+
+def conv_case(H, W, Cin, Cout, k, dil, resid, stride=1):
+    x = torch.randn(B, H, W, Cin, device='cuda').to(torch.bfloat16)
+    w = (torch.randn(Cout, k * k * Cin, device='cuda') * 0.03).to(torch.bfloat16)
+    b = torch.randn(Cout, device='cuda')
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = torch.randn(B, Ho, Wo, Cout, device='cuda').to(torch.bfloat16) if resid else None
+    out = torch.empty(B, Ho, Wo, Cout, device='cuda', dtype=torch.bfloat16)
+    return lambda: ops.conv2d_nhwc(x, w, b, ksize=k, stride=stride, pad=dil if k == 3 else 0, dil=dil, relu=True, resid=r, out=out)
+
+
+CASES = [  # name, count per step, args
+    ('res4 expand 256->1024 +res', 23, (38, 63, 256, 1024, 1, 1, True)),
+    ('res4 3x3 256', 23, (38, 63, 256, 256, 3, 1, False)),
+    ('res4 reduce 1024->256', 22, (38, 63, 1024, 256, 1, 1, False)),
+    ('res2 expand 64->256 +res', 3, (150, 250, 64, 256, 1, 1, True)),
+    ('res5 3x3 512 d2', 3, (38, 63, 512, 512, 3, 2, False)),
+    ('res5 expand 512->2048 +res', 3, (38, 63, 512, 2048, 1, 1, True)),
+    ('res3 expand 128->512 +res', 4, (75, 125, 128, 512, 1, 1, True)),
+    ('rpn 3x3 1024->512', 1, (38, 63, 1024, 512, 3, 1, False)),
+    ('res3 3x3 128', 4, (75, 125, 128, 128, 3, 1, False)),
+    ('res2 3x3 64', 3, (150, 250, 64, 64, 3, 1, False)),
+    ('res5 reduce 2048->512', 2, (38, 63, 2048, 512, 1, 1, False)),
+    ('res3 reduce 512->128', 3, (75, 125, 512, 128, 1, 1, False)),
+    ('res2 reduce 256->64', 2, (150, 250, 256, 64, 1, 1, False)),
+    ('conv_new_1 2048->256', 1, (38, 63, 2048, 256, 1, 1, False)),
+]
+def main():
+    tot = {t: 0.0 for t in (0, 1, 2, 3, 4)}
+    best_tot = 0.0
+    for name, cnt, args in CASES:
+        fn = conv_case(*args)
+        row = []
+        for t in (0, 1, 2, 3, 4):
+            L.relnet_gemm_force_tile(t)
+            try:
+                us = timeit(fn)
+            except Exception as ex:
+                us = float('nan')
+            row.append(us); tot[t] += cnt * us
+        L.relnet_gemm_force_tile(0)
+        best_tot += cnt * min(r for r in row if r == r)
+        print('%-30s x%2d  auto %7.1f | t1 %7.1f  t2 %7.1f  t3 %7.1f  t4 %7.1f us   best t%d' % (
+            name, cnt, row[0], row[1], row[2], row[3], row[4], 1 + min(range(4), key=lambda i: row[1 + i] if row[1 + i] == row[1 + i] else 1e30)))
+    print('per-step totals (ms): auto %.2f  t1 %.2f t2 %.2f t3 %.2f t4 %.2f   per-shape best %.2f' % (
+        tot[0] / 1e3, tot[1] / 1e3, tot[2] / 1e3, tot[3] / 1e3, tot[4] / 1e3, best_tot / 1e3))
+
+
+if __name__ == '__main__':
+    main()
