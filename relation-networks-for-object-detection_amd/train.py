@@ -46,6 +46,15 @@ class TrainConfig(Config):
     bbox_stds = (0.1, 0.1, 0.2, 0.2)
 
 
+def all_reduce_sum(*buffers):
+    """SUM each flat gradient buffer over the ranks (no-op in a single process): the whole data-parallel exchange of a
+    training step is these two collectives (weights 271 MB, biases 0.1 MB)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        for b in buffers:
+            dist.all_reduce(b, op=dist.ReduceOp.SUM)
+
+
 class _Flat(object):
     """Named fp32 tensors carved out of one flat buffer (64-element aligned slices)."""
 
@@ -520,10 +529,7 @@ class Trainer(object):
     # ---- optimizer ----------------------------------------------------------------------------------------
     def all_reduce(self):
         """ONE summed all-reduce per flat buffer over RCCL (MXNet kvstore 'device' + rescale_grad 1.0 semantics)."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.W.grad, op=dist.ReduceOp.SUM)
-            dist.all_reduce(self.Bv.grad, op=dist.ReduceOp.SUM)
+        all_reduce_sum(self.W.grad, self.Bv.grad)
 
     def update(self, lr=None):
         c = self.cfg

@@ -89,3 +89,43 @@ def test_gradient_bucket_sum_allreduce():
         assert names == ['res4b3_branch2a_weight', 'fc_new_1_weight', 'query_1_bias']   # conv1/res2/gamma frozen
         assert vals == [3.0, 6.0, 9.0]                                                 # (1 + 2) * (i + 1): SUM, not mean
         assert numel == 256 * 1024 + 448 + 64                                          # 64-element aligned slices
+
+
+def _flat_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import relnet_amd  # noqa: F401
+    from relnet_amd import dist as D
+    from relnet_amd import train
+    D.init(backend='gloo')
+    g = torch.Generator().manual_seed(0)                        # same initial weights on every rank
+    named = [('res4b3_branch2a', torch.randn(256, 1024, generator=g)), ('fc_new_2', torch.randn(8, 50, generator=g)),
+             ('pair_pos_fc1_1', torch.randn(16, 64, generator=g))]
+    flat = train._Flat(named, 'cpu')
+    for i, (n, t) in enumerate(named):
+        flat.view(flat.grad, n).fill_(float(rank + 1) * (i + 1))
+    train.all_reduce_sum(flat.grad)
+    q.put((rank, [float(flat.view(flat.grad, n).flatten()[0]) for n, _ in named], int(flat.size),
+           bool(torch.equal(flat.view(flat.master, 'fc_new_2'), named[1][1])), [flat.slices[n][0] % 64 for n, _ in named]))
+    torch.distributed.destroy_process_group()
+
+
+def test_trainer_flat_buffers_sum_allreduce():
+    """The training step's exchange (train.Trainer.all_reduce): flat fp32 gradient buffer, one SUM all-reduce, every rank
+    ends with the sum; slices are 64-element aligned views of one buffer."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_flat_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, firsts, size, master_ok, align in res:
+        assert firsts == [3.0, 6.0, 9.0]                        # (1 + 2) * (i + 1)
+        assert size == 256 * 1024 + 448 + 1024 and master_ok and align == [0, 0, 0]
