@@ -273,7 +273,7 @@ int relnet_relation_attention_bwd(const void* q, long q_ld, long q_bs, const voi
  * dpre = dlog / G where G > 1e-6; the 64-d embedding is recomputed from the boxes (SYM_REL:29-83).            */
 int relnet_geometry_bias_bwd(const float* boxes, int box_stride, int box_off, const float* bias, const float* dlog,
                              const float* divisors8, float* dwp, float* dbp, int B, int N, int M, int Mpad,
-                             void* stream);
+                             int fast_math /* 1: hardware sin / cos / exp (bf16 training path) */, void* stream);
 
 /* ---- Elementwise pieces of the training step ------------------------------
  * Gradient through Activation(relu) and the fused conv(+residual)+ReLU epilogues: dx = dy * (y > 0) (+ add).  */

@@ -371,15 +371,18 @@ __device__ __forceinline__ void position_features(float4 bi, float4 bj, float (&
   p[2] = (float)log((double)(wi / wj));
   p[3] = (float)log((double)(hi / hj));
 }
+template <bool FAST>
 __device__ __forceinline__ float embed_value(float p, int sc, float divisor) {
   const float arg = (100.0f * p) / divisor;
-  return sc ? cosf(arg) : sinf(arg);
+  if constexpr (FAST) return sc ? __cosf(arg) : __sinf(arg);      // v_cos / v_sin, like the forward's fp16-bias path
+  else return sc ? cosf(arg) : sinf(arg);
 }
 #pragma clang fp contract(fast)
 
 // one wavefront per (image, query i); MFMA k = pairs (two per instruction, one per half-wave).  The four fp64 logs of a
 // pair are computed ONCE (lane L of a 64-pair block owns pair j0 + L, like the forward kernel's one-thread-per-pair) and
 // handed to the lanes that need them with ds_bpermute; each lane then evaluates its two embedding columns.
+template <bool FAST>
 __global__ __launch_bounds__(256) void geometry_bias_bwd_kernel(GeomBwdArgs g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -415,11 +418,11 @@ __global__ __launch_bounds__(256) void geometry_bias_bwd_kernel(GeomBwdArgs g) {
       float dpre = 0.f;
       if (okj && l31 < 16) {
         const float lg = Brow[j];
-        dpre = lg > kLogFloor ? Lrow[j] * expf(-lg) : 0.f;          // dL / G, zero on the clamped branch
+        dpre = lg > kLogFloor ? Lrow[j] * (FAST ? __expf(-lg) : expf(-lg)) : 0.f;          // dL / G, zero on the clamped branch
       }
       bsum += dpre;
-      const float e0 = okj ? embed_value(hi_comp ? q1 : q0, sc, div) : 0.f;
-      const float e1 = okj ? embed_value(hi_comp ? q3 : q2, sc, div) : 0.f;
+      const float e0 = okj ? embed_value<FAST>(hi_comp ? q1 : q0, sc, div) : 0.f;
+      const float e1 = okj ? embed_value<FAST>(hi_comp ? q3 : q2, sc, div) : 0.f;
       c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(dpre, e0, c0, 0, 0, 0);
       c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dpre, e1, c1, 0, 0, 0);
     }
@@ -495,7 +498,7 @@ extern "C" int relnet_relation_attention_bwd(
 
 extern "C" int relnet_geometry_bias_bwd(const float* boxes, int box_stride, int box_off, const float* bias,
                                         const float* dlog, const float* divisors8, float* dwp, float* dbp, int B,
-                                        int N, int M, int Mpad, void* stream) {
+                                        int N, int M, int Mpad, int fast_math, void* stream) {
   RELNET_REQUIRE(boxes && bias && dlog && divisors8 && dwp && dbp, "relnet_geometry_bias_bwd: null operand");
   RELNET_REQUIRE(B > 0 && N > 0 && M > 0 && Mpad >= M, "relnet_geometry_bias_bwd: bad shape");
   GeomBwdArgs g;
@@ -503,6 +506,7 @@ extern "C" int relnet_geometry_bias_bwd(const float* boxes, int box_stride, int 
   for (int k = 0; k < 8; ++k) g.divisors[k] = divisors8[k];
   g.dwp = dwp; g.dbp = dbp; g.B = B; g.N = N; g.M = M; g.Mpad = Mpad;
   dim3 grid((unsigned)((N + 3) / 4), B);
-  geometry_bias_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g);
+  if (fast_math) geometry_bias_bwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(g);
+  else geometry_bias_bwd_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(g);
   return check_launch("relnet_geometry_bias_bwd");
 }

@@ -620,7 +620,7 @@ def relation_attention_bwd(q, k, kt, vw, bias, dy, y, bout, qt, dyt, M, heads=16
     return dq, dk, dvw, prob, dlog
 
 
-def geometry_bias_bwd(boxes, bias, dlog, M, divisors=None):
+def geometry_bias_bwd(boxes, bias, dlog, M, divisors=None, fast=False):
     """boxes [B,N,4|5]; bias / dlog [B,16,N,Mpad] fp32 -> (d pair_pos_fc1 weight [16,64], d bias [16]) fp32."""
     _chk(boxes, bias, dlog)
     assert boxes.dtype == torch.float32 and boxes.is_contiguous()
@@ -630,7 +630,7 @@ def geometry_bias_bwd(boxes, bias, dlog, M, divisors=None):
     dwp = torch.zeros((16, 64), device=boxes.device, dtype=torch.float32)
     dbp = torch.zeros((16,), device=boxes.device, dtype=torch.float32)
     _lib.call('relnet_geometry_bias_bwd', boxes.data_ptr(), bs, 1 if bs == 5 else 0, bias.data_ptr(), dlog.data_ptr(),
-              div.data_ptr(), dwp.data_ptr(), dbp.data_ptr(), B, N, M, bias.shape[-1], _stream())
+              div.data_ptr(), dwp.data_ptr(), dbp.data_ptr(), B, N, M, bias.shape[-1], int(fast), _stream())
     return dwp, dbp
 
 

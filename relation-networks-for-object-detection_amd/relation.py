@@ -176,7 +176,7 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
     qt = ops.transpose_2d(q, pad_cols_to=32)
     dyt = ops.transpose_2d(dY, pad_cols_to=32)
     dq, dk, dvw, prob, dlog = ops.relation_attention_bwd(q, k, kt, vw, bias, dY, y, mod.bout, qt, dyt, M)
-    dwp, dbp = ops.geometry_bias_bwd(bx, bias, dlog, M)
+    dwp, dbp = ops.geometry_bias_bwd(bx, bias, dlog, M, fast=(dtype == torch.bfloat16))
     # ---- projections: Q|K = F [Wq;Wk]^T + b,  VW = F_K Wout^T
     dqk = torch.zeros((B, N, 2 * d), device=f.device, dtype=dtype)
     dqk[:, :, :d] = dq
