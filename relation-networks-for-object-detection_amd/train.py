@@ -526,6 +526,53 @@ class Trainer(object):
         self._add_bgrad('pair_pos_fc1_%d' % i, r['pair_pos_fc1_%d_bias' % i])
         return (r['d_roi_feat'] + g.float()).to(torch.bfloat16)          # residual path + module path
 
+    # ---- checkpoint view -----------------------------------------------------------------------------------
+    def export_params(self):
+        """The trainable parameters back under the reference's names and layouts (fp32, on the host): convolution
+        weights [O,I,kh,kw] with the folded BatchNorm scale divided out again, fc_new_1 / roi_pool_fc1 columns back in
+        (c, ph, pw) order, the fused RPN / query|key / cls|bbox matrices split.  Frozen tensors are not returned."""
+        out = {}
+        wv = lambda n: self.W.view(self.W.master, n).detach().cpu()
+        bv = lambda n: self.Bv.view(self.Bv.master, n).detach().cpu()
+
+        def unpack(w2d, k):
+            o = w2d.shape[0]
+            return w2d.view(o, k, k, -1).permute(0, 3, 1, 2).contiguous()
+
+        for name in self.W.slices:
+            if name in self.bn_scale:                                   # res3..res5 convolutions
+                out[name + '_weight'] = unpack(wv(name) / self.bn_scale[name].cpu().view(-1, 1), self.ksize[name])
+            elif name.startswith('fpn_') or name in ('rpn_conv_3x3', 'conv_new_1') or name.endswith('_offset'):
+                out[name + '_weight'] = unpack(wv(name), self.ksize.get(name, 1)); out[name + '_bias'] = bv(name)
+        if not self.fpn:
+            w, b = wv('rpn_out'), bv('rpn_out')
+            out['rpn_cls_score_weight'], out['rpn_bbox_pred_weight'] = unpack(w[:self.na2], 1), unpack(w[self.na2:], 1)
+            out['rpn_cls_score_bias'], out['rpn_bbox_pred_bias'] = b[:self.na2].clone(), b[self.na2:].clone()
+        inv = torch.empty_like(self.fc1_perm); inv[self.fc1_perm] = torch.arange(len(self.fc1_perm))
+        n1, n2 = self.fc_names
+        out[n1 + '_weight'], out[n1 + '_bias'] = wv('fc_new_1')[:, inv].contiguous(), bv('fc_new_1')
+        out[n2 + '_weight'], out[n2 + '_bias'] = wv('fc_new_2').clone(), bv('fc_new_2')
+        nc = self.num_classes
+        out['cls_score_weight'], out['bbox_pred_weight'] = wv('cls_bbox')[:nc].clone(), wv('cls_bbox')[nc:].clone()
+        out['cls_score_bias'], out['bbox_pred_bias'] = bv('cls_bbox')[:nc].clone(), bv('cls_bbox')[nc:].clone()
+        mods = [('', i) for i in (1, 2)] + ([('nms_', 1)] if self.cfg.learn_nms else [])
+        for pre, i in mods:
+            qk, bq = wv('%sqk_%d' % (pre, i)), bv('%sqk_%d' % (pre, i))
+            h = qk.shape[0] // 2
+            out['%squery_%d_weight' % (pre, i)], out['%skey_%d_weight' % (pre, i)] = qk[:h].clone(), qk[h:].clone()
+            out['%squery_%d_bias' % (pre, i)], out['%skey_%d_bias' % (pre, i)] = bq[:h].clone(), bq[h:].clone()
+            wo = wv('%slinear_out_%d' % (pre, i))
+            out['%slinear_out_%d_weight' % (pre, i)] = wo.reshape(wo.shape[0], wo.shape[1], 1, 1).clone()
+            out['%slinear_out_%d_bias' % (pre, i)] = bv('%slinear_out_%d' % (pre, i))
+            out['%spair_pos_fc1_%d_weight' % (pre, i)] = wv('%spair_pos_fc1_%d' % (pre, i)).clone()
+            out['%spair_pos_fc1_%d_bias' % (pre, i)] = bv('%spair_pos_fc1_%d' % (pre, i))
+        if self.cfg.learn_nms:
+            for n in ('nms_rank', 'roi_feat_embedding', 'nms_logit'):
+                out[n + '_weight'], out[n + '_bias'] = wv(n).clone(), bv(n)
+        if self.cfg.dcn:
+            out['offset_weight'], out['offset_bias'] = wv('offset')[:, inv].contiguous(), bv('offset')
+        return out
+
     # ---- optimizer ----------------------------------------------------------------------------------------
     def all_reduce(self):
         """ONE summed all-reduce per flat buffer over RCCL (MXNet kvstore 'device' + rescale_grad 1.0 semantics)."""

@@ -252,3 +252,30 @@ def test_fpn_training_step_gradients_match_autograd():
         if nw > 1e-9 and (cos < cmin or abs(ng / nw - 1) > nmax):
             bad.append(report[-1])
     assert not bad, '\n'.join(bad) + '\n--- all ---\n' + '\n'.join(report)
+
+
+@pytest.mark.parametrize('kind', ['c4', 'dcn', 'fpn'])
+def test_export_params_round_trip(kind):
+    """Trainer keeps its weights in kernel layouts (BN folded, fc1 columns permuted, fused matrices): export_params must give
+    back exactly the reference-named tensors it was built from -- before any step, and a changed tensor after one."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import backbone, train, dist
+    p = backbone.init_params(seed=5, dcn_offset_std=0.01 if kind == 'dcn' else 0.0, fpn=(kind == 'fpn'))
+    g = torch.Generator().manual_seed(6)
+    for k in list(p):                      # non-trivial BN statistics so that the fold / unfold is exercised
+        if k.endswith('_gamma'):
+            p[k] = torch.rand(p[k].shape, generator=g) + 0.5
+        if k.endswith('_moving_var'):
+            p[k] = torch.rand(p[k].shape, generator=g) + 0.5
+    cfg = train.TrainConfig(); cfg.learn_nms = True; cfg.dcn = (kind == 'dcn')
+    tr = train.FPNTrainer(p, cfg) if kind == 'fpn' else train.Trainer(p, cfg, im_hw=(128, 160))
+    out = tr.export_params()
+    skip_fpn = ('rpn_', 'conv_new_1', 'fc_new_')
+    expected = [k for k in p if dist.is_trainable(k) and 'moving_' not in k and not k.startswith('fpn_ft64')      # moving_* = aux states
+                and not (kind == 'fpn' and k.startswith(skip_fpn)) and not (kind != 'fpn' and k.startswith(('fpn_', 'roi_pool_fc')))
+                and not (kind != 'dcn' and ('offset' in k))]
+    assert sorted(out) == sorted(expected), (sorted(set(out) ^ set(expected)))
+    for k in expected:
+        assert out[k].shape == p[k].shape, k
+        assert torch.allclose(out[k], p[k].float(), rtol=2e-6, atol=1e-7), k
+    assert sum(v.numel() for v in out.values()) == tr.num_trainable()
