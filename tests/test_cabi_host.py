@@ -196,3 +196,22 @@ def test_assign_anchor_matches_reference_loader():
         assert np.array_equal(L, g[name + '/label'][0]) and np.array_equal(W, g[name + '/bbox_weight'][0])
         assert np.abs(T - g[name + '/bbox_target'][0]).max() <= 2e-6
     assert int((g['crowded/label'] == 1).sum()) == 128          # the fg subsampling branch is exercised
+
+
+def test_every_registered_reference_op_name_resolves():
+    """The six names the reference registers with mx.operator.register (SURVEY.md section 8b) all have a Prop here;
+    `monitor` is a pure host identity and runs on CPU tensors."""
+    import torch
+    import relnet_amd  # noqa: F401
+    from relnet_amd import operator_py
+    for name in ('proposal', 'proposal_target', 'BoxAnnotatorOHEM', 'learn_nms', 'nms_multi_target', 'monitor'):
+        assert operator_py.get_prop(name) is not None
+    from relnet_amd.operator_py.monitor_op import monitor_wrapper, MonitorProp
+    x = torch.arange(12.0).view(3, 4)
+    assert torch.equal(monitor_wrapper(x, 'tap'), x)
+    prop = MonitorProp('tap')
+    assert prop.list_arguments() == ['input'] and prop.infer_shape([(3, 4)]) == ([(3, 4)], [(3, 4)])
+    op = prop.create_operator(None, None, None)
+    g = torch.zeros(3, 4)
+    op.backward(['write'], [x], [x], [x], [g], [])
+    assert torch.equal(g, x)
