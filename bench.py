@@ -313,7 +313,7 @@ def main():
                 if os.path.exists(pmc):
                     traffic = json.load(open(pmc)).get('hbm_bytes_per_launch_at_batch', {}).get(str(a.batch))
                 res['roofline'] = {
-                    'kernel': 'relation_attention_kernel (csrc/relation.hip)', 'bound': 'mfma',
+                    'kernel': 'relation_attention_lds_kernel (csrc/relation.hip; the fp32 run uses relation_attention_kernel)', 'bound': 'mfma',
                     'achieved': algo, 'peak': peak, 'unit': 'TFLOP/s', 'frac': algo / peak, 'traffic': traffic,
                     'executed': EXEC_GFLOP_PER_MODULE_IMAGE * rs * a.batch / 1e3 / sec,
                     'launch_ms': att['avg_ms'], 'launches': att['calls'],
