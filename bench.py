@@ -90,6 +90,33 @@ def cpu_baseline(params, relation=True, soft=True, images=4, seed=123, threads=3
                        % (images, cores, per, 1e3 * sum(t_post) / len(t_post)))
 
 
+def attention_isolated(batch, n_rois, dtype, launches=100, warm=10):
+    """SURVEY 8d protocol for the relation-attention kernel on its own: `launches` back-to-back launches after `warm`
+    warm-ups on seeded synthetic operands of the bench shape, one HIP-event pair per launch; returns the median in ms."""
+    from relnet_amd import ops, relation
+    g = torch.Generator().manual_seed(7)
+    B, N, H, Mpad = batch, n_rois, 16, (n_rois + 31) // 32 * 32
+    qk = (torch.randn(B, N, 2048, generator=g) * 0.5).cuda().to(dtype)
+    vwt = torch.zeros(B, 1024, Mpad, device='cuda', dtype=dtype)
+    vwt[:, :, :N] = (torch.randn(B, 1024, N, generator=g) * 0.5).cuda().to(dtype)
+    half = dtype == torch.bfloat16
+    bias = (torch.randn(B, H, N, Mpad, generator=g) - 3.0).cuda().to(torch.float16 if half else torch.float32)
+    resid = torch.randn(B, N, 1024, generator=g).cuda().to(dtype)
+    bout = torch.zeros(1024, device='cuda')
+    run = lambda: ops.relation_attention(qk[:, :, :1024], qk[:, :, 1024:], vwt, bias, bout=bout, resid=resid, M=N,
+                                         want_out=False, want_act=True)
+    for _ in range(warm):
+        run()
+    evs = []
+    for _ in range(launches):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); run(); e.record()
+        evs.append((s, e))
+    torch.cuda.synchronize()
+    ms = sorted(s.elapsed_time(e) for s, e in evs)
+    return ms[len(ms) // 2]
+
+
 def bench_train(a, rank, world, D):
     """Training throughput of the relation end2end graph (reference config ..._end2end_relation_8epoch.yaml): one step =
     forward + backward over `batch` images per GPU, ONE summed all-reduce of the 67.7 M trainable gradients, SGD."""
@@ -317,8 +344,10 @@ def main():
                     'achieved': algo, 'peak': peak, 'unit': 'TFLOP/s', 'frac': algo / peak, 'traffic': traffic,
                     'executed': EXEC_GFLOP_PER_MODULE_IMAGE * rs * a.batch / 1e3 / sec,
                     'launch_ms': att['avg_ms'], 'launches': att['calls'],
-                    'algorithmic_gflop_per_launch': ALGO_GFLOP_PER_MODULE_IMAGE * a.batch,
+                    'algorithmic_gflop_per_launch': ALGO_GFLOP_PER_MODULE_IMAGE * rs * a.batch,
                 }
+                iso = attention_isolated(a.batch, n_rois, tdt)           # kernel alone: median of 100 launches
+                res['roofline'].update(isolated_median_ms=iso, isolated_frac=ALGO_GFLOP_PER_MODULE_IMAGE * rs * a.batch / iso / peak)
         if world == 1 and not a.no_cpu_baseline and not a.dcn and not a.fpn:      # the CPU port of the DCN graph is parity-only (slow)
             res['cpu_baseline'] = cpu_baseline(params, relation=not a.no_relation, images=a.cpu_images, threads=a.cpu_threads)
         print(json.dumps(res))
