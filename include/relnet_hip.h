@@ -135,6 +135,12 @@ int relnet_detect_head(const float* cls_score, long cs_ld, const float* bbox_pre
  * threshold), float64 like numpy; dets [B,C-1,N,5] in pick order, counts [B,C-1].                    */
 int relnet_class_nms(const float* cls_prob, const double* boxes, double* dets, int* counts, int B, int N, int C,
                      float score_thresh, double nms_param, int soft, int max_picks, void* stream);
+/* same, for the `py_nms_wrapper` / `py_softnms_wrapper` call form of lib/nms/nms.py:21-31 (one class, float64
+ * `dets`): scores64 [B,N] replaces cls_prob when non-null (then C == 2); pick_index [B,C-1,N] (nullable) receives
+ * the roi index of every pick = the `keep` list of nms.py:45-82.                                           */
+int relnet_class_nms_ex(const float* cls_prob, const double* scores64, const double* boxes, double* dets, int* counts,
+                        int* pick_index, int B, int N, int C, float score_thresh, double nms_param, int soft,
+                        int max_picks, void* stream);
 /* tester.py:270-277: image threshold = max_per_image-th largest score; out [B,max_out,6] =
  * (class, score, x1, y1, x2, y2), class-major in pick order.                                        */
 int relnet_image_topk(const double* dets, const int* counts, double* thresh, int* total, float* out,
@@ -178,6 +184,10 @@ int relnet_box_annotator_ohem(const float* cls_score, const float* bbox_pred, co
                               const float* bbox_targets, const float* bbox_weights, float* labels_ohem,
                               float* weights_ohem, float* loss, int B, int R, int C, int D, int roi_per_img,
                               void* stream);
+/* lib/bbox/bbox.pyx:15-55 bbox_overlaps_cython: float64 IoU matrix with +1 extents, 0 when disjoint;
+ * boxes [N,4], query_boxes [K,4], overlaps [N,K] -- DEVICE pointers (the Python twin relnet_amd/bbox/bbox.py
+ * does the host copies when handed numpy arrays, as the Cython module's callers do).                      */
+int relnet_bbox_overlaps(const double* boxes, const double* query_boxes, double* overlaps, int N, int K, void* stream);
 /* operator_py/nms_multi_target.py:24-74: per class and IoU threshold, the highest-scoring box among those
  * whose arg-max gt is g and IoU > t gets target 1.  thresh: HOST double[T], T <= 8; first_n <= 256.      */
 int relnet_nms_multi_target(const float* bbox, const float* gt, const int* num_gt, const float* score, float* out,

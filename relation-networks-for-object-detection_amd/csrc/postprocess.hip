@@ -67,6 +67,9 @@ struct ClsNmsArgs {
   int max_picks;             // stop after this many picks per class (picks come out in
                              // non-increasing score order, so the first max_per_image picks of a
                              // class are the only ones that can survive tester.py:270-277)
+  const double* scores64;    // optional [B, N] float64 scores of a SINGLE class (C == 2): used instead of cls_prob
+                             // (the lib/nms/nms.py wrappers take float64 `dets`)
+  int* pick_index;           // optional [B, C-1, N]: roi index of every pick (`keep` of nms.py:45-82)
 };
 
 // kPerLane * 64 >= N candidates per (image, class)
@@ -84,9 +87,9 @@ __global__ __launch_bounds__(64) void class_nms_kernel(ClsNmsArgs g) {
     sc[s] = -1.0;
     x1[s] = y1[s] = x2[s] = y2[s] = area[s] = 0.0;
     if (i < g.N) {
-      const float p = prob[(long)i * g.C + cls];
-      if (p > g.score_thresh) {
-        sc[s] = (double)p;
+      const double p = g.scores64 ? g.scores64[(long)b * g.N + i] : (double)prob[(long)i * g.C + cls];
+      if (p > (double)g.score_thresh) {
+        sc[s] = p;
         x1[s] = bx[i * 4 + 0]; y1[s] = bx[i * 4 + 1]; x2[s] = bx[i * 4 + 2]; y2[s] = bx[i * 4 + 3];
         area[s] = (x2[s] - x1[s] + 1) * (y2[s] - y1[s] + 1);
         ++n;
@@ -120,6 +123,7 @@ __global__ __launch_bounds__(64) void class_nms_kernel(ClsNmsArgs g) {
     if (lane == 0) {
       double* o = out + (long)picked * 5;
       o[0] = px1; o[1] = py1; o[2] = px2; o[3] = py2; o[4] = best;
+      if (g.pick_index) g.pick_index[((long)b * (g.C - 1) + (cls - 1)) * g.N + picked] = bi;
     }
     ++picked;
 #pragma unroll
@@ -162,9 +166,9 @@ __global__ __launch_bounds__(256) void class_nms_block_kernel(ClsNmsArgs g) {
     sc[s] = -1.0;
     x1[s] = y1[s] = x2[s] = y2[s] = area[s] = 0.0;
     if (i < g.N) {
-      const float p = prob[(long)i * g.C + cls];
-      if (p > g.score_thresh) {
-        sc[s] = (double)p;
+      const double p = g.scores64 ? g.scores64[(long)b * g.N + i] : (double)prob[(long)i * g.C + cls];
+      if (p > (double)g.score_thresh) {
+        sc[s] = p;
         x1[s] = bx[i * 4 + 0]; y1[s] = bx[i * 4 + 1]; x2[s] = bx[i * 4 + 2]; y2[s] = bx[i * 4 + 3];
         area[s] = (x2[s] - x1[s] + 1) * (y2[s] - y1[s] + 1);
         ++n;
@@ -210,6 +214,7 @@ __global__ __launch_bounds__(256) void class_nms_block_kernel(ClsNmsArgs g) {
     if (tid == 0) {
       double* o = out + (long)picked * 5;
       o[0] = px1; o[1] = py1; o[2] = px2; o[3] = py2; o[4] = best;
+      if (g.pick_index) g.pick_index[((long)b * (g.C - 1) + (cls - 1)) * g.N + picked] = bi;
     }
     ++picked;
 #pragma unroll
@@ -342,18 +347,27 @@ extern "C" int relnet_detect_head(const float* cls_score, long cs_ld, const floa
   return check_launch("relnet_detect_head");
 }
 
-extern "C" int relnet_class_nms(const float* cls_prob, const double* boxes, double* dets, int* counts,
-                                int B, int N, int C, float score_thresh, double nms_param, int soft,
-                                int max_picks, void* stream) {
-  RELNET_REQUIRE(cls_prob && boxes && dets && counts, "relnet_class_nms: null operand");
+extern "C" int relnet_class_nms_ex(const float* cls_prob, const double* scores64, const double* boxes, double* dets,
+                                   int* counts, int* pick_index, int B, int N, int C, float score_thresh,
+                                   double nms_param, int soft, int max_picks, void* stream) {
+  RELNET_REQUIRE((cls_prob || scores64) && boxes && dets && counts, "relnet_class_nms: null operand");
   RELNET_REQUIRE(B > 0 && N > 0 && N <= 1024 && C > 1, "relnet_class_nms: need 0 < N <= 1024 (N=%d)", N);
-  ClsNmsArgs g{cls_prob, boxes, dets, counts, N, C, score_thresh, nms_param, soft, max_picks > 0 ? max_picks : N};
+  RELNET_REQUIRE(!scores64 || C == 2, "relnet_class_nms: float64 scores are one foreground class (C == 2), got C=%d", C);
+  ClsNmsArgs g{cls_prob, boxes, dets, counts, N, C, score_thresh, nms_param, soft, max_picks > 0 ? max_picks : N,
+               scores64, pick_index};
   dim3 grid(C - 1, B);
   hipStream_t s = (hipStream_t)stream;
   if (N <= 320) class_nms_kernel<5><<<grid, 64, 0, s>>>(g);
   else if (N <= 512) class_nms_kernel<8><<<grid, 64, 0, s>>>(g);
   else class_nms_block_kernel<4><<<grid, 256, 0, s>>>(g);
   return check_launch("relnet_class_nms");
+}
+
+extern "C" int relnet_class_nms(const float* cls_prob, const double* boxes, double* dets, int* counts,
+                                int B, int N, int C, float score_thresh, double nms_param, int soft,
+                                int max_picks, void* stream) {
+  return relnet_class_nms_ex(cls_prob, nullptr, boxes, dets, counts, nullptr, B, N, C, score_thresh, nms_param, soft,
+                             max_picks, stream);
 }
 
 extern "C" int relnet_image_topk(const double* dets, const int* counts, double* thresh, int* total,

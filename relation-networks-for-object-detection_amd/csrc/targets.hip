@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void proposal_target_kernel(PTArgs g) {
   for (int c = 0; c < 4 * g.num_reg; ++c) { bt[c] = 0.f; bwp[c] = 0.f; }
   if (r >= g.N + G) {                         // padding row (image has fewer than Gmax gt boxes)
     for (int c = 0; c < 5; ++c) ro[c] = 0.f;
+    ro[0] = (float)b;                         // still a valid image index for the batched pooling kernels
     g.label[(long)b * R + r] = -1.f;
     return;
   }
@@ -51,8 +52,8 @@ __global__ __launch_bounds__(256) void proposal_target_kernel(PTArgs g) {
     const float* p = g.rois + ((long)b * g.N + r) * 5;
     ro[0] = p[0];
     for (int c = 0; c < 4; ++c) box[c] = p[1 + c];
-  } else {                                    // proposal_target.py:64-67: gt boxes appended, batch idx 0
-    ro[0] = 0.f;
+  } else {                                    // proposal_target.py:64-67: gt boxes appended with batch idx 0 -- the
+    ro[0] = (float)b;                         // reference runs one image per executor; batched: the image's own index
     for (int c = 0; c < 4; ++c) box[c] = gtb[(r - g.N) * 5 + c];
   }
   for (int c = 0; c < 4; ++c) ro[1 + c] = box[c];
@@ -245,6 +246,30 @@ __global__ __launch_bounds__(kNmtF) void nms_multi_target_kernel(NMTArgs g) {
 }  // namespace relnet
 
 using namespace relnet;
+
+// ---------------------------------------------------------------------------------------
+// lib/bbox/bbox.pyx:15-55 `bbox_overlaps_cython(boxes f64 [N,4], query_boxes f64 [K,4]) -> f64 [N,K]`
+// (callers: core/rcnn.py:303, operator_py/nms_multi_target.py:51, lib/rpn/rpn.py:163): one thread per (n, k).
+namespace relnet {
+struct OverlapArgs { const double* boxes; const double* query; double* out; int N, K; };
+__global__ __launch_bounds__(256) void bbox_overlaps_kernel(OverlapArgs g) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)g.N * g.K) return;
+  const int n = (int)(t / g.K), k = (int)(t - (long)n * g.K);
+  g.out[t] = iou64(g.boxes + 4L * n, g.query + 4L * k);
+}
+}  // namespace relnet
+
+extern "C" int relnet_bbox_overlaps(const double* boxes, const double* query_boxes, double* overlaps, int N, int K,
+                                    void* stream) {
+  RELNET_REQUIRE(N >= 0 && K >= 0, "relnet_bbox_overlaps: bad shape N=%d K=%d", N, K);
+  if (N == 0 || K == 0) return 0;
+  RELNET_REQUIRE(boxes && query_boxes && overlaps, "relnet_bbox_overlaps: null operand");
+  relnet::OverlapArgs g{boxes, query_boxes, overlaps, N, K};
+  const long total = (long)N * K;
+  relnet::bbox_overlaps_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(g);
+  return check_launch("relnet_bbox_overlaps");
+}
 
 extern "C" int relnet_proposal_target(const float* rois, const float* gt, const int* num_gt, float* rois_out,
                                       float* label, float* bbox_target, float* bbox_weight, int B, int N, int Gmax,

@@ -66,6 +66,15 @@ class Detector(object):
         self.anchors = torch.as_tensor(generate_anchors(self.cfg.feat_stride, self.cfg.anchor_ratios,
                                                         self.cfg.anchor_scales), dtype=torch.float64, device=device)
 
+    @classmethod
+    def from_checkpoint(cls, prefix, epoch, **kw):
+        """Test-time construction from an MXNet `.params` file, as function/test_rcnn.py:57 does:
+        `load_param(prefix, epoch, process=True)` -- the `*_test` tensors (bbox_pred de-normalised by
+        BBOX_STDS / MEANS, core/callback.py:54-61) replace their training-time names."""
+        from . import checkpoint as ck
+        arg, aux = ck.load_param(prefix, epoch, process=True)
+        return cls(ck.merge_params(arg, aux), **kw)
+
     def forward(self, data, im_info, post=True):
         """data [B,3,H,W], im_info [B,3] fp32 (device).  No host synchronisation inside."""
         c = self.cfg

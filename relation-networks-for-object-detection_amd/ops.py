@@ -258,18 +258,40 @@ def detect_head(cls_score, bbox_pred, rois, im_info, rois_per_image, delta_off=4
     return prob, boxes
 
 
-def class_nms(cls_prob, boxes, score_thresh=1e-3, nms_param=0.6, soft=True, max_picks=0):
+def class_nms(cls_prob, boxes, score_thresh=1e-3, nms_param=0.6, soft=True, max_picks=0, scores64=None,
+              want_index=False):
     """cls_prob [B,N,C] fp32, boxes [B,N,4] float64 -> dets [B,C-1,N,5] float64 (pick order),
     counts [B,C-1] int32.  max_picks > 0 truncates every class list after that many picks
-    (exactly the rows that can survive the image-level max_per_image cut)."""
-    _chk(cls_prob, boxes)
-    B, N, Cn = cls_prob.shape
-    assert cls_prob.is_contiguous() and boxes.is_contiguous() and boxes.dtype == torch.float64
-    dets = torch.zeros((B, Cn - 1, N, 5), device=cls_prob.device, dtype=torch.float64)
-    counts = torch.empty((B, Cn - 1), device=cls_prob.device, dtype=torch.int32)
-    _lib.call('relnet_class_nms', cls_prob.data_ptr(), boxes.data_ptr(), dets.data_ptr(), counts.data_ptr(),
-              B, N, Cn, float(score_thresh), float(nms_param), int(soft), int(max_picks), _stream())
-    return dets, counts
+    (exactly the rows that can survive the image-level max_per_image cut).
+    scores64 [B,N] float64 (one class; cls_prob None) is the `dets[:, 4]` form of lib/nms/nms.py;
+    want_index also returns pick_index [B,C-1,N] int32 (roi index of every pick)."""
+    _chk(cls_prob, boxes, scores64)
+    if scores64 is not None:
+        assert cls_prob is None and scores64.dtype == torch.float64 and scores64.is_contiguous()
+        B, N = scores64.shape
+        Cn = 2
+    else:
+        B, N, Cn = cls_prob.shape
+        assert cls_prob.is_contiguous() and cls_prob.dtype == torch.float32
+    assert boxes.is_contiguous() and boxes.dtype == torch.float64 and boxes.shape == (B, N, 4)
+    dets = torch.zeros((B, Cn - 1, N, 5), device=boxes.device, dtype=torch.float64)
+    counts = torch.empty((B, Cn - 1), device=boxes.device, dtype=torch.int32)
+    index = torch.full((B, Cn - 1, N), -1, device=boxes.device, dtype=torch.int32) if want_index else None
+    _lib.call('relnet_class_nms_ex', _ptr(cls_prob), _ptr(scores64), boxes.data_ptr(), dets.data_ptr(), counts.data_ptr(),
+              _ptr(index), B, N, Cn, float(score_thresh), float(nms_param), int(soft), int(max_picks), _stream())
+    return (dets, counts, index) if want_index else (dets, counts)
+
+
+def bbox_overlaps(boxes, query_boxes):
+    """float64 IoU matrix [N,K] of device tensors boxes [N,4], query_boxes [K,4] (lib/bbox/bbox.pyx:15-55)."""
+    _chk(boxes, query_boxes)
+    assert boxes.dtype == torch.float64 and query_boxes.dtype == torch.float64
+    boxes, query_boxes = boxes.contiguous(), query_boxes.contiguous()
+    N, K = boxes.shape[0], query_boxes.shape[0]
+    assert boxes.shape == (N, 4) and query_boxes.shape == (K, 4)
+    out = torch.zeros((N, K), device=boxes.device, dtype=torch.float64)
+    _lib.call('relnet_bbox_overlaps', boxes.data_ptr(), query_boxes.data_ptr(), out.data_ptr(), N, K, _stream())
+    return out
 
 
 def image_topk(dets, counts, max_per_image=100, max_out=None):

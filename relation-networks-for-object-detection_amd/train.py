@@ -88,6 +88,10 @@ class Trainer(object):
         f32 = lambda t: torch.as_tensor(t).to(dev, torch.float32).contiguous()
         self.fpn = bool(getattr(c, 'fpn', False))
         self.units = unit_names(self.fpn)
+        # the tensors this step never changes (frozen by name, cfgs/*.yaml:23-29, and the BatchNorm running statistics):
+        # kept on the host under the reference's names so that a checkpoint holds the complete arg / aux dictionaries
+        self._fixed_src = {k: torch.as_tensor(v).detach().to('cpu', torch.float32).clone() for k, v in params.items()
+                           if ('moving_' in k) or not D.is_trainable(k)}
         # ---- frozen part (conv1, res2): the inference kernels with folded BN
         self.frozen = {}
         w1, b1 = fold_bn(params['conv1_weight'], params['bn_conv1_gamma'], params['bn_conv1_beta'],
@@ -572,6 +576,27 @@ class Trainer(object):
         if self.cfg.dcn:
             out['offset_weight'], out['offset_bias'] = wv('offset')[:, inv].contiguous(), bv('offset')
         return out
+
+    def checkpoint_params(self):
+        """(arg_params, aux_params) as MXNet's Module hands them to the epoch-end callback (core/module.py fit ->
+        callback.do_checkpoint): every trainable tensor (export_params) plus the frozen ones under `arg`, the BatchNorm
+        running statistics under `aux`.  `checkpoint.do_checkpoint(prefix, means, stds)` turns them into the reference's
+        `.params` file incl. the de-normalised `bbox_pred_*_test` pair (core/callback.py:54-61)."""
+        arg = self.export_params()
+        aux = {}
+        for k, v in self._fixed_src.items():
+            (aux if 'moving_' in k else arg).setdefault(k, v.clone())
+        return arg, aux
+
+    def save_checkpoint(self, prefix, epoch):
+        """`<prefix>-<epoch+1:04d>.params` exactly as train_end2end.py:149-152 + core/callback.py:54-61 write it
+        (means / stds tiled over the regression classes: 2 when class agnostic)."""
+        from . import checkpoint as ck
+        c = self.cfg
+        reps = 2 if getattr(c, 'class_agnostic', True) else c.num_classes
+        means, stds = list(c.bbox_means) * reps, list(c.bbox_stds) * reps
+        arg, aux = self.checkpoint_params()
+        return ck.do_checkpoint(prefix, means, stds)(epoch, None, arg, aux)
 
     # ---- optimizer ----------------------------------------------------------------------------------------
     def all_reduce(self):

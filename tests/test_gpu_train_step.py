@@ -279,3 +279,66 @@ def test_export_params_round_trip(kind):
         assert out[k].shape == p[k].shape, k
         assert torch.allclose(out[k], p[k].float(), rtol=2e-6, atol=1e-7), k
     assert sum(v.numel() for v in out.values()) == tr.num_trainable()
+
+
+def test_batched_step_equals_sum_of_single_image_steps():
+    """Two images in ONE step: the appended gt rows of image 1 must pool from image 1 (their roi batch index is the image's
+    own, csrc/targets.hip) -- the gradient of the 2-image step equals the sum of the two 1-image steps (MXNet sums the
+    per-device gradients, rescale_grad = 1.0, train_end2end.py:167)."""
+    H, W, G = 128, 160, 4
+    p, cfg, data0, gt0, L0, T0, W0, train = _setup(H, W, G, 51)
+    _, _, data1, gt1, L1, T1, W1, _ = _setup(H, W, G, 52)
+    tr = train.Trainer(p, cfg, im_hw=(H, W))
+    d = lambda a: torch.as_tensor(a).cuda()
+    info = torch.tensor([[H, W, 1.0]]).cuda()
+    grads, rois1 = [], []
+    for data, gt, L, Tg, Wg in ((data0, gt0, L0, T0, W0), (data1, gt1, L1, T1, W1)):
+        out = tr.forward_backward(data.cuda(), info, d(gt), d(L[None]), d(Tg[None]), d(Wg[None]))
+        grads.append((tr.W.grad.clone(), tr.Bv.grad.clone()))
+        rois1.append(out['rois'][0].clone())
+    out = tr.forward_backward(torch.cat([data0, data1]).cuda(), info.repeat(2, 1), d(np.concatenate([gt0, gt1])),
+                              d(np.stack([L0, L1])), d(np.stack([T0, T1])), d(np.stack([W0, W1])))
+    N = cfg.rpn_post_nms_top_n
+    for b in range(2):
+        r = out['rois'][b]
+        assert (r[:, 0] == b).all(), "every roi row (proposals, gt rows, padding) carries its image's index"
+        assert torch.equal(r[:, 1:], rois1[b][:, 1:])
+        assert torch.equal(r[N:N + G, 1:], d(np.concatenate([gt0, gt1]))[b, :, :4])
+    for got, a, b_, kind in ((tr.W.grad, grads[0][0], grads[1][0], 'weights'), (tr.Bv.grad, grads[0][1], grads[1][1], 'biases')):
+        want = (a + b_).double()
+        g = got.double()
+        cos = float((g * want).sum() / (g.norm() * want.norm()))
+        assert cos > 0.9995 and abs(float(g.norm() / want.norm()) - 1) < 5e-3, (kind, cos, float(g.norm() / want.norm()))
+        # and it is NOT what pooling image 1's gt rows from image 0 would give: the per-image gradients differ
+        assert float((a.double() * b_.double()).sum() / (a.norm() * b_.norm()).double()) < 0.99
+
+
+def test_checkpoint_round_trip_into_detector(tmp_path):
+    """Trainer -> `.params` (core/callback.py:54-61) -> Detector.from_checkpoint (load_param(process=True),
+    lib/utils/load_model.py:63-66): the test-time detector decodes with the DE-NORMALISED bbox_pred layer."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import checkpoint as ck, detector
+    H, W, G = 128, 160, 4
+    p, cfg, data, gt, L, Tg, Wg, train = _setup(H, W, G, 61)
+    tr = train.Trainer(p, cfg, im_hw=(H, W))
+    d = lambda a: torch.as_tensor(a).cuda()
+    info = torch.tensor([[H, W, 1.0]]).cuda()
+    tr.step(data.cuda(), info, d(gt), d(L[None]), d(Tg[None]), d(Wg[None]))
+    prefix = str(tmp_path / 'e2e')
+    path = tr.save_checkpoint(prefix, 0)
+    assert path.endswith('e2e-0001.params')
+    arg, aux = ck.load_param(prefix, 1)
+    have = set(arg) | set(aux)
+    need = {k for k in p if not k.startswith(('fpn_', 'roi_pool_fc', 'nms_')) and 'offset' not in k}
+    assert need <= have, sorted(need - have)[:8]
+    assert torch.equal(torch.as_tensor(arg['conv1_weight']), p['conv1_weight'])                   # frozen: untouched
+    assert not torch.equal(torch.as_tensor(arg['fc_new_2_weight']), p['fc_new_2_weight'])         # trained: moved
+    stds = torch.tensor(cfg.bbox_stds * 2)
+    assert torch.allclose(torch.as_tensor(arg['bbox_pred_weight_test']), torch.as_tensor(arg['bbox_pred_weight']) * stds[:, None])
+    dcfg = detector.Config(); dcfg.rpn_post_nms_top_n = 40
+    det = detector.Detector.from_checkpoint(prefix, 1, im_hw=(H, W), cfg=dcfg)
+    nc = det.head.num_classes
+    w_train = tr.W.view(tr.W.master, 'cls_bbox')[nc:].cpu()
+    assert torch.allclose(det.head.wcb[nc:].float().cpu(), (w_train * stds[:, None]).to(torch.bfloat16).float())
+    out = det.forward(data.cuda(), info)
+    assert torch.isfinite(out['pred_boxes']).all() and out['rois'].shape == (1, 40, 5)
