@@ -482,26 +482,31 @@ static void launch_cfg(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
 }
 
 // configs: 1 = 256x256 (8 waves) 2 = 256x128 (8 waves) 3 = 128x128 (4 waves) 4 = 128x64 5 = 64x64
+enum { GEMM_TILE_COUNT = 5 };
+static int pick_tile(long M, long N, long K, int batch, int out_dtype) {
+  // Picked from on-device timings of every GEMM / convolution shape of the detector at 16
+  // images per launch (tests/_bench_gemm.py; table in DESIGN.md): wide tiles cut the
+  // L2 -> LDS fill traffic of the compute-bound 3x3 / large-K layers, 128-row tiles keep more
+  // workgroups resident for the short-K, store-bound expand convolutions.
+  int cfg;
+  if (N <= 64) cfg = 4;
+  else if (M * batch <= 8192) cfg = (N >= 256 ? 4 : 5);
+  else if (N <= 128) cfg = 3;
+  else if (K <= 128) cfg = 4;
+  else if (N % 256 != 0) cfg = 3;
+  else cfg = 1;
+  // fp32 outputs (weight gradients, column gradients): the 256x256 epilogue needs a second fp32 staging tile and
+  // spills ~180 VGPRs; 256x128 holds everything in registers
+  if (cfg == 1 && out_dtype != RELNET_BF16) cfg = 2;
+  return cfg;
+}
+extern "C" int relnet_gemm_tile_count(void) { return GEMM_TILE_COUNT; }
+extern "C" int relnet_gemm_pick_tile(int M, int N, int K, int batch, int out_dtype) { return pick_tile(M, N, K, batch, out_dtype); }
+
 template <int CONV>
 static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t s) {
-  const long M = g.M, N = g.N;
   int cfg = g_force_tile;
-  if (cfg == 0) {
-    // Picked from on-device timings of every GEMM / convolution shape of the detector at 16
-    // images per launch (tests/_bench_gemm.py; table in DESIGN.md): wide tiles cut the
-    // L2 -> LDS fill traffic of the compute-bound 3x3 / large-K layers, 128-row tiles keep more
-    // workgroups resident for the short-K, store-bound expand convolutions.
-    const long K = g.K;
-    if (N <= 64) cfg = 4;
-    else if (M * batch <= 8192) cfg = (N >= 256 ? 4 : 5);
-    else if (N <= 128) cfg = 3;
-    else if (K <= 128) cfg = 4;
-    else if (N % 256 != 0) cfg = 3;
-    else cfg = 1;
-    // fp32 outputs (weight gradients, column gradients): the 256x256 epilogue needs a second fp32 staging tile and
-    // spills ~180 VGPRs; 256x128 holds everything in registers
-    if (cfg == 1 && out_dtype != RELNET_BF16) cfg = 2;
-  }
+  if (cfg <= 0 || cfg > GEMM_TILE_COUNT) cfg = pick_tile(g.M, g.N, g.K, batch, out_dtype);
   switch (cfg) {
     case 1: launch_cfg<256, 256, 2, 4, CONV>(g, batch, out_dtype, s); break;
     case 2: launch_cfg<256, 128, 4, 2, CONV>(g, batch, out_dtype, s); break;

@@ -66,6 +66,8 @@ _SIGNATURES = {
     'relnet_gemm_force_tile': (None, [_i]),
     'relnet_gemm_force_nloop': (None, [_i]),
     'relnet_gemm_set_swizzle': (None, [_i]),
+    'relnet_gemm_tile_count': (C.c_int, []),
+    'relnet_gemm_pick_tile': (C.c_int, [_i, _i, _i, _i, _i]),
     'relnet_nms_greedy': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     'relnet_stem_bias_relu_pool': (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_lnms_prepare': (C.c_int, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),

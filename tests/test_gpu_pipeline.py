@@ -221,3 +221,61 @@ def test_stem_conv7_matches_torch(rn):
         pooled = ops.stem_bias_relu_pool(got, torch.zeros(64, device='cuda'))
         ref = F.max_pool2d(got.permute(0, 3, 1, 2).float(), 3, 2, 0, ceil_mode=True).permute(0, 2, 3, 1)
         assert torch.equal(pooled.float(), ref)
+
+
+def test_detector_bf16_fullsize_stagewise(rn):
+    """The BENCHMARKED configuration (BASELINE configs[1]): 600x1000 images, 300 rois, bf16, batch > 1, relation head
+    + soft-NMS -- every stage against the oracle on the same inputs (teacher forced), at the sizes at which the
+    256x256 conv tiles, the XCD swizzle and the LDS attention kernel are the ones that run."""
+    ops, backbone, detector = rn
+    H, W, B = 600, 1000, 2
+    p = backbone.init_params(seed=1)
+    g = torch.Generator().manual_seed(11)
+    for k in ('cls_score_weight', 'bbox_pred_weight'):
+        p[k] = torch.randn(p[k].shape, generator=g) * 0.05
+    p['conv_new_1_bias'] = torch.rand(256, generator=g) * 0.1 + 0.05
+    data = torch.randn(B, 3, H, W, generator=g)
+    im_info = torch.tensor([[H, W, 1.0]] * B)
+    det = detector.Detector(p, dtype=torch.bfloat16, im_hw=(H, W))
+    f = det.backbone.forward(data.cuda())
+    out = det.forward(data.cuda(), im_info.cuda())
+    assert out['rois'].shape == (B, 300, 5)
+    # A1/A2: bf16 HIP backbone (~100 layers) vs the float32 torch-CPU restatement
+    with torch.no_grad():
+        c4, c5 = ON.backbone(data, p)
+        cls, box, feat = ON.rpn_and_feat(c4, c5, p)
+    for name, got, want in (('conv4', f['conv4'], c4), ('conv5', f['conv5'], c5), ('conv_new_1', f['conv_new_1_relu'], feat),
+                            ('rpn_cls_score', f['rpn_cls_score'], cls), ('rpn_bbox_pred', f['rpn_bbox_pred'], box)):
+        d_ = got.float().cpu() - want
+        rel_l2 = (d_.norm() / want.norm()).item()
+        rel_max = d_.abs().max().item() / want.abs().max().item()
+        assert rel_l2 < 2.5e-2 and rel_max < 8e-2, (name, rel_l2, rel_max)
+    pn = {k: v.numpy() for k, v in p.items()}
+    for b in range(B):
+        # A3: proposal on the GPU's own RPN maps -> identical roi rows (discrete decisions on identical inputs)
+        prob = ON.rpn_softmax(_np(f['rpn_cls_score'][b:b + 1]))
+        rois_o, _, dbg = OP.proposal(prob, _np(f['rpn_bbox_pred'][b:b + 1]), im_info[b:b + 1].numpy(), 16, det.cfg.anchor_scales,
+                                     det.cfg.anchor_ratios, 6000, 300, 0.7, 0, return_debug=True)
+        rois = _np(out['rois'][b])
+        assert (rois[:, 0] == b).all()
+        n_same = int((np.abs(rois[:, 1:] - rois_o[:, 1:]).max(axis=1) == 0).sum())
+        assert n_same == 300 or np.abs(rois[:, 1:] - rois_o[:, 1:]).max() < 1e-3, (b, n_same)
+        # A4: ROIPooling of the GPU feature map -> bit exact
+        r0 = rois.copy(); r0[:, 0] = 0
+        pooled_o = ORP.roi_pooling(_np(f['conv_new_1_relu'][b:b + 1]), r0)
+        pooled = ops.roi_pool(f['conv_new_1_relu'], out['rois'][b].contiguous(), channels_last_out=True)
+        assert np.array_equal(_np(pooled), pooled_o)
+        # A6/A7: bf16 2FC + relation head vs the float32 oracle on the same pooled features
+        r = OR.relation_head(pooled_o, r0, pn, return_intermediates=True)
+        for key in ('cls_score', 'bbox_pred'):
+            want = r[key]
+            err = np.abs(_np(out[key][b]) - want).max() / max(np.abs(want).max(), 1e-3)
+            assert err <= 3e-2, (key, b, err)
+        # A9: post-processing of the GPU's probabilities / boxes (float64, exact up to exp ulps)
+        full = np.zeros((300, 8)); full[:, 4:8] = out['pred_boxes'][b].cpu().numpy()
+        prob0 = _np(out['cls_prob'][b])
+        want = OPP.detections(prob0, full, 81, 1e-3, 0.6, True, 100)
+        n = int(out['num_detections'][b])
+        flat = np.concatenate([np.hstack((np.full((len(w_), 1), c + 1.0), w_[:, 4:5], w_[:, :4])) for c, w_ in enumerate(want)])
+        assert n == len(flat), (n, len(flat))
+        np.testing.assert_allclose(_np(out['detections'][b, :n]), flat.astype(np.float32), rtol=1e-5)
