@@ -329,7 +329,7 @@ def test_checkpoint_round_trip_into_detector(tmp_path):
     assert path.endswith('e2e-0001.params')
     arg, aux = ck.load_param(prefix, 1)
     have = set(arg) | set(aux)
-    need = {k for k in p if not k.startswith(('fpn_', 'roi_pool_fc', 'nms_')) and 'offset' not in k}
+    need = {k for k in p if not k.startswith(('fpn_', 'roi_pool_fc', 'nms_', 'roi_feat_embedding')) and 'offset' not in k}
     assert need <= have, sorted(need - have)[:8]
     assert torch.equal(torch.as_tensor(arg['conv1_weight']), p['conv1_weight'])                   # frozen: untouched
     assert not torch.equal(torch.as_tensor(arg['fc_new_2_weight']), p['fc_new_2_weight'])         # trained: moved
