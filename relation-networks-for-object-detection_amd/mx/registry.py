@@ -16,7 +16,7 @@ import math
 
 import torch
 
-from .symbol import Symbol, Node, _names
+from .graph import Symbol, Node, _names
 
 OPS = {}
 
@@ -102,6 +102,11 @@ def make(op, args, kwargs):
     sym_kw = {k: v for k, v in kwargs.items() if isinstance(v, Symbol)}
     attrs = {k: v for k, v in kwargs.items() if not isinstance(v, Symbol) and v is not None or k in ('end',)}
     attrs = {k: v for k, v in attrs.items() if not isinstance(v, Symbol)}
+    pos_attrs = getattr(d, 'pos_attrs', None)
+    if pos_attrs and args and not isinstance(args[0], Symbol):          # mx.sym.full((1,), 1000.0), mx.sym.arange(0, 8)
+        for k_, v_ in zip(pos_attrs, args):
+            attrs[k_] = v_
+        args = ()
     if d.variadic:
         ins = list(args) + [sym_kw[k] for k in sorted(sym_kw)]
         attrs.setdefault('num_args', len(ins))
@@ -336,6 +341,9 @@ defop('zeros', [], lambda a, ctx=None: torch.zeros(a_tuple(a, 'shape'), device=_
 defop('ones', [], lambda a, ctx=None: torch.ones(a_tuple(a, 'shape'), device=_device_of(ctx), dtype=torch.float32))
 for _n in ('full', 'zeros', 'ones'):
     OPS[_n].no_input = True
+OPS['full'].pos_attrs = ('shape', 'val')
+OPS['zeros'].pos_attrs = OPS['ones'].pos_attrs = ('shape',)
+OPS['arange'].pos_attrs = ('start', 'stop', 'step', 'repeat')
 
 
 def _take(a, x, idx):

@@ -41,7 +41,20 @@ class ProposalTargetProp(CustomOpProp):
         self._num_classes, self._batch_images, self._batch_rois = int(num_classes), int(batch_images), int(batch_rois)
         d = dict(class_agnostic=True, bg_thresh_hi=0.5, means=(0., 0., 0., 0.), stds=(0.1, 0.1, 0.2, 0.2), weights=(1., 1., 1., 1.))
         if cfg not in (None, 'None'):
-            d.update(eval(cfg) if isinstance(cfg, str) else cfg)
+            if isinstance(cfg, str):
+                import ast
+                cfg = ast.literal_eval(cfg)
+            if isinstance(cfg, bytes):                        # the reference's form: cPickle.dumps(config tree), SYM_REL:220
+                import pickle
+                cfg = pickle.loads(cfg)
+            if 'TRAIN' in cfg:                                # reference config tree (config/config.py) -> the fields used
+                t = cfg['TRAIN']                              # by sample_rois_v2 / expand_bbox_regression_targets
+                norm = bool(t['BBOX_NORMALIZATION_PRECOMPUTED'])
+                cfg = dict(class_agnostic=bool(cfg['CLASS_AGNOSTIC']), bg_thresh_hi=float(t['BG_THRESH_HI']),
+                           means=tuple(float(v) for v in t['BBOX_MEANS']) if norm else (0., 0., 0., 0.),
+                           stds=tuple(float(v) for v in t['BBOX_STDS']) if norm else (1., 1., 1., 1.),
+                           weights=tuple(float(v) for v in t['BBOX_WEIGHTS']))
+            d.update(cfg)
         self._cfg, self._fg_fraction = d, float(fg_fraction)
 
     def list_arguments(self):
