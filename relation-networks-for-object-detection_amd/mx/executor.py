@@ -90,6 +90,7 @@ class Executor(object):
         self.arg_dict = {k: _t(v, device).float() for k, v in args.items()}
         self.aux_dict = {k: _t(v, device).float() for k, v in (aux_states or {}).items()}
         self.order = sym._topo()
+        self.topo_index = {id(n): i for i, n in enumerate(self.order)}
         self.consumers = {}
         for n in self.order:
             for s, i in n.inputs:
@@ -145,7 +146,10 @@ class Executor(object):
                 if c is not None:
                     other = [h for h in c.inputs if h[0] is not last]
                     c2 = self._sole_consumer(c, 0, 'Activation')
-                    if len(other) == 1 and c2 is not None and a_str(c2.attrs, 'act_type') == 'relu' and not self._depends_on(other[0][0], node):
+                    # the shortcut operand must already exist when this chain runs (it is the EARLIER operand of the add):
+                    # res2a = branch1 + branch2c fuses into branch2c's convolution, with branch1's conv+BN as the residual
+                    if (len(other) == 1 and c2 is not None and a_str(c2.attrs, 'act_type') == 'relu'
+                            and self.topo_index[id(other[0][0])] < self.topo_index[id(node)]):
                         resid, relu, last = other[0], True, c2
             if last is node and bn is None:
                 continue
