@@ -11,6 +11,7 @@
 //     its 8 k-slots (A and W use the same permutation, so the product is unchanged).
 // Batched-strided over blockIdx.z (used for the per-image V*Wout^T product).
 #include "common.h"
+#include <type_traits>
 
 namespace relnet {
 
@@ -375,6 +376,371 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
 }
 
 // ---------------------------------------------------------------------------------------
+// Deep-pipeline variant of the kernel above (same tile geometry, staging instruction, MFMA operand order and
+// epilogue): NSTAGE LDS buffers of BK-deep k-slabs filled by global_load_lds, NSTAGE-1 slabs in flight.  One RAW
+// s_barrier per slab behind a COUNTED s_waitcnt vmcnt (never 0 in steady state), so the loads of the next slabs
+// stay in flight across the barrier -- __syncthreads() would drain them (its fence waits vmcnt(0) for a pending
+// LDS-DMA), which is what bounds the 2-stage kernel: one slab's MFMA time (~0.85 us at 256x256x64) is shorter than
+// a loaded-chip L2/HBM round trip, and with one 128 KB workgroup per CU nothing else hides it.
+//   ordering (guide, "8-phase template"): slab t is read only after (own counted vmcnt) + (a barrier every wave has
+//   passed); buffer (t-1) % NSTAGE is re-filled only after that same barrier, i.e. after every wave's MFMAs of slab
+//   t-1 were issued, which implies its ds_reads had returned.
+// LDS image: rows of BK bf16 (128 B / 64 B), 16-byte chunk c of row r stored at slot c ^ swz(r) -- applied on the
+// SOURCE address of the LDS-direct load and on the fragment read.  swz is chosen so that the four 16-lane groups of
+// a ds_read_b128 ({0-3,12-15,20-27} ...) hit 16 distinct 16-byte bank slots: (r >> 1) & 7 for 128-byte rows
+// ((r & 7), used by the 2-stage kernel above, is 2-way conflicted: rows 0 / 24 and 12 / 20 collide), (r >> 2) & 3
+// for 64-byte rows.
+// ---------------------------------------------------------------------------------------
+template <int BK> __device__ __forceinline__ int ring_swz(int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+
+template <int N> __device__ __forceinline__ void wait_vm_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// RESID = false instantiations carry no residual-prefetch registers (64 VGPRs at 256x256): the MFMA-bound 3x3
+// convolutions, which have no shortcut operand, keep all A / W fragments of a k-step live instead.
+// SCHED = 1: fragment-pipelined schedule.  The A / W fragments of k-step kk+1 are read from LDS while the MFMAs of
+// k-step kk run (two named fragment sets, order pinned with sched_barrier), and the slab hand-over (counted vmcnt +
+// lgkmcnt(0) + barrier, refill of the buffer just consumed, first fragments of the next slab) sits in front of the
+// LAST MFMA group of a slab instead of between slabs, so neither the LDS read latency nor the barrier skew is exposed.
+// A buffer is refilled only after every wave has waited for its own reads of it (lgkmcnt(0) before the barrier).
+template <int BM, int BN, int WM, int WN, typename TOUT, int MODE, int BK, int NSTAGE, bool RESID, int SCHED = 0>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
+  constexpr bool CONV = MODE == 1;
+  constexpr bool STEM = MODE == 2;
+  static_assert(!STEM || BK == 64, "stem mode is laid out for 64-deep slabs");
+  static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 LDS buffers");
+  constexpr int NW = WM * WN, NT = 64 * NW;
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr int ROWB = BK * 2;                         // bytes per LDS row
+  constexpr int CPR = BK / 8;                          // 16-byte chunks per row
+  constexpr int RPI = 64 / CPR;                        // rows filled by one global_load_lds (1 KiB)
+  constexpr int A_GROUPS = BM / (RPI * NW), B_GROUPS = BN / (RPI * NW);
+  static_assert(TM >= 1 && TN >= 1 && A_GROUPS >= 1 && B_GROUPS >= 1, "tile too small for the wave grid");
+  constexpr int LPS = A_GROUPS + B_GROUPS;             // LDS-direct loads per thread per slab
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int CLD = BN + 4;
+  constexpr int BAND = 32 * WM;
+  constexpr int LDS_BYTES = (NSTAGE * STAGE > BAND * CLD * 4) ? NSTAGE * STAGE : BAND * CLD * 4;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wc = wave % WN;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (g.xcd_swizzle) {
+    const int gx = gridDim.x, nwg = gx * gridDim.y;
+    const int id = bx + gx * by, xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    by = t / gx; bx = t - by * gx;
+  }
+  const int m0 = by * BM;
+  const unsigned short* A = (const unsigned short*)g.A + (long)blockIdx.z * g.strideA;
+  const unsigned short* W = (const unsigned short*)g.W + (long)blockIdx.z * g.strideW;
+  TOUT* C = (TOUT*)g.C + (long)blockIdx.z * g.strideC;
+  const TOUT* R = (RESID && g.resid) ? (const TOUT*)g.resid + (long)blockIdx.z * g.strideC : nullptr;
+
+  const int lrow = lane / CPR, lslot = lane % CPR;
+  const unsigned short* arow[A_GROUPS];
+  const unsigned short* brow[B_GROUPS];
+  int ciy[A_GROUPS], cix[A_GROUPS];
+#pragma unroll
+  for (int j = 0; j < A_GROUPS; ++j) {
+    const int tr_ = (wave * A_GROUPS + j) * RPI + lrow;            // row inside the tile
+    const int lchunk = lslot ^ ring_swz<BK>(tr_);
+    const int gr = m0 + tr_;
+    if constexpr (CONV) {
+      const int hw = g.cHout * g.cWout;
+      const int b = gr / hw, rem = gr - b * hw;
+      const int oy = rem / g.cWout, ox = rem - oy * g.cWout;
+      arow[j] = A + (long)b * g.cImg + lchunk * 8;
+      ciy[j] = (gr < g.M) ? oy * g.cStride - g.cPad : -(1 << 28);
+      cix[j] = ox * g.cStride - g.cPad;
+    } else if constexpr (STEM) {
+      const int hw = g.cHout * g.cWout;
+      const int gr2 = gr < g.M ? gr : g.M - 1;
+      const int b = gr2 / hw, rem = gr2 - b * hw;
+      const int oy = rem / g.cWout, ox = rem - oy * g.cWout;
+      arow[j] = A + (long)b * g.cImg + ((long)(2 * oy + (lchunk >> 2)) * g.cW + 2 * ox) * 4 + (lchunk & 3) * 8;
+      ciy[j] = 0; cix[j] = 0;
+    } else {
+      arow[j] = (gr < g.M) ? A + (long)gr * g.lda + lchunk * 8 : nullptr;
+    }
+  }
+  for (int nt = 0; nt < g.n_loop; ++nt) {
+  const int n0 = (bx * g.n_loop + nt) * BN;
+  if (n0 >= g.N) break;
+  if (nt > 0) __syncthreads();
+#pragma unroll
+  for (int j = 0; j < B_GROUPS; ++j) {
+    const int tr_ = (wave * B_GROUPS + j) * RPI + lrow;
+    const int gr = n0 + tr_;
+    brow[j] = (gr < g.N) ? W + (long)gr * g.ldw + (lslot ^ ring_swz<BK>(tr_)) * 8 : nullptr;
+  }
+  auto stage = [&](int kt, int buf) {
+    const int k0 = kt * BK;
+    int tr = 0, ts = 0, ic0 = k0;
+    if constexpr (CONV) {
+      const int tap = k0 / g.cCin;
+      ic0 = k0 - tap * g.cCin;
+      tr = tap / g.cS; ts = tap - tr * g.cS;
+    }
+    unsigned char* la = lds + buf * STAGE + wave * (A_GROUPS * 1024);
+    unsigned char* lb = lds + buf * STAGE + BM * ROWB + wave * (B_GROUPS * 1024);
+#pragma unroll
+    for (int j = 0; j < A_GROUPS; ++j) {
+      const void* src;
+      if constexpr (CONV) {
+        const int iy = ciy[j] + tr * g.cDil, ix = cix[j] + ts * g.cDil;
+        const bool ok = (iy >= 0) && (iy < g.cH) && (ix >= 0) && (ix < g.cW);
+        src = ok ? (const void*)(arow[j] + ((long)iy * g.cW + ix) * g.cPix + ic0) : (const void*)g_zero16;
+      } else if constexpr (STEM) {
+        src = (const void*)(arow[j] + (long)(2 * kt) * g.cW * 4);
+      } else {
+        src = arow[j] ? (const void*)(arow[j] + k0) : (const void*)g_zero16;
+      }
+      __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(la + j * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < B_GROUPS; ++j) {
+      const void* src = brow[j] ? (const void*)(brow[j] + k0) : (const void*)g_zero16;
+      __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(lb + j * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto compute = [&](int buf) {
+    const unsigned char* la = lds + buf * STAGE;
+    const unsigned char* lb = la + BM * ROWB;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 af[TM], bfr[TN];
+      const int ch = 2 * kk + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wr * (BM / WM) + i * 32 + (lane & 31);
+        af[i] = *(const bf16x8*)(la + row * ROWB + ((ch ^ ring_swz<BK>(row)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wc * (BN / WN) + j * 32 + (lane & 31);
+        bfr[j] = *(const bf16x8*)(lb + row * ROWB + ((ch ^ ring_swz<BK>(row)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  constexpr int VEC = 16 / sizeof(TOUT);
+  constexpr int TPR = BN / VEC;
+  constexpr int RPP = NT / TPR;
+  constexpr int NP = (BAND + RPP - 1) / RPP;
+  const int tcol = (tid % TPR) * VEC, trow = tid / TPR;
+  const int n = n0 + tcol;
+  const bool vec_ok = ((g.ldc % VEC) == 0) && ((((size_t)C) & 15) == 0) && (!R || (((size_t)R) & 15) == 0);
+  auto out_row = [&](int i, int p) {
+    const int brow_i = p * RPP + trow;
+    if (brow_i >= BAND) return -1;
+    const int m = m0 + (brow_i >> 5) * (BM / WM) + i * 32 + (brow_i & 31);
+    return (m < g.M && n < g.N) ? m : -1;
+  };
+  uint4 rpre[RESID ? TM : 1][RESID ? NP : 1];
+  if constexpr (RESID) if (R && vec_ok) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int m = out_row(i, p);
+        rpre[i][p] = (m >= 0 && n + VEC <= g.N) ? *(const uint4*)(R + (long)m * g.ldc + n) : make_uint4(0, 0, 0, 0);
+      }
+  }
+
+  const int nk = g.K / BK;
+  if constexpr (SCHED == 0) {
+    constexpr int D = NSTAGE - 1;                        // slabs in flight
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+      if (s < nk) stage(s, s);
+    for (int kt = 0; kt < nk; ++kt) {
+      // slabs issued so far: min(kt + D, nk); everything up to slab kt must have landed
+      const int ahead = (kt + D < nk ? kt + D : nk) - kt - 1;          // 0 .. D-1 (wave uniform)
+      if (ahead >= 2) wait_vm_barrier<2 * LPS>();
+      else if (ahead == 1) wait_vm_barrier<LPS>();
+      else wait_vm_barrier<0>();
+      if (kt + D < nk) stage(kt + D, (kt + D) % NSTAGE);
+      compute(kt % NSTAGE);
+    }
+  } else {
+    constexpr int KK = BK / 16;
+    static_assert(KK % 2 == 0, "two fragment sets alternate per k-step");
+    bf16x8 fa[2][TM], fb[2][TN];
+    auto load_frag = [&](int buf, int kk, bf16x8 (&xa)[TM], bf16x8 (&xb)[TN]) {
+      const unsigned char* la = lds + buf * STAGE;
+      const unsigned char* lb = la + BM * ROWB;
+      const int ch = 2 * kk + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wr * (BM / WM) + i * 32 + (lane & 31);
+        xa[i] = *(const bf16x8*)(la + row * ROWB + ((ch ^ ring_swz<BK>(row)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wc * (BN / WN) + j * 32 + (lane & 31);
+        xb[j] = *(const bf16x8*)(lb + row * ROWB + ((ch ^ ring_swz<BK>(row)) << 4));
+      }
+    };
+    // MFMAs of one k-step, rows [I0, I1) of the wave's TM x TN tile grid
+    auto mma = [&](const bf16x8 (&xa)[TM], const bf16x8 (&xb)[TN], auto i0c, auto i1c) {
+      constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
+#pragma unroll
+      for (int i = I0; i < I1; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[j], xa[i], acc[i][j], 0, 0, 0);
+    };
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    using cT = std::integral_constant<int, TM>;
+    // one k-step: the first row of MFMAs consumes fragments that landed a whole step ago (the compiler's lgkmcnt(0) in
+    // front of them is then free), the reads of the NEXT fragments are issued behind it and have the remaining
+    // (TM-1) x TN MFMAs to land
+#define RELNET_KSTEP(CUR, NEXT_LOAD)                 \
+    mma(fa[CUR], fb[CUR], c0{}, c1{});               \
+    __builtin_amdgcn_sched_barrier(0);               \
+    NEXT_LOAD;                                       \
+    __builtin_amdgcn_sched_barrier(0);               \
+    mma(fa[CUR], fb[CUR], c1{}, cT{});               \
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < NSTAGE; ++s)
+      if (s < nk) stage(s, s);
+    {
+      const int ahead = (NSTAGE < nk ? NSTAGE : nk) - 1;               // slabs that may still be in flight
+      if (ahead >= 3) wait_vm_barrier<3 * LPS>();
+      else if (ahead == 2) wait_vm_barrier<2 * LPS>();
+      else if (ahead == 1) wait_vm_barrier<LPS>();
+      else wait_vm_barrier<0>();
+    }
+    load_frag(0, 0, fa[0], fb[0]);
+    int kt = 0;
+    // steady state (branch-free): NSTAGE - 1 slabs are in flight at every hand-over and the consumed buffer is refilled
+    for (; kt + NSTAGE < nk; ++kt) {
+      const int buf = kt % NSTAGE;
+#pragma unroll
+      for (int kk = 0; kk < KK - 1; ++kk) {
+        RELNET_KSTEP(kk & 1, load_frag(buf, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]))
+      }
+      // hand-over: every read of this slab has returned (own lgkmcnt(0)), slab kt+1 has landed (counted vmcnt), all
+      // waves agree (barrier) -> refill this buffer, fetch the first fragments of the next slab
+      RELNET_KSTEP((KK - 1) & 1,
+                   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NSTAGE - 2) * LPS) : "memory");
+                   stage(kt + NSTAGE, buf);
+                   load_frag((kt + 1) % NSTAGE, 0, fa[0], fb[0]))
+    }
+    for (; kt < nk; ++kt) {                                            // drain: nothing left to issue
+      const int buf = kt % NSTAGE;
+#pragma unroll
+      for (int kk = 0; kk < KK - 1; ++kk) {
+        RELNET_KSTEP(kk & 1, load_frag(buf, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]))
+      }
+      if (kt + 1 < nk) {
+        const int ahead = nk - kt - 2;                                 // slabs beyond kt+1 still in flight: 0 .. NSTAGE-2
+        RELNET_KSTEP((KK - 1) & 1,
+                     if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
+                     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(LPS) : "memory");
+                     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                     load_frag((kt + 1) % NSTAGE, 0, fa[0], fb[0]))
+      } else {
+        mma(fa[(KK - 1) & 1], fb[(KK - 1) & 1], c0{}, cT{});
+      }
+    }
+#undef RELNET_KSTEP
+  }
+  __syncthreads();                                     // every wave is done reading the ring: the epilogue band reuses it
+
+  float* ct = (float*)lds;
+  float bv[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) bv[e] = (g.bias_mode == 1 && n + e < g.N) ? g.bias[n + e] : 0.f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    if (i > 0) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int row = wr * 32 + (lane & 31);
+        const int col = wc * (BN / WN) + j * 32 + 8 * gq + 4 * (lane >> 5);
+        *(float4*)(ct + row * CLD + col) = make_float4(acc[i][j][4 * gq], acc[i][j][4 * gq + 1],
+                                                       acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]);
+      }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int m = out_row(i, p);
+      if (m < 0) continue;
+      const int brow_i = p * RPP + trow;
+      float v[VEC];
+#pragma unroll
+      for (int q = 0; q < VEC / 4; ++q) {
+        const float4 x = *(const float4*)(ct + brow_i * CLD + tcol + 4 * q);
+        v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+      }
+      const float brow = (g.bias_mode == 2) ? g.bias[m] : 0.f;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] += bv[e] + brow;
+      TOUT* cp = C + (long)m * g.ldc + n;
+      if (vec_ok && n + VEC <= g.N) {
+        if constexpr (sizeof(TOUT) == 2) {
+          if constexpr (RESID) if (R) {
+            const unsigned int rw[4] = {rpre[i][p].x, rpre[i][p].y, rpre[i][p].z, rpre[i][p].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f(rw[e] & 0xffff); v[2 * e + 1] += bf2f(rw[e] >> 16); }
+          }
+          if (g.relu) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          *(uint4*)cp = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        } else {
+          if constexpr (RESID) if (R) {
+            v[0] += __uint_as_float(rpre[i][p].x); v[1] += __uint_as_float(rpre[i][p].y);
+            v[2] += __uint_as_float(rpre[i][p].z); v[3] += __uint_as_float(rpre[i][p].w);
+          }
+          if (g.relu) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      } else {
+        const TOUT* rp = R ? R + (long)m * g.ldc + n : nullptr;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          if (n + e < g.N) {
+            float x = v[e];
+            if (rp) x += load_out<TOUT>(rp + e);
+            if (g.relu) x = fmaxf(x, 0.f);
+            store_out<TOUT>(cp + e, x);
+          }
+        }
+      }
+    }
+  }
+  }   // nt (row-panel loop)
+}
+
+// ---------------------------------------------------------------------------------------
 // f32 in / f32 accumulate (exact fp32 MFMA, bit-wise an fmaf chain).  128x128 tile.
 // ---------------------------------------------------------------------------------------
 template <typename TOUT>
@@ -481,8 +847,33 @@ static void launch_cfg(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
   else gemm_nt_bf16_kernel<BM, BN, WM, WN, float, CONV><<<grid, 64 * WM * WN, 0, s>>>(g);
 }
 
-// configs: 1 = 256x256 (8 waves) 2 = 256x128 (8 waves) 3 = 128x128 (4 waves) 4 = 128x64 5 = 64x64
-enum { GEMM_TILE_COUNT = 5 };
+template <int BM, int BN, int WM, int WN, int CONV, int BK, int NSTAGE, int SCHED = 0>
+static void launch_ring(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
+  const int ntile = (g.N + BN - 1) / BN;
+  int nloop = g_force_nloop > 0 ? g_force_nloop : g.n_loop;
+  const bool swz = g_swizzle && batch == 1 && ntile > 1 && (long)ntile * ((g.M + BM - 1) / BM) >= 16;
+  if (swz && g_force_nloop == 0) nloop = 1;
+  if (nloop < 1) nloop = 1;
+  if (nloop > ntile) nloop = ntile;
+  g.n_loop = nloop;
+  dim3 grid((ntile + nloop - 1) / nloop, (g.M + BM - 1) / BM, batch);
+  g.xcd_swizzle = (swz && grid.x > 1) ? 1 : 0;
+  const int nthr = 64 * WM * WN;
+  if (g.resid) {
+    if (out_dtype == RELNET_BF16) gemm_ring_kernel<BM, BN, WM, WN, unsigned short, CONV, BK, NSTAGE, true><<<grid, nthr, 0, s>>>(g);
+    else gemm_ring_kernel<BM, BN, WM, WN, float, CONV, BK, NSTAGE, true><<<grid, nthr, 0, s>>>(g);
+  } else {
+    // (the fragment-pipelined schedule needs the registers the residual prefetch would take: shortcut-free layers only)
+    if (out_dtype == RELNET_BF16) gemm_ring_kernel<BM, BN, WM, WN, unsigned short, CONV, BK, NSTAGE, false, SCHED><<<grid, nthr, 0, s>>>(g);
+    else gemm_ring_kernel<BM, BN, WM, WN, float, CONV, BK, NSTAGE, false, SCHED><<<grid, nthr, 0, s>>>(g);
+  }
+}
+
+// configs: 1 = 256x256 (8 waves) 2 = 256x128 (8 waves) 3 = 128x128 (4 waves) 4 = 128x64 5 = 64x64   (2 LDS stages, BK 64)
+// deep-pipeline (gemm_ring_kernel): 6 = 256x256, BK 32, 4 buffers   7 = 256x128, BK 64, 3 buffers
+//                                   8 = 256x256, BK 64, 2 buffers (conflict-free swizzle only: the A/B of that change)
+//                                   9 = 6 and 10 = 7 with the fragment-pipelined schedule on shortcut-free layers
+enum { GEMM_TILE_COUNT = 10 };
 static int pick_tile(long M, long N, long K, int batch, int out_dtype) {
   // Picked from on-device timings of every GEMM / convolution shape of the detector at 16
   // images per launch (tests/_bench_gemm.py; table in DESIGN.md): wide tiles cut the
@@ -512,7 +903,18 @@ static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t
     case 2: launch_cfg<256, 128, 4, 2, CONV>(g, batch, out_dtype, s); break;
     case 3: launch_cfg<128, 128, 2, 2, CONV>(g, batch, out_dtype, s); break;
     case 4: launch_cfg<128, 64, 2, 2, CONV>(g, batch, out_dtype, s); break;
-    default: launch_cfg<64, 64, 2, 2, CONV>(g, batch, out_dtype, s); break;
+    case 5: launch_cfg<64, 64, 2, 2, CONV>(g, batch, out_dtype, s); break;
+    case 6:
+      if constexpr (CONV == 2) launch_cfg<256, 256, 2, 4, CONV>(g, batch, out_dtype, s);      // stem slabs are 64 deep
+      else launch_ring<256, 256, 2, 4, CONV, 32, 4>(g, batch, out_dtype, s);
+      break;
+    case 7: launch_ring<256, 128, 4, 2, CONV, 64, 3>(g, batch, out_dtype, s); break;
+    case 8: launch_ring<256, 256, 2, 4, CONV, 64, 2>(g, batch, out_dtype, s); break;
+    case 9:
+      if constexpr (CONV == 2) launch_cfg<256, 256, 2, 4, CONV>(g, batch, out_dtype, s);
+      else launch_ring<256, 256, 2, 4, CONV, 32, 4, 1>(g, batch, out_dtype, s);
+      break;
+    default: launch_ring<256, 128, 4, 2, CONV, 64, 3, 1>(g, batch, out_dtype, s); break;
   }
 }
 

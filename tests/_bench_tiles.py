@@ -47,13 +47,16 @@ CASES = [  # name, count per step, args
     ('res2 reduce 256->64', 2, (150, 250, 256, 64, 1, 1, False)),
     ('conv_new_1 2048->256', 1, (38, 63, 2048, 256, 1, 1, False)),
 ]
+TILES = [int(x) for x in os.environ.get('TILES', '0,1,3,4,6,7,8,9,10').split(',')]
+
+
 def main():
-    tot = {t: 0.0 for t in (0, 1, 2, 3, 4)}
+    tot = {t: 0.0 for t in TILES}
     best_tot = 0.0
     for name, cnt, args in CASES:
         fn = conv_case(*args)
         row = []
-        for t in (0, 1, 2, 3, 4):
+        for t in TILES:
             L.relnet_gemm_force_tile(t)
             try:
                 us = timeit(fn)
@@ -62,10 +65,9 @@ def main():
             row.append(us); tot[t] += cnt * us
         L.relnet_gemm_force_tile(0)
         best_tot += cnt * min(r for r in row if r == r)
-        print('%-30s x%2d  auto %7.1f | t1 %7.1f  t2 %7.1f  t3 %7.1f  t4 %7.1f us   best t%d' % (
-            name, cnt, row[0], row[1], row[2], row[3], row[4], 1 + min(range(4), key=lambda i: row[1 + i] if row[1 + i] == row[1 + i] else 1e30)))
-    print('per-step totals (ms): auto %.2f  t1 %.2f t2 %.2f t3 %.2f t4 %.2f   per-shape best %.2f' % (
-        tot[0] / 1e3, tot[1] / 1e3, tot[2] / 1e3, tot[3] / 1e3, tot[4] / 1e3, best_tot / 1e3))
+        bi = min(range(len(row)), key=lambda i: row[i] if row[i] == row[i] else 1e30)
+        print('%-30s x%2d ' % (name, cnt) + ' '.join('t%d %7.1f' % (t, r) for t, r in zip(TILES, row)) + '  us   best t%d' % TILES[bi])
+    print('per-step totals (ms): ' + ' '.join('t%d %.2f' % (t, tot[t] / 1e3) for t in TILES) + '   per-shape best %.2f' % (best_tot / 1e3))
 
 
 if __name__ == '__main__':
