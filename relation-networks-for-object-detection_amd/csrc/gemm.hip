@@ -404,7 +404,14 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
 // lgkmcnt(0) + barrier, refill of the buffer just consumed, first fragments of the next slab) sits in front of the
 // LAST MFMA group of a slab instead of between slabs, so neither the LDS read latency nor the barrier skew is exposed.
 // A buffer is refilled only after every wave has waited for its own reads of it (lgkmcnt(0) before the barrier).
-template <int BM, int BN, int WM, int WN, typename TOUT, int MODE, int BK, int NSTAGE, bool RESID, int SCHED = 0>
+// ABLATE (measurement only, results are garbage): 1 = no LDS fragment reads / MFMAs (fill path alone),
+// 2 = no global->LDS fills after the first slab (LDS read + MFMA path alone)
+// EPI = 1: register epilogue.  With the swapped MFMA operands a lane owns one output ROW and, per register group gq, four
+// consecutive columns (8 gq + 4 (lane >> 5) + 0..3); v_permlane32_swap of the fp32 values of groups (2p, 2p+1) gives every
+// lane EIGHT consecutive columns (16 p + 8 (lane >> 5) + 0..7), so bias / shortcut / ReLU apply on 16 contiguous bytes and
+// the tile leaves as 16-byte stores without the LDS transposition band (no LDS traffic, no epilogue barriers, and the ring
+// buffers stay free for the next tile's prefetch).
+template <int BM, int BN, int WM, int WN, typename TOUT, int MODE, int BK, int NSTAGE, bool RESID, int SCHED = 0, int ABLATE = 0, int EPI = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
   constexpr bool CONV = MODE == 1;
   constexpr bool STEM = MODE == 2;
@@ -421,7 +428,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
   constexpr int STAGE = (BM + BN) * ROWB;
   constexpr int CLD = BN + 4;
   constexpr int BAND = 32 * WM;
-  constexpr int LDS_BYTES = (NSTAGE * STAGE > BAND * CLD * 4) ? NSTAGE * STAGE : BAND * CLD * 4;
+  constexpr int LDS_BYTES = (EPI == 1 || NSTAGE * STAGE > BAND * CLD * 4) ? NSTAGE * STAGE : BAND * CLD * 4;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -478,6 +485,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
     brow[j] = (gr < g.N) ? W + (long)gr * g.ldw + (lslot ^ ring_swz<BK>(tr_)) * 8 : nullptr;
   }
   auto stage = [&](int kt, int buf) {
+    if constexpr (ABLATE == 2) { if (kt > 0) return; }
     const int k0 = kt * BK;
     int tr = 0, ts = 0, ic0 = k0;
     if constexpr (CONV) {
@@ -517,6 +525,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto compute = [&](int buf) {
+    if constexpr (ABLATE == 1) { asm volatile("" ::"v"(buf)); return; }
     const unsigned char* la = lds + buf * STAGE;
     const unsigned char* lb = la + BM * ROWB;
 #pragma unroll
@@ -554,8 +563,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
     const int m = m0 + (brow_i >> 5) * (BM / WM) + i * 32 + (brow_i & 31);
     return (m < g.M && n < g.N) ? m : -1;
   };
-  uint4 rpre[RESID ? TM : 1][RESID ? NP : 1];
-  if constexpr (RESID) if (R && vec_ok) {
+  // register epilogue: this lane's row / first column of tile (i, j), 16-byte piece p
+  const int ehalf = lane >> 5;
+  auto erow = [&](int i) { return m0 + wr * (BM / WM) + i * 32 + (lane & 31); };
+  auto ecol = [&](int j, int p) { return n0 + wc * (BN / WN) + j * 32 + 16 * p + 8 * ehalf; };
+  constexpr bool RDIR = RESID && EPI == 1 && sizeof(TOUT) == 2;
+  uint4 rdir[RDIR ? TM : 1][RDIR ? TN : 1][2];
+  if constexpr (RDIR) if (R && vec_ok) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int m = erow(i), c = ecol(j, p);
+          rdir[i][j][p] = (m < g.M && c + 8 <= g.N) ? *(const uint4*)(R + (long)m * g.ldc + c) : make_uint4(0, 0, 0, 0);
+        }
+  }
+  uint4 rpre[(RESID && EPI == 0) ? TM : 1][(RESID && EPI == 0) ? NP : 1];
+  if constexpr (RESID && EPI == 0) if (R && vec_ok) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -585,6 +611,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
     static_assert(KK % 2 == 0, "two fragment sets alternate per k-step");
     bf16x8 fa[2][TM], fb[2][TN];
     auto load_frag = [&](int buf, int kk, bf16x8 (&xa)[TM], bf16x8 (&xb)[TN]) {
+      if constexpr (ABLATE == 1) return;
       const unsigned char* la = lds + buf * STAGE;
       const unsigned char* lb = la + BM * ROWB;
       const int ch = 2 * kk + (lane >> 5);
@@ -602,6 +629,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
     // MFMAs of one k-step, rows [I0, I1) of the wave's TM x TN tile grid
     auto mma = [&](const bf16x8 (&xa)[TM], const bf16x8 (&xb)[TN], auto i0c, auto i1c) {
       constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
+      if constexpr (ABLATE == 1) return;
 #pragma unroll
       for (int i = I0; i < I1; ++i)
 #pragma unroll
@@ -666,6 +694,90 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
     }
 #undef RELNET_KSTEP
   }
+  if constexpr (EPI == 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = erow(i);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (sizeof(TOUT) == 2) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned int a = __float_as_uint(acc[i][j][8 * p + e]), b = __float_as_uint(acc[i][j][8 * p + 4 + e]);
+              const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+              v[e] = __uint_as_float(r[0]); v[4 + e] = __uint_as_float(r[1]);
+            }
+            const int c = ecol(j, p);
+            if (m >= g.M || c >= g.N) continue;
+            const float brow = (g.bias_mode == 2) ? g.bias[m] : 0.f;
+            TOUT* cp = C + (long)m * g.ldc + c;
+            if (vec_ok && c + 8 <= g.N) {
+              if (g.bias_mode == 1) {
+                const float4 b0 = *(const float4*)(g.bias + c), b1 = *(const float4*)(g.bias + c + 4);
+                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+              }
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += brow;
+              if constexpr (RDIR) if (R) {
+                const unsigned int rw[4] = {rdir[i][j][p].x, rdir[i][j][p].y, rdir[i][j][p].z, rdir[i][j][p].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f(rw[e] & 0xffff); v[2 * e + 1] += bf2f(rw[e] >> 16); }
+              }
+              if (g.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+              }
+              if constexpr (ABLATE == 3) { asm volatile("" ::"v"(v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7])); }
+              else *(uint4*)cp = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+            } else {
+              const TOUT* rp = R ? R + (long)m * g.ldc + c : nullptr;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                if (c + e < g.N) {
+                  float x = v[e] + brow + (g.bias_mode == 1 ? g.bias[c + e] : 0.f);
+                  if (rp) x += load_out<TOUT>(rp + e);
+                  if (g.relu) x = fmaxf(x, 0.f);
+                  store_out<TOUT>(cp + e, x);
+                }
+              }
+            }
+          }
+        } else {
+          // fp32 outputs: a register group is already 16 contiguous bytes
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int c = n0 + wc * (BN / WN) + j * 32 + 8 * gq + 4 * ehalf;
+            if (m >= g.M || c >= g.N) continue;
+            const float brow = (g.bias_mode == 2) ? g.bias[m] : 0.f;
+            TOUT* cp = C + (long)m * g.ldc + c;
+            const TOUT* rp = R ? R + (long)m * g.ldc + c : nullptr;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e] + brow;
+            if (vec_ok && c + 4 <= g.N) {
+              if (g.bias_mode == 1) { const float4 b0 = *(const float4*)(g.bias + c); v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; }
+              if (rp) { const float4 r0 = *(const float4*)rp; v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; }
+              if (g.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+              *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                if (c + e < g.N) {
+                  float x = v[e] + (g.bias_mode == 1 ? g.bias[c + e] : 0.f);
+                  if (rp) x += load_out<TOUT>(rp + e);
+                  if (g.relu) x = fmaxf(x, 0.f);
+                  store_out<TOUT>(cp + e, x);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  } else {
   __syncthreads();                                     // every wave is done reading the ring: the epilogue band reuses it
 
   float* ct = (float*)lds;
@@ -711,7 +823,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
           }
-          *(uint4*)cp = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+          if constexpr (ABLATE == 3) { asm volatile("" ::"v"(v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7])); }
+          else *(uint4*)cp = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
         } else {
           if constexpr (RESID) if (R) {
             v[0] += __uint_as_float(rpre[i][p].x); v[1] += __uint_as_float(rpre[i][p].y);
@@ -737,6 +850,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
       }
     }
   }
+  }   // EPI
   }   // nt (row-panel loop)
 }
 
@@ -822,6 +936,8 @@ using namespace relnet;
 // dtype codes shared by the whole C-ABI
 enum { RELNET_F32 = 0, RELNET_BF16 = 1 };
 
+static int g_ablate = 0;         // measurement knob (ring tiles, conv mode, bf16 out, no shortcut): 1 = fill path only, 2 = LDS + MFMA only
+extern "C" void relnet_gemm_debug_ablate(int a) { g_ablate = a; }
 static int g_force_tile = 0;     // tuning knob: 0 auto, else index into the config list below
 static int g_force_nloop = 0;    // tuning knob: 0 auto, else column tiles per workgroup
 static int g_swizzle = 1;        // tuning knob: XCD-aware tile order (0 = plain blockIdx order)
@@ -847,7 +963,7 @@ static void launch_cfg(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
   else gemm_nt_bf16_kernel<BM, BN, WM, WN, float, CONV><<<grid, 64 * WM * WN, 0, s>>>(g);
 }
 
-template <int BM, int BN, int WM, int WN, int CONV, int BK, int NSTAGE, int SCHED = 0>
+template <int BM, int BN, int WM, int WN, int CONV, int BK, int NSTAGE, int SCHED = 0, int EPI = 0>
 static void launch_ring(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
   const int ntile = (g.N + BN - 1) / BN;
   int nloop = g_force_nloop > 0 ? g_force_nloop : g.n_loop;
@@ -859,6 +975,28 @@ static void launch_ring(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
   dim3 grid((ntile + nloop - 1) / nloop, (g.M + BM - 1) / BM, batch);
   g.xcd_swizzle = (swz && grid.x > 1) ? 1 : 0;
   const int nthr = 64 * WM * WN;
+  if constexpr (CONV == 1) {
+    if (g_ablate && g_ablate <= 2 && out_dtype == RELNET_BF16 && !g.resid) {
+      if (g_ablate == 1) gemm_ring_kernel<BM, BN, WM, WN, unsigned short, CONV, BK, NSTAGE, false, SCHED, 1><<<grid, nthr, 0, s>>>(g);
+      else gemm_ring_kernel<BM, BN, WM, WN, unsigned short, CONV, BK, NSTAGE, false, SCHED, 2><<<grid, nthr, 0, s>>>(g);
+      return;
+    }
+    if (g_ablate == 3 && out_dtype == RELNET_BF16) {           // no output stores
+      if (g.resid) gemm_ring_kernel<BM, BN, WM, WN, unsigned short, CONV, BK, NSTAGE, true, 0, 3><<<grid, nthr, 0, s>>>(g);
+      else gemm_ring_kernel<BM, BN, WM, WN, unsigned short, CONV, BK, NSTAGE, false, 0, 3><<<grid, nthr, 0, s>>>(g);
+      return;
+    }
+  }
+  if constexpr (EPI == 1) {
+    if (g.resid) {
+      if (out_dtype == RELNET_BF16) gemm_ring_kernel<BM, BN, WM, WN, unsigned short, CONV, BK, NSTAGE, true, 0, 0, 1><<<grid, nthr, 0, s>>>(g);
+      else gemm_ring_kernel<BM, BN, WM, WN, float, CONV, BK, NSTAGE, true, 0, 0, 1><<<grid, nthr, 0, s>>>(g);
+    } else {
+      if (out_dtype == RELNET_BF16) gemm_ring_kernel<BM, BN, WM, WN, unsigned short, CONV, BK, NSTAGE, false, SCHED, 0, 1><<<grid, nthr, 0, s>>>(g);
+      else gemm_ring_kernel<BM, BN, WM, WN, float, CONV, BK, NSTAGE, false, SCHED, 0, 1><<<grid, nthr, 0, s>>>(g);
+    }
+    return;
+  }
   if (g.resid) {
     if (out_dtype == RELNET_BF16) gemm_ring_kernel<BM, BN, WM, WN, unsigned short, CONV, BK, NSTAGE, true><<<grid, nthr, 0, s>>>(g);
     else gemm_ring_kernel<BM, BN, WM, WN, float, CONV, BK, NSTAGE, true><<<grid, nthr, 0, s>>>(g);
@@ -873,8 +1011,10 @@ static void launch_ring(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
 // deep-pipeline (gemm_ring_kernel): 6 = 256x256, BK 32, 4 buffers   7 = 256x128, BK 64, 3 buffers
 //                                   8 = 256x256, BK 64, 2 buffers (conflict-free swizzle only: the A/B of that change)
 //                                   9 = 6 and 10 = 7 with the fragment-pipelined schedule on shortcut-free layers
-enum { GEMM_TILE_COUNT = 10 };
-static int pick_tile(long M, long N, long K, int batch, int out_dtype) {
+//                                   11 = 8 with the register epilogue (no LDS band)
+//                                   12 = 8 with the fragment-pipelined schedule on shortcut-free layers
+enum { GEMM_TILE_COUNT = 12 };
+static int pick_tile(long M, long N, long K, int batch, int out_dtype, int has_resid) {
   // Picked from on-device timings of every GEMM / convolution shape of the detector at 16
   // images per launch (tests/_bench_gemm.py; table in DESIGN.md): wide tiles cut the
   // L2 -> LDS fill traffic of the compute-bound 3x3 / large-K layers, 128-row tiles keep more
@@ -889,15 +1029,18 @@ static int pick_tile(long M, long N, long K, int batch, int out_dtype) {
   // fp32 outputs (weight gradients, column gradients): the 256x256 epilogue needs a second fp32 staging tile and
   // spills ~180 VGPRs; 256x128 holds everything in registers
   if (cfg == 1 && out_dtype != RELNET_BF16) cfg = 2;
+  // shortcut-free 256x256 layers (3x3 / reduce convolutions, FC layers): the ring kernel's conflict-free LDS image and
+  // residual-free register budget are worth 3-11 % (r02 tile table: res5 3x3 642 -> 574 us, rpn 3x3 1244 -> 1131 us)
+  if (cfg == 1 && !has_resid) cfg = 8;
   return cfg;
 }
 extern "C" int relnet_gemm_tile_count(void) { return GEMM_TILE_COUNT; }
-extern "C" int relnet_gemm_pick_tile(int M, int N, int K, int batch, int out_dtype) { return pick_tile(M, N, K, batch, out_dtype); }
+extern "C" int relnet_gemm_pick_tile(int M, int N, int K, int batch, int out_dtype) { return pick_tile(M, N, K, batch, out_dtype, 0); }
 
 template <int CONV>
 static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t s) {
   int cfg = g_force_tile;
-  if (cfg <= 0 || cfg > GEMM_TILE_COUNT) cfg = pick_tile(g.M, g.N, g.K, batch, out_dtype);
+  if (cfg <= 0 || cfg > GEMM_TILE_COUNT) cfg = pick_tile(g.M, g.N, g.K, batch, out_dtype, g.resid != nullptr);
   switch (cfg) {
     case 1: launch_cfg<256, 256, 2, 4, CONV>(g, batch, out_dtype, s); break;
     case 2: launch_cfg<256, 128, 4, 2, CONV>(g, batch, out_dtype, s); break;
@@ -914,7 +1057,9 @@ static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t
       if constexpr (CONV == 2) launch_cfg<256, 256, 2, 4, CONV>(g, batch, out_dtype, s);
       else launch_ring<256, 256, 2, 4, CONV, 32, 4, 1>(g, batch, out_dtype, s);
       break;
-    default: launch_ring<256, 128, 4, 2, CONV, 64, 3, 1>(g, batch, out_dtype, s); break;
+    case 10: launch_ring<256, 128, 4, 2, CONV, 64, 3, 1>(g, batch, out_dtype, s); break;
+    case 11: launch_ring<256, 256, 2, 4, CONV, 64, 2, 0, 1>(g, batch, out_dtype, s); break;
+    default: launch_ring<256, 256, 2, 4, CONV, 64, 2, 1>(g, batch, out_dtype, s); break;
   }
 }
 
