@@ -11,12 +11,20 @@ Images are independent units: ranks share nothing on the data path (weak scaling
 collective); the barrier + max-over-ranks timing is the only communication.
 
 The JSON line also carries
-  roofline      the relation-attention kernel (north_star's named kernel): algorithmic FLOPs of
+  roofline      the relation-attention kernel (north_star's named kernel): `frac` = algorithmic FLOPs of
                 the graph as written (3.13 GFLOP per module-image) / measured
-                launch duration (HIP events on the launching stream, inside the timed steps);
-                `executed` = FLOPs the re-associated kernel really performs.
-  cpu_baseline  the CPU oracle (numpy + torch-CPU fp32 restatement of the same graph) timed on
-                a bounded sample of the same workload on this host's cores.
+                launch duration (HIP events on the launching stream) / dense bf16 MFMA peak;
+                `frac_executed` = the same with the FLOPs the re-associated kernel really performs,
+                `hbm_frac` = bytes one launch must move / duration / 8 TB/s.
+  cpu_baseline  the CPU oracle (numpy + torch-CPU fp32 restatement of the same graph): 3 warm-up + 10 timed
+                images, median, on this host's cores (N = 1 only).
+  parity        the timed detector, on images of the timed batch, checked stage by stage against the oracle
+                (oracle/parity.py): identical proposal rows, ROIPooling mismatches, max |cls_prob| error,
+                detection-set agreement (N = 1 only).
+  batch_sweep   images/s of the same step at 1 (the reference's BATCH_IMAGES) and 8 images per GPU per step.
+  train         BASELINE configs[2] on the same N GPUs: training step of relation + learn-NMS end2end with ONE
+                summed RCCL all-reduce of the 68.3 M gradients per step (the path the 1 -> 8 GPU scaling target
+                is stated on; `value` stays the inference figure so that the N = 1..8 curve is one metric).
 """
 import argparse
 import contextlib
@@ -63,8 +71,9 @@ class KernelTimer(object):
         return out
 
 
-def cpu_baseline(params, relation=True, soft=True, images=4, seed=123, threads=32):
-    """Oracle (oracle/network.py) on `images` synthetic 600x1000 images; returns the dict."""
+def cpu_baseline(params, relation=True, soft=True, images=10, warm=3, seed=123, threads=32):
+    """Oracle (oracle/network.py) on `images` synthetic 600x1000 images after `warm` warm-up images; median s/image
+    (SURVEY 8d protocol)."""
     import numpy as np
     from oracle import network as ON
     # 32 threads: the torch-CPU convolutions stop scaling there on the GPU box's host (0.74 s
@@ -74,20 +83,20 @@ def cpu_baseline(params, relation=True, soft=True, images=4, seed=123, threads=3
     g = torch.Generator().manual_seed(seed)
     im_info = np.array([[600, 1000, 1.0]], np.float32)
     t_img, t_post = [], []
-    for i in range(images + 1):                       # first image = warm-up (thread pools, caches)
+    for i in range(images + warm):                    # first images = warm-up (thread pools, caches)
         data = torch.randn(1, 3, 600, 1000, generator=g)
         t0 = time.time()
         r = ON.detect(data, im_info, params, relation=relation, soft=soft)
-        if i > 0:
+        if i >= warm:
             t_img.append(time.time() - t0)
             t_post.append(r['post_seconds'])
-    per = sum(t_img) / len(t_img)
+    per = sorted(t_img)[len(t_img) // 2]
     return dict(value=1.0 / per, unit='images/s', cores=cores, kind='port',
-                sample='%d synthetic 600x1000 images through oracle/network.py:detect (torch-CPU fp32 convs on '
-                       '%d threads + numpy proposal/ROI/relation/soft-NMS), %.2f s/image, of which per-class soft-NMS + top-100 '
-                       '(1 core, numpy) %.0f ms (random-init scores keep all 300 rois candidates in all 80 classes: the worst case; the '
-                       'reference README reports 59 ms for this stage with trained weights on its own box)'
-                       % (images, cores, per, 1e3 * sum(t_post) / len(t_post)))
+                sample='%d synthetic 600x1000 images (after %d warm-up images) through oracle/network.py:detect (torch-CPU fp32 convs on '
+                       '%d threads + numpy proposal/ROI/relation/soft-NMS), median %.2f s/image (min %.2f, max %.2f), of which per-class '
+                       'soft-NMS + top-100 (1 core, numpy) median %.0f ms (random-init scores keep all 300 rois candidates in all 80 '
+                       'classes: the worst case; the reference README reports 59 ms for this stage with trained weights on its own box)'
+                       % (images, warm, cores, per, min(t_img), max(t_img), 1e3 * sorted(t_post)[len(t_post) // 2]))
 
 
 def attention_isolated(batch, n_rois, dtype, launches=100, warm=10):
@@ -117,7 +126,30 @@ def attention_isolated(batch, n_rois, dtype, launches=100, warm=10):
     return ms[len(ms) // 2]
 
 
-def bench_train(a, rank, world, D):
+def _replay_rate(det, bsz, a, D):
+    """images/s of `det` at `bsz` images per step: warm-up, one hipGraph capture, a.steps timed replays."""
+    g = torch.Generator().manual_seed(4242 + bsz)
+    data = torch.randn(bsz, 3, 600, 1000, generator=g).cuda()
+    im_info = torch.tensor([[600.0, 1000.0, 1.0]] * bsz).cuda()
+    with torch.no_grad():
+        for _ in range(2):
+            det.forward(data, im_info)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            det.forward(data, im_info)
+        graph.replay()
+        D.fence(device='cuda')
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            graph.replay()
+        D.fence(device='cuda')
+        dt = time.perf_counter() - t0
+    del graph
+    return {'images_per_s': bsz * a.steps / dt, 'ms_per_step': 1e3 * dt / a.steps}
+
+
+def bench_train(a, rank, world, D, emit=True):
     """Training throughput of the relation end2end graph (reference config ..._end2end_relation_8epoch.yaml): one step =
     forward + backward over `batch` images per GPU, ONE summed all-reduce of the 67.7 M trainable gradients, SGD."""
     import numpy as np
@@ -179,9 +211,10 @@ def bench_train(a, rank, world, D):
     elapsed = D.max_over_ranks(elapsed, device='cuda')
     ok = bool(torch.isfinite(tr.W.master).all())
     assert ok, "non-finite weights after training steps"
+    res = None
     if rank == 0:
         images = world * B * a.steps
-        print(json.dumps({
+        res = {
             'metric': 'images/sec (1000x600, 300 ROIs)', 'value': images / elapsed, 'unit': 'images/s', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
@@ -195,10 +228,12 @@ def bench_train(a, rank, world, D):
                                    '300 proposals + 8 gt rows, OHEM 128, random-init weights' % tr.num_trainable(),
                        'images_per_gpu_per_step': B, 'launch': 'eager' if a.no_graph else 'hipGraph replay (forward+backward)',
                        'parallelism': 'dp%d (RCCL all-reduce SUM)' % world},
-            'losses': {k: float(out[k]) for k in ('bbox_loss', 'rpn_bbox_loss', 'nms_pos_loss', 'nms_neg_loss') if k in out}}))
-    if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+            'losses': {k: float(out[k]) for k in ('bbox_loss', 'rpn_bbox_loss', 'nms_pos_loss', 'nms_neg_loss') if k in out}}
+        if emit:
+            print(json.dumps(res))
+    del tr
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -214,7 +249,11 @@ def main():
     ap.add_argument('--fpn', action='store_true', help='FPN graph, 800x1024 images, 1000 given proposals (inference graph of config 5)')
     ap.add_argument('--train', action='store_true', help='training step (relation end2end graph): forward + backward + summed all-reduce + SGD')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-images', type=int, default=4)
+    ap.add_argument('--cpu-images', type=int, default=10)
+    ap.add_argument('--parity-images', type=int, default=2, help='images of the batch checked stage by stage against the oracle')
+    ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--no-batch-sweep', action='store_true')
+    ap.add_argument('--no-train-line', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--stem', default='hip', choices=['hip', 'miopen'], help='7x7 stem conv: MFMA implicit GEMM or library')
@@ -236,7 +275,11 @@ def main():
     assert world == a.gpus or world == 1, "WORLD_SIZE=%d but --gpus %d" % (world, a.gpus)
 
     if a.train:
-        return bench_train(a, rank, world, D)
+        bench_train(a, rank, world, D)
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
     tdt = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
     params = backbone.init_params(seed=1, dcn_offset_std=0.01 if a.dcn else 0.0, fpn=a.fpn)
     cfg = detector.Config()
@@ -306,6 +349,8 @@ def main():
     # (random-init learn-NMS logits start at sigmoid(-3) x ~1/81 < 1e-3: zero detections is expected there)
     assert (n_det > 0 or a.learn_nms) and bool(torch.isfinite(out['cls_score']).all())
 
+    plain_graph = not (a.dcn or a.fpn or a.learn_nms or a.no_relation) and a.dtype == 'bf16'
+    res = None
     if rank == 0:
         images = world * a.batch * a.steps
         res = {
@@ -346,10 +391,45 @@ def main():
                     'launch_ms': att['avg_ms'], 'launches': att['calls'],
                     'algorithmic_gflop_per_launch': ALGO_GFLOP_PER_MODULE_IMAGE * rs * a.batch,
                 }
+                # honest utilisation figures next to the contract's `frac`: `frac` prices the graph AS WRITTEN (SURVEY 8d:
+                # softmax.V over 1024-d values, then the grouped linear_out); the kernel executes the re-associated form
+                # S.(F_K Wout^T) = 8.5x fewer FLOPs, so its MFMA pipes are `frac_executed` busy; `hbm_frac` = the bytes one
+                # launch must move (Q, K, VW^T, fp16 geometry bias, shortcut in, activation out) / duration / 8 TB/s
+                mp = (n_rois + 31) // 32 * 32
+                hbm_bytes = a.batch * (n_rois * 2048 * 2 + 1024 * mp * 2 + 16 * n_rois * mp * 2 + 2 * n_rois * 1024 * 2)
+                res['roofline'].update(frac_executed=res['roofline']['executed'] / peak, hbm_algorithmic_bytes=hbm_bytes,
+                                       hbm_frac=hbm_bytes / sec / 8e12,
+                                       frac_basis='algorithmic FLOPs of the graph as written (SURVEY 8d); see frac_executed / hbm_frac',
+                                       traffic_source='profiles/attention_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of an earlier '
+                                                      'run of this kernel at this batch; not re-measured by this process)' if traffic else None)
                 iso = attention_isolated(a.batch, n_rois, tdt)           # kernel alone: median of 100 launches
                 res['roofline'].update(isolated_median_ms=iso, isolated_frac=ALGO_GFLOP_PER_MODULE_IMAGE * rs * a.batch / iso / peak)
+        plain = not (a.dcn or a.fpn or a.learn_nms)
+        if world == 1 and plain and not a.no_parity and a.dtype == 'bf16':
+            # the timed configuration itself (same detector object, same batch) checked stage by stage against the oracle
+            from oracle import parity as OPAR
+            res['parity'] = OPAR.stagewise(det, data, im_info, params, images=range(min(a.parity_images, a.batch)),
+                                           relation=not a.no_relation)
+        if world == 1 and plain and not a.no_batch_sweep:
+            res['batch_sweep'] = {'note': 'images/s of the same step at other images-per-GPU-per-step settings (hipGraph replay); '
+                                          '1 = the reference protocol (BATCH_IMAGES: 1, SURVEY 8d)'}
+            for bsz in (1, 8):
+                if bsz == a.batch:
+                    continue
+                res['batch_sweep'][str(bsz)] = _replay_rate(det, bsz, a, D)
         if world == 1 and not a.no_cpu_baseline and not a.dcn and not a.fpn:      # the CPU port of the DCN graph is parity-only (slow)
             res['cpu_baseline'] = cpu_baseline(params, relation=not a.no_relation, images=a.cpu_images, threads=a.cpu_threads)
+    if plain_graph and not a.no_train_line:
+        # BASELINE configs[2] (relation + learn-NMS end2end TRAINING, one summed RCCL all-reduce per step) on the same N GPUs:
+        # the data-parallel path north_star's scaling target is stated on; every rank takes part in the collective
+        del det
+        torch.cuda.empty_cache()
+        ta = argparse.Namespace(**vars(a))
+        ta.batch, ta.learn_nms, ta.steps, ta.warmup = 8, True, min(a.steps, 10), 2
+        tr_res = bench_train(ta, rank, world, D, emit=False)
+        if rank == 0:
+            res['train'] = {k: tr_res[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'n_gpus', 'config', 'losses')}
+    if rank == 0:
         print(json.dumps(res))
     if world > 1:
         torch.distributed.barrier()

@@ -279,3 +279,9 @@ def test_detector_bf16_fullsize_stagewise(rn):
         flat = np.concatenate([np.hstack((np.full((len(w_), 1), c + 1.0), w_[:, 4:5], w_[:, :4])) for c, w_ in enumerate(want)])
         assert n == len(flat), (n, len(flat))
         np.testing.assert_allclose(_np(out['detections'][b, :n]), flat.astype(np.float32), rtol=1e-5)
+    # the same comparison as bench.py's `parity` block reports it
+    from oracle import parity as OPAR
+    rep = OPAR.stagewise(det, data.cuda(), im_info.cuda(), p, images=[1])
+    w = rep['worst']
+    assert w['proposal_rows_identical'] == 300 and w['roi_pool_mismatches'] == 0 and w['detections_all_matched'], rep
+    assert w['cls_prob_max_abs_err'] < 2e-2 and w['bbox_pred_max_rel_err'] < 3e-2, rep
