@@ -69,3 +69,29 @@ def stagewise(det, data, im_info, params, images=None, relation=True):
                         cls_prob_max_abs_err=max(res['cls_prob_max_abs_err']), bbox_pred_max_rel_err=max(res['bbox_pred_max_rel_err']),
                         detections_all_matched=bool(res['detections_matched'] == res['detections_oracle'] == res['detections_gpu']))
     return res
+
+
+def logit_report(logits, want, gw, wp):
+    """How far the attention logits `weighted_aff` (SYM_REL:139) are from the reference values, stated exactly.
+
+    logits / want [N, H, M]; gw = geometry weight relu(E.w_h + b_h) [N, H, M]; wp = pair_pos_fc1 weight [H, 64].
+    north_star's bar is |dL| <= 1e-4 in float32.  L contains log(max(G, 1e-6)) of a value G that the graph itself
+    computes from sin / cos of arguments scaled by 100 (SYM_REL:36): where G is tiny its float32 rounding noise
+    (~1e-7 ||w_h||_1) is amplified by 1 / G, for ANY implementation including MXNet's own kernels.  Reported:
+      max_abs_err            over ALL logits
+      frac_within_1e-4       share of all logits under the strict bar
+      frac_well_conditioned  share with G >= 2e-3 ||w_h||_1; max_abs_err_well_conditioned over those (must be <= 1e-4)
+      max_softmax_weighted   max over all logits of softmax(want) * |dL| -- the error as the module output sees it
+      max_bound_ratio        max of |dL| / (1e-4 + 8e-7 ||w_h||_1 / max(G, 1e-6)): <= 1 means inside the conditioned bound
+    """
+    logits, want, gw = np.asarray(logits, np.float64), np.asarray(want, np.float64), np.asarray(gw, np.float64)
+    s = np.abs(np.asarray(wp, np.float64)).sum(axis=1)[None, :, None]
+    dl = np.abs(logits - want)
+    well = gw >= 2e-3 * s
+    e = np.exp(want - want.max(axis=2, keepdims=True))
+    sm = e / e.sum(axis=2, keepdims=True)
+    return dict(max_abs_err=float(dl.max()), frac_within_1e_4=float((dl <= 1e-4).mean()),
+                frac_well_conditioned=float(well.mean()),
+                max_abs_err_well_conditioned=float(dl[well].max()) if well.any() else 0.0,
+                max_softmax_weighted=float((sm * dl).max()),
+                max_bound_ratio=float((dl / (1e-4 + 8e-7 * s / np.maximum(gw, 1e-6))).max()))

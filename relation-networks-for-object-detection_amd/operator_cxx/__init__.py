@@ -9,13 +9,29 @@ HIP kernels of csrc/deform.hip + the GEMM kernel.  `contrib` carries the Python 
 files use (`mx.contrib.sym.DeformableConvolution(...)`, SYM_DCN_RELNMS:702-704, 1073-1080).
 
 Tensors are the reference's: NCHW, fp32 (or bf16 / channels-last memory format for the throughput
-path -- the kernels take explicit strides).  Backward is not built yet.
+path -- the kernels take explicit strides).  `Backward(ctx, out_grad, in_data, out_data, req, in_grad, aux)` follows
+deformable_convolution-inl.h:145-237 / deformable_psroi_pooling-inl.h:97-140 (`req` per input: 'null' | 'write' | 'add';
+the data / offset / trans gradients come from relnet_deformable_col2im / relnet_deformable_psroi_pool_bwd).
+A C++ binding of the same classes over the C-ABI is include/relnet_operator_cxx.hpp.
 """
 import torch
 
 from .. import ops
 
-kWriteTo, kNullOp = 'write', 'null'
+kWriteTo, kNullOp, kAddTo, kWriteInplace = 'write', 'null', 'add', 'inplace'
+
+
+def _assign(dst, req, src):
+    """mshadow ASSIGN_DISPATCH / Assign: kNullOp leaves dst alone, kAddTo accumulates, kWriteTo / kWriteInplace overwrite."""
+    if req == kNullOp:
+        return
+    src = src.to(dst.dtype).reshape(dst.shape)
+    if req == kAddTo:
+        dst.add_(src)
+    elif req in (kWriteTo, kWriteInplace):
+        dst.copy_(src)
+    else:
+        raise ValueError('unknown OpReqType %r' % (req,))
 
 
 def _shape2(v, default):
@@ -93,6 +109,22 @@ class DeformableConvolutionProp(object):
         shapes = [dshape, oshape, wshape] + ([] if p.no_bias else [(p.num_filter,)])
         return shapes, [out]
 
+    def InferType(self, in_type):
+        """deformable_convolution-inl.h:419-437: one uniform dtype; unspecified (None) entries take the first input's."""
+        if not in_type or in_type[0] is None:
+            raise ValueError("First input must have specified type")
+        dt = in_type[0]
+        for i, t in enumerate(in_type):
+            if t is not None and t != dt:
+                raise ValueError("This layer requires uniform type. Expected %s v.s. given %s at %s" % (dt, t, self.ListArguments()[i]))
+        return [dt] * len(in_type), [dt]
+
+    def TypeString(self):
+        return '_contrib_DeformableConvolution'
+
+    def DeclareBackwardDependency(self, out_grad, in_data, out_data):
+        return [out_grad[0], in_data[0], in_data[1], in_data[2]]          # :448-453: kOut grad, kData, kOffset, kWeight
+
     def CreateOperatorEx(self, ctx=None, in_shape=None, in_type=None):
         return DeformableConvolutionOp(self.param_)
 
@@ -123,6 +155,28 @@ class DeformableConvolutionOp(object):
         y = ops.deformable_conv(data, offset.float(), self._pack(weight), bias, p.kernel, p.stride, p.dilate, p.pad,
                                 p.num_deformable_group, out_dtype=out_data[0].dtype)
         out_data[0].copy_(y)
+
+    def Backward(self, ctx, out_grad, in_data, out_data, req, in_grad, aux_args=None):
+        """DeformableConvolutionOp::Backward (deformable_convolution-inl.h:145-237): in_grad = [d data, d offset, d weight(, d bias)]
+        NCHW / OIHW like in_data; the data gradient starts from zero (`data_grad = 0`, :189-190) unless req is 'add'."""
+        p = self.param_
+        expected = 3 if p.no_bias else 4
+        if len(out_grad) != 1 or len(in_data) != expected or len(in_grad) != expected or len(req) != expected:
+            raise ValueError("DeformableConvolution.Backward: wrong number of out_grad / in_data / in_grad / req entries")
+        data, offset, weight = in_data[0], in_data[1], in_data[2]
+        if not weight.is_contiguous():
+            raise ValueError("DeformableConvolution.Backward: weight must be contiguous (:158)")
+        dy = out_grad[0]
+        cdt = data.dtype if data.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        dy_cl = dy.to(cdt).contiguous(memory_format=torch.channels_last)       # [B,Ho,Wo,Cout] memory the kernels read
+        gdata, goff, gw = ops.deformable_conv_bwd(data.to(cdt), offset.float(), self._pack(weight.to(cdt)), dy_cl, p.kernel, p.stride,
+                                                  p.dilate, p.pad, p.num_deformable_group)
+        kh, kw = p.kernel
+        _assign(in_grad[0], req[0], gdata.permute(0, 3, 1, 2))
+        _assign(in_grad[1], req[1], goff.permute(0, 3, 1, 2))
+        _assign(in_grad[2], req[2], gw.view(p.num_filter, kh, kw, -1).permute(0, 3, 1, 2))
+        if not p.no_bias:
+            _assign(in_grad[3], req[3], dy.float().sum((0, 2, 3)))                # sumall_except_dim<1>, :228-233
 
 
 class DeformablePSROIPoolingParam(object):
@@ -168,6 +222,13 @@ class DeformablePSROIPoolingProp(object):
         out = (bshape[0], p.output_dim, p.pooled_size, p.pooled_size)
         return list(in_shape), [out, out]
 
+    def TypeString(self):
+        return '_contrib_DeformablePSROIPooling'
+
+    def DeclareBackwardDependency(self, out_grad, in_data, out_data):
+        # deformable_psroi_pooling-inl.h:243-255: kOut grad, kData, kBox(, kTrans), kTopCount
+        return [out_grad[0]] + list(in_data[:2 if self.param_.no_trans else 3]) + [out_data[1]]
+
     def CreateOperatorEx(self, ctx=None, in_shape=None, in_type=None):
         return DeformablePSROIPoolingOp(self.param_)
 
@@ -194,6 +255,26 @@ class DeformablePSROIPoolingOp(object):
                                              want_top_count=True)
         out_data[0].copy_(out)
         out_data[1].copy_(cnt)
+
+    def Backward(self, ctx, out_grad, in_data, out_data, req, in_grad, aux_args=None):
+        """DeformablePSROIPoolingOp::Backward (deformable_psroi_pooling-inl.h:97-140): in_grad = [d data, d rois(, d trans)];
+        rois receive no gradient (the reference never writes grad_roi); kWriteInplace is rejected like there."""
+        p = self.param_
+        n_in = 2 if p.no_trans else 3
+        if len(in_data) != n_in or len(out_data) != 2 or len(in_grad) != n_in:
+            raise ValueError("DeformablePSROIPooling.Backward: wrong number of inputs / outputs")
+        if req[0] == kWriteInplace or req[1] == kWriteInplace:
+            raise ValueError("DeformablePSROIPooling: Backward doesn't support kWriteInplace.")
+        data, rois = in_data[0], in_data[1]
+        if out_grad[0].shape[0] != rois.shape[0] or out_data[1].shape[0] != rois.shape[0]:
+            raise ValueError("DeformablePSROIPooling.Backward: rows of out_grad / top_count must equal the number of rois")
+        trans = None if p.no_trans else in_data[2].float().contiguous()
+        g = out_grad[0].to(data.dtype).contiguous()
+        gdata, gtrans = ops.deformable_psroi_pool_bwd(g, data, rois.float().contiguous(), trans, p.spatial_scale, p.output_dim,
+                                                      p.group_size, p.pooled_size, p.part_size, p.sample_per_part, p.trans_std, p.no_trans)
+        _assign(in_grad[0], req[0], gdata)
+        if not p.no_trans:
+            _assign(in_grad[2], req[2], gtrans)
 
 
 class contrib(object):

@@ -79,6 +79,26 @@ LEARN_NMS_ARG_ORDER = ['nms_rank_weight', 'nms_rank_bias', 'roi_feat_embedding_w
                        'nms_key_1_weight', 'nms_key_1_bias', 'nms_linear_out_1_weight',
                        'nms_linear_out_1_bias', 'nms_logit_weight', 'nms_logit_bias']
 
+#: full-size cases (tests/golden/relation_large.npz keeps a SUBSET of query rows: the logits of one N = 1000 case are 64 MB)
+RELATION_LARGE_CASES = {
+    # name: (n, m, seed, std, rows kept)
+    'rel_n300_m300_std01': (300, 300, 13, 0.01, 48),
+    'rel_n333_m300_std05': (333, 300, 14, 0.05, 48),      # training shape: 300 proposals + gt rows, keys = first 300
+    'rel_n1000_m1000_std02': (1000, 1000, 15, 0.02, 24),  # FPN configuration (TOP_ROIS 1000)
+}
+
+
+def kept_rows(n, k, seed):
+    """The query rows stored for a large case: first, last and k-2 seeded random ones (sorted)."""
+    rng = np.random.default_rng(seed + 5000)
+    r = set([0, n - 1]) | set(int(x) for x in rng.choice(n, k, replace=False))
+    return np.array(sorted(r)[:k], dtype=np.int64)
+
+
+LEARN_NMS_LARGE_CASES = {
+    'lnms_n300_c80_f100': (300, 80, 100, 22),               # the benchmark's learn-NMS shape
+}
+
 LEARN_NMS_CASES = {
     # name: (n_rois, num_fg_classes, first_n, seed)
     'lnms_n60_c6_f20': (60, 6, 20, 21),

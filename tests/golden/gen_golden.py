@@ -173,6 +173,45 @@ def gen_relation(rel, out):
     np.savez_compressed(os.path.join(out, 'relation.npz'), **d)
 
 
+def gen_relation_large(rel, lnms, out):
+    """Full-size relation modules (N = M = 300, N = 333 / M = 300, N = M = 1000) and the 300-roi x 80-class learn-NMS
+    operator through the reference's own Python; only a subset of query rows is stored (cases.kept_rows)."""
+    import mxnet as mx
+    cls = rel.resnet_v1_101_rcnn_attention_1024_pairwise_position_multi_head_16
+    net = cls()
+    d = {}
+    for name, (n, m, seed, std, k) in cases.RELATION_LARGE_CASES.items():
+        boxes, feat, p = cases.relation_case(n, m, seed, std)
+        mx.PARAMS.clear(); mx.TRACE.clear()
+        mx.PARAMS.update({kk: mx.NDArray(v) for kk, v in p.items()})
+        pm = net.extract_position_matrix(mx.NDArray(boxes), nongt_dim=m)
+        pe = net.extract_position_embedding(pm, feat_dim=64)
+        y = net.attention_module_multi_head(mx.NDArray(feat), pe, nongt_dim=m, fc_dim=16, feat_dim=1024, index=1, group=16,
+                                            dim=(1024, 1024, 1024))
+        logits, soft = mx.TRACE['softmax_1']
+        rows = cases.kept_rows(n, k, seed)
+        d[name + '/rows'] = rows
+        d[name + '/logits'] = logits[rows]                # weighted_aff [rows, 16, M]
+        d[name + '/output'] = y.asnumpy()[rows]
+        d[name + '/position_matrix'] = pm.asnumpy()[rows]
+        print('   ', name, 'done', flush=True)
+        del pm, pe, y, logits, soft
+    for name, (n, c, first_n, seed) in cases.LEARN_NMS_LARGE_CASES.items():
+        cls_score, bbox_pred, rois, im_info, feat, p = cases.learn_nms_case(n, c, seed)
+        op = lnms.LearnNmsOperator(num_fg_classes=c, bbox_means=None, bbox_stds=None, first_n=first_n, class_agnostic=True,
+                                   num_thresh=5, class_thresh=0.01, nongt_dim=n, has_non_gt_index=False)
+        in_data = [mx.NDArray(x) for x in (cls_score, bbox_pred, rois, im_info, feat)]
+        in_data += [mx.NDArray(p[kk]) for kk in cases.LEARN_NMS_ARG_ORDER]
+        outs = [mx.nd.zeros((first_n, c, 5)), mx.nd.zeros((first_n, c, 4)), mx.nd.zeros((first_n, c))]
+        mx.TRACE.clear()
+        op.forward(False, ['write'] * 3, in_data, outs, [])
+        d[name + '/nms_multi_score'] = outs[0].asnumpy()
+        d[name + '/sorted_bbox'] = outs[1].asnumpy()
+        d[name + '/sorted_score'] = outs[2].asnumpy()
+        print('   ', name, 'done', flush=True)
+    np.savez_compressed(os.path.join(out, 'relation_large.npz'), **d)
+
+
 def gen_learn_nms(lnms, out):
     import mxnet as mx
     d = {}
@@ -304,8 +343,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
     ap.add_argument('--out', default=HERE)
+    ap.add_argument('--only-large', action='store_true', help='regenerate relation_large.npz only (minutes of numpy at N = 1000)')
+    ap.add_argument('--skip-large', action='store_true')
     a = ap.parse_args()
     ga, bt, nm, rel, lnms = setup_reference(a.ref)
+    if not a.skip_large:
+        gen_relation_large(rel, lnms, a.out)
+    if a.only_large:
+        return
     gen_boxes(ga, bt, a.out)
     gen_nms(nm, a.out)
     gen_relation(rel, a.out)

@@ -311,3 +311,59 @@ def test_psroi_backward(case):
         assert _relerr(gt.cpu().numpy(), tt.grad.numpy()) <= 2e-4
     else:
         assert gt is None
+
+
+def test_operator_backward_protocol():
+    """`DeformableConvolutionOp::Backward` / `DeformablePSROIPoolingOp::Backward` through the mirrored OperatorProperty /
+    Operator classes (deformable_convolution-inl.h:145-237, deformable_psroi_pooling-inl.h:97-140): NCHW fp32 blobs,
+    per-input OpReqType (write / add / null), bias gradient, vs float64 autograd of the restated forward."""
+    _, cxx = _mods()
+    from oracle import deform_torch as DT
+    rng = np.random.default_rng(31)
+    B, C, H, W, Co, k, pad, dil, dg = 2, 64, 9, 11, 64, 3, 2, 2, 4
+    data = rng.normal(0, 1, (B, C, H, W)).astype(F)
+    off = rng.normal(0, 1.0, (B, 2 * k * k * dg, H, W)).astype(F)
+    wgt = rng.normal(0, 0.05, (Co, C, k, k)).astype(F)
+    bias = rng.normal(0, 1, (Co,)).astype(F)
+    dy = rng.normal(0, 1, (B, Co, H, W)).astype(F)
+    td, to, tw = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (data, off, wgt))
+    y = DT.deformable_convolution(td, to, tw, (k, k), (1, 1), (dil, dil), (pad, pad), dg)
+    (y * torch.as_tensor(dy).double()).sum().backward()
+    prop = cxx.DeformableConvolutionProp(kernel=(k, k), num_filter=Co, pad=(pad, pad), dilate=(dil, dil), num_deformable_group=dg)
+    assert prop.TypeString() == '_contrib_DeformableConvolution' and prop.ListArguments() == ['data', 'offset', 'weight', 'bias']
+    assert prop.DeclareBackwardDependency(['og'], ['d', 'o', 'w', 'b'], ['out']) == ['og', 'd', 'o', 'w']
+    op = prop.CreateOperatorEx()
+    d = lambda a: torch.as_tensor(a).cuda()
+    in_data = [d(data), d(off), d(wgt), d(bias)]
+    prior = torch.ones(Co, C, k, k, device='cuda')
+    in_grad = [torch.full((B, C, H, W), 7.0, device='cuda'), torch.empty(B, 2 * k * k * dg, H, W, device='cuda'), prior.clone(),
+               torch.full((Co,), 5.0, device='cuda')]
+    op.Backward(None, [d(dy)], in_data, [None], ['write', 'write', 'add', 'null'], in_grad)
+    assert _relerr(in_grad[0].cpu().numpy(), td.grad.numpy()) <= 3e-4
+    assert _relerr(in_grad[1].cpu().numpy(), to.grad.numpy()) <= 3e-4
+    assert _relerr((in_grad[2] - prior).cpu().numpy(), tw.grad.numpy()) <= 3e-4          # kAddTo accumulated onto the ones
+    assert bool((in_grad[3] == 5.0).all())                                               # kNullOp left alone
+    op.Backward(None, [d(dy)], in_data, [None], ['null', 'null', 'null', 'write'], in_grad)
+    assert _relerr(in_grad[3].cpu().numpy(), dy.sum((0, 2, 3))) <= 1e-5
+    # pooling operator
+    P, R, od = 7, 10, 16
+    feat = rng.normal(0, 1, (B, od, 14, 17)).astype(F)
+    rois = _rois(rng, R, B, 17, 14)
+    trans = rng.normal(0, 1.0, (R, 2, P, P)).astype(F)
+    gout = rng.normal(0, 1, (R, od, P, P)).astype(F)
+    tf = torch.tensor(feat, dtype=torch.float64, requires_grad=True)
+    tt = torch.tensor(trans, dtype=torch.float64, requires_grad=True)
+    yp = DT.deformable_psroi_pooling(tf, rois, tt, 0.0625, od, 1, P, P, 4, 0.1, False)
+    (yp * torch.as_tensor(gout).double()).sum().backward()
+    pprop = cxx.DeformablePSROIPoolingProp(spatial_scale=0.0625, output_dim=od, group_size=1, pooled_size=P, part_size=P,
+                                           sample_per_part=4, trans_std=0.1, no_trans=False)
+    assert pprop.DeclareBackwardDependency(['og'], ['d', 'r', 't'], ['out', 'cnt']) == ['og', 'd', 'r', 't', 'cnt']
+    pop = pprop.CreateOperatorEx()
+    out = [torch.empty(R, od, P, P, device='cuda'), torch.empty(R, od, P, P, device='cuda')]
+    pop.Forward(None, [d(feat), d(rois), d(trans)], ['write', 'write'], out)
+    gin = [torch.empty(B, od, 14, 17, device='cuda'), torch.zeros(R, 5, device='cuda'), torch.empty(R, 2, P, P, device='cuda')]
+    pop.Backward(None, [d(gout)], [d(feat), d(rois), d(trans)], out, ['write', 'null', 'write'], gin)
+    assert _relerr(gin[0].cpu().numpy(), tf.grad.numpy()) <= 2e-5 and _relerr(gin[2].cpu().numpy(), tt.grad.numpy()) <= 2e-4
+    assert bool((gin[1] == 0).all())
+    with pytest.raises(ValueError):
+        pop.Backward(None, [d(gout)], [d(feat), d(rois), d(trans)], out, ['inplace', 'null', 'write'], gin)

@@ -72,3 +72,21 @@ def test_learn_nms_full_config_vs_oracle(rn, dtype, tol):
     assert nd >= k
     got_scores = np.sort(r['detections'][0, :nd, 1].cpu().numpy())[::-1]
     np.testing.assert_allclose(got_scores[:k], flat[:k].astype(np.float32), rtol=1e-6)
+
+
+def test_learn_nms_benchmark_shape_vs_reference_run_golden(rn):
+    """300 rois x 80 classes x first_n 100 against the reference's own LearnNmsOperator.forward output (relation_large.npz)."""
+    import os
+    learn_nms, operator_py = rn
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'relation_large.npz'))
+    for name, (n, c, first_n, seed) in cases.LEARN_NMS_LARGE_CASES.items():
+        cls_score, bbox_pred, rois, im_info, feat, p = cases.learn_nms_case(n, c, seed)
+        kw = dict(cls_score=_d(cls_score), bbox_pred=_d(bbox_pred), rois=_d(rois), im_info=_d(im_info), fc_all_2_relu=_d(feat))
+        kw.update({k: _d(p[k]) for k in cases.LEARN_NMS_ARG_ORDER})
+        multi, sbox, sscore = operator_py.Custom(op_type='learn_nms', name='nms_multi_score', num_fg_classes=c, bbox_means='None',
+                                                 bbox_stds='None', first_n=first_n, class_agnostic=True, num_thresh=5,
+                                                 class_thresh=0.01, nongt_dim=n, has_non_gt_index=False, **kw)
+        np.testing.assert_allclose(sscore.cpu().numpy(), g[name + '/sorted_score'], rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(sbox.cpu().numpy(), g[name + '/sorted_bbox'], rtol=0, atol=1e-4)
+        want = g[name + '/nms_multi_score']
+        np.testing.assert_allclose(multi.cpu().numpy(), want, rtol=1e-3, atol=1e-5 * np.abs(want).max())

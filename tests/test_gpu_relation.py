@@ -21,14 +21,19 @@ from oracle import relation as OR
 pytestmark = pytest.mark.gpu
 
 
-def check_logits(logits, want, gw, wp):
-    """gw: oracle geometry weight [N, H, M]; wp: pair_pos_fc1 weight [H, 64]."""
-    s = np.abs(wp).sum(axis=1)[None, :, None]
-    dl = np.abs(logits - want)
-    well = gw >= 2e-3 * s
-    assert well.mean() > 0.3
-    assert dl[well].max() <= 1e-4, dl[well].max()
-    assert (dl <= 1e-4 + 8e-7 * s / np.maximum(gw, 1e-6)).all()
+def check_logits(logits, want, gw, wp, what=''):
+    """gw: oracle geometry weight [N, H, M]; wp: pair_pos_fc1 weight [H, 64].  Prints and asserts the exact statement of
+    the logit bar (oracle/parity.py:logit_report): the strict 1e-4 bound holds for EVERY well-conditioned logit and for
+    > 99.9 % of all logits; the rest sit at G ~ 1e-6 (softmax weight ~ 0) inside the conditioned bound; as the module
+    output sees them (softmax-weighted) all errors are < 1e-6."""
+    from oracle import parity as OPAR
+    r = OPAR.logit_report(logits, want, gw, wp)
+    print('logits %s: %s' % (what, ' '.join('%s=%.3g' % kv for kv in r.items())))
+    assert r['max_abs_err_well_conditioned'] <= 1e-4, r
+    assert r['max_bound_ratio'] <= 1.0, r
+    assert r['frac_within_1e_4'] >= 0.999, r
+    assert r['max_softmax_weighted'] <= 1e-6, r
+    return r
 
 
 def _dev(x, dtype=None):
@@ -98,7 +103,7 @@ def test_relation_module_fp32_vs_golden_and_oracle(rn, golden, name):
                                                      dtype=torch.float32, return_logits=True)
     y, logits = y.cpu().numpy(), logits.cpu().numpy()
     gw = OR.relation_module(feat, g[name + '/position_embedding'], p, 1, m, return_intermediates=True)['aff_weight']
-    check_logits(logits, g[name + '/logits'], gw, p['pair_pos_fc1_1_weight'])
+    check_logits(logits, g[name + '/logits'], gw, p['pair_pos_fc1_1_weight'], name)
     want = g[name + '/output']
     assert np.abs(y - want).max() <= 1e-4 * np.abs(want).max()
 
@@ -114,12 +119,36 @@ def test_relation_module_full_size(rn, n, m, seed, std):
     r = OR.relation_module(feat, pe, p, 1, m, return_intermediates=True)
     y, logits = relation.attention_module_multi_head(_dev(feat), _dev(boxes), pt, nongt_dim=m,
                                                      dtype=torch.float32, return_logits=True)
-    check_logits(logits.cpu().numpy(), r['logits'], r['aff_weight'], p['pair_pos_fc1_1_weight'])
+    check_logits(logits.cpu().numpy(), r['logits'], r['aff_weight'], p['pair_pos_fc1_1_weight'], 'oracle N=%d M=%d std=%g' % (n, m, std))
     scale = np.abs(r['output']).max()
     assert np.abs(y.cpu().numpy() - r['output']).max() <= 1e-4 * scale
     # bf16 throughput path: same module, bf16 operands, fp32 softmax/accumulate
     yb = relation.attention_module_multi_head(_dev(feat), _dev(boxes), pt, nongt_dim=m, dtype=torch.bfloat16)
     assert np.abs(yb.float().cpu().numpy() - r['output']).max() <= 2e-2 * scale
+
+
+@pytest.mark.parametrize('name', list(cases.RELATION_LARGE_CASES))
+def test_relation_module_full_size_vs_reference_run_golden(rn, name):
+    """Full-size modules against tests/golden/relation_large.npz = the reference's OWN attention_module_multi_head /
+    extract_position_* run on the numpy MXNet stand-in (gen_golden.py --only-large); stored rows only."""
+    import os
+    ops, relation = rn
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'relation_large.npz'))
+    n, m, seed, std, k = cases.RELATION_LARGE_CASES[name]
+    boxes, feat, p = cases.relation_case(n, m, seed, std)
+    rows = g[name + '/rows']
+    assert np.array_equal(rows, cases.kept_rows(n, k, seed))
+    pt = {kk: torch.as_tensor(v) for kk, v in p.items()}
+    y, logits = relation.attention_module_multi_head(_dev(feat), _dev(boxes), pt, nongt_dim=m, dtype=torch.float32, return_logits=True)
+    y, logits = y.cpu().numpy()[rows], logits.cpu().numpy()[rows]
+    pm = OR.position_matrix(boxes, m)
+    assert np.array_equal(pm[rows], g[name + '/position_matrix'])                      # oracle == reference run, bit exact
+    gw = OR.relation_module(feat, OR.position_embedding(pm), p, 1, m, return_intermediates=True)['aff_weight'][rows]
+    check_logits(logits, g[name + '/logits'], gw, p['pair_pos_fc1_1_weight'], 'golden ' + name)
+    want = g[name + '/output']
+    assert np.abs(y - want).max() <= 1e-4 * np.abs(want).max()
+    yb = relation.attention_module_multi_head(_dev(feat), _dev(boxes), pt, nongt_dim=m, dtype=torch.bfloat16)
+    assert np.abs(yb.float().cpu().numpy()[rows] - want).max() <= 2e-2 * np.abs(want).max()
 
 
 def test_relation_batched_equals_single(rn):

@@ -1,6 +1,7 @@
 """The CPU oracle against golden vectors produced by the reference's own python
 (tests/golden/gen_golden.py) plus hand-checkable known answers."""
 import numpy as np
+import pytest
 
 import cases
 from oracle import boxes as OB
@@ -186,3 +187,33 @@ def test_proposal_operator_matches_reference_operator(golden):
         # a 1-ulp exp error in the predicted width / height (up to ~1000 px) moves a corner by up to 2 ulps OF THAT SIZE
         assert rois.shape == want.shape and np.abs(rois - want).max() <= 2 * np.spacing(np.float32(1000.0))
         assert np.array_equal(rois[:, 0], want[:, 0])
+
+
+@pytest.mark.parametrize('name', ['rel_n300_m300_std01', 'rel_n333_m300_std05'])
+def test_relation_module_full_size_matches_reference_run(name):
+    """The oracle pinned at the BENCHMARK size (N = M = 300, and the training shape N = 333 / M = 300) by
+    tests/golden/relation_large.npz = the reference's own graph code run on the numpy MXNet stand-in
+    (gen_golden.py --only-large).  (The N = 1000 case is exercised by the GPU suite; its oracle needs ~2 GB.)"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'relation_large.npz'))
+    n, m, seed, std, k = cases.RELATION_LARGE_CASES[name]
+    boxes, feat, p = cases.relation_case(n, m, seed, std)
+    rows = g[name + '/rows']
+    assert np.array_equal(rows, cases.kept_rows(n, k, seed))
+    pm = OR.position_matrix(boxes, m)
+    assert np.array_equal(pm[rows], g[name + '/position_matrix'])
+    r = OR.relation_module(feat, OR.position_embedding(pm), p, index=1, nongt_dim=m, return_intermediates=True)
+    np.testing.assert_allclose(r['logits'][rows], g[name + '/logits'], rtol=0, atol=4e-6)
+    np.testing.assert_allclose(r['output'][rows], g[name + '/output'], rtol=2e-5, atol=2e-6)
+
+
+def test_learn_nms_benchmark_shape_matches_reference_operator():
+    """300 rois x 80 classes x first_n 100 through the reference's LearnNmsOperator.forward (relation_large.npz)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'relation_large.npz'))
+    for name, (n, c, first_n, seed) in cases.LEARN_NMS_LARGE_CASES.items():
+        cls_score, bbox_pred, rois, im_info, feat, p = cases.learn_nms_case(n, c, seed)
+        multi, sbox, sscore = OL.learn_nms(cls_score, bbox_pred, rois, im_info, feat, p, num_fg_classes=c, first_n=first_n, nongt_dim=n)
+        np.testing.assert_allclose(sscore, g[name + '/sorted_score'], rtol=1e-6, atol=0)
+        np.testing.assert_allclose(sbox, g[name + '/sorted_bbox'], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(multi, g[name + '/nms_multi_score'], rtol=5e-5, atol=2e-7)
