@@ -1,0 +1,56 @@
+"""Data side on the GPU: `pred_eval` (loader -> HIP detector -> COCO bbox evaluation) and the
+precomputed-proposal flow `generate_proposals` -> `<name>_rpn.pkl` -> `rpn_roidb(append_gt)` -> `ROIIter` -> FPN training
+step, on a miniature synthetic COCO tree (random-init weights: the numbers are meaningless, the plumbing is what is tested)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_dataset import make_dataset  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pred_eval_and_precomputed_proposal_training(tmp_path):
+    import relnet_amd  # noqa: F401
+    from relnet_amd import backbone, detector, train, config as C
+    from relnet_amd.dataset import loader as LD, tester as TS
+    db = make_dataset(str(tmp_path), degenerate=False)
+    roidb = db.gt_roidb()
+    cfg = C.experiment('rcnn_end2end_relation_8epoch')
+    cfg.SCALES[0] = (128, 192)
+    p = backbone.init_params(seed=2, num_classes=db.num_classes)
+    g = torch.Generator().manual_seed(3)
+    for k in ('cls_score_weight', 'bbox_pred_weight'):
+        p[k] = torch.randn(p[k].shape, generator=g) * 0.05
+    dcfg = detector.Config()
+    dcfg.num_classes, dcfg.rpn_post_nms_top_n = db.num_classes, 60
+    det = detector.Detector(p, dtype=torch.bfloat16, cfg=dcfg, im_hw=(128, 192))
+    # ---- test.py / pred_eval: every image through the detector, all_boxes[cls][image], results json, 12 COCO stats
+    info, stats, all_boxes = TS.pred_eval(det, LD.TestLoader(roidb, cfg, batch_size=1, has_rpn=True), db)
+    assert len(all_boxes) == db.num_classes and len(all_boxes[1]) == db.num_images
+    n_det = sum(len(all_boxes[c][i]) for c in range(1, db.num_classes) for i in range(db.num_images))
+    assert 0 < n_det <= 100 * db.num_images and stats.shape == (12,) and (stats >= -1).all() and (stats <= 1).all()
+    assert os.path.exists(os.path.join(db.result_path, 'results', 'detections_val2014_results.json'))
+    b = all_boxes[1][0]
+    assert b.shape[1] == 5 and (b[:, 2] >= b[:, 0]).all() and b[:, 2].max() <= roidb[0]['width'] - 1 + 1e-3     # original-image coordinates
+    # ---- generate_proposals: RPN pass -> <name>_rpn.pkl in the reference's format
+    boxes = TS.generate_proposals(det, LD.TestLoader(roidb, cfg, batch_size=2, has_rpn=True), db)
+    assert len(boxes) == db.num_images and boxes[0].shape == (60, 5) and os.path.exists(db.rpn_file())
+    assert boxes[0][:, 2].max() <= roidb[0]['width'] - 1 + 1e-3 and (np.diff(boxes[0][:, 4]) <= 1e-6).all()      # sorted by RPN score
+    # ---- alternate / FPN training on the stored proposals: rpn_roidb(append_gt) -> ROIIter -> FPNTrainer step
+    fcfg = C.experiment('rcnn_fpn_relation_learn_nms_8epoch')
+    fcfg.SCALES[0] = (128, 192); fcfg.TRAIN.TOP_ROIS = 48
+    merged = db.rpn_roidb(db.gt_roidb(), append_gt=True, top_roi=48)            # bbox_overlaps on the device twin
+    assert merged[0]['boxes'].shape[0] == 48 + len(roidb[0]['boxes']) and merged[0]['is_gt'].sum() == len(roidb[0]['boxes'])
+    pf = backbone.init_params(seed=4, fpn=True, num_classes=db.num_classes)
+    tcfg = train.TrainConfig(); tcfg.learn_nms, tcfg.first_n, tcfg.num_classes = True, 16, db.num_classes
+    tr = train.FPNTrainer(pf, tcfg)
+    it = LD.ROIIter(merged, fcfg, batch_size=2, shuffle=True, aspect_grouping=True, seed=1, device='cuda')
+    batch = next(iter(it))
+    out = tr.step(batch['data'], batch['im_info'], batch['gt_boxes'], batch['proposals'], num_gt=batch['num_gt'])
+    assert out['rois'].shape[1] == 48 + batch['gt_boxes'].shape[1] and torch.isfinite(out['bbox_loss']).all()
+    assert torch.isfinite(tr.W.master).all()
