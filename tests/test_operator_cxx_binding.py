@@ -1,0 +1,89 @@
+"""include/relnet_operator_cxx.hpp -- the C++ OperatorProperty / Operator binding of the reference's `operator_cxx`
+interface over the C-ABI.  CPU: the header and its harness compile and link against librelnet_hip.so.  GPU: the harness
+(tests/cxx/opcxx_harness.cpp, driven through ctypes) runs Prop::InferShape + Op::Forward / Op::Backward on device buffers
+and is compared with float64 autograd of the restated operators (oracle/deform_torch.py)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'relation-networks-for-object-detection_amd')
+SO = os.path.join(ROOT, 'tests', 'cxx', 'libopcxx_test.so')
+
+
+def _build():
+    import __graft_entry__ as ge
+    ge.build()
+    src = os.path.join(ROOT, 'tests', 'cxx', 'opcxx_harness.cpp')
+    hdr = os.path.join(ROOT, 'include', 'relnet_operator_cxx.hpp')
+    if os.path.exists(SO) and os.path.getmtime(SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        return SO
+    cmd = [os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '-std=c++17', '-O2', '-fPIC', '-shared', '-x', 'hip', '--offload-arch=gfx950',
+           '-I' + os.path.join(ROOT, 'include'), src, '-o', SO, '-L' + PKG, '-lrelnet_hip', '-Wl,-rpath,' + PKG]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    return SO
+
+
+def test_header_and_harness_compile_and_link():
+    so = _build()
+    syms = subprocess.run(['nm', '-D', '--defined-only', so], stdout=subprocess.PIPE).stdout.decode()
+    assert 'opcxx_deformable_conv' in syms and 'opcxx_deformable_psroi' in syms
+
+
+def _p(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+@pytest.mark.gpu
+def test_cxx_operators_forward_backward_match_autograd():
+    from oracle import deform_torch as DT
+    lib = C.CDLL(_build())
+    lib.opcxx_last_error.restype = C.c_char_p
+    rng = np.random.default_rng(41)
+    N, Cc, H, W, Co, k, pad, dil, dg = 2, 32, 9, 11, 48, 3, 2, 2, 4
+    f = np.float32
+    data = rng.normal(0, 1, (N, Cc, H, W)).astype(f); off = rng.normal(0, 1, (N, 2 * k * k * dg, H, W)).astype(f)
+    wgt = rng.normal(0, 0.05, (Co, Cc, k, k)).astype(f); bias = rng.normal(0, 1, (Co,)).astype(f); dy = rng.normal(0, 1, (N, Co, H, W)).astype(f)
+    td, to, tw, tb = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (data, off, wgt, bias))
+    y = DT.deformable_convolution(td, to, tw, (k, k), (1, 1), (dil, dil), (pad, pad), dg) + tb.view(1, -1, 1, 1)
+    (y * torch.as_tensor(dy).double()).sum().backward()
+    d = lambda a: torch.as_tensor(a).cuda().contiguous()
+    x, o, w, b, g = d(data), d(off), d(wgt), d(bias), d(dy)
+    out = torch.empty(N, Co, H, W, device='cuda')
+    prior_w = torch.full((Co, Cc, k, k), 0.5, device='cuda')
+    gx, go, gw, gb = torch.empty_like(x), torch.empty_like(o), prior_w.clone(), torch.full((Co,), 9.0, device='cuda')
+    req = (C.c_int * 4)(1, 1, 3, 1)                      # data write, offset write, weight ADD, bias write
+    oshape = (C.c_long * 4)()
+    rc = lib.opcxx_deformable_conv(_p(x), _p(o), _p(w), _p(b), _p(out), _p(g), _p(gx), _p(go), _p(gw), _p(gb), req,
+                                   N, Cc, H, W, Co, k, pad, 1, dil, dg, oshape)
+    assert rc == 0, (rc, lib.opcxx_last_error())
+    assert tuple(oshape) == (N, Co, H, W)
+    rel = lambda a, t: float((a.double().cpu() - t).abs().max() / t.abs().max())
+    assert rel(out, y.detach()) < 2e-5
+    assert rel(gx, td.grad) < 3e-4 and rel(go, to.grad) < 3e-4
+    assert rel(gw - prior_w, tw.grad) < 3e-4                                  # kAddTo accumulated onto the prior contents
+    assert rel(gb, tb.grad) < 1e-5
+    # pooling operator with learned part offsets
+    R, od, P = 10, 16, 7
+    feat = rng.normal(0, 1, (N, od, 14, 17)).astype(f)
+    x1 = rng.uniform(0, 150, R); y1 = rng.uniform(0, 120, R)
+    rois = np.stack([rng.integers(0, N, R), x1, y1, x1 + rng.uniform(20, 100, R), y1 + rng.uniform(20, 90, R)], 1).astype(f)
+    trans = rng.normal(0, 1, (R, 2, P, P)).astype(f); gout = rng.normal(0, 1, (R, od, P, P)).astype(f)
+    tf = torch.tensor(feat, dtype=torch.float64, requires_grad=True); tt = torch.tensor(trans, dtype=torch.float64, requires_grad=True)
+    yp = DT.deformable_psroi_pooling(tf, rois, tt, 0.0625, od, 1, P, P, 4, 0.1, False)
+    (yp * torch.as_tensor(gout).double()).sum().backward()
+    po, pc = torch.empty(R, od, P, P, device='cuda'), torch.empty(R, od, P, P, device='cuda')
+    gf, gt = torch.empty(N, od, 14, 17, device='cuda'), torch.empty(R, 2, P, P, device='cuda')
+    lib.opcxx_deformable_psroi.argtypes = [C.c_void_p] * 8 + [C.c_int] * 9 + [C.c_float, C.c_float, C.c_int]
+    rc = lib.opcxx_deformable_psroi(_p(d(feat)), _p(d(rois)), _p(d(trans)), _p(po), _p(pc), _p(d(gout)), _p(gf), _p(gt), N, od, 14, 17, R, od, 1, P, 4,
+                                    0.0625, 0.1, 1)
+    assert rc == 0, (rc, lib.opcxx_last_error())
+    assert rel(po, yp.detach()) < 1e-5 and rel(gf, tf.grad) < 2e-5 and rel(gt, tt.grad) < 2e-4
+    # a violated CHECK surfaces as an error, not as an abort
+    rc = lib.opcxx_deformable_conv(_p(x), _p(o), _p(w), _p(b), _p(out), None, None, None, None, None, req, N, Cc, H, W, Co, k, pad, 1, dil, dg + 1, oshape)
+    assert rc == -1 and b'deformable group' in lib.opcxx_last_error()
