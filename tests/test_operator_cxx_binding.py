@@ -80,7 +80,8 @@ def test_cxx_operators_forward_backward_match_autograd():
     po, pc = torch.empty(R, od, P, P, device='cuda'), torch.empty(R, od, P, P, device='cuda')
     gf, gt = torch.empty(N, od, 14, 17, device='cuda'), torch.empty(R, 2, P, P, device='cuda')
     lib.opcxx_deformable_psroi.argtypes = [C.c_void_p] * 8 + [C.c_int] * 9 + [C.c_float, C.c_float, C.c_int]
-    rc = lib.opcxx_deformable_psroi(_p(d(feat)), _p(d(rois)), _p(d(trans)), _p(po), _p(pc), _p(d(gout)), _p(gf), _p(gt), N, od, 14, 17, R, od, 1, P, 4,
+    dfeat, drois, dtrans, dgout = d(feat), d(rois), d(trans), d(gout)                     # (kept alive across the call)
+    rc = lib.opcxx_deformable_psroi(_p(dfeat), _p(drois), _p(dtrans), _p(po), _p(pc), _p(dgout), _p(gf), _p(gt), N, od, 14, 17, R, od, 1, P, 4,
                                     0.0625, 0.1, 1)
     assert rc == 0, (rc, lib.opcxx_last_error())
     assert rel(po, yp.detach()) < 1e-5 and rel(gf, tf.grad) < 2e-5 and rel(gt, tt.grad) < 2e-4
