@@ -89,7 +89,7 @@ class LearnNMS(object):
         xr = x.view(BC, F, 128)
         qk = ops.gemm_nt(xr.reshape(BC * F, 128), self.wqk, self.bqk).view(BC, F, 2048)
         Mpad = ops.pad32(F)
-        key = (BC, Mpad)
+        key = (BC, Mpad, F)            # keyed on F too: pad columns [F, Mpad) must stay zero
         if key not in self._vwt:
             self._vwt[key] = torch.zeros((BC, 1024, Mpad), device=dev, dtype=self.dtype)
         vwt = self._vwt[key]

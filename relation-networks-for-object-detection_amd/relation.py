@@ -107,8 +107,8 @@ class RelationHead(object):
             self.wp_t, self.bp = pack_pair_pos(self.mods, device)
         self._vwt = {}
 
-    def _vwt_buf(self, B, Mpad):
-        key = (B, Mpad)
+    def _vwt_buf(self, B, Mpad, M):
+        key = (B, Mpad, M)            # keyed on M too: a smaller M in the same padded width would inherit stale columns [M, Mpad)
         if key not in self._vwt:      # pad columns stay zero: the GEMM only writes [:, :, :M]
             self._vwt[key] = [torch.zeros((B, 1024, Mpad), device=self.device, dtype=self.dtype) for _ in range(2)]
         return self._vwt[key]
@@ -124,7 +124,7 @@ class RelationHead(object):
             return cb[:, :, :self.num_classes], cb[:, :, self.num_classes:], x2
         M = N if nongt_dim is None else nongt_dim
         bias = ops.geometry_bias(rois, self.wp_t, self.bp, M, half=self.dtype == torch.bfloat16)   # [2,B,16,N,Mpad]
-        vw = self._vwt_buf(B, bias.shape[-1])
+        vw = self._vwt_buf(B, bias.shape[-1], M)
         f1 = ops.gemm_nt(pooled.reshape(B * N, K), self.w1, self.b1).reshape(B, N, -1)
         y1, x1, _ = _module_forward(f1, self.mods[0], bias[0], M, return_intermediates, True, False, vw[0])
         f2 = ops.gemm_nt(x1.reshape(B * N, -1), self.w2, self.b2).reshape(B, N, -1)
