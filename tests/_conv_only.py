@@ -4,7 +4,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import relnet_amd
-from relnet_amd import ops
+from relnet_amd import ops, lib
+lib.load().relnet_gemm_force_tile(int(os.environ.get('TILE', '0')))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 54
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 H, W = 38, 63
