@@ -128,6 +128,15 @@ int relnet_relation_attention(const void* q, long q_ld, long q_bs, const void* k
                               int B, int H, int N, int M, int Mpad, float scale, int in_dtype, int out_dtype,
                               void* stream);
 
+/* Row-panel form of the 1x1 convolutions (csrc/gemm.hip:gemm_panelw_kernel): `w_frag` is the weight matrix re-ordered once
+ * at model load by relnet_pack_w_frag ([Cout][K] bf16 -> MFMA fragment order, same byte count; Cout % 32 == 0, K % 16 == 0).
+ * relnet_conv2d_nhwc_wf == relnet_conv2d_nhwc when w_frag is NULL or the layer is not a stride-1 1x1 convolution with
+ * K in {64,128,256,512} and Cout % 256 == 0.                                                                        */
+int relnet_pack_w_frag(const void* w, long ldw, void* out, int N, int K, void* stream);
+int relnet_conv2d_nhwc_wf(const void* in, long in_pix, long in_img, const void* w, const void* w_frag, const float* bias,
+                          const void* resid, int relu, void* out, long ldc, int B, int H, int W, int Cin, int Cout, int R,
+                          int S, int stride, int dil, int pad, int out_dtype, void* stream);
+
 /* ---- relation_rcnn/core/tester.py:148-156 (im_detect) + :244-277 (per-class NMS, max_per_image) ----
  * detect_head: SoftmaxActivation over classes + class-agnostic decode (bbox_transform.py:103-140,
  * float64) + clip + 1/scale; boxes [R,4] float64.                                                   */

@@ -130,6 +130,7 @@ class Backbone(object):
         self.mf = torch.channels_last if channels_last else torch.contiguous_format
         self.w = {}
         self.wp = {}
+        self.wf = {}          # name -> fragment-order weight copy (panel kernel)
         self.b32 = {}
         for conv, bn, oc, ic, k in conv_bn_names():
             w, b = fold_bn(params[conv + '_weight'], params[bn + '_gamma'], params[bn + '_beta'],
@@ -169,11 +170,16 @@ class Backbone(object):
         if self.impl == 'hip' and w.shape[1] % 64 == 0:
             self.wp[name] = (ops.pack_conv_weight(w, self.dtype, self.device),
                              b.to(self.device, torch.float32).contiguous(), int(w.shape[2]))
+            # 256-deep expand convolutions (res4 branch2c, 23 per step): a second copy of the weights in MFMA-fragment
+            # order lets relnet_conv2d_nhwc_wf pick the panel kernel (A resident in LDS, W streamed through registers)
+            if self.dtype == torch.bfloat16 and tuple(w.shape[1:]) == (256, 1, 1) and w.shape[0] % 256 == 0 \
+                    and name.endswith('_branch2c'):
+                self.wf[name] = ops.pack_w_frag(self.wp[name][0])
 
     def _hconv(self, x, name, stride=1, pad=0, dil=1, relu=False, resid=None, out_dtype=None):
         w, b, k = self.wp[name]
         return ops.conv2d_nhwc(x, w, b, ksize=k, stride=stride, pad=pad, dil=dil, relu=relu, resid=resid,
-                               out_dtype=out_dtype)
+                               out_dtype=out_dtype, w_frag=self.wf.get(name))
 
     def _forward_hip(self, data):
         if self.stem == 'hip':

@@ -30,6 +30,7 @@ struct GemmArgs {
   long cPix, cImg;         // element strides between pixels / images of the input
   int n_loop;              // column tiles walked by one workgroup (row-panel mode), >= 1
   int xcd_swizzle;         // 1: remap the linear workgroup id so that every XCD owns a contiguous run of tiles
+  const void* Wf;          // optional: W pre-packed in MFMA fragment order (relnet_pack_w_frag), used by gemm_panelw_kernel
 };
 
 template <typename TOUT> __device__ __forceinline__ void store_out(TOUT* p, float v);
@@ -855,6 +856,378 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Row-panel kernel for the HBM-bound 1x1 "expand" convolutions / short-K GEMMs (K = 64 .. 512, N a multiple of 256):
+// ONE workgroup owns BM output rows and ALL N columns.
+//   * the A panel [BM][K] is loaded into LDS once and stays there (the tiled kernels re-stream it per column tile);
+//   * W [N][K] streams through a 3-buffer ring of 32-deep slabs as ONE continuous sequence over (column tile, k-slab):
+//     the slabs of the next column tile are already in flight while the current tile's epilogue runs, so the
+//     load -> MFMA -> store phases of consecutive tiles overlap inside the workgroup (the 256x256 kernels run them
+//     back to back at one workgroup per CU: 26 us per tile for 4 k-slabs, r02 ablation in DESIGN.md);
+//   * the epilogue band (32 rows) has its own LDS, and the shortcut rows of the NEXT tile are fetched before the
+//     current tile's stores are issued.
+// vmcnt discipline: global stores and loads retire out of order with respect to each other, so the first wait of every
+// column tile is vmcnt(0) (stores of the previous epilogue, shortcut prefetch, first slabs); inside a tile only
+// LDS-direct loads are outstanding and the waits are counted (one slab stays in flight across the barrier).
+// ---------------------------------------------------------------------------------------
+template <int KP> __device__ __forceinline__ int panel_swz(int slot, int row) {
+  if constexpr (KP / 8 >= 16) return (slot & ~15) | ((slot & 15) ^ (row & 15));
+  else return slot ^ ((row >> 1) & 7);
+}
+
+template <int BM, int KP, bool RESID>
+__global__ __launch_bounds__(512) void gemm_panel_kernel(GemmArgs g) {
+  constexpr int WM = 2, WN = 4, NW = 8, NT = 512, BN = 256;
+  constexpr int TM = BM / (32 * WM), TN = 2;
+  constexpr int ROWA = KP * 2;                         // bytes per A row in LDS
+  constexpr int A_BYTES = BM * ROWA;
+  constexpr int A_INSTR = A_BYTES / 1024 / NW;         // LDS-direct loads per wave for the panel
+  constexpr int BKW = 32, WROWB = 64, NSTAGE = 3, WSTAGE = BN * WROWB;      // 16 KiB slabs
+  constexpr int WG_PER_WAVE = BN / (16 * NW);          // 16-row groups of a slab per wave = LDS-direct loads per slab
+  constexpr int NKS = KP / BKW;                        // slabs per column tile
+  constexpr int CLD = BN + 4, BROWS = 32;
+  constexpr int BAND_BYTES = BROWS * CLD * 4;
+  constexpr int LDS_BYTES = A_BYTES + NSTAGE * WSTAGE + BAND_BYTES;
+  static_assert(A_INSTR >= 1 && LDS_BYTES <= 160 * 1024, "panel does not fit");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+  unsigned char* sA = lds;
+  unsigned char* sW = lds + A_BYTES;
+  float* ct = (float*)(lds + A_BYTES + NSTAGE * WSTAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wc = wave % WN;
+  const int m0 = blockIdx.x * BM;
+  const unsigned short* A = (const unsigned short*)g.A;
+  const unsigned short* W = (const unsigned short*)g.W;
+  unsigned short* C = (unsigned short*)g.C;
+  const unsigned short* R = (RESID && g.resid) ? (const unsigned short*)g.resid : nullptr;
+  const int ntiles = g.N / BN;
+  const int S = ntiles * NKS;                          // slabs of the whole W stream
+
+  // ---- A panel: lane -> (row, 16-byte slot) of a 1 KiB piece, chunk permuted on the source side
+#pragma unroll
+  for (int j = 0; j < A_INSTR; ++j) {
+    const int byte = ((wave * A_INSTR + j) << 10) + lane * 16;
+    const int row = byte / ROWA, slot = (byte % ROWA) >> 4;
+    const int gr = m0 + row;
+    const void* src = (gr < g.M) ? (const void*)(A + (long)gr * g.lda + panel_swz<KP>(slot, row) * 8) : (const void*)g_zero16;
+    __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(sA + ((wave * A_INSTR + j) << 10)), 16, 0, 0);
+  }
+  // ---- W ring: slab s = (column tile s / NKS, k-slab s % NKS); rows of 64 B, slot = chunk ^ ((row >> 2) & 3)
+  const int wl_row = lane >> 2, wl_slot = lane & 3;
+  auto stage_w = [&](int s) {
+    const int tile = s / NKS, ks = s - tile * NKS;
+    unsigned char* dst = sW + (s % NSTAGE) * WSTAGE + wave * (WG_PER_WAVE * 1024);
+#pragma unroll
+    for (int j = 0; j < WG_PER_WAVE; ++j) {
+      const int tr_ = (wave * WG_PER_WAVE + j) * 16 + wl_row;
+      const int gr = tile * BN + tr_;
+      const void* src = (const void*)(W + (long)gr * g.ldw + ks * BKW + (wl_slot ^ ((tr_ >> 2) & 3)) * 8);
+      __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(dst + j * 1024), 16, 0, 0);
+    }
+  };
+  stage_w(0);
+  if (S > 1) stage_w(1);
+
+  // epilogue geometry: band of 32 rows x 256 columns, 32 threads per row (8 columns each), 16 rows per sweep
+  constexpr int TPR = BN / 8, RPP = NT / TPR, NSW = BROWS / RPP;
+  const int tcol = (tid % TPR) * 8, trow = tid / TPR;
+  const bool vec_ok = ((g.ldc & 7) == 0) && ((((size_t)C) & 15) == 0) && (!R || (((size_t)R) & 15) == 0);
+  auto out_row = [&](int pass, int sw) {               // pass = i * WM + wrow
+    const int i = pass / WM, wrow = pass % WM;
+    const int m = m0 + wrow * (BM / WM) + i * 32 + sw * RPP + trow;
+    return m < g.M ? m : -1;
+  };
+  constexpr int NPASS = TM * WM;
+  uint4 rcur[RESID ? NPASS : 1][RESID ? NSW : 1], rnext[RESID ? NPASS : 1][RESID ? NSW : 1];
+  auto load_resid = [&](int tile, uint4 (&dst)[RESID ? NPASS : 1][RESID ? NSW : 1]) {
+    if constexpr (RESID) {
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+        for (int sw = 0; sw < NSW; ++sw) {
+          const int m = out_row(p, sw);
+          dst[p][sw] = (R && vec_ok && m >= 0) ? *(const uint4*)(R + (long)m * g.ldc + tile * BN + tcol) : make_uint4(0, 0, 0, 0);
+        }
+    }
+  };
+  load_resid(0, rcur);
+
+  for (int tile = 0; tile < ntiles; ++tile) {
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int s = tile * NKS + ks;
+      // first slab of a tile: drain everything (stores of the previous epilogue, shortcut rows, panel, first slabs);
+      // afterwards only LDS-direct loads issued inside this loop are outstanding: leave the newest slab in flight
+      if (ks == 0 || s + 1 >= S) wait_vm_barrier<0>();
+      else wait_vm_barrier<WG_PER_WAVE>();
+      if (s + 2 < S) stage_w(s + 2);
+      const unsigned char* lb = sW + (s % NSTAGE) * WSTAGE;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 af[TM], bfr[TN];
+        const int ch = 2 * kk + (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = wr * (BM / WM) + i * 32 + (lane & 31);
+          af[i] = *(const bf16x8*)(sA + row * ROWA + (panel_swz<KP>(ks * 4 + ch, row) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = wc * 64 + j * 32 + (lane & 31);
+          bfr[j] = *(const bf16x8*)(lb + row * WROWB + ((ch ^ ((row >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+    }
+    // shortcut rows of the NEXT column tile: in flight while this tile's band passes run
+    if (tile + 1 < ntiles) load_resid(tile + 1, rnext);
+
+    const int n = tile * BN + tcol;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (g.bias_mode == 1) ? g.bias[n + e] : 0.f;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int i = p / WM, wrow = p % WM;
+      // (raw barriers: __syncthreads() would wait vmcnt(0) and expose the shortcut / slab prefetch issued above)
+      if (p > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // previous band fully read
+      if (wr == wrow) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int row = lane & 31;
+            const int col = wc * 64 + j * 32 + 8 * gq + 4 * (lane >> 5);
+            *(float4*)(ct + row * CLD + col) = make_float4(acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]);
+          }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+      for (int sw = 0; sw < NSW; ++sw) {
+        const int m = out_row(p, sw);
+        if (m < 0) continue;
+        const int brow = sw * RPP + trow;
+        float v[8];
+        const float4 x0 = *(const float4*)(ct + brow * CLD + tcol), x1 = *(const float4*)(ct + brow * CLD + tcol + 4);
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+        unsigned short* cp = C + (long)m * g.ldc + n;
+        if (vec_ok) {
+          if constexpr (RESID) if (R) {
+            const unsigned int rw[4] = {rcur[p][sw].x, rcur[p][sw].y, rcur[p][sw].z, rcur[p][sw].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f(rw[e] & 0xffff); v[2 * e + 1] += bf2f(rw[e] >> 16); }
+          }
+          if (g.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          *(uint4*)cp = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        } else {
+          const unsigned short* rp = R ? R + (long)m * g.ldc + n : nullptr;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = v[e];
+            if (rp) x += bf2f(rp[e]);
+            if (g.relu) x = fmaxf(x, 0.f);
+            cp[e] = f2bf(x);
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // band free for the next tile
+    if constexpr (RESID) {
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+        for (int sw = 0; sw < NSW; ++sw) rcur[p][sw] = rnext[p][sw];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Row-panel kernel, second form: the A panel [BM][K] is LDS resident as above, but W never touches LDS.  It is
+// pre-packed ONCE (model load) in MFMA fragment order -- block (column tile of 32, k-step of 16) = 64 lanes x 16 bytes,
+// lane l = W[n0 + (l & 31)][k0 + 8 (l >> 5) .. +8] -- so that every fragment load is one contiguous 1 KiB request, and
+// each wave streams the fragments of ITS 32 columns through a register ring D k-steps deep.  Consequences:
+//   * no barrier in the main loop (A is static, W is private to the wave): waves drift apart and hide each other's waits;
+//   * 8 waves x D loads x 1 KiB = 64 KiB of W in flight per CU on top of the shortcut rows and stores, without spending
+//     LDS on it -- the LDS-ring form above can keep 32 KiB in flight and is latency bound at ~0.1 us of MFMA per slab;
+//   * the ring keeps running across column tiles: the first fragments of the next tile are requested during the last
+//     k-steps of the current one and land while its epilogue runs.
+// Wave grid 1 x 8: wave w owns columns [256 tile + 32 w, +32) of all BM rows (TM = BM / 32 accumulator tiles).
+// ---------------------------------------------------------------------------------------
+// OCC = 2: two workgroups per CU (BM = 64: 32 KiB panel + 33 KiB band each, <= 128 VGPRs): while one workgroup waits for
+// its stores to be acknowledged (loads and stores share vmcnt, so the first fragment use after an epilogue drains both)
+// the other one computes.  The shortcut rows are then fetched at the start of their own tile (no second register set).
+template <int BM, int KP, bool RESID, int OCC = 1>
+__global__ __launch_bounds__(512, 2 * OCC) void gemm_panelw_kernel(GemmArgs g) {
+  constexpr int NT = 512, BN = 256;
+  constexpr int TM = BM / 32;
+  constexpr int ROWA = KP * 2, A_BYTES = BM * ROWA, A_INSTR = A_BYTES / 1024 / 8;
+  constexpr int NK = KP / 16;                          // k-steps per column tile
+  constexpr int D = NK < 8 ? NK : 8;                   // fragment ring depth
+  static_assert(NK % D == 0 && A_INSTR >= 1, "ring depth must divide the k-steps of a tile");
+  constexpr int CLD = BN + 4, BROWS = 32;
+  constexpr int LDS_BYTES = A_BYTES + BROWS * CLD * 4;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+  unsigned char* sA = lds;
+  float* ct = (float*)(lds + A_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * BM;
+  const unsigned short* A = (const unsigned short*)g.A;
+  const uint4* Wf = (const uint4*)g.Wf;
+  unsigned short* C = (unsigned short*)g.C;
+  const unsigned short* R = (RESID && g.resid) ? (const unsigned short*)g.resid : nullptr;
+  const int ntiles = g.N / BN;
+
+#pragma unroll
+  for (int j = 0; j < A_INSTR; ++j) {
+    const int byte = ((wave * A_INSTR + j) << 10) + lane * 16;
+    const int row = byte / ROWA, slot = (byte % ROWA) >> 4;
+    const int gr = m0 + row;
+    const void* src = (gr < g.M) ? (const void*)(A + (long)gr * g.lda + panel_swz<KP>(slot, row) * 8) : (const void*)g_zero16;
+    __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(sA + ((wave * A_INSTR + j) << 10)), 16, 0, 0);
+  }
+  // fragment stream of this wave: column tile of 32 = tile * 8 + wave; blocks of 64 uint4 per k-step
+  auto frag_ptr = [&](int tile, int ks) { return Wf + ((long)(tile * 8 + wave) * NK + ks) * 64 + lane; };
+  uint4 ring[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) ring[d] = *frag_ptr(0, d);
+
+  constexpr int TPR = BN / 8, RPP = NT / TPR, NSW = BROWS / RPP;
+  const int tcol = (tid % TPR) * 8, trow = tid / TPR;
+  const bool vec_ok = ((g.ldc & 7) == 0) && ((((size_t)C) & 15) == 0) && (!R || (((size_t)R) & 15) == 0);
+  auto out_row = [&](int i, int sw) {
+    const int m = m0 + i * 32 + sw * RPP + trow;
+    return m < g.M ? m : -1;
+  };
+  constexpr bool PREF = RESID && OCC == 1;             // shortcut rows of tile t+1 requested before the epilogue of tile t
+  uint4 rcur[RESID ? TM : 1][RESID ? NSW : 1], rnext[PREF ? TM : 1][PREF ? NSW : 1];
+  auto load_resid = [&](int tile, auto& dst) {
+    if constexpr (RESID) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int sw = 0; sw < NSW; ++sw) {
+          const int m = out_row(i, sw);
+          dst[i][sw] = (R && vec_ok && m >= 0) ? *(const uint4*)(R + (long)m * g.ldc + tile * BN + tcol) : make_uint4(0, 0, 0, 0);
+        }
+    }
+  };
+  if constexpr (PREF) load_resid(0, rcur);
+  __syncthreads();                                     // A panel landed (drains the LDS-direct loads)
+
+  for (int tile = 0; tile < ntiles; ++tile) {
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int tnext = tile + 1 < ntiles ? tile + 1 : tile;           // (last tile: harmless re-read of its own fragments)
+    if constexpr (RESID && !PREF) load_resid(tile, rcur);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      bf16x8 af[TM];
+      const int ch = 2 * ks + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = i * 32 + (lane & 31);
+        af[i] = *(const bf16x8*)(sA + row * ROWA + (panel_swz<KP>(ch, row) << 4));
+      }
+      bf16x8 wfr;
+      *(uint4*)&wfr = ring[ks % D];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr, af[i], acc[i], 0, 0, 0);
+      // refill this ring slot with the fragment D k-steps ahead (possibly of the next column tile)
+      ring[ks % D] = (ks + D < NK) ? *frag_ptr(tile, ks + D) : *frag_ptr(tnext, ks + D - NK);
+    }
+    if constexpr (PREF) { if (tile + 1 < ntiles) load_resid(tile + 1, rnext); }
+
+    const int n = tile * BN + tcol;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (g.bias_mode == 1) ? g.bias[n + e] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (i > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // previous band fully read
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int row = lane & 31;
+        const int col = wave * 32 + 8 * gq + 4 * (lane >> 5);
+        *(float4*)(ct + row * CLD + col) = make_float4(acc[i][4 * gq], acc[i][4 * gq + 1], acc[i][4 * gq + 2], acc[i][4 * gq + 3]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+      for (int sw = 0; sw < NSW; ++sw) {
+        const int m = out_row(i, sw);
+        if (m < 0) continue;
+        const int brow = sw * RPP + trow;
+        float v[8];
+        const float4 x0 = *(const float4*)(ct + brow * CLD + tcol), x1 = *(const float4*)(ct + brow * CLD + tcol + 4);
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+        unsigned short* cp = C + (long)m * g.ldc + n;
+        if (vec_ok) {
+          if constexpr (RESID) if (R) {
+            const unsigned int rw[4] = {rcur[i][sw].x, rcur[i][sw].y, rcur[i][sw].z, rcur[i][sw].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f(rw[e] & 0xffff); v[2 * e + 1] += bf2f(rw[e] >> 16); }
+          }
+          if (g.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          *(uint4*)cp = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        } else {
+          const unsigned short* rp = R ? R + (long)m * g.ldc + n : nullptr;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = v[e];
+            if (rp) x += bf2f(rp[e]);
+            if (g.relu) x = fmaxf(x, 0.f);
+            cp[e] = f2bf(x);
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                   // band free for the next tile
+    if constexpr (PREF) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int sw = 0; sw < NSW; ++sw) rcur[i][sw] = rnext[i][sw];
+    }
+  }
+}
+
+// W [N][K] (row stride ldw) -> fragment order: block (n / 32, k / 16) = 64 x 16 bytes, lane l = W[32 nb + (l & 31)][16 kb + 8 (l >> 5) ..]
+__global__ __launch_bounds__(256) void pack_w_frag_kernel(const unsigned short* w, long ldw, uint4* out, int N, int K) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)(N / 32) * (K / 16) * 64;
+  if (t >= total) return;
+  const int l = (int)(t & 63);
+  const long blk = t >> 6;
+  const int kb = (int)(blk % (K / 16)), nb = (int)(blk / (K / 16));
+  out[t] = *(const uint4*)(w + (long)(nb * 32 + (l & 31)) * ldw + kb * 16 + 8 * (l >> 5));
+}
+
+// ---------------------------------------------------------------------------------------
 // f32 in / f32 accumulate (exact fp32 MFMA, bit-wise an fmaf chain).  128x128 tile.
 // ---------------------------------------------------------------------------------------
 template <typename TOUT>
@@ -1013,8 +1386,74 @@ static void launch_ring(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
 //                                   9 = 6 and 10 = 7 with the fragment-pipelined schedule on shortcut-free layers
 //                                   11 = 8 with the register epilogue (no LDS band)
 //                                   12 = 8 with the fragment-pipelined schedule on shortcut-free layers
-enum { GEMM_TILE_COUNT = 12 };
-static int pick_tile(long M, long N, long K, int batch, int out_dtype, int has_resid) {
+// row-panel (gemm_panel_kernel):    13 = A panel resident, all column tiles per workgroup (K in {64,128,256,512}, N % 256 == 0,
+//                                        bf16 out, 1x1 / plain GEMM); other shapes under 13 run configuration 1
+//                                   14 = the same with W streamed from its fragment-order copy through registers
+//                                        (gemm_panelw_kernel; needs the Wf operand, else configuration 13)
+//                                   15 = 14 with 64-row panels, two workgroups per CU
+enum { GEMM_TILE_COUNT = 15 };
+
+template <int CONV>
+static bool launch_panel(const GemmArgs& g0, int batch, int out_dtype, hipStream_t s, bool use_wf = false, bool occ2 = false) {
+  GemmArgs g = g0;
+  if (batch != 1 || out_dtype != RELNET_BF16 || g.N % 256 != 0 || (g.ldc & 7)) return false;
+  if constexpr (CONV == 2) return false;
+  if constexpr (CONV == 1) {                             // 1x1, stride 1, no padding: a plain GEMM over the pixels
+    if (g.cR != 1 || g.cS != 1 || g.cStride != 1 || g.cPad != 0) return false;
+    if (g.cImg != (long)g.cH * g.cW * g.cPix) return false;          // images must be contiguous pixel runs
+    g.lda = g.cPix;
+  }
+  const bool res = g.resid != nullptr;
+  if (use_wf && g.Wf && occ2) {
+#define RELNET_PANELW2(KP_)                                                                            \
+  do {                                                                                                  \
+    dim3 grid((g.M + 63) / 64);                                                                         \
+    if (res) gemm_panelw_kernel<64, KP_, true, 2><<<grid, 512, 0, s>>>(g);                              \
+    else gemm_panelw_kernel<64, KP_, false, 2><<<grid, 512, 0, s>>>(g);                                 \
+    return true;                                                                                        \
+  } while (0)
+    switch (g.K) {
+      case 64: RELNET_PANELW2(64);
+      case 128: RELNET_PANELW2(128);
+      case 256: RELNET_PANELW2(256);
+      default: break;                              // (K = 512: a 64-row panel + band is 97 KiB, one workgroup per CU anyway)
+    }
+#undef RELNET_PANELW2
+  }
+  if (use_wf && g.Wf) {
+#define RELNET_PANELW(BM_, KP_)                                                                        \
+  do {                                                                                                  \
+    dim3 grid((g.M + BM_ - 1) / BM_);                                                                   \
+    if (res) gemm_panelw_kernel<BM_, KP_, true><<<grid, 512, 0, s>>>(g);                                \
+    else gemm_panelw_kernel<BM_, KP_, false><<<grid, 512, 0, s>>>(g);                                   \
+    return true;                                                                                        \
+  } while (0)
+    switch (g.K) {
+      case 64: RELNET_PANELW(128, 64);
+      case 128: RELNET_PANELW(128, 128);
+      case 256: RELNET_PANELW(128, 256);
+      case 512: RELNET_PANELW(64, 512);
+      default: break;
+    }
+#undef RELNET_PANELW
+  }
+#define RELNET_PANEL(BM_, KP_)                                                                         \
+  do {                                                                                                  \
+    dim3 grid((g.M + BM_ - 1) / BM_);                                                                   \
+    if (res) gemm_panel_kernel<BM_, KP_, true><<<grid, 512, 0, s>>>(g);                                 \
+    else gemm_panel_kernel<BM_, KP_, false><<<grid, 512, 0, s>>>(g);                                    \
+    return true;                                                                                        \
+  } while (0)
+  switch (g.K) {
+    case 64: RELNET_PANEL(128, 64);
+    case 128: RELNET_PANEL(128, 128);
+    case 256: RELNET_PANEL(128, 256);
+    case 512: RELNET_PANEL(64, 512);
+    default: return false;
+  }
+#undef RELNET_PANEL
+}
+static int pick_tile(long M, long N, long K, int batch, int out_dtype, int has_resid, int has_wf = 0) {
   // Picked from on-device timings of every GEMM / convolution shape of the detector at 16
   // images per launch (tests/_bench_gemm.py; table in DESIGN.md): wide tiles cut the
   // L2 -> LDS fill traffic of the compute-bound 3x3 / large-K layers, 128-row tiles keep more
@@ -1032,6 +1471,9 @@ static int pick_tile(long M, long N, long K, int batch, int out_dtype, int has_r
   // shortcut-free 256x256 layers (3x3 / reduce convolutions, FC layers): the ring kernel's conflict-free LDS image and
   // residual-free register budget are worth 3-11 % (r02 tile table: res5 3x3 642 -> 574 us, rpn 3x3 1244 -> 1131 us)
   if (cfg == 1 && !has_resid) cfg = 8;
+  // res4 expand convolutions (256 -> 1024 + shortcut, 23 per step): with the weights also available in fragment order the
+  // panel kernel reads A once and never stages W in LDS: 219 -> 191..203 us (r02 tile table; every other shape is slower)
+  if (cfg == 1 && has_resid && has_wf && K == 256 && batch == 1) cfg = 14;
   return cfg;
 }
 extern "C" int relnet_gemm_tile_count(void) { return GEMM_TILE_COUNT; }
@@ -1040,7 +1482,7 @@ extern "C" int relnet_gemm_pick_tile(int M, int N, int K, int batch, int out_dty
 template <int CONV>
 static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t s) {
   int cfg = g_force_tile;
-  if (cfg <= 0 || cfg > GEMM_TILE_COUNT) cfg = pick_tile(g.M, g.N, g.K, batch, out_dtype, g.resid != nullptr);
+  if (cfg <= 0 || cfg > GEMM_TILE_COUNT) cfg = pick_tile(g.M, g.N, g.K, batch, out_dtype, g.resid != nullptr, CONV == 1 && g.Wf != nullptr);
   switch (cfg) {
     case 1: launch_cfg<256, 256, 2, 4, CONV>(g, batch, out_dtype, s); break;
     case 2: launch_cfg<256, 128, 4, 2, CONV>(g, batch, out_dtype, s); break;
@@ -1059,7 +1501,16 @@ static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t
       break;
     case 10: launch_ring<256, 128, 4, 2, CONV, 64, 3, 1>(g, batch, out_dtype, s); break;
     case 11: launch_ring<256, 256, 2, 4, CONV, 64, 2, 0, 1>(g, batch, out_dtype, s); break;
-    default: launch_ring<256, 256, 2, 4, CONV, 64, 2, 1>(g, batch, out_dtype, s); break;
+    case 12: launch_ring<256, 256, 2, 4, CONV, 64, 2, 1>(g, batch, out_dtype, s); break;
+    case 13:
+      if (!launch_panel<CONV>(g, batch, out_dtype, s)) launch_cfg<256, 256, 2, 4, CONV>(g, batch, out_dtype, s);
+      break;
+    case 14:
+      if (!launch_panel<CONV>(g, batch, out_dtype, s, true)) launch_cfg<256, 256, 2, 4, CONV>(g, batch, out_dtype, s);
+      break;
+    default:
+      if (!launch_panel<CONV>(g, batch, out_dtype, s, true, true)) launch_cfg<256, 256, 2, 4, CONV>(g, batch, out_dtype, s);
+      break;
   }
 }
 
@@ -1110,6 +1561,36 @@ extern "C" int relnet_conv2d_nhwc(const void* in, long in_pix, long in_img, cons
   g.M = B * Hout * Wout; g.N = Cout; g.K = R * S * Cin; g.bias_mode = bias ? 1 : 0; g.relu = relu;
   g.cH = H; g.cW = W; g.cCin = Cin; g.cHout = Hout; g.cWout = Wout; g.cR = R; g.cS = S;
   g.cStride = stride; g.cDil = dil; g.cPad = pad; g.cPix = in_pix; g.cImg = in_img;
+  launch_bf16<1>(g, 1, out_dtype, (hipStream_t)stream);
+  return check_launch("relnet_conv2d_nhwc");
+}
+
+// W [N][K] bf16 -> MFMA fragment order for gemm_panelw_kernel (N % 32 == 0, K % 16 == 0); done once at model load
+extern "C" int relnet_pack_w_frag(const void* w, long ldw, void* out, int N, int K, void* stream) {
+  RELNET_REQUIRE(w && out && N > 0 && K > 0 && N % 32 == 0 && K % 16 == 0 && ldw % 8 == 0, "relnet_pack_w_frag: bad arguments (N=%d K=%d)", N, K);
+  const long total = (long)(N / 32) * (K / 16) * 64;
+  pack_w_frag_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>((const unsigned short*)w, ldw, (uint4*)out, N, K);
+  return check_launch("relnet_pack_w_frag");
+}
+
+// relnet_conv2d_nhwc with the optional fragment-order copy of the weights (w_frag may be NULL)
+extern "C" int relnet_conv2d_nhwc_wf(const void* in, long in_pix, long in_img, const void* w, const void* w_frag,
+                                     const float* bias, const void* resid, int relu, void* out, long ldc,
+                                     int B, int H, int W, int Cin, int Cout, int R, int S, int stride,
+                                     int dil, int pad, int out_dtype, void* stream) {
+  RELNET_REQUIRE(in && w && out, "relnet_conv2d_nhwc: null operand");
+  RELNET_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && dil > 0 && pad >= 0, "relnet_conv2d_nhwc: bad geometry");
+  RELNET_REQUIRE(Cin % 64 == 0 && in_pix % 8 == 0 && in_img % 8 == 0, "relnet_conv2d_nhwc: Cin %% 64 == 0 and 16-byte aligned strides required (Cin=%d)", Cin);
+  const int Hout = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1;
+  const int Wout = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
+  RELNET_REQUIRE(Hout > 0 && Wout > 0 && (long)B * Hout * Wout < (1L << 31), "relnet_conv2d_nhwc: empty or too large output");
+  GemmArgs g{};
+  g.A = in; g.lda = in_pix; g.strideA = 0; g.W = w; g.ldw = (long)R * S * Cin; g.strideW = 0;
+  g.C = out; g.ldc = ldc; g.strideC = 0; g.bias = bias; g.resid = resid;
+  g.M = B * Hout * Wout; g.N = Cout; g.K = R * S * Cin; g.bias_mode = bias ? 1 : 0; g.relu = relu;
+  g.cH = H; g.cW = W; g.cCin = Cin; g.cHout = Hout; g.cWout = Wout; g.cR = R; g.cS = S;
+  g.cStride = stride; g.cDil = dil; g.cPad = pad; g.cPix = in_pix; g.cImg = in_img;
+  g.Wf = w_frag;
   launch_bf16<1>(g, 1, out_dtype, (hipStream_t)stream);
   return check_launch("relnet_conv2d_nhwc");
 }

@@ -316,8 +316,20 @@ def pack_conv_weight(w_oihw, dtype=torch.bfloat16, device='cuda'):
     return w_oihw.permute(0, 2, 3, 1).reshape(w_oihw.shape[0], -1).to(device=device, dtype=dtype).contiguous()
 
 
+def pack_w_frag(w_packed):
+    """[Cout, K] bf16 -> the same weights in MFMA fragment order (for the row-panel 1x1 kernel); None if the shape does
+    not qualify (stride-1 1x1 convolutions with K in {64,128,256,512} and Cout % 256 == 0 use it)."""
+    _chk(w_packed)
+    N, K = w_packed.shape
+    if w_packed.dtype != torch.bfloat16 or K not in (64, 128, 256, 512) or N % 256:
+        return None
+    out = torch.empty_like(w_packed)
+    _lib.call('relnet_pack_w_frag', w_packed.data_ptr(), w_packed.stride(0), out.data_ptr(), N, K, _stream())
+    return out
+
+
 def conv2d_nhwc(x, w_packed, bias, ksize=1, stride=1, pad=0, dil=1, relu=False, resid=None, out=None,
-                out_dtype=None):
+                out_dtype=None, w_frag=None):
     """x [B,H,W,Cin] bf16 (last dim contiguous; pixel/image strides free), w_packed
     [Cout, k*k*Cin], bias fp32 [Cout] -> [B,Hout,Wout,Cout]; optional fused residual + ReLU."""
     _chk(x, w_packed, bias, resid, out)
@@ -335,7 +347,7 @@ def conv2d_nhwc(x, w_packed, bias, ksize=1, stride=1, pad=0, dil=1, relu=False, 
     assert out.stride(1) == Wout * out.stride(2) and out.stride(0) == Hout * out.stride(1)
     if resid is not None:
         assert resid.dtype == out.dtype and resid.stride() == out.stride()
-    _lib.call('relnet_conv2d_nhwc', x.data_ptr(), x.stride(2), x.stride(0), w_packed.data_ptr(), _ptr(bias),
+    _lib.call('relnet_conv2d_nhwc_wf', x.data_ptr(), x.stride(2), x.stride(0), w_packed.data_ptr(), _ptr(w_frag), _ptr(bias),
               _ptr(resid), int(relu), out.data_ptr(), out.stride(2), B, H, W, Cin, Cout, ksize, ksize,
               stride, dil, pad, _dt(out), _stream(),
               tag='M%d_N%d_K%d_k%d' % (B * Hout * Wout, Cout, ksize * ksize * Cin, ksize))

@@ -118,6 +118,10 @@ def _conv_rows64(x, w_oihw, bias, rows, Hout, Wout, stride, pad, dil):
     (54, (38, 63), 256, 256, 3, 1, 1, 'relu'),           # the benchmark's res4 3x3: M = 129 276
     (54, (38, 63), 256, 1024, 1, 1, 1, 'resid+relu'),    # the benchmark's res4 expand
     (54, (38, 63), 1024, 256, 1, 1, 1, 'relu'),          # the benchmark's res4 reduce
+    (2, (150, 250), 64, 256, 1, 1, 1, 'resid+relu'),     # res2 expand: K = 64   (row-panel kernel, tile 13)
+    (3, (75, 125), 128, 512, 1, 1, 1, 'resid+relu'),     # res3 expand: K = 128
+    (5, (38, 63), 512, 2048, 1, 1, 1, 'resid+relu'),     # res5 expand: K = 512, ragged last row panel
+    (3, (38, 63), 256, 512, 1, 1, 1, 'relu'),            # K = 256 without a shortcut
 ])
 def test_conv2d_every_tile(rn, B, hw, cin, cout, k, stride, dil, extras):
     ops, L = rn
@@ -133,6 +137,7 @@ def test_conv2d_every_tile(rn, B, hw, cin, cout, k, stride, dil, extras):
     rows = _sample_rows(M, np.random.default_rng(M + k), n=24)
     r64 = _conv_rows64(x, w, b, rows, Hout, Wout, stride, pad, dil)
     wp = ops.pack_conv_weight(w)
+    wf = ops.pack_w_frag(wp) if (k == 1 and stride == 1) else None          # fragment-order copy for the row-panel kernel (tile 14)
     relu = 'relu' in extras
     big = M > 20000
     for odt, tol in ((torch.bfloat16, 1e-2), (torch.float32, 3e-5 * (cin * k * k) ** 0.5)):
@@ -146,7 +151,7 @@ def test_conv2d_every_tile(rn, B, hw, cin, cout, k, stride, dil, extras):
             want = want.relu(); w64 = np.maximum(w64, 0)
         for (t, s, nl) in _variants(L, quick=big):
             _set(L, t, s, nl)
-            got = ops.conv2d_nhwc(x, wp, b, ksize=k, stride=stride, pad=pad, dil=dil, relu=relu, resid=res, out_dtype=odt)
+            got = ops.conv2d_nhwc(x, wp, b, ksize=k, stride=stride, pad=pad, dil=dil, relu=relu, resid=res, out_dtype=odt, w_frag=wf)
             _check(got, want, rows, w64, tol, ('conv', B, hw, cin, cout, k, stride, dil, 'tile', t, 'swz', s, 'nloop', nl, str(odt)))
     _set(L, 0, 1, 0)
 
