@@ -63,6 +63,8 @@ def test_targets_full_size_batched_vs_oracle(rn):
     for b in range(B):
         wr, wl, wt, ww = OT.proposal_target(cs[b][0], cs[b][1])
         k = N + ng[b]
+        wr = wr.copy(); wr[N:, 0] = b        # appended gt rows carry their image's index (the reference runs one image per
+        #                                      device and writes 0 there, proposal_target.py:79; ROI pooling of a batch needs b)
         assert np.array_equal(r[b, :k].cpu().numpy(), wr) and np.array_equal(lab[b, :k].cpu().numpy(), wl)
         assert np.array_equal(bt[b, :k].cpu().numpy(), wt) and np.array_equal(bw[b, :k].cpu().numpy(), ww)
         assert (lab[b, k:] == -1).all() and (bw[b, k:] == 0).all()
