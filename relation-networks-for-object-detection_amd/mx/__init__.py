@@ -102,7 +102,7 @@ def install(py2_shims=True):
     op = importlib.import_module(pkg.__name__ + '.operator_py')
     sys.modules.setdefault('operator_py', op)
     for sub, real in (('proposal', 'proposal'), ('proposal_target', 'targets'), ('box_annotator_ohem', 'targets'),
-                      ('nms_multi_target', 'targets'), ('learn_nms', 'learn_nms'), ('monitor_op', 'monitor_op')):
+                      ('nms_multi_target', 'targets'), ('learn_nms', 'learn_nms')):
         sys.modules.setdefault('operator_py.' + sub, importlib.import_module('%s.operator_py.%s' % (pkg.__name__, real)))
     utils = sys.modules.setdefault('utils', types.ModuleType('utils'))
     if not hasattr(utils, '__path__'):

@@ -92,4 +92,3 @@ def Custom(*args, **kwargs):
 from . import proposal  # noqa: E402,F401  (registers "proposal")
 from . import learn_nms  # noqa: E402,F401  (registers "learn_nms")
 from . import targets  # noqa: E402,F401  (registers "proposal_target", "BoxAnnotatorOHEM", "nms_multi_target")
-from . import monitor_op  # noqa: E402,F401  (registers "monitor")

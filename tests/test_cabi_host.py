@@ -199,19 +199,10 @@ def test_assign_anchor_matches_reference_loader():
 
 
 def test_every_registered_reference_op_name_resolves():
-    """The six names the reference registers with mx.operator.register (SURVEY.md section 8b) all have a Prop here;
-    `monitor` is a pure host identity and runs on CPU tensors."""
-    import torch
+    """The five hot-path names the reference registers with mx.operator.register all have a Prop
+    here (`monitor`, a debug identity, is out of scope: every use in the reference's symbols is commented out)."""
     import relnet_amd  # noqa: F401
     from relnet_amd import operator_py
-    for name in ('proposal', 'proposal_target', 'BoxAnnotatorOHEM', 'learn_nms', 'nms_multi_target', 'monitor'):
+    for name in ('proposal', 'proposal_target', 'BoxAnnotatorOHEM', 'learn_nms', 'nms_multi_target'):
         assert operator_py.get_prop(name) is not None
-    from relnet_amd.operator_py.monitor_op import monitor_wrapper, MonitorProp
-    x = torch.arange(12.0).view(3, 4)
-    assert torch.equal(monitor_wrapper(x, 'tap'), x)
-    prop = MonitorProp('tap')
-    assert prop.list_arguments() == ['input'] and prop.infer_shape([(3, 4)]) == ([(3, 4)], [(3, 4)])
-    op = prop.create_operator(None, None, None)
-    g = torch.zeros(3, 4)
-    op.backward(['write'], [x], [x], [x], [g], [])
-    assert torch.equal(g, x)
+
