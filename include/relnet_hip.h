@@ -128,6 +128,18 @@ int relnet_relation_attention(const void* q, long q_ld, long q_bs, const void* k
                               int B, int H, int N, int M, int Mpad, float scale, int in_dtype, int out_dtype,
                               void* stream);
 
+/* Geometry + attention of ONE relation module in a single kernel (bf16 throughput path; csrc/relation.hip:
+ * relation_fused_kernel): the position embedding (SYM_REL:29-83), pair_pos_fc1 + ReLU + log (:109-116, :139) and the
+ * attention (:132-150) run per 32-query x 16-head workgroup; the [B][16][N][Mpad] bias tensor never reaches HBM.
+ * boxes [B][N][box_stride] fp32 (xyxy at +box_off); wp [16][64] / bp [16] fp32 = pair_pos_fc1_<i>_{weight,bias};
+ * divisors8 = wave_length^(t/8) (HOST pointer); other operands as relnet_relation_attention.  H = 16, M <= 640.  */
+int relnet_relation_attention_fused(const void* q, long q_ld, long q_bs, const void* k, long k_ld, long k_bs,
+                                    const void* vwt, long vwt_ld, long vwt_bs, const float* boxes, int box_stride,
+                                    int box_off, const float* wp, const float* bp, const float* divisors8,
+                                    const float* bout, const void* resid, long resid_ld, long resid_bs, void* out,
+                                    long out_ld, long out_bs, void* out_act, long act_ld, long act_bs, int B, int H,
+                                    int N, int M, int Mpad, float scale, void* stream);
+
 /* Row-panel form of the 1x1 convolutions (csrc/gemm.hip:gemm_panelw_kernel): `w_frag` is the weight matrix re-ordered once
  * at model load by relnet_pack_w_frag ([Cout][K] bf16 -> MFMA fragment order, same byte count; Cout % 32 == 0, K % 16 == 0).
  * relnet_conv2d_nhwc_wf == relnet_conv2d_nhwc when w_frag is NULL or the layer is not a stride-1 1x1 convolution with

@@ -28,6 +28,7 @@ struct GeomArgs {
   const float* wp;         // [64, NMOD*FC]  pair_pos_fc1 weights, embedding-index major
   const float* bp;         // [NMOD, FC]
   float divisors[8];       // wave_length^(k/8), fp32 (host computes them like the graph)
+  float c2[8];             // ln2 * 100 / (2 pi divisors[k]): log2-domain position value -> revolutions (MFMA kernel)
   void* bias;              // [NMOD, B, FC, N, Mpad]   log(max(relu(E Wp^T + bp), 1e-6)) float, or log2(.) half
   float* pos_mat;          // optional [B, N, M, 4]
   float* pos_emb;          // optional [B, N, M, 64]
@@ -112,6 +113,96 @@ __global__ __launch_bounds__(256) void geometry_bias_kernel(GeomArgs g) {
     }
 }
 #pragma clang fp contract(fast)
+
+// ---------------------------------------------------------------------------------------
+// geometry bias, throughput form (fp16 log2 G for the bf16 attention kernel): the 64 -> 16 pair_pos_fc1 product of
+// BOTH relation modules is one 32 x 32 x 64 MFMA problem per 32 (query, key) pairs -- rows = (module, head), columns =
+// pairs -- instead of 2048 scalar FMAs per pair (the VALU kernel above spends ~80 % of its 324 us at B = 54 there).
+// One wavefront = one query x 64 keys per step (two 32-pair sets, keys 2 l31 and 2 l31 + 1, so that a lane packs two
+// adjacent keys into one 4-byte store and a (module, head) row leaves as 128 contiguous bytes).  Lane (l31, half)
+// evaluates, per coordinate c = k-step, the 8 sines (half 0) or cosines (half 1) of its pair: feature
+// f = 16 c + 8 half + t (SYM_REL:29-44) is exactly the B-operand slot of mfma_f32_32x32x16_f16.  Features and weights
+// are fp16 in the product (|feature| <= 1), accumulation fp32; hardware log2 / sin as in the kFast VALU path.
+// ---------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// two fp32 -> packed fp16, round to nearest even: the vector fptrunc selects gfx950's v_cvt_pk_f16_f32
+// (__builtin_amdgcn_cvt_pkrtz truncates; inline asm would hide the trans -> VALU forwarding hazard of its v_sin inputs
+// from the compiler's hazard recogniser -- measured: wrong results)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pack_f16x2_rn(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2));
+}
+
+__global__ __launch_bounds__(256) void geometry_bias_mfma_kernel(GeomArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float sKey[];   // [nblk * 64][4]: cx, cy, log2 w, log2 h of the keys
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.y;
+  const int NO = g.nmod * 16;
+  const int nblk = (g.M + 63) / 64;
+  const float* bx = g.boxes + (long)b * g.N * g.box_stride + g.box_off;
+  for (int j = tid; j < nblk * 64; j += 256) {
+    const float* pj = bx + (long)(j < g.M ? j : g.M - 1) * g.box_stride;
+    *(float4*)(sKey + 4 * j) = make_float4(0.5f * (pj[0] + pj[2]), 0.5f * (pj[1] + pj[3]),
+                                            __builtin_amdgcn_logf(pj[2] - pj[0] + 1.f), __builtin_amdgcn_logf(pj[3] - pj[1] + 1.f));
+  }
+  // pair_pos_fc1 fragments (A operand): row = l31 = module * 16 + head, k = 16 kk + 8 half + t; wp is [64][NO]
+  f16x8 wf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) wf[kk][t] = l31 < NO ? (_Float16)g.wp[(16 * kk + 8 * half + t) * NO + l31] : (_Float16)0.f;
+  f32x16 bpv;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = 8 * (r >> 2) + 4 * half + (r & 3);
+    bpv[r] = row < NO ? g.bp[row] : 1.f;
+  }
+  const float phase = half ? 0.25f : 0.f;                 // cos x = sin(x + 1/4 revolution)
+  __syncthreads();
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= g.N) return;
+  const float* pi = bx + (long)i * g.box_stride;
+  const float wi = pi[2] - pi[0] + 1.f, hi = pi[3] - pi[1] + 1.f;
+  const float cxi = 0.5f * (pi[0] + pi[2]), cyi = 0.5f * (pi[1] + pi[3]);
+  const float iwi = 1.0f / wi, ihi = 1.0f / hi, l2wi = __builtin_amdgcn_logf(wi), l2hi = __builtin_amdgcn_logf(hi);
+  __half* out = (__half*)g.bias;
+  for (int jb = 0; jb < nblk; ++jb) {
+    f32x16 acc[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const float4 kb = *(const float4*)(sKey + 4 * (jb * 64 + 2 * l31 + ps));
+      float p[4];
+      p[0] = __builtin_amdgcn_logf(fmaxf(fabsf(cxi - kb.x) * iwi, 1e-3f));     // SYM_REL:59-66 (log2; ln 2 folded into c2)
+      p[1] = __builtin_amdgcn_logf(fmaxf(fabsf(cyi - kb.y) * ihi, 1e-3f));
+      p[2] = l2wi - kb.z;                                                       // log2(w_i / w_j), SYM_REL:67-70
+      p[3] = l2hi - kb.w;
+      acc[ps] = bpv;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        u32x4 w;
+#pragma unroll
+        for (int t = 0; t < 8; t += 2)
+          w[t >> 1] = pack_f16x2_rn(__builtin_amdgcn_sinf(fmaf(p[kk], g.c2[t], phase)), __builtin_amdgcn_sinf(fmaf(p[kk], g.c2[t + 1], phase)));
+        acc[ps] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk], __builtin_bit_cast(f16x8, w), acc[ps], 0, 0, 0);
+      }
+    }
+    const int j2 = jb * 64 + 2 * l31;
+    if (j2 >= g.Mpad) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 8 * (r >> 2) + 4 * half + (r & 3);
+      if (row >= NO) continue;
+      const int m = row >> 4, h = row & 15;
+      const float v0 = __builtin_amdgcn_logf(fmaxf(acc[0][r], 1e-6f));        // relu, clamp (SYM_REL:116,139), log2
+      const float v1 = __builtin_amdgcn_logf(fmaxf(acc[1][r], 1e-6f));
+      *(__half2*)(out + ((((long)m * g.B + b) * 16 + h) * g.N + i) * g.Mpad + j2) = __floats2half2_rn(v0, v1);
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------
 // relation attention.  One wave = 32 queries of one (image, head); key tiles of 32.
@@ -514,6 +605,258 @@ __global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Fused relation module (bf16 throughput path): geometry bias + attention in ONE kernel; the
+// [B,16,N,Mpad] bias tensor never exists in HBM (322 MB written + 2 x 166 MB read per step at
+// B = 54 with the two-kernel path).
+//
+// One workgroup = 32 queries of one image x ALL 16 heads (wave w = head w), so the 64 sin/cos
+// features of a (query, key) pair are evaluated once for the 16 heads that consume them:
+//   phase G (key tile t+1): wave w takes queries 2w, 2w+1 of the tile against the 32 keys, as four
+//       16-pair sets.  Lane (col = lane & 15, grp = lane >> 4) owns pair `col` and the 8 wavelengths
+//       of ONE (coordinate, sin|cos) combination per k-step: axis = grp >> 1 (x|y), sc = grp & 1, k-step
+//       0 = centre distance, 1 = log size ratio -- exactly the B-operand layout of
+//       mfma_f32_16x16x32_f16 for feature f = 32 kk + 8 grp + t (SYM_REL:29-44: f = 16 c + 8 sc + t).
+//       pair_pos_fc1 (64 -> 16, SYM_REL:109-116) is two MFMAs against the fp16 weight fragments
+//       (A operand, rows = heads); log2(max(relu(.), 1e-6)) of the 16 x 16 result goes to LDS as
+//       fp32 [head][query][key] (double buffered: one barrier per key tile).
+//   phase A (key tile t): wave h runs the flash-style update of relation_attention_lds_kernel for its
+//       head, bias from LDS, K rows / VW^T columns straight from L2 (no other wave shares them; the
+//       workgroup -> image mapping keeps the 10 query tiles of an image on one XCD so that the
+//       re-reads hit that XCD's L2).
+// Precision: fp16 features and weights in the 64 -> 16 product (|feature| <= 1: 2^-11 absolute;
+// measured against the fp32 geometry kernel in tests/test_gpu_relation.py) -- tighter than the fp16
+// rounding of log2 G the two-kernel path stores.
+// ---------------------------------------------------------------------------------------
+constexpr int kGQ = 36;                    // floats per query row of the LDS bias tile (32 keys + 4: conflict-free float4 reads)
+constexpr int kGH = 32 * kGQ + 4;          // floats per head (+4: the four lane groups of a store hit distinct banks)
+constexpr int kGBuf = 16 * kGH;            // floats per buffer
+
+struct FusedArgs {
+  AttnArgs a;
+  const float* boxes; int box_stride, box_off;
+  const float* wp;                         // [16][64] fp32 pair_pos_fc1 weight of this module
+  const float* bp;                         // [16]
+  float c2[8];                             // ln2 * 100 / (2 pi * wave_length^(t/8)): log2-domain position -> revolutions
+  int nq;                                  // query tiles per image
+};
+
+__global__ __launch_bounds__(1024) void relation_fused_kernel(FusedArgs f) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const AttnArgs& a = f.a;
+  float* sG = (float*)smem;                               // [2][16][kGH]
+  float* sBox = sG + 2 * kGBuf;                           // [ntile * 32][4]: cx, cy, log2 w, log2 h of the keys
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int col = lane & 15, grp = lane >> 4, axis = grp >> 1;
+  // images in groups of 8, one per XCD (consecutive workgroup ids go round-robin over the 8 XCDs)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int b = (slot / f.nq) * 8 + xcd, qt = slot % f.nq;
+  if (b >= a.B) return;
+  const int h = wave;
+  const int ntile = (a.M + 31) / 32;
+  typedef unsigned short T;
+  const float* bx = f.boxes + (long)b * a.N * f.box_stride + f.box_off;
+
+  // ---- key table ------------------------------------------------------------------------------
+  for (int j = tid; j < ntile * 32; j += 1024) {
+    const float* pj = bx + (long)(j < a.M ? j : a.M - 1) * f.box_stride;
+    const float w = pj[2] - pj[0] + 1.f, hh = pj[3] - pj[1] + 1.f;
+    *(float4*)(sBox + 4 * j) = make_float4(0.5f * (pj[0] + pj[2]), 0.5f * (pj[1] + pj[3]),
+                                            __builtin_amdgcn_logf(w), __builtin_amdgcn_logf(hh));
+  }
+  // ---- this wave's two geometry queries (phase G) ---------------------------------------------------
+  float cq[2], isq[2], l2q[2];
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs) {
+    int qi = qt * 32 + 2 * wave + qs;
+    qi = qi < a.N ? qi : a.N - 1;
+    const float* pi = bx + (long)qi * f.box_stride;
+    const float lo = pi[axis], hi = pi[2 + axis];
+    const float sz = hi - lo + 1.f;
+    cq[qs] = 0.5f * (lo + hi); isq[qs] = 1.0f / sz; l2q[qs] = __builtin_amdgcn_logf(sz);
+  }
+  // pair_pos_fc1 fragments: A operand, row = head (lane & 15), k = 32 kk + 8 grp + t
+  f16x8 wf[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const float* wr = f.wp + col * 64 + 32 * kk + 8 * grp;
+    const float4 w0 = *(const float4*)wr, w1 = *(const float4*)(wr + 4);
+    wf[kk][0] = (_Float16)w0.x; wf[kk][1] = (_Float16)w0.y; wf[kk][2] = (_Float16)w0.z; wf[kk][3] = (_Float16)w0.w;
+    wf[kk][4] = (_Float16)w1.x; wf[kk][5] = (_Float16)w1.y; wf[kk][6] = (_Float16)w1.z; wf[kk][7] = (_Float16)w1.w;
+  }
+  f32x4 bp4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bp4[e] = f.bp[4 * grp + e];
+  const float phase = (grp & 1) ? 0.25f : 0.f;            // cos x = sin(x + 1/4 revolution)
+
+  auto geometry_tile = [&](int kt, float* gb) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int key = kt * 32 + 16 * ks + col;
+      const float ck = sBox[4 * key + axis], l2k = sBox[4 * key + 2 + axis];
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        const float d = fmaxf(fabsf(cq[qs] - ck) * isq[qs], 1e-3f);       // SYM_REL:59-66
+        const float Ld = __builtin_amdgcn_logf(d);                          // log2; ln 2 is folded into c2
+        const float Ls = l2q[qs] - l2k;                                     // log2(w_i / w_j), SYM_REL:67-70
+        u32x4 w0, w1;                                                       // 8 fp16 features each
+#pragma unroll
+        for (int t = 0; t < 8; t += 2) {
+          w0[t >> 1] = pack_f16x2_rn(__builtin_amdgcn_sinf(fmaf(Ld, f.c2[t], phase)), __builtin_amdgcn_sinf(fmaf(Ld, f.c2[t + 1], phase)));
+          w1[t >> 1] = pack_f16x2_rn(__builtin_amdgcn_sinf(fmaf(Ls, f.c2[t], phase)), __builtin_amdgcn_sinf(fmaf(Ls, f.c2[t + 1], phase)));
+        }
+        const f16x8 e0 = __builtin_bit_cast(f16x8, w0), e1 = __builtin_bit_cast(f16x8, w1);
+        f32x4 acc = bp4;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], e0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1], e1, acc, 0, 0, 0);
+        float* gp = gb + (4 * grp) * kGH + (2 * wave + qs) * kGQ + 16 * ks + col;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gp[e * kGH] = __builtin_amdgcn_logf(fmaxf(acc[e], 1e-6f));   // relu, clamp, log (SYM_REL:116,139)
+      }
+    }
+  };
+
+  // ---- attention state of (head h, queries qt*32 + l31) ---------------------------------------------
+  const int q = qt * 32 + l31;
+  const int qc = q < a.N ? q : a.N - 1;
+  const T* Q = (const T*)a.q + (long)b * a.q_bs + (long)qc * a.q_ld + h * 64;
+  const T* Kb = (const T*)a.k + (long)b * a.k_bs + h * 64;
+  const T* Vb = (const T*)a.vwt + (long)b * a.vwt_bs + (long)(h * 64) * a.vwt_ld;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(Q + 16 * kk + 8 * half);
+  f32x16 o[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float scale2 = a.scale * 1.44269504088896340736f;
+
+  __syncthreads();                                         // key table
+  geometry_tile(0, sG);
+  __syncthreads();
+  for (int kt = 0; kt < ntile; ++kt) {
+    const int key0 = kt * 32;
+    const float* gb = sG + (kt & 1) * kGBuf + h * kGH + l31 * kGQ + 4 * half;
+    // K rows of this tile: requested before the geometry of the next tile so that their latency is covered
+    bf16x8 kf[4];
+    {
+      int kr = key0 + l31;
+      kr = kr < a.M ? kr : a.M - 1;                       // keys past M: any valid row, masked below
+      const T* Kr = Kb + (long)kr * a.k_ld + 8 * half;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) kf[kk] = *(const bf16x8*)(Kr + 16 * kk);
+    }
+    if (kt + 1 < ntile) geometry_tile(kt + 1, sG + ((kt + 1) & 1) * kGBuf);
+    bf16x8 vf[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const T* Vr = Vb + (long)(32 * d + l31) * a.vwt_ld + key0 + 16 * ks + 4 * half;   // pad columns are 0
+        *(uint2*)&vf[ks][d] = *(const uint2*)Vr;
+        *((uint2*)&vf[ks][d] + 1) = *(const uint2*)(Vr + 8);
+      }
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], s, 0, 0, 0);
+    // logits in the log2 domain: v = log2(G) + (scale * log2 e) * (q . k)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const float4 bv = *(const float4*)(gb + 8 * gq);
+      s[4 * gq + 0] = fmaf(s[4 * gq + 0], scale2, bv.x);
+      s[4 * gq + 1] = fmaf(s[4 * gq + 1], scale2, bv.y);
+      s[4 * gq + 2] = fmaf(s[4 * gq + 2], scale2, bv.z);
+      s[4 * gq + 3] = fmaf(s[4 * gq + 3], scale2, bv.w);
+    }
+    if (key0 + 32 > a.M) {                                // only the last tile has keys past M
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (key0 + 8 * gq + 4 * half + e >= a.M) s[4 * gq + e] = -INFINITY;
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    if (__any(tmax > m_run + 8.0f)) {                     // deferred rescale, as in relation_attention_lds_kernel
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = __builtin_amdgcn_exp2f(s[r] - m_run);
+      s[r] = pv;
+      psum += pv;
+    }
+    l_run += psum;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 pf;
+      unsigned int* pw = (unsigned int*)&pf;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) pw[t] = pack_bf16x2(s[8 * ks + 2 * t], s[8 * ks + 2 * t + 1]);
+#pragma unroll
+      for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks][d], pf, o[d], 0, 0, 0);
+    }
+    __syncthreads();                                      // tile kt consumed by every head, tile kt+1 complete
+  }
+  // ---- epilogue: (O^T / l + bout) -> bf16 -> LDS [q][dv] -> 16-byte coalesced rows (the bias buffers are free now)
+  unsigned short* so = (unsigned short*)smem + wave * (32 * kOLD);
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int dv = 32 * d + 8 * gq + 4 * half;
+      float y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = o[d][4 * gq + e] * inv + (a.bout ? a.bout[h * 64 + dv + e] : 0.f);
+      *(uint2*)(so + l31 * kOLD + dv) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+    }
+  __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the same wave reads back what it wrote
+  __builtin_amdgcn_wave_barrier();
+  unsigned short* Y = a.out ? (unsigned short*)a.out + (long)b * a.out_bs + h * 64 : nullptr;
+  unsigned short* Z = a.out_act ? (unsigned short*)a.out_act + (long)b * a.act_bs + h * 64 : nullptr;
+  const unsigned short* R = a.resid ? (const unsigned short*)a.resid + (long)b * a.resid_bs + h * 64 : nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = lane + 64 * i, qq = idx >> 3, c8 = (idx & 7) * 8;
+    const int qrow = qt * 32 + qq;
+    if (qrow >= a.N) continue;
+    const uint4 yv = *(const uint4*)(so + qq * kOLD + c8);
+    if (Y) *(uint4*)(Y + (long)qrow * a.out_ld + c8) = yv;
+    if (Z) {
+      const unsigned int yw[4] = {yv.x, yv.y, yv.z, yv.w};
+      unsigned int rw[4] = {0u, 0u, 0u, 0u};
+      if (R) {
+        const uint4 rv = *(const uint4*)(R + (long)qrow * a.resid_ld + c8);
+        rw[0] = rv.x; rw[1] = rv.y; rw[2] = rv.z; rw[3] = rv.w;
+      }
+      unsigned int zw[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        zw[e] = pack_bf16x2(fmaxf(bf2f(yw[e] & 0xffff) + bf2f(rw[e] & 0xffff), 0.f),
+                            fmaxf(bf2f(yw[e] >> 16) + bf2f(rw[e] >> 16), 0.f));
+      *(uint4*)(Z + (long)qrow * a.act_ld + c8) = make_uint4(zw[0], zw[1], zw[2], zw[3]);
+    }
+  }
+}
+
 }  // namespace relnet
 
 using namespace relnet;
@@ -535,7 +878,13 @@ extern "C" int relnet_geometry_bias(const float* boxes, int box_stride, int box_
   g.B = B; g.N = N; g.M = M; g.Mpad = Mpad; g.nmod = nmod;
   dim3 grid((unsigned)(((long)N * M + 255) / 256), B);
   hipStream_t s = (hipStream_t)stream;
-  if (bias_half) {
+  for (int k = 0; k < 8; ++k) g.c2[k] = (float)(0.69314718055994530942 * 100.0 / (6.283185307179586476925 * (double)divisors8[k]));
+  const size_t key_lds = (size_t)((M + 63) / 64) * 64 * 16;
+  if (bias_half && !pos_mat && !pos_emb && key_lds <= 64 * 1024) {
+    // throughput path: pair_pos_fc1 of all modules on the matrix cores, one wavefront per query
+    dim3 g2((unsigned)((N + 3) / 4), B);
+    geometry_bias_mfma_kernel<<<g2, 256, key_lds, s>>>(g);
+  } else if (bias_half) {
     if (nmod == 1) geometry_bias_kernel<16, 1, __half><<<grid, 256, 0, s>>>(g);
     else geometry_bias_kernel<16, 2, __half><<<grid, 256, 0, s>>>(g);
   } else {
@@ -600,4 +949,43 @@ extern "C" int relnet_relation_attention(
     RELNET_REQUIRE(false, "relnet_relation_attention: unknown dtype %d", in_dtype);
   }
   return check_launch("relnet_relation_attention");
+}
+
+// Fused geometry + attention of one relation module (bf16; H = 16 heads x 64; M <= 640 keys).
+// boxes [B][N][box_stride] fp32 (xyxy at +box_off), wp [16][64] / bp [16] = pair_pos_fc1 of this module,
+// divisors8 = wave_length^(t/8) (host pointer).  Replaces relnet_geometry_bias + relnet_relation_attention
+// (SYM_REL:29-83 + :109-150) on the throughput path; outputs as relnet_relation_attention.
+extern "C" int relnet_relation_attention_fused(
+    const void* q, long q_ld, long q_bs, const void* k, long k_ld, long k_bs, const void* vwt,
+    long vwt_ld, long vwt_bs, const float* boxes, int box_stride, int box_off, const float* wp,
+    const float* bp, const float* divisors8, const float* bout, const void* resid, long resid_ld,
+    long resid_bs, void* out, long out_ld, long out_bs, void* out_act, long act_ld, long act_bs,
+    int B, int H, int N, int M, int Mpad, float scale, void* stream) {
+  RELNET_REQUIRE(q && k && vwt && boxes && wp && bp && divisors8, "relnet_relation_attention_fused: null operand");
+  RELNET_REQUIRE(out || out_act, "relnet_relation_attention_fused: no output requested");
+  RELNET_REQUIRE(H == 16, "relnet_relation_attention_fused: %d heads unsupported (16 only: one wavefront per head)", H);
+  RELNET_REQUIRE(B > 0 && N > 0 && M > 0 && M <= N && M <= 640 && Mpad >= M && Mpad % 32 == 0,
+                 "relnet_relation_attention_fused: bad shape B=%d N=%d M=%d Mpad=%d (M <= 640)", B, N, M, Mpad);
+  RELNET_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && vwt_ld % 4 == 0 && out_ld % 8 == 0 && act_ld % 8 == 0 && resid_ld % 8 == 0,
+                 "relnet_relation_attention_fused: row strides must be 16-byte (q, k, outputs) / 8-byte (vwt) aligned");
+  FusedArgs f;
+  AttnArgs& a = f.a;
+  a.q = q; a.q_ld = q_ld; a.q_bs = q_bs; a.k = k; a.k_ld = k_ld; a.k_bs = k_bs;
+  a.vwt = vwt; a.vwt_ld = vwt_ld; a.vwt_bs = vwt_bs; a.bias = nullptr; a.bias_bs = 0;
+  a.bout = bout; a.resid = resid; a.resid_ld = resid_ld; a.resid_bs = resid_bs;
+  a.out = out; a.out_ld = out_ld; a.out_bs = out_bs; a.out_act = out_act; a.act_ld = act_ld;
+  a.act_bs = act_bs; a.logits = nullptr; a.B = B; a.H = H; a.N = N; a.M = M; a.Mpad = Mpad; a.scale = scale;
+  f.boxes = boxes; f.box_stride = box_stride; f.box_off = box_off; f.wp = wp; f.bp = bp;
+  for (int t = 0; t < 8; ++t) f.c2[t] = (float)(0.69314718055994530942 * 100.0 / (6.283185307179586476925 * (double)divisors8[t]));
+  f.nq = (N + 31) / 32;
+  const int ntile = (M + 31) / 32;
+  const size_t lds = (size_t)2 * kGBuf * 4 + (size_t)ntile * 32 * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)relation_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const unsigned grid = (unsigned)(f.nq * ((B + 7) / 8) * 8);
+  relation_fused_kernel<<<grid, 1024, lds, (hipStream_t)stream>>>(f);
+  return check_launch("relnet_relation_attention_fused");
 }

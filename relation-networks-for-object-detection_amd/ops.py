@@ -128,6 +128,37 @@ def relation_attention(q, k, vwt, bias, bout=None, resid=None, M=None, want_out=
     return out, act, logits
 
 
+FUSED_MAX_KEYS = 640          # key table + two bias tiles must fit the 160 KiB LDS (csrc/relation.hip)
+
+
+def relation_attention_fused(q, k, vwt, boxes, wp, bp, bout=None, resid=None, M=None, want_out=True,
+                             want_act=False, heads=16, divisors=None):
+    """Geometry bias + attention of one relation module in one kernel (bf16): operands as `relation_attention`, with the
+    bias tensor replaced by its inputs: boxes [B,N,4|5] fp32, wp [16,64] / bp [16] fp32 (pair_pos_fc1 of the module).
+    -> (out | None, relu(resid + out) | None)."""
+    _chk(q, k, vwt, boxes, wp, bp, bout, resid)
+    B, N = q.shape[0], q.shape[1]
+    H = heads
+    Mpad = vwt.shape[-1]
+    M = k.shape[1] if M is None else M
+    assert q.dtype == torch.bfloat16 and H == 16 and M <= FUSED_MAX_KEYS
+    assert boxes.dtype == torch.float32 and boxes.is_contiguous() and boxes.shape[:2] == (B, N)
+    assert wp.shape == (16, 64) and wp.dtype == torch.float32 and wp.is_contiguous() and bp.dtype == torch.float32
+    assert vwt.shape[1] == H * 64 and vwt.stride(-1) == 1 and q.stride(-1) == 1 and k.stride(-1) == 1
+    bs = boxes.shape[2]
+    div = (divisors if divisors is not None else embedding_divisors()).to('cpu', torch.float32).contiguous()
+    out = torch.empty((B, N, H * 64), device=q.device, dtype=q.dtype) if want_out else None
+    act = torch.empty((B, N, H * 64), device=q.device, dtype=q.dtype) if want_act else None
+    rs = (resid.stride(1), resid.stride(0)) if resid is not None else (0, 0)
+    _lib.call('relnet_relation_attention_fused',
+              q.data_ptr(), q.stride(1), q.stride(0), k.data_ptr(), k.stride(1), k.stride(0),
+              vwt.data_ptr(), vwt.stride(1), vwt.stride(0), boxes.data_ptr(), bs, 1 if bs == 5 else 0,
+              wp.data_ptr(), bp.data_ptr(), div.data_ptr(), _ptr(bout), _ptr(resid), rs[0], rs[1],
+              _ptr(out), H * 64, N * H * 64, _ptr(act), H * 64, N * H * 64,
+              B, H, N, M, Mpad, 1.0 / math.sqrt(64.0), _stream())
+    return out, act
+
+
 # ---------------------------------------------------------------------------------------
 # RPN proposal path
 # ---------------------------------------------------------------------------------------

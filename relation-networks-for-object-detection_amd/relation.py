@@ -30,6 +30,7 @@ class RelationParams(object):
         self.bout = t(g('linear_out_bias'), torch.float32)
         self.wp = torch.as_tensor(g('pair_pos_fc1_weight')).to(torch.float32)      # [16, 64]
         self.bp = torch.as_tensor(g('pair_pos_fc1_bias')).to(torch.float32)
+        self.wp_dev, self.bp_dev = t(self.wp, torch.float32), t(self.bp, torch.float32)   # operands of the fused kernel
 
 
 def pack_pair_pos(mods, device):
@@ -41,7 +42,7 @@ def pack_pair_pos(mods, device):
 
 def attention_module_multi_head(roi_feat, rois, params, nongt_dim=None, fc_dim=16, feat_dim=1024,
                                 dim=(1024, 1024, 1024), group=16, index=1, dtype=None,
-                                return_logits=False, packed=None, bias=None):
+                                return_logits=False, packed=None, bias=None, fused=False):
     """Drop-in for SYM_REL.attention_module_multi_head (:85-151) on device tensors.
 
     roi_feat [N, feat_dim] or [B, N, feat_dim]; `rois` [.., N, 4|5] takes the place of the
@@ -57,27 +58,39 @@ def attention_module_multi_head(roi_feat, rois, params, nongt_dim=None, fc_dim=1
     B, N, _ = f.shape
     M = N if nongt_dim is None else nongt_dim
     mod = packed or RelationParams(params, index, dtype, f.device)
-    if bias is None:
+    bx = bx.to(torch.float32).contiguous()
+    if bias is None and not (fused and not return_logits and fused_ok(dtype, M)):
         wp_t, bp = pack_pair_pos([mod], f.device)
-        bias = ops.geometry_bias(bx.to(torch.float32).contiguous(), wp_t, bp, M,
-                                 half=(dtype == torch.bfloat16 and not return_logits))[0]
+        bias = ops.geometry_bias(bx, wp_t, bp, M, half=(dtype == torch.bfloat16 and not return_logits))[0]
     y, _, logits = _module_forward(f, mod, bias, M, want_out=True, want_act=False,
-                                   want_logits=return_logits)
+                                   want_logits=return_logits, rois=bx)
     if squeeze:
         y = y[0]
         logits = logits[0] if logits is not None else None
     return (y, logits) if return_logits else y
 
 
-def _module_forward(f, mod, bias, M, want_out, want_act, want_logits, vwt_buf=None):
+def fused_ok(dtype, M, heads=16):
+    """The one-kernel geometry + attention path (ops.relation_attention_fused) covers the bf16 throughput configuration."""
+    return dtype == torch.bfloat16 and heads == 16 and M <= ops.FUSED_MAX_KEYS
+
+
+def _module_forward(f, mod, bias, M, want_out, want_act, want_logits, vwt_buf=None, rois=None):
+    """`bias` None + `rois` given: fused geometry + attention kernel (no bias tensor, no logits output)."""
     B, N, F = f.shape
     qk = ops.gemm_nt(f.reshape(B * N, F), mod.wqk, mod.bqk).reshape(B, N, -1)
-    Mpad = bias.shape[-1]
+    Mpad = bias.shape[-1] if bias is not None else ops.pad32(M)
     if vwt_buf is None:
         vwt_buf = torch.zeros((B, mod.wout.shape[0], Mpad), device=f.device, dtype=f.dtype)
     # VW^T[b] = Wout F_b[:M]^T  (linear_out re-associated in front of the softmax sum)
     ops.gemm_nt(mod.wout, f[:, :M, :], out=vwt_buf, n_cols=M)
     d = mod.wqk.shape[0] // 2
+    if bias is None:
+        assert rois is not None and not want_logits
+        y, act = ops.relation_attention_fused(qk[:, :, :d], qk[:, :M, d:], vwt_buf, rois, mod.wp_dev, mod.bp_dev,
+                                              bout=mod.bout, resid=f if want_act else None, M=M, want_out=want_out,
+                                              want_act=want_act)
+        return y, act, None
     return ops.relation_attention(qk[:, :, :d], qk[:, :M, d:], vwt_buf, bias, bout=mod.bout,
                                   resid=f if want_act else None, M=M, want_out=want_out,
                                   want_act=want_act, want_logits=want_logits)
@@ -88,7 +101,7 @@ class RelationHead(object):
     (SYM_REL:254-280).  `dtype` bf16 is the throughput path, float32 the parity path."""
 
     def __init__(self, params, dtype=torch.bfloat16, device='cuda', fc1_perm=None, use_relation=True,
-                 fc_names=('fc_new_1', 'fc_new_2')):
+                 fc_names=('fc_new_1', 'fc_new_2'), fused=False):
         t = lambda x, dt: torch.as_tensor(x).to(device=device, dtype=dt).contiguous()
         self.dtype, self.device = dtype, device
         n1, n2 = fc_names          # ('roi_pool_fc1', 'roi_pool_fc2') in the FPN graphs
@@ -102,6 +115,9 @@ class RelationHead(object):
         self.num_classes = int(params['cls_score_weight'].shape[0])
         self.wcb, self.bcb = t(wcb, dtype), t(bcb, torch.float32)
         self.use_relation = use_relation
+        # fused: one geometry + attention kernel per module, no bias tensor in HBM -- built and parity-tested, but at B = 54
+        # it is slower (272 us / module) than the matrix-core geometry kernel + LDS attention kernel
+        self.fused = fused
         if use_relation:
             self.mods = [RelationParams(params, i, dtype, device) for i in (1, 2)]
             self.wp_t, self.bp = pack_pair_pos(self.mods, device)
@@ -123,12 +139,15 @@ class RelationHead(object):
             cb = ops.gemm_nt(x2.reshape(B * N, -1), self.wcb, self.bcb, out_dtype=torch.float32).reshape(B, N, -1)
             return cb[:, :, :self.num_classes], cb[:, :, self.num_classes:], x2
         M = N if nongt_dim is None else nongt_dim
-        bias = ops.geometry_bias(rois, self.wp_t, self.bp, M, half=self.dtype == torch.bfloat16)   # [2,B,16,N,Mpad]
-        vw = self._vwt_buf(B, bias.shape[-1], M)
+        if self.fused and fused_ok(self.dtype, M):
+            bias = (None, None)                 # geometry evaluated inside the attention kernel of each module
+        else:
+            bias = ops.geometry_bias(rois, self.wp_t, self.bp, M, half=self.dtype == torch.bfloat16)   # [2,B,16,N,Mpad]
+        vw = self._vwt_buf(B, ops.pad32(M), M)
         f1 = ops.gemm_nt(pooled.reshape(B * N, K), self.w1, self.b1).reshape(B, N, -1)
-        y1, x1, _ = _module_forward(f1, self.mods[0], bias[0], M, return_intermediates, True, False, vw[0])
+        y1, x1, _ = _module_forward(f1, self.mods[0], bias[0], M, return_intermediates, True, False, vw[0], rois)
         f2 = ops.gemm_nt(x1.reshape(B * N, -1), self.w2, self.b2).reshape(B, N, -1)
-        y2, x2, _ = _module_forward(f2, self.mods[1], bias[1], M, return_intermediates, True, False, vw[1])
+        y2, x2, _ = _module_forward(f2, self.mods[1], bias[1], M, return_intermediates, True, False, vw[1], rois)
         cb = ops.gemm_nt(x2.reshape(B * N, -1), self.wcb, self.bcb, out_dtype=torch.float32).reshape(B, N, -1)
         cls_score, bbox_pred = cb[:, :, :self.num_classes], cb[:, :, self.num_classes:]
         if return_intermediates:

@@ -187,3 +187,64 @@ def test_attention_lds_kernel_matches_streaming_kernel(rn):
     assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-2 * scale
     assert (outs[0][1] - outs[1][1]).abs().max().item() <= 1e-2 * outs[0][1].abs().max().item()
     assert torch.equal(outs[1][1], torch.relu(outs[1][1]))
+
+
+@pytest.mark.parametrize('B,n,m,seed', [(2, 300, 300, 44), (9, 333, 300, 45), (1, 77, 50, 46), (3, 64, 64, 47), (1, 640, 640, 48)])
+def test_fused_geometry_attention_kernel(rn, B, n, m, seed):
+    """One-kernel geometry + attention (fp16 pair_pos_fc1 product on the matrix cores, bias tiles in LDS) against
+    (a) the same bf16 operands through the fp32 geometry kernel + streaming attention kernel (fp32 bias: the tighter of the
+    two-kernel paths) and (b) the two-kernel throughput path it replaces (fp16 log2 G through HBM): the fused kernel must
+    be at least as close to (a) as (b) is, ragged query / key tiles, B > 8 (XCD image groups) and the act output included."""
+    ops, relation = rn
+    boxes, feat, p = cases.relation_case(n, m, seed, 0.02)
+    pt = {k: torch.as_tensor(v) for k, v in p.items()}
+    mod = relation.RelationParams(pt, 1, torch.bfloat16, 'cuda')
+    wp_t, bp = relation.pack_pair_pos([mod], 'cuda')
+    rng = np.random.default_rng(seed)
+    fs, bs = [], []
+    for b in range(B):
+        perm = rng.permutation(n)
+        fs.append(_dev(feat[perm])); bs.append(_dev(boxes[perm]))
+    f = torch.stack(fs).to(torch.bfloat16)
+    bx = torch.stack(bs)
+    ref = relation._module_forward(f, mod, ops.geometry_bias(bx, wp_t, bp, m, half=False)[0], m, True, True, False)
+    two = relation._module_forward(f, mod, ops.geometry_bias(bx, wp_t, bp, m, half=True)[0], m, True, True, False)
+    fus = relation._module_forward(f, mod, None, m, True, True, False, rois=bx)
+    for i, what in ((0, 'out'), (1, 'act')):
+        r, t, u = ref[i].float(), two[i].float(), fus[i].float()
+        scale = r.abs().max().item()
+        e_two, e_fus = (t - r).abs().max().item(), (u - r).abs().max().item()
+        m_two, m_fus = (t - r).abs().mean().item(), (u - r).abs().mean().item()
+        print('%s B=%d N=%d M=%d: two-kernel - ref max %.3e mean %.3e | fused - ref max %.3e mean %.3e (scale %.3e)'
+              % (what, B, n, m, e_two, m_two, e_fus, m_fus, scale))
+        assert e_fus <= 2.0 ** -6 * scale, (what, e_fus, scale)            # <= 2 bf16 ulps of the largest output
+        assert m_fus <= 1.25 * m_two + 1e-6 * scale, (what, m_fus, m_two)   # on average no further from the fp32-bias result
+    assert torch.equal(fus[1], torch.relu(fus[1]))
+    # the drop-in entry point with fused=True returns the same tensor
+    y = relation.attention_module_multi_head(f, bx, pt, nongt_dim=m, dtype=torch.bfloat16, packed=mod, fused=True)
+    assert torch.equal(y, fus[0])
+
+
+@pytest.mark.parametrize('n,m,nmod', [(300, 300, 2), (77, 50, 1), (333, 300, 2), (64, 64, 1)])
+def test_geometry_bias_mfma_kernel(rn, n, m, nmod):
+    """fp16 log2 G from the matrix-core geometry kernel (pair_pos_fc1 of all modules as one fp16 MFMA product, hardware
+    sin / log2) against the fp32 ln G of the VALU kernel (correctly rounded log, sincosf): G itself within 2e-3 relative
+    wherever the fp32 pre-activation is not within cancellation distance of the 1e-6 clamp, ragged M, one and two modules."""
+    ops, relation = rn
+    boxes, feat, p = cases.relation_case(n, m, 51, 0.02)
+    rng = np.random.default_rng(52)
+    wp_t = _dev(rng.normal(0, 0.05, (64, nmod * 16)).astype(np.float32))
+    bp = _dev(rng.normal(0, 0.05, (nmod * 16,)).astype(np.float32))
+    bx = torch.stack([_dev(boxes), _dev(boxes[::-1].copy())])
+    want = ops.geometry_bias(bx, wp_t, bp, m, half=False)[..., :m].double()                # ln G
+    got = ops.geometry_bias(bx, wp_t, bp, m, half=True)[..., :m].double() * np.log(2.0)    # log2 G -> ln G
+    assert got.shape == (nmod, 2, 16, n, m) and torch.isfinite(got).all()
+    G = want.exp()
+    ok = G > 2e-2                   # |fc| error of the fp16 product is ~1e-4 absolute: 5e-3 relative at G = 2e-2
+    err = (got - want).abs()
+    print('N=%d M=%d nmod=%d: ln G error max %.2e (G > 2e-2: %.1f%% of entries), mean %.2e; clamped entries agree: %.4f'
+          % (n, m, nmod, err[ok].max().item(), 100 * ok.double().mean().item(), err[ok].mean().item(),
+             ((got < -13) == (want < -13)).double().mean().item()))
+    assert err[ok].max().item() <= 8e-3 + 2.0 ** -9 * 16         # fp16 product + fp16 rounding of log2 G (|log2 G| < 16)
+    assert err[ok].mean().item() <= 2e-3
+    assert ((got < -13) == (want < -13)).double().mean().item() >= 0.998      # relu-clamped pairs (G = 1e-6) stay clamped
