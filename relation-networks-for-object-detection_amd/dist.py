@@ -77,33 +77,65 @@ def is_trainable(name, fixed=FIXED_PARAMS):
     return not any(f in name for f in fixed)
 
 
-class GradientBucket(object):
-    """All trainable gradients in ONE flat buffer, reduced with a single all-reduce(SUM) per step
-    instead of one push/pull per tensor: on xGMI (point-to-point links, ~153 GB/s each) a ring
-    all-reduce is per-link bound, so the 68.3 M-element payload (273 MB fp32 / 137 MB bf16) wants one
-    large collective, issued as soon as the backward pass has filled the buffer."""
+class BucketedAllReduce(object):
+    """The gradient exchange of the training step: SUM all-reduce (MXNet rescale_grad = 1.0 semantics,
+    train_end2end.py:167; the reference pushes / pulls one tensor at a time, core/module.py:569-591) of ONE flat
+    gradient buffer in a few large contiguous buckets, each issued as soon as the backward pass has finished writing it.
 
-    def __init__(self, named_shapes, dtype=torch.float32, device='cpu', fixed=FIXED_PARAMS):
-        self.names = [n for n, _ in named_shapes if is_trainable(n, fixed)]
-        self.shapes = {n: tuple(s) for n, s in named_shapes}
-        self.offsets, off = {}, 0
-        for n in self.names:
-            self.offsets[n] = off
-            numel = 1
-            for d in self.shapes[n]:
-                numel *= d
-            off += (numel + 63) // 64 * 64                 # 64-element alignment of every slice
-        self.flat = torch.zeros(off, dtype=dtype, device=device)
+    `bounds` are element offsets [b0 = 0 < b1 < ... < bn = numel]; bucket i = flat[b_i : b_{i+1}].  The trainer lays the
+    buffer out in forward order (res3 | res4 | res5 | heads), so the backward pass completes the buckets from the last
+    to the first: `ready(i)` launches bucket i asynchronously -- on CUDA from a side stream that waits for an event
+    recorded on the compute stream, so RCCL's ring over xGMI (point-to-point links, ~153 GB/s each: the collective is
+    per-link bound and wants few, large messages) overlaps the remaining backward kernels; `finish()` launches whatever
+    was not announced and makes the caller's stream wait for all of them.  With no process group (or one rank) every
+    call is a no-op.  Buckets are disjoint slices: a collective in flight never touches memory the backward pass still
+    writes, whatever the order of `ready` calls (tests/test_dist_gloo.py proves order independence on 2 gloo ranks)."""
 
-    def view(self, name):
-        numel = 1
-        for d in self.shapes[name]:
-            numel *= d
-        o = self.offsets[name]
-        return self.flat[o:o + numel].view(self.shapes[name])
+    def __init__(self, flat, bounds):
+        assert flat.dim() == 1 and bounds[0] == 0 and bounds[-1] == flat.numel() and list(bounds) == sorted(set(bounds))
+        self.flat, self.bounds = flat, list(bounds)
+        self.n = len(self.bounds) - 1
+        self.cuda = flat.is_cuda
+        self.stream = torch.cuda.Stream(device=flat.device) if self.cuda else None
+        self.pending, self.done, self.launch_order = [], set(), []
 
-    def all_reduce(self, async_op=False):
-        """SUM over ranks (MXNet rescale_grad = 1.0 semantics, train_end2end.py:167)."""
-        if not dist.is_initialized():
-            return None
-        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+    @staticmethod
+    def active():
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def bucket(self, i):
+        return self.flat[self.bounds[i]:self.bounds[i + 1]]
+
+    def ready(self, i):
+        """Bucket i holds its final local gradients (everything queued on the current stream so far)."""
+        if i in self.done:
+            return
+        self.done.add(i)
+        self.launch_order.append(i)
+        if not self.active():
+            return
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record()                                     # compute stream: all writers of bucket i are queued before this
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                work = dist.all_reduce(self.bucket(i), op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            work = dist.all_reduce(self.bucket(i), op=dist.ReduceOp.SUM, async_op=True)
+        self.pending.append(work)
+
+    def reset(self):
+        """Start of a new backward pass: nothing announced yet (collectives of an abandoned pass are waited for first)."""
+        for w in self.pending:
+            w.wait()
+        self.pending, self.done, self.launch_order = [], set(), []
+
+    def finish(self):
+        """Launch the buckets nobody announced (in backward order) and wait: after this the flat buffer holds the sums."""
+        for i in reversed(range(self.n)):
+            self.ready(i)
+        for w in self.pending:
+            w.wait()                                        # CUDA: the current stream waits for the collective's stream
+        order = self.launch_order
+        self.pending, self.done, self.launch_order = [], set(), []
+        return order

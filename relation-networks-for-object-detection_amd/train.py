@@ -245,6 +245,7 @@ class Trainer(object):
         returns the loss values (reference metric names)."""
         c = self.cfg
         B = data.shape[0]
+        self._grad_buckets().reset()
         self.W.grad.zero_(); self.Bv.grad.zero_()
         conv5, conv4, saved, _ = self._trunk_forward(data)
         feat = self._conv(conv5, 'conv_new_1', relu=True, bias=self.b('conv_new_1'))
@@ -325,8 +326,19 @@ class Trainer(object):
         """res5 -> res3 backward.  d_x = gradient of the last unit's output; inject[unit] = extra gradient of that unit's output."""
         B = saved[0][5].shape[0]
         bt = torch.bfloat16
-        # trunk: res5 -> res3
+        # trunk: res5 -> res3.  Gradient buckets are announced as they complete (heads first; with DCN the res5 offset
+        # convolutions live in the heads bucket, which is then complete only after res5): dist.BucketedAllReduce overlaps
+        # each bucket's all-reduce with the rest of the backward pass
+        dcn = self.cfg.dcn
+        if not dcn:
+            self._bucket_ready('heads')
+        prev = None
         for stage, nm, stride, dil, proj, x_in, y1, y2, o, off in reversed(saved):
+            if prev is not None and stage != prev:
+                self._bucket_ready('res%d' % prev)
+                if dcn and prev == 5:
+                    self._bucket_ready('heads')
+            prev = stage
             n1, na, nb, nc_ = 'res%s_branch1' % nm, 'res%s_branch2a' % nm, 'res%s_branch2b' % nm, 'res%s_branch2c' % nm
             if inject.get(nm) is not None:       # a second consumer of this unit's output (RPN head at conv4, FPN laterals)
                 d_x = inject[nm] if d_x is None else d_x + inject[nm]
@@ -361,6 +373,7 @@ class Trainer(object):
             else:
                 d_x, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, dx_add=g_out, keep_splits=True)       # identity shortcut
                 self._add_wgrad(na, dw, self.bn_scale[na])
+        self._bucket_ready('res%d' % prev)
 
     def _head_forward_backward(self, pooled2, rois_t, N, label, bbox_target, bbox_weight, im_info, gt_boxes, num_gt, out):
         """2FC head + relation modules + OHEM + losses (+ learn-NMS branch) and their adjoint down to the pooled features.
@@ -599,9 +612,30 @@ class Trainer(object):
         return ck.do_checkpoint(prefix, means, stds)(epoch, None, arg, aux)
 
     # ---- optimizer ----------------------------------------------------------------------------------------
+    def _grad_buckets(self):
+        """Weight-gradient buckets in buffer (= forward) order: res3 | res4 | res5 | everything after the trunk (RPN,
+        conv_new_1 / FPN neck, 2FC + relation + learn-NMS heads).  The backward pass completes them last to first."""
+        if getattr(self, '_buckets', None) is None:
+            trunk = [n for n in self.W.slices if n in self.bn_scale]            # BN-folded res3..res5 convolutions
+            first = lambda pre: min(self.W.slices[n][0] for n in trunk if n.startswith(pre))
+            trunk_end = max(self.W.slices[n][0] + (int(np.prod(self.W.slices[n][1])) + 63) // 64 * 64 for n in trunk)
+            cuts = [0, first('res4'), first('res5'), trunk_end, self.W.size]
+            self._bucket_names = ('res3', 'res4', 'res5', 'heads')
+            assert cuts == sorted(set(cuts)), cuts
+            self._buckets = D.BucketedAllReduce(self.W.grad, cuts)
+        return self._buckets
+
+    def _bucket_ready(self, name):
+        """Called by the backward pass when the last gradient of a bucket has been queued (no-op on one rank)."""
+        bk = self._grad_buckets()
+        bk.ready(self._bucket_names.index(name))
+
     def all_reduce(self):
-        """ONE summed all-reduce per flat buffer over RCCL (MXNet kvstore 'device' + rescale_grad 1.0 semantics)."""
-        all_reduce_sum(self.W.grad, self.Bv.grad)
+        """Summed all-reduce of the gradients over RCCL (MXNet kvstore 'device' + rescale_grad 1.0 semantics): the four
+        weight buckets -- those the backward pass has not already launched -- and the 0.1 MB bias buffer."""
+        order = self._grad_buckets().finish()
+        all_reduce_sum(self.Bv.grad)
+        return order
 
     def update(self, lr=None):
         c = self.cfg
@@ -649,6 +683,7 @@ class FPNTrainer(Trainer):
         bt = torch.bfloat16
         if data.shape[2] % 32 or data.shape[3] % 32:
             raise ValueError("FPN images must be padded to IMAGE_STRIDE 32, got %s" % (tuple(data.shape),))
+        self._grad_buckets().reset()
         self.W.grad.zero_(); self.Bv.grad.zero_()
         out = {}
         conv5, conv4, saved, ends = self._trunk_forward(data)

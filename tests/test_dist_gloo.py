@@ -54,7 +54,7 @@ def test_shard_edges():
     assert shard_images(16, 3, 4) == (12, 16)
 
 
-def _grad_worker(rank, world, port, q):
+def _bucket_worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     import sys
@@ -63,32 +63,55 @@ def _grad_worker(rank, world, port, q):
     import relnet_amd  # noqa: F401
     from relnet_amd import dist as D
     D.init(backend='gloo')
-    shapes = [('conv1_weight', (64, 3, 7, 7)), ('res2a_branch2a_weight', (64, 64, 1, 1)), ('bn4b3_branch2a_gamma', (256,)),
-              ('res4b3_branch2a_weight', (256, 1024, 1, 1)), ('fc_new_1_weight', (8, 50)), ('query_1_bias', (7,))]
-    b = D.GradientBucket(shapes)
-    for i, n in enumerate(b.names):
-        b.view(n).fill_(float(rank + 1) * (i + 1))
-    b.all_reduce()
-    q.put((rank, b.names, [float(b.view(n).flatten()[0]) for n in b.names], int(b.flat.numel())))
+    n = 4096
+    bounds = [0, 1024, 1600, 3008, n]                              # four uneven buckets ("res3 | res4 | res5 | heads")
+    results = []
+    for order in ((3, 2, 1, 0), (3, 2), (0, 1, 2, 3), ()):         # backward order, partial, wrong-way-round, none announced
+        g = torch.Generator().manual_seed(100 + rank)
+        local = torch.randn(n, generator=g)
+        flat = torch.zeros(n)
+        bk = D.BucketedAllReduce(flat, bounds)
+        bk.reset()
+        if order == (0, 1, 2, 3):                                   # everything written, announced first to last
+            flat.copy_(local)
+            for i in order:
+                bk.ready(i)
+        else:
+            for i in reversed(range(4)):                           # the "backward pass" fills the buckets last to first ...
+                flat[bounds[i]:bounds[i + 1]] = local[bounds[i]:bounds[i + 1]]
+                if i in order:                                      # ... and announces (some of) them right away, while the
+                    bk.ready(i)                                     # lower buckets are still being written
+        launched = bk.finish()
+        want = sum(torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) for r in range(world))
+        results.append((list(order), launched, bool(torch.equal(flat, want))))
+    # equals ONE all-reduce of the whole buffer (the round-1 exchange)
+    whole = torch.randn(n, generator=torch.Generator().manual_seed(100 + rank))
+    torch.distributed.all_reduce(whole)
+    results.append(('whole', [], bool(torch.equal(whole, want))))
+    q.put((rank, results))
     torch.distributed.destroy_process_group()
 
 
-def test_gradient_bucket_sum_allreduce():
-    """A13: frozen-by-substring rule + one flat SUM all-reduce (rescale_grad = 1 semantics)."""
+def test_bucketed_allreduce_order_and_overlap():
+    """Training exchange (dist.BucketedAllReduce, used by train.Trainer): buckets announced while the rest of the buffer
+    is still being written give exactly the SUM over ranks (rescale_grad = 1 semantics), for the backward order, a
+    partial announcement (finish() launches the rest, last to first), the reverse order and no announcement at all."""
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, names, vals, numel in res:
-        assert names == ['res4b3_branch2a_weight', 'fc_new_1_weight', 'query_1_bias']   # conv1/res2/gamma frozen
-        assert vals == [3.0, 6.0, 9.0]                                                 # (1 + 2) * (i + 1): SUM, not mean
-        assert numel == 256 * 1024 + 448 + 64                                          # 64-element aligned slices
+    for rank, results in res:
+        for order, launched, ok in results:
+            assert ok, (rank, order)
+        assert results[0][1] == [3, 2, 1, 0] and results[2][1] == [0, 1, 2, 3]     # launch order = announcement order
+        assert results[1][1][:2] == [3, 2] and sorted(results[1][1]) == [0, 1, 2, 3]      # announced first, the rest by finish()
+        assert results[3][1] == [3, 2, 1, 0]                                               # finish() alone: backward order
 
 
 def _flat_worker(rank, world, port, q):

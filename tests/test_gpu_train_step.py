@@ -165,6 +165,15 @@ def test_training_steps_reduce_the_loss_and_update_only_trainable():
     assert torch.isfinite(tr.W.master).all() and not torch.equal(tr.W.master, w0)
     assert all(torch.equal(tr.frozen[k], frozen_before[k]) for k in frozen_before)
     assert torch.equal(tr.W.work, tr.W.master.to(torch.bfloat16))  # bf16 working copy refreshed by the optimizer kernel
+    # gradient buckets (dist.BucketedAllReduce): announced by the backward pass heads -> res5 -> res4 -> res3, and the
+    # four contiguous ranges hold exactly those parameters
+    tr.forward_backward(*batch)
+    assert tr.all_reduce() == [3, 2, 1, 0]
+    bk = tr._grad_buckets()
+    for name, (off, _) in tr.W.slices.items():
+        i = max(j for j in range(4) if bk.bounds[j] <= off)
+        want = {'res3': 0, 'res4': 1, 'res5': 2}.get(name[:4], 3) if name in tr.bn_scale else 3
+        assert i == want, (name, i, want)
 
 
 def test_fpn_training_step_gradients_match_autograd():
