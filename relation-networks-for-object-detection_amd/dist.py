@@ -110,6 +110,8 @@ class BucketedAllReduce(object):
         """Bucket i holds its final local gradients (everything queued on the current stream so far)."""
         if i in self.done:
             return
+        if self.cuda and self.active() and torch.cuda.is_current_stream_capturing():
+            return          # inside a hipGraph capture the collective stays out of the graph: finish() issues it after the replay
         self.done.add(i)
         self.launch_order.append(i)
         if not self.active():
