@@ -140,6 +140,15 @@ int relnet_relation_attention_fused(const void* q, long q_ld, long q_bs, const v
                                     long out_ld, long out_bs, void* out_act, long act_ld, long act_bs, int B, int H,
                                     int N, int M, int Mpad, float scale, void* stream);
 
+/* Residual-block boundary of the ResNet trunk as ONE pixel-wise kernel (csrc/bottleneck.hip; reference graph
+ * symbols/resnet_v1_101_rcnn_base.py: res<s><u>_branch2c + bn + shortcut + relu, then res<s><u+1>_branch2a + bn + relu):
+ *   x_next = relu(W3 . mid2 + b3 + x),  mid1_next = relu(W1n . x_next + b1n)        (BN folded into W / b)
+ * mid2 [P][mid], x / x_next [P][4 mid], mid1_next [P][mid] bf16, dense pixel rows.  w3f = relnet_pack_w_frag(W3 [4 mid][mid]);
+ * w1f = W1n [mid][4 mid] in the accumulator-permuted fragment order: block (rt, ks) = 64 lanes x 8 values, lane (l31, half)
+ * slot t <- W1n[32 rt + l31][16 ks + 8 (t >> 2) + 4 half + (t & 3)].  mid = 64.                                      */
+int relnet_bottleneck_chain(const void* mid2, const void* x, const void* w3f, const void* w1f, const float* b3,
+                            const float* b1, void* x_next, void* mid1_next, long P, int mid, void* stream);
+
 /* Row-panel form of the 1x1 convolutions (csrc/gemm.hip:gemm_panelw_kernel): `w_frag` is the weight matrix re-ordered once
  * at model load by relnet_pack_w_frag ([Cout][K] bf16 -> MFMA fragment order, same byte count; Cout % 32 == 0, K % 16 == 0).
  * relnet_conv2d_nhwc_wf == relnet_conv2d_nhwc when w_frag is NULL or the layer is not a stride-1 1x1 convolution with

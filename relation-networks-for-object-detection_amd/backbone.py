@@ -122,7 +122,7 @@ class Backbone(object):
     in torch.nn.functional.conv2d (used for the float32 parity path)."""
 
     def __init__(self, params, dtype=torch.bfloat16, device='cuda', channels_last=True, impl=None, stem='hip', dcn=False,
-                 fpn=False):
+                 fpn=False, chain=True):
         self.dtype, self.device, self.dcn, self.fpn = dtype, device, dcn, fpn
         self.impl = impl or ('hip' if dtype == torch.bfloat16 else 'miopen')
         self.stem = stem
@@ -161,6 +161,15 @@ class Backbone(object):
                              params['bn_conv1_moving_mean'], params['bn_conv1_moving_var'])
             self.w_stem = ops.pack_stem_weight(w1, self.dtype, self.device)
             self.zero_bias64 = torch.zeros(64, device=self.device, dtype=torch.float32)
+        # block boundaries inside a stage (identity shortcut, stride 1) of the HBM-bound stages: expand + shortcut + ReLU of
+        # unit u and reduce + ReLU of unit u+1 as one pixel-wise kernel (ops.bottleneck_chain); unit -> its operands
+        self.chain = {}
+        if self.impl == 'hip' and chain:
+            for (st, nm, ic, mc, oc, stride, dil, proj), nxt in zip(self.units[:-1], self.units[1:]):
+                if nxt[0] == st and not nxt[7] and mc in ops.CHAIN_MIDS:
+                    w3, b3, _ = self.wp['res%s_branch2c' % nm]
+                    w1n, b1n, _ = self.wp['res%s_branch2a' % nxt[1]]
+                    self.chain[nm] = (ops.pack_w_frag(w3), ops.pack_chain_w1(w1n), b3, b1n)
 
     def _put(self, name, w, b):
         self.w[name] = (w.to(self.device, self.dtype).contiguous(memory_format=self.mf),
@@ -193,20 +202,26 @@ class Backbone(object):
             x = ops.stem_bias_relu_pool(x.permute(0, 2, 3, 1), self.b32['conv1'])
         conv4 = None
         ends = {}
+        y_next = None
         for stage, nm, ic, mc, oc, stride, dil, proj in self.units:
             if stage == 5 and conv4 is None:
                 conv4 = x
             if proj and stage > 2:
                 ends[stage - 1] = x
             sc = self._hconv(x, 'res%s_branch1' % nm, stride=stride) if proj else x
-            y = self._hconv(x, 'res%s_branch2a' % nm, stride=stride, relu=True)
+            y = y_next if y_next is not None else self._hconv(x, 'res%s_branch2a' % nm, stride=stride, relu=True)
+            y_next = None
             if self.dcn and stage == 5:
                 y = self._deform_2b(y.permute(0, 3, 1, 2), 'res%s_branch2b' % nm,
                                     self._hconv(y, 'res%s_branch2b_offset' % nm, pad=2, dil=2, out_dtype=torch.float32).permute(0, 3, 1, 2))
                 y = y.permute(0, 2, 3, 1)
             else:
                 y = self._hconv(y, 'res%s_branch2b' % nm, pad=dil, dil=dil, relu=True)
-            x = self._hconv(y, 'res%s_branch2c' % nm, relu=True, resid=sc)     # relu(bn(conv) + shortcut)
+            ch = self.chain.get(nm)
+            if ch is not None:       # expand + shortcut + ReLU and the next unit's reduce + ReLU in one pixel-wise kernel
+                x, y_next = ops.bottleneck_chain(y, sc.contiguous(), *ch)
+            else:
+                x = self._hconv(y, 'res%s_branch2c' % nm, relu=True, resid=sc)     # relu(bn(conv) + shortcut)
         conv5 = x
         nchw = lambda t: t.permute(0, 3, 1, 2)
         if self.fpn:

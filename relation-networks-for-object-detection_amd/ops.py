@@ -359,6 +359,40 @@ def pack_w_frag(w_packed):
     return out
 
 
+CHAIN_MIDS = (64,)          # bottleneck widths relnet_bottleneck_chain is built for (res2)
+
+
+def pack_chain_w1(w_packed):
+    """Reduce weights [mid, 4 mid] bf16 of the NEXT block -> fragment order of bottleneck_chain's second product: block
+    (row tile rt, k-step ks) = 64 lanes x 8 values, lane (l31, half) slot t <- W[32 rt + l31][16 ks + 8 (t >> 2) + 4 half + (t & 3)]
+    (the contraction index in the order the accumulator registers of the first product hold it)."""
+    _chk(w_packed)
+    N, K = w_packed.shape
+    assert w_packed.dtype == torch.bfloat16 and N % 32 == 0 and K % 16 == 0
+    dev = w_packed.device
+    rt = torch.arange(N // 32, device=dev).view(-1, 1, 1, 1)
+    ks = torch.arange(K // 16, device=dev).view(1, -1, 1, 1)
+    lane = torch.arange(64, device=dev).view(1, 1, -1, 1)
+    t = torch.arange(8, device=dev).view(1, 1, 1, -1)
+    row = rt * 32 + (lane & 31)
+    col = ks * 16 + 8 * (t >> 2) + 4 * (lane >> 5) + (t & 3)
+    return w_packed[row, col].contiguous()
+
+
+def bottleneck_chain(mid2, x, w3_frag, w1_frag, b3, b1):
+    """x_next = relu(conv1x1(mid2; W3, b3) + x); mid1_next = relu(conv1x1(x_next; W1n, b1n)) in one kernel (NHWC bf16).
+    mid2 [.., mid], x [.., 4 mid] dense; w3_frag = pack_w_frag(W3), w1_frag = pack_chain_w1(W1n)."""
+    _chk(mid2, x, w3_frag, w1_frag, b3, b1)
+    mid = mid2.shape[-1]
+    assert mid2.is_contiguous() and x.is_contiguous() and x.shape[-1] == 4 * mid and x.shape[:-1] == mid2.shape[:-1]
+    assert mid2.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and b3.dtype == torch.float32 and b1.dtype == torch.float32
+    xn = torch.empty_like(x)
+    m1 = torch.empty_like(mid2)
+    _lib.call('relnet_bottleneck_chain', mid2.data_ptr(), x.data_ptr(), w3_frag.data_ptr(), w1_frag.data_ptr(), b3.data_ptr(),
+              b1.data_ptr(), xn.data_ptr(), m1.data_ptr(), mid2.numel() // mid, mid, _stream())
+    return xn, m1
+
+
 def conv2d_nhwc(x, w_packed, bias, ksize=1, stride=1, pad=0, dil=1, relu=False, resid=None, out=None,
                 out_dtype=None, w_frag=None):
     """x [B,H,W,Cin] bf16 (last dim contiguous; pixel/image strides free), w_packed

@@ -1,0 +1,60 @@
+"""Pixel-wise residual-boundary kernel (csrc/bottleneck.hip): relu(W3 mid2 + b3 + x) and the next unit's reduce in one
+launch, against the two convolution launches it replaces and a float64 evaluation of the same bf16 operands."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('shape', [(1, 5, 7), (2, 38, 63), (3, 150, 250)])
+def test_bottleneck_chain_vs_two_convolutions(shape):
+    import relnet_amd  # noqa: F401
+    from relnet_amd import ops
+    B, H, W = shape
+    mid, cout = 64, 256
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    bf = torch.bfloat16
+    m2 = torch.relu(torch.randn(B, H, W, mid, generator=g)).to(bf).cuda()
+    x = torch.relu(torch.randn(B, H, W, cout, generator=g)).to(bf).cuda()
+    w3 = (torch.randn(cout, mid, generator=g) * 0.1).to(bf).cuda()
+    w1 = (torch.randn(mid, cout, generator=g) * 0.05).to(bf).cuda()
+    b3 = (torch.randn(cout, generator=g) * 0.1).cuda()
+    b1 = (torch.randn(mid, generator=g) * 0.1).cuda()
+    xn, m1 = ops.bottleneck_chain(m2, x, ops.pack_w_frag(w3), ops.pack_chain_w1(w1), b3, b1)
+    # (a) the two launches of the unfused path
+    xn_ref = ops.conv2d_nhwc(m2, w3, b3, relu=True, resid=x)
+    m1_ref = ops.conv2d_nhwc(xn_ref, w1, b1, relu=True)
+    # (b) float64 on the same bf16 operands, with the bf16 rounding of x_next that both paths apply
+    xn64 = torch.relu(m2.double() @ w3.double().t() + b3.double() + x.double())
+    m164 = torch.relu(xn.double() @ w1.double().t() + b1.double())          # from THIS kernel's x_next: isolates the 2nd product
+    ulp = lambda t: torch.maximum(t.abs(), torch.tensor(2.0 ** -126, dtype=torch.float64, device=t.device)) * 2.0 ** -7   # >= the bf16 spacing at |t|
+    # correctly rounded up to the fp32 accumulation noise (~1e-6 of the summed magnitudes) that can move a near-tie or a
+    # value next to the ReLU threshold
+    ex = (xn.double() - xn64).abs() - 0.5 * ulp(xn64)
+    em = (m1.double() - m164).abs() - 0.5 * ulp(m164)
+    print('shape %s: worst excess over half a bf16 step: x_next %.2e, mid1 %.2e' % (shape, ex.max().item(), em.max().item()))
+    assert ex.max().item() <= 2e-5 and em.max().item() <= 2e-5
+    # the two-launch path differs by at most one bf16 ulp, and only rarely (different fp32 summation order)
+    dx = (xn.float() - xn_ref.float()).abs().double()
+    dm = (m1.float() - m1_ref.float()).abs().double()
+    fx, fm = (dx > 0).double().mean().item(), (dm > 0).double().mean().item()
+    print('  vs two launches: x_next differs in %.3f%% of elements (max %.1f steps), mid1 in %.3f%% (max %.1f steps)'
+          % (100 * fx, (dx / ulp(xn64)).max().item(), 100 * fm, (dm / (ulp(m164) + 1e-6)).max().item()))
+    assert (dx <= ulp(xn64) * 1.01 + 1e-6).all() and fx < 0.02     # (+ fp32 summation-order noise next to the ReLU threshold)
+    assert (dm <= 4 * ulp(m164) + 1e-2).all() and fm < 0.05        # (a one-step difference of x_next times |W1|)
+
+def test_backbone_with_and_without_chain_kernel():
+    """The detector trunk with the res2 boundaries fused equals the unfused trunk up to bf16 rounding of a few elements."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import backbone
+    p = backbone.init_params(seed=5)
+    data = torch.randn(2, 3, 224, 320, generator=torch.Generator().manual_seed(1)).cuda() * 50
+    a = backbone.Backbone(p, dtype=torch.bfloat16, chain=True)
+    b = backbone.Backbone(p, dtype=torch.bfloat16, chain=False)
+    assert sorted(a.chain) == ['2a', '2b'] and not b.chain
+    fa, fb = a.forward(data), b.forward(data)
+    for k in ('conv4', 'conv5', 'rpn_cls_score', 'rpn_bbox_pred'):
+        d = (fa[k].float() - fb[k].float()).abs().max().item()
+        s = fb[k].float().abs().max().item()
+        assert d <= 2e-2 * s, (k, d, s)
