@@ -291,7 +291,7 @@ def main():
     else:
         det = detector.Detector(params, dtype=tdt, device='cuda', relation=not a.no_relation, cfg=cfg, stem=a.stem)
     if a.no_chain:
-        det.backbone.chain = {}
+        det.backbone.chain, det.backbone.halo3 = {}, {}
     g = torch.Generator().manual_seed(1000 + rank)
     # unit-variance synthetic pixels: with random-init weights (no checkpoints offline) this gives
     # O(1) RPN logits/deltas, i.e. several hundred distinct proposals survive NMS per image; N(0,50)

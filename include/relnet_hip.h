@@ -149,6 +149,12 @@ int relnet_relation_attention_fused(const void* q, long q_ld, long q_bs, const v
 int relnet_bottleneck_chain(const void* mid2, const void* x, const void* w3f, const void* w1f, const float* b3,
                             const float* b1, void* x_next, void* mid1_next, long P, int mid, void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolution + bias (+ ReLU) of a dense 64-channel NHWC bf16 tensor with the input tile and its halo
+ * resident in LDS (res2*_branch2b + BN + ReLU, resnet_v1_101_rcnn_base.py:52-56): the input is fetched 1.33 x instead of once
+ * per tap.  w_frag = relnet_pack_w_frag of the packed weight [64][576] (k = (r * 3 + s) * 64 + c).                        */
+int relnet_conv3x3_c64(const void* in, const void* w_frag, const float* bias, int relu, void* out, int B, int H, int W,
+                       void* stream);
+
 /* Row-panel form of the 1x1 convolutions (csrc/gemm.hip:gemm_panelw_kernel): `w_frag` is the weight matrix re-ordered once
  * at model load by relnet_pack_w_frag ([Cout][K] bf16 -> MFMA fragment order, same byte count; Cout % 32 == 0, K % 16 == 0).
  * relnet_conv2d_nhwc_wf == relnet_conv2d_nhwc when w_frag is NULL or the layer is not a stride-1 1x1 convolution with

@@ -163,13 +163,18 @@ class Backbone(object):
             self.zero_bias64 = torch.zeros(64, device=self.device, dtype=torch.float32)
         # block boundaries inside a stage (identity shortcut, stride 1) of the HBM-bound stages: expand + shortcut + ReLU of
         # unit u and reduce + ReLU of unit u+1 as one pixel-wise kernel (ops.bottleneck_chain); unit -> its operands
-        self.chain = {}
+        self.chain, self.halo3 = {}, {}
         if self.impl == 'hip' and chain:
             for (st, nm, ic, mc, oc, stride, dil, proj), nxt in zip(self.units[:-1], self.units[1:]):
                 if nxt[0] == st and not nxt[7] and mc in ops.CHAIN_MIDS:
                     w3, b3, _ = self.wp['res%s_branch2c' % nm]
                     w1n, b1n, _ = self.wp['res%s_branch2a' % nxt[1]]
                     self.chain[nm] = (ops.pack_w_frag(w3), ops.pack_chain_w1(w1n), b3, b1n)
+            # 64-channel 3x3 convolutions (res2*_branch2b): halo tile resident in LDS instead of one LDS fill per tap
+            for st, nm, ic, mc, oc, stride, dil, proj in self.units:
+                if mc == 64 and dil == 1:
+                    w, b, _ = self.wp['res%s_branch2b' % nm]
+                    self.halo3['res%s_branch2b' % nm] = (ops.pack_w_frag(w, panel_only=False), b)
 
     def _put(self, name, w, b):
         self.w[name] = (w.to(self.device, self.dtype).contiguous(memory_format=self.mf),
@@ -215,6 +220,8 @@ class Backbone(object):
                 y = self._deform_2b(y.permute(0, 3, 1, 2), 'res%s_branch2b' % nm,
                                     self._hconv(y, 'res%s_branch2b_offset' % nm, pad=2, dil=2, out_dtype=torch.float32).permute(0, 3, 1, 2))
                 y = y.permute(0, 2, 3, 1)
+            elif ('res%s_branch2b' % nm) in self.halo3:
+                y = ops.conv3x3_c64(y.contiguous(), *self.halo3['res%s_branch2b' % nm], relu=True)
             else:
                 y = self._hconv(y, 'res%s_branch2b' % nm, pad=dil, dil=dil, relu=True)
             ch = self.chain.get(nm)

@@ -20,6 +20,7 @@
 //            mid1'^T[c][px] accumulates over the two passes, then bias + ReLU + LDS transpose + coalesced rows.
 // Rounding points are those of the two-launch path (x_next is rounded to bf16 before the reduce product).
 #include "common.h"
+#include <stdlib.h>
 
 namespace relnet {
 
@@ -169,4 +170,162 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
   const unsigned grid = (unsigned)(ntile < 8 * 256 ? (ntile + 7) / 8 : 256);     // persistent: one workgroup per CU
   bottleneck_chain64_kernel<<<grid, 512, 65536 + 8 * 8192, (hipStream_t)stream>>>(a);
   return check_launch("relnet_bottleneck_chain");
+}
+
+// ---------------------------------------------------------------------------------------
+// 3x3 convolution of the 64-channel bottleneck (res2*_branch2b: stride 1, pad 1, BN folded, ReLU) with the input tile
+// and its halo resident in LDS.  The implicit-GEMM kernel fills LDS once per tap (9 x the input through L2 -> LDS,
+// 2.3 GB per launch at B = 54, the measured bound of its 297 us); here a (8+2) x (32+2)-pixel halo tile is fetched ONCE
+// (1.33 x the input) and the nine taps are row offsets into it.
+// Workgroup = 8 x 32 output pixels, persistent over tiles with the next halo tile in flight; wave (c, r) owns output
+// channels 32 c .. 32 c + 31 for pixel rows 2 r, 2 r + 1.  Its 36 weight fragments (32 channels x 576) stay in VGPRs for
+// the life of the workgroup, so LDS serves only the pixel operand.
+// ---------------------------------------------------------------------------------------
+namespace relnet {
+
+__device__ __attribute__((aligned(16))) const unsigned int g_zero_chunk[4] = {0u, 0u, 0u, 0u};
+
+struct Halo3Args {
+  const unsigned short* in;    // [B][H][W][64] bf16, dense
+  const uint4* wf;             // W [64][576] (k = tap * 64 + c) in fragment order (relnet_pack_w_frag)
+  const float* bias;           // [64]
+  unsigned short* out;         // [B][H][W][64]
+  int B, H, W, relu;
+  int tiles_x, tiles_y;        // ceil(W / 32), ceil(H / 8)
+  int ablate;
+};
+
+constexpr int kHaloW = 34, kHaloSlots = 40;                 // halo columns used / allocated per row (5 x 8 pixels)
+constexpr int kHaloBytes = 10 * kHaloSlots * 128;           // 50 DMA instructions x 1 KiB
+
+__global__ __launch_bounds__(512) void conv3x3_c64_halo_kernel(Halo3Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sOut = smem + 2 * kHaloBytes;               // [256 px][128 B], chunk c of pixel p at slot c ^ ((p >> 1) & 7)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keeps tile / row arithmetic on the scalar unit
+  const int half = lane >> 5, l31 = lane & 31;
+  const int chh = wave & 1, rg = wave >> 1;                  // channel half, row group
+  bf16x8 wfrag[36];
+#pragma unroll
+  for (int ks = 0; ks < 36; ++ks) wfrag[ks] = *(const bf16x8*)&a.wf[(chh * 36 + ks) * 64 + lane];
+  float* sBias = (float*)(sOut + 32768);                     // [64]
+  if (tid < 64) sBias[tid] = a.bias[tid];
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int ntile = a.B * per_img;
+
+  // halo tile in LDS: [10 rows][40 pixel slots][128 B] (34 used per row; 5 one-KiB DMA instructions per row), chunk c of
+  // slot q at position c ^ ((q >> 1) & 7), q = row * 40 + column.  Everything per-instruction is wave-uniform (scalar)
+  // except (lane >> 3, lane & 7): no per-lane address state survives between tiles (spilled addresses would be reloaded
+  // through scratch, whose vmcnt wait would serialise the LDS-direct loads behind each other -- measured 9 us per tile).
+  auto issue_halo = [&](int t, unsigned char* buf) {
+    asm volatile("" : "+s"(t));                             // opaque: no loop-carried (and then spilled) per-lane pointers
+    const int b = t / per_img, ty = (t % per_img) / a.tiles_x, tx = t % a.tiles_x;
+    const int y0 = ty * 8 - 1, x0 = tx * 32 - 1;
+    const unsigned short* img = a.in + (long)b * a.H * a.W * 64;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                            // opaque too: the per-lane parts are recomputed per tile, not kept live
+    const int r8 = ln >> 3, slot = ln & 7;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int j = wave + 8 * i;                            // DMA instruction j: halo row j / 5, pixel slots 8 (j % 5) ..
+      if (j >= 50) break;
+      const int hy = j / 5, part = j - 5 * hy;
+      const int y = y0 + hy, hx = part * 8 + r8, x = x0 + hx;
+      const int sw = (4 * (hy + part) + (r8 >> 1)) & 7;      // ((hy * 40 + hx) >> 1) & 7
+      const bool ok = hx < kHaloW && y >= 0 && y < a.H && x >= 0 && x < a.W;
+      const void* src = ok ? (const void*)(img + ((long)y * a.W + x) * 64 + ((slot ^ sw) << 3)) : (const void*)g_zero_chunk;
+      __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(buf + j * 1024), 16, 0, 0);
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t < ntile) issue_halo(t, smem);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  int cur = 0;
+  for (; t < ntile; t += gridDim.x, cur ^= 1) {
+    // the next tile's halo is requested first and is only waited for after this tile's arithmetic; this tile's stores are
+    // issued after that wait and drain during the NEXT tile's arithmetic (loads and stores share vmcnt and complete out of
+    // order with respect to each other, so the only safe wait is vmcnt(0): it is placed where both have had a tile's time)
+    const int tn = t + gridDim.x;
+    if (tn < ntile && !(a.ablate & 2)) issue_halo(tn, smem + (cur ^ 1) * kHaloBytes);
+    const unsigned char* hb = smem + cur * kHaloBytes;
+    int lq = l31;
+    asm volatile("" : "+v"(lq));                            // the 72 swizzled read offsets are recomputed per tile, not held in VGPRs
+    f32x16 acc[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rr][r] = 0.f;
+    if (!(a.ablate & 1)) {
+      // 36 k-steps (tap, 16-channel block); the two pixel rows alternate (two independent MFMA chains) and the fragments
+      // of step s + 2 are requested before the MFMAs of step s
+      auto frag = [&](int s_, int rr) -> bf16x8 {
+        const int tap = s_ >> 2, kb = s_ & 3, dy = tap / 3, dx = tap % 3;
+        const int hp = (2 * rg + rr + dy) * kHaloSlots + lq + dx;
+        return *(const bf16x8*)(hb + hp * 128 + (((2 * kb + half) ^ ((hp >> 1) & 7)) << 4));
+      };
+      bf16x8 pq[3][2];
+      pq[0][0] = frag(0, 0); pq[0][1] = frag(0, 1);
+      pq[1][0] = frag(1, 0); pq[1][1] = frag(1, 1);
+#pragma unroll
+      for (int s_ = 0; s_ < 36; ++s_) {
+        if (s_ + 2 < 36) { pq[(s_ + 2) % 3][0] = frag(s_ + 2, 0); pq[(s_ + 2) % 3][1] = frag(s_ + 2, 1); }
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[s_], pq[s_ % 3][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[s_], pq[s_ % 3][1], acc[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // bias -> ReLU -> bf16 -> staging [pixel][64 channels]
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int p = (2 * rg + rr) * 32 + l31;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bq = *(const float4*)(sBias + chh * 32 + 8 * g + 4 * half);
+        float v[4] = {acc[rr][4 * g] + bq.x, acc[rr][4 * g + 1] + bq.y, acc[rr][4 * g + 2] + bq.z, acc[rr][4 * g + 3] + bq.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = a.relu ? fmaxf(v[e], 0.f) : v[e];
+        *(uint2*)(sOut + p * 128 + (((chh * 4 + g) ^ ((p >> 1) & 7)) << 4) + 8 * half) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // both channel halves of every pixel are staged
+    {
+      const int b = t / per_img, ty = (t % per_img) / a.tiles_x, tx = t % a.tiles_x;
+      unsigned short* img = a.out + (long)b * a.H * a.W * 64;
+      const unsigned char* so = sOut + wave * 4096 + lane * 16;
+      const uint4 v0 = *(const uint4*)so, v1 = *(const uint4*)(so + 1024), v2 = *(const uint4*)(so + 2048), v3 = *(const uint4*)(so + 3072);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // next halo landed (this wave's part); staging read
+      auto put = [&](int i, const uint4& v) {
+        const int p = 8 * (wave * 4 + i) + (lane >> 3), slot = lane & 7;
+        const int y = ty * 8 + (p >> 5), x = tx * 32 + (p & 31);
+        if (y < a.H && x < a.W && !(a.ablate & 4)) *(uint4*)(img + ((long)y * a.W + x) * 64 + ((slot ^ ((p >> 1) & 7)) << 3)) = v;
+      };
+      put(0, v0); put(1, v1); put(2, v2); put(3, v3);
+    }
+    __builtin_amdgcn_s_barrier();                           // every wave's part of the next halo is in LDS; staging is free
+  }
+}
+
+}  // namespace relnet
+
+// 3x3 / stride 1 / pad 1 convolution + bias (+ ReLU) of a dense 64-channel NHWC bf16 tensor (res2*_branch2b with BN folded;
+// resnet_v1_101_rcnn_base.py:52-56).  w_frag = relnet_pack_w_frag of the packed weight [64][9 * 64] (k = (r * 3 + s) * 64 + c).
+extern "C" int relnet_conv3x3_c64(const void* in, const void* w_frag, const float* bias, int relu, void* out, int B, int H,
+                                  int W, void* stream) {
+  RELNET_REQUIRE(in && w_frag && bias && out, "relnet_conv3x3_c64: null operand");
+  RELNET_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "relnet_conv3x3_c64: bad geometry B=%d H=%d W=%d", B, H, W);
+  Halo3Args a;
+  a.in = (const unsigned short*)in; a.wf = (const uint4*)w_frag; a.bias = bias; a.out = (unsigned short*)out;
+  a.B = B; a.H = H; a.W = W; a.relu = relu;
+  a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8;
+  { const char* e = getenv("RELNET_HALO_ABLATE"); a.ablate = e ? atoi(e) : 0; }
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)conv3x3_c64_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const long ntile = (long)B * a.tiles_x * a.tiles_y;
+  const unsigned grid = (unsigned)(ntile < 256 ? ntile : 256);
+  conv3x3_c64_halo_kernel<<<grid, 512, 2 * kHaloBytes + 32768 + 256, (hipStream_t)stream>>>(a);
+  return check_launch("relnet_conv3x3_c64");
 }

@@ -347,15 +347,28 @@ def pack_conv_weight(w_oihw, dtype=torch.bfloat16, device='cuda'):
     return w_oihw.permute(0, 2, 3, 1).reshape(w_oihw.shape[0], -1).to(device=device, dtype=dtype).contiguous()
 
 
-def pack_w_frag(w_packed):
-    """[Cout, K] bf16 -> the same weights in MFMA fragment order (for the row-panel 1x1 kernel); None if the shape does
-    not qualify (stride-1 1x1 convolutions with K in {64,128,256,512} and Cout % 256 == 0 use it)."""
+def pack_w_frag(w_packed, panel_only=True):
+    """[Cout, K] bf16 -> the same weights in MFMA fragment order: block (n / 32, k / 16) = 64 lanes x 16 bytes, lane l <-
+    W[32 nb + (l & 31)][16 kb + 8 (l >> 5) ..].  panel_only: None unless the shape qualifies for the row-panel 1x1 kernel
+    (K in {64,128,256,512}, Cout % 256 == 0); otherwise any Cout % 32 == 0, K % 16 == 0."""
     _chk(w_packed)
     N, K = w_packed.shape
-    if w_packed.dtype != torch.bfloat16 or K not in (64, 128, 256, 512) or N % 256:
+    if panel_only and (w_packed.dtype != torch.bfloat16 or K not in (64, 128, 256, 512) or N % 256):
         return None
+    assert w_packed.dtype == torch.bfloat16 and N % 32 == 0 and K % 16 == 0 and w_packed.stride(1) == 1
     out = torch.empty_like(w_packed)
     _lib.call('relnet_pack_w_frag', w_packed.data_ptr(), w_packed.stride(0), out.data_ptr(), N, K, _stream())
+    return out
+
+
+def conv3x3_c64(x, w_frag, bias, relu=True):
+    """3x3 / stride 1 / pad 1 convolution + bias (+ ReLU) of a dense NHWC bf16 tensor with 64 channels in and out, input tile
+    + halo resident in LDS (csrc/bottleneck.hip).  w_frag = pack_w_frag(packed weight [64, 576], panel_only=False)."""
+    _chk(x, w_frag, bias)
+    B, H, W, C = x.shape
+    assert C == 64 and x.is_contiguous() and x.dtype == torch.bfloat16 and bias.dtype == torch.float32 and w_frag.numel() == 64 * 576
+    out = torch.empty_like(x)
+    _lib.call('relnet_conv3x3_c64', x.data_ptr(), w_frag.data_ptr(), bias.data_ptr(), int(relu), out.data_ptr(), B, H, W, _stream())
     return out
 
 

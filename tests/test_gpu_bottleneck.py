@@ -58,3 +58,30 @@ def test_backbone_with_and_without_chain_kernel():
         d = (fa[k].float() - fb[k].float()).abs().max().item()
         s = fb[k].float().abs().max().item()
         assert d <= 2e-2 * s, (k, d, s)
+
+
+@pytest.mark.parametrize('shape', [(1, 5, 7), (2, 38, 63), (2, 150, 250), (1, 8, 32), (3, 17, 65)])
+def test_conv3x3_c64_halo_kernel(shape):
+    """Halo-resident 3x3 kernel against float64 on the same bf16 operands (correctly rounded up to fp32 accumulation noise)
+    and against the implicit-GEMM launch it replaces; ragged tiles in both directions, image borders = zero padding."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(7 * B + H)
+    bf = torch.bfloat16
+    x = torch.relu(torch.randn(B, H, W, 64, generator=g)).to(bf).cuda()
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(bf)
+    b = (torch.randn(64, generator=g) * 0.1).cuda()
+    wp = ops.pack_conv_weight(w, bf, 'cuda')
+    for relu in (True, False):
+        y = ops.conv3x3_c64(x, ops.pack_w_frag(wp, panel_only=False), b, relu=relu)
+        ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().cuda(), b.double(), padding=1).permute(0, 2, 3, 1)
+        ref = torch.relu(ref) if relu else ref
+        step = torch.maximum(ref.abs(), torch.tensor(2.0 ** -126, dtype=torch.float64, device='cuda')) * 2.0 ** -7
+        ex = ((y.double() - ref).abs() - 0.5 * step).max().item()
+        y2 = ops.conv2d_nhwc(x, wp, b, ksize=3, pad=1, relu=relu)
+        d = (y.float() - y2.float()).abs().double()
+        print('shape %s relu=%d: excess over half a bf16 step %.2e; differs from the implicit-GEMM launch in %.4f%% of elements'
+              % (shape, relu, ex, 100 * (d > 0).double().mean().item()))
+        assert ex <= 2e-5
+        assert (d <= step * 1.01 + 1e-6).all()
