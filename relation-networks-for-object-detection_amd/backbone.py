@@ -1,11 +1,13 @@
 """ResNet-101 conv1..conv5 + RPN head + conv_new_1 of the reference graph
 (relation_rcnn/symbols/resnet_v1_101_rcnn_base.py:29-693, SYM_REL:249-250).
 
-Dense convolutions are plain library calls (MIOpen through torch.nn.functional.conv2d) in
-channels-last memory; what this module owns is the graph itself: the Caffe-style ResNet
-(stride on the FIRST 1x1 of a stage, :99,103), conv5 dilated 2 with stride 1 (:632-633),
-ceil-mode pool1 (pooling_convention='full', :35-36) and the frozen BatchNorm
-(use_global_stats=True, eps=1e-5, :32) folded into the preceding convolution at load time.
+impl='hip' (bf16, the throughput path): every convolution, the 7x7 stem included, is a kernel of librelnet_hip.so over
+NHWC activations -- the implicit-GEMM MFMA kernels of csrc/gemm.hip with bias / ReLU / shortcut fused into the epilogue,
+the halo-resident 3x3 kernel and the block-boundary chain kernel of csrc/bottleneck.hip for res2; no library call.
+impl='miopen' (float32 parity path) runs the same graph through torch.nn.functional.conv2d.  What this module owns is the
+graph itself: the Caffe-style ResNet (stride on the FIRST 1x1 of a stage, :99,103), conv5 dilated 2 with stride 1
+(:632-633), ceil-mode pool1 (pooling_convention='full', :35-36) and the frozen BatchNorm (use_global_stats=True, eps=1e-5,
+:32) folded into the preceding convolution at load time.
 Parameter names are the reference's (`res4b7_branch2a_weight`, `bn4b7_branch2a_gamma`, ...).
 """
 import math

@@ -23,11 +23,17 @@ def _digest():
     return h.hexdigest()
 
 
+LAST_ACTION = None        # 'compiled' | 'reused' after build(): lets the driver see whether hipcc actually ran
+
+
 def build(force=False, verbose=False):
     """Compile every csrc/*.hip and link the shared library; returns its path."""
+    global LAST_ACTION
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:
+        LAST_ACTION = 'reused'          # sources, flags and compiler unchanged since the library was linked
         return LIB
+    LAST_ACTION = 'compiled'
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
     procs = []

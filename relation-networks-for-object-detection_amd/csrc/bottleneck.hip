@@ -20,7 +20,6 @@
 //            mid1'^T[c][px] accumulates over the two passes, then bias + ReLU + LDS transpose + coalesced rows.
 // Rounding points are those of the two-launch path (x_next is rounded to bf16 before the reduce product).
 #include "common.h"
-#include <stdlib.h>
 
 namespace relnet {
 
@@ -192,7 +191,6 @@ struct Halo3Args {
   unsigned short* out;         // [B][H][W][64]
   int B, H, W, relu;
   int tiles_x, tiles_y;        // ceil(W / 32), ceil(H / 8)
-  int ablate;
 };
 
 constexpr int kHaloW = 34, kHaloSlots = 40;                 // halo columns used / allocated per row (5 x 8 pixels)
@@ -247,7 +245,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_halo_kernel(Halo3Args a) {
     // issued after that wait and drain during the NEXT tile's arithmetic (loads and stores share vmcnt and complete out of
     // order with respect to each other, so the only safe wait is vmcnt(0): it is placed where both have had a tile's time)
     const int tn = t + gridDim.x;
-    if (tn < ntile && !(a.ablate & 2)) issue_halo(tn, smem + (cur ^ 1) * kHaloBytes);
+    if (tn < ntile) issue_halo(tn, smem + (cur ^ 1) * kHaloBytes);
     const unsigned char* hb = smem + cur * kHaloBytes;
     int lq = l31;
     asm volatile("" : "+v"(lq));                            // the 72 swizzled read offsets are recomputed per tile, not held in VGPRs
@@ -256,7 +254,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_halo_kernel(Halo3Args a) {
     for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rr][r] = 0.f;
-    if (!(a.ablate & 1)) {
+    {
       // 36 k-steps (tap, 16-channel block); the two pixel rows alternate (two independent MFMA chains) and the fragments
       // of step s + 2 are requested before the MFMAs of step s
       auto frag = [&](int s_, int rr) -> bf16x8 {
@@ -298,7 +296,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_halo_kernel(Halo3Args a) {
       auto put = [&](int i, const uint4& v) {
         const int p = 8 * (wave * 4 + i) + (lane >> 3), slot = lane & 7;
         const int y = ty * 8 + (p >> 5), x = tx * 32 + (p & 31);
-        if (y < a.H && x < a.W && !(a.ablate & 4)) *(uint4*)(img + ((long)y * a.W + x) * 64 + ((slot ^ ((p >> 1) & 7)) << 3)) = v;
+        if (y < a.H && x < a.W) *(uint4*)(img + ((long)y * a.W + x) * 64 + ((slot ^ ((p >> 1) & 7)) << 3)) = v;
       };
       put(0, v0); put(1, v1); put(2, v2); put(3, v3);
     }
@@ -318,7 +316,6 @@ extern "C" int relnet_conv3x3_c64(const void* in, const void* w_frag, const floa
   a.in = (const unsigned short*)in; a.wf = (const uint4*)w_frag; a.bias = bias; a.out = (unsigned short*)out;
   a.B = B; a.H = H; a.W = W; a.relu = relu;
   a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8;
-  { const char* e = getenv("RELNET_HALO_ABLATE"); a.ablate = e ? atoi(e) : 0; }
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)conv3x3_c64_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

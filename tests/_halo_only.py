@@ -28,6 +28,6 @@ def timeit(fn, name):
         g.replay()
     e1.record(); torch.cuda.synchronize()
     print('%s: %.1f us' % (name, e0.elapsed_time(e1) * 1e3 / 50))
-timeit(lambda: ops.conv3x3_c64(x, wf, b), 'halo3x3 ablate=%s' % os.environ.get('RELNET_HALO_ABLATE', '0'))
-if not os.environ.get('RELNET_HALO_ABLATE'):
+timeit(lambda: ops.conv3x3_c64(x, wf, b), 'halo 3x3')
+if True:
     timeit(lambda: ops.conv2d_nhwc(x, wp, b, ksize=3, pad=1, relu=True), 'implicit gemm')
