@@ -144,18 +144,137 @@ __global__ __launch_bounds__(512) void bottleneck_chain64_kernel(ChainArgs a) {
   }
 }
 
+
+// MID = 128 (res3): the weights (2 x 128 KiB) do not fit LDS, so the workgroup walks the 128-output-channel passes in
+// lock step and re-loads the pass's W3 / W1' slices (32 KiB each, LDS-direct) between two barriers; every wavefront keeps
+// one 32-pixel tile (mid2 fragments + the mid1' accumulators) across the passes.  The exposed weight load (~2 us per pass)
+// is inside the HBM time of the tile (655 KB per 256 pixels), weights come from L2 (256 KiB per 256-pixel tile set).
+template <int MID>
+__global__ __launch_bounds__(512) void bottleneck_chain_stream_kernel(ChainArgs a) {
+  constexpr int COUT = 4 * MID, KS = MID / 16, RT = MID / 32, NP = COUT / 128;
+  constexpr int W3B = 4 * KS * 1024, W1B = RT * 8 * 1024;     // bytes per pass
+  constexpr int MROW = MID * 2, MCH = MID / 8;                 // mid1' staging: bytes per pixel row, 16-byte chunks per row
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint4* sW3 = (const uint4*)smem;                       // [4 ct][KS][64 lanes]
+  const uint4* sW1 = (const uint4*)(smem + W3B);               // [RT][8 k-steps of this pass][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  unsigned char* stage = smem + W3B + W1B + wave * 8192;
+  const int ntile = (a.P + 31) / 32, nset = (ntile + 7) / 8;
+  const int drow = lane >> 4, dcp = lane & 15;
+  for (int set = blockIdx.x; set < nset; set += gridDim.x) {
+    const int p0 = (set * 8 + wave) * 32;                      // >= P for the idle waves of the last set: loads clamp, stores are masked
+    const int px = min(p0 + l31, a.P - 1);
+    bf16x8 m2f[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) m2f[ks] = *(const bf16x8*)(a.m2 + (long)px * MID + 16 * ks + 8 * half);
+    f32x16 m1acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m1acc[rt][r] = 0.f;
+#pragma unroll 1
+    for (int hf = 0; hf < NP; ++hf) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the previous pass's weights / its stage
+#pragma unroll
+      for (int i = 0; i < (4 * KS + 7) / 8; ++i) {
+        const int q = wave + 8 * i;
+        if (q < 4 * KS) __builtin_amdgcn_global_load_lds((gas_ptr)(a.w3f + ((long)(hf * 4 * KS + q) * 64 + lane)), (las_ptr)(smem + q * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const int q = wave + 8 * i, rt = q >> 3, kk = q & 7;
+        __builtin_amdgcn_global_load_lds((gas_ptr)(a.w1f + ((long)(rt * (COUT / 16) + hf * 8 + kk) * 64 + lane)), (las_ptr)(smem + W3B + q * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + drow;
+        const unsigned short* src = a.x + (long)min(p0 + row, a.P - 1) * COUT + hf * 128 + ((dcp ^ (row & 15)) << 3);
+        __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(stage + i * 1024), 16, 0, 0);
+      }
+      f32x16 acc[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // weights of this pass (all waves' parts) and the shortcut slice landed
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&sW3[(ct * KS + ks) * 64 + lane], m2f[ks], acc[ct], 0, 0, 0);
+      // per 32-channel tile: shortcut + ReLU in place, then straight into the second product (the packed values of one tile
+      // are the only live copy: register budget)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        uint2 pk[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2* sp = (uint2*)(stage + l31 * 256 + (((ct * 4 + g) ^ (l31 & 15)) << 4) + 8 * half);
+          const uint2 xv = *sp;
+          const float4 bv = *(const float4*)(a.b3 + hf * 128 + ct * 32 + 8 * g + 4 * half);
+          const float v0 = fmaxf(acc[ct][4 * g + 0] + bv.x + bf2f(xv.x & 0xffff), 0.f), v1 = fmaxf(acc[ct][4 * g + 1] + bv.y + bf2f(xv.x >> 16), 0.f);
+          const float v2 = fmaxf(acc[ct][4 * g + 2] + bv.z + bf2f(xv.y & 0xffff), 0.f), v3 = fmaxf(acc[ct][4 * g + 3] + bv.w + bf2f(xv.y >> 16), 0.f);
+          pk[g] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+          *sp = pk[g];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bf16x8 xf;
+          *(uint2*)&xf = pk[2 * j];
+          *((uint2*)&xf + 1) = pk[2 * j + 1];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            m1acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&sW1[(rt * 8 + ct * 2 + j) * 64 + lane], xf, m1acc[rt], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + drow;
+        const uint4 v = *(const uint4*)(stage + i * 1024 + lane * 16);
+        if (p0 + row < a.P) *(uint4*)(a.xn + (long)(p0 + row) * COUT + hf * 128 + ((dcp ^ (row & 15)) << 3)) = v;
+      }
+    }
+    // mid1' = relu(. + b1): [32 px][MID] through the wave's stage (chunk c of row r at c ^ (r & (MCH - 1)))
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ch = rt * 32 + 8 * g + 4 * half;
+        const float4 bv = *(const float4*)(a.b1 + ch);
+        const float v0 = fmaxf(m1acc[rt][4 * g + 0] + bv.x, 0.f), v1 = fmaxf(m1acc[rt][4 * g + 1] + bv.y, 0.f);
+        const float v2 = fmaxf(m1acc[rt][4 * g + 2] + bv.z, 0.f), v3 = fmaxf(m1acc[rt][4 * g + 3] + bv.w, 0.f);
+        *(uint2*)(stage + l31 * MROW + (((ch >> 3) ^ (l31 & (MCH - 1))) << 4) + 8 * half) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int RPI = 1024 / MROW;                           // pixel rows per 1 KiB store instruction
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+      const int row = RPI * i + lane / MCH, cp = lane % MCH;
+      const uint4 v = *(const uint4*)(stage + i * 1024 + lane * 16);
+      if (p0 + row < a.P) *(uint4*)(a.m1 + (long)(p0 + row) * MID + ((cp ^ (row & (MCH - 1))) << 3)) = v;
+    }
+  }
+}
+
 }  // namespace relnet
 
 using namespace relnet;
 
 // x_next = relu(conv1x1(mid2; W3, b3) + x), mid1_next = relu(conv1x1(x_next; W1n, b1n)) over P pixels (NHWC bf16, dense
-// rows).  mid = 64 (res2: 64 -> 256 -> 64).  w3f = relnet_pack_w_frag of W3 [4 mid][mid]; w1f = W1n [mid][4 mid] in the
+// rows).  mid = 64 (res2: 64 -> 256 -> 64) or 128 (res3: 128 -> 512 -> 128).  w3f = relnet_pack_w_frag of W3 [4 mid][mid]; w1f = W1n [mid][4 mid] in the
 // accumulator-permuted fragment order (ops.pack_chain_w1).  Replaces two relnet_conv2d_nhwc launches
 // (resnet_v1_101_rcnn_base.py: res<s><u>_branch2c + shortcut + relu, res<s><u+1>_branch2a + relu).
 extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const void* w3f, const void* w1f, const float* b3,
                                        const float* b1, void* x_next, void* mid1_next, long P, int mid, void* stream) {
   RELNET_REQUIRE(mid2 && x && w3f && w1f && b3 && b1 && x_next && mid1_next, "relnet_bottleneck_chain: null operand");
-  RELNET_REQUIRE(mid == 64, "relnet_bottleneck_chain: mid = %d unsupported (64)", mid);
+  RELNET_REQUIRE(mid == 64 || mid == 128, "relnet_bottleneck_chain: mid = %d unsupported (64, 128)", mid);
   RELNET_REQUIRE(P > 0 && P < (1L << 31), "relnet_bottleneck_chain: bad pixel count %ld", P);
   ChainArgs a;
   a.m2 = (const unsigned short*)mid2; a.x = (const unsigned short*)x; a.w3f = (const uint4*)w3f; a.w1f = (const uint4*)w1f;
@@ -163,11 +282,13 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)bottleneck_chain64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)bottleneck_chain_stream_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const long ntile = (P + 31) / 32;
   const unsigned grid = (unsigned)(ntile < 8 * 256 ? (ntile + 7) / 8 : 256);     // persistent: one workgroup per CU
-  bottleneck_chain64_kernel<<<grid, 512, 65536 + 8 * 8192, (hipStream_t)stream>>>(a);
+  if (mid == 64) bottleneck_chain64_kernel<<<grid, 512, 65536 + 8 * 8192, (hipStream_t)stream>>>(a);
+  else bottleneck_chain_stream_kernel<128><<<grid, 512, 65536 + 8 * 8192, (hipStream_t)stream>>>(a);
   return check_launch("relnet_bottleneck_chain");
 }
 

@@ -372,7 +372,7 @@ def conv3x3_c64(x, w_frag, bias, relu=True):
     return out
 
 
-CHAIN_MIDS = (64,)          # bottleneck widths relnet_bottleneck_chain is built for (res2)
+CHAIN_MIDS = (64, 128)      # bottleneck widths relnet_bottleneck_chain is built for (res2: weights LDS-resident; res3: streamed per pass)
 
 
 def pack_chain_w1(w_packed):

@@ -7,13 +7,16 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize('mid', [64, 128])
 @pytest.mark.parametrize('shape', [(1, 5, 7), (2, 38, 63), (3, 150, 250)])
-def test_bottleneck_chain_vs_two_convolutions(shape):
+def test_bottleneck_chain_vs_two_convolutions(shape, mid):
     import relnet_amd  # noqa: F401
     from relnet_amd import ops
     B, H, W = shape
-    mid, cout = 64, 256
-    g = torch.Generator().manual_seed(B * 1000 + H)
+    if mid == 128 and H == 150:
+        H, W = 75, 125                     # the res3 map of a 600 x 1000 image
+    cout = 4 * mid
+    g = torch.Generator().manual_seed(B * 1000 + H + mid)
     bf = torch.bfloat16
     m2 = torch.relu(torch.randn(B, H, W, mid, generator=g)).to(bf).cuda()
     x = torch.relu(torch.randn(B, H, W, cout, generator=g)).to(bf).cuda()
@@ -52,7 +55,7 @@ def test_backbone_with_and_without_chain_kernel():
     data = torch.randn(2, 3, 224, 320, generator=torch.Generator().manual_seed(1)).cuda() * 50
     a = backbone.Backbone(p, dtype=torch.bfloat16, chain=True)
     b = backbone.Backbone(p, dtype=torch.bfloat16, chain=False)
-    assert sorted(a.chain) == ['2a', '2b'] and not b.chain
+    assert sorted(a.chain) == ['2a', '2b', '3a', '3b1', '3b2'] and not b.chain
     fa, fb = a.forward(data), b.forward(data)
     for k in ('conv4', 'conv5', 'rpn_cls_score', 'rpn_bbox_pred'):
         d = (fa[k].float() - fb[k].float()).abs().max().item()
