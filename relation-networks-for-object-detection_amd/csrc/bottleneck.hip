@@ -38,133 +38,87 @@ struct ChainArgs {
   int P;
 };
 
-// MID = 64 (res2): W3 (32 KiB) and W1' (32 KiB) stay in LDS for the life of the workgroup; 8 KiB stage per wavefront.
-__global__ __launch_bounds__(512) void bottleneck_chain64_kernel(ChainArgs a) {
-  constexpr int MID = 64, COUT = 256;
+// One kernel for both widths, in passes of 64 output channels of the expand product:
+//   MID = 64  (res2, STREAM = false): W3 / W1' (32 KiB each) stay in LDS for the life of the workgroup and the eight
+//             wavefronts run independently (no barrier after the weight load);
+//   MID = 128 (res3, STREAM = true):  the weights (2 x 128 KiB) do not fit, so the workgroup walks the passes in lock step and
+//             the pass's W3 / W1' slices (16 KiB each) go through a two-slot LDS ring, requested one pass ahead.
+// Per wavefront the shortcut slice of pass p+1 (32 px x 64 channels, 4 KiB, second stage buffer) is requested and the
+// finished slice of pass p-1 is stored BEFORE the arithmetic of pass p, so both are in flight during it; loads and stores
+// share vmcnt and complete out of order with respect to each other, hence the single vmcnt(0) at the top of a pass.
+// Nothing on the vector-memory path is issued inside the arithmetic (biases come from LDS): a load there would make the
+// compiler wait for the prefetch in front of it.
+template <int MID, bool STREAM>
+__global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
+  constexpr int COUT = 4 * MID, KS = MID / 16, RT = MID / 32, NP = COUT / 64;
+  constexpr int W3P = 2 * KS * 1024, W1P = 4 * RT * 1024;     // bytes of one pass's W3 / W1' slice
+  constexpr int WBYTES = STREAM ? 2 * (W3P + W1P) : NP * (W3P + W1P);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint4* sW3 = (uint4*)smem;                                  // [8 tiles][4 ks][64 lanes]
-  uint4* sW1 = sW3 + 8 * 4 * 64;                              // [2 tiles][16 ks][64 lanes]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, l31 = lane & 31;
-  unsigned char* stage = smem + 65536 + wave * 8192;          // [32 px][256 B], chunk c of row r at position c ^ (r & 15)
-  for (int i = tid; i < 2048; i += 512) sW3[i] = a.w3f[i];
-  for (int i = tid; i < 2048; i += 512) sW1[i] = a.w1f[i];
-  __syncthreads();
-  const int ntile = (a.P + 31) / 32;
-  const int drow = lane >> 4, dcp = lane & 15;                // DMA / coalesced-store role of this lane: row 4 i + drow, chunk slot dcp
-  for (int tile = blockIdx.x * 8 + wave; tile < ntile; tile += gridDim.x * 8) {
-    const int p0 = tile * 32;
-    const int px = min(p0 + l31, a.P - 1);
-    bf16x8 m2f[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) m2f[ks] = *(const bf16x8*)(a.m2 + (long)px * MID + 16 * ks + 8 * half);
-    f32x16 m1acc[2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) m1acc[rt][r] = 0.f;
-#pragma unroll 1
-    for (int hf = 0; hf < 2; ++hf) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // LDS reads of the previous pass are done before the DMA overwrites
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = 4 * i + drow;
-        const unsigned short* src = a.x + (long)min(p0 + row, a.P - 1) * COUT + hf * 128 + ((dcp ^ (row & 15)) << 3);
-        __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(stage + i * 1024), 16, 0, 0);
-      }
-      f32x16 acc[4];
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 bv = *(const float4*)(a.b3 + hf * 128 + ct * 32 + 8 * g + 4 * half);
-          acc[ct][4 * g] = bv.x; acc[ct][4 * g + 1] = bv.y; acc[ct][4 * g + 2] = bv.z; acc[ct][4 * g + 3] = bv.w;
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&sW3[((hf * 4 + ct) * 4 + ks) * 64 + lane], m2f[ks], acc[ct], 0, 0, 0);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // shortcut slice landed (LDS-direct loads count in vmcnt)
-      // shortcut + ReLU, in place; the packed values are also phase B's operand
-      uint2 pk[4][4];
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          uint2* sp = (uint2*)(stage + l31 * 256 + (((ct * 4 + g) ^ (l31 & 15)) << 4) + 8 * half);
-          const uint2 xv = *sp;
-          const float v0 = fmaxf(acc[ct][4 * g + 0] + bf2f(xv.x & 0xffff), 0.f), v1 = fmaxf(acc[ct][4 * g + 1] + bf2f(xv.x >> 16), 0.f);
-          const float v2 = fmaxf(acc[ct][4 * g + 2] + bf2f(xv.y & 0xffff), 0.f), v3 = fmaxf(acc[ct][4 * g + 3] + bf2f(xv.y >> 16), 0.f);
-          pk[ct][g] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-          *sp = pk[ct][g];
-        }
-      // phase B: k-step (hf, ct, j) <-> accumulator registers 8 j .. 8 j + 7 of tile ct
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          bf16x8 xf;
-          *(uint2*)&xf = pk[ct][2 * j];
-          *((uint2*)&xf + 1) = pk[ct][2 * j + 1];
-          const int ksg = hf * 8 + ct * 2 + j;
-#pragma unroll
-          for (int rt = 0; rt < 2; ++rt)
-            m1acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&sW1[(rt * 16 + ksg) * 64 + lane], xf, m1acc[rt], 0, 0, 0);
-        }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own LDS writes are visible to its reads
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = 4 * i + drow;
-        const uint4 v = *(const uint4*)(stage + i * 1024 + lane * 16);
-        if (p0 + row < a.P) *(uint4*)(a.xn + (long)(p0 + row) * COUT + hf * 128 + ((dcp ^ (row & 15)) << 3)) = v;
-      }
-    }
-    // mid1' = relu(. + b1): [32 px][128 B] through the first 4 KiB of the stage (chunk c of row r at c ^ (r & 7))
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int ch = rt * 32 + 8 * g + 4 * half;
-        const float4 bv = *(const float4*)(a.b1 + ch);
-        const float v0 = fmaxf(m1acc[rt][4 * g + 0] + bv.x, 0.f), v1 = fmaxf(m1acc[rt][4 * g + 1] + bv.y, 0.f);
-        const float v2 = fmaxf(m1acc[rt][4 * g + 2] + bv.z, 0.f), v3 = fmaxf(m1acc[rt][4 * g + 3] + bv.w, 0.f);
-        *(uint2*)(stage + l31 * 128 + ((((ch >> 3)) ^ (l31 & 7)) << 4) + 8 * half) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = 8 * i + (lane >> 3), cp = lane & 7;
-      const uint4 v = *(const uint4*)(stage + i * 1024 + lane * 16);
-      if (p0 + row < a.P) *(uint4*)(a.m1 + (long)(p0 + row) * MID + ((cp ^ (row & 7)) << 3)) = v;
-    }
-  }
-}
-
-
-// MID = 128 (res3): the weights (2 x 128 KiB) do not fit LDS, so the workgroup walks the 128-output-channel passes in
-// lock step and re-loads the pass's W3 / W1' slices (32 KiB each, LDS-direct) between two barriers; every wavefront keeps
-// one 32-pixel tile (mid2 fragments + the mid1' accumulators) across the passes.  The exposed weight load (~2 us per pass)
-// is inside the HBM time of the tile (655 KB per 256 pixels), weights come from L2 (256 KiB per 256-pixel tile set).
-template <int MID>
-__global__ __launch_bounds__(512) void bottleneck_chain_stream_kernel(ChainArgs a) {
-  constexpr int COUT = 4 * MID, KS = MID / 16, RT = MID / 32, NP = COUT / 128;
-  constexpr int W3B = 4 * KS * 1024, W1B = RT * 8 * 1024;     // bytes per pass
-  constexpr int MROW = MID * 2, MCH = MID / 8;                 // mid1' staging: bytes per pixel row, 16-byte chunks per row
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint4* sW3 = (const uint4*)smem;                       // [4 ct][KS][64 lanes]
-  const uint4* sW1 = (const uint4*)(smem + W3B);               // [RT][8 k-steps of this pass][64 lanes]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  unsigned char* stage = smem + W3B + W1B + wave * 8192;
-  const int ntile = (a.P + 31) / 32, nset = (ntile + 7) / 8;
-  const int drow = lane >> 4, dcp = lane & 15;
-  for (int set = blockIdx.x; set < nset; set += gridDim.x) {
-    const int p0 = (set * 8 + wave) * 32;                      // >= P for the idle waves of the last set: loads clamp, stores are masked
+  unsigned char* stage = smem + WBYTES + wave * 8192;          // 2 x [32 px][128 B], chunk c of row r at c ^ ((r >> 1) & 7)
+  float* sB3 = (float*)(smem + WBYTES + 65536);                // [COUT]
+  float* sB1 = sB3 + COUT;                                     // [MID]
+  for (int i = tid; i < COUT; i += 512) sB3[i] = a.b3[i];
+  for (int i = tid; i < MID; i += 512) sB1[i] = a.b1[i];
+  if constexpr (!STREAM) {                                      // resident layout: pass-major, [pass][W3 slice | W1' slice]
+    for (int i = tid; i < NP * (W3P + W1P) / 16; i += 512) {
+      const int p = i / ((W3P + W1P) / 16), r = i % ((W3P + W1P) / 16);
+      uint4 v;
+      if (r < W3P / 16) v = a.w3f[(long)p * (W3P / 16) + r];
+      else { const int q = (r - W3P / 16) >> 6, rt = q >> 2, kk = q & 3; v = a.w1f[((long)rt * (COUT / 16) + p * 4 + kk) * 64 + (r & 63)]; }
+      ((uint4*)smem)[i] = v;
+    }
+  }
+  __syncthreads();
+  const int ntile = (a.P + 31) / 32;
+  const int drow = lane >> 3, dslot = lane & 7;                // DMA / coalesced-store role: row 8 i + drow, chunk slot dslot
+  auto wslot = [&](int p) -> const unsigned char* { return smem + (STREAM ? (p & 1) : p) * (W3P + W1P); };
+  // loads of (tile base pixel p0, pass p): shortcut slice into stage buffer p & 1, and (STREAM) this wave's share of the weights
+  auto issue = [&](int p0, int p) {
+    unsigned char* sb = stage + (p & 1) * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 8 * i + drow;
+      const unsigned short* src = a.x + (long)min(p0 + row, a.P - 1) * COUT + p * 64 + ((dslot ^ ((row >> 1) & 7)) << 3);
+      __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(sb + i * 1024), 16, 0, 0);
+    }
+    if constexpr (STREAM) {
+      unsigned char* wb = smem + (p & 1) * (W3P + W1P);
+#pragma unroll
+      for (int i = 0; i < (2 * KS + 4 * RT) / 8; ++i) {
+        const int q = wave + 8 * i;
+        if (q < 2 * KS) {
+          __builtin_amdgcn_global_load_lds((gas_ptr)(a.w3f + ((long)(p * 2 * KS + q) * 64 + lane)), (las_ptr)(wb + q * 1024), 16, 0, 0);
+        } else {
+          const int q1 = q - 2 * KS, rt = q1 >> 2, kk = q1 & 3;
+          __builtin_amdgcn_global_load_lds((gas_ptr)(a.w1f + ((long)(rt * (COUT / 16) + p * 4 + kk) * 64 + lane)), (las_ptr)(wb + W3P + q1 * 1024), 16, 0, 0);
+        }
+      }
+    }
+  };
+  // stores of a finished 32 px x 64 channel slice of x_next from stage buffer b
+  auto flush = [&](int p0, int p) {
+    const unsigned char* sb = stage + (p & 1) * 4096 + lane * 16;
+    const uint4 v0 = *(const uint4*)sb, v1 = *(const uint4*)(sb + 1024), v2 = *(const uint4*)(sb + 2048), v3 = *(const uint4*)(sb + 3072);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    auto put = [&](int i, const uint4& v) {
+      const int row = 8 * i + drow;
+      if (p0 + row < a.P) *(uint4*)(a.xn + (long)(p0 + row) * COUT + p * 64 + ((dslot ^ ((row >> 1) & 7)) << 3)) = v;
+    };
+    put(0, v0); put(1, v1); put(2, v2); put(3, v3);
+  };
+
+  // tile sequence of this wavefront: independent tiles (resident) or lock-step sets of 8 tiles (streaming)
+  const int t_first = STREAM ? blockIdx.x * 8 + wave : blockIdx.x * 8 + wave;
+  const int t_step = gridDim.x * 8;
+  const int n_iter = STREAM ? ((ntile + 7) / 8 - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x
+                            : (ntile - t_first + t_step - 1) / t_step;      // (streaming: idle waves of the last set still take part)
+  if (n_iter <= 0) return;
+  issue(t_first * 32, 0);
+  for (int it = 0; it < n_iter; ++it) {
+    const int p0 = (t_first + it * t_step) * 32;               // >= P for idle waves: loads clamp, stores are masked
     const int px = min(p0 + l31, a.P - 1);
     bf16x8 m2f[KS];
 #pragma unroll
@@ -175,47 +129,32 @@ __global__ __launch_bounds__(512) void bottleneck_chain_stream_kernel(ChainArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) m1acc[rt][r] = 0.f;
 #pragma unroll 1
-    for (int hf = 0; hf < NP; ++hf) {
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the previous pass's weights / its stage
+    for (int p = 0; p < NP; ++p) {
+      if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // pass p landed everywhere; everyone left pass p-1
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (p > 0) flush(p0, p - 1);
+      if (p + 1 < NP) issue(p0, p + 1);
+      else if (it + 1 < n_iter) issue(p0 + t_step * 32, 0);
+      const uint4* w3 = (const uint4*)wslot(p);
+      const uint4* w1 = (const uint4*)(wslot(p) + W3P);
+      unsigned char* sb = stage + (p & 1) * 4096;
 #pragma unroll
-      for (int i = 0; i < (4 * KS + 7) / 8; ++i) {
-        const int q = wave + 8 * i;
-        if (q < 4 * KS) __builtin_amdgcn_global_load_lds((gas_ptr)(a.w3f + ((long)(hf * 4 * KS + q) * 64 + lane)), (las_ptr)(smem + q * 1024), 16, 0, 0);
-      }
+      for (int ct = 0; ct < 2; ++ct) {
+        f32x16 acc;
 #pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        const int q = wave + 8 * i, rt = q >> 3, kk = q & 7;
-        __builtin_amdgcn_global_load_lds((gas_ptr)(a.w1f + ((long)(rt * (COUT / 16) + hf * 8 + kk) * 64 + lane)), (las_ptr)(smem + W3B + q * 1024), 16, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = 4 * i + drow;
-        const unsigned short* src = a.x + (long)min(p0 + row, a.P - 1) * COUT + hf * 128 + ((dcp ^ (row & 15)) << 3);
-        __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(stage + i * 1024), 16, 0, 0);
-      }
-      f32x16 acc[4];
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // weights of this pass (all waves' parts) and the shortcut slice landed
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&sW3[(ct * KS + ks) * 64 + lane], m2f[ks], acc[ct], 0, 0, 0);
-      // per 32-channel tile: shortcut + ReLU in place, then straight into the second product (the packed values of one tile
-      // are the only live copy: register budget)
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&w3[(ct * KS + ks) * 64 + lane], m2f[ks], acc, 0, 0, 0);
+        // bias + shortcut + ReLU in place; the packed values feed the second product directly
         uint2 pk[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          uint2* sp = (uint2*)(stage + l31 * 256 + (((ct * 4 + g) ^ (l31 & 15)) << 4) + 8 * half);
+          uint2* sp = (uint2*)(sb + l31 * 128 + (((ct * 4 + g) ^ ((l31 >> 1) & 7)) << 4) + 8 * half);
           const uint2 xv = *sp;
-          const float4 bv = *(const float4*)(a.b3 + hf * 128 + ct * 32 + 8 * g + 4 * half);
-          const float v0 = fmaxf(acc[ct][4 * g + 0] + bv.x + bf2f(xv.x & 0xffff), 0.f), v1 = fmaxf(acc[ct][4 * g + 1] + bv.y + bf2f(xv.x >> 16), 0.f);
-          const float v2 = fmaxf(acc[ct][4 * g + 2] + bv.z + bf2f(xv.y & 0xffff), 0.f), v3 = fmaxf(acc[ct][4 * g + 3] + bv.w + bf2f(xv.y >> 16), 0.f);
+          const float4 bv = *(const float4*)(sB3 + p * 64 + ct * 32 + 8 * g + 4 * half);
+          const float v0 = fmaxf(acc[4 * g + 0] + bv.x + bf2f(xv.x & 0xffff), 0.f), v1 = fmaxf(acc[4 * g + 1] + bv.y + bf2f(xv.x >> 16), 0.f);
+          const float v2 = fmaxf(acc[4 * g + 2] + bv.z + bf2f(xv.y & 0xffff), 0.f), v3 = fmaxf(acc[4 * g + 3] + bv.w + bf2f(xv.y >> 16), 0.f);
           pk[g] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
           *sp = pk[g];
         }
@@ -226,39 +165,38 @@ __global__ __launch_bounds__(512) void bottleneck_chain_stream_kernel(ChainArgs 
           *((uint2*)&xf + 1) = pk[2 * j + 1];
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
-            m1acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&sW1[(rt * 8 + ct * 2 + j) * 64 + lane], xf, m1acc[rt], 0, 0, 0);
+            m1acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&w1[(rt * 4 + ct * 2 + j) * 64 + lane], xf, m1acc[rt], 0, 0, 0);
         }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slice is complete in LDS (same-wave readers only)
+      __builtin_amdgcn_wave_barrier();
+    }
+    flush(p0, NP - 1);
+    // mid1' = relu(. + b1), 64 channels at a time through the buffer that was just flushed (the other one is receiving
+    // the next tile's first slice)
+    unsigned char* sb = stage + ((NP - 1) & 1) * 4096;
+#pragma unroll
+    for (int hc = 0; hc < RT / 2; ++hc) {
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int rt = 2 * hc + r2;
+          const float4 bv = *(const float4*)(sB1 + rt * 32 + 8 * g + 4 * half);
+          const float v0 = fmaxf(m1acc[rt][4 * g + 0] + bv.x, 0.f), v1 = fmaxf(m1acc[rt][4 * g + 1] + bv.y, 0.f);
+          const float v2 = fmaxf(m1acc[rt][4 * g + 2] + bv.z, 0.f), v3 = fmaxf(m1acc[rt][4 * g + 3] + bv.w, 0.f);
+          *(uint2*)(sb + l31 * 128 + (((r2 * 4 + g) ^ ((l31 >> 1) & 7)) << 4) + 8 * half) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+        }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = 4 * i + drow;
-        const uint4 v = *(const uint4*)(stage + i * 1024 + lane * 16);
-        if (p0 + row < a.P) *(uint4*)(a.xn + (long)(p0 + row) * COUT + hf * 128 + ((dcp ^ (row & 15)) << 3)) = v;
-      }
-    }
-    // mid1' = relu(. + b1): [32 px][MID] through the wave's stage (chunk c of row r at c ^ (r & (MCH - 1)))
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int ch = rt * 32 + 8 * g + 4 * half;
-        const float4 bv = *(const float4*)(a.b1 + ch);
-        const float v0 = fmaxf(m1acc[rt][4 * g + 0] + bv.x, 0.f), v1 = fmaxf(m1acc[rt][4 * g + 1] + bv.y, 0.f);
-        const float v2 = fmaxf(m1acc[rt][4 * g + 2] + bv.z, 0.f), v3 = fmaxf(m1acc[rt][4 * g + 3] + bv.w, 0.f);
-        *(uint2*)(stage + l31 * MROW + (((ch >> 3) ^ (l31 & (MCH - 1))) << 4) + 8 * half) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    constexpr int RPI = 1024 / MROW;                           // pixel rows per 1 KiB store instruction
-#pragma unroll
-    for (int i = 0; i < 32 / RPI; ++i) {
-      const int row = RPI * i + lane / MCH, cp = lane % MCH;
-      const uint4 v = *(const uint4*)(stage + i * 1024 + lane * 16);
-      if (p0 + row < a.P) *(uint4*)(a.m1 + (long)(p0 + row) * MID + ((cp ^ (row & (MCH - 1))) << 3)) = v;
+      const unsigned char* sl = sb + lane * 16;
+      const uint4 v0 = *(const uint4*)sl, v1 = *(const uint4*)(sl + 1024), v2 = *(const uint4*)(sl + 2048), v3 = *(const uint4*)(sl + 3072);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      auto put = [&](int i, const uint4& v) {
+        const int row = 8 * i + drow;
+        if (p0 + row < a.P) *(uint4*)(a.m1 + (long)(p0 + row) * MID + hc * 64 + ((dslot ^ ((row >> 1) & 7)) << 3)) = v;
+      };
+      put(0, v0); put(1, v1); put(2, v2); put(3, v3);
     }
   }
 }
@@ -281,14 +219,15 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
   a.b3 = b3; a.b1 = b1; a.xn = (unsigned short*)x_next; a.m1 = (unsigned short*)mid1_next; a.P = (int)P;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)bottleneck_chain64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)bottleneck_chain_stream_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)bottleneck_chain_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)bottleneck_chain_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const long ntile = (P + 31) / 32;
   const unsigned grid = (unsigned)(ntile < 8 * 256 ? (ntile + 7) / 8 : 256);     // persistent: one workgroup per CU
-  if (mid == 64) bottleneck_chain64_kernel<<<grid, 512, 65536 + 8 * 8192, (hipStream_t)stream>>>(a);
-  else bottleneck_chain_stream_kernel<128><<<grid, 512, 65536 + 8 * 8192, (hipStream_t)stream>>>(a);
+  const size_t lds = 65536 /* weights: resident (mid 64) or two ring slots (mid 128) */ + 65536 /* 8 x 2 stage buffers */ + (size_t)5 * mid * 4;
+  if (mid == 64) bottleneck_chain_kernel<64, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);
+  else bottleneck_chain_kernel<128, true><<<grid, 512, lds, (hipStream_t)stream>>>(a);
   return check_launch("relnet_bottleneck_chain");
 }
 

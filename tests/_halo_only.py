@@ -31,3 +31,15 @@ def timeit(fn, name):
 timeit(lambda: ops.conv3x3_c64(x, wf, b), 'halo 3x3')
 if True:
     timeit(lambda: ops.conv2d_nhwc(x, wp, b, ksize=3, pad=1, relu=True), 'implicit gemm')
+for mid, (H, W) in ((64, (150, 250)), (128, (75, 125))):
+    m2 = torch.relu(torch.randn(B, H, W, mid, device='cuda')).to(bf)
+    xx = torch.relu(torch.randn(B, H, W, 4 * mid, device='cuda')).to(bf)
+    w3 = (torch.randn(4 * mid, mid, device='cuda') * 0.1).to(bf); w1 = (torch.randn(mid, 4 * mid, device='cuda') * 0.05).to(bf)
+    b3 = torch.randn(4 * mid, device='cuda') * 0.1; b1 = torch.randn(mid, device='cuda') * 0.1
+    w3f, w1f = ops.pack_w_frag(w3), ops.pack_chain_w1(w1)
+    gb = m2.numel() * 2 * 2 * 5 / 1e9
+    timeit(lambda: ops.bottleneck_chain(m2, xx, w3f, w1f, b3, b1), 'chain mid=%d (%.2f GB)' % (mid, gb))
+    def two():
+        xn = ops.conv2d_nhwc(m2, w3, b3, relu=True, resid=xx)
+        return ops.conv2d_nhwc(xn, w1, b1, relu=True)
+    timeit(two, 'two launches mid=%d' % mid)
