@@ -99,6 +99,8 @@ class Executor(object):
         self.cache = {}                 # per-node packed weights etc.
         self.override = {}              # id(node) -> (deps [(node, i)], fn(values...) -> outputs)
         self.fused_report = {'conv_chains': 0, 'attention_modules': 0, 'probe': []}
+        self.conv_chain = {}            # id(last node of a fused conv chain) -> (conv, bn, relu, resid, last)
+        self._parked = {}               # reduce outputs produced early by a block-boundary launch
         if fuse:
             if dtype == torch.bfloat16:
                 self._fuse_conv_chains()
@@ -155,7 +157,51 @@ class Executor(object):
                 continue
             deps = [node.inputs[0]] + ([resid] if resid is not None else [])
             self.override[id(last)] = (deps, self._conv_runner(node, bn, relu, resid is not None, last))
+            self.conv_chain[id(last)] = (node, bn, relu, resid, last)
             self.fused_report['conv_chains'] += 1
+        self._fuse_block_boundaries()
+
+    def _fuse_block_boundaries(self):
+        """expand (1x1, 4 mid outputs, + shortcut + ReLU) followed by the next unit's reduce (1x1 -> mid, + ReLU), mid in
+        ops.CHAIN_MIDS: both run as ONE relnet_bottleneck_chain launch.  The expand node's runner computes both tensors and
+        parks the reduce output for the reduce node, which is evaluated later in topological order."""
+        is1x1 = lambda n: (a_tuple(n.attrs, 'kernel') == (1, 1) and a_tuple(n.attrs, 'stride', (1, 1)) == (1, 1)
+                           and a_tuple(n.attrs, 'pad', (0, 0)) == (0, 0))
+        for lid, (node, bn, relu, resid, last) in list(self.conv_chain.items()):
+            nf = a_int(node.attrs, 'num_filter')
+            if resid is None or not relu or not is1x1(node) or nf % 4 or (nf // 4) not in K.CHAIN_MIDS or self._wants_fp32(last):
+                continue
+            mid = nf // 4
+            nxt = [c for c in self.consumers.get((id(last), 0), []) if c.op == 'Convolution' and c.inputs[0][0] is last]
+            nxt = [c for c in nxt if is1x1(c) and a_int(c.attrs, 'num_filter') == mid and a_int(c.attrs, 'num_group', 1) == 1]
+            if len(nxt) != 1:
+                continue
+            rc = [v for v in self.conv_chain.values() if v[0] is nxt[0]]
+            if not rc or rc[0][3] is not None or not rc[0][2] or self._wants_fp32(rc[0][4]):
+                continue
+            rnode, rbn, _, _, rlast = rc[0]
+            wshape = lambda n: self._var(n.inputs[OPS['Convolution'].inputs_for(n.attrs).index('weight')][0].name).shape
+            if wshape(node)[1] != mid or wshape(rnode)[1] != nf:
+                continue
+            self.override[lid] = (self.override[lid][0], self._chain_runner(node, bn, rnode, rbn, id(rlast)))
+            plain = self.override[id(rlast)][1]
+            self.override[id(rlast)] = (self.override[id(rlast)][0] + [(last, 0)],
+                                        lambda x, xn_dep, plain=plain, key=id(rlast): self._parked.pop(key) if key in self._parked else plain(x))
+            self.fused_report['block_boundaries'] = self.fused_report.get('block_boundaries', 0) + 1
+
+    def _chain_runner(self, node, bn, rnode, rbn, rkey):
+        def run(x, resid):
+            key = ('chain', id(node))
+            if key not in self.cache:
+                w3, b3 = self._conv_weights(node, bn)
+                w1, b1 = self._conv_weights(rnode, rbn)
+                self.cache[key] = (K.pack_w_frag(K.pack_conv_weight(w3, torch.bfloat16, self.device)),
+                                   K.pack_chain_w1(K.pack_conv_weight(w1, torch.bfloat16, self.device)), b3, b1)
+            nhwc = lambda t: t.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+            xn, m1 = K.bottleneck_chain(nhwc(x), nhwc(resid), *self.cache[key])
+            self._parked[rkey] = m1.permute(0, 3, 1, 2)
+            return xn.permute(0, 3, 1, 2)
+        return run
 
     def _depends_on(self, a, b):
         seen, stack = set(), [a]
@@ -214,6 +260,11 @@ class Executor(object):
         if xn.dtype != torch.bfloat16 or not xn.is_contiguous():
             xn = xn.to(torch.bfloat16).contiguous()
         odt = torch.float32 if out32 else torch.bfloat16
+        if k == (3, 3) and s == (1, 1) and d == (1, 1) and p == (1, 1) and cin == 64 and w.shape[0] == 64 and resid is None and not out32:
+            fkey = ('halo3', id(node))                    # 64-channel 3x3 (res2*_branch2b): halo-resident kernel, same bits
+            if fkey not in self.cache:
+                self.cache[fkey] = K.pack_w_frag(self.cache[key], panel_only=False)
+            return K.conv3x3_c64(xn, self.cache[fkey], b, relu=relu).permute(0, 3, 1, 2)
         rn = None
         if resid is not None:
             rn = resid.permute(0, 2, 3, 1)
