@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+python -m pytest tests -m gpu -q 2>&1 | tail -4
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py 2>/dev/null | tail -1 > gpurun_out/bench_final.json
