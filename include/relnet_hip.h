@@ -145,7 +145,8 @@ int relnet_relation_attention_fused(const void* q, long q_ld, long q_bs, const v
  *   x_next = relu(W3 . mid2 + b3 + x),  mid1_next = relu(W1n . x_next + b1n)        (BN folded into W / b)
  * mid2 [P][mid], x / x_next [P][4 mid], mid1_next [P][mid] bf16, dense pixel rows.  w3f = relnet_pack_w_frag(W3 [4 mid][mid]);
  * w1f = W1n [mid][4 mid] in the accumulator-permuted fragment order: block (rt, ks) = 64 lanes x 8 values, lane (l31, half)
- * slot t <- W1n[32 rt + l31][16 ks + 8 (t >> 2) + 4 half + (t & 3)].  mid = 64 (res2) or 128 (res3).                     */
+ * slot t <- W1n[32 rt + l31][16 ks + 8 (t >> 2) + 4 half + (t & 3)].  mid = 64 (res2) or 128 (res3).  w1f = b1 = mid1_next =
+ * NULL: only x_next (last unit of a stage).                                                                          */
 int relnet_bottleneck_chain(const void* mid2, const void* x, const void* w3f, const void* w1f, const float* b3,
                             const float* b1, void* x_next, void* mid1_next, long P, int mid, void* stream);
 

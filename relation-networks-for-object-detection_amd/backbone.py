@@ -172,6 +172,9 @@ class Backbone(object):
                     w3, b3, _ = self.wp['res%s_branch2c' % nm]
                     w1n, b1n, _ = self.wp['res%s_branch2a' % nxt[1]]
                     self.chain[nm] = (ops.pack_w_frag(w3), ops.pack_chain_w1(w1n), b3, b1n)
+                elif mc in ops.CHAIN_MIDS:       # last unit of the stage: the same kernel without the second product
+                    w3, b3, _ = self.wp['res%s_branch2c' % nm]
+                    self.chain[nm] = (ops.pack_w_frag(w3), None, b3, None)
             # 64-channel 3x3 convolutions (res2*_branch2b): halo tile resident in LDS instead of one LDS fill per tap
             for st, nm, ic, mc, oc, stride, dil, proj in self.units:
                 if mc == 64 and dil == 1:

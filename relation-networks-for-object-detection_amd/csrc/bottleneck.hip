@@ -48,10 +48,10 @@ struct ChainArgs {
 // share vmcnt and complete out of order with respect to each other, hence the single vmcnt(0) at the top of a pass.
 // Nothing on the vector-memory path is issued inside the arithmetic (biases come from LDS): a load there would make the
 // compiler wait for the prefetch in front of it.
-template <int MID, bool STREAM>
+template <int MID, bool STREAM, bool REDUCE = true>       // REDUCE = false: only x_next (last unit of a stage: no next reduce)
 __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
   constexpr int COUT = 4 * MID, KS = MID / 16, RT = MID / 32, NP = COUT / 64;
-  constexpr int W3P = 2 * KS * 1024, W1P = 4 * RT * 1024;     // bytes of one pass's W3 / W1' slice
+  constexpr int W3P = 2 * KS * 1024, W1P = REDUCE ? 4 * RT * 1024 : 0;     // bytes of one pass's W3 / W1' slice
   constexpr int WBYTES = STREAM ? 2 * (W3P + W1P) : NP * (W3P + W1P);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -61,12 +61,12 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
   float* sB3 = (float*)(smem + WBYTES + 65536);                // [COUT]
   float* sB1 = sB3 + COUT;                                     // [MID]
   for (int i = tid; i < COUT; i += 512) sB3[i] = a.b3[i];
-  for (int i = tid; i < MID; i += 512) sB1[i] = a.b1[i];
+  if constexpr (REDUCE) for (int i = tid; i < MID; i += 512) sB1[i] = a.b1[i];
   if constexpr (!STREAM) {                                      // resident layout: pass-major, [pass][W3 slice | W1' slice]
     for (int i = tid; i < NP * (W3P + W1P) / 16; i += 512) {
       const int p = i / ((W3P + W1P) / 16), r = i % ((W3P + W1P) / 16);
       uint4 v;
-      if (r < W3P / 16) v = a.w3f[(long)p * (W3P / 16) + r];
+      if (r < W3P / 16 || !REDUCE) v = a.w3f[(long)p * (W3P / 16) + r];
       else { const int q = (r - W3P / 16) >> 6, rt = q >> 2, kk = q & 3; v = a.w1f[((long)rt * (COUT / 16) + p * 4 + kk) * 64 + (r & 63)]; }
       ((uint4*)smem)[i] = v;
     }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
     if constexpr (STREAM) {
       unsigned char* wb = smem + (p & 1) * (W3P + W1P);
 #pragma unroll
-      for (int i = 0; i < (2 * KS + 4 * RT) / 8; ++i) {
+      for (int i = 0; i < (2 * KS + (REDUCE ? 4 * RT : 0)) / 8; ++i) {
         const int q = wave + 8 * i;
         if (q < 2 * KS) {
           __builtin_amdgcn_global_load_lds((gas_ptr)(a.w3f + ((long)(p * 2 * KS + q) * 64 + lane)), (las_ptr)(wb + q * 1024), 16, 0, 0);
@@ -158,20 +158,23 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
           pk[g] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
           *sp = pk[g];
         }
+        if constexpr (REDUCE) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          bf16x8 xf;
-          *(uint2*)&xf = pk[2 * j];
-          *((uint2*)&xf + 1) = pk[2 * j + 1];
+          for (int j = 0; j < 2; ++j) {
+            bf16x8 xf;
+            *(uint2*)&xf = pk[2 * j];
+            *((uint2*)&xf + 1) = pk[2 * j + 1];
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-            m1acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&w1[(rt * 4 + ct * 2 + j) * 64 + lane], xf, m1acc[rt], 0, 0, 0);
+            for (int rt = 0; rt < RT; ++rt)
+              m1acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&w1[(rt * 4 + ct * 2 + j) * 64 + lane], xf, m1acc[rt], 0, 0, 0);
+          }
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slice is complete in LDS (same-wave readers only)
       __builtin_amdgcn_wave_barrier();
     }
     flush(p0, NP - 1);
+    if constexpr (!REDUCE) continue;
     // mid1' = relu(. + b1), 64 channels at a time through the buffer that was just flushed (the other one is receiving
     // the next tile's first slice)
     unsigned char* sb = stage + ((NP - 1) & 1) * 4096;
@@ -211,7 +214,8 @@ using namespace relnet;
 // (resnet_v1_101_rcnn_base.py: res<s><u>_branch2c + shortcut + relu, res<s><u+1>_branch2a + relu).
 extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const void* w3f, const void* w1f, const float* b3,
                                        const float* b1, void* x_next, void* mid1_next, long P, int mid, void* stream) {
-  RELNET_REQUIRE(mid2 && x && w3f && w1f && b3 && b1 && x_next && mid1_next, "relnet_bottleneck_chain: null operand");
+  RELNET_REQUIRE(mid2 && x && w3f && b3 && x_next, "relnet_bottleneck_chain: null operand");
+  RELNET_REQUIRE((w1f && b1 && mid1_next) || (!w1f && !b1 && !mid1_next), "relnet_bottleneck_chain: w1f, b1 and mid1_next are given together (or all NULL: expand + shortcut + ReLU only)");
   RELNET_REQUIRE(mid == 64 || mid == 128, "relnet_bottleneck_chain: mid = %d unsupported (64, 128)", mid);
   RELNET_REQUIRE(P > 0 && P < (1L << 31), "relnet_bottleneck_chain: bad pixel count %ld", P);
   ChainArgs a;
@@ -221,13 +225,20 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
   if (!attr_set) {
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)bottleneck_chain_kernel<64, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)bottleneck_chain_kernel<128, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const long ntile = (P + 31) / 32;
   const unsigned grid = (unsigned)(ntile < 8 * 256 ? (ntile + 7) / 8 : 256);     // persistent: one workgroup per CU
   const size_t lds = 65536 /* weights: resident (mid 64) or two ring slots (mid 128) */ + 65536 /* 8 x 2 stage buffers */ + (size_t)5 * mid * 4;
-  if (mid == 64) bottleneck_chain_kernel<64, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);
-  else bottleneck_chain_kernel<128, true><<<grid, 512, lds, (hipStream_t)stream>>>(a);
+  if (mid1_next) {
+    if (mid == 64) bottleneck_chain_kernel<64, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);
+    else bottleneck_chain_kernel<128, true><<<grid, 512, lds, (hipStream_t)stream>>>(a);
+  } else {
+    if (mid == 64) bottleneck_chain_kernel<64, false, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);
+    else bottleneck_chain_kernel<128, true, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);
+  }
   return check_launch("relnet_bottleneck_chain");
 }
 

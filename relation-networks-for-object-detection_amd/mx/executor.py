@@ -172,17 +172,18 @@ class Executor(object):
             if resid is None or not relu or not is1x1(node) or nf % 4 or (nf // 4) not in K.CHAIN_MIDS or self._wants_fp32(last):
                 continue
             mid = nf // 4
+            wshape = lambda n: self._var(n.inputs[OPS['Convolution'].inputs_for(n.attrs).index('weight')][0].name).shape
+            if wshape(node)[1] != mid:
+                continue
             nxt = [c for c in self.consumers.get((id(last), 0), []) if c.op == 'Convolution' and c.inputs[0][0] is last]
             nxt = [c for c in nxt if is1x1(c) and a_int(c.attrs, 'num_filter') == mid and a_int(c.attrs, 'num_group', 1) == 1]
-            if len(nxt) != 1:
-                continue
-            rc = [v for v in self.conv_chain.values() if v[0] is nxt[0]]
-            if not rc or rc[0][3] is not None or not rc[0][2] or self._wants_fp32(rc[0][4]):
+            rc = [v for v in self.conv_chain.values() if len(nxt) == 1 and v[0] is nxt[0]]
+            if not rc or rc[0][3] is not None or not rc[0][2] or self._wants_fp32(rc[0][4]) or wshape(rc[0][0])[1] != nf:
+                # last unit of a stage (or a consumer the kernel does not cover): expand + shortcut + ReLU only
+                self.override[lid] = (self.override[lid][0], self._chain_runner(node, bn, None, None, None))
+                self.fused_report['block_boundaries'] = self.fused_report.get('block_boundaries', 0) + 1
                 continue
             rnode, rbn, _, _, rlast = rc[0]
-            wshape = lambda n: self._var(n.inputs[OPS['Convolution'].inputs_for(n.attrs).index('weight')][0].name).shape
-            if wshape(node)[1] != mid or wshape(rnode)[1] != nf:
-                continue
             self.override[lid] = (self.override[lid][0], self._chain_runner(node, bn, rnode, rbn, id(rlast)))
             plain = self.override[id(rlast)][1]
             self.override[id(rlast)] = (self.override[id(rlast)][0] + [(last, 0)],
@@ -194,12 +195,16 @@ class Executor(object):
             key = ('chain', id(node))
             if key not in self.cache:
                 w3, b3 = self._conv_weights(node, bn)
-                w1, b1 = self._conv_weights(rnode, rbn)
-                self.cache[key] = (K.pack_w_frag(K.pack_conv_weight(w3, torch.bfloat16, self.device)),
-                                   K.pack_chain_w1(K.pack_conv_weight(w1, torch.bfloat16, self.device)), b3, b1)
+                w3f = K.pack_w_frag(K.pack_conv_weight(w3, torch.bfloat16, self.device))
+                if rnode is None:
+                    self.cache[key] = (w3f, None, b3, None)
+                else:
+                    w1, b1 = self._conv_weights(rnode, rbn)
+                    self.cache[key] = (w3f, K.pack_chain_w1(K.pack_conv_weight(w1, torch.bfloat16, self.device)), b3, b1)
             nhwc = lambda t: t.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
             xn, m1 = K.bottleneck_chain(nhwc(x), nhwc(resid), *self.cache[key])
-            self._parked[rkey] = m1.permute(0, 3, 1, 2)
+            if m1 is not None:
+                self._parked[rkey] = m1.permute(0, 3, 1, 2)
             return xn.permute(0, 3, 1, 2)
         return run
 

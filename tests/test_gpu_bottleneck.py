@@ -25,6 +25,8 @@ def test_bottleneck_chain_vs_two_convolutions(shape, mid):
     b3 = (torch.randn(cout, generator=g) * 0.1).cuda()
     b1 = (torch.randn(mid, generator=g) * 0.1).cuda()
     xn, m1 = ops.bottleneck_chain(m2, x, ops.pack_w_frag(w3), ops.pack_chain_w1(w1), b3, b1)
+    xe, none = ops.bottleneck_chain(m2, x, ops.pack_w_frag(w3), None, b3, None)        # expand-only form: same x_next bits
+    assert none is None and torch.equal(xe, xn)
     # (a) the two launches of the unfused path
     xn_ref = ops.conv2d_nhwc(m2, w3, b3, relu=True, resid=x)
     m1_ref = ops.conv2d_nhwc(xn_ref, w1, b1, relu=True)
@@ -55,7 +57,7 @@ def test_backbone_with_and_without_chain_kernel():
     data = torch.randn(2, 3, 224, 320, generator=torch.Generator().manual_seed(1)).cuda() * 50
     a = backbone.Backbone(p, dtype=torch.bfloat16, chain=True)
     b = backbone.Backbone(p, dtype=torch.bfloat16, chain=False)
-    assert sorted(a.chain) == ['2a', '2b', '3a', '3b1', '3b2'] and not b.chain
+    assert sorted(a.chain) == ['2a', '2b', '2c', '3a', '3b1', '3b2', '3b3'] and a.chain['2c'][1] is None and not b.chain
     fa, fb = a.forward(data), b.forward(data)
     for k in ('conv4', 'conv5', 'rpn_cls_score', 'rpn_bbox_pred'):
         d = (fa[k].float() - fb[k].float()).abs().max().item()
