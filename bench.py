@@ -291,7 +291,12 @@ def main():
     else:
         det = detector.Detector(params, dtype=tdt, device='cuda', relation=not a.no_relation, cfg=cfg, stem=a.stem)
     if a.no_chain:
-        det.backbone.chain, det.backbone.halo3 = {}, {}
+        from relnet_amd import ops as _ops
+        bb = det.backbone
+        bb.chain, bb.halo3 = {}, {}
+        for name, (w, _, k) in bb.wp.items():          # res4 expand layers back on the row-panel kernel (the pre-fusion state)
+            if name.endswith('_branch2c') and k == 1 and w.shape[1] == 256 and w.shape[0] % 256 == 0:
+                bb.wf[name] = _ops.pack_w_frag(w)
     g = torch.Generator().manual_seed(1000 + rank)
     # unit-variance synthetic pixels: with random-init weights (no checkpoints offline) this gives
     # O(1) RPN logits/deltas, i.e. several hundred distinct proposals survive NMS per image; N(0,50)

@@ -126,6 +126,7 @@ class Backbone(object):
     def __init__(self, params, dtype=torch.bfloat16, device='cuda', channels_last=True, impl=None, stem='hip', dcn=False,
                  fpn=False, chain=True):
         self.dtype, self.device, self.dcn, self.fpn = dtype, device, dcn, fpn
+        self.use_chain = chain
         self.impl = impl or ('hip' if dtype == torch.bfloat16 else 'miopen')
         self.stem = stem
         assert self.impl in ('hip', 'miopen') and (self.impl == 'miopen' or dtype == torch.bfloat16)
@@ -172,7 +173,7 @@ class Backbone(object):
                     w3, b3, _ = self.wp['res%s_branch2c' % nm]
                     w1n, b1n, _ = self.wp['res%s_branch2a' % nxt[1]]
                     self.chain[nm] = (ops.pack_w_frag(w3), ops.pack_chain_w1(w1n), b3, b1n)
-                elif mc in ops.CHAIN_MIDS:       # last unit of the stage: the same kernel without the second product
+                elif mc in ops.CHAIN_EXPAND_MIDS:   # last unit of a stage, and every res4 unit: the kernel without the second product
                     w3, b3, _ = self.wp['res%s_branch2c' % nm]
                     self.chain[nm] = (ops.pack_w_frag(w3), None, b3, None)
             # 64-channel 3x3 convolutions (res2*_branch2b): halo tile resident in LDS instead of one LDS fill per tap
@@ -192,7 +193,7 @@ class Backbone(object):
             # 256-deep expand convolutions (res4 branch2c, 23 per step): a second copy of the weights in MFMA-fragment
             # order lets relnet_conv2d_nhwc_wf pick the panel kernel (A resident in LDS, W streamed through registers)
             if self.dtype == torch.bfloat16 and tuple(w.shape[1:]) == (256, 1, 1) and w.shape[0] % 256 == 0 \
-                    and name.endswith('_branch2c'):
+                    and name.endswith('_branch2c') and not self.use_chain:
                 self.wf[name] = ops.pack_w_frag(self.wp[name][0])
 
     def _hconv(self, x, name, stride=1, pad=0, dil=1, relu=False, resid=None, out_dtype=None):

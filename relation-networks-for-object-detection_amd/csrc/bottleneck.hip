@@ -216,7 +216,7 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
                                        const float* b1, void* x_next, void* mid1_next, long P, int mid, void* stream) {
   RELNET_REQUIRE(mid2 && x && w3f && b3 && x_next, "relnet_bottleneck_chain: null operand");
   RELNET_REQUIRE((w1f && b1 && mid1_next) || (!w1f && !b1 && !mid1_next), "relnet_bottleneck_chain: w1f, b1 and mid1_next are given together (or all NULL: expand + shortcut + ReLU only)");
-  RELNET_REQUIRE(mid == 64 || mid == 128, "relnet_bottleneck_chain: mid = %d unsupported (64, 128)", mid);
+  RELNET_REQUIRE(mid == 64 || mid == 128 || (mid == 256 && !mid1_next), "relnet_bottleneck_chain: mid = %d unsupported (64, 128; 256 without the reduce product)", mid);
   RELNET_REQUIRE(P > 0 && P < (1L << 31), "relnet_bottleneck_chain: bad pixel count %ld", P);
   ChainArgs a;
   a.m2 = (const unsigned short*)mid2; a.x = (const unsigned short*)x; a.w3f = (const uint4*)w3f; a.w1f = (const uint4*)w1f;
@@ -227,6 +227,7 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<64, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<128, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)bottleneck_chain_kernel<256, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const long ntile = (P + 31) / 32;
@@ -237,7 +238,8 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
     else bottleneck_chain_kernel<128, true><<<grid, 512, lds, (hipStream_t)stream>>>(a);
   } else {
     if (mid == 64) bottleneck_chain_kernel<64, false, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);
-    else bottleneck_chain_kernel<128, true, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);
+    else if (mid == 128) bottleneck_chain_kernel<128, true, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);
+    else bottleneck_chain_kernel<256, true, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);
   }
   return check_launch("relnet_bottleneck_chain");
 }

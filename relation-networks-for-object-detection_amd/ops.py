@@ -373,6 +373,7 @@ def conv3x3_c64(x, w_frag, bias, relu=True):
 
 
 CHAIN_MIDS = (64, 128)      # bottleneck widths relnet_bottleneck_chain is built for (res2: weights LDS-resident; res3: streamed per pass)
+CHAIN_EXPAND_MIDS = (64, 128, 256)      # ... and for its expand + shortcut + ReLU form without the second product (res4 too)
 
 
 def pack_chain_w1(w_packed):
@@ -401,6 +402,7 @@ def bottleneck_chain(mid2, x, w3_frag, w1_frag, b3, b1):
     assert mid2.is_contiguous() and x.is_contiguous() and x.shape[-1] == 4 * mid and x.shape[:-1] == mid2.shape[:-1]
     assert mid2.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and b3.dtype == torch.float32
     assert (w1_frag is None) == (b1 is None) and (b1 is None or b1.dtype == torch.float32)
+    assert mid in (CHAIN_MIDS if w1_frag is not None else CHAIN_EXPAND_MIDS)
     xn = torch.empty_like(x)
     m1 = torch.empty_like(mid2) if w1_frag is not None else None
     _lib.call('relnet_bottleneck_chain', mid2.data_ptr(), x.data_ptr(), w3_frag.data_ptr(), _ptr(w1_frag), b3.data_ptr(),

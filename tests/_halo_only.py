@@ -43,3 +43,15 @@ for mid, (H, W) in ((64, (150, 250)), (128, (75, 125))):
         xn = ops.conv2d_nhwc(m2, w3, b3, relu=True, resid=xx)
         return ops.conv2d_nhwc(xn, w1, b1, relu=True)
     timeit(two, 'two launches mid=%d' % mid)
+# res4 expand + shortcut: expand-only chain vs the row-panel kernel
+mid, (H, W) = 256, (38, 63)
+m2 = torch.relu(torch.randn(B, H, W, mid, device='cuda')).to(bf)
+xx = torch.relu(torch.randn(B, H, W, 4 * mid, device='cuda')).to(bf)
+w3 = (torch.randn(4 * mid, mid, device='cuda') * 0.05).to(bf); b3 = torch.randn(4 * mid, device='cuda') * 0.1
+w3f = ops.pack_w_frag(w3)
+timeit(lambda: ops.bottleneck_chain(m2, xx, w3f, None, b3, None), 'chain expand-only mid=256')
+timeit(lambda: ops.conv2d_nhwc(m2, w3, b3, relu=True, resid=xx, w_frag=w3f), 'row-panel kernel (tile 14)')
+timeit(lambda: ops.conv2d_nhwc(m2, w3, b3, relu=True, resid=xx), 'tile 1 (256x256)')
+a_, _ = ops.bottleneck_chain(m2, xx, w3f, None, b3, None)
+b_ = ops.conv2d_nhwc(m2, w3, b3, relu=True, resid=xx)
+print('max diff vs conv', (a_.float() - b_.float()).abs().max().item(), 'differs in %.4f%%' % (100 * (a_ != b_).float().mean().item()))
