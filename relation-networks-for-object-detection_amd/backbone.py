@@ -168,8 +168,8 @@ class Backbone(object):
         # unit u and reduce + ReLU of unit u+1 as one pixel-wise kernel (ops.bottleneck_chain); unit -> its operands
         self.chain, self.halo3 = {}, {}
         if self.impl == 'hip' and chain:
-            for (st, nm, ic, mc, oc, stride, dil, proj), nxt in zip(self.units[:-1], self.units[1:]):
-                if nxt[0] == st and not nxt[7] and mc in ops.CHAIN_MIDS:
+            for (st, nm, ic, mc, oc, stride, dil, proj), nxt in zip(self.units, self.units[1:] + [None]):
+                if nxt is not None and nxt[0] == st and not nxt[7] and mc in ops.CHAIN_MIDS:
                     w3, b3, _ = self.wp['res%s_branch2c' % nm]
                     w1n, b1n, _ = self.wp['res%s_branch2a' % nxt[1]]
                     self.chain[nm] = (ops.pack_w_frag(w3), ops.pack_chain_w1(w1n), b3, b1n)

@@ -48,10 +48,12 @@ struct ChainArgs {
 // share vmcnt and complete out of order with respect to each other, hence the single vmcnt(0) at the top of a pass.
 // Nothing on the vector-memory path is issued inside the arithmetic (biases come from LDS): a load there would make the
 // compiler wait for the prefetch in front of it.
-template <int MID, bool STREAM, bool REDUCE = true>       // REDUCE = false: only x_next (last unit of a stage: no next reduce)
+// KSPLIT > 1 (MID = 512, res5; expand-only): the k range of a pass is cut in KSPLIT sub-steps so that a ring slot stays 32 KiB.
+template <int MID, bool STREAM, bool REDUCE = true, int KSPLIT = 1>       // REDUCE = false: only x_next (no next reduce)
 __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
-  constexpr int COUT = 4 * MID, KS = MID / 16, RT = MID / 32, NP = COUT / 64;
-  constexpr int W3P = 2 * KS * 1024, W1P = REDUCE ? 4 * RT * 1024 : 0;     // bytes of one pass's W3 / W1' slice
+  static_assert(KSPLIT == 1 || (STREAM && !REDUCE), "k-split passes exist for the streamed expand-only form");
+  constexpr int COUT = 4 * MID, KS = MID / 16, KSS = KS / KSPLIT, RT = MID / 32, NP = COUT / 64;
+  constexpr int W3P = 2 * KSS * 1024, W1P = REDUCE ? 4 * RT * 1024 : 0;     // bytes of one (sub-)step's W3 / W1' slice
   constexpr int WBYTES = STREAM ? 2 * (W3P + W1P) : NP * (W3P + W1P);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -74,9 +76,8 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
   __syncthreads();
   const int ntile = (a.P + 31) / 32;
   const int drow = lane >> 3, dslot = lane & 7;                // DMA / coalesced-store role: row 8 i + drow, chunk slot dslot
-  auto wslot = [&](int p) -> const unsigned char* { return smem + (STREAM ? (p & 1) : p) * (W3P + W1P); };
-  // loads of (tile base pixel p0, pass p): shortcut slice into stage buffer p & 1, and (STREAM) this wave's share of the weights
-  auto issue = [&](int p0, int p) {
+  // shortcut slice of (tile base pixel p0, pass p) into stage buffer p & 1
+  auto issue_x = [&](int p0, int p) {
     unsigned char* sb = stage + (p & 1) * 4096;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -84,21 +85,26 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
       const unsigned short* src = a.x + (long)min(p0 + row, a.P - 1) * COUT + p * 64 + ((dslot ^ ((row >> 1) & 7)) << 3);
       __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(sb + i * 1024), 16, 0, 0);
     }
+  };
+  // (STREAM) this wave's share of the weights of step st = pass * KSPLIT + k-part into ring slot st & 1
+  auto issue_w = [&](int st) {
     if constexpr (STREAM) {
-      unsigned char* wb = smem + (p & 1) * (W3P + W1P);
+      const int p = st / KSPLIT, kh = st % KSPLIT;
+      unsigned char* wb = smem + (st & 1) * (W3P + W1P);
 #pragma unroll
-      for (int i = 0; i < (2 * KS + (REDUCE ? 4 * RT : 0)) / 8; ++i) {
+      for (int i = 0; i < (2 * KSS + (REDUCE ? 4 * RT : 0)) / 8; ++i) {
         const int q = wave + 8 * i;
-        if (q < 2 * KS) {
-          __builtin_amdgcn_global_load_lds((gas_ptr)(a.w3f + ((long)(p * 2 * KS + q) * 64 + lane)), (las_ptr)(wb + q * 1024), 16, 0, 0);
+        if (q < 2 * KSS) {
+          const int ct = q / KSS, ks = q % KSS;
+          __builtin_amdgcn_global_load_lds((gas_ptr)(a.w3f + ((long)((p * 2 + ct) * KS + kh * KSS + ks) * 64 + lane)), (las_ptr)(wb + q * 1024), 16, 0, 0);
         } else {
-          const int q1 = q - 2 * KS, rt = q1 >> 2, kk = q1 & 3;
+          const int q1 = q - 2 * KSS, rt = q1 >> 2, kk = q1 & 3;
           __builtin_amdgcn_global_load_lds((gas_ptr)(a.w1f + ((long)(rt * (COUT / 16) + p * 4 + kk) * 64 + lane)), (las_ptr)(wb + W3P + q1 * 1024), 16, 0, 0);
         }
       }
     }
   };
-  // stores of a finished 32 px x 64 channel slice of x_next from stage buffer b
+  // stores of a finished 32 px x 64 channel slice of x_next from stage buffer p & 1
   auto flush = [&](int p0, int p) {
     const unsigned char* sb = stage + (p & 1) * 4096 + lane * 16;
     const uint4 v0 = *(const uint4*)sb, v1 = *(const uint4*)(sb + 1024), v2 = *(const uint4*)(sb + 2048), v3 = *(const uint4*)(sb + 3072);
@@ -111,12 +117,13 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
   };
 
   // tile sequence of this wavefront: independent tiles (resident) or lock-step sets of 8 tiles (streaming)
-  const int t_first = STREAM ? blockIdx.x * 8 + wave : blockIdx.x * 8 + wave;
+  const int t_first = blockIdx.x * 8 + wave;
   const int t_step = gridDim.x * 8;
   const int n_iter = STREAM ? ((ntile + 7) / 8 - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x
                             : (ntile - t_first + t_step - 1) / t_step;      // (streaming: idle waves of the last set still take part)
   if (n_iter <= 0) return;
-  issue(t_first * 32, 0);
+  issue_x(t_first * 32, 0);
+  issue_w(0);
   for (int it = 0; it < n_iter; ++it) {
     const int p0 = (t_first + it * t_step) * 32;               // >= P for idle waves: loads clamp, stores are masked
     const int px = min(p0 + l31, a.P - 1);
@@ -130,22 +137,34 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
       for (int r = 0; r < 16; ++r) m1acc[rt][r] = 0.f;
 #pragma unroll 1
     for (int p = 0; p < NP; ++p) {
-      if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // pass p landed everywhere; everyone left pass p-1
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (p > 0) flush(p0, p - 1);
-      if (p + 1 < NP) issue(p0, p + 1);
-      else if (it + 1 < n_iter) issue(p0 + t_step * 32, 0);
-      const uint4* w3 = (const uint4*)wslot(p);
-      const uint4* w1 = (const uint4*)(wslot(p) + W3P);
+      f32x16 acc[2];
+#pragma unroll
+      for (int kh = 0; kh < KSPLIT; ++kh) {
+        const int st = p * KSPLIT + kh;
+        if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // step st landed everywhere; everyone left step st-1
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kh == 0) {
+          if (p > 0) flush(p0, p - 1);
+          if (p + 1 < NP) issue_x(p0, p + 1);
+          else if (it + 1 < n_iter) issue_x(p0 + t_step * 32, 0);
+        }
+        if (st + 1 < NP * KSPLIT) issue_w(st + 1);
+        else if (it + 1 < n_iter) issue_w(0);
+        const uint4* w3 = (const uint4*)(smem + (STREAM ? (st & 1) : st) * (W3P + W1P));
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          if (kh == 0)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KSS; ++ks)
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&w3[(ct * KSS + ks) * 64 + lane], m2f[kh * KSS + ks], acc[ct], 0, 0, 0);
+        }
+      }
+      const uint4* w1 = (const uint4*)(smem + (STREAM ? (p & 1) : p) * (W3P + W1P) + W3P);      // (REDUCE implies KSPLIT == 1: step == pass)
       unsigned char* sb = stage + (p & 1) * 4096;
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&w3[(ct * KS + ks) * 64 + lane], m2f[ks], acc, 0, 0, 0);
         // bias + shortcut + ReLU in place; the packed values feed the second product directly
         uint2 pk[4];
 #pragma unroll
@@ -153,8 +172,8 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
           uint2* sp = (uint2*)(sb + l31 * 128 + (((ct * 4 + g) ^ ((l31 >> 1) & 7)) << 4) + 8 * half);
           const uint2 xv = *sp;
           const float4 bv = *(const float4*)(sB3 + p * 64 + ct * 32 + 8 * g + 4 * half);
-          const float v0 = fmaxf(acc[4 * g + 0] + bv.x + bf2f(xv.x & 0xffff), 0.f), v1 = fmaxf(acc[4 * g + 1] + bv.y + bf2f(xv.x >> 16), 0.f);
-          const float v2 = fmaxf(acc[4 * g + 2] + bv.z + bf2f(xv.y & 0xffff), 0.f), v3 = fmaxf(acc[4 * g + 3] + bv.w + bf2f(xv.y >> 16), 0.f);
+          const float v0 = fmaxf(acc[ct][4 * g + 0] + bv.x + bf2f(xv.x & 0xffff), 0.f), v1 = fmaxf(acc[ct][4 * g + 1] + bv.y + bf2f(xv.x >> 16), 0.f);
+          const float v2 = fmaxf(acc[ct][4 * g + 2] + bv.z + bf2f(xv.y & 0xffff), 0.f), v3 = fmaxf(acc[ct][4 * g + 3] + bv.w + bf2f(xv.y >> 16), 0.f);
           pk[g] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
           *sp = pk[g];
         }
@@ -216,7 +235,7 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
                                        const float* b1, void* x_next, void* mid1_next, long P, int mid, void* stream) {
   RELNET_REQUIRE(mid2 && x && w3f && b3 && x_next, "relnet_bottleneck_chain: null operand");
   RELNET_REQUIRE((w1f && b1 && mid1_next) || (!w1f && !b1 && !mid1_next), "relnet_bottleneck_chain: w1f, b1 and mid1_next are given together (or all NULL: expand + shortcut + ReLU only)");
-  RELNET_REQUIRE(mid == 64 || mid == 128 || (mid == 256 && !mid1_next), "relnet_bottleneck_chain: mid = %d unsupported (64, 128; 256 without the reduce product)", mid);
+  RELNET_REQUIRE(mid == 64 || mid == 128 || ((mid == 256 || mid == 512) && !mid1_next), "relnet_bottleneck_chain: mid = %d unsupported (64, 128; 256 / 512 without the reduce product)", mid);
   RELNET_REQUIRE(P > 0 && P < (1L << 31), "relnet_bottleneck_chain: bad pixel count %ld", P);
   ChainArgs a;
   a.m2 = (const unsigned short*)mid2; a.x = (const unsigned short*)x; a.w3f = (const uint4*)w3f; a.w1f = (const uint4*)w1f;
@@ -228,6 +247,7 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<64, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<128, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<256, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)bottleneck_chain_kernel<512, true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const long ntile = (P + 31) / 32;
@@ -239,7 +259,8 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
   } else {
     if (mid == 64) bottleneck_chain_kernel<64, false, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);
     else if (mid == 128) bottleneck_chain_kernel<128, true, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);
-    else bottleneck_chain_kernel<256, true, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);
+    else if (mid == 256) bottleneck_chain_kernel<256, true, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);
+    else bottleneck_chain_kernel<512, true, false, 2><<<grid, 512, lds, (hipStream_t)stream>>>(a);
   }
   return check_launch("relnet_bottleneck_chain");
 }

@@ -49,6 +49,30 @@ def test_bottleneck_chain_vs_two_convolutions(shape, mid):
     assert (dx <= ulp(xn64) * 1.01 + 1e-6).all() and fx < 0.02     # (+ fp32 summation-order noise next to the ReLU threshold)
     assert (dm <= 4 * ulp(m164) + 1e-2).all() and fm < 0.05        # (a one-step difference of x_next times |W1|)
 
+@pytest.mark.parametrize('mid,shape', [(256, (2, 38, 63)), (512, (2, 38, 63)), (256, (1, 5, 7)), (512, (3, 19, 32))])
+def test_expand_only_chain_wide(mid, shape):
+    """res4 / res5 expand + shortcut + ReLU on the chain kernel (weights through the LDS ring, k split in two for mid = 512):
+    float64 on the same bf16 operands, and the implicit-GEMM launch it replaces."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(mid + H)
+    bf = torch.bfloat16
+    m2 = torch.relu(torch.randn(B, H, W, mid, generator=g)).to(bf).cuda()
+    x = torch.relu(torch.randn(B, H, W, 4 * mid, generator=g)).to(bf).cuda()
+    w3 = (torch.randn(4 * mid, mid, generator=g) * 0.05).to(bf).cuda()
+    b3 = (torch.randn(4 * mid, generator=g) * 0.1).cuda()
+    xn, none = ops.bottleneck_chain(m2, x, ops.pack_w_frag(w3), None, b3, None)
+    assert none is None
+    ref64 = torch.relu(m2.double() @ w3.double().t() + b3.double() + x.double())
+    step = torch.maximum(ref64.abs(), torch.tensor(2.0 ** -126, dtype=torch.float64, device='cuda')) * 2.0 ** -7
+    ex = ((xn.double() - ref64).abs() - 0.5 * step).max().item()
+    y2 = ops.conv2d_nhwc(m2, w3, b3, relu=True, resid=x)
+    d = (xn.float() - y2.float()).abs().double()
+    print('mid %d %s: excess over half a bf16 step %.2e; differs from the implicit-GEMM launch in %.4f%% of elements' % (mid, shape, ex, 100 * (d > 0).double().mean().item()))
+    assert ex <= 5e-5 and (d <= step * 1.01 + 1e-5).all()
+
+
 def test_backbone_with_and_without_chain_kernel():
     """The detector trunk with the res2 boundaries fused equals the unfused trunk up to bf16 rounding of a few elements."""
     import relnet_amd  # noqa: F401
@@ -58,7 +82,8 @@ def test_backbone_with_and_without_chain_kernel():
     a = backbone.Backbone(p, dtype=torch.bfloat16, chain=True)
     b = backbone.Backbone(p, dtype=torch.bfloat16, chain=False)
     assert [k for k in sorted(a.chain) if k[0] in '23'] == ['2a', '2b', '2c', '3a', '3b1', '3b2', '3b3'] and a.chain['2c'][1] is None
-    assert sum(k[0] == '4' for k in a.chain) == 23 and all(a.chain[k][1] is None for k in a.chain if k[0] == '4') and not b.chain
+    assert sum(k[0] == '4' for k in a.chain) == 23 and all(a.chain[k][1] is None for k in a.chain if k[0] in '45') and not b.chain
+    assert sum(k[0] == '5' for k in a.chain) == 3
     fa, fb = a.forward(data), b.forward(data)
     for k in ('conv4', 'conv5', 'rpn_cls_score', 'rpn_bbox_pred'):
         d = (fa[k].float() - fb[k].float()).abs().max().item()
