@@ -156,6 +156,7 @@ int relnet_bottleneck_chain(const void* mid2, const void* x, const void* w3f, co
 int relnet_conv3x3_c64(const void* in, const void* w_frag, const float* bias, int relu, void* out, int B, int H, int W,
                        void* stream);
 
+
 /* Row-panel form of the 1x1 convolutions (csrc/gemm.hip:gemm_panelw_kernel): `w_frag` is the weight matrix re-ordered once
  * at model load by relnet_pack_w_frag ([Cout][K] bf16 -> MFMA fragment order, same byte count; Cout % 32 == 0, K % 16 == 0).
  * relnet_conv2d_nhwc_wf == relnet_conv2d_nhwc when w_frag is NULL or the layer is not a stride-1 1x1 convolution with

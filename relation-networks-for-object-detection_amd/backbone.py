@@ -176,9 +176,9 @@ class Backbone(object):
                 elif mc in ops.CHAIN_EXPAND_MIDS:   # last unit of a stage, and every res4 unit: the kernel without the second product
                     w3, b3, _ = self.wp['res%s_branch2c' % nm]
                     self.chain[nm] = (ops.pack_w_frag(w3), None, b3, None)
-            # 64-channel 3x3 convolutions (res2*_branch2b): halo tile resident in LDS instead of one LDS fill per tap
+            # 64-channel 3x3 convolutions (res2 branch2b): halo tile resident in LDS instead of one LDS fill per tap
             for st, nm, ic, mc, oc, stride, dil, proj in self.units:
-                if mc == 64 and dil == 1:
+                if mc in ops.HALO3_CHANNELS and dil == 1 and not (self.dcn and st == 5):
                     w, b, _ = self.wp['res%s_branch2b' % nm]
                     self.halo3['res%s_branch2b' % nm] = (ops.pack_w_frag(w, panel_only=False), b)
 
@@ -227,7 +227,7 @@ class Backbone(object):
                                     self._hconv(y, 'res%s_branch2b_offset' % nm, pad=2, dil=2, out_dtype=torch.float32).permute(0, 3, 1, 2))
                 y = y.permute(0, 2, 3, 1)
             elif ('res%s_branch2b' % nm) in self.halo3:
-                y = ops.conv3x3_c64(y.contiguous(), *self.halo3['res%s_branch2b' % nm], relu=True)
+                y = ops.conv3x3_halo(y.contiguous(), *self.halo3['res%s_branch2b' % nm], relu=True)
             else:
                 y = self._hconv(y, 'res%s_branch2b' % nm, pad=dil, dil=dil, relu=True)
             ch = self.chain.get(nm)

@@ -420,3 +420,8 @@ extern "C" int relnet_conv3x3_c64(const void* in, const void* w_frag, const floa
   conv3x3_c64_halo_kernel<<<grid, 512, 2 * kHaloBytes + 32768 + 256, (hipStream_t)stream>>>(a);
   return check_launch("relnet_conv3x3_c64");
 }
+
+// (Measured and dropped: the same halo-resident form for the 256-channel res4 3x3 layers -- halo tile per 64- or 128-channel
+//  part, weights [256][64] through a 2-, 3- or 4-slot LDS ring -- reaches 178-186 us against 166 us of the implicit-GEMM ring
+//  kernel in isolation.  With 8 fragment MFMAs per 6 LDS fragment reads and a workgroup barrier per weight slab the LDS-read +
+//  MFMA rate, not the L2 -> LDS fill it removes, is what bounds those layers.)

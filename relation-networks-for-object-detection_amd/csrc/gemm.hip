@@ -1391,6 +1391,8 @@ static void launch_ring(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
 //                                   14 = the same with W streamed from its fragment-order copy through registers
 //                                        (gemm_panelw_kernel; needs the Wf operand, else configuration 13)
 //                                   15 = 14 with 64-row panels, two workgroups per CU
+// (measured and dropped: tile 8 with FOUR wavefronts of 128x128 -- 4x4 fragments, accumulators in AGPRs, half the LDS fragment
+//  reads per MFMA -- is 20-40 % slower on every layer shape: one wavefront per SIMD cannot cover the LDS / MFMA latencies)
 enum { GEMM_TILE_COUNT = 15 };
 
 template <int CONV>

@@ -265,11 +265,12 @@ class Executor(object):
         if xn.dtype != torch.bfloat16 or not xn.is_contiguous():
             xn = xn.to(torch.bfloat16).contiguous()
         odt = torch.float32 if out32 else torch.bfloat16
-        if k == (3, 3) and s == (1, 1) and d == (1, 1) and p == (1, 1) and cin == 64 and w.shape[0] == 64 and resid is None and not out32:
-            fkey = ('halo3', id(node))                    # 64-channel 3x3 (res2*_branch2b): halo-resident kernel, same bits
+        if (k == (3, 3) and s == (1, 1) and d == (1, 1) and p == (1, 1) and cin in K.HALO3_CHANNELS and w.shape[0] == cin
+                and resid is None and not out32):
+            fkey = ('halo3', id(node))                    # 64- / 256-channel 3x3 (res2 / res4 branch2b): halo-resident kernels
             if fkey not in self.cache:
                 self.cache[fkey] = K.pack_w_frag(self.cache[key], panel_only=False)
-            return K.conv3x3_c64(xn, self.cache[fkey], b, relu=relu).permute(0, 3, 1, 2)
+            return K.conv3x3_halo(xn, self.cache[fkey], b, relu=relu).permute(0, 3, 1, 2)
         rn = None
         if resid is not None:
             rn = resid.permute(0, 2, 3, 1)

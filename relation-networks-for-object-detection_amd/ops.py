@@ -361,15 +361,23 @@ def pack_w_frag(w_packed, panel_only=True):
     return out
 
 
-def conv3x3_c64(x, w_frag, bias, relu=True):
-    """3x3 / stride 1 / pad 1 convolution + bias (+ ReLU) of a dense NHWC bf16 tensor with 64 channels in and out, input tile
-    + halo resident in LDS (csrc/bottleneck.hip).  w_frag = pack_w_frag(packed weight [64, 576], panel_only=False)."""
+HALO3_CHANNELS = (64,)            # widths with a halo-resident 3x3 kernel (res2)
+
+
+def conv3x3_halo(x, w_frag, bias, relu=True):
+    """3x3 / stride 1 / pad 1 convolution + bias (+ ReLU) of a dense NHWC bf16 tensor with C in HALO3_CHANNELS channels in and out, input
+    tile + halo resident in LDS (csrc/bottleneck.hip).  w_frag = pack_w_frag(packed weight [C, 9 C], panel_only=False)."""
     _chk(x, w_frag, bias)
     B, H, W, C = x.shape
-    assert C == 64 and x.is_contiguous() and x.dtype == torch.bfloat16 and bias.dtype == torch.float32 and w_frag.numel() == 64 * 576
+    assert C in HALO3_CHANNELS and x.is_contiguous() and x.dtype == torch.bfloat16 and bias.dtype == torch.float32
+    assert w_frag.numel() == 9 * C * C
     out = torch.empty_like(x)
-    _lib.call('relnet_conv3x3_c64', x.data_ptr(), w_frag.data_ptr(), bias.data_ptr(), int(relu), out.data_ptr(), B, H, W, _stream())
+    _lib.call('relnet_conv3x3_c%d' % C, x.data_ptr(), w_frag.data_ptr(), bias.data_ptr(), int(relu), out.data_ptr(), B, H, W, _stream())
     return out
+
+
+def conv3x3_c64(x, w_frag, bias, relu=True):
+    return conv3x3_halo(x, w_frag, bias, relu)
 
 
 CHAIN_MIDS = (64, 128)      # bottleneck widths relnet_bottleneck_chain is built for (res2: weights LDS-resident; res3: streamed per pass)

@@ -48,7 +48,7 @@ CASES = [  # name, count per step, args
     ('res2 reduce 256->64', 2, (150, 250, 256, 64, 1, 1, False)),
     ('conv_new_1 2048->256', 1, (38, 63, 2048, 256, 1, 1, False)),
 ]
-TILES = [int(x) for x in os.environ.get('TILES', '0,14,15').split(',')]
+TILES = [int(x) for x in os.environ.get('TILES', '0,1,8,14').split(',')]
 
 
 def main():

@@ -55,3 +55,10 @@ timeit(lambda: ops.conv2d_nhwc(m2, w3, b3, relu=True, resid=xx), 'tile 1 (256x25
 a_, _ = ops.bottleneck_chain(m2, xx, w3f, None, b3, None)
 b_ = ops.conv2d_nhwc(m2, w3, b3, relu=True, resid=xx)
 print('max diff vs conv', (a_.float() - b_.float()).abs().max().item(), 'differs in %.4f%%' % (100 * (a_ != b_).float().mean().item()))
+mid, (H, W) = 512, (38, 63)
+m2 = torch.relu(torch.randn(B, H, W, mid, device='cuda')).to(bf)
+xx = torch.relu(torch.randn(B, H, W, 4 * mid, device='cuda')).to(bf)
+w3 = (torch.randn(4 * mid, mid, device='cuda') * 0.05).to(bf); b3 = torch.randn(4 * mid, device='cuda') * 0.1
+w3f = ops.pack_w_frag(w3)
+timeit(lambda: ops.bottleneck_chain(m2, xx, w3f, None, b3, None), 'chain expand-only mid=512')
+timeit(lambda: ops.conv2d_nhwc(m2, w3, b3, relu=True, resid=xx), 'tile 1 (256x256) mid=512')

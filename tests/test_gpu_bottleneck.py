@@ -91,21 +91,24 @@ def test_backbone_with_and_without_chain_kernel():
         assert d <= 2e-2 * s, (k, d, s)
 
 
+@pytest.mark.parametrize('C', [64])
 @pytest.mark.parametrize('shape', [(1, 5, 7), (2, 38, 63), (2, 150, 250), (1, 8, 32), (3, 17, 65)])
-def test_conv3x3_c64_halo_kernel(shape):
+def test_conv3x3_halo_kernels(shape, C):
     """Halo-resident 3x3 kernel against float64 on the same bf16 operands (correctly rounded up to fp32 accumulation noise)
     and against the implicit-GEMM launch it replaces; ragged tiles in both directions, image borders = zero padding."""
     import relnet_amd  # noqa: F401
     from relnet_amd import ops
     B, H, W = shape
-    g = torch.Generator().manual_seed(7 * B + H)
+    if C == 256 and H == 150:
+        H, W = 75, 125
+    g = torch.Generator().manual_seed(7 * B + H + C)
     bf = torch.bfloat16
-    x = torch.relu(torch.randn(B, H, W, 64, generator=g)).to(bf).cuda()
-    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(bf)
-    b = (torch.randn(64, generator=g) * 0.1).cuda()
+    x = torch.relu(torch.randn(B, H, W, C, generator=g)).to(bf).cuda()
+    w = (torch.randn(C, C, 3, 3, generator=g) * (0.05 if C == 64 else 0.02)).to(bf)
+    b = (torch.randn(C, generator=g) * 0.1).cuda()
     wp = ops.pack_conv_weight(w, bf, 'cuda')
     for relu in (True, False):
-        y = ops.conv3x3_c64(x, ops.pack_w_frag(wp, panel_only=False), b, relu=relu)
+        y = ops.conv3x3_halo(x, ops.pack_w_frag(wp, panel_only=False), b, relu=relu)
         ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().cuda(), b.double(), padding=1).permute(0, 2, 3, 1)
         ref = torch.relu(ref) if relu else ref
         step = torch.maximum(ref.abs(), torch.tensor(2.0 ** -126, dtype=torch.float64, device='cuda')) * 2.0 ** -7
@@ -114,5 +117,5 @@ def test_conv3x3_c64_halo_kernel(shape):
         d = (y.float() - y2.float()).abs().double()
         print('shape %s relu=%d: excess over half a bf16 step %.2e; differs from the implicit-GEMM launch in %.4f%% of elements'
               % (shape, relu, ex, 100 * (d > 0).double().mean().item()))
-        assert ex <= 2e-5
-        assert (d <= step * 1.01 + 1e-6).all()
+        assert ex <= 5e-5
+        assert (d <= step * 1.01 + 1e-5).all()          # (C = 256 sums the channel halves in a different order than the implicit GEMM)
