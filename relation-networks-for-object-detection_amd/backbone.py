@@ -193,7 +193,7 @@ class Backbone(object):
             # 256-deep expand convolutions (res4 branch2c, 23 per step): a second copy of the weights in MFMA-fragment
             # order lets relnet_conv2d_nhwc_wf pick the panel kernel (A resident in LDS, W streamed through registers)
             if self.dtype == torch.bfloat16 and tuple(w.shape[1:]) == (256, 1, 1) and w.shape[0] % 256 == 0 \
-                    and name.endswith('_branch2c') and not self.use_chain:
+                    and name.endswith('_branch2c'):
                 self.wf[name] = ops.pack_w_frag(self.wp[name][0])
 
     def _hconv(self, x, name, stride=1, pad=0, dil=1, relu=False, resid=None, out_dtype=None):
@@ -231,6 +231,8 @@ class Backbone(object):
             else:
                 y = self._hconv(y, 'res%s_branch2b' % nm, pad=dil, dil=dil, relu=True)
             ch = self.chain.get(nm)
+            if ch is not None and not ops.chain_worthwhile(y.numel() // y.shape[-1], y.shape[-1]):
+                ch = None            # small maps (B = 1, late stages at small B): the tiled convolution kernels fill the GPU better
             if ch is not None:       # expand + shortcut + ReLU and the next unit's reduce + ReLU in one pixel-wise kernel
                 x, y_next = ops.bottleneck_chain(y, sc.contiguous(), *ch)
             else:

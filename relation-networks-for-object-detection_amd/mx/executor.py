@@ -180,17 +180,17 @@ class Executor(object):
             rc = [v for v in self.conv_chain.values() if len(nxt) == 1 and v[0] is nxt[0]]
             if not rc or rc[0][3] is not None or not rc[0][2] or self._wants_fp32(rc[0][4]) or wshape(rc[0][0])[1] != nf:
                 # last unit of a stage (or a consumer the kernel does not cover): expand + shortcut + ReLU only
-                self.override[lid] = (self.override[lid][0], self._chain_runner(node, bn, None, None, None))
+                self.override[lid] = (self.override[lid][0], self._chain_runner(node, bn, None, None, None, self.override[lid][1]))
                 self.fused_report['block_boundaries'] = self.fused_report.get('block_boundaries', 0) + 1
                 continue
             rnode, rbn, _, _, rlast = rc[0]
-            self.override[lid] = (self.override[lid][0], self._chain_runner(node, bn, rnode, rbn, id(rlast)))
+            self.override[lid] = (self.override[lid][0], self._chain_runner(node, bn, rnode, rbn, id(rlast), self.override[lid][1]))
             plain = self.override[id(rlast)][1]
             self.override[id(rlast)] = (self.override[id(rlast)][0] + [(last, 0)],
                                         lambda x, xn_dep, plain=plain, key=id(rlast): self._parked.pop(key) if key in self._parked else plain(x))
             self.fused_report['block_boundaries'] = self.fused_report.get('block_boundaries', 0) + 1
 
-    def _chain_runner(self, node, bn, rnode, rbn, rkey):
+    def _chain_runner(self, node, bn, rnode, rbn, rkey, plain):
         def run(x, resid):
             key = ('chain', id(node))
             if key not in self.cache:
@@ -202,6 +202,8 @@ class Executor(object):
                     w1, b1 = self._conv_weights(rnode, rbn)
                     self.cache[key] = (w3f, K.pack_chain_w1(K.pack_conv_weight(w1, torch.bfloat16, self.device)), b3, b1)
             nhwc = lambda t: t.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+            if not K.chain_worthwhile(x.numel() // x.shape[1], x.shape[1]):      # same rule as Backbone (small maps)
+                return plain(x, resid)
             xn, m1 = K.bottleneck_chain(nhwc(x), nhwc(resid), *self.cache[key])
             if m1 is not None:
                 self._parked[rkey] = m1.permute(0, 3, 1, 2)

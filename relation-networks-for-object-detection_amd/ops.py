@@ -384,6 +384,13 @@ CHAIN_MIDS = (64, 128)      # bottleneck widths relnet_bottleneck_chain is built
 CHAIN_EXPAND_MIDS = (64, 128, 256, 512)      # ... and for its expand + shortcut + ReLU form without the second product (res4, res5 too)
 
 
+def chain_worthwhile(pixels, mid):
+    """The chain kernels are persistent with one workgroup per CU; the streamed forms (mid >= 128) walk lock-step sets of
+    8 x 32 pixels, so they need >= ~1.5 sets per CU (256 CUs) to beat the tiled convolution kernels (measured: B = 1 / B = 8
+    steps are slower with them on the small late-stage maps)."""
+    return pixels >= (16384 if mid == 64 else 98304)
+
+
 def pack_chain_w1(w_packed):
     """Reduce weights [mid, 4 mid] bf16 of the NEXT block -> fragment order of bottleneck_chain's second product: block
     (row tile rt, k-step ks) = 64 lanes x 8 values, lane (l31, half) slot t <- W[32 rt + l31][16 ks + 8 (t >> 2) + 4 half + (t & 3)]

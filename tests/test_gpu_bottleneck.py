@@ -78,7 +78,7 @@ def test_backbone_with_and_without_chain_kernel():
     import relnet_amd  # noqa: F401
     from relnet_amd import backbone
     p = backbone.init_params(seed=5)
-    data = torch.randn(2, 3, 224, 320, generator=torch.Generator().manual_seed(1)).cuda() * 50
+    data = torch.randn(2, 3, 608, 1008, generator=torch.Generator().manual_seed(1)).cuda() * 50     # res2 maps above ops.chain_worthwhile's threshold
     a = backbone.Backbone(p, dtype=torch.bfloat16, chain=True)
     b = backbone.Backbone(p, dtype=torch.bfloat16, chain=False)
     assert [k for k in sorted(a.chain) if k[0] in '23'] == ['2a', '2b', '2c', '3a', '3b1', '3b2', '3b3'] and a.chain['2c'][1] is None
