@@ -148,3 +148,25 @@ def test_fpn_detector_stagewise():
     o16 = det16.forward(data2, boxes2, torch.tensor([[H, W, 1.0]] * 2).cuda())
     assert torch.isfinite(o16['cls_score']).all() and o16['cls_score'].shape == (2, N, 81)
     assert torch.equal(o16['rois'][0], out['rois'][0])          # dispatch does not depend on the dtype
+
+
+def test_fpn_empty_level_is_reported_not_padded():
+    """Known parity gap, stated in DESIGN.md section 2: when a pyramid level receives no roi the reference's host-side dispatch
+    appends an all-zero dummy roi for it (core/rcnn.py:61-71), which then also becomes an extra relation key.  The device
+    dispatch does not add that row: `level_counts` shows the empty level, `check_levels=True` turns it into an error."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import backbone, detector
+    H, W, N = 256, 320, 16
+    p = backbone.init_params(seed=3, fpn=True)
+    g = torch.Generator().manual_seed(4)
+    xy = torch.rand(1, N, 2, generator=g) * 20
+    boxes = torch.cat([xy, xy + 250.0], 2).clamp(max=W - 1).contiguous()           # every roi is large: only the coarse levels are used
+    det = detector.FPNDetector(p, dtype=torch.bfloat16)
+    data = torch.randn(1, 3, H, W, generator=g).cuda()
+    im_info = torch.tensor([[H, W, 1.0]]).cuda()
+    out = det.forward(data, boxes.cuda(), im_info)
+    counts = out['level_counts'][0].cpu().numpy()
+    assert counts.sum() == N and (counts == 0).any()
+    assert out['rois'].shape[1] == N                                                # no dummy row appended
+    with pytest.raises(ValueError, match='dummy roi'):
+        det.forward(data, boxes.cuda(), im_info, check_levels=True)
