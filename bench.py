@@ -243,6 +243,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (default 54; 8 with --train)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-overlap', action='store_true', help='A/B: RPN head + proposal on the main stream instead of beside res5')
     ap.add_argument('--no-chain', action='store_true', help='A/B: res2 block boundaries as two convolution launches instead of relnet_bottleneck_chain')
     ap.add_argument('--no-relation', action='store_true', help='plain 2FC head (config 1 graph)')
     ap.add_argument('--learn-nms', action='store_true', help='learned duplicate removal instead of soft-NMS (config 3 graph, inference)')
@@ -290,6 +291,8 @@ def main():
         det = detector.FPNDetector(params, dtype=tdt, device='cuda', relation=not a.no_relation, cfg=cfg, stem=a.stem)
     else:
         det = detector.Detector(params, dtype=tdt, device='cuda', relation=not a.no_relation, cfg=cfg, stem=a.stem)
+    if a.no_overlap and hasattr(det, 'overlap_rpn'):
+        det.overlap_rpn = False
     if a.no_chain:
         from relnet_amd import ops as _ops
         bb = det.backbone

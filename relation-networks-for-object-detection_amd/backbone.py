@@ -201,7 +201,7 @@ class Backbone(object):
         return ops.conv2d_nhwc(x, w, b, ksize=k, stride=stride, pad=pad, dil=dil, relu=relu, resid=resid,
                                out_dtype=out_dtype, w_frag=self.wf.get(name))
 
-    def _forward_hip(self, data):
+    def _forward_hip(self, data, rpn_hook=None):
         if self.stem == 'hip':
             # repack to padded NHWC4, 7x7/2 conv + bias + ReLU on the MFMA kernel, then pool1
             x = ops.stem_conv7(data, self.w_stem, self.b32['conv1'], relu=True)
@@ -214,9 +214,17 @@ class Backbone(object):
         conv4 = None
         ends = {}
         y_next = None
+        side, hooked = None, None
         for stage, nm, ic, mc, oc, stride, dil, proj in self.units:
             if stage == 5 and conv4 is None:
                 conv4 = x
+                if rpn_hook is not None and not self.fpn:      # fork: RPN head + hook next to res5
+                    main = torch.cuda.current_stream()
+                    side = self._side_stream()
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        hooked = self._rpn_head(conv4)
+                        hooked = hooked + (rpn_hook(hooked[0], hooked[1]),)
             if proj and stage > 2:
                 ends[stage - 1] = x
             sc = self._hconv(x, 'res%s_branch1' % nm, stride=stride) if proj else x
@@ -248,11 +256,24 @@ class Backbone(object):
             out.update(conv4=nchw(conv4), conv5=nchw(conv5))
             return out
         feat = self._hconv(conv5, 'conv_new_1', relu=True)
+        out = dict(conv4=nchw(conv4), conv5=nchw(conv5), conv_new_1_relu=nchw(feat))
+        if hooked is not None:
+            torch.cuda.current_stream().wait_stream(side)      # join
+            out.update(rpn_cls_score=hooked[0], rpn_bbox_pred=hooked[1], rpn_hook=hooked[2])
+        else:
+            out['rpn_cls_score'], out['rpn_bbox_pred'] = self._rpn_head(conv4)
+        return out
+
+    def _rpn_head(self, conv4):
         r = self._hconv(conv4, 'rpn_conv_3x3', pad=1, relu=True)
         rpn = self._hconv(r, 'rpn_out', out_dtype=torch.float32)
         na2 = self.w['rpn_cls_score'][0].shape[0]
-        return dict(conv4=nchw(conv4), conv5=nchw(conv5), conv_new_1_relu=nchw(feat),
-                    rpn_cls_score=nchw(rpn[..., :na2]), rpn_bbox_pred=nchw(rpn[..., na2:]))
+        return rpn[..., :na2].permute(0, 3, 1, 2), rpn[..., na2:].permute(0, 3, 1, 2)
+
+    def _side_stream(self):
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def _deform_2b(self, y, name, offset):
         """DeformableConvolution(kernel 3x3, pad 2, dilate 2, num_deformable_group 4, no_bias) + BN + ReLU
@@ -265,11 +286,16 @@ class Backbone(object):
         y = F.conv2d(x, w, b, stride=stride, padding=pad, dilation=dil)
         return F.relu_(y) if relu else y
 
-    def forward(self, data):
+    def forward(self, data, rpn_hook=None):
         """data [B,3,H,W] -> dict(conv4, conv5, conv_new_1_relu, rpn_cls_score, rpn_bbox_pred)
-        (logical NCHW tensors; channels-last memory)."""
+        (logical NCHW tensors; channels-last memory).
+
+        rpn_hook (impl 'hip'): callable(rpn_cls_score, rpn_bbox_pred) -> anything, e.g. the proposal operator.  The RPN head
+        and the hook then run on a SIDE stream as soon as conv4 exists, concurrently with res5 / conv_new_1 on the caller's
+        stream (the proposal kernels are latency bound and occupy ~54 workgroups; res5 fills the rest of the GPU); the two
+        streams join before this function returns and the hook's result is returned under the key 'rpn_hook'."""
         if self.impl == 'hip':
-            return self._forward_hip(data)
+            return self._forward_hip(data, rpn_hook)
         x = data.to(self.dtype).contiguous(memory_format=self.mf)
         x = self._conv(x, 'conv1', stride=2, pad=3, relu=True)
         x = F.max_pool2d(x, kernel_size=3, stride=2, padding=0, ceil_mode=True)

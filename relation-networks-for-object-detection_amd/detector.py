@@ -52,6 +52,7 @@ class Detector(object):
                  im_hw=(600, 1000), stem='hip'):
         self.cfg = cfg or Config()
         self.dtype, self.device, self.relation, self.im_hw = dtype, device, relation, im_hw
+        self.overlap_rpn = True
         self.backbone = Backbone(params, dtype, device, stem=stem, dcn=self.cfg.dcn)
         if self.cfg.dcn:          # FC 12544 -> 2*7*7 offsets (SYM_DCN_RELNMS:1075), columns in (ph, pw, c) order
             self.w_offset = params['offset_weight'][:, fc1_channels_last_perm()].to(device, dtype).contiguous()
@@ -79,10 +80,15 @@ class Detector(object):
         """data [B,3,H,W], im_info [B,3] fp32 (device).  No host synchronisation inside."""
         c = self.cfg
         B = data.shape[0]
-        f = self.backbone.forward(data)
-        rois, roi_scores = propose_batch(f['rpn_cls_score'].float(), f['rpn_bbox_pred'].float(), im_info,
-                                         self.anchors, c.feat_stride, c.rpn_pre_nms_top_n, c.rpn_post_nms_top_n,
-                                         c.rpn_nms_thresh, c.rpn_min_size, im_hw=self.im_hw, softmax_pairs=True)
+        propose = lambda cls, box: propose_batch(cls.float(), box.float(), im_info, self.anchors, c.feat_stride,
+                                                 c.rpn_pre_nms_top_n, c.rpn_post_nms_top_n, c.rpn_nms_thresh, c.rpn_min_size,
+                                                 im_hw=self.im_hw, softmax_pairs=True)
+        if self.overlap_rpn and self.backbone.impl == 'hip':       # RPN head + proposal on a side stream, beside res5
+            f = self.backbone.forward(data, rpn_hook=propose)
+            rois, roi_scores = f['rpn_hook']
+        else:
+            f = self.backbone.forward(data)
+            rois, roi_scores = propose(f['rpn_cls_score'], f['rpn_bbox_pred'])
         N = rois.shape[1]
         if c.dcn:                 # SYM_DCN_RELNMS:1073-1080
             feat, r5, sc = f['conv_new_1_relu'], rois.view(B * N, 5), 1.0 / c.feat_stride
