@@ -6,18 +6,20 @@
 //
 // Both are 1x1 convolutions, i.e. per-pixel products, so block n+1's reduce can consume x_next while it is still in
 // registers: the 256- (512-) channel activation is written once and NOT read back by a separate reduce kernel.  For the
-// HBM-bound stages that is the dominant saving (res2 at B = 54: expand 535 us + reduce 256 us as two GEMM launches;
-// DESIGN.md section 4 has the measured figure of this kernel).
+// HBM-bound stages that is the dominant saving (res2 at B = 54: expand 535 us + reduce 256 us as two GEMM launches ->
+// 461 us; DESIGN.md section 4 / 4a have the measured figures).  The same kernel without the second product is the
+// expand + shortcut + ReLU layer of every residual unit (res2 .. res5), bit-identical to the implicit-GEMM launch.
 //
-// One wavefront = 32 pixels (independent of every other wavefront after the weights are in LDS):
-//   phase A  acc^T[cout][px] = W3 (A operand, rows = cout) x mid2^T (B operand: lane = pixel, 8 channels per k-step, read
-//            straight from HBM: a pixel row of mid2 is one 128-byte line), 128 output channels per pass;
-//   shortcut the 32 x 128-channel slice of x arrives in LDS by global_load_lds (1 KiB per instruction = 4 pixel rows,
-//            16-byte chunks XOR-swizzled on the SOURCE side so that the per-lane 8-byte reads spread over the banks);
-//            relu(acc + b3 + x) is written back IN PLACE as bf16 and leaves as 16-byte coalesced rows;
+// One wavefront = 32 pixels, in passes of 64 output channels:
+//   phase A  acc^T[cout][px] = W3 (A operand, rows = cout, fragments from LDS) x mid2^T (B operand: lane = pixel, 8 channels
+//            per k-step, read straight from HBM once per tile and kept in VGPRs);
+//   shortcut the 32 px x 64-channel slice of x arrives in LDS by global_load_lds (1 KiB per instruction = 8 pixel rows of
+//            128 B, 16-byte chunks XOR-swizzled on the SOURCE side so that the per-lane 8-byte reads spread over the banks),
+//            one pass ahead; relu(acc + b3 + x) is written back IN PLACE as bf16 and leaves as 16-byte coalesced rows
+//            one pass later;
 //   phase B  the same packed bf16 values are the B operand of the second product (the contraction index cout is permuted
 //            identically in the accumulator registers and in the pre-packed W1' fragments, as in the attention kernel),
-//            mid1'^T[c][px] accumulates over the two passes, then bias + ReLU + LDS transpose + coalesced rows.
+//            mid1'^T[c][px] accumulates over the passes, then bias + ReLU + LDS transpose + coalesced rows.
 // Rounding points are those of the two-launch path (x_next is rounded to bf16 before the reduce product).
 #include "common.h"
 
