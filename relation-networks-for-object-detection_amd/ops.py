@@ -394,8 +394,8 @@ def chain_worthwhile(pixels, mid):
 def pack_chain_w1(w_packed):
     """Reduce weights [mid, 4 mid] bf16 of the NEXT block -> fragment order of bottleneck_chain's second product: block
     (row tile rt, k-step ks) = 64 lanes x 8 values, lane (l31, half) slot t <- W[32 rt + l31][16 ks + 8 (t >> 2) + 4 half + (t & 3)]
-    (the contraction index in the order the accumulator registers of the first product hold it)."""
-    _chk(w_packed)
+    (the contraction index in the order the accumulator registers of the first product hold it).  Pure indexing (a weight
+    re-ordering done once at load time): runs on whatever device holds `w_packed`."""
     N, K = w_packed.shape
     assert w_packed.dtype == torch.bfloat16 and N % 32 == 0 and K % 16 == 0
     dev = w_packed.device

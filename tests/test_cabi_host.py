@@ -206,3 +206,28 @@ def test_every_registered_reference_op_name_resolves():
     for name in ('proposal', 'proposal_target', 'BoxAnnotatorOHEM', 'learn_nms', 'nms_multi_target'):
         assert operator_py.get_prop(name) is not None
 
+
+
+def test_chain_weight_fragment_order_matches_the_header():
+    """ops.pack_chain_w1 is the host half of relnet_bottleneck_chain's contract (include/relnet_hip.h): block (rt, ks) = 64 lanes x 8
+    values, lane (l31, half) slot t <- W1n[32 rt + l31][16 ks + 8 (t >> 2) + 4 half + (t & 3)].  Checked element by element on CPU;
+    and ops.chain_worthwhile keeps the persistent kernels off maps that cannot fill 256 CUs."""
+    import torch
+    import relnet_amd  # noqa: F401
+    from relnet_amd import ops
+    mid, cout = 64, 256
+    w = torch.arange(mid * cout, dtype=torch.float32).reshape(mid, cout).to(torch.bfloat16)   # (values collide in bf16; compare indices)
+    idx = torch.arange(mid * cout, dtype=torch.int32).reshape(mid, cout)
+    got = ops.pack_chain_w1(w)
+    assert got.shape == (mid // 32, cout // 16, 64, 8) and got.is_contiguous()
+    for rt, ks, lane, t in ((0, 0, 0, 0), (1, 5, 37, 6), (0, 15, 63, 7), (1, 9, 31, 3), (0, 3, 32, 4)):
+        l31, half = lane & 31, lane >> 5
+        r, c = 32 * rt + l31, 16 * ks + 8 * (t >> 2) + 4 * half + (t & 3)
+        assert got[rt, ks, lane, t] == w[r, c], (rt, ks, lane, t)
+    # every source element appears exactly once
+    flat = idx[(torch.arange(mid // 32).view(-1, 1, 1, 1) * 32 + (torch.arange(64).view(1, 1, -1, 1) & 31)),
+               (torch.arange(cout // 16).view(1, -1, 1, 1) * 16 + 8 * (torch.arange(8).view(1, 1, 1, -1) >> 2)
+                + 4 * (torch.arange(64).view(1, 1, -1, 1) >> 5) + (torch.arange(8).view(1, 1, 1, -1) & 3))]
+    assert sorted(flat.flatten().tolist()) == list(range(mid * cout))
+    assert ops.chain_worthwhile(54 * 150 * 250, 64) and ops.chain_worthwhile(54 * 38 * 63, 256)
+    assert not ops.chain_worthwhile(38 * 63, 256) and not ops.chain_worthwhile(8 * 38 * 63, 256) and not ops.chain_worthwhile(75 * 125, 128)
