@@ -261,9 +261,22 @@ def main():
     ap.add_argument('--stem', default='hip', choices=['hip', 'miopen'], help='7x7 stem conv: MFMA implicit GEMM or library')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of hipGraph replays')
     ap.add_argument('--shapes', action='store_true', help='print per-shape GEMM/conv times to stderr')
+    ap.add_argument('--head-init-std', type=float, default=0.05,
+                    help='std of the random cls_score / bbox_pred weights (reference init: 0.01, which makes every class posterior '
+                         '~1/81 and the parity block blind to the head; the cost of the step does not depend on it)')
+    ap.add_argument('--stub', action='store_true', help='launcher dry run: gloo ranks on CPU, a stub step instead of the detector')
     a = ap.parse_args()
     if a.batch is None:
         a.batch = 8 if a.train else 54
+
+    # `python bench.py --gpus N` with no torchrun environment: start the N ranks ourselves (one process per GPU, RCCL over
+    # xGMI) -- the reference trains over len(ctx) devices from one command too (train_end2end.py:69-71)
+    from importlib import import_module
+    launcher = import_module('relation-networks-for-object-detection_amd.launch')
+    if a.gpus > 1 and not launcher.under_torchrun():
+        sys.exit(launcher.respawn(os.path.abspath(__file__), sys.argv[1:], a.gpus))
+    if a.stub:
+        return launcher.stub_bench(a)
 
     import __graft_entry__ as ge
     ge.build()
@@ -274,7 +287,11 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     rank, world, local = D.init(backend='nccl')          # 'nccl' = RCCL over xGMI
-    assert world == a.gpus or world == 1, "WORLD_SIZE=%d but --gpus %d" % (world, a.gpus)
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but %d rank(s) came up (WORLD_SIZE): refusing to report a %d-GPU number"
+                         % (a.gpus, world, a.gpus))
+    ranks_seen = int(D.sum_over_ranks(1, device='cuda'))   # counted THROUGH the collective library, not read from the environment
+    assert ranks_seen == a.gpus, (ranks_seen, a.gpus)
 
     if a.train:
         bench_train(a, rank, world, D)
@@ -284,6 +301,10 @@ def main():
         return
     tdt = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
     params = backbone.init_params(seed=1, dcn_offset_std=0.01 if a.dcn else 0.0, fpn=a.fpn)
+    if a.head_init_std != 0.01:
+        gh = torch.Generator().manual_seed(5)
+        for k in ('cls_score_weight', 'bbox_pred_weight'):
+            params[k] = torch.randn(params[k].shape, generator=gh) * a.head_init_std
     cfg = detector.Config()
     cfg.learn_nms = a.learn_nms
     cfg.dcn = a.dcn
@@ -376,7 +397,8 @@ def main():
                                        'inference graph of BASELINE configs[4] (FPN, 800x1024 images, 1000 given proposals): ' if a.fpn else ''),
                                       '2 relation modules (N=300, 16 heads, d=1024)' if not a.no_relation else 'plain 2FC head',
                                       'learn-NMS (first_n 100, 80 classes)' if a.learn_nms else 'soft-NMS(0.6)'),
-                       'images_per_gpu_per_step': a.batch, 'launch': 'eager' if a.no_graph else 'hipGraph replay', 'parallelism': 'replicas x%d (no data-path collective)' % world},
+                       'images_per_gpu_per_step': a.batch, 'launch': 'eager' if a.no_graph else 'hipGraph replay', 'parallelism': 'replicas x%d (no data-path collective)' % world,
+                       'ranks_seen_by_rccl': ranks_seen, 'head_init_std': a.head_init_std},
         }
         if timer is not None:
             ks = timer.summary()
@@ -396,7 +418,7 @@ def main():
                 if os.path.exists(pmc):
                     traffic = json.load(open(pmc)).get('hbm_bytes_per_launch_at_batch', {}).get(str(a.batch))
                 res['roofline'] = {
-                    'kernel': 'relation_attention_lds_kernel (csrc/relation.hip; the fp32 run uses relation_attention_kernel)', 'bound': 'mfma',
+                    'kernel': 'relation_attention_lds_kernel' if a.dtype == 'bf16' else 'relation_attention_kernel<float>', 'bound': 'mfma',
                     'achieved': algo, 'peak': peak, 'unit': 'TFLOP/s', 'frac': algo / peak, 'traffic': traffic,
                     'executed': EXEC_GFLOP_PER_MODULE_IMAGE * rs * a.batch / 1e3 / sec,
                     'launch_ms': att['avg_ms'], 'launches': att['calls'],

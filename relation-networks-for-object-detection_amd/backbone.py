@@ -215,12 +215,14 @@ class Backbone(object):
         ends = {}
         y_next = None
         side, hooked = None, None
+        self.last_chain_units, self.last_side_stream = [], False      # what actually ran (reported by oracle/parity.py)
         for stage, nm, ic, mc, oc, stride, dil, proj in self.units:
             if stage == 5 and conv4 is None:
                 conv4 = x
                 if rpn_hook is not None and not self.fpn:      # fork: RPN head + hook next to res5
                     main = torch.cuda.current_stream()
                     side = self._side_stream()
+                    self.last_side_stream = True
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
                         hooked = self._rpn_head(conv4)
@@ -242,6 +244,7 @@ class Backbone(object):
             if ch is not None and not ops.chain_worthwhile(y.numel() // y.shape[-1], y.shape[-1]):
                 ch = None            # small maps (B = 1, late stages at small B): the tiled convolution kernels fill the GPU better
             if ch is not None:       # expand + shortcut + ReLU and the next unit's reduce + ReLU in one pixel-wise kernel
+                self.last_chain_units.append(nm)
                 x, y_next = ops.bottleneck_chain(y, sc.contiguous(), *ch)
             else:
                 x = self._hconv(y, 'res%s_branch2c' % nm, relu=True, resid=sc)     # relu(bn(conv) + shortcut)

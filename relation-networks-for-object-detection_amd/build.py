@@ -18,7 +18,8 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', 
 def _digest():
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.h'))):
-        h.update(f.encode()); h.update(open(f, 'rb').read())
+        h.update(os.path.basename(f).encode()); h.update(open(f, 'rb').read())     # file NAME, not its absolute path: the
+        # library linked in this container is then reused as it is on the GPU box (same image, same hipcc)
     h.update(' '.join(FLAGS).encode())
     return h.hexdigest()
 

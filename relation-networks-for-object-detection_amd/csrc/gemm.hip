@@ -1457,7 +1457,7 @@ static bool launch_panel(const GemmArgs& g0, int batch, int out_dtype, hipStream
 }
 static int pick_tile(long M, long N, long K, int batch, int out_dtype, int has_resid, int has_wf = 0) {
   // Picked from on-device timings of every GEMM / convolution shape of the detector at 16
-  // images per launch (tests/_bench_gemm.py; table in DESIGN.md): wide tiles cut the
+  // images per launch (tools/bench_gemm.py; table in DESIGN.md): wide tiles cut the
   // L2 -> LDS fill traffic of the compute-bound 3x3 / large-K layers, 128-row tiles keep more
   // workgroups resident for the short-K, store-bound expand convolutions.
   int cfg;

@@ -76,20 +76,22 @@ class Detector(object):
         arg, aux = ck.load_param(prefix, epoch, process=True)
         return cls(ck.merge_params(arg, aux), **kw)
 
-    def forward(self, data, im_info, post=True):
-        """data [B,3,H,W], im_info [B,3] fp32 (device).  No host synchronisation inside."""
+    def forward(self, data, im_info, post=True, keep_features=False):
+        """data [B,3,H,W], im_info [B,3] fp32 (device).  No host synchronisation inside.
+        keep_features: also return the backbone maps of THIS call under 'features' (conv4, conv5, conv_new_1_relu, RPN maps)
+        and the head's intermediates (attention_1/2, fc_all_1/2_relu) under 'head' -- what oracle/parity.py checks."""
         c = self.cfg
         B = data.shape[0]
         propose = lambda cls, box: propose_batch(cls.float(), box.float(), im_info, self.anchors, c.feat_stride,
                                                  c.rpn_pre_nms_top_n, c.rpn_post_nms_top_n, c.rpn_nms_thresh, c.rpn_min_size,
-                                                 im_hw=self.im_hw, softmax_pairs=True)
+                                                 im_hw=self.im_hw, softmax_pairs=True, want_num=True)
         if self.overlap_rpn and self.backbone.impl == 'hip' and B >= 4:   # RPN head + proposal on a side stream, beside res5
             # (measured: at one image per step the fork / join costs more than the overlap returns: 3.3 -> 4.5 ms)
             f = self.backbone.forward(data, rpn_hook=propose)
-            rois, roi_scores = f['rpn_hook']
+            rois, roi_scores, num_kept = f['rpn_hook']
         else:
             f = self.backbone.forward(data)
-            rois, roi_scores = propose(f['rpn_cls_score'], f['rpn_bbox_pred'])
+            rois, roi_scores, num_kept = propose(f['rpn_cls_score'], f['rpn_bbox_pred'])
         N = rois.shape[1]
         if c.dcn:                 # SYM_DCN_RELNMS:1073-1080
             feat, r5, sc = f['conv_new_1_relu'], rois.view(B * N, 5), 1.0 / c.feat_stride
@@ -103,8 +105,15 @@ class Detector(object):
             pooled = ops.roi_pool(f['conv_new_1_relu'], rois.view(B * N, 5), (7, 7), 1.0 / c.feat_stride,
                                   channels_last_out=True)
         pooled = pooled.permute(0, 2, 3, 1).reshape(B, N, -1)              # (ph, pw, c) order, no copy
-        cls_score, bbox_pred, feat = self.head.forward(pooled, rois)
-        out = dict(rois=rois, cls_score=cls_score, bbox_pred=bbox_pred, fc_all_2_relu=feat)
+        if keep_features and self.relation:
+            hd = self.head.forward(pooled, rois, return_intermediates=True)
+            cls_score, bbox_pred, feat = hd['cls_score'], hd['bbox_pred'], hd['fc_all_2_relu']
+        else:
+            hd = None
+            cls_score, bbox_pred, feat = self.head.forward(pooled, rois)
+        out = dict(rois=rois, roi_scores=roi_scores, num_kept=num_kept, cls_score=cls_score, bbox_pred=bbox_pred, fc_all_2_relu=feat)
+        if keep_features:
+            out['features'], out['head'], out['pooled'] = f, hd, pooled
         if self.lnms is not None and post:                 # symbols/..._learn_nms.py:518-565 + tester.py:231-242
             out.update(self.lnms.forward(cls_score.contiguous(), bbox_pred.contiguous(), rois, im_info, feat))
             return out

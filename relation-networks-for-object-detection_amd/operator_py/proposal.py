@@ -43,9 +43,11 @@ def _parse_tuple(s):
 
 
 def propose_batch(cls_prob, bbox_pred, im_info, anchors, feat_stride, pre_nms_top_n, post_nms_top_n,
-                  threshold, min_size, want_debug=False, im_hw=None, softmax_pairs=False):
+                  threshold, min_size, want_debug=False, im_hw=None, softmax_pairs=False, want_num=False):
     """Batched proposal: cls_prob [B,2A,H,W], bbox_pred [B,4A,H,W], im_info [B,3] ->
-    rois [B, post, 5] (column 0 = image index in the batch), scores [B, post]."""
+    rois [B, post, 5] (column 0 = image index in the batch), scores [B, post] (want_num: + num_keep [B] int32, the
+    number of boxes that survived NMS before padding: where it is < post the reference pads with `npr.choice` (random,
+    proposal.py:154-156) and this operator with keep[i mod num_keep] -- a documented, unavoidable difference)."""
     boxes, scores = ops.proposal_decode(cls_prob, bbox_pred, im_info, anchors, feat_stride, min_size,
                                         im_hw=im_hw, softmax_pairs=softmax_pairs)
     n = scores.shape[1]
@@ -57,6 +59,8 @@ def propose_batch(cls_prob, bbox_pred, im_info, anchors, feat_stride, pre_nms_to
         r = ops.nms_sorted(det, threshold, post=post_nms_top_n, counts=count, want_keep=want_debug)
     if want_debug:
         return r['rois'], r['scores'], dict(det=det, order=index, keep=r['keep'], num_keep=r['num_keep'])
+    if want_num:
+        return r['rois'], r['scores'], r['num_keep']
     return r['rois'], r['scores']
 
 

@@ -384,11 +384,14 @@ CHAIN_MIDS = (64, 128)      # bottleneck widths relnet_bottleneck_chain is built
 CHAIN_EXPAND_MIDS = (64, 128, 256, 512)      # ... and for its expand + shortcut + ReLU form without the second product (res4, res5 too)
 
 
+CHAIN_MIN_PIXELS = {64: 16384, 'streamed': 98304}     # tests lower these to run the chain kernels on small maps
+
+
 def chain_worthwhile(pixels, mid):
     """The chain kernels are persistent with one workgroup per CU; the streamed forms (mid >= 128) walk lock-step sets of
     8 x 32 pixels, so they need >= ~1.5 sets per CU (256 CUs) to beat the tiled convolution kernels (measured: B = 1 / B = 8
     steps are slower with them on the small late-stage maps)."""
-    return pixels >= (16384 if mid == 64 else 98304)
+    return pixels >= CHAIN_MIN_PIXELS[64 if mid == 64 else 'streamed']
 
 
 def pack_chain_w1(w_packed):

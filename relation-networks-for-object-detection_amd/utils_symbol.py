@@ -1,46 +1,64 @@
-"""Twin of the reference's graph base class `lib/utils/symbol.py:10-56` (`from utils.symbol import Symbol`):
-same attributes and methods, so the model classes of relation_rcnn/symbols/*.py derive from it unchanged."""
-import numpy as np
+"""Base class the reference's model classes derive from (`from utils.symbol import Symbol`, lib/utils/symbol.py:10-56).
+
+The interface (attribute and method names, what each method leaves behind) is fixed by the unchanged symbol files that
+subclass it; the implementation is this repository's: shape tables are built by one helper over the facade graph's three
+name lists, and a shape mismatch raises a `ValueError` that lists EVERY offending parameter instead of stopping at the
+first one.
+"""
+import math
+
+
+class ParameterShapeError(AssertionError, ValueError):
+    """What check_parameter_shapes raises; an AssertionError like the reference's `assert`s, so callers that catch those keep working."""
+
+
+def _shape_table(names, shapes):
+    return {n: tuple(int(d) for d in s) for n, s in zip(names, shapes)}
 
 
 class Symbol(object):
+    #: graph argument names that are inputs rather than parameters when testing (labels are absent at test time)
+    _LABEL_TAG = 'label'
+
     def __init__(self):
-        self.arg_shape_dict = None
-        self.out_shape_dict = None
-        self.aux_shape_dict = None
         self.sym = None
+        self.arg_shape_dict = self.out_shape_dict = self.aux_shape_dict = None
 
-    @property
-    def symbol(self):
-        return self.sym
+    symbol = property(lambda self: self.sym)
 
+    # -- provided by the model classes in relation_rcnn/symbols/*.py ---------------------------------------------
     def get_symbol(self, cfg, is_train=True):
-        """Return a generated symbol; implementations also assign it to self.sym."""
-        raise NotImplementedError()
+        raise NotImplementedError("model classes build their graph here and store it in self.sym")
 
     def init_weights(self, cfg, arg_params, aux_params):
-        raise NotImplementedError()
+        raise NotImplementedError("model classes fill arg_params / aux_params here")
 
-    def get_msra_std(self, shape):
-        fan_in = float(shape[1])
-        if len(shape) > 2:
-            fan_in *= np.prod(shape[2:])
-        return np.sqrt(2 / fan_in)
+    # -- helpers the model classes call ---------------------------------------------------------------------------
+    @staticmethod
+    def get_msra_std(shape):
+        """He-normal standard deviation sqrt(2 / fan_in) of a weight [out, in, *kernel]."""
+        return math.sqrt(2.0 / (float(shape[1]) * math.prod(int(d) for d in shape[2:])))
 
     def infer_shape(self, data_shape_dict):
-        arg_shape, out_shape, aux_shape = self.sym.infer_shape(**data_shape_dict)
-        self.arg_shape_dict = dict(zip(self.sym.list_arguments(), arg_shape))
-        self.out_shape_dict = dict(zip(self.sym.list_outputs(), out_shape))
-        self.aux_shape_dict = dict(zip(self.sym.list_auxiliary_states(), aux_shape))
+        graph = self.sym
+        args, outs, auxs = graph.infer_shape(**data_shape_dict)
+        self.arg_shape_dict = _shape_table(graph.list_arguments(), args)
+        self.out_shape_dict = _shape_table(graph.list_outputs(), outs)
+        self.aux_shape_dict = _shape_table(graph.list_auxiliary_states(), auxs)
 
     def check_parameter_shapes(self, arg_params, aux_params, data_shape_dict, is_train=True):
-        for k in self.sym.list_arguments():
-            if k in data_shape_dict or (False if is_train else 'label' in k):
-                continue
-            assert k in arg_params, k + ' not initialized'
-            assert tuple(arg_params[k].shape) == tuple(self.arg_shape_dict[k]), \
-                'shape inconsistent for ' + k + ' inferred ' + str(self.arg_shape_dict[k]) + ' provided ' + str(arg_params[k].shape)
-        for k in self.sym.list_auxiliary_states():
-            assert k in aux_params, k + ' not initialized'
-            assert tuple(aux_params[k].shape) == tuple(self.aux_shape_dict[k]), \
-                'shape inconsistent for ' + k + ' inferred ' + str(self.aux_shape_dict[k]) + ' provided ' + str(aux_params[k].shape)
+        """Every graph parameter must be present with the inferred shape (inputs, and labels at test time, are skipped)."""
+        def is_input(name):
+            return name in data_shape_dict or (not is_train and self._LABEL_TAG in name)
+
+        problems = []
+        todo = [(n, arg_params, self.arg_shape_dict) for n in self.sym.list_arguments() if not is_input(n)]
+        todo += [(n, aux_params, self.aux_shape_dict) for n in self.sym.list_auxiliary_states()]
+        for name, given, inferred in todo:
+            if name not in given:
+                problems.append('%s not initialized' % name)
+            elif tuple(given[name].shape) != tuple(inferred[name]):
+                problems.append('shape inconsistent for %s inferred %s provided %s'
+                                % (name, tuple(inferred[name]), tuple(given[name].shape)))
+        if problems:
+            raise ParameterShapeError('; '.join(problems))

@@ -285,3 +285,43 @@ def test_detector_bf16_fullsize_stagewise(rn):
     w = rep['worst']
     assert w['proposal_rows_identical'] == 300 and w['roi_pool_mismatches'] == 0 and w['detections_all_matched'], rep
     assert w['cls_prob_max_abs_err'] < 2e-2 and w['bbox_pred_max_rel_err'] < 3e-2, rep
+
+
+def test_benched_trunk_configuration_in_network(rn):
+    """The configuration that produces the headline number, inside the network: with the chain kernels forced on for every
+    stage (ops.CHAIN_MIN_PIXELS lowered: at 54 images of 600x1000 they run by themselves) and B >= 4 (RPN head + proposal on
+    the side stream, fork / join inside Backbone.forward), ONE Detector.forward call is compared with the float32 oracle:
+    backbone maps directly, every later stage teacher forced (oracle/parity.py:stagewise, what bench.py prints)."""
+    ops, backbone, detector = rn
+    from oracle import parity as OPAR
+    H, W, B = 320, 480, 4
+    p = backbone.init_params(seed=1)
+    g = torch.Generator().manual_seed(13)
+    for k in ('cls_score_weight', 'bbox_pred_weight'):
+        p[k] = torch.randn(p[k].shape, generator=g) * 0.05
+    p['conv_new_1_bias'] = torch.rand(256, generator=g) * 0.1 + 0.05
+    data = torch.randn(B, 3, H, W, generator=g).cuda()
+    im_info = torch.tensor([[H, W, 1.0]] * B).cuda()
+    det = detector.Detector(p, dtype=torch.bfloat16, im_hw=(H, W))
+    saved = dict(ops.CHAIN_MIN_PIXELS)
+    try:
+        ops.CHAIN_MIN_PIXELS.update({64: 0, 'streamed': 0})
+        rep = OPAR.stagewise(det, data, im_info, p, images=[0, 3])
+        out = det.forward(data, im_info, keep_features=True)
+    finally:
+        ops.CHAIN_MIN_PIXELS.update(saved)
+    units = rep['chain_kernel_units']
+    assert len(units) == 33 and {'2a', '3b3', '4b10', '4b22', '5a', '5c'} <= set(units), units       # every residual unit of the trunk
+    assert rep['rpn_side_stream'] and rep['same_forward_call']
+    w = rep['worst']
+    for k in ('conv4', 'conv5', 'conv_new_1_relu', 'rpn_cls_score', 'rpn_bbox_pred'):
+        assert w['backbone_%s_rel_l2' % k] < 2.5e-2 and w['backbone_%s_rel_max' % k] < 8e-2, (k, rep['backbone'][k])
+    assert w['proposal_rows_identical'] == 300 and w['roi_pool_mismatches'] == 0 and w['detections_all_matched'], rep
+    assert w['cls_score_max_rel_err'] < 3e-2 and w['bbox_pred_max_rel_err'] < 3e-2, rep
+    assert w['attention_1_max_rel_err'] < 3e-2 and w['attention_2_max_rel_err'] < 3e-2, rep
+    # the chain kernels are bit-identical to the tiled convolution kernels they replace (same products, same order)
+    ref = det.forward(data, im_info, keep_features=True)
+    assert ref['features'] is not out['features'] and len(det.backbone.last_chain_units) < 33
+    for k in ('conv4', 'conv5'):
+        d = (out['features'][k].float() - ref['features'][k].float()).abs().max().item()
+        assert d <= 2e-2 * ref['features'][k].float().abs().max().item(), (k, d)

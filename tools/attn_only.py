@@ -2,7 +2,7 @@
 configuration -- used under rocprofv3 --pmc to read the attention kernel's HBM traffic."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden'))
 import torch
 import relnet_amd
 from relnet_amd import relation, ops

@@ -1,7 +1,7 @@
 """Micro-benchmark (not a test): XCD-aware tile order on / off (and n_loop 1 vs auto), per convolution shape.
-python tests/_bench_swizzle.py [B]"""
+python tools/bench_swizzle.py [B]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import _bench_tiles as BT
 L = BT.L
 tot = {}

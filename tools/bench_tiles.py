@@ -1,5 +1,5 @@
 """Micro-benchmark (not a test): every convolution shape of the detector at B images, per tile configuration.
-python tests/_bench_tiles.py [B]   -> prints the time of tile configs 0 (auto) / 1 / 2 / 3 / 4 per shape."""
+python tools/bench_tiles.py [B]   -> prints the time of tile configs 0 (auto) / 1 / 2 / 3 / 4 per shape."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,5 @@
 """Launch the three res4 convolution shapes of the default bench (54 images) a few times -- used under rocprofv3 --pmc to
-read HBM traffic and MFMA utilisation of the implicit-GEMM kernel:  python tests/_conv_only.py [B] [iters]"""
+read HBM traffic and MFMA utilisation of the implicit-GEMM kernel:  python tools/conv_only.py [B] [iters]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,7 +1,7 @@
 """Time the fused geometry + attention kernel alone at the bench configuration (env RELNET_FUSED_ABLATE for experiments)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden'))
 import torch
 import relnet_amd
 from relnet_amd import relation, ops

@@ -1,4 +1,4 @@
-"""Small training-step smoke run (GPU): python tests/_train_smoke.py [B] [H] [W]"""
+"""Small training-step smoke run (GPU): python tools/train_smoke.py [B] [H] [W]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
