@@ -166,14 +166,10 @@ def bench_train(a, rank, world, D, emit=True):
     im_info = torch.tensor([[float(H), float(W), 1.0]] * B).cuda()
     rng = np.random.default_rng(2 + rank)
     gt = np.zeros((B, G, 5), np.float32)
-    labs, tgts, wgts = [], [], []
     for b in range(B):                      # 8 gt boxes, w,h in [32,400], classes uniform in 1..80
         bw, bh = rng.uniform(32, 400, G), rng.uniform(32, 400, G)
         x1, y1 = rng.uniform(0, W - 1 - bw), rng.uniform(0, H - 1 - bh)
         gt[b] = np.stack([x1, y1, x1 + bw, y1 + bh, rng.integers(1, 81, G)], 1)
-        if not a.fpn:
-            L, Tg, Wg = train.assign_anchor((38, 63), gt[b], (H, W), cfg, seed=b)  # host loader work, outside the step
-            labs.append(L); tgts.append(Tg); wgts.append(Wg)
     if a.fpn:       # proposals are an input of the FPN graphs (HAS_RPN: false, TOP_ROIS 1000): log-uniform sizes over all levels
         n_rois = 1000
         side = torch.exp(torch.empty(B, n_rois).uniform_(math.log(16), math.log(640), generator=g))
@@ -181,9 +177,8 @@ def bench_train(a, rank, world, D, emit=True):
         bw_, bh_ = (side * ar).clamp(max=W - 2), (side / ar).clamp(max=H - 2)
         x1_ = torch.rand(B, n_rois, generator=g) * (W - 1 - bw_); y1_ = torch.rand(B, n_rois, generator=g) * (H - 1 - bh_)
         batch = (data, im_info, torch.as_tensor(gt).cuda(), torch.stack([x1_, y1_, x1_ + bw_, y1_ + bh_], 2).cuda())
-    else:
-        batch = (data, im_info, torch.as_tensor(gt).cuda(), torch.as_tensor(np.stack(labs)).cuda(),
-                 torch.as_tensor(np.stack(tgts)).cuda(), torch.as_tensor(np.stack(wgts)).cuda())
+    else:       # RPN anchor labels / targets (lib/rpn/rpn.py:assign_anchor, host numpy in the reference's loader) are computed
+        batch = (data, im_info, torch.as_tensor(gt).cuda())       # on the device INSIDE the step (relnet_assign_anchor)
 
     def fence():
         D.fence(device='cuda')

@@ -113,7 +113,7 @@ int relnet_stem_bias_relu_pool(const void* in, const float* bias, void* out, int
  * divisors8: HOST array, wave_length^(k/8) in fp32; bias [nmod,B,16,N,Mpad] fp32.
  * pos_mat [B,N,M,4] / pos_emb [B,N,M,64]: optional debug outputs (NULL to skip).                   */
 int relnet_geometry_bias(const float* boxes, int box_stride, int box_off, const float* wp_t, const float* bp,
-                         const float* divisors8, void* bias, int bias_half /*1: fp16 output*/, float* pos_mat,
+                         const float* divisors8, void* bias, int bias_half /* 0: float32 log G in the oracle's arithmetic (sin / cos / log correctly rounded, float64 accumulation: the parity path); 1: fp16 log2 G (bf16 throughput path, matrix cores); -1: float32 log G with float32 libm arithmetic (training recompute) */, float* pos_mat,
                          float* pos_emb, int B, int N, int M, int Mpad, int fc_dim, int nmod, void* stream);
 
 /* ---- SYM_REL:132-150: logits = bias + scale * Q K^T (`weighted_aff`), softmax over keys, value sum
@@ -127,6 +127,17 @@ int relnet_relation_attention(const void* q, long q_ld, long q_bs, const void* k
                               long out_ld, long out_bs, void* out_act, long act_ld, long act_bs, float* logits,
                               int B, int H, int N, int M, int Mpad, float scale, int in_dtype, int out_dtype,
                               void* stream);
+
+/* Same, for a FIXED-SIZE roi buffer that holds a different number of real rows per image (the reference runs one image
+ * per executor, so its graphs simply see a different roi count each time: the FPN loader's dummy roi of an empty level,
+ * core/rcnn.py:61-71, TRAIN.TOP_ROIS truncation :128-146): key_count [B] (device, may be NULL) = keys of image b that exist;
+ * keys in [key_count[b], M) are masked exactly like the columns past M.                                              */
+int relnet_relation_attention_kc(const void* q, long q_ld, long q_bs, const void* k, long k_ld, long k_bs,
+                                 const void* vwt, long vwt_ld, long vwt_bs, const void* bias, int bias_half,
+                                 long bias_bs, const float* bout, const void* resid, long resid_ld, long resid_bs, void* out,
+                                 long out_ld, long out_bs, void* out_act, long act_ld, long act_bs, float* logits,
+                                 int B, int H, int N, int M, int Mpad, float scale, int in_dtype, int out_dtype,
+                                 const int* key_count, void* stream);
 
 /* Geometry + attention of ONE relation module in a single kernel (bf16 throughput path; csrc/relation.hip:
  * relation_fused_kernel): the position embedding (SYM_REL:29-83), pair_pos_fc1 + ReLU + log (:109-116, :139) and the
@@ -172,6 +183,11 @@ int relnet_conv2d_nhwc_wf(const void* in, long in_pix, long in_img, const void* 
 int relnet_detect_head(const float* cls_score, long cs_ld, const float* bbox_pred, long bp_ld, const float* rois,
                        const float* im_info, float* cls_prob, double* boxes, int R, int C, int rois_per_image,
                        int delta_off, void* stream);
+/* ..._ex: n_valid [B] (device, may be NULL): rows past n_valid[b] of image b are padding of a fixed-size roi buffer
+ * (see relnet_fpn_roi_dispatch_ex) and get all-zero probabilities / boxes, i.e. they can never become detections.  */
+int relnet_detect_head_ex(const float* cls_score, long cs_ld, const float* bbox_pred, long bp_ld, const float* rois,
+                          const float* im_info, float* cls_prob, double* boxes, int R, int C, int rois_per_image,
+                          int delta_off, const int* n_valid, void* stream);
 /* lib/nms/nms.py:85-141 soft_nms (soft != 0, nms_param = sigma) or :45-82 nms (nms_param = IoU
  * threshold), float64 like numpy; dets [B,C-1,N,5] in pick order, counts [B,C-1].                    */
 int relnet_class_nms(const float* cls_prob, const double* boxes, double* dets, int* counts, int B, int N, int C,
@@ -193,6 +209,10 @@ int relnet_image_topk(const double* dets, const int* counts, double* thresh, int
 int relnet_lnms_prepare(const float* cls_score, long cs_ld, const float* bbox_pred, long bp_ld, const float* rois,
                         const float* im_info, float* prob /*[B,N,C-1]*/, float* boxes /*[B,N,4]*/, int B, int N,
                         int C, int delta_off, const float* means4, const float* stds4, void* stream);
+/* ..._ex: n_valid [B] (device, may be NULL): padding rows get probability 0 (they sort behind every real roi).       */
+int relnet_lnms_prepare_ex(const float* cls_score, long cs_ld, const float* bbox_pred, long bp_ld, const float* rois,
+                           const float* im_info, float* prob, float* boxes, int B, int N, int C, int delta_off,
+                           const float* means4, const float* stds4, const int* n_valid, void* stream);
 /* :289-308: per (image, class) descending sort, first_n ranks; rank_idx [B,NC,F], sorted_score [B,F,NC],
  * sorted_bbox [B,F,NC,4], class_boxes [B,NC,F,4], class_max [B,NC].  Ties: smaller roi index first.  */
 int relnet_lnms_sort(const float* prob, const float* boxes, int* rank_idx, float* sorted_score, float* sorted_bbox,
@@ -219,6 +239,28 @@ int relnet_proposal_target(const float* rois, const float* gt, const int* num_gt
                            float* bbox_target, float* bbox_weight, int B, int N, int Gmax, int num_reg,
                            int class_agnostic, float bg_thresh_hi, const double* means4, const double* stds4,
                            const double* weights4, void* stream);
+/* ..._ex: num_rois [B] (device, may be NULL): only the first num_rois[b] of the N input rows of image b are proposals
+ * (core/rcnn.py:128-146 hands the reference a different roi count per image; a batched step pads to a common N): the
+ * padded rows come out like the rows past num_gt -- zero box, label -1, zero weights -- so no loss ever sees them. */
+int relnet_proposal_target_ex(const float* rois, const float* gt, const int* num_gt, float* rois_out, float* label,
+                              float* bbox_target, float* bbox_weight, int B, int N, int Gmax, int num_reg,
+                              int class_agnostic, float bg_thresh_hi, const double* means4, const double* stds4,
+                              const double* weights4, const int* num_rois, void* stream);
+/* lib/rpn/rpn.py:80-244 `assign_anchor(feat_shape, gt_boxes, im_info, cfg, feat_stride, scales, ratios, allowed_border)`
+ * -- RPN labels / regression targets, host numpy inside the reference's data loader -- for B images on the device.
+ * gt [B,Gmax,5] float32, num_gt [B], im_info [B,3]; base_anchors: HOST double [A,4] (generate_anchors); outputs in the
+ * reference's layouts: label [B, A*fh*fw] ((a, y, x) order, -1 / 0 / 1), bbox_target and bbox_weight [B, 4A, fh, fw];
+ * label_all (may be NULL) = the labels before sub-sampling; workspace: B*Gmax 64-bit words.  float64 overlaps and
+ * bbox_transform as numpy.  The random sub-sampling (npr.choice, :189-204) keeps the anchors with the LARGEST keys,
+ * key = 32-bit hash of (seed, image, anchor index in (y, x, a) order): a uniformly random subset for every seed,
+ * reproducible and independent of the launch geometry (oracle/anchors.py restates the hash).  seed_dev (may be NULL):
+ * a device word added to `seed` -- a step counter that a captured hipGraph advances, so replays draw fresh subsets.   */
+int relnet_assign_anchor(const float* gt, const int* num_gt, const float* im_info, const double* base_anchors,
+                         float* label, float* bbox_target, float* bbox_weight, float* label_all,
+                         unsigned long long* workspace, int B, int A, int feat_h, int feat_w, int Gmax, int feat_stride,
+                         int rpn_batch_size, int num_fg, double negative_overlap, double positive_overlap,
+                         int clobber_positives, int allowed_border, unsigned long long seed,
+                         const unsigned long long* seed_dev, void* stream);
 /* operator_py/box_annotator_ohem.py:26-53: per-roi loss (-log softmax[label] + sum w*smooth_l1), keep the
  * roi_per_img largest; others get label -1 / zero weights.  R <= 2048.  loss [B,R] optional.           */
 int relnet_box_annotator_ohem(const float* cls_score, const float* bbox_pred, const float* labels,
@@ -261,10 +303,19 @@ int relnet_deformable_psroi_pool_fwd(const void* data, const long* data_strides4
  * feat_id = clip(floor(2 + log2(sqrt(w*h)/224)), 0, 3) per roi and the stable regrouping by level in which
  * symbols/resnet_v1_101_rcnn_fpn_..._learn_nms.py:1108-1121 concatenates rois_0..rois_3.  rois: [B,N,box_stride]
  * fp32 with x1,y1,x2,y2 at box_off.  Outputs: rois_out [B,N,5] (image index + base, box) level-sorted,
- * level_out [B,N], perm [B,N] (original row of each sorted row), counts [B,4].  The reference's all-zero dummy
- * roi for an empty level (rcnn.py:61-71) is NOT appended: counts tells the caller.                          */
+ * level_out [B,N], perm [B,N] (original row of each sorted row), counts [B,4].  This form does not append the
+ * reference's all-zero dummy roi of an empty level (rcnn.py:61-71): counts tells the caller; ..._ex does.            */
 int relnet_fpn_roi_dispatch(const float* rois, int box_stride, int box_off, float* rois_out, int* level_out,
                             int* perm, int* counts, int B, int N, int batch_index_base, void* stream);
+/* The loader's full behaviour on a fixed-size row buffer: outputs have n_out rows per image (n_out >= N + 4 when
+ * pad_empty).  Row order of an image: level 0 | level 1 | level 2 | level 3 | padding, where with pad_empty != 0 a level
+ * that received no roi contributes ONE all-zero roi (perm = -1) exactly as rcnn.py:61-71 builds it (test AND train
+ * loaders, :53-74 / :153-212).  n_valid [B] (may be NULL): only the first n_valid[b] input rows are rois; the others are
+ * moved behind the real rows as zero boxes (level 0, perm = their input row).  n_rows [B] (may be NULL) = real rows of
+ * the image (rois + dummies): feed it to relnet_relation_attention_kc (key_count) and relnet_detect_head_ex (n_valid). */
+int relnet_fpn_roi_dispatch_ex(const float* rois, int box_stride, int box_off, float* rois_out, int* level_out,
+                               int* perm, int* counts, int B, int N, int batch_index_base, const int* n_valid,
+                               int pad_empty, int n_out, int* n_rows, void* stream);
 
 /* The four mx.symbol.ROIPooling calls at 1/4, 1/8, 1/16, 1/32 + Concat(dim=0) (symbols/...fpn...:1108-1119)
  * as ONE launch: roi r pools from level roi_level[r].  data_levels / heights / widths / spatial_scales are
@@ -319,6 +370,14 @@ int relnet_relation_attention_bwd(const void* q, long q_ld, long q_bs, const voi
                                   long qt_bs, const void* dyt, long dyt_ld, long dyt_bs, float* prob, float* dlog,
                                   float* dq, float* dk, float* dvw, int B, int H, int N, int M, int Mpad, int Npad,
                                   float scale, int dtype, void* stream);
+/* ..._kc: key_count as in relnet_relation_attention_kc (masked keys get zero probability and zero gradients).       */
+int relnet_relation_attention_bwd_kc(const void* q, long q_ld, long q_bs, const void* k, long k_ld, long k_bs,
+                                     const void* kt, long kt_ld, long kt_bs, const void* vw, long vw_ld, long vw_bs,
+                                     const float* bias, long bias_bs, const void* dy, long dy_ld, long dy_bs,
+                                     const void* y, long y_ld, long y_bs, const float* bout, const void* qt, long qt_ld,
+                                     long qt_bs, const void* dyt, long dyt_ld, long dyt_bs, float* prob, float* dlog,
+                                     float* dq, float* dk, float* dvw, int B, int H, int N, int M, int Mpad, int Npad,
+                                     float scale, int dtype, const int* key_count, void* stream);
 
 /* d pair_pos_fc1_{weight [16][64], bias [16]} += from dlog and the forward's fp32 bias (= log max(G,1e-6)):
  * dpre = dlog / G where G > 1e-6; the 64-d embedding is recomputed from the boxes (SYM_REL:29-83).            */

@@ -242,15 +242,14 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
   ChainArgs a;
   a.m2 = (const unsigned short*)mid2; a.x = (const unsigned short*)x; a.w3f = (const uint4*)w3f; a.w1f = (const uint4*)w1f;
   a.b3 = b3; a.b1 = b1; a.xn = (unsigned short*)x_next; a.m1 = (unsigned short*)mid1_next; a.P = (int)P;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static relnet::PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<64, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<128, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<256, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<512, true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   const long ntile = (P + 31) / 32;
   const unsigned grid = (unsigned)(ntile < 8 * 256 ? (ntile + 7) / 8 : 256);     // persistent: one workgroup per CU
@@ -412,10 +411,9 @@ extern "C" int relnet_conv3x3_c64(const void* in, const void* w_frag, const floa
   a.in = (const unsigned short*)in; a.wf = (const uint4*)w_frag; a.bias = bias; a.out = (unsigned short*)out;
   a.B = B; a.H = H; a.W = W; a.relu = relu;
   a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static relnet::PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)conv3x3_c64_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   const long ntile = (long)B * a.tiles_x * a.tiles_y;
   const unsigned grid = (unsigned)(ntile < 256 ? ntile : 256);

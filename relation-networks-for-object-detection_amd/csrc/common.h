@@ -47,6 +47,21 @@ void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 }  // namespace relnet
 
+namespace relnet {
+// True exactly once per (call site, device): the "opt in to > 64 KiB dynamic LDS" attribute of a kernel is per DEVICE, so a
+// process that drives several GPUs has to set it on each of them (thread-safe: the flag word is atomic; setting the
+// attribute twice from two racing threads is harmless).
+struct PerDeviceOnce {
+  unsigned long long done = 0;
+  bool first() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    return (__atomic_fetch_or(&done, bit, __ATOMIC_ACQ_REL) & bit) == 0;
+  }
+};
+}  // namespace relnet
+
 #define RELNET_REQUIRE(cond, ...)            \
   do {                                       \
     if (!(cond)) {                           \

@@ -7,8 +7,9 @@
 //      (symbols/resnet_v1_101_rcnn_fpn_..._learn_nms.py:1108-1121 concatenates pooled features and rois in
 //      that level order).  The arithmetic is float32 like numpy's on float32 boxes, with log2 evaluated
 //      correctly rounded (fp64 log2 rounded once).
-//      Not reproduced: the all-zero dummy roi the reference appends for an EMPTY level (rcnn.py:61-71),
-//      which changes the number of rows; `counts` lets the caller detect that case.
+//      relnet_fpn_roi_dispatch_ex(pad_empty = 1) also appends the all-zero dummy roi of an EMPTY level (rcnn.py:61-71)
+//      into a fixed [B, N + 4] row buffer and reports the real row count per image (`n_rows`); rows past it are
+//      padding that the relation kernels skip as keys (`key_count`) and the post-processing kernels drop (`n_valid`).
 //  * relnet_upsample2x_add : mx.symbol.UpSampling(scale=2, sample_type='nearest') + ElementWiseSum of the
 //      top-down pathway (symbols/...fpn...:817-829), in place on the lateral map.
 #include "common.h"
@@ -19,11 +20,14 @@ enum { RELNET_F32 = 0, RELNET_BF16 = 1 };
 
 struct DispatchArgs {
   const float* rois; int box_stride, box_off;      // [B, N, box_stride], xyxy at box_off
-  float* rois_out;                                  // [B, N, 5] level-sorted, column 0 = image index + base
-  int* level_out;                                   // [B, N] level of each sorted row
-  int* perm;                                        // [B, N] original index of each sorted row
-  int* counts;                                      // [B, 4]
+  float* rois_out;                                  // [B, n_out, 5] level-sorted, column 0 = image index + base
+  int* level_out;                                   // [B, n_out] level of each sorted row
+  int* perm;                                        // [B, n_out] original index of each sorted row (-1: dummy / unused row)
+  int* counts;                                      // [B, 4] input rois per level (dummies not counted)
   int N, batch_index_base;
+  const int* n_valid;                               // [B] or nullptr: only the first n_valid[b] input rows are rois
+  int pad_empty, n_out;                             // pad_empty: one all-zero roi for every level without a roi (rcnn.py:61-71)
+  int* n_rows;                                      // [B] or nullptr: rows of this image that are real (rois + dummies)
 };
 
 #pragma clang fp contract(off)
@@ -35,58 +39,93 @@ __device__ __forceinline__ int fpn_level(float x1, float y1, float x2, float y2)
   return (int)fminf(fmaxf(v, 0.f), 3.f);                      // boxes are valid (x2 >= x1 - 1): w*h >= 0
 }
 
-// One workgroup (1024 threads = 16 waves) per image; N <= 16384.
+// One workgroup (1024 threads = 16 waves) per image; N <= 16384.  Output row order of an image:
+//   level 0 rois (input order) | level 1 | level 2 | level 3 | input rows past n_valid (padding) | unused rows up to n_out,
+// where with pad_empty a level without rois contributes ONE all-zero roi (perm -1), exactly the rows the reference's loader
+// builds (core/rcnn.py:53-74).  Rows >= n_rows[b] are padding: zero boxes, level 0, never real rois.
 __global__ __launch_bounds__(1024) void fpn_roi_dispatch_kernel(DispatchArgs g) {
-  __shared__ int wave_cnt[16][16][4];        // [chunk][wave][level]
-  __shared__ int base[16][16][4];
+  __shared__ int wave_cnt[16][16][5];        // [chunk][wave][level], level 4 = input rows past n_valid
+  __shared__ int base[16][16][5];
+  __shared__ int lvl_start[6];               // first output row of each group, [5] = first unused row
+  __shared__ int lvl_cnt[5];
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float* rois = g.rois + (long)b * g.N * g.box_stride;
   const int chunks = (g.N + 1023) / 1024;
+  const int nv = g.n_valid ? min(max(g.n_valid[b], 0), g.N) : g.N;
 #pragma unroll 1
   for (int c = 0; c < chunks; ++c) {
     const int i = c * 1024 + tid;
     int lv = -1;
     if (i < g.N) {
       const float* r = rois + (long)i * g.box_stride + g.box_off;
-      lv = fpn_level(r[0], r[1], r[2], r[3]);
+      lv = i < nv ? fpn_level(r[0], r[1], r[2], r[3]) : 4;
     }
 #pragma unroll
-    for (int l = 0; l < 4; ++l) {
+    for (int l = 0; l < 5; ++l) {
       const unsigned long long m = __ballot(lv == l);
       if (lane == 0) wave_cnt[c][wave][l] = __popcll(m);
     }
   }
   __syncthreads();
-  if (tid < 4) {                              // thread l: exclusive scan of level l, placed after the lower levels
-    int start = 0;
-    for (int ll = 0; ll < tid; ++ll)
-      for (int c = 0; c < chunks; ++c)
-        for (int w = 0; w < 16; ++w) start += wave_cnt[c][w][ll];
-    int run = start;
+  if (tid < 5) {                              // thread l: size of group l
+    int n = 0;
     for (int c = 0; c < chunks; ++c)
-      for (int w = 0; w < 16; ++w) { base[c][w][tid] = run; run += wave_cnt[c][w][tid]; }
-    g.counts[b * 4 + tid] = run - start;
+      for (int w = 0; w < 16; ++w) n += wave_cnt[c][w][tid];
+    lvl_cnt[tid] = n;
+    if (tid < 4) g.counts[b * 4 + tid] = n;
   }
   __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int l = 0; l < 5; ++l) {
+      lvl_start[l] = run;
+      run += lvl_cnt[l] + ((l < 4 && g.pad_empty && lvl_cnt[l] == 0) ? 1 : 0);
+      if (l == 3 && g.n_rows) g.n_rows[b] = run;
+    }
+    lvl_start[5] = run;
+  }
+  __syncthreads();
+  if (tid < 5) {                              // thread l: exclusive scan of group l over (chunk, wave)
+    int run = lvl_start[tid];
+    for (int c = 0; c < chunks; ++c)
+      for (int w = 0; w < 16; ++w) { base[c][w][tid] = run; run += wave_cnt[c][w][tid]; }
+  }
+  __syncthreads();
+  float* ro = g.rois_out + (long)b * g.n_out * 5;
+  int* lo = g.level_out + (long)b * g.n_out;
+  int* po = g.perm + (long)b * g.n_out;
+  const float bidx = (float)(b + g.batch_index_base);
 #pragma unroll 1
   for (int c = 0; c < chunks; ++c) {
     const int i = c * 1024 + tid;
     int lv = -1;
     const float* r = rois + (long)(i < g.N ? i : 0) * g.box_stride + g.box_off;
-    const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
-    if (i < g.N) lv = fpn_level(x1, y1, x2, y2);
+    float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
+    if (i < g.N) lv = i < nv ? fpn_level(x1, y1, x2, y2) : 4;
     int pos = -1;
 #pragma unroll
-    for (int l = 0; l < 4; ++l) {
+    for (int l = 0; l < 5; ++l) {
       const unsigned long long m = __ballot(lv == l);
       if (lv == l) pos = base[c][wave][l] + __popcll(m & ((1ull << lane) - 1ull));
     }
     if (i < g.N) {
-      float* o = g.rois_out + ((long)b * g.N + pos) * 5;
-      o[0] = (float)(b + g.batch_index_base); o[1] = x1; o[2] = y1; o[3] = x2; o[4] = y2;
-      g.level_out[(long)b * g.N + pos] = lv;
-      g.perm[(long)b * g.N + pos] = i;
+      if (lv == 4) { x1 = y1 = x2 = y2 = 0.f; }
+      float* o = ro + (long)pos * 5;
+      o[0] = bidx; o[1] = x1; o[2] = y1; o[3] = x2; o[4] = y2;
+      lo[pos] = lv == 4 ? 0 : lv;
+      po[pos] = i;
     }
+  }
+  if (tid < 4 && g.pad_empty && lvl_cnt[tid] == 0) {          // the dummy roi of an empty level
+    const int pos = lvl_start[tid];
+    float* o = ro + (long)pos * 5;
+    o[0] = bidx; o[1] = o[2] = o[3] = o[4] = 0.f;
+    lo[pos] = tid; po[pos] = -1;
+  }
+  for (int pos = lvl_start[5] + tid; pos < g.n_out; pos += 1024) {   // rows nobody owns
+    float* o = ro + (long)pos * 5;
+    o[0] = bidx; o[1] = o[2] = o[3] = o[4] = 0.f;
+    lo[pos] = 0; po[pos] = -1;
   }
 }
 #pragma clang fp contract(fast)
@@ -132,15 +171,23 @@ __global__ __launch_bounds__(256) void upsample2x_add_kernel(UpAddArgs g) {
 
 using namespace relnet;
 
-extern "C" int relnet_fpn_roi_dispatch(const float* rois, int box_stride, int box_off, float* rois_out,
-                                       int* level_out, int* perm, int* counts, int B, int N,
-                                       int batch_index_base, void* stream) {
+extern "C" int relnet_fpn_roi_dispatch_ex(const float* rois, int box_stride, int box_off, float* rois_out,
+                                          int* level_out, int* perm, int* counts, int B, int N, int batch_index_base,
+                                          const int* n_valid, int pad_empty, int n_out, int* n_rows, void* stream) {
   RELNET_REQUIRE(rois && rois_out && level_out && perm && counts, "relnet_fpn_roi_dispatch: null operand");
   RELNET_REQUIRE(B > 0 && N > 0 && N <= 16384, "relnet_fpn_roi_dispatch: need 0 < N <= 16384 rois per image, got %d", N);
   RELNET_REQUIRE(box_off >= 0 && box_off + 4 <= box_stride, "relnet_fpn_roi_dispatch: box_off %d / stride %d", box_off, box_stride);
-  DispatchArgs g{rois, box_stride, box_off, rois_out, level_out, perm, counts, N, batch_index_base};
+  RELNET_REQUIRE(n_out >= N + (pad_empty ? 4 : 0), "relnet_fpn_roi_dispatch: n_out %d < N %d%s", n_out, N, pad_empty ? " + 4 dummy rows" : "");
+  DispatchArgs g{rois, box_stride, box_off, rois_out, level_out, perm, counts, N, batch_index_base, n_valid, pad_empty, n_out, n_rows};
   fpn_roi_dispatch_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(g);
   return check_launch("relnet_fpn_roi_dispatch");
+}
+
+extern "C" int relnet_fpn_roi_dispatch(const float* rois, int box_stride, int box_off, float* rois_out,
+                                       int* level_out, int* perm, int* counts, int B, int N,
+                                       int batch_index_base, void* stream) {
+  return relnet_fpn_roi_dispatch_ex(rois, box_stride, box_off, rois_out, level_out, perm, counts, B, N, batch_index_base,
+                                    nullptr, 0, N, nullptr, stream);
 }
 
 extern "C" int relnet_upsample2x_add(const void* top, void* lateral, int B, int H, int W, int C, int dtype,

@@ -26,11 +26,17 @@ struct PrepArgs {
   float* boxes;                         // [B*N, 4]    refined + clipped
   int C, N, delta_off;
   float m0, m1, m2, m3, s0, s1, s2, s3; // bbox means / stds (0/1 when the graph passes None)
+  const int* n_valid;                   // optional [B]: rows past n_valid[b] are padding -> probability 0 (they sort last)
 };
 
 #pragma clang fp contract(off)
 __global__ __launch_bounds__(64) void lnms_prepare_kernel(PrepArgs g) {
   const int r = blockIdx.x, lane = threadIdx.x;
+  if (g.n_valid && (r % g.N) >= g.n_valid[r / g.N]) {
+    for (int c = lane + 1; c < g.C; c += 64) g.prob[(long)r * (g.C - 1) + c - 1] = 0.f;
+    if (lane == 0) *(float4*)(g.boxes + (long)r * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   const float* z = g.cls_score + (long)r * g.cs_ld;
   float m = -INFINITY;
   for (int c = lane; c < g.C; c += 64) m = fmaxf(m, z[c]);
@@ -240,17 +246,25 @@ __global__ __launch_bounds__(64) void lnms_score_kernel(ScoreArgs g) {
 
 using namespace relnet;
 
-extern "C" int relnet_lnms_prepare(const float* cls_score, long cs_ld, const float* bbox_pred, long bp_ld,
-                                   const float* rois, const float* im_info, float* prob, float* boxes, int B,
-                                   int N, int C, int delta_off, const float* means4, const float* stds4,
-                                   void* stream) {
+extern "C" int relnet_lnms_prepare_ex(const float* cls_score, long cs_ld, const float* bbox_pred, long bp_ld,
+                                      const float* rois, const float* im_info, float* prob, float* boxes, int B,
+                                      int N, int C, int delta_off, const float* means4, const float* stds4,
+                                      const int* n_valid, void* stream) {
   RELNET_REQUIRE(cls_score && bbox_pred && rois && im_info && prob && boxes, "relnet_lnms_prepare: null operand");
   RELNET_REQUIRE(B > 0 && N > 0 && C > 1, "relnet_lnms_prepare: bad shape");
   PrepArgs g{cls_score, cs_ld, bbox_pred, bp_ld, rois, im_info, prob, boxes, C, N, delta_off,
              means4 ? means4[0] : 0.f, means4 ? means4[1] : 0.f, means4 ? means4[2] : 0.f, means4 ? means4[3] : 0.f,
-             stds4 ? stds4[0] : 1.f, stds4 ? stds4[1] : 1.f, stds4 ? stds4[2] : 1.f, stds4 ? stds4[3] : 1.f};
+             stds4 ? stds4[0] : 1.f, stds4 ? stds4[1] : 1.f, stds4 ? stds4[2] : 1.f, stds4 ? stds4[3] : 1.f, n_valid};
   lnms_prepare_kernel<<<B * N, 64, 0, (hipStream_t)stream>>>(g);
   return check_launch("relnet_lnms_prepare");
+}
+
+extern "C" int relnet_lnms_prepare(const float* cls_score, long cs_ld, const float* bbox_pred, long bp_ld,
+                                   const float* rois, const float* im_info, float* prob, float* boxes, int B,
+                                   int N, int C, int delta_off, const float* means4, const float* stds4,
+                                   void* stream) {
+  return relnet_lnms_prepare_ex(cls_score, cs_ld, bbox_pred, bp_ld, rois, im_info, prob, boxes, B, N, C, delta_off, means4,
+                                stds4, nullptr, stream);
 }
 
 extern "C" int relnet_lnms_sort(const float* prob, const float* boxes, int* rank_idx, float* sorted_score,

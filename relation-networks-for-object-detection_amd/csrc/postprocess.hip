@@ -21,11 +21,17 @@ struct HeadArgs {
   float* cls_prob;                        // [R, C]
   double* boxes;                          // [R, 4] decoded, clipped, divided by im scale
   int R, C, rois_per_image, delta_off;
+  const int* n_valid;                     // optional [B]: rows past n_valid[b] of image b are padding -> all-zero outputs
 };
 
 #pragma clang fp contract(off)
 __global__ __launch_bounds__(64) void detect_head_kernel(HeadArgs g) {
   const int r = blockIdx.x, lane = threadIdx.x;
+  if (g.n_valid && (r % g.rois_per_image) >= g.n_valid[r / g.rois_per_image]) {     // padding row: never a detection
+    for (int c = lane; c < g.C; c += 64) g.cls_prob[(long)r * g.C + c] = 0.f;
+    if (lane < 4) g.boxes[(long)r * 4 + lane] = 0.0;
+    return;
+  }
   const float* z = g.cls_score + (long)r * g.cs_ld;
   float m = -INFINITY;
   for (int c = lane; c < g.C; c += 64) m = fmaxf(m, z[c]);
@@ -337,14 +343,21 @@ __global__ __launch_bounds__(1024) void image_topk_kernel(ImgTopkArgs g) {
 
 using namespace relnet;
 
+extern "C" int relnet_detect_head_ex(const float* cls_score, long cs_ld, const float* bbox_pred, long bp_ld,
+                                     const float* rois, const float* im_info, float* cls_prob, double* boxes,
+                                     int R, int C, int rois_per_image, int delta_off, const int* n_valid, void* stream) {
+  RELNET_REQUIRE(cls_score && bbox_pred && rois && im_info && cls_prob && boxes, "relnet_detect_head: null operand");
+  RELNET_REQUIRE(R > 0 && C > 1 && rois_per_image > 0, "relnet_detect_head: bad shape");
+  HeadArgs g{cls_score, cs_ld, bbox_pred, bp_ld, rois, im_info, cls_prob, boxes, R, C, rois_per_image, delta_off, n_valid};
+  detect_head_kernel<<<R, 64, 0, (hipStream_t)stream>>>(g);
+  return check_launch("relnet_detect_head");
+}
+
 extern "C" int relnet_detect_head(const float* cls_score, long cs_ld, const float* bbox_pred, long bp_ld,
                                   const float* rois, const float* im_info, float* cls_prob, double* boxes,
                                   int R, int C, int rois_per_image, int delta_off, void* stream) {
-  RELNET_REQUIRE(cls_score && bbox_pred && rois && im_info && cls_prob && boxes, "relnet_detect_head: null operand");
-  RELNET_REQUIRE(R > 0 && C > 1 && rois_per_image > 0, "relnet_detect_head: bad shape");
-  HeadArgs g{cls_score, cs_ld, bbox_pred, bp_ld, rois, im_info, cls_prob, boxes, R, C, rois_per_image, delta_off};
-  detect_head_kernel<<<R, 64, 0, (hipStream_t)stream>>>(g);
-  return check_launch("relnet_detect_head");
+  return relnet_detect_head_ex(cls_score, cs_ld, bbox_pred, bp_ld, rois, im_info, cls_prob, boxes, R, C, rois_per_image,
+                               delta_off, nullptr, stream);
 }
 
 extern "C" int relnet_class_nms_ex(const float* cls_prob, const double* scores64, const double* boxes, double* dets,

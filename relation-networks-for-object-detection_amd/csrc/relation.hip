@@ -14,6 +14,7 @@
 //                         with d_k = d_v = 64 (executed FLOPs 4.4x below the graph as
 //                         written; DESIGN.md reports both).
 #include "common.h"
+#include <type_traits>
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 
@@ -51,7 +52,12 @@ __device__ __forceinline__ void position_features(float4 bi, float4 bj, float (&
   p[3] = (float)log((double)(hi / hj));
 }
 
-template <int FC, int NMOD, typename TB>
+// EXACT (float output only): the float32 PARITY form -- sin / cos / log correctly rounded (float64 evaluation, one rounding)
+// and the 64 -> 16 pair_pos_fc1 product accumulated in float64 and rounded once, i.e. the arithmetic of oracle/relation.py
+// (`cr`, `_mm`): the logits `weighted_aff` (SYM_REL:139) then agree with the oracle to float32 rounding for EVERY pair,
+// also where log(max(G, 1e-6)) amplifies G's last bits.  !EXACT keeps libm float32 sincosf / logf and float32 FMAs (the
+// training backward's recompute), fp16 output = hardware v_sin / v_cos / v_log (throughput path without the MFMA kernel).
+template <int FC, int NMOD, typename TB, bool EXACT = false>
 __global__ __launch_bounds__(256) void geometry_bias_kernel(GeomArgs g) {
   constexpr bool kFast = sizeof(TB) == 2;    // fp16 bias = bf16 throughput path: hardware sin/cos
   const long pair = (long)blockIdx.x * 256 + threadIdx.x;
@@ -68,9 +74,10 @@ __global__ __launch_bounds__(256) void geometry_bias_kernel(GeomArgs g) {
   if (g.pos_mat) *(float4*)(g.pos_mat + (((long)b * g.N + i) * g.M + j) * 4) = make_float4(p[0], p[1], p[2], p[3]);
 
   constexpr int NO = NMOD * FC;                  // outputs per pair
-  float acc[NO];
+  typedef typename std::conditional<EXACT, double, float>::type ACC;
+  ACC acc[NO];
 #pragma unroll
-  for (int o = 0; o < NO; ++o) acc[o] = ((const float __attribute__((address_space(4))) *)(unsigned long long)g.bp)[o];
+  for (int o = 0; o < NO; ++o) acc[o] = (ACC)((const float __attribute__((address_space(4))) *)(unsigned long long)g.bp)[o];
 
 #pragma unroll 1
   for (int c = 0; c < 4; ++c) {
@@ -82,6 +89,10 @@ __global__ __launch_bounds__(256) void geometry_bias_kernel(GeomArgs g) {
       const float arg = x100 / g.divisors[k];
       if constexpr (kFast) {       // v_sin/v_cos (|arg| <= 700 rad is inside their range); abs err ~1e-5
         e[k] = __sinf(arg); e[8 + k] = __cosf(arg);
+      } else if constexpr (EXACT) {
+        double sn, cs;
+        sincos((double)arg, &sn, &cs);
+        e[k] = (float)sn; e[8 + k] = (float)cs;
       } else {
         sincosf(arg, &e[k], &e[8 + k]);
       }
@@ -101,15 +112,19 @@ __global__ __launch_bounds__(256) void geometry_bias_kernel(GeomArgs g) {
 #pragma unroll
     for (int k = 0; k < 16; ++k)
 #pragma unroll
-      for (int o = 0; o < NO; ++o) acc[o] = fmaf(e[k], w[k * NO + o], acc[o]);
+      for (int o = 0; o < NO; ++o) {
+        if constexpr (EXACT) acc[o] += (double)e[k] * (double)w[k * NO + o];      // exact product, float64 sum
+        else acc[o] = fmaf(e[k], w[k * NO + o], acc[o]);
+      }
   }
 #pragma unroll
   for (int m = 0; m < NMOD; ++m)
 #pragma unroll
     for (int h = 0; h < FC; ++h) {
-      const float gw = fmaxf(fmaxf(acc[m * FC + h], 0.f), 1e-6f);
+      const float gw = fmaxf(fmaxf((float)acc[m * FC + h], 0.f), 1e-6f);
       // fp16 bias feeds the exp2-based LDS attention kernel: store log2(G) (v_log_f32 is log2)
-      ((TB*)g.bias)[((((long)m * g.B + b) * FC + h) * g.N + i) * g.Mpad + j] = (TB)(kFast ? __log2f(gw) : logf(gw));
+      ((TB*)g.bias)[((((long)m * g.B + b) * FC + h) * g.N + i) * g.Mpad + j] =
+          (TB)(kFast ? __log2f(gw) : EXACT ? (float)log((double)gw) : logf(gw));
     }
 }
 #pragma clang fp contract(fast)
@@ -224,6 +239,8 @@ struct AttnArgs {
   float* logits;                         // optional [B][N][H][M] fp32 (weighted_aff)
   int B, H, N, M, Mpad;
   float scale;
+  const int* key_count;                  // optional [B]: only the first key_count[b] (<= M) keys of image b exist; the others
+                                         // are masked like the columns past M (padding rows of a fixed-size roi buffer)
 };
 
 template <typename T, typename TOUT>
@@ -263,6 +280,7 @@ __global__ __launch_bounds__(256) void relation_attention_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
+  const int Mb = a.key_count ? min(max(a.key_count[b], 1), a.M) : a.M;      // keys of THIS image
   const int nkt = (a.M + 31) / 32;
   for (int kt = 0; kt < nkt; ++kt) {
     const int key0 = kt * 32;
@@ -300,7 +318,7 @@ __global__ __launch_bounds__(256) void relation_attention_kernel(AttnArgs a) {
         const int r = 4 * gq + e;
         float v = a.scale * s[r];
         v = bb[e] + v;                                   // weighted_aff (SYM_REL:139)
-        v = (kbase + e < a.M) ? v : -INFINITY;
+        v = (kbase + e < Mb) ? v : -INFINITY;
         s[r] = v;
         tmax = fmaxf(tmax, v);
       }
@@ -444,6 +462,7 @@ __global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
   const float scale2 = a.scale * 1.44269504088896340736f;
+  const int Mb = a.key_count ? min(max(a.key_count[b], 1), a.M) : a.M;      // keys of THIS image
 
   for (int kc0 = 0; kc0 < a.M; kc0 += kKC) {
     if (kc0 > 0) __syncthreads();
@@ -506,12 +525,12 @@ __global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a
             s[r] = fmaf(s[r], scale2, bb[e]);
           }
         }
-        if (key0 + 32 > a.M) {                           // only the last tile has keys past M
+        if (key0 + 32 > Mb) {                            // only the tiles that hold keys past the image's count
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (key0 + 8 * gq + 4 * half + e >= a.M) s[4 * gq + e] = -INFINITY;
+              if (key0 + 8 * gq + 4 * half + e >= Mb) s[4 * gq + e] = -INFINITY;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
@@ -880,26 +899,30 @@ extern "C" int relnet_geometry_bias(const float* boxes, int box_stride, int box_
   hipStream_t s = (hipStream_t)stream;
   for (int k = 0; k < 8; ++k) g.c2[k] = (float)(0.69314718055994530942 * 100.0 / (6.283185307179586476925 * (double)divisors8[k]));
   const size_t key_lds = (size_t)((M + 63) / 64) * 64 * 16;
-  if (bias_half && !pos_mat && !pos_emb && key_lds <= 64 * 1024) {
+  RELNET_REQUIRE(bias_half >= -1 && bias_half <= 1, "relnet_geometry_bias: bias_half %d (0: float32 exact, 1: fp16 log2, -1: float32 fast)", bias_half);
+  if (bias_half == 1 && !pos_mat && !pos_emb && key_lds <= 64 * 1024) {
     // throughput path: pair_pos_fc1 of all modules on the matrix cores, one wavefront per query
     dim3 g2((unsigned)((N + 3) / 4), B);
     geometry_bias_mfma_kernel<<<g2, 256, key_lds, s>>>(g);
-  } else if (bias_half) {
+  } else if (bias_half == 1) {
     if (nmod == 1) geometry_bias_kernel<16, 1, __half><<<grid, 256, 0, s>>>(g);
     else geometry_bias_kernel<16, 2, __half><<<grid, 256, 0, s>>>(g);
-  } else {
+  } else if (bias_half == -1) {    // float32 output, float32 libm arithmetic: the training backward's recompute of log G
     if (nmod == 1) geometry_bias_kernel<16, 1, float><<<grid, 256, 0, s>>>(g);
     else geometry_bias_kernel<16, 2, float><<<grid, 256, 0, s>>>(g);
+  } else if (bias_half == 0) {      // float32 parity path: oracle arithmetic (float64 sin / cos / log, float64 accumulation)
+    if (nmod == 1) geometry_bias_kernel<16, 1, float, true><<<grid, 256, 0, s>>>(g);
+    else geometry_bias_kernel<16, 2, float, true><<<grid, 256, 0, s>>>(g);
   }
   return check_launch("relnet_geometry_bias");
 }
 
-extern "C" int relnet_relation_attention(
+extern "C" int relnet_relation_attention_kc(
     const void* q, long q_ld, long q_bs, const void* k, long k_ld, long k_bs, const void* vwt,
     long vwt_ld, long vwt_bs, const void* bias, int bias_half, long bias_bs, const float* bout,
     const void* resid, long resid_ld, long resid_bs, void* out, long out_ld, long out_bs,
     void* out_act, long act_ld, long act_bs, float* logits, int B, int H, int N, int M, int Mpad,
-    float scale, int in_dtype, int out_dtype, void* stream) {
+    float scale, int in_dtype, int out_dtype, const int* key_count, void* stream) {
   RELNET_REQUIRE(q && k && vwt && bias, "relnet_relation_attention: null operand");
   RELNET_REQUIRE(out || out_act, "relnet_relation_attention: no output requested");
   RELNET_REQUIRE(B > 0 && H > 0 && N > 0 && M > 0 && Mpad >= M && Mpad % 32 == 0,
@@ -911,7 +934,7 @@ extern "C" int relnet_relation_attention(
   a.bout = bout; a.resid = resid; a.resid_ld = resid_ld; a.resid_bs = resid_bs;
   a.out = out; a.out_ld = out_ld; a.out_bs = out_bs; a.out_act = out_act; a.act_ld = act_ld;
   a.act_bs = act_bs; a.logits = logits; a.B = B; a.H = H; a.N = N; a.M = M; a.Mpad = Mpad;
-  a.scale = scale;
+  a.scale = scale; a.key_count = key_count;
   dim3 grid((unsigned)(((N + 31) / 32 + 3) / 4), H, B);
   hipStream_t s = (hipStream_t)stream;
   if (in_dtype == RELNET_BF16 && bias_half) {
@@ -931,10 +954,9 @@ extern "C" int relnet_relation_attention(
     const size_t kv = (size_t)kc_rows * 128 + (size_t)64 * vld * 2 + 128 /* slack for the masked tail */;
     const size_t ep = (size_t)nwave * 32 * kOLD * 2;
     const size_t lds = kv > ep ? kv : ep;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static relnet::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
       hipFuncSetAttribute((const void*)relation_attention_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
     }
     dim3 g2((unsigned)((qtiles + nwave - 1) / nwave), H, B);
     relation_attention_lds_kernel<<<g2, nwave * 64, lds, s>>>(a, kc_rows, vld);
@@ -949,6 +971,17 @@ extern "C" int relnet_relation_attention(
     RELNET_REQUIRE(false, "relnet_relation_attention: unknown dtype %d", in_dtype);
   }
   return check_launch("relnet_relation_attention");
+}
+
+extern "C" int relnet_relation_attention(
+    const void* q, long q_ld, long q_bs, const void* k, long k_ld, long k_bs, const void* vwt,
+    long vwt_ld, long vwt_bs, const void* bias, int bias_half, long bias_bs, const float* bout,
+    const void* resid, long resid_ld, long resid_bs, void* out, long out_ld, long out_bs,
+    void* out_act, long act_ld, long act_bs, float* logits, int B, int H, int N, int M, int Mpad,
+    float scale, int in_dtype, int out_dtype, void* stream) {
+  return relnet_relation_attention_kc(q, q_ld, q_bs, k, k_ld, k_bs, vwt, vwt_ld, vwt_bs, bias, bias_half, bias_bs, bout, resid,
+                                      resid_ld, resid_bs, out, out_ld, out_bs, out_act, act_ld, act_bs, logits, B, H, N, M, Mpad,
+                                      scale, in_dtype, out_dtype, nullptr, stream);
 }
 
 // Fused geometry + attention of one relation module (bf16; H = 16 heads x 64; M <= 640 keys).
@@ -974,16 +1007,15 @@ extern "C" int relnet_relation_attention_fused(
   a.vwt = vwt; a.vwt_ld = vwt_ld; a.vwt_bs = vwt_bs; a.bias = nullptr; a.bias_bs = 0;
   a.bout = bout; a.resid = resid; a.resid_ld = resid_ld; a.resid_bs = resid_bs;
   a.out = out; a.out_ld = out_ld; a.out_bs = out_bs; a.out_act = out_act; a.act_ld = act_ld;
-  a.act_bs = act_bs; a.logits = nullptr; a.B = B; a.H = H; a.N = N; a.M = M; a.Mpad = Mpad; a.scale = scale;
+  a.act_bs = act_bs; a.logits = nullptr; a.B = B; a.H = H; a.N = N; a.M = M; a.Mpad = Mpad; a.scale = scale; a.key_count = nullptr;
   f.boxes = boxes; f.box_stride = box_stride; f.box_off = box_off; f.wp = wp; f.bp = bp;
   for (int t = 0; t < 8; ++t) f.c2[t] = (float)(0.69314718055994530942 * 100.0 / (6.283185307179586476925 * (double)divisors8[t]));
   f.nq = (N + 31) / 32;
   const int ntile = (M + 31) / 32;
   const size_t lds = (size_t)2 * kGBuf * 4 + (size_t)ntile * 32 * 16;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static relnet::PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)relation_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   const unsigned grid = (unsigned)(f.nq * ((B + 7) / 8) * 8);
   relation_fused_kernel<<<grid, 1024, lds, (hipStream_t)stream>>>(f);

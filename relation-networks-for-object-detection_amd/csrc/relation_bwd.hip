@@ -90,6 +90,7 @@ struct AttnBwdArgs {
   float* dq; float* dk; float* dvw;        // fp32 [B][N][H*64], [B][M][H*64], [B][M][H*64]
   int B, H, N, M, Mpad;
   float scale;
+  const int* key_count;                    // optional [B]: keys >= key_count[b] of image b are masked (as in the forward kernels)
 };
 
 template <typename T> struct Frag;
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(256) void relation_attention_bwd_q_kernel(AttnBwdAr
   D += __shfl_xor(D, 32);
 
   const int nkt = (a.M + 31) / 32;
+  const int Mb = a.key_count ? min(max(a.key_count[b], 1), a.M) : a.M;
   // pass 1: row maximum and normaliser
   float m_run = -INFINITY, l_run = 0.f;
   for (int kt = 0; kt < nkt; ++kt) {
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256) void relation_attention_bwd_q_kernel(AttnBwdAr
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float v = bb[e] + a.scale * s[4 * gq + e];
-        v = (kbase + e < a.M) ? v : -INFINITY;
+        v = (kbase + e < Mb) ? v : -INFINITY;
         s[4 * gq + e] = v;
         tmax = fmaxf(tmax, v);
       }
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256) void relation_attention_bwd_q_kernel(AttnBwdAr
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * gq + e;
         const float v = bb[e] + a.scale * s[r];
-        pv[e] = (kbase + e < a.M) ? expf(v - m_run) * inv : 0.f;
+        pv[e] = (kbase + e < Mb) ? expf(v - m_run) * inv : 0.f;
         lv[e] = pv[e] * (ds[r] - D);
         dl[r] = lv[e];
       }
@@ -461,12 +463,12 @@ extern "C" int relnet_transpose_2d(const void* in, long in_ld, long in_bs, void*
   return check_launch("relnet_transpose_2d");
 }
 
-extern "C" int relnet_relation_attention_bwd(
+extern "C" int relnet_relation_attention_bwd_kc(
     const void* q, long q_ld, long q_bs, const void* k, long k_ld, long k_bs, const void* kt, long kt_ld, long kt_bs,
     const void* vw, long vw_ld, long vw_bs, const float* bias, long bias_bs, const void* dy, long dy_ld, long dy_bs,
     const void* y, long y_ld, long y_bs, const float* bout, const void* qt, long qt_ld, long qt_bs, const void* dyt,
     long dyt_ld, long dyt_bs, float* prob, float* dlog, float* dq, float* dk, float* dvw, int B, int H, int N, int M,
-    int Mpad, int Npad, float scale, int dtype, void* stream) {
+    int Mpad, int Npad, float scale, int dtype, const int* key_count, void* stream) {
   RELNET_REQUIRE(q && k && kt && vw && bias && dy && y && qt && dyt && prob && dlog && dq && dk && dvw,
                  "relnet_relation_attention_bwd: null operand");
   RELNET_REQUIRE(B > 0 && H > 0 && N > 0 && M > 0 && M <= N && Mpad >= M && Mpad % 32 == 0 && Npad >= N && Npad % 32 == 0,
@@ -477,7 +479,7 @@ extern "C" int relnet_relation_attention_bwd(
   a.vw = vw; a.vw_ld = vw_ld; a.vw_bs = vw_bs; a.bias = bias; a.bias_bs = bias_bs; a.dy = dy; a.dy_ld = dy_ld; a.dy_bs = dy_bs;
   a.y = y; a.y_ld = y_ld; a.y_bs = y_bs; a.bout = bout; a.qt = qt; a.qt_ld = qt_ld; a.qt_bs = qt_bs;
   a.dyt = dyt; a.dyt_ld = dyt_ld; a.dyt_bs = dyt_bs; a.prob = prob; a.dlog = dlog; a.dq = dq; a.dk = dk; a.dvw = dvw;
-  a.B = B; a.H = H; a.N = N; a.M = M; a.Mpad = Mpad; a.scale = scale;
+  a.B = B; a.H = H; a.N = N; a.M = M; a.Mpad = Mpad; a.scale = scale; a.key_count = key_count;
   hipStream_t s = (hipStream_t)stream;
   dim3 gq((unsigned)(((N + 31) / 32 + 3) / 4), H, B), gk((unsigned)(((M + 31) / 32 + 3) / 4), H, B);
   if (dtype == RELNET_F32) {
@@ -494,6 +496,17 @@ extern "C" int relnet_relation_attention_bwd(
     RELNET_REQUIRE(false, "relnet_relation_attention_bwd: unknown dtype %d", dtype);
   }
   return check_launch("relnet_relation_attention_bwd");
+}
+
+extern "C" int relnet_relation_attention_bwd(
+    const void* q, long q_ld, long q_bs, const void* k, long k_ld, long k_bs, const void* kt, long kt_ld, long kt_bs,
+    const void* vw, long vw_ld, long vw_bs, const float* bias, long bias_bs, const void* dy, long dy_ld, long dy_bs,
+    const void* y, long y_ld, long y_bs, const float* bout, const void* qt, long qt_ld, long qt_bs, const void* dyt,
+    long dyt_ld, long dyt_bs, float* prob, float* dlog, float* dq, float* dk, float* dvw, int B, int H, int N, int M,
+    int Mpad, int Npad, float scale, int dtype, void* stream) {
+  return relnet_relation_attention_bwd_kc(q, q_ld, q_bs, k, k_ld, k_bs, kt, kt_ld, kt_bs, vw, vw_ld, vw_bs, bias, bias_bs, dy, dy_ld,
+                                          dy_bs, y, y_ld, y_bs, bout, qt, qt_ld, qt_bs, dyt, dyt_ld, dyt_bs, prob, dlog, dq, dk, dvw,
+                                          B, H, N, M, Mpad, Npad, scale, dtype, nullptr, stream);
 }
 
 extern "C" int relnet_geometry_bias_bwd(const float* boxes, int box_stride, int box_off, const float* bias,

@@ -29,6 +29,7 @@ struct PTArgs {
   int N, Gmax, num_reg, class_agnostic;
   float bg_thresh_hi;
   double mean[4], stdv[4], bw[4];
+  const int* num_rois;    // optional [B]: only the first num_rois[b] of the N input rows are proposals, the rest padding
 };
 
 __global__ __launch_bounds__(256) void proposal_target_kernel(PTArgs g) {
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void proposal_target_kernel(PTArgs g) {
   float* bt = g.bbox_target + ((long)b * R + r) * 4 * g.num_reg;
   float* bwp = g.bbox_weight + ((long)b * R + r) * 4 * g.num_reg;
   for (int c = 0; c < 4 * g.num_reg; ++c) { bt[c] = 0.f; bwp[c] = 0.f; }
-  if (r >= g.N + G) {                         // padding row (image has fewer than Gmax gt boxes)
+  if (r >= g.N + G || (g.num_rois && r < g.N && r >= g.num_rois[b])) {   // padding row (fewer than Gmax gt boxes / than N proposals)
     for (int c = 0; c < 5; ++c) ro[c] = 0.f;
     ro[0] = (float)b;                         // still a valid image index for the batched pooling kernels
     g.label[(long)b * R + r] = -1.f;
@@ -251,6 +252,173 @@ using namespace relnet;
 // lib/bbox/bbox.pyx:15-55 `bbox_overlaps_cython(boxes f64 [N,4], query_boxes f64 [K,4]) -> f64 [N,K]`
 // (callers: core/rcnn.py:303, operator_py/nms_multi_target.py:51, lib/rpn/rpn.py:163): one thread per (n, k).
 namespace relnet {
+// ---------------------------------------------------------------------------------------
+// RPN anchor targets on the device (reference: lib/rpn/rpn.py:80-244 assign_anchor, host numpy in the data loader).
+//   anchors   base[a] + (x, y, x, y) * stride in (y, x, a) order (:127-141), float64 like numpy
+//   inside    x1, y1 >= -border, x2 < im_w + border, y2 < im_h + border (:144-147): every other anchor keeps label -1
+//   overlaps  bbox_overlaps (lib/bbox/bbox.pyx:33-55, float64); argmax over gt = first maximum (:166-167)
+//   labels    max < RPN_NEGATIVE_OVERLAP -> 0; every anchor that ties some gt's best overlap -> 1 (:168-170,177);
+//             max >= RPN_POSITIVE_OVERLAP -> 1 (:180); RPN_CLOBBER_POSITIVES moves the first rule last (:172-184)
+//   sampling  more than num_fg positives / more than batch - #fg negatives: a uniformly random subset is switched to -1
+//             (npr.choice, :189-204).  Here the random subset = the anchors with the SMALLEST keys, key = a 32-bit hash of
+//             (seed, image, anchor index): reproducible, order independent, no RNG stream to keep in step
+//   targets   bbox_transform(anchor, matched gt) in float64, stored float32 (:206-208); weights 1 on the positives (:210-211)
+//   layouts   label [B, A*fh*fw] in (a, y, x) order, bbox_target / bbox_weight [B, 4A, fh, fw] (:236-239)
+// Three launches: best overlap per gt (atomic max on the float64 bit pattern: overlaps are >= 0), labels + targets,
+// sub-sampling (one workgroup per image, radix select over the 64-bit (key, index) words).
+// ---------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+struct AnchorArgs {
+  const float* gt;              // [B, Gmax, 5]
+  const int* num_gt;            // [B]
+  const float* im_info;         // [B, 3] (height, width, scale)
+  double base[32][4];           // base anchors (A <= 32)
+  float* label;                 // [B, A*fh*fw]
+  float* bbox_target;           // [B, 4A, fh, fw]
+  float* bbox_weight;           // [B, 4A, fh, fw]
+  float* label_all;             // optional [B, A*fh*fw]: the labels BEFORE sub-sampling
+  unsigned long long* gt_best;  // workspace [B, Gmax], zeroed by the entry point
+  int A, fh, fw, Gmax, stride, batch_size, num_fg, allowed_border, clobber;
+  double neg_ov, pos_ov;
+  unsigned long long seed;
+  const unsigned long long* seed_dev;   // optional device word added to `seed` (a step counter that a captured graph can advance)
+};
+
+__device__ __forceinline__ unsigned int anchor_key(unsigned long long seed, int b, int idx) {
+  // 32-bit avalanche hash (two multiply-xorshift rounds) of the (seed, image, anchor) triple
+  unsigned int x = (unsigned int)idx * 0x9E3779B1u ^ (unsigned int)(seed & 0xffffffffu) ^ ((unsigned int)b * 0x85EBCA77u)
+                   ^ (unsigned int)(seed >> 32) * 0xC2B2AE3Du;
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+
+__device__ __forceinline__ bool anchor_box(const AnchorArgs& g, int b, int idx, double* box) {
+  const int a = idx % g.A, k = idx / g.A, x = k % g.fw, y = k / g.fw;
+  box[0] = g.base[a][0] + (double)(x * g.stride); box[1] = g.base[a][1] + (double)(y * g.stride);
+  box[2] = g.base[a][2] + (double)(x * g.stride); box[3] = g.base[a][3] + (double)(y * g.stride);
+  const double im_h = (double)g.im_info[b * 3], im_w = (double)g.im_info[b * 3 + 1], bd = (double)g.allowed_border;
+  return box[0] >= -bd && box[1] >= -bd && box[2] < im_w + bd && box[3] < im_h + bd;
+}
+
+__global__ __launch_bounds__(256) void anchor_best_kernel(AnchorArgs g) {
+  const int b = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+  const int total = g.A * g.fh * g.fw, G = g.num_gt[b];
+  if (idx >= total || G <= 0) return;
+  double box[4];
+  if (!anchor_box(g, b, idx, box)) return;
+  const float* gtb = g.gt + (long)b * g.Gmax * 5;
+  for (int k = 0; k < G; ++k) {
+    const double q[4] = {gtb[k * 5], gtb[k * 5 + 1], gtb[k * 5 + 2], gtb[k * 5 + 3]};
+    const double ov = iou64(box, q);
+    if (ov > 0.0) atomicMax(g.gt_best + (long)b * g.Gmax + k, (unsigned long long)__double_as_longlong(ov));
+  }
+}
+
+__global__ __launch_bounds__(256) void anchor_label_kernel(AnchorArgs g) {
+  const int b = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+  const int total = g.A * g.fh * g.fw, G = g.num_gt[b];
+  if (idx >= total) return;
+  const int a = idx % g.A, k = idx / g.A, x = k % g.fw, y = k / g.fw;
+  double box[4];
+  const bool inside = anchor_box(g, b, idx, box);
+  float lab = -1.f;
+  float t[4] = {0.f, 0.f, 0.f, 0.f};
+  if (inside) {
+    if (G <= 0) {
+      lab = 0.f;                                                        // :186 no gt: everything inside is background
+    } else {
+      const float* gtb = g.gt + (long)b * g.Gmax * 5;
+      double best = -1.0; int bi = 0; bool gt_arg = false;
+      for (int kk = 0; kk < G; ++kk) {
+        const double q[4] = {gtb[kk * 5], gtb[kk * 5 + 1], gtb[kk * 5 + 2], gtb[kk * 5 + 3]};
+        const double ov = iou64(box, q);
+        if (ov > best) { best = ov; bi = kk; }
+        gt_arg = gt_arg || (ov == __longlong_as_double((long long)g.gt_best[(long)b * g.Gmax + kk]));
+      }
+      if (!g.clobber && best < g.neg_ov) lab = 0.f;
+      if (gt_arg) lab = 1.f;
+      if (best >= g.pos_ov) lab = 1.f;
+      if (g.clobber && best < g.neg_ov) lab = 0.f;
+      // bbox_transform.py:74-100 in float64 (float64 anchors, float32 gt promoted), rounded to float32 on store
+      const float* q = gtb + bi * 5;
+      const double ew = box[2] - box[0] + 1.0, eh = box[3] - box[1] + 1.0;
+      const double ecx = box[0] + 0.5 * (ew - 1.0), ecy = box[1] + 0.5 * (eh - 1.0);
+      const double gw = (double)q[2] - (double)q[0] + 1.0, gh = (double)q[3] - (double)q[1] + 1.0;
+      const double gcx = (double)q[0] + 0.5 * (gw - 1.0), gcy = (double)q[1] + 0.5 * (gh - 1.0);
+      t[0] = (float)((gcx - ecx) / (ew + 1e-14)); t[1] = (float)((gcy - ecy) / (eh + 1e-14));
+      t[2] = (float)log(gw / ew); t[3] = (float)log(gh / eh);
+    }
+  }
+  const long lo = (long)b * total + ((long)a * g.fh + y) * g.fw + x;     // (a, y, x) order
+  g.label[lo] = lab;
+  if (g.label_all) g.label_all[lo] = lab;
+  const long hw = (long)g.fh * g.fw;
+  float* bt = g.bbox_target + ((long)b * 4 * g.A + 4 * a) * hw + (long)y * g.fw + x;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) bt[c * hw] = t[c];
+}
+
+// One workgroup per image.  which = 1: positives beyond num_fg, then which = 0: negatives beyond batch - #fg.
+__global__ __launch_bounds__(1024) void anchor_sample_kernel(AnchorArgs g) {
+  __shared__ int s_cnt[2];
+  __shared__ int s_red[16];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int total = g.A * g.fh * g.fw;
+  float* lab = g.label + (long)b * total;
+  const unsigned long long seed = g.seed + (g.seed_dev ? *g.seed_dev : 0ull);
+  auto block_count = [&](auto pred) -> int {       // number of positions with pred(pos) over the whole image
+    int c = 0;
+    for (int p = tid; p < total; p += 1024) c += pred(p) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    __syncthreads();
+    if (lane == 0) s_red[wave] = c;
+    __syncthreads();
+    int t = 0;
+    for (int w = 0; w < 16; ++w) t += s_red[w];
+    return t;
+  };
+  // position p (a, y, x order) <-> anchor index in (y, x, a) order, the index the keys are defined on
+  auto key_of = [&](int p) -> unsigned long long {
+    const int hw = g.fh * g.fw, a = p / hw, k = p % hw, idx = k * g.A + a;
+    return ((unsigned long long)anchor_key(seed, b, idx) << 32) | (unsigned int)idx;
+  };
+  for (int which = 1; which >= 0; --which) {
+    const float want = (float)which;
+    const int n = block_count([&](int p) { return lab[p] == want; });
+    int keep = g.num_fg;
+    if (which == 0) keep = g.batch_size - block_count([&](int p) { return lab[p] == 1.f; });
+    if (keep < 0) keep = 0;
+    const int drop = n - keep;
+    if (drop > 0) {
+      // the `drop` smallest (key, index) words: radix select, most significant bit first
+      unsigned long long prefix = 0ull, mask = 0ull;
+      int need = drop;                                   // rank (1-based) of the threshold word among the matching ones
+      for (int bit = 63; bit >= 0; --bit) {
+        const unsigned long long m2 = mask | (1ull << bit);
+        const int zeros = block_count([&](int p) { return lab[p] == want && (key_of(p) & m2) == prefix; });
+        if (need > zeros) { need -= zeros; prefix |= (1ull << bit); }
+        mask = m2;
+      }
+      // prefix = the drop-th smallest word: everything <= it is switched off
+      __syncthreads();
+      for (int p = tid; p < total; p += 1024)
+        if (lab[p] == want && key_of(p) <= prefix) lab[p] = -1.f;
+      __syncthreads();
+    }
+  }
+  // weights: RPN_BBOX_WEIGHTS (1, 1, 1, 1) on the surviving positives
+  const long hw = (long)g.fh * g.fw;
+  for (int p = tid; p < total; p += 1024) {
+    const int a = p / (int)hw, k = p % (int)hw;
+    const float w = lab[p] == 1.f ? 1.f : 0.f;
+    float* bw = g.bbox_weight + ((long)b * 4 * g.A + 4 * a) * hw + k;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bw[c * hw] = w;
+  }
+}
+
+#pragma clang fp contract(fast)
 struct OverlapArgs { const double* boxes; const double* query; double* out; int N, K; };
 __global__ __launch_bounds__(256) void bbox_overlaps_kernel(OverlapArgs g) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -271,18 +439,56 @@ extern "C" int relnet_bbox_overlaps(const double* boxes, const double* query_box
   return check_launch("relnet_bbox_overlaps");
 }
 
-extern "C" int relnet_proposal_target(const float* rois, const float* gt, const int* num_gt, float* rois_out,
-                                      float* label, float* bbox_target, float* bbox_weight, int B, int N, int Gmax,
-                                      int num_reg, int class_agnostic, float bg_thresh_hi, const double* means4,
-                                      const double* stds4, const double* weights4, void* stream) {
+extern "C" int relnet_assign_anchor(const float* gt, const int* num_gt, const float* im_info, const double* base_anchors,
+                                    float* label, float* bbox_target, float* bbox_weight, float* label_all,
+                                    unsigned long long* workspace, int B, int A, int feat_h, int feat_w, int Gmax,
+                                    int feat_stride, int rpn_batch_size, int num_fg, double negative_overlap,
+                                    double positive_overlap, int clobber_positives, int allowed_border,
+                                    unsigned long long seed, const unsigned long long* seed_dev, void* stream) {
+  RELNET_REQUIRE(gt && num_gt && im_info && base_anchors && label && bbox_target && bbox_weight && workspace,
+                 "relnet_assign_anchor: null operand");
+  RELNET_REQUIRE(B > 0 && A > 0 && A <= 32 && feat_h > 0 && feat_w > 0 && Gmax > 0, "relnet_assign_anchor: bad shape (A <= 32)");
+  AnchorArgs g;
+  g.gt = gt; g.num_gt = num_gt; g.im_info = im_info;
+  for (int a = 0; a < A; ++a)
+    for (int c = 0; c < 4; ++c) g.base[a][c] = base_anchors[a * 4 + c];
+  g.label = label; g.bbox_target = bbox_target; g.bbox_weight = bbox_weight; g.label_all = label_all; g.gt_best = workspace;
+  g.A = A; g.fh = feat_h; g.fw = feat_w; g.Gmax = Gmax; g.stride = feat_stride; g.batch_size = rpn_batch_size; g.num_fg = num_fg;
+  g.allowed_border = allowed_border; g.clobber = clobber_positives; g.neg_ov = negative_overlap; g.pos_ov = positive_overlap;
+  g.seed = seed; g.seed_dev = seed_dev;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(workspace, 0, (size_t)B * Gmax * sizeof(unsigned long long), s) != hipSuccess) {
+    relnet::set_error("relnet_assign_anchor: memset failed");
+    return -2;
+  }
+  const int total = A * feat_h * feat_w;
+  dim3 grid((total + 255) / 256, B);
+  anchor_best_kernel<<<grid, 256, 0, s>>>(g);
+  anchor_label_kernel<<<grid, 256, 0, s>>>(g);
+  anchor_sample_kernel<<<B, 1024, 0, s>>>(g);
+  return check_launch("relnet_assign_anchor");
+}
+
+extern "C" int relnet_proposal_target_ex(const float* rois, const float* gt, const int* num_gt, float* rois_out,
+                                         float* label, float* bbox_target, float* bbox_weight, int B, int N, int Gmax,
+                                         int num_reg, int class_agnostic, float bg_thresh_hi, const double* means4,
+                                         const double* stds4, const double* weights4, const int* num_rois, void* stream) {
   RELNET_REQUIRE(rois && gt && num_gt && rois_out && label && bbox_target && bbox_weight && means4 && stds4 && weights4,
                  "relnet_proposal_target: null operand");
   RELNET_REQUIRE(B > 0 && N >= 0 && Gmax >= 0 && N + Gmax > 0 && num_reg > 0, "relnet_proposal_target: bad shape");
   PTArgs g{rois, gt, num_gt, rois_out, label, bbox_target, bbox_weight, N, Gmax, num_reg, class_agnostic, bg_thresh_hi,
            {means4[0], means4[1], means4[2], means4[3]}, {stds4[0], stds4[1], stds4[2], stds4[3]},
-           {weights4[0], weights4[1], weights4[2], weights4[3]}};
+           {weights4[0], weights4[1], weights4[2], weights4[3]}, num_rois};
   proposal_target_kernel<<<dim3((N + Gmax + 255) / 256, B), 256, 0, (hipStream_t)stream>>>(g);
   return check_launch("relnet_proposal_target");
+}
+
+extern "C" int relnet_proposal_target(const float* rois, const float* gt, const int* num_gt, float* rois_out,
+                                      float* label, float* bbox_target, float* bbox_weight, int B, int N, int Gmax,
+                                      int num_reg, int class_agnostic, float bg_thresh_hi, const double* means4,
+                                      const double* stds4, const double* weights4, void* stream) {
+  return relnet_proposal_target_ex(rois, gt, num_gt, rois_out, label, bbox_target, bbox_weight, B, N, Gmax, num_reg,
+                                   class_agnostic, bg_thresh_hi, means4, stds4, weights4, nullptr, stream);
 }
 
 extern "C" int relnet_box_annotator_ohem(const float* cls_score, const float* bbox_pred, const float* labels,

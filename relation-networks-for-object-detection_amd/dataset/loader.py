@@ -3,7 +3,8 @@
   TestLoader    :25-168   one image per step (`get_rpn_testbatch` / `get_rcnn_testbatch`): data, im_info (+ the image's
                           precomputed proposals when `has_rpn` is False)
   AnchorLoader  :402-607  end2end training: image, im_info, gt_boxes and the RPN anchor targets (`assign_anchor`,
-                          lib/rpn/rpn.py:80-244 -- host numpy as in the reference: train.assign_anchor)
+                          lib/rpn/rpn.py:80-244 -- host numpy as in the reference: train.assign_anchor -- or, with
+                          device_targets=True, left to the trainer's device kernel relnet_assign_anchor)
   ROIIter       :170-400  training on precomputed proposals (FPN / alternate training): image, im_info, gt_boxes,
                           proposals.  The reference's `get_rcnn_batch` also computes labels / regression targets / the
                           pyramid dispatch on the host; here those are device kernels inside the trainer
@@ -109,7 +110,10 @@ def _conv4_size(n):
 
 class AnchorLoader(_Iter):
     def __init__(self, roidb, config, batch_size=1, shuffle=False, aspect_grouping=False, seed=0, device='cpu',
-                 feat_shape_fn=None):
+                 feat_shape_fn=None, device_targets=False):
+        """device_targets: leave `assign_anchor` to the trainer (relnet_assign_anchor on the GPU, Trainer.rpn_targets): the
+        batch then carries only data / im_info / gt_boxes / num_gt and the loader does no per-anchor work on the host."""
+        self.device_targets = device_targets
         self.feat_shape_fn = feat_shape_fn or (lambda h, w: (_conv4_size(h), _conv4_size(w)))
         super(AnchorLoader, self).__init__(roidb, config, batch_size, shuffle, aspect_grouping, seed, device)
 
@@ -127,6 +131,10 @@ class AnchorLoader(_Iter):
         tc.rpn_batch_size, tc.rpn_fg_fraction = self.cfg.TRAIN.RPN_BATCH_SIZE, self.cfg.TRAIN.RPN_FG_FRACTION
         tc.rpn_positive_overlap, tc.rpn_negative_overlap = self.cfg.TRAIN.RPN_POSITIVE_OVERLAP, self.cfg.TRAIN.RPN_NEGATIVE_OVERLAP
         gts = [_gt_boxes(r) for r in recs]
+        if self.device_targets:
+            gt_pad, num_gt = _pad_rows(gts, 5)
+            return self._tensors(dict(data=data, im_info=np.array([r['im_info'] for r in recs], dtype=np.float32),
+                                      gt_boxes=gt_pad, num_gt=num_gt))
         fh, fw = self.feat_shape_fn(H, W)
         labs, tgts, wgts = [], [], []
         for r, gt in zip(recs, gts):
@@ -155,9 +163,13 @@ class ROIIter(_Iter):
                 if is_gt.any() else np.empty((0, 5), np.float32)
             gts.append(gt)
         top = self.cfg.TRAIN.TOP_ROIS
-        if top > 0:                  # fixed proposal count per image: truncate, pad by cycling (static shapes for the graph)
-            props = [p[np.arange(top) % max(len(p), 1)] if len(p) else np.zeros((top, 4), np.float32) for p in props]
-        p_pad, num_p = _pad_rows(props, 4)
+        if top > 0:                  # load_rpn_roidb's top_roi: TRUNCATE only (the reference keeps a variable roi count)
+            props = [p[:top] for p in props]
+        # zero rows up to a common length (TOP_ROIS when set: static shapes for a captured graph); `num_proposals` carries the
+        # TRUE count of every image and the trainer masks the padded rows on the device (FPNTrainer.forward_backward)
+        p_pad, num_p = _pad_rows(props + ([np.zeros((top, 4), np.float32)] if top > 0 else []), 4)
+        if top > 0:
+            p_pad, num_p = p_pad[:-1], num_p[:-1]
         gt_pad, num_gt = _pad_rows(gts, 5)
         return self._tensors(dict(data=tensor_vstack(ims), im_info=np.array([r['im_info'] for r in recs], dtype=np.float32),
                                   proposals=p_pad, num_proposals=num_p, gt_boxes=gt_pad, num_gt=num_gt))

@@ -38,7 +38,9 @@ def pred_eval(detector, test_data, imdb, vis=False, thresh=1e-3, logger=None, de
             t0 = time.time()
             data, im_info = batch['data'].to(device), batch['im_info'].to(device)
             if 'proposals' in batch:
-                out = detector.forward(data, batch['proposals'].to(device), im_info)
+                nprop = batch.get('num_proposals')                       # TestLoader pads the images' proposal lists to one length
+                out = detector.forward(data, batch['proposals'].to(device), im_info,
+                                       num_proposals=None if nprop is None else nprop.to(device=device, dtype=torch.int32))
             else:
                 detector.im_hw = (int(data.shape[2]), int(data.shape[3]))
                 out = detector.forward(data, im_info)

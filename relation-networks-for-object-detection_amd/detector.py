@@ -136,7 +136,14 @@ class FPNDetector(object):
     fpn_ft4..fpn_ft32, then roi_pool_fc1/fc2 with two relation modules over all N proposals.
 
     Rows of every per-roi output are in the reference's level-major order; `perm` maps them back to the input
-    order.  Images must be padded to a multiple of 32 (IMAGE_STRIDE) like the reference's loader does."""
+    order.  Images must be padded to a multiple of 32 (IMAGE_STRIDE) like the reference's loader does.
+
+    Row count: the reference's loader appends one all-zero roi for every pyramid level that received none
+    (core/rcnn.py:61-71) -- a real row of its graph (pooled, scored, and a key of both relation modules).  With
+    `pad_empty_levels` (default) the device dispatch does the same into a fixed buffer of N + 4 rows per image;
+    `num_rows` [B] says how many of them are real (N + the image's empty levels), the rest is padding that the relation
+    kernels skip as keys and the post-processing never reports.  `num_proposals` [B] int32 handles images that bring fewer
+    than N proposals (rows past it are padding too)."""
 
     scales = (1 / 4.0, 1 / 8.0, 1 / 16.0, 1 / 32.0)
 
@@ -152,28 +159,34 @@ class FPNDetector(object):
                                  self.cfg.learn_nms_class_thresh, None, None, self.cfg.merge_method,
                                  self.cfg.score_thresh, self.cfg.max_per_image, dtype=dtype, device=device)
 
-    def forward(self, data, proposals, im_info, post=True, check_levels=False):
-        """data [B,3,H,W] (H, W multiples of 32); proposals [B,N,4] fp32 xyxy; im_info [B,3]."""
+    pad_empty_levels = True
+
+    def forward(self, data, proposals, im_info, post=True, num_proposals=None):
+        """data [B,3,H,W] (H, W multiples of 32); proposals [B,N,4] fp32 xyxy; im_info [B,3]; num_proposals [B] int32
+        (optional, device): valid rows of `proposals` per image.  No host synchronisation inside."""
         c = self.cfg
         B, N = proposals.shape[:2]
         if data.shape[2] % 32 or data.shape[3] % 32:
             raise ValueError("FPN images must be padded to IMAGE_STRIDE 32, got %s" % (tuple(data.shape),))
         f = self.backbone.forward(data)
-        rois, level, perm, counts = ops.fpn_roi_dispatch(proposals.contiguous())
-        if check_levels and bool((counts == 0).any()):       # host sync: debugging aid only
-            raise ValueError("a pyramid level received no roi: the reference appends an all-zero dummy roi there "
-                             "(core/rcnn.py:61-71), which this path does not reproduce")
+        n_rows = None
+        if self.pad_empty_levels or num_proposals is not None:
+            rois, level, perm, counts, n_rows = ops.fpn_roi_dispatch(proposals.contiguous(), n_valid=num_proposals,
+                                                                     pad_empty=self.pad_empty_levels)
+        else:
+            rois, level, perm, counts = ops.fpn_roi_dispatch(proposals.contiguous())
+        N = rois.shape[1]
         pooled = ops.roi_pool_fpn([f['fpn_ft4'], f['fpn_ft8'], f['fpn_ft16'], f['fpn_ft32']], self.scales,
                                   rois.view(B * N, 5), level.view(-1), (7, 7), channels_last_out=True)
         pooled = pooled.permute(0, 2, 3, 1).reshape(B, N, -1)
-        cls_score, bbox_pred, feat = self.head.forward(pooled, rois)
-        out = dict(rois=rois, roi_level=level, perm=perm, level_counts=counts, cls_score=cls_score, bbox_pred=bbox_pred,
-                   fc_all_2_relu=feat)
+        cls_score, bbox_pred, feat = self.head.forward(pooled, rois, key_count=n_rows)
+        out = dict(rois=rois, roi_level=level, perm=perm, level_counts=counts, num_rows=n_rows, cls_score=cls_score,
+                   bbox_pred=bbox_pred, fc_all_2_relu=feat)
         if self.lnms is not None and post:
-            out.update(self.lnms.forward(cls_score.contiguous(), bbox_pred.contiguous(), rois, im_info, feat))
+            out.update(self.lnms.forward(cls_score.contiguous(), bbox_pred.contiguous(), rois, im_info, feat, n_valid=n_rows))
             return out
         prob, boxes = ops.detect_head(cls_score.reshape(B * N, -1), bbox_pred.reshape(B * N, -1),
-                                      rois.view(B * N, 5), im_info, N)
+                                      rois.view(B * N, 5), im_info, N, n_valid=n_rows)
         out['cls_prob'], out['pred_boxes'] = prob.view(B, N, -1), boxes.view(B, N, 4)
         if post:
             dets, cnts = ops.class_nms(out['cls_prob'], out['pred_boxes'], c.score_thresh, c.nms, c.softnms,

@@ -59,7 +59,7 @@ class LearnNMS(object):
         self.w_logit, self.b_logit = t(p['nms_logit_weight'], torch.float32), t(p['nms_logit_bias'], torch.float32)
         self._vwt = {}
 
-    def forward(self, cls_score, bbox_pred, rois, im_info, feat, want_detections=True):
+    def forward(self, cls_score, bbox_pred, rois, im_info, feat, want_detections=True, n_valid=None):
         """cls_score [B,N,C+1] fp32, bbox_pred [B,N,4*num_reg] fp32, rois [B,N,5], im_info [B,3],
         feat = fc_all_2_relu [B,N,1024] -> dict(nms_multi_score [B,F,C,T], sorted_bbox [B,F,C,4],
         sorted_score [B,F,C], nms_final_score [B,F,C], detections ...)."""
@@ -72,8 +72,9 @@ class LearnNMS(object):
         assert cs.stride(1) == 1 and bp.stride(1) == 1 and cs.dtype == torch.float32 and bp.dtype == torch.float32
         prob = torch.empty((B, N, C), device=dev, dtype=torch.float32)
         boxes = torch.empty((B, N, 4), device=dev, dtype=torch.float32)
-        _lib.call('relnet_lnms_prepare', cs.data_ptr(), cs.stride(0), bp.data_ptr(), bp.stride(0), rois.data_ptr(),
-                  im_info.data_ptr(), prob.data_ptr(), boxes.data_ptr(), B, N, C1, 4, self.means, self.stds, s)
+        _lib.call('relnet_lnms_prepare_ex', cs.data_ptr(), cs.stride(0), bp.data_ptr(), bp.stride(0), rois.data_ptr(),
+                  im_info.data_ptr(), prob.data_ptr(), boxes.data_ptr(), B, N, C1, 4, self.means, self.stds,
+                  ops._ptr(n_valid), s)       # n_valid [B] int32: rows past it are padding (probability 0: they sort last)
         rank_idx = torch.empty((B, C, F), device=dev, dtype=torch.int32)
         sorted_score = torch.empty((B, F, C), device=dev, dtype=torch.float32)
         sorted_bbox = torch.empty((B, F, C, 4), device=dev, dtype=torch.float32)

@@ -31,6 +31,9 @@ _SIGNATURES = {
     'relnet_relation_attention': (C.c_int, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _i, _l, _vp,
                                             _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp,
                                             _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    'relnet_relation_attention_kc': (C.c_int, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _i, _l, _vp,
+                                               _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp,
+                                               _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp]),
     'relnet_relation_attention_fused': (C.c_int, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _i, _i, _vp, _vp, _vp,
                                                   _vp, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l,
                                                   _i, _i, _i, _i, _i, _f, _vp]),
@@ -44,6 +47,7 @@ _SIGNATURES = {
     'relnet_roi_pool_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     'relnet_roi_pool_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_detect_head': (C.c_int, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'relnet_detect_head_ex': (C.c_int, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'relnet_class_nms': (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, C.c_double, _i, _i, _vp]),
     'relnet_class_nms_ex': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, C.c_double, _i, _i, _vp]),
     'relnet_bbox_overlaps': (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),
@@ -55,6 +59,7 @@ _SIGNATURES = {
     'relnet_deformable_psroi_pool_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_f, _f, _i, _i, _i, _vp]),
     'relnet_roi_pool_fpn_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_fpn_roi_dispatch': (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'relnet_fpn_roi_dispatch_ex': (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     'relnet_upsample2x_add': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'relnet_softmax_output': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _i, _l, _i, _f, _f, _vp]),
     'relnet_smooth_l1_loss': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _vp]),
@@ -63,6 +68,9 @@ _SIGNATURES = {
     'relnet_relation_attention_bwd': (C.c_int, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _vp, _l, _l,
                                                 _vp, _l, _l, _vp, _vp, _l, _l, _vp, _l, _l, _vp, _vp, _vp, _vp, _vp,
                                                 _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    'relnet_relation_attention_bwd_kc': (C.c_int, [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _vp, _l, _l,
+                                                   _vp, _l, _l, _vp, _vp, _l, _l, _vp, _l, _l, _vp, _vp, _vp, _vp, _vp,
+                                                   _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     'relnet_geometry_bias_bwd': (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'relnet_relu_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _l, _i, _vp]),
     'relnet_sgd_update': (C.c_int, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _vp]),
@@ -79,6 +87,7 @@ _SIGNATURES = {
     'relnet_nms_greedy': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     'relnet_stem_bias_relu_pool': (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_lnms_prepare': (C.c_int, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'relnet_lnms_prepare_ex': (C.c_int, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'relnet_lnms_sort': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'relnet_lnms_embed': (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_lnms_score': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -86,6 +95,9 @@ _SIGNATURES = {
     'relnet_stem_pack_input': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_stem_conv7': (C.c_int, [_vp, _vp, _vp, _i, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_proposal_target': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    'relnet_proposal_target_ex': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    'relnet_assign_anchor': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
+                                       C.c_double, C.c_double, _i, _i, C.c_ulonglong, _vp, _vp]),
     'relnet_box_annotator_ohem': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'relnet_nms_multi_target': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
 }

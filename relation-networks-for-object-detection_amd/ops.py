@@ -78,9 +78,11 @@ def embedding_divisors(feat_dim=64, wave_length=1000.0):
                      torch.tensor(8.0 / feat_dim, dtype=torch.float32) * k)
 
 
-def geometry_bias(boxes, wp_t, bp, M=None, divisors=None, debug=False, half=False):
+def geometry_bias(boxes, wp_t, bp, M=None, divisors=None, debug=False, half=False, fast32=False):
     """boxes [B,N,4|5] fp32 (xyxy, or batch_idx + xyxy); wp_t [64, nmod*16]; bp [nmod*16]
-    -> bias [nmod, B, 16, N, Mpad] fp32 = log(max(relu(E Wp^T + bp), 1e-6)).
+    -> bias [nmod, B, 16, N, Mpad] fp32 = log(max(relu(E Wp^T + bp), 1e-6)) (the oracle's arithmetic: correctly rounded
+    sin / cos / log, float64 accumulation; fast32: float32 libm arithmetic, for the training recompute), or with half=True
+    fp16 log2(.) from the matrix-core kernel (bf16 throughput path).
     debug=True also returns (position_matrix [B,N,M,4], position_embedding [B,N,M,64])."""
     _chk(boxes, wp_t, bp)
     assert boxes.dtype == torch.float32 and boxes.is_contiguous()
@@ -97,17 +99,19 @@ def geometry_bias(boxes, wp_t, bp, M=None, divisors=None, debug=False, half=Fals
         pm = torch.empty((B, N, M, 4), device=boxes.device, dtype=torch.float32)
         pe = torch.empty((B, N, M, 64), device=boxes.device, dtype=torch.float32)
     _lib.call('relnet_geometry_bias', boxes.data_ptr(), bs, off, wp_t.data_ptr(), bp.data_ptr(),
-              div.data_ptr(), bias.data_ptr(), int(half), _ptr(pm), _ptr(pe), B, N, M, Mpad, 16, nmod, _stream())
+              div.data_ptr(), bias.data_ptr(), 1 if half else (-1 if fast32 else 0), _ptr(pm), _ptr(pe), B, N, M, Mpad, 16, nmod, _stream())
     if debug:
         return bias, pm, pe
     return bias
 
 
 def relation_attention(q, k, vwt, bias, bout=None, resid=None, M=None, want_out=True,
-                       want_act=False, want_logits=False, heads=16):
+                       want_act=False, want_logits=False, heads=16, key_count=None):
     """q [B,N,>=H*64] (row stride free), k [B,>=M,..], vwt [B,H*64,Mpad] (zero padded),
-    bias [B,H,N,Mpad] fp32 -> (out [B,N,H*64] | None, relu(resid+out) | None, logits | None)."""
-    _chk(q, k, vwt, bias, bout, resid)
+    bias [B,H,N,Mpad] fp32 -> (out [B,N,H*64] | None, relu(resid+out) | None, logits | None).
+    key_count [B] int32 (optional): image b has only key_count[b] <= M keys, the rest of its key rows are padding."""
+    _chk(q, k, vwt, bias, bout, resid, key_count)
+    assert key_count is None or (key_count.dtype == torch.int32 and key_count.is_contiguous() and key_count.numel() == q.shape[0])
     B, N = q.shape[0], q.shape[1]
     H = heads
     Mpad = vwt.shape[-1]
@@ -119,12 +123,12 @@ def relation_attention(q, k, vwt, bias, bout=None, resid=None, M=None, want_out=
     act = torch.empty((B, N, H * 64), device=q.device, dtype=dt) if want_act else None
     logits = torch.empty((B, N, H, M), device=q.device, dtype=torch.float32) if want_logits else None
     rs = (resid.stride(1), resid.stride(0)) if resid is not None else (0, 0)
-    _lib.call('relnet_relation_attention',
+    _lib.call('relnet_relation_attention_kc',
               q.data_ptr(), q.stride(1), q.stride(0), k.data_ptr(), k.stride(1), k.stride(0),
               vwt.data_ptr(), vwt.stride(1), vwt.stride(0), bias.data_ptr(), int(bias.dtype == torch.float16), bias.stride(0),
               _ptr(bout), _ptr(resid), rs[0], rs[1],
               _ptr(out), H * 64, N * H * 64, _ptr(act), H * 64, N * H * 64, _ptr(logits),
-              B, H, N, M, Mpad, 1.0 / math.sqrt(64.0), _dt(q), _dt(q), _stream())
+              B, H, N, M, Mpad, 1.0 / math.sqrt(64.0), _dt(q), _dt(q), _ptr(key_count), _stream())
     return out, act, logits
 
 
@@ -274,18 +278,19 @@ def roi_pool_bwd(grad_out, argmax, rois, in_shape, batch_index_base=0):
 # ---------------------------------------------------------------------------------------
 # detection post-processing
 # ---------------------------------------------------------------------------------------
-def detect_head(cls_score, bbox_pred, rois, im_info, rois_per_image, delta_off=4):
+def detect_head(cls_score, bbox_pred, rois, im_info, rois_per_image, delta_off=4, n_valid=None):
     """cls_score [R,C] fp32 logits, bbox_pred [R,4*num_reg] fp32, rois [R,5], im_info [B,3]
-    -> cls_prob [R,C] fp32, boxes [R,4] float64 (decoded class-agnostic fg box / im scale)."""
-    _chk(cls_score, bbox_pred, rois, im_info)
+    -> cls_prob [R,C] fp32, boxes [R,4] float64 (decoded class-agnostic fg box / im scale).
+    n_valid [B] int32 (optional): rows past n_valid[b] of image b are padding -> all-zero probabilities and boxes."""
+    _chk(cls_score, bbox_pred, rois, im_info, n_valid)
     R, Cn = cls_score.shape
     assert cls_score.dtype == torch.float32 and bbox_pred.dtype == torch.float32
     assert cls_score.stride(1) == 1 and bbox_pred.stride(1) == 1 and rois.is_contiguous()
     prob = torch.empty((R, Cn), device=cls_score.device, dtype=torch.float32)
     boxes = torch.empty((R, 4), device=cls_score.device, dtype=torch.float64)
-    _lib.call('relnet_detect_head', cls_score.data_ptr(), cls_score.stride(0), bbox_pred.data_ptr(),
+    _lib.call('relnet_detect_head_ex', cls_score.data_ptr(), cls_score.stride(0), bbox_pred.data_ptr(),
               bbox_pred.stride(0), rois.data_ptr(), im_info.data_ptr(), prob.data_ptr(), boxes.data_ptr(),
-              R, Cn, rois_per_image, delta_off, _stream())
+              R, Cn, rois_per_image, delta_off, _ptr(n_valid), _stream())
     return prob, boxes
 
 
@@ -506,11 +511,13 @@ def _d4(v):
 
 
 def proposal_target(rois, gt_boxes, num_gt=None, num_reg=2, class_agnostic=True, bg_thresh_hi=0.5,
-                    means=(0.0, 0.0, 0.0, 0.0), stds=(0.1, 0.1, 0.2, 0.2), weights=(1.0, 1.0, 1.0, 1.0)):
+                    means=(0.0, 0.0, 0.0, 0.0), stds=(0.1, 0.1, 0.2, 0.2), weights=(1.0, 1.0, 1.0, 1.0), num_rois=None):
     """rois [B,N,5], gt_boxes [B,Gmax,5] (x1,y1,x2,y2,cls), num_gt [B] int32 (default: all Gmax valid)
     -> rois_out [B,N+Gmax,5], label [B,N+Gmax], bbox_target / bbox_weight [B,N+Gmax,4*num_reg]
-    (BATCH_ROIS = -1 semantics; rows past N + num_gt[b] carry label -1 and zero weights)."""
-    _chk(rois, gt_boxes, num_gt)
+    (BATCH_ROIS = -1 semantics; rows past N + num_gt[b] carry label -1 and zero weights).
+    num_rois [B] int32 (optional): only the first num_rois[b] input rows are proposals; the padded rows come out with a
+    zero box, label -1 and zero weights."""
+    _chk(rois, gt_boxes, num_gt, num_rois)
     B, N, _ = rois.shape
     G = gt_boxes.shape[1]
     dev = rois.device
@@ -521,10 +528,42 @@ def proposal_target(rois, gt_boxes, num_gt=None, num_reg=2, class_agnostic=True,
     lab = torch.empty((B, R), device=dev, dtype=torch.float32)
     bt = torch.empty((B, R, 4 * num_reg), device=dev, dtype=torch.float32)
     bw = torch.empty((B, R, 4 * num_reg), device=dev, dtype=torch.float32)
-    _lib.call('relnet_proposal_target', rois.contiguous().data_ptr(), gt_boxes.contiguous().data_ptr(), num_gt.data_ptr(),
+    _lib.call('relnet_proposal_target_ex', rois.contiguous().data_ptr(), gt_boxes.contiguous().data_ptr(), num_gt.data_ptr(),
               ro.data_ptr(), lab.data_ptr(), bt.data_ptr(), bw.data_ptr(), B, N, G, num_reg, int(class_agnostic),
-              float(bg_thresh_hi), _d4(means), _d4(stds), _d4(weights), _stream())
+              float(bg_thresh_hi), _d4(means), _d4(stds), _d4(weights), _ptr(num_rois), _stream())
     return ro, lab, bt, bw
+
+
+def assign_anchor(gt_boxes, num_gt, im_info, base_anchors, feat_hw, feat_stride=16, rpn_batch_size=256, fg_fraction=0.5,
+                  negative_overlap=0.3, positive_overlap=0.7, clobber_positives=False, allowed_border=0, seed=0,
+                  want_all=False, seed_dev=None):
+    """lib/rpn/rpn.py:80-244 for B images on the device.  gt_boxes [B,Gmax,5] fp32, num_gt [B] int32 (None: all valid),
+    im_info [B,3], base_anchors [A,4] float64 (host or device) -> label [B, A*h*w] ((a,y,x) order), bbox_target /
+    bbox_weight [B,4A,h,w] (+ the pre-sub-sampling labels with want_all).  `seed` (+ the device int64 word `seed_dev`, e.g. a
+    step counter advanced inside a captured graph) selects the random fg / bg subset."""
+    import ctypes
+    _chk(gt_boxes, num_gt, im_info)
+    B, G, _ = gt_boxes.shape
+    dev = gt_boxes.device
+    assert gt_boxes.dtype == torch.float32 and im_info.dtype == torch.float32
+    if num_gt is None:
+        num_gt = torch.full((B,), G, device=dev, dtype=torch.int32)
+    if G == 0:                       # images without any box: one (ignored) gt slot keeps the buffers non-empty
+        gt_boxes, G = torch.zeros((B, 1, 5), device=dev, dtype=torch.float32), 1
+    base = torch.as_tensor(base_anchors).detach().to('cpu', torch.float64).contiguous()
+    A = base.shape[0]
+    fh, fw = feat_hw
+    label = torch.empty((B, A * fh * fw), device=dev, dtype=torch.float32)
+    bt = torch.empty((B, 4 * A, fh, fw), device=dev, dtype=torch.float32)
+    bw = torch.empty((B, 4 * A, fh, fw), device=dev, dtype=torch.float32)
+    lall = torch.empty_like(label) if want_all else None
+    ws = torch.empty((B, G), device=dev, dtype=torch.int64)
+    _lib.call('relnet_assign_anchor', gt_boxes.contiguous().data_ptr(), num_gt.data_ptr(), im_info.contiguous().data_ptr(),
+              base.data_ptr(), label.data_ptr(), bt.data_ptr(), bw.data_ptr(), _ptr(lall), ws.data_ptr(), B, A, fh, fw, G,
+              int(feat_stride), int(rpn_batch_size), int(fg_fraction * rpn_batch_size), float(negative_overlap),
+              float(positive_overlap), int(clobber_positives), int(allowed_border), ctypes.c_ulonglong(int(seed) & (2 ** 64 - 1)),
+              _ptr(seed_dev), _stream())
+    return (label, bt, bw, lall) if want_all else (label, bt, bw)
 
 
 def box_annotator_ohem(cls_score, bbox_pred, labels, bbox_targets, bbox_weights, roi_per_img=128, want_loss=False):
@@ -632,19 +671,26 @@ def deformable_psroi_pool(data, rois, trans=None, spatial_scale=0.0625, output_d
 # ---------------------------------------------------------------------------------------
 # FPN configuration
 # ---------------------------------------------------------------------------------------
-def fpn_roi_dispatch(rois, batch_index_base=0):
-    """rois [B,N,4] (xyxy) or [B,N,5] (idx + xyxy) fp32 -> (rois_sorted [B,N,5], level [B,N] int32,
-    perm [B,N] int32, counts [B,4] int32); core/rcnn.py:53-74 on the device."""
-    _chk(rois)
+def fpn_roi_dispatch(rois, batch_index_base=0, n_valid=None, pad_empty=False):
+    """rois [B,N,4] (xyxy) or [B,N,5] (idx + xyxy) fp32 -> (rois_sorted [B,N',5], level [B,N'] int32,
+    perm [B,N'] int32, counts [B,4] int32); core/rcnn.py:53-74 on the device.  N' = N, or N + 4 with pad_empty: a pyramid
+    level without a roi then gets the reference's all-zero dummy roi (rcnn.py:61-71; perm -1) and a fifth result,
+    n_rows [B] int32 = the image's real rows (rois + dummies), is returned; rows past it are padding.
+    n_valid [B] int32 (optional): only the first n_valid[b] input rows are rois (the others are moved behind the real rows)."""
+    _chk(rois, n_valid)
     assert rois.dtype == torch.float32 and rois.is_contiguous() and rois.dim() == 3
     B, N, bs = rois.shape
-    out = torch.empty((B, N, 5), device=rois.device, dtype=torch.float32)
-    level = torch.empty((B, N), device=rois.device, dtype=torch.int32)
-    perm = torch.empty((B, N), device=rois.device, dtype=torch.int32)
+    n_out = N + 4 if pad_empty else N
+    want_rows = pad_empty or n_valid is not None
+    out = torch.empty((B, n_out, 5), device=rois.device, dtype=torch.float32)
+    level = torch.empty((B, n_out), device=rois.device, dtype=torch.int32)
+    perm = torch.empty((B, n_out), device=rois.device, dtype=torch.int32)
     counts = torch.empty((B, 4), device=rois.device, dtype=torch.int32)
-    _lib.call('relnet_fpn_roi_dispatch', rois.data_ptr(), bs, bs - 4, out.data_ptr(), level.data_ptr(),
-              perm.data_ptr(), counts.data_ptr(), B, N, batch_index_base, _stream())
-    return out, level, perm, counts
+    n_rows = torch.empty((B,), device=rois.device, dtype=torch.int32) if want_rows else None
+    _lib.call('relnet_fpn_roi_dispatch_ex', rois.data_ptr(), bs, bs - 4, out.data_ptr(), level.data_ptr(),
+              perm.data_ptr(), counts.data_ptr(), B, N, batch_index_base, _ptr(n_valid), int(pad_empty), n_out,
+              _ptr(n_rows), _stream())
+    return (out, level, perm, counts, n_rows) if want_rows else (out, level, perm, counts)
 
 
 def roi_pool_fpn(levels, scales, rois, roi_level, pooled=(7, 7), channels_last_out=False, batch_index_base=0,
@@ -730,9 +776,9 @@ def transpose_2d(x, out=None, pad_cols_to=1):
     return out
 
 
-def relation_attention_bwd(q, k, kt, vw, bias, dy, y, bout, qt, dyt, M, heads=16):
+def relation_attention_bwd(q, k, kt, vw, bias, dy, y, bout, qt, dyt, M, heads=16, key_count=None):
     """Adjoint of relation_attention: -> (dq [B,N,H*64], dk [B,M,H*64], dvw [B,M,H*64], prob, dlog [B,H,N,Mpad]), fp32."""
-    _chk(q, k, kt, vw, bias, dy, y, bout, qt, dyt)
+    _chk(q, k, kt, vw, bias, dy, y, bout, qt, dyt, key_count)
     B, N = q.shape[0], q.shape[1]
     H = heads
     Mpad, Npad = bias.shape[-1], qt.shape[-1]
@@ -744,13 +790,13 @@ def relation_attention_bwd(q, k, kt, vw, bias, dy, y, bout, qt, dyt, M, heads=16
     dq = torch.empty((B, N, H * 64), device=dev, dtype=torch.float32)
     dk = torch.empty((B, M, H * 64), device=dev, dtype=torch.float32)
     dvw = torch.empty((B, M, H * 64), device=dev, dtype=torch.float32)
-    _lib.call('relnet_relation_attention_bwd',
+    _lib.call('relnet_relation_attention_bwd_kc',
               q.data_ptr(), q.stride(1), q.stride(0), k.data_ptr(), k.stride(1), k.stride(0),
               kt.data_ptr(), kt.stride(1), kt.stride(0), vw.data_ptr(), vw.stride(1), vw.stride(0),
               bias.data_ptr(), bias.stride(0), dy.data_ptr(), dy.stride(1), dy.stride(0),
               y.data_ptr(), y.stride(1), y.stride(0), _ptr(bout), qt.data_ptr(), qt.stride(1), qt.stride(0),
               dyt.data_ptr(), dyt.stride(1), dyt.stride(0), prob.data_ptr(), dlog.data_ptr(), dq.data_ptr(),
-              dk.data_ptr(), dvw.data_ptr(), B, H, N, M, Mpad, Npad, 1.0 / math.sqrt(64.0), _dt(q), _stream())
+              dk.data_ptr(), dvw.data_ptr(), B, H, N, M, Mpad, Npad, 1.0 / math.sqrt(64.0), _dt(q), _ptr(key_count), _stream())
     return dq, dk, dvw, prob, dlog
 
 

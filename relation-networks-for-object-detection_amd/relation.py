@@ -42,7 +42,7 @@ def pack_pair_pos(mods, device):
 
 def attention_module_multi_head(roi_feat, rois, params, nongt_dim=None, fc_dim=16, feat_dim=1024,
                                 dim=(1024, 1024, 1024), group=16, index=1, dtype=None,
-                                return_logits=False, packed=None, bias=None, fused=False):
+                                return_logits=False, packed=None, bias=None, fused=False, key_count=None):
     """Drop-in for SYM_REL.attention_module_multi_head (:85-151) on device tensors.
 
     roi_feat [N, feat_dim] or [B, N, feat_dim]; `rois` [.., N, 4|5] takes the place of the
@@ -59,11 +59,11 @@ def attention_module_multi_head(roi_feat, rois, params, nongt_dim=None, fc_dim=1
     M = N if nongt_dim is None else nongt_dim
     mod = packed or RelationParams(params, index, dtype, f.device)
     bx = bx.to(torch.float32).contiguous()
-    if bias is None and not (fused and not return_logits and fused_ok(dtype, M)):
+    if bias is None and not (fused and not return_logits and key_count is None and fused_ok(dtype, M)):
         wp_t, bp = pack_pair_pos([mod], f.device)
         bias = ops.geometry_bias(bx, wp_t, bp, M, half=(dtype == torch.bfloat16 and not return_logits))[0]
     y, _, logits = _module_forward(f, mod, bias, M, want_out=True, want_act=False,
-                                   want_logits=return_logits, rois=bx)
+                                   want_logits=return_logits, rois=bx, key_count=key_count)
     if squeeze:
         y = y[0]
         logits = logits[0] if logits is not None else None
@@ -75,8 +75,9 @@ def fused_ok(dtype, M, heads=16):
     return dtype == torch.bfloat16 and heads == 16 and M <= ops.FUSED_MAX_KEYS
 
 
-def _module_forward(f, mod, bias, M, want_out, want_act, want_logits, vwt_buf=None, rois=None):
-    """`bias` None + `rois` given: fused geometry + attention kernel (no bias tensor, no logits output)."""
+def _module_forward(f, mod, bias, M, want_out, want_act, want_logits, vwt_buf=None, rois=None, key_count=None):
+    """`bias` None + `rois` given: fused geometry + attention kernel (no bias tensor, no logits output).
+    key_count [B] int32: per-image number of real keys among the first M rows (ops.relation_attention)."""
     B, N, F = f.shape
     qk = ops.gemm_nt(f.reshape(B * N, F), mod.wqk, mod.bqk).reshape(B, N, -1)
     Mpad = bias.shape[-1] if bias is not None else ops.pad32(M)
@@ -86,14 +87,14 @@ def _module_forward(f, mod, bias, M, want_out, want_act, want_logits, vwt_buf=No
     ops.gemm_nt(mod.wout, f[:, :M, :], out=vwt_buf, n_cols=M)
     d = mod.wqk.shape[0] // 2
     if bias is None:
-        assert rois is not None and not want_logits
+        assert rois is not None and not want_logits and key_count is None
         y, act = ops.relation_attention_fused(qk[:, :, :d], qk[:, :M, d:], vwt_buf, rois, mod.wp_dev, mod.bp_dev,
                                               bout=mod.bout, resid=f if want_act else None, M=M, want_out=want_out,
                                               want_act=want_act)
         return y, act, None
     return ops.relation_attention(qk[:, :, :d], qk[:, :M, d:], vwt_buf, bias, bout=mod.bout,
                                   resid=f if want_act else None, M=M, want_out=want_out,
-                                  want_act=want_act, want_logits=want_logits)
+                                  want_act=want_act, want_logits=want_logits, key_count=key_count)
 
 
 class RelationHead(object):
@@ -129,9 +130,10 @@ class RelationHead(object):
             self._vwt[key] = [torch.zeros((B, 1024, Mpad), device=self.device, dtype=self.dtype) for _ in range(2)]
         return self._vwt[key]
 
-    def forward(self, pooled, rois, nongt_dim=None, return_intermediates=False):
+    def forward(self, pooled, rois, nongt_dim=None, return_intermediates=False, key_count=None):
         """pooled [B, N, 12544] (dtype), rois [B, N, 5] fp32 -> cls_score [B,N,C], bbox_pred [B,N,8]
-        (fp32 logits; softmax / decoding live in postprocess)."""
+        (fp32 logits; softmax / decoding live in postprocess).  key_count [B] int32: real rows per image when the roi
+        buffer is padded to a fixed size (FPN dummy rois, truncated proposal lists); padded rows are no relation keys."""
         B, N, K = pooled.shape
         if not self.use_relation:        # plain 2FC head, resnet_v1_101_rcnn.py:125-134
             x1 = ops.gemm_nt(pooled.reshape(B * N, K), self.w1, self.b1, relu=True)
@@ -139,15 +141,15 @@ class RelationHead(object):
             cb = ops.gemm_nt(x2.reshape(B * N, -1), self.wcb, self.bcb, out_dtype=torch.float32).reshape(B, N, -1)
             return cb[:, :, :self.num_classes], cb[:, :, self.num_classes:], x2
         M = N if nongt_dim is None else nongt_dim
-        if self.fused and fused_ok(self.dtype, M):
+        if self.fused and fused_ok(self.dtype, M) and key_count is None:
             bias = (None, None)                 # geometry evaluated inside the attention kernel of each module
         else:
             bias = ops.geometry_bias(rois, self.wp_t, self.bp, M, half=self.dtype == torch.bfloat16)   # [2,B,16,N,Mpad]
         vw = self._vwt_buf(B, ops.pad32(M), M)
         f1 = ops.gemm_nt(pooled.reshape(B * N, K), self.w1, self.b1).reshape(B, N, -1)
-        y1, x1, _ = _module_forward(f1, self.mods[0], bias[0], M, return_intermediates, True, False, vw[0], rois)
+        y1, x1, _ = _module_forward(f1, self.mods[0], bias[0], M, return_intermediates, True, False, vw[0], rois, key_count)
         f2 = ops.gemm_nt(x1.reshape(B * N, -1), self.w2, self.b2).reshape(B, N, -1)
-        y2, x2, _ = _module_forward(f2, self.mods[1], bias[1], M, return_intermediates, True, False, vw[1], rois)
+        y2, x2, _ = _module_forward(f2, self.mods[1], bias[1], M, return_intermediates, True, False, vw[1], rois, key_count)
         cb = ops.gemm_nt(x2.reshape(B * N, -1), self.wcb, self.bcb, out_dtype=torch.float32).reshape(B, N, -1)
         cls_score, bbox_pred = cb[:, :, :self.num_classes], cb[:, :, self.num_classes:]
         if return_intermediates:
@@ -156,7 +158,7 @@ class RelationHead(object):
         return cls_score, bbox_pred, x2
 
 
-def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, index=1, dtype=None, packed=None):
+def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, index=1, dtype=None, packed=None, key_count=None):
     """Gradient of `attention_module_multi_head` (the adjoint MXNet's autograd derives from SYM_REL:85-151).
 
     roi_feat [B,N,1024] (or [N,1024]), rois [..,N,4|5], d_out = d loss / d module output, same shape.
@@ -177,7 +179,7 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
     M = N if nongt_dim is None else nongt_dim
     mod = packed or RelationParams(params, index, dtype, f.device)
     wp_t, bp = pack_pair_pos([mod], f.device)
-    bias = ops.geometry_bias(bx, wp_t, bp, M)[0]                       # fp32 log G  [B,16,N,Mpad]
+    bias = ops.geometry_bias(bx, wp_t, bp, M, fast32=(dtype == torch.bfloat16))[0]   # fp32 log G  [B,16,N,Mpad]
     Mpad = bias.shape[-1]
     d = mod.wqk.shape[0] // 2
     kpad = 64 if dtype == torch.bfloat16 else 16                        # GEMM K granularity
@@ -186,7 +188,7 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
     q, k = qk[:, :, :d], qk[:, :M, d:]
     vwt = torch.zeros((B, d, Mpad), device=f.device, dtype=dtype)
     ops.gemm_nt(mod.wout, f[:, :M, :], out=vwt, n_cols=M)
-    y, _, _ = ops.relation_attention(q, k, vwt, bias, bout=mod.bout, M=M, want_out=True)
+    y, _, _ = ops.relation_attention(q, k, vwt, bias, bout=mod.bout, M=M, want_out=True, key_count=key_count)
     # ---- operand layouts of the backward kernels
     vw = ops.gemm_nt(f[:, :M, :].reshape(B * M, Fd) if M == N else f[:, :M, :].contiguous().reshape(B * M, Fd),
                      mod.wout).reshape(B, M, d)                          # F_K Wout^T, not transposed
@@ -194,7 +196,7 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
     ops.transpose_2d(k, out=kt)
     qt = ops.transpose_2d(q, pad_cols_to=32)
     dyt = ops.transpose_2d(dY, pad_cols_to=32)
-    dq, dk, dvw, prob, dlog = ops.relation_attention_bwd(q, k, kt, vw, bias, dY, y, mod.bout, qt, dyt, M)
+    dq, dk, dvw, prob, dlog = ops.relation_attention_bwd(q, k, kt, vw, bias, dY, y, mod.bout, qt, dyt, M, key_count=key_count)
     dwp, dbp = ops.geometry_bias_bwd(bx, bias, dlog, M, fast=(dtype == torch.bfloat16))
     # ---- projections: Q|K = F [Wq;Wk]^T + b,  VW = F_K Wout^T
     dqk = torch.zeros((B, N, 2 * d), device=f.device, dtype=dtype)

@@ -239,10 +239,23 @@ class Trainer(object):
         ends[5] = x
         return x, conv4, saved, ends
 
-    def forward_backward(self, data, im_info, gt_boxes, rpn_label, rpn_bbox_target, rpn_bbox_weight, num_gt=None):
+    def rpn_targets(self, gt_boxes, num_gt, im_info, feat_hw):
+        """lib/rpn/rpn.py:80-244 (`assign_anchor`, host numpy inside the reference's AnchorLoader) on the device for the whole
+        batch: one C-ABI call, no host round trip.  The random fg / bg subset is keyed by cfg.seed + a device step counter that
+        is advanced here, i.e. also by every replay of a captured step."""
+        c = self.cfg
+        if getattr(self, '_anchor_step', None) is None:
+            self._anchor_step = torch.zeros(1, device=gt_boxes.device, dtype=torch.int64)
+        out = ops.assign_anchor(gt_boxes, num_gt, im_info, self.anchors, feat_hw, c.feat_stride, c.rpn_batch_size,
+                                getattr(c, 'rpn_fg_fraction', 0.5), getattr(c, 'rpn_negative_overlap', 0.3),
+                                getattr(c, 'rpn_positive_overlap', 0.7), seed=getattr(c, 'seed', 0), seed_dev=self._anchor_step)
+        self._anchor_step += 1
+        return out
+
+    def forward_backward(self, data, im_info, gt_boxes, rpn_label=None, rpn_bbox_target=None, rpn_bbox_weight=None, num_gt=None):
         """data [B,3,H,W] fp32; gt_boxes [B,G,5]; rpn_label [B, A*h*w] ((a,y,x) order), rpn_bbox_target / weight
-        [B, 4A, h, w] (lib/rpn/rpn.py:assign_anchor layouts).  Accumulates gradients into the flat buffers and
-        returns the loss values (reference metric names)."""
+        [B, 4A, h, w] (lib/rpn/rpn.py:assign_anchor layouts) -- or None: computed on the device from gt_boxes
+        (`rpn_targets`).  Accumulates gradients into the flat buffers and returns the loss values (reference metric names)."""
         c = self.cfg
         B = data.shape[0]
         self._grad_buckets().reset()
@@ -253,6 +266,8 @@ class Trainer(object):
         rpn = self._conv(r, 'rpn_out', bias=self.b('rpn_out'), out_dtype=torch.float32)             # [B,h,w,72]
         h, wd_ = rpn.shape[1], rpn.shape[2]
         na2 = self.na2
+        if rpn_label is None:
+            rpn_label, rpn_bbox_target, rpn_bbox_weight = self.rpn_targets(gt_boxes, num_gt, im_info, (h, wd_))
         # -- RPN losses (per image, like one image per device in the reference)
         score_nchw = rpn[..., :na2].permute(0, 3, 1, 2).contiguous()                                 # [B,2A,h,w]
         d_score = torch.empty_like(score_nchw)
@@ -375,9 +390,12 @@ class Trainer(object):
                 self._add_wgrad(na, dw, self.bn_scale[na])
         self._bucket_ready('res%d' % prev)
 
-    def _head_forward_backward(self, pooled2, rois_t, N, label, bbox_target, bbox_weight, im_info, gt_boxes, num_gt, out):
+    def _head_forward_backward(self, pooled2, rois_t, N, label, bbox_target, bbox_weight, im_info, gt_boxes, num_gt, out,
+                               key_count=None):
         """2FC head + relation modules + OHEM + losses (+ learn-NMS branch) and their adjoint down to the pooled features.
         pooled2 [B*R, 12544] bf16 ((ph, pw, c) column order), rois_t [B,R,5] with the N non-gt rows first.
+        key_count [B] int32 (optional): how many of the first N rows of each image are real proposals (the rest is padding
+        of a truncated / short proposal list: no relation keys, label -1, never ranked by the learn-NMS branch).
         Returns (d_pool [B*R,12544] bf16, (x2, f1, cls_score, bbox_pred, labels_ohem, weights_ohem))."""
         c = self.cfg
         B, R = rois_t.shape[0], rois_t.shape[1]
@@ -387,9 +405,9 @@ class Trainer(object):
         wp_t, bp = pack_pair_pos(mods, self.device)
         bias = ops.geometry_bias(rois_t, wp_t, bp, N, half=True)
         f1 = ops.gemm_nt(pooled2, self.w('fc_new_1'), self.b('fc_new_1')).reshape(B, R, -1)
-        _, x1, _ = _module_forward(f1, mods[0], bias[0], N, False, True, False)
+        _, x1, _ = _module_forward(f1, mods[0], bias[0], N, False, True, False, key_count=key_count)
         f2 = ops.gemm_nt(x1.reshape(B * R, -1), self.w('fc_new_2'), self.b('fc_new_2')).reshape(B, R, -1)
-        _, x2, _ = _module_forward(f2, mods[1], bias[1], N, False, True, False)
+        _, x2, _ = _module_forward(f2, mods[1], bias[1], N, False, True, False, key_count=key_count)
         cb = ops.gemm_nt(x2.reshape(B * R, -1), self.w('cls_bbox'), self.b('cls_bbox'), out_dtype=torch.float32).reshape(B, R, -1)
         nc = self.num_classes
         cls_score, bbox_pred = cb[:, :, :nc].contiguous(), cb[:, :, nc:].contiguous()
@@ -404,7 +422,7 @@ class Trainer(object):
         d_x2_lnms = None
         if c.learn_nms:     # the learn-NMS head sees the first N (non-gt) rows; its gradient joins cls_score and fc_all_2_relu
             d_cls_l, d_x2_lnms, lo = self._lnms_forward_backward(cls_score[:, :N], bbox_pred[:, :N], rois_t[:, :N].contiguous(),
-                                                                 im_info, x2[:, :N], gt_boxes, num_gt)
+                                                                 im_info, x2[:, :N], gt_boxes, num_gt, n_valid=key_count)
             d_cls[:, :N] += d_cls_l
             out.update(lo)
         # ================= backward =================
@@ -414,15 +432,15 @@ class Trainer(object):
         if d_x2_lnms is not None:
             d_x2 = d_x2.reshape(B, R, -1)
             d_x2[:, :N] += d_x2_lnms.to(d_x2.dtype)
-        d_f2 = self._relation_bwd(2, mods[1], f2, x2, rois_t, d_x2.reshape(B, R, -1), N)
+        d_f2 = self._relation_bwd(2, mods[1], f2, x2, rois_t, d_x2.reshape(B, R, -1), N, key_count)
         d_x1, dw, db = T.linear_bwd(x1.reshape(B * R, -1), self.w('fc_new_2'), d_f2.reshape(B * R, -1), keep_splits=True)
         self._add_wgrad('fc_new_2', dw); self._add_bgrad('fc_new_2', db)
-        d_f1 = self._relation_bwd(1, mods[0], f1, x1, rois_t, d_x1.reshape(B, R, -1), N)
+        d_f1 = self._relation_bwd(1, mods[0], f1, x1, rois_t, d_x1.reshape(B, R, -1), N, key_count)
         d_pool, dw, db = T.linear_bwd(pooled2, self.w('fc_new_1'), d_f1.reshape(B * R, -1), keep_splits=True)
         self._add_wgrad('fc_new_1', dw); self._add_bgrad('fc_new_1', db)
         return d_pool, (x2, f1, cls_score, bbox_pred, labels_ohem, weights_ohem)
 
-    def _lnms_forward_backward(self, cls_score, bbox_pred, rois, im_info, feat, gt_boxes, num_gt):
+    def _lnms_forward_backward(self, cls_score, bbox_pred, rois, im_info, feat, gt_boxes, num_gt, n_valid=None):
         """Train branch of the learn-NMS head (symbols/..._learn_nms.py:424-551) and its adjoint.
         cls_score [B,N,81] fp32, bbox_pred [B,N,8] (BlockGrad), rois [B,N,5], feat = fc_all_2_relu[:, :N] bf16.
         Returns (d cls_score [B,N,81] fp32, d feat [B,N,1024] fp32, losses)."""
@@ -436,8 +454,8 @@ class Trainer(object):
         prob = torch.empty((B, N, C), device=dev, dtype=torch.float32)
         boxes = torch.empty((B, N, 4), device=dev, dtype=torch.float32)
         means, stds = (ctypes.c_float * 4)(*c.bbox_means), (ctypes.c_float * 4)(*c.bbox_stds)
-        _lib.call('relnet_lnms_prepare', cs.data_ptr(), cs.stride(0), bp_.data_ptr(), bp_.stride(0), rois.data_ptr(),
-                  im_info.data_ptr(), prob.data_ptr(), boxes.data_ptr(), B, N, C1, 4, means, stds, s_)
+        _lib.call('relnet_lnms_prepare_ex', cs.data_ptr(), cs.stride(0), bp_.data_ptr(), bp_.stride(0), rois.data_ptr(),
+                  im_info.data_ptr(), prob.data_ptr(), boxes.data_ptr(), B, N, C1, 4, means, stds, ops._ptr(n_valid), s_)
         rank_idx = torch.empty((B, C, F), device=dev, dtype=torch.int32)
         sorted_score = torch.empty((B, F, C), device=dev, dtype=torch.float32)
         sorted_bbox = torch.empty((B, F, C, 4), device=dev, dtype=torch.float32)
@@ -530,10 +548,10 @@ class Trainer(object):
         m.bp = self.b('pair_pos_fc1_%d' % i)
         return m
 
-    def _relation_bwd(self, i, mod, f, x_act, rois, d_x, N):
+    def _relation_bwd(self, i, mod, f, x_act, rois, d_x, N, key_count=None):
         """x_act = relu(f + relation_i(f)); returns d f and accumulates the module's parameter gradients."""
         g = T.relu_bwd(d_x.contiguous(), x_act)
-        r = attention_module_backward(f, rois, None, g, nongt_dim=N, index=i, dtype=torch.bfloat16, packed=mod)
+        r = attention_module_backward(f, rois, None, g, nongt_dim=N, index=i, dtype=torch.bfloat16, packed=mod, key_count=key_count)
         d = mod.wqk.shape[0] // 2
         self._add_wgrad('qk_%d' % i, torch.cat([r['query_%d_weight' % i], r['key_%d_weight' % i]], 0))
         self._add_bgrad('qk_%d' % i, torch.cat([r['query_%d_bias' % i], r['key_%d_bias' % i]], 0))
@@ -676,8 +694,12 @@ class FPNTrainer(Trainer):
         cfg.fpn = True
         Trainer.__init__(self, params, cfg, device, im_hw=None)
 
-    def forward_backward(self, data, im_info, gt_boxes, proposals, num_gt=None):
-        """data [B,3,H,W] (H, W multiples of 32), proposals [B,N,4] fp32, gt_boxes [B,G,5]."""
+    def forward_backward(self, data, im_info, gt_boxes, proposals, num_gt=None, num_proposals=None):
+        """data [B,3,H,W] (H, W multiples of 32), proposals [B,N,4] fp32, gt_boxes [B,G,5]; num_proposals [B] int32
+        (optional): real rows of `proposals` per image -- the reference hands every image its own roi count
+        (core/rcnn.py:128-146, TOP_ROIS truncation only); a batched step pads to a common N and the padded rows are
+        taken out on the device: zero box, label -1, zero weights (relnet_proposal_target_ex), moved behind the real rows by
+        the level dispatch, no relation keys (key_count), never ranked by the learn-NMS branch."""
         c = self.cfg
         B, N = proposals.shape[:2]
         bt = torch.bfloat16
@@ -696,9 +718,13 @@ class FPNTrainer(Trainer):
         # ---- rois: labels / targets, then level dispatch (non-gt rows first, gt rows after)
         rois5 = torch.cat([torch.zeros((B, N, 1), device=proposals.device), proposals], 2)
         rois5[:, :, 0] = torch.arange(B, device=proposals.device, dtype=torch.float32).view(B, 1)
-        rois_t, label, bbox_target, bbox_weight = ops.proposal_target(rois5.contiguous(), gt_boxes, num_gt)
+        rois_t, label, bbox_target, bbox_weight = ops.proposal_target(rois5.contiguous(), gt_boxes, num_gt, num_rois=num_proposals)
         R = rois_t.shape[1]
-        ra, la, pa, _ = ops.fpn_roi_dispatch(rois_t[:, :N].contiguous())
+        key_count = None
+        if num_proposals is not None:
+            ra, la, pa, _, key_count = ops.fpn_roi_dispatch(rois_t[:, :N].contiguous(), n_valid=num_proposals)
+        else:
+            ra, la, pa, _ = ops.fpn_roi_dispatch(rois_t[:, :N].contiguous())
         rb, lb, pb, _ = ops.fpn_roi_dispatch(rois_t[:, N:].contiguous())
         rois_s = torch.cat([ra, rb], 1).contiguous()
         level = torch.cat([la, lb], 1).contiguous()
@@ -711,7 +737,7 @@ class FPNTrainer(Trainer):
                                           want_argmax=True)
         pooled2 = pooled.permute(0, 2, 3, 1).reshape(B * R, -1)
         d_pool, hs = self._head_forward_backward(pooled2, rois_s, N, label.contiguous(), bbox_target, bbox_weight, im_info,
-                                                 gt_boxes, num_gt, out)
+                                                 gt_boxes, num_gt, out, key_count=key_count)
         x2, f1, cls_score, bbox_pred, labels_ohem, weights_ohem = hs
         # ---- pooling backward into the four pyramid maps
         g_lv = ops.roi_pool_fpn_bwd(d_pool.view(B * R, 7, 7, -1).permute(0, 3, 1, 2), argmax, rois_s.view(B * R, 5), level.view(-1),

@@ -124,6 +124,8 @@ def test_loaders(tmp_path):
         assert set(np.unique(b['label'].numpy())) <= {-1.0, 0.0, 1.0}
         seen += 1
     assert seen == 3
+    bd = next(iter(LD.AnchorLoader(roidb, cfg, batch_size=2, device_targets=True)))       # targets left to the device kernel
+    assert set(bd) == {'data', 'im_info', 'gt_boxes', 'num_gt'} and bd['gt_boxes'].shape[2] == 5
     # aspect grouping: both images of a batch have the same orientation
     al.reset()
     for k in range(0, 6, 2):
@@ -140,6 +142,12 @@ def test_loaders(tmp_path):
     it = LD.ROIIter(merged, fcfg, batch_size=2)
     b = next(iter(it))
     assert b['proposals'].shape == (2, 50, 4) and b['gt_boxes'].shape[2] == 5 and int(b['num_gt'][0]) == 4
+    # TOP_ROIS only truncates (core/rcnn.py:128-146 keeps the variable count): 30 real rows, zero padding, TRUE count reported
+    assert b['num_proposals'].tolist() == [30, 30] and float(b['proposals'][:, 30:].abs().max()) == 0.0
+    fcfg.TRAIN.TOP_ROIS = 20
+    b20 = next(iter(LD.ROIIter(merged, fcfg, batch_size=2)))
+    assert b20['proposals'].shape == (2, 20, 4) and b20['num_proposals'].tolist() == [20, 20]
+    assert np.array_equal(b20['proposals'].numpy(), b['proposals'][:, :20].numpy())
     assert b['data'].shape[2] % 32 == 0 and b['data'].shape[3] % 32 == 0           # IMAGE_STRIDE 32
     sc = float(b['im_info'][0, 2])
     want = IMG.clip_boxes(np.round(merged[0]['boxes'][:30].astype(np.float64) * sc), (float(b['im_info'][0, 0]), float(b['im_info'][0, 1])))

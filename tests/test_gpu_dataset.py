@@ -56,8 +56,13 @@ def test_pred_eval_and_precomputed_proposal_training(tmp_path):
     tr = train.FPNTrainer(pf, tcfg)
     it = LD.ROIIter(merged, fcfg, batch_size=2, shuffle=True, aspect_grouping=True, seed=1, device='cuda')
     batch = next(iter(it))
-    out = tr.forward_backward(batch['data'], batch['im_info'], batch['gt_boxes'], batch['proposals'], num_gt=batch['num_gt'])
+    out = tr.forward_backward(batch['data'], batch['im_info'], batch['gt_boxes'], batch['proposals'], num_gt=batch['num_gt'],
+                              num_proposals=batch['num_proposals'])
     assert out['rois'].shape[1] == 48 + batch['gt_boxes'].shape[1] and torch.isfinite(out['bbox_loss']).all()
+    # short proposal lists: the padded rows sit behind the real ones, carry a zero box and never a label
+    for b_ in range(2):
+        n = int(batch['num_proposals'][b_])
+        assert (out['rois'][b_, n:48, 1:] == 0).all() and (out['label'][b_, n:48] == -1).all()
     bad = [n for n in tr.W.slices if not torch.isfinite(tr.W.view(tr.W.grad, n)).all()]
     assert not bad, ('non-finite gradients', bad[:6], {k: float(v) for k, v in out.items() if k.endswith('loss')})
     tr.all_reduce(); tr.update()

@@ -125,7 +125,10 @@ def test_fpn_detector_stagewise():
         assert got.shape == w.shape
         err = (got - w).abs().max().item() / w.abs().max().item()
         assert err < 3e-4, (name, err)               # fp32 conv stacks, different summation orders
-    out = det.forward(data.cuda(), torch.as_tensor(boxes).cuda(), im_info.cuda(), check_levels=True)
+    out = det.forward(data.cuda(), torch.as_tensor(boxes).cuda(), im_info.cuda())
+    assert int(out['num_rows'][0]) == N and out['rois'].shape[1] == N + 4      # every level populated: N real rows, 4 padding rows
+    for k in ('rois', 'roi_level', 'cls_score', 'bbox_pred'):
+        out[k] = out[k][:, :N]
     rois = out['rois'][0].cpu().numpy(); lv = out['roi_level'][0].cpu().numpy()
     feats = [f[n].float().cpu().numpy() for n in ('fpn_ft4', 'fpn_ft8', 'fpn_ft16', 'fpn_ft32')]
     pooled_o = OF.pool_levels(feats, rois, lv)
@@ -146,27 +149,90 @@ def test_fpn_detector_stagewise():
         err = (f16[name][0].float() - f[name][0]).abs().max().item() / f[name].abs().max().item()
         assert err < 6e-2, (name, err)
     o16 = det16.forward(data2, boxes2, torch.tensor([[H, W, 1.0]] * 2).cuda())
-    assert torch.isfinite(o16['cls_score']).all() and o16['cls_score'].shape == (2, N, 81)
-    assert torch.equal(o16['rois'][0], out['rois'][0])          # dispatch does not depend on the dtype
+    assert torch.isfinite(o16['cls_score']).all() and o16['cls_score'].shape == (2, N + 4, 81)
+    assert torch.equal(o16['rois'][0, :N], out['rois'][0])      # dispatch does not depend on the dtype
 
 
-def test_fpn_empty_level_is_reported_not_padded():
-    """Known parity gap, stated in DESIGN.md section 2: when a pyramid level receives no roi the reference's host-side dispatch
-    appends an all-zero dummy roi for it (core/rcnn.py:61-71), which then also becomes an extra relation key.  The device
-    dispatch does not add that row: `level_counts` shows the empty level, `check_levels=True` turns it into an error."""
-    import relnet_amd  # noqa: F401
-    from relnet_amd import backbone, detector
-    H, W, N = 256, 320, 16
+def test_fpn_empty_level_dummy_roi_matches_reference_loader(golden):
+    """A pyramid level that receives no roi gets the reference loader's all-zero dummy roi (core/rcnn.py:61-71): the device
+    dispatch must produce EXACTLY the rows of `get_rcnn_testbatch` (tests/golden/fpn.npz, written by running the reference's
+    own loader), and the dummy row must behave like a real roi of the graph: a key of both relation modules and a scored
+    row -- checked against the oracle head evaluated on the reference's row list."""
+    ops, backbone, detector = _mods()
+    g = golden['fpn']
+    for name in ('all_levels', 'empty_level0'):
+        boxes = g[name + '/boxes']
+        want = np.vstack([g['%s/rois_%d' % (name, l)] for l in range(4)]).astype(np.float32)
+        rois, level, perm, counts, n_rows = ops.fpn_roi_dispatch(torch.as_tensor(boxes[None]).cuda(), pad_empty=True)
+        n = int(n_rows[0])
+        assert n == len(want) and rois.shape[1] == len(boxes) + 4
+        assert np.array_equal(rois[0, :n].cpu().numpy(), want), name
+        lv_want = np.concatenate([np.full(len(g['%s/rois_%d' % (name, l)]), l) for l in range(4)])
+        assert np.array_equal(level[0, :n].cpu().numpy(), lv_want)
+        pm = perm[0].cpu().numpy()
+        assert (pm[n:] == -1).all() and (rois[0, n:, 1:] == 0).all()
+        real = pm[:n][pm[:n] >= 0]
+        assert sorted(real.tolist()) == list(range(len(boxes)))                         # a permutation of the input rows
+        if name == 'empty_level0':
+            assert pm[0] == -1 and (want[0] == 0).all() and int(counts[0, 0]) == 0      # the dummy roi leads the list
+    # n_valid: rows past it leave the level lists and land behind the real rows
+    boxes = g['all_levels/boxes'][None]
+    nv = torch.tensor([250], dtype=torch.int32).cuda()
+    rois, level, perm, counts, n_rows = ops.fpn_roi_dispatch(torch.as_tensor(boxes).cuda(), n_valid=nv, pad_empty=True)
+    ref = ops.fpn_roi_dispatch(torch.as_tensor(boxes[:, :250].copy()).cuda(), pad_empty=True)
+    n = int(n_rows[0])
+    assert n == int(ref[4][0]) and torch.equal(rois[0, :n], ref[0][0, :n]) and torch.equal(perm[0, :n], ref[2][0, :n])
+    assert sorted(perm[0, n:n + 150].cpu().tolist()) == list(range(250, 400)) and (rois[0, n:, 1:] == 0).all()
+
+
+def test_fpn_detector_with_empty_level_equals_oracle_on_reference_rows():
+    """FPNDetector on proposals that leave pyramid level 0 empty (two images, the second with all levels populated): per-roi
+    outputs of the real rows == the oracle head on the reference's row list INCLUDING the dummy roi (float32), the padding
+    rows are no keys (their content cannot change any real row) and never become detections."""
+    ops, backbone, detector = _mods()
+    H, W, N = 256, 320, 40
     p = backbone.init_params(seed=3, fpn=True)
     g = torch.Generator().manual_seed(4)
-    xy = torch.rand(1, N, 2, generator=g) * 20
-    boxes = torch.cat([xy, xy + 250.0], 2).clamp(max=W - 1).contiguous()           # every roi is large: only the coarse levels are used
-    det = detector.FPNDetector(p, dtype=torch.bfloat16)
-    data = torch.randn(1, 3, H, W, generator=g).cuda()
-    im_info = torch.tensor([[H, W, 1.0]]).cuda()
+    for k in ('cls_score_weight', 'bbox_pred_weight'):
+        p[k] = torch.randn(p[k].shape, generator=g) * 0.05
+    for lvl in (4, 8, 16, 32):
+        p['fpn_ft%d_1x1_weight' % lvl] = p['fpn_ft%d_1x1_weight' % lvl] * 5
+        p['fpn_ft%d_3x3_weight' % lvl] = p['fpn_ft%d_3x3_weight' % lvl] * 5
+        p['fpn_ft%d_3x3_bias' % lvl] = torch.rand(256, generator=g) * 0.1
+    xy = torch.rand(N, 2, generator=g) * 20
+    big = torch.cat([xy, xy + 150.0 + 100 * torch.rand(N, 2, generator=g)], 1).clamp(max=W - 1)    # levels 1-3 only
+    boxes = torch.stack([big, torch.as_tensor(_proposals(N, 24, H, W))]).float().contiguous()
+    data = torch.randn(2, 3, H, W, generator=g).cuda()
+    im_info = torch.tensor([[H, W, 1.0]] * 2).cuda()
+    det = detector.FPNDetector(p, dtype=torch.float32)
     out = det.forward(data, boxes.cuda(), im_info)
-    counts = out['level_counts'][0].cpu().numpy()
-    assert counts.sum() == N and (counts == 0).any()
-    assert out['rois'].shape[1] == N                                                # no dummy row appended
-    with pytest.raises(ValueError, match='dummy roi'):
-        det.forward(data, boxes.cuda(), im_info, check_levels=True)
+    counts = out['level_counts'].cpu().numpy()
+    n_rows = out['num_rows'].cpu().numpy()
+    assert counts[0, 0] == 0 and (counts[1] > 0).all() and n_rows.tolist() == [N + int((counts[0] == 0).sum()), N]
+    f = det.backbone.forward(data)
+    pn = {k: v.numpy() for k, v in p.items()}
+    pn['fc_new_1_weight'], pn['fc_new_1_bias'] = pn['roi_pool_fc1_weight'], pn['roi_pool_fc1_bias']
+    pn['fc_new_2_weight'], pn['fc_new_2_bias'] = pn['roi_pool_fc2_weight'], pn['roi_pool_fc2_bias']
+    for b in range(2):
+        rois_o, lv_o, perm_o, _ = OF.roi_dispatch(boxes[b].numpy(), dummy_for_empty=True)       # pinned to the reference loader
+        n = len(rois_o)
+        assert n == n_rows[b]
+        got_rois = out['rois'][b, :n].cpu().numpy()
+        assert np.array_equal(got_rois[:, 1:], rois_o[:, 1:]) and np.array_equal(out['roi_level'][b, :n].cpu().numpy(), lv_o)
+        feats = [f[k][b:b + 1].float().cpu().numpy() for k in ('fpn_ft4', 'fpn_ft8', 'fpn_ft16', 'fpn_ft32')]
+        r = OR.relation_head(OF.pool_levels(feats, rois_o, lv_o), rois_o, pn, return_intermediates=True)
+        for key in ('cls_score', 'bbox_pred'):
+            want = r[key]
+            err = np.abs(out[key][b, :n].cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-3)
+            assert err <= 2e-4, (b, key, err)
+        # padding rows: zero probability, hence never detections
+        assert (out['cls_prob'][b, n:] == 0).all()
+        nd = int(out['num_detections'][b])
+        assert nd > 0
+    # the same graph WITHOUT the dummy roi differs on the real rows (it is one more relation key): the row matters
+    det.pad_empty_levels = False
+    o2 = det.forward(data, boxes.cuda(), im_info)
+    d = (o2['cls_score'][0, :N - 0] - out['cls_score'][0, 1:N + 1]).abs().max().item()
+    assert d > 1e-6
+    assert torch.equal(o2['cls_score'][1], out['cls_score'][1, :N]) or \
+        (o2['cls_score'][1] - out['cls_score'][1, :N]).abs().max().item() <= 1e-6 * out['cls_score'][1].abs().max().item()

@@ -91,3 +91,50 @@ def test_relation_module_backward_batched_bf16():
             assert np.abs(g).max() <= 1e-2 * np.abs(w0['query_1_bias'] + w1['query_1_bias']).max()
             continue
         assert _rel(g, want) <= 4e-2, (k, _rel(g, want))
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_key_count_masks_padding_rows(dtype):
+    """Fixed-size roi buffers with a different number of REAL rows per image (FPN dummy rois, short proposal lists): with
+    key_count[b] the first key_count[b] rows are the keys of image b -- forward and backward must equal the same module run
+    on that image alone with nongt_dim = key_count[b] (float32: to rounding of the shared GEMMs; bf16: to its tolerance),
+    whatever the padding rows contain."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import relation
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    tol = 2e-5 if dtype == 'f32' else 3e-2
+    n = 70
+    counts = [70, 41, 33, 64]
+    B = len(counts)
+    boxes, feat, p = cases.relation_case(n, n, 77, 0.04)
+    rng = np.random.default_rng(5)
+    feats = np.stack([feat + 0.3 * rng.normal(0, 1, feat.shape).astype(np.float32) for _ in range(B)])
+    bxs = np.stack([boxes] * B)
+    for b, c in enumerate(counts):        # poison the padding rows: they must not influence the real ones
+        feats[b, c:] = 50.0 * rng.normal(0, 1, (n - c, 1024))
+        bxs[b, c:] = 0.0
+    d_out = rng.normal(0, 1, (B, n, 1024)).astype(np.float32)
+    for b, c in enumerate(counts):
+        d_out[b, c:] = 0.0                # padded rows carry no loss (label -1, zero weights)
+    pt = {k: torch.as_tensor(v) for k, v in p.items()}
+    kc = torch.tensor(counts, dtype=torch.int32).cuda()
+    F_, X_, D_ = torch.as_tensor(feats).cuda(), torch.as_tensor(bxs).cuda(), torch.as_tensor(d_out).cuda()
+    y = relation.attention_module_multi_head(F_, X_, pt, nongt_dim=n, dtype=dt, key_count=kc)
+    g = relation.attention_module_backward(F_, X_, pt, D_, nongt_dim=n, dtype=dt, key_count=kc)
+    acc = {}
+    for b, c in enumerate(counts):
+        yb = relation.attention_module_multi_head(F_[b, :c], X_[b, :c], pt, nongt_dim=c, dtype=dt)
+        err = (y[b, :c].float() - yb.float()).abs().max().item() / yb.float().abs().max().item()
+        assert err <= tol, (b, c, err)
+        gb = relation.attention_module_backward(F_[b, :c], X_[b, :c], pt, D_[b, :c], nongt_dim=c, dtype=dt)
+        e = _rel(g['d_roi_feat'][b, :c].float().cpu().numpy(), gb['d_roi_feat'].float().cpu().numpy())
+        assert e <= 10 * tol, ('d_roi_feat', b, e)
+        for k, v in gb.items():
+            if k != 'd_roi_feat':
+                acc[k] = acc.get(k, 0) + v.double().cpu().numpy()
+    assert torch.isfinite(g['d_roi_feat']).all()
+    for k, want in acc.items():           # parameter gradients: the sum over the images' own runs
+        if k == 'key_1_bias':
+            continue
+        e = _rel(g[k].double().cpu().numpy().reshape(want.shape), want)
+        assert e <= 10 * tol, (k, e)

@@ -80,3 +80,46 @@ def test_targets_full_size_batched_vs_oracle(rn):
     for b in range(B):
         want = OT.nms_multi_target(cs2[b][0], cs2[b][1], cs2[b][2])
         assert np.array_equal(t[b].cpu().numpy(), want) and want.sum() > 0
+
+
+def test_assign_anchor_on_device_matches_oracle_and_reference_golden(rn):
+    """relnet_assign_anchor (lib/rpn/rpn.py:80-244 on the device, B images per launch) against oracle/anchors.py -- itself
+    held bit-for-bit to the reference's own function (tests/golden/rpn_targets.npz) -- with the kernel's hash sampler:
+    identical labels (before AND after the random fg / bg sub-sampling), identical weights, targets to 1e-6; images with
+    6, 40 and 0 gt boxes in one launch, one of them smaller than the padded batch frame."""
+    import os
+    ops, _ = rn
+    from oracle import anchors as OA
+    from relnet_amd.operator_py.proposal import generate_anchors
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'rpn_targets.npz'))
+    gts = [g['six_gt/gt'], g['crowded/gt'], np.zeros((0, 5), np.float32), g['six_gt/gt'][:3] * 0.5]
+    hw = [(600, 1000), (600, 1000), (600, 1000), (300, 520)]               # the last image covers part of the frame only
+    B, G = len(gts), max(len(x) for x in gts)
+    pad = np.zeros((B, G, 5), np.float32)
+    for b, x in enumerate(gts):
+        pad[b, :len(x)] = x
+    num_gt = torch.tensor([len(x) for x in gts], dtype=torch.int32).cuda()
+    im_info = torch.tensor([[h, w, 1.0] for h, w in hw]).cuda()
+    base = generate_anchors(16, (0.5, 1, 2), (4, 8, 16, 32))
+    seed = 20260924
+    L, T, W, Lall = ops.assign_anchor(_d(pad), num_gt, im_info, base, (38, 63), seed=seed, want_all=True)
+    for b in range(B):
+        wl, wt, ww, wall = OA.assign_anchor((38, 63), gts[b], hw[b], sampler='hash', seed=seed, image_index=b, return_all=True)
+        assert np.array_equal(Lall[b].cpu().numpy(), wall), b
+        assert np.array_equal(L[b].cpu().numpy(), wl), (b, int((L[b].cpu().numpy() != wl).sum()))
+        assert np.array_equal(W[b].cpu().numpy(), ww), b
+        assert np.abs(T[b].cpu().numpy() - wt).max() <= 1e-6, b
+        nfg, nbg = int((wl == 1).sum()), int((wl == 0).sum())
+        assert nfg <= 128 and nfg + nbg == 256
+    # the deterministic part equals the reference run itself (golden labels are a random subset of these candidates)
+    for b, name in ((0, 'six_gt'), (1, 'crowded')):
+        gl = g[name + '/label'][0]
+        la = Lall[b].cpu().numpy()
+        assert (la[gl == 1] == 1).all() and (la[gl == 0] == 0).all()
+        assert np.abs(T[b].cpu().numpy() - g[name + '/bbox_target'][0]).max() <= 2e-6
+    # seed_dev: a device step counter shifts the seed (what a captured training graph advances between replays)
+    ctr = torch.tensor([5], dtype=torch.int64).cuda()
+    L5 = ops.assign_anchor(_d(pad), num_gt, im_info, base, (38, 63), seed=seed - 5, seed_dev=ctr)[0]
+    assert torch.equal(L5, L)
+    L6 = ops.assign_anchor(_d(pad), num_gt, im_info, base, (38, 63), seed=seed + 1)[0]
+    assert not torch.equal(L6[1], L[1]) and int((L6[1] == 1).sum()) == 128

@@ -217,3 +217,25 @@ def test_learn_nms_benchmark_shape_matches_reference_operator():
         np.testing.assert_allclose(sscore, g[name + '/sorted_score'], rtol=1e-6, atol=0)
         np.testing.assert_allclose(sbox, g[name + '/sorted_bbox'], rtol=0, atol=1e-4)
         np.testing.assert_allclose(multi, g[name + '/nms_multi_score'], rtol=5e-5, atol=2e-7)
+
+
+def test_assign_anchor_oracle_matches_reference_loader():
+    """oracle/anchors.py (sampler='numpy') vs tests/golden/rpn_targets.npz = the output of the reference's own
+    lib/rpn/rpn.py:assign_anchor with the same numpy seed: identical labels incl. the random fg / bg sub-sampling, identical
+    weights, targets to 2e-6; the hash sampler (the device kernel's definition of the random subset) changes nothing else."""
+    from oracle import anchors as OA
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'rpn_targets.npz'))
+    for name, seed in (('six_gt', 3), ('crowded', 4)):
+        L, T, W, Lall = OA.assign_anchor((38, 63), g[name + '/gt'], (600, 1000), seed=seed, return_all=True)
+        assert np.array_equal(L, g[name + '/label'][0]) and np.array_equal(W, g[name + '/bbox_weight'][0])
+        assert np.abs(T - g[name + '/bbox_target'][0]).max() <= 2e-6
+        Lh, Th, Wh, Lall_h = OA.assign_anchor((38, 63), g[name + '/gt'], (600, 1000), sampler='hash', seed=1234, image_index=2, return_all=True)
+        assert np.array_equal(Lall_h, Lall) and np.array_equal(Th, T)
+        assert (Lh == 1).sum() == (L == 1).sum() and (Lh == 0).sum() == (L == 0).sum() == 256 - (L == 1).sum()
+        assert (Lall[Lh == 1] == 1).all() and (Lall[Lh == 0] == 0).all()              # a subset of the candidates
+        assert np.array_equal(Wh.reshape(12, 4, 38, 63).sum(1) == 4, Lh.reshape(12, 38, 63) == 1)
+    # a different seed draws a different subset of the same size
+    L2 = OA.assign_anchor((38, 63), g['crowded/gt'], (600, 1000), sampler='hash', seed=99)[0]
+    L3 = OA.assign_anchor((38, 63), g['crowded/gt'], (600, 1000), sampler='hash', seed=100)[0]
+    assert (L2 == 1).sum() == (L3 == 1).sum() == 128 and not np.array_equal(L2, L3)
