@@ -402,7 +402,7 @@ def main():
                     sys.stderr.write('%-60s calls/step %5.1f avg %8.1f us  per-step %8.3f ms\n' % (
                         k, v['calls'] / min(a.steps, 5), v['avg_ms'] * 1e3, v['total_ms'] / min(a.steps, 5)))
             res['kernels_ms'] = {k: round(v['avg_ms'], 5) for k, v in sorted(ks.items())}
-            att = ks.get('relnet_relation_attention')
+            att = ks.get('relnet_relation_attention_kc') or ks.get('relnet_relation_attention')
             if att:
                 sec = att['avg_ms'] * 1e-3
                 rs = (n_rois / 300.0) ** 2                                         # N = M = n_rois keys and queries

@@ -550,7 +550,10 @@ def assign_anchor(gt_boxes, num_gt, im_info, base_anchors, feat_hw, feat_stride=
         num_gt = torch.full((B,), G, device=dev, dtype=torch.int32)
     if G == 0:                       # images without any box: one (ignored) gt slot keeps the buffers non-empty
         gt_boxes, G = torch.zeros((B, 1, 5), device=dev, dtype=torch.float32), 1
-    base = torch.as_tensor(base_anchors).detach().to('cpu', torch.float64).contiguous()
+    base = torch.as_tensor(base_anchors).detach()
+    if base.is_cuda:
+        raise _lib.RelnetError('assign_anchor: base_anchors is a HOST table (a device tensor would need a synchronising copy)')
+    base = base.to(torch.float64).contiguous()
     A = base.shape[0]
     fh, fw = feat_hw
     label = torch.empty((B, A * fh * fw), device=dev, dtype=torch.float32)

@@ -166,7 +166,8 @@ class Trainer(object):
         self.Bv = _Flat(biases, dev)          # biases: wd_mult 0 (MXNet's rule for names not ending in _weight / _gamma)
         if c.dcn:
             self.lr_mult_tail = (self.W.slices['offset'][0], self.Bv.slices['offset'][0], 0.01)
-        self.anchors = torch.as_tensor(generate_anchors(c.feat_stride, c.anchor_ratios, c.anchor_scales), dtype=torch.float64, device=dev)
+        self.anchors_host = generate_anchors(c.feat_stride, c.anchor_ratios, c.anchor_scales)      # float64 [A,4], host (kernel argument)
+        self.anchors = torch.as_tensor(self.anchors_host, dtype=torch.float64, device=dev)
         self.step_count = 0
 
     # ---- accessors ----------------------------------------------------------------------------------------
@@ -246,7 +247,7 @@ class Trainer(object):
         c = self.cfg
         if getattr(self, '_anchor_step', None) is None:
             self._anchor_step = torch.zeros(1, device=gt_boxes.device, dtype=torch.int64)
-        out = ops.assign_anchor(gt_boxes, num_gt, im_info, self.anchors, feat_hw, c.feat_stride, c.rpn_batch_size,
+        out = ops.assign_anchor(gt_boxes, num_gt, im_info, self.anchors_host, feat_hw, c.feat_stride, c.rpn_batch_size,
                                 getattr(c, 'rpn_fg_fraction', 0.5), getattr(c, 'rpn_negative_overlap', 0.3),
                                 getattr(c, 'rpn_positive_overlap', 0.7), seed=getattr(c, 'seed', 0), seed_dev=self._anchor_step)
         self._anchor_step += 1

@@ -235,4 +235,4 @@ def test_fpn_detector_with_empty_level_equals_oracle_on_reference_rows():
     d = (o2['cls_score'][0, :N - 0] - out['cls_score'][0, 1:N + 1]).abs().max().item()
     assert d > 1e-6
     assert torch.equal(o2['cls_score'][1], out['cls_score'][1, :N]) or \
-        (o2['cls_score'][1] - out['cls_score'][1, :N]).abs().max().item() <= 1e-6 * out['cls_score'][1].abs().max().item()
+        (o2['cls_score'][1] - out['cls_score'][1, :N]).abs().max().item() <= 1e-4 * out['cls_score'][1].abs().max().item()
