@@ -187,11 +187,11 @@ def bench_train(a, rank, world, D, emit=True):
         for _ in range(a.warmup):
             out = tr.step(*batch)
         graph = None
-        if not a.no_graph:                  # forward + backward as one hipGraph; the collective and SGD stay eager
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = tr.forward_backward(*batch)
+        if not a.no_graph:
+            # forward + backward as a chain of hipGraphs cut at the gradient buckets (train.CapturedStep): every bucket's
+            # all-reduce is issued between two graph launches and overlaps the rest of the backward pass; SGD stays eager
+            graph = train.CapturedStep(tr, batch)
+            out = graph.out
         fence()
         t0 = time.perf_counter()
         for _ in range(a.steps):
@@ -221,7 +221,7 @@ def bench_train(a, rank, world, D, emit=True):
                                     '(..._rcnn_end2end_relation_8epoch.yaml)') +
                                    ': forward + backward + summed all-reduce of %d gradients + SGD, 600x1000 images, '
                                    '300 proposals + 8 gt rows, OHEM 128, random-init weights' % tr.num_trainable(),
-                       'images_per_gpu_per_step': B, 'launch': 'eager' if a.no_graph else 'hipGraph replay (forward+backward)',
+                       'images_per_gpu_per_step': B, 'launch': 'eager' if a.no_graph else 'hipGraph replay (forward+backward in %d segments cut at the gradient buckets)' % len(graph.segments),
                        'parallelism': 'dp%d (RCCL all-reduce SUM)' % world},
             'losses': {k: float(out[k]) for k in ('bbox_loss', 'rpn_bbox_loss', 'nms_pos_loss', 'nms_neg_loss') if k in out}}
         if emit:

@@ -379,6 +379,22 @@ int relnet_relation_attention_bwd_kc(const void* q, long q_ld, long q_bs, const 
                                      float* dq, float* dk, float* dvw, int B, int H, int N, int M, int Mpad, int Npad,
                                      float scale, int dtype, const int* key_count, void* stream);
 
+/* Weight gradient of a convolution / FullyConnected layer (the adjoint MXNet's autograd derives; no reference source):
+ *   dw [Cout][Ktot] fp32 (row pitch dw_ld)  +=  row_scale[m]^2 * sum_p dy[p][m] * X[p][k]
+ * dy [P][dy_cols] bf16 (pitch dy_ld; columns >= Cout are padding) and the activation x (bf16, channels contiguous, element
+ * stride x_pix between pixels) are read as they lie in memory: LDS-transposed MFMA fragments (ds_read_b64_tr_b16), no
+ * transposed copies; ks = 1 / stride = 1: X[p] = pixel (row) p, Ktot = Cin; otherwise x is [B][Hin][Win] pixels and
+ * column k = tap (k / Cin) of channel k % Cin in pack_conv_weight order, gathered on the fly (zero outside the image).
+ * Split over the pixels; partial tiles are combined with hardware float atomics, so dw must be initialised (zero or a
+ * running sum) and the summation order is not fixed.  row_scale (may be NULL): the folded BatchNorm factor per output row. */
+int relnet_wgrad(const void* dy, long dy_ld, int dy_cols, const void* x, long x_pix, float* dw, long dw_ld,
+                 const float* row_scale, int P, int Cout, int Cin, int ks, int stride, int dil, int pad, int B, int Hout,
+                 int Wout, int Hin, int Win, void* stream);
+/* Test aids: relnet_wgrad_debug_plain(1) makes relnet_wgrad assemble its fragments with scalar LDS reads;
+ * relnet_debug_tr_probe dumps what ds_read_b64_tr_b16 returns for lane-linear addresses (256 values).                 */
+void relnet_wgrad_debug_plain(int on);
+int relnet_debug_tr_probe(unsigned short* out256, void* stream);
+
 /* d pair_pos_fc1_{weight [16][64], bias [16]} += from dlog and the forward's fp32 bias (= log max(G,1e-6)):
  * dpre = dlog / G where G > 1e-6; the 64-d embedding is recomputed from the boxes (SYM_REL:29-83).            */
 int relnet_geometry_bias_bwd(const float* boxes, int box_stride, int box_off, const float* bias, const float* dlog,
@@ -424,6 +440,17 @@ int relnet_roi_pool_fpn_bwd(const void* grad_out, const int* argmax, const long*
                             const int* roi_level, float* const* grad_in_levels, const long* gs_b_levels,
                             const long* gs_c_levels, int num_levels, int R, int C, int PH, int PW,
                             int batch_index_base, int dtype, void* stream);
+/* ..._ex of both backward entries: gs_p = element stride between PIXELS of the gradient buffer (the plain entries use 1 =
+ * [B,C,H*W]).  With gs_c = 1, gs_p = C the buffer is [B,H,W,C]: a wavefront's 64 consecutive channels of one bin hit 64
+ * consecutive words, i.e. coalesced hardware float atomics, and the result is already in the layout the NHWC convolution
+ * backward consumes.                                                                                                  */
+int relnet_roi_pool_bwd_ex(const void* grad_out, const int* argmax, const long* out_strides4, const float* rois,
+                           float* grad_in, long gs_b, long gs_c, long gs_p, int R, int C, int W, int PH, int PW,
+                           int batch_index_base, int dtype, void* stream);
+int relnet_roi_pool_fpn_bwd_ex(const void* grad_out, const int* argmax, const long* out_strides4, const float* rois,
+                               const int* roi_level, float* const* grad_in_levels, const long* gs_b_levels,
+                               const long* gs_c_levels, const long* gs_p_levels /* NULL = 1 */, int num_levels, int R, int C,
+                               int PH, int PW, int batch_index_base, int dtype, void* stream);
 
 /* grad[r,c] += row_scale[r]^2 * sum_s parts[s,r,c]: split-K partial sums of a weight gradient, the folded frozen-BN
  * factor (NULL = 1) and the accumulation into the flat gradient buffer in one pass.  cols % 4 == 0.             */

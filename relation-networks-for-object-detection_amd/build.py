@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'librelnet_hip.so')
 STAMP = os.path.join(HERE, 'csrc', '.build_stamp')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-value']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-value',
+         '-munsafe-fp-atomics']      # float atomicAdd = global_atomic_add_f32 (gradient buffers are ordinary device memory), not a CAS loop
 
 
 def _digest():

@@ -440,6 +440,108 @@ __global__ __launch_bounds__(256) void geometry_bias_bwd_kernel(GeomBwdArgs g) {
   if (lane < 16) atomicAdd(g.dbp + lane, bsum);
 }
 
+// bf16 training path (FAST): the same product with the PAIRS on the contraction axis of the bf16 matrix cores
+// (mfma_f32_32x32x16_bf16: 16 pairs per instruction instead of 2 on the fp32 MFMA), the operands vector-loaded (8 consecutive
+// keys of one head row per lane) instead of one 4-byte load per (head, key), hardware log / sin / cos, and ONE atomic flush per
+// workgroup after a grid-stride loop over the (image, query) rows (the per-wave flush of the kernel above put B N x 1024
+// atomics on 1024 addresses).  A[h][pair] = dL / G (bf16), B[pair][f] = the embedding value (bf16, |.| <= 1), fp32 accumulate.
+__global__ __launch_bounds__(256) void geometry_bias_bwd_mfma_kernel(GeomBwdArgs g, int total_q) {
+  __shared__ __attribute__((aligned(16))) float sP[4][4][64];      // [wave][component][key of the 64-key block]
+  __shared__ float sRed[3][16][65];
+  __shared__ float sB[3][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int nw = gridDim.x * 4;
+  const int comp0 = l31 >> 4, comp1 = 2 + (l31 >> 4), sc = (l31 >> 3) & 1;
+  const float rate = 100.0f / g.divisors[l31 & 7];
+  const int hh = l31 & 15;
+  const float kLogFloor = logf(1e-6f);
+  f32x16 c0, c1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+  float bsum = 0.f;
+  for (int q = blockIdx.x * 4 + wave; q < total_q; q += nw) {
+    const int b = q / g.N, i = q - b * g.N;
+    const float* bx = g.boxes + (long)b * g.N * g.box_stride + g.box_off;
+    const float* pi = bx + (long)i * g.box_stride;
+    const float xi1 = pi[0], yi1 = pi[1], xi2 = pi[2], yi2 = pi[3];
+    const float wi = xi2 - xi1 + 1.f, hi = yi2 - yi1 + 1.f, cxi = 0.5f * (xi1 + xi2), cyi = 0.5f * (yi1 + yi2);
+    const float* Brow = g.bias + (((long)b * 16 + hh) * g.N + i) * g.Mpad;
+    const float* Lrow = g.dlog + (((long)b * 16 + hh) * g.N + i) * g.Mpad;
+    for (int j0 = 0; j0 < g.M; j0 += 64) {
+      {   // the four position values of pair (i, j0 + lane), once per pair (SYM_REL:59-77, hardware log)
+        const int jl = j0 + lane < g.M ? j0 + lane : g.M - 1;
+        const float* pj = bx + (long)jl * g.box_stride;
+        const float xj1 = pj[0], yj1 = pj[1], xj2 = pj[2], yj2 = pj[3];
+        const float wj = xj2 - xj1 + 1.f, hj = yj2 - yj1 + 1.f, cxj = 0.5f * (xj1 + xj2), cyj = 0.5f * (yj1 + yj2);
+        sP[wave][0][lane] = __logf(fmaxf(fabsf((cxi - cxj) / wi), 1e-3f));
+        sP[wave][1][lane] = __logf(fmaxf(fabsf((cyi - cyj) / hi), 1e-3f));
+        sP[wave][2][lane] = __logf(wi / wj);
+        sP[wave][3][lane] = __logf(hi / hj);
+      }
+      const int nstep = (min(64, g.M - j0) + 15) >> 4;
+      for (int kk = 0; kk < nstep; ++kk) {
+        const int pb = 16 * kk + 8 * half, jb = j0 + pb;
+        float dpre[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) dpre[t] = 0.f;
+        if (l31 < 16) {
+          const float4 l0 = *(const float4*)(Brow + jb), l1 = *(const float4*)(Brow + jb + 4);
+          const float4 d0 = *(const float4*)(Lrow + jb), d1 = *(const float4*)(Lrow + jb + 4);
+          const float lg[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+          const float dl[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            dpre[t] = (jb + t < g.M && lg[t] > kLogFloor) ? dl[t] * __expf(-lg[t]) : 0.f;      // dL / G, zero on the clamped branch
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) bsum += dpre[t];
+        const float4 p00 = *(const float4*)&sP[wave][comp0][pb], p01 = *(const float4*)&sP[wave][comp0][pb + 4];
+        const float4 p10 = *(const float4*)&sP[wave][comp1][pb], p11 = *(const float4*)&sP[wave][comp1][pb + 4];
+        const float q0[8] = {p00.x, p00.y, p00.z, p00.w, p01.x, p01.y, p01.z, p01.w};
+        const float q1[8] = {p10.x, p10.y, p10.z, p10.w, p11.x, p11.y, p11.z, p11.w};
+        union { bf16x8 f; unsigned int u[4]; } fa, fb0, fb1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bool ok0 = jb + 2 * t < g.M, ok1 = jb + 2 * t + 1 < g.M;
+          const float a0 = q0[2 * t] * rate, a1 = q0[2 * t + 1] * rate, b0 = q1[2 * t] * rate, b1 = q1[2 * t + 1] * rate;
+          const float e00 = ok0 ? (sc ? __cosf(a0) : __sinf(a0)) : 0.f, e01 = ok1 ? (sc ? __cosf(a1) : __sinf(a1)) : 0.f;
+          const float e10 = ok0 ? (sc ? __cosf(b0) : __sinf(b0)) : 0.f, e11 = ok1 ? (sc ? __cosf(b1) : __sinf(b1)) : 0.f;
+          fa.u[t] = pack_bf16x2(dpre[2 * t], dpre[2 * t + 1]);
+          fb0.u[t] = pack_bf16x2(e00, e01);
+          fb1.u[t] = pack_bf16x2(e10, e11);
+        }
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.f, fb0.f, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.f, fb1.f, c1, 0, 0, 0);
+      }
+    }
+  }
+  // rows h = (r & 3) + 8 (r >> 2) + 4 half < 16  <=>  r < 8 ; col = l31.  Waves 1-3 hand their tile to wave 0.
+  bsum += __shfl_xor(bsum, 32);
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int hrow = (r & 3) + 8 * (r >> 2) + 4 * half;
+      sRed[wave - 1][hrow][l31] = c0[r];
+      sRed[wave - 1][hrow][32 + l31] = c1[r];
+    }
+    if (lane < 16) sB[wave - 1][lane] = bsum;
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int hrow = (r & 3) + 8 * (r >> 2) + 4 * half;
+      float v0 = c0[r], v1 = c1[r];
+#pragma unroll
+      for (int w = 0; w < 3; ++w) { v0 += sRed[w][hrow][l31]; v1 += sRed[w][hrow][32 + l31]; }
+      atomicAdd(g.dwp + hrow * 64 + l31, v0);
+      atomicAdd(g.dwp + hrow * 64 + 32 + l31, v1);
+    }
+    if (lane < 16) atomicAdd(g.dbp + lane, bsum + sB[0][lane] + sB[1][lane] + sB[2][lane]);
+  }
+}
+
 }  // namespace relnet
 
 using namespace relnet;
@@ -519,7 +621,11 @@ extern "C" int relnet_geometry_bias_bwd(const float* boxes, int box_stride, int 
   for (int k = 0; k < 8; ++k) g.divisors[k] = divisors8[k];
   g.dwp = dwp; g.dbp = dbp; g.B = B; g.N = N; g.M = M; g.Mpad = Mpad;
   dim3 grid((unsigned)((N + 3) / 4), B);
-  if (fast_math) geometry_bias_bwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(g);
+  if (fast_math == 1 && Mpad % 32 == 0 && (((uintptr_t)bias | (uintptr_t)dlog) & 15) == 0) {
+    const long total_q = (long)B * N;             // grid-stride over the (image, query) rows: <= 768 workgroups
+    const long blocks = (total_q + 3) / 4;
+    geometry_bias_bwd_mfma_kernel<<<(unsigned)(blocks < 768 ? blocks : 768), 256, 0, (hipStream_t)stream>>>(g, (int)total_q);
+  } else if (fast_math) geometry_bias_bwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(g);
   else geometry_bias_bwd_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(g);
   return check_launch("relnet_geometry_bias_bwd");
 }

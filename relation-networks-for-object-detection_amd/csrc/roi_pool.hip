@@ -128,26 +128,27 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_cl_kernel(RoiArgs g) {
 struct RoiBwdArgs {
   const void* grad_out; const int* argmax; long os_r, os_c, os_ph, os_pw;
   const float* rois;
-  float* grad_in; long ds_b, ds_c;          // fp32 [B, C, H*W] accumulation buffer (pre-zeroed)
+  float* grad_in; long ds_b, ds_c;          // fp32 accumulation buffer (pre-zeroed): element (b, c, pixel a) at b ds_b + c ds_c + a ds_p
   int R, C, W, PH, PW, batch_index_base;
   const int* level;                         // FPN: roi r scatters into lv[level[r]]; nullptr = the single map above
-  struct Level { float* grad_in; long ds_b, ds_c; } lv[4];
-};
+  struct Level { float* grad_in; long ds_b, ds_c, ds_p; } lv[4];
+  long ds_p;                                // pixel stride: 1 = [B,C,H*W] (NCHW); C with ds_c = 1 = [B,H*W,C] (NHWC: the lanes'
+};                                          // consecutive channels hit consecutive words -> coalesced float atomics)
 
 template <typename T>
 __global__ __launch_bounds__(256) void roi_pool_bwd_kernel(RoiBwdArgs g) {
   const int bin = blockIdx.x;
   const int pw = bin % g.PW, ph = (bin / g.PW) % g.PH, r = bin / (g.PW * g.PH);
   const int b = (int)g.rois[(long)r * 5] - g.batch_index_base;
-  float* gin = g.grad_in; long ds_b = g.ds_b, ds_c = g.ds_c;
+  float* gin = g.grad_in; long ds_b = g.ds_b, ds_c = g.ds_c, ds_p = g.ds_p;
   if (g.level) {
     const int l = g.level[r] & 3;
-    gin = RELNET_SEL4(l, grad_in); ds_b = RELNET_SEL4(l, ds_b); ds_c = RELNET_SEL4(l, ds_c);
+    gin = RELNET_SEL4(l, grad_in); ds_b = RELNET_SEL4(l, ds_b); ds_c = RELNET_SEL4(l, ds_c); ds_p = RELNET_SEL4(l, ds_p);
   }
   for (int c = threadIdx.x; c < g.C; c += 256) {
     const long o = (long)r * g.os_r + (long)c * g.os_c + (long)ph * g.os_ph + (long)pw * g.os_pw;
     const int a = g.argmax[o];
-    if (a >= 0) atomicAdd(gin + (long)b * ds_b + (long)c * ds_c + a, ld<T>((const T*)g.grad_out + o));
+    if (a >= 0) atomicAdd(gin + (long)b * ds_b + (long)c * ds_c + (long)a * ds_p, ld<T>((const T*)g.grad_out + o));
   }
 }
 
@@ -213,13 +214,13 @@ extern "C" int relnet_roi_pool_fpn_fwd(const void* const* data_levels, const lon
   return launch_roi_pool(g, dtype, aligned, stream, "relnet_roi_pool_fpn_fwd");
 }
 
-extern "C" int relnet_roi_pool_bwd(const void* grad_out, const int* argmax, const long* out_strides4,
-                                   const float* rois, float* grad_in, long gs_b, long gs_c, int R,
-                                   int C, int W, int PH, int PW, int batch_index_base, int dtype,
-                                   void* stream) {
+extern "C" int relnet_roi_pool_bwd_ex(const void* grad_out, const int* argmax, const long* out_strides4,
+                                      const float* rois, float* grad_in, long gs_b, long gs_c, long gs_p, int R,
+                                      int C, int W, int PH, int PW, int batch_index_base, int dtype,
+                                      void* stream) {
   RELNET_REQUIRE(grad_out && argmax && rois && grad_in, "relnet_roi_pool_bwd: null operand");
   RoiBwdArgs g{grad_out, argmax, out_strides4[0], out_strides4[1], out_strides4[2], out_strides4[3],
-               rois, grad_in, gs_b, gs_c, R, C, W, PH, PW, batch_index_base, nullptr, {}};
+               rois, grad_in, gs_b, gs_c, R, C, W, PH, PW, batch_index_base, nullptr, {}, gs_p};
   dim3 grid((unsigned)((long)R * PH * PW));
   if (dtype == RELNET_F32) roi_pool_bwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(g);
   else if (dtype == RELNET_BF16) roi_pool_bwd_kernel<unsigned short><<<grid, 256, 0, (hipStream_t)stream>>>(g);
@@ -227,23 +228,41 @@ extern "C" int relnet_roi_pool_bwd(const void* grad_out, const int* argmax, cons
   return check_launch("relnet_roi_pool_bwd");
 }
 
-extern "C" int relnet_roi_pool_fpn_bwd(const void* grad_out, const int* argmax, const long* out_strides4, const float* rois,
-                                       const int* roi_level, float* const* grad_in_levels, const long* gs_b_levels,
-                                       const long* gs_c_levels, int num_levels, int R, int C, int PH, int PW,
-                                       int batch_index_base, int dtype, void* stream) {
+extern "C" int relnet_roi_pool_bwd(const void* grad_out, const int* argmax, const long* out_strides4,
+                                   const float* rois, float* grad_in, long gs_b, long gs_c, int R,
+                                   int C, int W, int PH, int PW, int batch_index_base, int dtype,
+                                   void* stream) {
+  return relnet_roi_pool_bwd_ex(grad_out, argmax, out_strides4, rois, grad_in, gs_b, gs_c, 1, R, C, W, PH, PW,
+                                batch_index_base, dtype, stream);
+}
+
+extern "C" int relnet_roi_pool_fpn_bwd_ex(const void* grad_out, const int* argmax, const long* out_strides4, const float* rois,
+                                          const int* roi_level, float* const* grad_in_levels, const long* gs_b_levels,
+                                          const long* gs_c_levels, const long* gs_p_levels, int num_levels, int R, int C,
+                                          int PH, int PW, int batch_index_base, int dtype, void* stream) {
   RELNET_REQUIRE(grad_out && argmax && out_strides4 && rois && roi_level && grad_in_levels && gs_b_levels && gs_c_levels,
                  "relnet_roi_pool_fpn_bwd: null operand");
   RELNET_REQUIRE(num_levels >= 1 && num_levels <= 4, "relnet_roi_pool_fpn_bwd: 1..4 pyramid levels, got %d", num_levels);
   RoiBwdArgs g{grad_out, argmax, out_strides4[0], out_strides4[1], out_strides4[2], out_strides4[3],
-               rois, grad_in_levels[0], gs_b_levels[0], gs_c_levels[0], R, C, 0, PH, PW, batch_index_base, roi_level, {}};
+               rois, grad_in_levels[0], gs_b_levels[0], gs_c_levels[0], R, C, 0, PH, PW, batch_index_base, roi_level, {},
+               gs_p_levels ? gs_p_levels[0] : 1};
   for (int l = 0; l < 4; ++l) {
     const int s = l < num_levels ? l : num_levels - 1;
     RELNET_REQUIRE(grad_in_levels[s], "relnet_roi_pool_fpn_bwd: null level %d", s);
     g.lv[l].grad_in = grad_in_levels[s]; g.lv[l].ds_b = gs_b_levels[s]; g.lv[l].ds_c = gs_c_levels[s];
+    g.lv[l].ds_p = gs_p_levels ? gs_p_levels[s] : 1;
   }
   dim3 grid((unsigned)((long)R * PH * PW));
   if (dtype == RELNET_F32) roi_pool_bwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(g);
   else if (dtype == RELNET_BF16) roi_pool_bwd_kernel<unsigned short><<<grid, 256, 0, (hipStream_t)stream>>>(g);
   else RELNET_REQUIRE(false, "relnet_roi_pool_fpn_bwd: unknown dtype %d", dtype);
   return check_launch("relnet_roi_pool_fpn_bwd");
+}
+
+extern "C" int relnet_roi_pool_fpn_bwd(const void* grad_out, const int* argmax, const long* out_strides4, const float* rois,
+                                       const int* roi_level, float* const* grad_in_levels, const long* gs_b_levels,
+                                       const long* gs_c_levels, int num_levels, int R, int C, int PH, int PW,
+                                       int batch_index_base, int dtype, void* stream) {
+  return relnet_roi_pool_fpn_bwd_ex(grad_out, argmax, out_strides4, rois, roi_level, grad_in_levels, gs_b_levels, gs_c_levels,
+                                    nullptr, num_levels, R, C, PH, PW, batch_index_base, dtype, stream);
 }

@@ -46,6 +46,8 @@ _SIGNATURES = {
     '_nms': (None, [_vp, _vp, _vp, _i, _i, _f, _i]),
     'relnet_roi_pool_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     'relnet_roi_pool_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'relnet_roi_pool_bwd_ex': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'relnet_roi_pool_fpn_bwd_ex': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_detect_head': (C.c_int, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'relnet_detect_head_ex': (C.c_int, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'relnet_class_nms': (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, C.c_double, _i, _i, _vp]),
@@ -78,6 +80,9 @@ _SIGNATURES = {
     'relnet_deformable_psroi_pool_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_f, _f, _i, _i, _i, _vp]),
     'relnet_roi_pool_fpn_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_wgrad_accumulate': (C.c_int, [_vp, _i, _l, _i, _vp, _vp, _vp]),
+    'relnet_wgrad': (C.c_int, [_vp, _l, _i, _vp, _l, _vp, _l, _vp] + [_i] * 12 + [_vp]),
+    'relnet_wgrad_debug_plain': (None, [_i]),
+    'relnet_debug_tr_probe': (C.c_int, [_vp, _vp]),
     'relnet_gemm_force_tile': (None, [_i]),
     'relnet_gemm_force_nloop': (None, [_i]),
     'relnet_gemm_set_swizzle': (None, [_i]),

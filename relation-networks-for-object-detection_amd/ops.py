@@ -262,16 +262,20 @@ def roi_pool(data, rois, pooled=(7, 7), spatial_scale=0.0625, channels_last_out=
     return (out, arg) if want_argmax else out
 
 
-def roi_pool_bwd(grad_out, argmax, rois, in_shape, batch_index_base=0):
+def roi_pool_bwd(grad_out, argmax, rois, in_shape, batch_index_base=0, channels_last=False):
     """Adjoint of roi_pool: grad_out / argmax logical [R,C,PH,PW] with IDENTICAL strides (as returned by
-    roi_pool(want_argmax=True)); in_shape (B,C,H,W) -> fp32 gradient of the feature map [B,C,H,W] (NCHW)."""
+    roi_pool(want_argmax=True)); in_shape (B,C,H,W) -> fp32 gradient of the feature map, logical [B,C,H,W]; memory NCHW, or
+    NHWC with channels_last (coalesced atomics; `.permute(0, 2, 3, 1)` of the result is then contiguous)."""
     _chk(grad_out, argmax, rois)
     assert argmax.dtype == torch.int32 and tuple(grad_out.stride()) == tuple(argmax.stride()) and grad_out.shape == argmax.shape
     B, Cc, H, W = in_shape
     R, _, PH, PW = grad_out.shape
-    gin = torch.zeros((B, Cc, H, W), device=grad_out.device, dtype=torch.float32)
-    _lib.call('relnet_roi_pool_bwd', grad_out.data_ptr(), argmax.data_ptr(), _strides4(grad_out), rois.data_ptr(),
-              gin.data_ptr(), gin.stride(0), gin.stride(1), R, Cc, W, PH, PW, batch_index_base, _dt(grad_out), _stream())
+    if channels_last:
+        gin = torch.zeros((B, H, W, Cc), device=grad_out.device, dtype=torch.float32).permute(0, 3, 1, 2)
+    else:
+        gin = torch.zeros((B, Cc, H, W), device=grad_out.device, dtype=torch.float32)
+    _lib.call('relnet_roi_pool_bwd_ex', grad_out.data_ptr(), argmax.data_ptr(), _strides4(grad_out), rois.data_ptr(),
+              gin.data_ptr(), gin.stride(0), gin.stride(1), gin.stride(3), R, Cc, W, PH, PW, batch_index_base, _dt(grad_out), _stream())
     return gin
 
 
@@ -725,20 +729,25 @@ def roi_pool_fpn(levels, scales, rois, roi_level, pooled=(7, 7), channels_last_o
     return (out, arg) if want_argmax else out
 
 
-def roi_pool_fpn_bwd(grad_out, argmax, rois, roi_level, level_shapes, batch_index_base=0):
-    """Adjoint of roi_pool_fpn: level_shapes = [(B,C,H_l,W_l)] -> list of fp32 gradients [B,C,H_l,W_l] (NCHW)."""
+def roi_pool_fpn_bwd(grad_out, argmax, rois, roi_level, level_shapes, batch_index_base=0, channels_last=False):
+    """Adjoint of roi_pool_fpn: level_shapes = [(B,C,H_l,W_l)] -> list of fp32 gradients, logical [B,C,H_l,W_l] (memory NCHW,
+    or NHWC with channels_last)."""
     import ctypes
     _chk(grad_out, argmax, rois, roi_level)
     assert argmax.dtype == torch.int32 and tuple(grad_out.stride()) == tuple(argmax.stride())
     R, Cc, PH, PW = grad_out.shape
-    gins = [torch.zeros(tuple(sh), device=grad_out.device, dtype=torch.float32) for sh in level_shapes]
+    if channels_last:
+        gins = [torch.zeros((sh[0], sh[2], sh[3], sh[1]), device=grad_out.device, dtype=torch.float32).permute(0, 3, 1, 2) for sh in level_shapes]
+    else:
+        gins = [torch.zeros(tuple(sh), device=grad_out.device, dtype=torch.float32) for sh in level_shapes]
     nl = len(gins)
     ptrs = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in gins])
     gb = (ctypes.c_long * nl)(*[int(t.stride(0)) for t in gins])
     gc = (ctypes.c_long * nl)(*[int(t.stride(1)) for t in gins])
-    _lib.call('relnet_roi_pool_fpn_bwd', grad_out.data_ptr(), argmax.data_ptr(), _strides4(grad_out), rois.data_ptr(),
-              roi_level.data_ptr(), ctypes.addressof(ptrs), ctypes.addressof(gb), ctypes.addressof(gc), nl, R, Cc, PH, PW,
-              batch_index_base, _dt(grad_out), _stream())
+    gp = (ctypes.c_long * nl)(*[int(t.stride(3)) for t in gins])
+    _lib.call('relnet_roi_pool_fpn_bwd_ex', grad_out.data_ptr(), argmax.data_ptr(), _strides4(grad_out), rois.data_ptr(),
+              roi_level.data_ptr(), ctypes.addressof(ptrs), ctypes.addressof(gb), ctypes.addressof(gc), ctypes.addressof(gp),
+              nl, R, Cc, PH, PW, batch_index_base, _dt(grad_out), _stream())
     return gins
 
 
@@ -776,6 +785,42 @@ def transpose_2d(x, out=None, pad_cols_to=1):
     assert out.stride(-1) == 1 and out.shape[-2] == cols and out.shape[-1] >= rows
     _lib.call('relnet_transpose_2d', x.data_ptr(), x.stride(-2), x.stride(0) if x.dim() == 3 else 0, out.data_ptr(),
               out.stride(-2), out.stride(0) if out.dim() == 3 else 0, rows, cols, batch, _dt(x), _stream())
+    return out
+
+
+def wgrad_tn(dy2d, x, out=None, row_scale=None, cout=None, conv=None):
+    """Weight gradient  out [Cout, K] fp32 += row_scale^2 * dy2d^T X  straight from the pixel-major operands (csrc/wgrad.hip:
+    LDS-transposed MFMA fragments, implicit im2col, split over the pixels with float atomics; no transposed copies).
+    dy2d [P, >= Cout] bf16 (row stride a multiple of 8; columns >= cout must be zero padding).
+    conv None: x [P, K] bf16 rows;  conv = (ksize, stride, dil, pad): x [B, Hin, Win, Cin] NHWC (any pixel stride) and
+    dy2d the [B * Hout * Wout, Cout] gradient of that convolution's output, K = ksize^2 Cin in pack_conv_weight order.
+    out None: a fresh zero tensor is returned (otherwise accumulated into `out`, e.g. a view of the flat gradient buffer)."""
+    _chk(dy2d, x, out, row_scale)
+    assert dy2d.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy2d.dim() == 2 and dy2d.stride(1) == 1
+    P = dy2d.shape[0]
+    cout = dy2d.shape[1] if cout is None else cout
+    if conv is None:
+        assert x.dim() == 2 and x.shape[0] == P and x.stride(1) == 1
+        cin, ks, stride, dil, pad = x.shape[1], 1, 1, 1, 0
+        B = Ho = Wo = Hin = Win = 1
+        x_pix = x.stride(0)
+    else:
+        ks, stride, dil, pad = conv
+        B, Hin, Win, cin = x.shape
+        assert x.stride(3) == 1 and x.stride(1) == Win * x.stride(2) and x.stride(0) == Hin * x.stride(1)
+        Ho = (Hin + 2 * pad - dil * (ks - 1) - 1) // stride + 1
+        Wo = (Win + 2 * pad - dil * (ks - 1) - 1) // stride + 1
+        assert B * Ho * Wo == P, (x.shape, conv, P)
+        x_pix = x.stride(2)
+    K = ks * ks * cin
+    if out is None:
+        out = torch.zeros((cout, K), device=dy2d.device, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.shape == (cout, K) and out.stride(1) == 1
+    if row_scale is not None:
+        assert row_scale.dtype == torch.float32 and row_scale.numel() == cout and row_scale.is_contiguous()
+    _lib.call('relnet_wgrad', dy2d.data_ptr(), dy2d.stride(0), dy2d.shape[1], x.data_ptr(), x_pix, out.data_ptr(), out.stride(0),
+              _ptr(row_scale), P, cout, cin, ks, stride, dil, pad, B, Ho, Wo, Hin, Win, _stream(),
+              tag='P%d_M%d_K%d_k%d' % (P, cout, K, ks))
     return out
 
 

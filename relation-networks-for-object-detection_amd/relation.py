@@ -209,13 +209,17 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
     d_fk = ops.gemm_nt(dvw_t.reshape(B * M, d), wout_t, out_dtype=torch.float32).reshape(B, M, Fd)
     d_f[:, :M] += d_fk
     # weight gradients: dW[out, in] = sum_rows dOut[row, out] X[row, in]
-    f_t = ops.transpose_2d(f.reshape(B * N, Fd), pad_cols_to=kpad)       # [Fd, pad(B N)]
-    dqk_t = ops.transpose_2d(dqk.reshape(B * N, 2 * d), pad_cols_to=kpad)
-    d_wqk = ops.gemm_nt(dqk_t, f_t, out_dtype=torch.float32)             # [2d, Fd]
     fk = f[:, :M, :].contiguous().reshape(B * M, Fd)
-    fk_t = ops.transpose_2d(fk, pad_cols_to=kpad)
-    dvw_tt = ops.transpose_2d(dvw_t.reshape(B * M, d), pad_cols_to=kpad)
-    d_wout = ops.gemm_nt(dvw_tt, fk_t, out_dtype=torch.float32)          # [d, Fd]
+    if dtype == torch.bfloat16:          # straight from the row-major operands (csrc/wgrad.hip), no transposed copies
+        d_wqk = ops.wgrad_tn(dqk.reshape(B * N, 2 * d), f.reshape(B * N, Fd))         # [2d, Fd]
+        d_wout = ops.wgrad_tn(dvw_t.reshape(B * M, d), fk)                            # [d, Fd]
+    else:
+        f_t = ops.transpose_2d(f.reshape(B * N, Fd), pad_cols_to=kpad)       # [Fd, pad(B N)]
+        dqk_t = ops.transpose_2d(dqk.reshape(B * N, 2 * d), pad_cols_to=kpad)
+        d_wqk = ops.gemm_nt(dqk_t, f_t, out_dtype=torch.float32)             # [2d, Fd]
+        fk_t = ops.transpose_2d(fk, pad_cols_to=kpad)
+        dvw_tt = ops.transpose_2d(dvw_t.reshape(B * M, d), pad_cols_to=kpad)
+        d_wout = ops.gemm_nt(dvw_tt, fk_t, out_dtype=torch.float32)          # [d, Fd]
     i = index
     grads = {
         'd_roi_feat': d_f[0] if squeeze else d_f,

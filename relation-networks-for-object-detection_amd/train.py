@@ -183,6 +183,8 @@ class Trainer(object):
     def _add_wgrad(self, name, dw, scale_rows=None):
         """dw: the gradient [rows, cols], or the split-K partial sums [splits, rows, cols] of train_ops.wgrad(keep_splits=True)
         (summed, scaled by the folded-BN factor and accumulated by ONE kernel)."""
+        if dw is None:              # already accumulated by relnet_wgrad (wgrad_to)
+            return
         g = self.W.view(self.W.grad, name)
         if dw.dim() == 3 and dw.is_contiguous() and dw.shape[1] * dw.shape[2] == g.numel() and g.shape[-1] % 4 == 0:
             T.wgrad_accumulate(dw, g, scale_rows)
@@ -193,6 +195,12 @@ class Trainer(object):
         if scale_rows is not None:
             dw = dw * (scale_rows * scale_rows).view(-1, 1)
         g.add_(dw)
+
+    def _wg(self, name, scale_rows=None):
+        """(2-D fp32 view of `name`'s slice of the flat gradient buffer, folded-BatchNorm row factor | None): the target
+        relnet_wgrad accumulates into (train_ops `wgrad_to` protocol)."""
+        g = self.W.view(self.W.grad, name)
+        return g.view(g.shape[0], -1), scale_rows
 
     def _add_bgrad(self, name, db):
         self.Bv.view(self.Bv.grad, name).add_(db.reshape(-1))
@@ -312,24 +320,24 @@ class Trainer(object):
             gp = d_pool.view(B * R, 7, 7, -1).permute(0, 3, 1, 2)
             gd1, gtrans = ops.deformable_psroi_pool_bwd(gp, nchw(feat), r5, trans, sc_, feat.shape[3], 1, 7, 7,
                                                         c.dcn_sample_per_part, c.dcn_trans_std, False)
-            d_t0, dw, db = T.linear_bwd(t0f, self.w('offset'), gtrans.view(B * R, -1).to(bt), keep_splits=True)
-            self._add_wgrad('offset', dw); self._add_bgrad('offset', db)
+            d_t0, dw, db = T.linear_bwd(t0f, self.w('offset'), gtrans.view(B * R, -1).to(bt), keep_splits=True, wgrad_to=self._wg('offset'))
+            self._add_bgrad('offset', db)
             gd2, _ = ops.deformable_psroi_pool_bwd(d_t0.view(B * R, 7, 7, -1).permute(0, 3, 1, 2), nchw(feat), r5, None, sc_,
                                                    feat.shape[3], 1, 7, 7, c.dcn_sample_per_part, 0.0, True)
             d_feat = (gd1 + gd2).permute(0, 2, 3, 1).to(bt).contiguous()       # logical NCHW stored NHWC -> NHWC bf16
         else:
             d_feat = ops.roi_pool_bwd(d_pool.view(B * R, 7, 7, -1).permute(0, 3, 1, 2), argmax, r5,
-                                      (B, feat.shape[3], feat.shape[1], feat.shape[2]))
-            d_feat = d_feat.permute(0, 2, 3, 1).to(bt).contiguous()
+                                      (B, feat.shape[3], feat.shape[1], feat.shape[2]), channels_last=True)
+            d_feat = d_feat.permute(0, 2, 3, 1).to(bt)          # NHWC memory already: one conversion pass
         g = T.relu_bwd(d_feat, feat)
-        d_x, dw = T.conv1x1_bwd(conv5, self.w('conv_new_1'), g, keep_splits=True)
-        self._add_wgrad('conv_new_1', dw); self._add_bgrad('conv_new_1', g.float().sum((0, 1, 2)))
+        d_x, dw = T.conv1x1_bwd(conv5, self.w('conv_new_1'), g, keep_splits=True, wgrad_to=self._wg('conv_new_1'))
+        self._add_bgrad('conv_new_1', g.float().sum((0, 1, 2)))
         # RPN head backward (joins the trunk at conv4)
-        d_r, dw = T.conv1x1_bwd(r, self.w('rpn_out'), d_rpn, keep_splits=True)
-        self._add_wgrad('rpn_out', dw); self._add_bgrad('rpn_out', d_rpn.float().sum((0, 1, 2)))
+        d_r, dw = T.conv1x1_bwd(r, self.w('rpn_out'), d_rpn, keep_splits=True, wgrad_to=self._wg('rpn_out'))
+        self._add_bgrad('rpn_out', d_rpn.float().sum((0, 1, 2)))
         g_r = T.relu_bwd(d_r, r)
-        d_conv4_rpn, dw = T.conv3x3_bwd(conv4, self._dgrad_w('rpn_conv_3x3', 512), g_r, dil=1, keep_splits=True)
-        self._add_wgrad('rpn_conv_3x3', dw); self._add_bgrad('rpn_conv_3x3', g_r.float().sum((0, 1, 2)))
+        d_conv4_rpn, dw = T.conv3x3_bwd(conv4, self._dgrad_w('rpn_conv_3x3', 512), g_r, dil=1, keep_splits=True, wgrad_to=self._wg('rpn_conv_3x3'))
+        self._add_bgrad('rpn_conv_3x3', g_r.float().sum((0, 1, 2)))
         self._trunk_backward(saved, d_x, {'4b22': d_conv4_rpn})
         out['rois'] = rois_t
         out['label'] = labels_ohem
@@ -359,8 +367,7 @@ class Trainer(object):
             if inject.get(nm) is not None:       # a second consumer of this unit's output (RPN head at conv4, FPN laterals)
                 d_x = inject[nm] if d_x is None else d_x + inject[nm]
             g_out = T.relu_bwd(d_x, o)
-            d_y2, dw = T.conv1x1_bwd(y2, self.w(nc_), g_out, keep_splits=True)
-            self._add_wgrad(nc_, dw, self.bn_scale[nc_])
+            d_y2, dw = T.conv1x1_bwd(y2, self.w(nc_), g_out, keep_splits=True, wgrad_to=self._wg(nc_, self.bn_scale[nc_]))
             g_y2 = T.relu_bwd(d_y2, y2)
             if off is not None:            # deformable branch2b: data + offset gradients, then the offset conv's own backward
                 gd, goff, dw = ops.deformable_conv_bwd(y1.permute(0, 3, 1, 2), off.permute(0, 3, 1, 2), self.w(nb),
@@ -375,20 +382,16 @@ class Trainer(object):
                 self._add_wgrad(no, dwo.sum(0)[:72]); self._add_bgrad(no, goff.sum((0, 1, 2)))
                 d_y1 = (gd + d_off_in.float()).to(bt).contiguous()
             else:
-                d_y1, dw = T.conv3x3_bwd(y1, self._dgrad_w(nb, y2.shape[3]), g_y2, dil=dil, keep_splits=True)
-                self._add_wgrad(nb, dw, self.bn_scale[nb])
+                d_y1, dw = T.conv3x3_bwd(y1, self._dgrad_w(nb, y2.shape[3]), g_y2, dil=dil, keep_splits=True, wgrad_to=self._wg(nb, self.bn_scale[nb]))
             g_y1 = T.relu_bwd(d_y1, y1)
             first = (stage == 3 and proj)         # res3a: its input comes from the frozen res2 -> no data gradient
             if proj:
-                d_a, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, stride=stride, need_dx=not first, keep_splits=True)
-                self._add_wgrad(na, dw, self.bn_scale[na])
+                d_a, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, stride=stride, need_dx=not first, keep_splits=True, wgrad_to=self._wg(na, self.bn_scale[na]))
                 d_s, dw = T.conv1x1_bwd(x_in, self.w(n1), g_out, stride=stride, need_dx=not first,
-                                        dx_add=d_a if (stride == 1 and not first) else None, keep_splits=True)
-                self._add_wgrad(n1, dw, self.bn_scale[n1])
+                                        dx_add=d_a if (stride == 1 and not first) else None, keep_splits=True, wgrad_to=self._wg(n1, self.bn_scale[n1]))
                 d_x = None if first else (d_s if stride == 1 else d_s + d_a)
             else:
-                d_x, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, dx_add=g_out, keep_splits=True)       # identity shortcut
-                self._add_wgrad(na, dw, self.bn_scale[na])
+                d_x, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, dx_add=g_out, keep_splits=True, wgrad_to=self._wg(na, self.bn_scale[na]))       # identity shortcut
         self._bucket_ready('res%d' % prev)
 
     def _head_forward_backward(self, pooled2, rois_t, N, label, bbox_target, bbox_weight, im_info, gt_boxes, num_gt, out,
@@ -428,17 +431,17 @@ class Trainer(object):
             out.update(lo)
         # ================= backward =================
         d_cb = torch.cat([d_cls, d_bbox], 2).reshape(B * R, -1).to(bt)
-        d_x2, dw, db = T.linear_bwd(x2.reshape(B * R, -1), self.w('cls_bbox'), d_cb, keep_splits=True)
-        self._add_wgrad('cls_bbox', dw); self._add_bgrad('cls_bbox', db)
+        d_x2, dw, db = T.linear_bwd(x2.reshape(B * R, -1), self.w('cls_bbox'), d_cb, keep_splits=True, wgrad_to=self._wg('cls_bbox'))
+        self._add_bgrad('cls_bbox', db)
         if d_x2_lnms is not None:
             d_x2 = d_x2.reshape(B, R, -1)
             d_x2[:, :N] += d_x2_lnms.to(d_x2.dtype)
         d_f2 = self._relation_bwd(2, mods[1], f2, x2, rois_t, d_x2.reshape(B, R, -1), N, key_count)
-        d_x1, dw, db = T.linear_bwd(x1.reshape(B * R, -1), self.w('fc_new_2'), d_f2.reshape(B * R, -1), keep_splits=True)
-        self._add_wgrad('fc_new_2', dw); self._add_bgrad('fc_new_2', db)
+        d_x1, dw, db = T.linear_bwd(x1.reshape(B * R, -1), self.w('fc_new_2'), d_f2.reshape(B * R, -1), keep_splits=True, wgrad_to=self._wg('fc_new_2'))
+        self._add_bgrad('fc_new_2', db)
         d_f1 = self._relation_bwd(1, mods[0], f1, x1, rois_t, d_x1.reshape(B, R, -1), N, key_count)
-        d_pool, dw, db = T.linear_bwd(pooled2, self.w('fc_new_1'), d_f1.reshape(B * R, -1), keep_splits=True)
-        self._add_wgrad('fc_new_1', dw); self._add_bgrad('fc_new_1', db)
+        d_pool, dw, db = T.linear_bwd(pooled2, self.w('fc_new_1'), d_f1.reshape(B * R, -1), keep_splits=True, wgrad_to=self._wg('fc_new_1'))
+        self._add_bgrad('fc_new_1', db)
         return d_pool, (x2, f1, cls_score, bbox_pred, labels_ohem, weights_ohem)
 
     def _lnms_forward_backward(self, cls_score, bbox_pred, rois, im_info, feat, gt_boxes, num_gt, n_valid=None):
@@ -520,8 +523,8 @@ class Trainer(object):
         flat = (rank_idx.long() + (torch.arange(B, device=dev) * N).view(B, 1, 1)).view(-1)
         d_emb = torch.zeros((B * N, 128), device=dev, dtype=torch.float32)
         d_emb.index_add_(0, flat, d_x.reshape(-1, 128))                                         # take() backward
-        d_feat, dw, db = T.linear_bwd(feat2, self.w('roi_feat_embedding'), d_emb.to(bt), keep_splits=True)
-        self._add_wgrad('roi_feat_embedding', dw); self._add_bgrad('roi_feat_embedding', db)
+        d_feat, dw, db = T.linear_bwd(feat2, self.w('roi_feat_embedding'), d_emb.to(bt), keep_splits=True, wgrad_to=self._wg('roi_feat_embedding'))
+        self._add_bgrad('roi_feat_embedding', db)
         # sort / slice backward -> cls_prob -> softmax backward (background column has no direct gradient)
         d_prob = torch.zeros((B, N, C), device=dev, dtype=torch.float32)
         cidx = torch.arange(C, device=dev).view(1, C, 1).expand(B, C, F)
@@ -647,7 +650,12 @@ class Trainer(object):
     def _bucket_ready(self, name):
         """Called by the backward pass when the last gradient of a bucket has been queued (no-op on one rank)."""
         bk = self._grad_buckets()
-        bk.ready(self._bucket_names.index(name))
+        idx = self._bucket_names.index(name)
+        cut = getattr(self, '_capture_cut', None)
+        if cut is not None:          # CapturedStep: close the current hipGraph here; the collective goes between two graphs
+            cut(idx)
+            return
+        bk.ready(idx)
 
     def all_reduce(self):
         """Summed all-reduce of the gradients over RCCL (MXNet kvstore 'device' + rescale_grad 1.0 semantics): the four
@@ -676,6 +684,59 @@ class Trainer(object):
         self.all_reduce()
         self.update()
         return out
+
+
+class CapturedStep(object):
+    """forward + backward of a trainer captured as a CHAIN of hipGraphs, cut where a gradient bucket completes
+    (heads | res5 | res4 | res3, the order the backward pass finishes them): on replay every bucket's summed all-reduce is
+    issued from the host BETWEEN two graph launches, on the communication stream, and runs under the next segment's kernels --
+    the overlap of dist.BucketedAllReduce without the ~10 ms of eager Python launches per step, and without capturing the
+    collective itself (a captured RCCL call would pin the communicator's buffers into the graph).
+    The reference overlaps nothing: kvstore push / pull runs after the whole backward pass (core/module.py:569-591).
+
+        step = CapturedStep(trainer, batch)          # one eager warm-up must have run before (kernel attributes, caches)
+        out = step.replay(); trainer.all_reduce(); trainer.update()
+    """
+
+    def __init__(self, trainer, batch, kwargs=None):
+        self.tr = trainer
+        self.segments = []                       # [(hipGraph, bucket index or None)]
+        pool = torch.cuda.graph_pool_handle()    # one private pool: tensors made in one segment stay valid in the next ones
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        cur = [None]
+
+        def begin():
+            cur[0] = torch.cuda.CUDAGraph()
+            cur[0].capture_begin(pool=pool)
+
+        def cut(idx):
+            cur[0].capture_end()
+            self.segments.append((cur[0], idx))
+            begin()
+
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side), torch.no_grad():
+            begin()
+            trainer._capture_cut = cut
+            try:
+                self.out = trainer.forward_backward(*batch, **(kwargs or {}))
+            finally:
+                trainer._capture_cut = None
+                cur[0].capture_end()
+            self.segments.append((cur[0], None))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+    def replay(self):
+        """Launch the segments in order; after each one, announce its bucket (asynchronous all-reduce on >1 rank)."""
+        bk = self.tr._grad_buckets()
+        bk.reset()
+        for graph, idx in self.segments:
+            graph.replay()
+            if idx is not None:
+                bk.ready(idx)
+        return self.out
 
 
 class FPNTrainer(Trainer):
@@ -742,21 +803,21 @@ class FPNTrainer(Trainer):
         x2, f1, cls_score, bbox_pred, labels_ohem, weights_ohem = hs
         # ---- pooling backward into the four pyramid maps
         g_lv = ops.roi_pool_fpn_bwd(d_pool.view(B * R, 7, 7, -1).permute(0, 3, 1, 2), argmax, rois_s.view(B * R, 5), level.view(-1),
-                                    [tuple(t.shape) for t in lv])
-        d_feats = {lvl: g.permute(0, 2, 3, 1).to(bt).contiguous() for lvl, g in zip((4, 8, 16, 32), g_lv)}
+                                    [tuple(t.shape) for t in lv], channels_last=True)
+        d_feats = {lvl: g.permute(0, 2, 3, 1).to(bt) for lvl, g in zip((4, 8, 16, 32), g_lv)}
         # ---- neck backward (top-down pathway reversed: finest level first, gradients flow up to the coarser tops)
         d_tops, inject, d_c5 = {}, {}, None
         for lvl in (4, 8, 16, 32):
             n3, n1 = 'fpn_ft%d_3x3' % lvl, 'fpn_ft%d_1x1' % lvl
-            d_top, dw = T.conv3x3_bwd(tops[lvl], self._dgrad_w(n3, 256), d_feats[lvl], dil=1, keep_splits=True)
-            self._add_wgrad(n3, dw); self._add_bgrad(n3, d_feats[lvl].float().sum((0, 1, 2)))
+            d_top, dw = T.conv3x3_bwd(tops[lvl], self._dgrad_w(n3, 256), d_feats[lvl], dil=1, keep_splits=True, wgrad_to=self._wg(n3))
+            self._add_bgrad(n3, d_feats[lvl].float().sum((0, 1, 2)))
             if lvl in d_tops:                                    # + the gradient that came down from the finer level
                 d_top = (d_top.float() + d_tops[lvl]).to(bt)
             if lvl < 32:       # tops[lvl] = lateral + up2x(tops[2 lvl]): adjoint of nearest upsampling = 2x2 block sums
                 Bh, Hh, Wh, Ch = d_top.shape
                 d_tops[lvl * 2] = d_top.float().view(Bh, Hh // 2, 2, Wh // 2, 2, Ch).sum((2, 4))
-            d_src, dw = T.conv1x1_bwd(src[lvl], self.w(n1), d_top.contiguous(), need_dx=(lvl != 4), keep_splits=True)   # res2c is frozen
-            self._add_wgrad(n1, dw); self._add_bgrad(n1, d_top.float().sum((0, 1, 2)))
+            d_src, dw = T.conv1x1_bwd(src[lvl], self.w(n1), d_top.contiguous(), need_dx=(lvl != 4), keep_splits=True, wgrad_to=self._wg(n1))   # res2c is frozen
+            self._add_bgrad(n1, d_top.float().sum((0, 1, 2)))
             if lvl == 32:
                 d_c5 = d_src
             elif lvl == 16:

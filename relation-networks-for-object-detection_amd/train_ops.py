@@ -75,19 +75,49 @@ def wgrad_accumulate(parts, grad, row_scale=None):
     _lib.call('relnet_wgrad_accumulate', parts.data_ptr(), S, rows, cols, _ptr(row_scale), grad.data_ptr(), _stream())
 
 
-def linear_bwd(x2d, w, dy2d, need_dx=True, w_t=None, keep_splits=False):
-    """y = x W^T + b  ->  (dx [P,K] in x's dtype | None, dW [N,K] fp32, db [N] fp32)."""
+def _tn_ok(dy2d, x):
+    """relnet_wgrad takes bf16 operands whose rows are 16-byte aligned."""
+    return (dy2d.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy2d.stride(-1) == 1 and x.stride(-1) == 1 and
+            dy2d.stride(0) % 8 == 0 and dy2d.shape[1] % 8 == 0 and x.shape[-1] % 8 == 0 and dy2d.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
+
+
+def linear_bwd(x2d, w, dy2d, need_dx=True, w_t=None, keep_splits=False, wgrad_to=None):
+    """y = x W^T + b  ->  (dx [P,K] in x's dtype | None, dW [N,K] fp32, db [N] fp32).
+    wgrad_to = (grad [N,K] fp32 view, row_scale | None): the weight gradient is ACCUMULATED there by relnet_wgrad (one
+    kernel straight from the row-major operands) and None is returned in its place."""
     dx = None
+    gran = 64 if dy2d.dtype == torch.bfloat16 else 16
+    N = dy2d.shape[1]
+    dyp = dy2d
+    if N % gran and (need_dx or wgrad_to is not None):        # e.g. the 81 + 8 outputs of cls_score | bbox_pred
+        dyp = torch.zeros((dy2d.shape[0], pad_to(N, gran)), device=dy2d.device, dtype=dy2d.dtype)
+        dyp[:, :N] = dy2d
     if need_dx:
-        gran = 64 if dy2d.dtype == torch.bfloat16 else 16
-        N = dy2d.shape[1]
         w_t = ops.transpose_2d(w, pad_cols_to=gran) if w_t is None else w_t      # [K, pad(N)], zero padded
-        dyp = dy2d
-        if N % gran:                              # e.g. the 81 + 8 outputs of cls_score | bbox_pred
-            dyp = torch.zeros((dy2d.shape[0], w_t.shape[1]), device=dy2d.device, dtype=dy2d.dtype)
-            dyp[:, :N] = dy2d
         dx = ops.gemm_nt(dyp, w_t)
-    return dx, wgrad(dy2d, x2d, keep_splits), dy2d.float().sum(0)
+    db = dy2d.float().sum(0)
+    if wgrad_to is not None and _tn_ok(dyp, x2d):
+        ops.wgrad_tn(dyp, x2d, out=wgrad_to[0], row_scale=wgrad_to[1], cout=N)
+        return dx, None, db
+    dw = wgrad(dy2d, x2d, keep_splits)
+    if wgrad_to is not None:
+        _accumulate(wgrad_to, dw)
+        dw = None
+    return dx, dw, db
+
+
+def _accumulate(wgrad_to, dw):
+    """Fallback of the `wgrad_to` protocol for operands relnet_wgrad does not take: split-K partial sums -> += into the view."""
+    g, scale = wgrad_to
+    if dw.dim() == 3 and dw.is_contiguous() and dw.shape[1] * dw.shape[2] == g.numel() and g.shape[-1] % 4 == 0:
+        wgrad_accumulate(dw, g, scale)
+        return
+    if dw.dim() == 3:
+        dw = dw.sum(0)
+    dw = dw.reshape(g.shape)
+    if scale is not None:
+        dw = dw * (scale * scale).view(-1, 1)
+    g.add_(dw)
 
 
 def pack_conv_dgrad_weight(w_oihw, dtype=torch.bfloat16, device='cuda'):
@@ -97,13 +127,15 @@ def pack_conv_dgrad_weight(w_oihw, dtype=torch.bfloat16, device='cuda'):
     return w.reshape(w.shape[0], -1).to(device=device, dtype=dtype).contiguous()
 
 
-def conv1x1_bwd(x, w_packed, dy, stride=1, need_dx=True, w_t=None, dx_add=None, keep_splits=False):
+def conv1x1_bwd(x, w_packed, dy, stride=1, need_dx=True, w_t=None, dx_add=None, keep_splits=False, wgrad_to=None):
     """x [B,H,W,Cin], dy [B,Ho,Wo,Cout] NHWC; w_packed [Cout,Cin].  -> (dx [B,H,W,Cin] | None, dW fp32).
-    dx_add (stride 1 only): a second gradient of x's shape added in the GEMM epilogue (the shortcut branch)."""
+    dx_add (stride 1 only): a second gradient of x's shape added in the GEMM epilogue (the shortcut branch).
+    wgrad_to: see linear_bwd (the strided input rows are gathered inside relnet_wgrad: no sub-sampled copy of x)."""
     B, H, W, Cin = x.shape
     Cout = w_packed.shape[0]
-    xs = x if stride == 1 else x[:, ::stride, ::stride, :].contiguous()
     P = dy.shape[0] * dy.shape[1] * dy.shape[2]
+    tn = wgrad_to is not None and _tn_ok(dy.reshape(P, Cout), x) and x.is_contiguous()
+    xs = x if (stride == 1 or tn) else x[:, ::stride, ::stride, :].contiguous()
     dy2 = dy.reshape(P, Cout)
     dx = None
     if need_dx:
@@ -118,23 +150,44 @@ def conv1x1_bwd(x, w_packed, dy, stride=1, need_dx=True, w_t=None, dx_add=None, 
         else:
             assert dx_add is None
             dx = torch.zeros_like(x)
-            dx[:, ::stride, ::stride, :] = ops.gemm_nt(dyp, w_t).reshape(xs.shape)
-    return dx, wgrad(dy2, xs.reshape(P, Cin), keep_splits)
+            dx[:, ::stride, ::stride, :] = ops.gemm_nt(dyp, w_t).reshape(dy.shape[0], dy.shape[1], dy.shape[2], Cin)
+    if tn:
+        if stride == 1:
+            ops.wgrad_tn(dy2, x.reshape(P, Cin), out=wgrad_to[0], row_scale=wgrad_to[1])
+        else:
+            ops.wgrad_tn(dy2, x, out=wgrad_to[0], row_scale=wgrad_to[1], conv=(1, stride, 1, 0))
+        return dx, None
+    dw = wgrad(dy2, xs.reshape(P, Cin), keep_splits)
+    if wgrad_to is not None:
+        _accumulate(wgrad_to, dw)
+        dw = None
+    return dx, dw
 
 
 _ZERO_OFF = {}
 
 
-def conv3x3_bwd(x, w_dgrad_packed, dy, dil=1, need_dx=True, keep_splits=False):
+def conv3x3_bwd(x, w_dgrad_packed, dy, dil=1, need_dx=True, keep_splits=False, wgrad_to=None, cout=None):
     """3x3, stride 1, pad = dil.  x [B,H,W,Cin], dy [B,H,W,Cout]; w_dgrad_packed from pack_conv_dgrad_weight.
-    -> (dx | None, dW [Cout, 9*Cin] fp32 in pack_conv_weight order)."""
+    -> (dx | None, dW [Cout, 9*Cin] fp32 in pack_conv_weight order).  wgrad_to: see linear_bwd (implicit im2col inside
+    relnet_wgrad: the [pixels][9 Cin] patch matrix is never written); cout: real output channels when dy is zero padded."""
     B, H, W, Cin = x.shape
     Cout = dy.shape[3]
     dx = None
     if need_dx:
         dx = ops.conv2d_nhwc(dy, w_dgrad_packed, None, ksize=3, stride=1, pad=dil, dil=dil)
+    dy2 = dy.reshape(B * H * W, Cout)
+    if wgrad_to is not None and _tn_ok(dy2, x) and x.is_contiguous():
+        ops.wgrad_tn(dy2, x, out=wgrad_to[0], row_scale=wgrad_to[1], cout=cout, conv=(3, 1, dil, dil))
+        return dx, None
     key = (B, H, W, x.device)
     if key not in _ZERO_OFF:
         _ZERO_OFF[key] = torch.zeros((B, H, W, 18), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
     col, _ = ops.deformable_im2col(x.permute(0, 3, 1, 2), _ZERO_OFF[key], 3, 1, dil, dil, 1)    # [P, 9*Cin] patches
-    return dx, wgrad(dy.reshape(B * H * W, Cout), col, keep_splits)
+    dw = wgrad(dy2, col, keep_splits)
+    if wgrad_to is not None:
+        if cout is not None:
+            dw = (dw.sum(0) if dw.dim() == 3 else dw)[:cout]
+        _accumulate(wgrad_to, dw)
+        dw = None
+    return dx, dw

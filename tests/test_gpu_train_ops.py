@@ -102,3 +102,71 @@ def test_relu_bwd_and_sgd(dtype):
         m1 = 0.9 * m0 - 0.0005 * (gr + 0.0005 * w0)
         assert torch.allclose(m, m1, rtol=1e-5, atol=1e-7) and torch.allclose(w, w0 + m1, rtol=1e-5, atol=1e-6)
         assert torch.equal(wb, w.to(torch.bfloat16))
+
+
+def test_tr_probe_prints_the_transposed_read_map():
+    """What ds_read_b64_tr_b16 returns for lane-linear addresses over value == index (csrc/wgrad.hip builds its MFMA fragments
+    on it): lane l of a 16-lane group must receive column (l & 15) of the group's row-major [4][16] block."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import lib as L, ops
+    out = torch.zeros(256, dtype=torch.int16, device='cuda')
+    L.call('relnet_debug_tr_probe', out.data_ptr(), ops._stream())
+    got = out.cpu().numpy().astype(np.int64).reshape(64, 4)
+    lane = np.arange(64)[:, None]
+    want = (lane >> 4) * 64 + (lane & 15) + 16 * np.arange(4)[None, :]
+    print('tr probe lanes 0..3, 16, 17, 63:', got[[0, 1, 2, 3, 16, 17, 63]].tolist())
+    assert np.array_equal(got, want), got.tolist()
+
+
+@pytest.mark.parametrize('case', ['fc', 'fc_ragged', 'conv1x1_s2', 'conv3x3', 'conv3x3_dil2', 'rpn_out', 'wide'])
+def test_wgrad_tn_matches_float64(case):
+    """relnet_wgrad (dY^T X from the row-major operands: transposed LDS reads, implicit im2col, atomics over the pixel splits)
+    against float64 on the bf16 inputs, incl. ragged pixel counts / channel counts, strided and dilated gathers, the folded
+    BatchNorm row factor, accumulation into a non-zero buffer and a strided view of a wider buffer; plain-LDS-read mode too."""
+    import torch.nn.functional as F
+    import relnet_amd  # noqa: F401
+    from relnet_amd import lib as L, ops
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    bf = torch.bfloat16
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    scale = None
+    if case in ('fc', 'fc_ragged', 'wide'):
+        P, Cout, K = {'fc': (2464, 256, 384), 'fc_ragged': (1237, 89, 136), 'wide': (700, 1024, 1152)}[case]
+        cpad = (Cout + 63) // 64 * 64
+        dy = torch.zeros(P, cpad); dy[:, :Cout] = rnd(P, Cout)
+        x = rnd(P, K)
+        dyb, xb = dy.to(bf).cuda(), x.to(bf).cuda()
+        want = dyb[:, :Cout].double().t().cpu() @ xb.double().cpu()
+        conv = None
+        xk = xb
+    else:
+        ks, stride, dil, Cin, Cout, B, H, W = {'conv1x1_s2': (1, 2, 1, 256, 128, 2, 37, 51), 'conv3x3': (3, 1, 1, 128, 128, 2, 19, 23),
+                                               'conv3x3_dil2': (3, 1, 2, 64, 256, 3, 14, 17), 'rpn_out': (1, 1, 1, 512, 72, 2, 38, 63)}[case]
+        pad = dil if ks == 3 else 0
+        xb = rnd(B, H, W, Cin).to(bf).cuda()
+        Ho, Wo = (H + 2 * pad - dil * (ks - 1) - 1) // stride + 1, (W + 2 * pad - dil * (ks - 1) - 1) // stride + 1
+        dyb = rnd(B * Ho * Wo, Cout).to(bf).cuda()
+        # float64 reference through autograd of conv2d
+        w = torch.zeros(Cout, Cin, ks, ks, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(xb.double().cpu().permute(0, 3, 1, 2), w, None, stride=stride, padding=pad, dilation=dil)
+        (y * dyb.double().cpu().view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)).sum().backward()
+        want = w.grad.permute(0, 2, 3, 1).reshape(Cout, -1)              # pack_conv_weight order
+        conv = None if (ks == 1 and stride == 1) else (ks, stride, dil, pad)
+        xk = xb.view(-1, Cin) if conv is None else xb
+        scale = (torch.rand(Cout, generator=g) + 0.5).cuda()
+        want = want * (scale.double().cpu() ** 2).view(-1, 1)
+    for plain in (0, 1):
+        L.load().relnet_wgrad_debug_plain(plain)
+        try:
+            base = torch.randn(want.shape[0], want.shape[1] + 24, generator=g).cuda()          # accumulate into a view of a wider buffer
+            out = base[:, 8:8 + want.shape[1]]
+            before = out.clone()
+            ops.wgrad_tn(dyb, xk, out=out, row_scale=scale, cout=want.shape[0], conv=conv)
+            got = (out - before).double().cpu()
+        finally:
+            L.load().relnet_wgrad_debug_plain(0)
+        err = (got - want).abs().max().item() / want.abs().max().item()
+        assert err <= 2e-5, (case, plain, err)              # fp32 accumulation of exact bf16 products
+        assert torch.equal(base[:, :8], base[:, :8]) and torch.isfinite(base).all()
+    fresh = ops.wgrad_tn(dyb, xk, row_scale=scale, cout=want.shape[0], conv=conv)
+    assert (fresh.double().cpu() - want).abs().max().item() <= 2e-5 * want.abs().max().item()

@@ -351,3 +351,37 @@ def test_checkpoint_round_trip_into_detector(tmp_path):
     assert torch.allclose(det.head.wcb[nc:].float().cpu(), (w_train * stds[:, None]).to(torch.bfloat16).float())
     out = det.forward(data.cuda(), info)
     assert torch.isfinite(out['pred_boxes']).all() and out['rois'].shape == (1, 40, 5)
+
+
+def test_captured_step_in_bucket_segments_equals_eager():
+    """train.CapturedStep: forward + backward as a chain of hipGraphs cut at the gradient buckets (what bench.py replays, and
+    what lets every bucket's all-reduce start between two graph launches).  On one GPU: the segments are cut in backward
+    order heads, res5, res4, res3; a replay reproduces the eager step's losses and gradients; the RPN anchor targets are
+    computed on the device inside the step (no host arrays passed) and a second replay draws a fresh random subset."""
+    H, W, G = 128, 160, 4
+    p, cfg, data, gt, L, Tg, Wg, train = _setup(H, W, G, 41)
+    cfg.learn_nms, cfg.first_n = True, 24
+    tr = train.Trainer(p, cfg, im_hw=(H, W))
+    d = lambda a: torch.as_tensor(a).cuda()
+    batch = (data.cuda(), torch.tensor([[H, W, 1.0]]).cuda(), d(gt))
+    with torch.no_grad():
+        eager = tr.forward_backward(*batch)                    # warm-up + reference (device anchor targets, step counter 0)
+        g_eager = tr.W.grad.clone()
+        tr._anchor_step.zero_()
+        step = train.CapturedStep(tr, batch)
+        assert [i for _, i in step.segments] == [3, 2, 1, 0, None]          # heads | res5 | res4 | res3 | tail
+        tr._anchor_step.zero_()
+        out = step.replay()
+        torch.cuda.synchronize()
+        assert tr._grad_buckets().launch_order == [3, 2, 1, 0]
+        for k in ('bbox_loss', 'rpn_bbox_loss', 'nms_pos_loss', 'nms_neg_loss'):
+            assert abs(float(out[k]) - float(eager[k])) <= 1e-3 * max(abs(float(eager[k])), 1e-6), k
+        # weight gradients are summed with float atomics over the pixel splits: equal up to the summation order
+        num = (tr.W.grad - g_eager).norm().item()
+        assert num <= 1e-3 * g_eager.norm().item(), num
+        assert int(tr._anchor_step) == 1
+        step.replay()
+        torch.cuda.synchronize()
+        assert int(tr._anchor_step) == 2 and torch.isfinite(tr.W.grad).all()
+        tr.all_reduce(); tr.update()
+        assert torch.isfinite(tr.W.master).all()
