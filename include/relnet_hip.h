@@ -340,6 +340,12 @@ int relnet_upsample2x_add(const void* top, void* lateral, int B, int H, int W, i
 int relnet_softmax_output(const float* data, const float* label, float* prob, float* grad, int* valid_count_scratch,
                           long outer, int C, long inner, int use_ignore, float ignore_label, float grad_scale,
                           void* stream);
+/* ..._ex: 'valid' normalisation per group of `group_positions` consecutive (outer, inner) positions (0 = all of them): the
+ * reference normalises per executor = per image; a batched call passes one image's positions (valid_count_scratch then
+ * holds one int per group).                                                                                          */
+int relnet_softmax_output_ex(const float* data, const float* label, float* prob, float* grad, int* valid_count_scratch,
+                             long outer, int C, long inner, int use_ignore, float ignore_label, float grad_scale,
+                             long group_positions, void* stream);
 
 /* weight * mx.sym.smooth_l1(scalar=sigma, data=pred - target) inside mx.sym.MakeLoss(grad_scale) (:276-278,
  * :374-377): loss (may be NULL) = w * f(pred - target), grad (may be NULL) = grad_scale * w * f'(pred - target);
@@ -379,20 +385,31 @@ int relnet_relation_attention_bwd_kc(const void* q, long q_ld, long q_bs, const 
                                      float* dq, float* dk, float* dvw, int B, int H, int N, int M, int Mpad, int Npad,
                                      float scale, int dtype, const int* key_count, void* stream);
 
-/* Weight gradient of a convolution / FullyConnected layer (the adjoint MXNet's autograd derives; no reference source):
- *   dw [Cout][Ktot] fp32 (row pitch dw_ld)  +=  row_scale[m]^2 * sum_p dy[p][m] * X[p][k]
- * dy [P][dy_cols] bf16 (pitch dy_ld; columns >= Cout are padding) and the activation x (bf16, channels contiguous, element
- * stride x_pix between pixels) are read as they lie in memory: LDS-transposed MFMA fragments (ds_read_b64_tr_b16), no
- * transposed copies; ks = 1 / stride = 1: X[p] = pixel (row) p, Ktot = Cin; otherwise x is [B][Hin][Win] pixels and
+/* Weight gradients of convolution / FullyConnected layers (the adjoint MXNet's autograd derives; no reference source), n
+ * layers per launch:          dw_i [Cout][Ktot] fp32 (row pitch dw_ld)  +=  row_scale_i[m]^2 * sum_p dy_i[p][m] * X_i[p][k]
+ * dy [P][dy_cols] bf16 (pitch dy_ld; columns >= Cout are zero padding) and the activation x (bf16, channels contiguous,
+ * element stride x_pix between pixels) are read as they lie in memory: LDS-transposed MFMA fragments (ds_read_b64_tr_b16),
+ * no transposed copies; ks = 1 / stride = 1: X[p] = pixel (row) p, Ktot = Cin; otherwise x is [B][Hin][Win] pixels and
  * column k = tap (k / Cin) of channel k % Cin in pack_conv_weight order, gathered on the fly (zero outside the image).
- * Split over the pixels; partial tiles are combined with hardware float atomics, so dw must be initialised (zero or a
- * running sum) and the summation order is not fixed.  row_scale (may be NULL): the folded BatchNorm factor per output row. */
-int relnet_wgrad(const void* dy, long dy_ld, int dy_cols, const void* x, long x_pix, float* dw, long dw_ld,
-                 const float* row_scale, int P, int Cout, int Cin, int ks, int stride, int dil, int pad, int B, int Hout,
-                 int Wout, int Hin, int Win, void* stream);
-/* Test aids: relnet_wgrad_debug_plain(1) makes relnet_wgrad assemble its fragments with scalar LDS reads;
+ * The (layer, 256 x 256 tile, 64-pixel slab) units of ALL n layers are dealt in equal contiguous shares to one persistent
+ * workgroup per CU (stream-K): tiles cut by a share boundary are combined with hardware float atomics, so dw must be
+ * initialised (zero or a running sum) and the summation order is not fixed.  row_scale (may be NULL): the folded BatchNorm
+ * factor per output row.  descs: HOST array; table_workspace: relnet_wgrad_workspace_bytes(n) bytes of device memory the
+ * launch owns until it has run (filled by small kernels on the stream: no host copy, capture safe).                     */
+typedef struct relnet_wgrad_desc {
+  const void* dy; long dy_ld; int dy_cols;
+  const void* x; long x_pix;
+  float* dw; long dw_ld;
+  const float* row_scale;
+  int P, Cout, Cin, ks, stride, dil, pad, B, Hout, Wout, Hin, Win;
+} relnet_wgrad_desc;
+long relnet_wgrad_workspace_bytes(int n);
+int relnet_wgrad_grouped(const relnet_wgrad_desc* descs, int n, void* table_workspace, void* stream);
+/* Test / measurement aids: relnet_wgrad_debug_plain(1) assembles the MFMA fragments with scalar LDS reads;
+ * relnet_wgrad_tune(workgroups (0 = one per CU), ablation bits (1 no flush, 4 no loads), wave rows (0 = by shape));
  * relnet_debug_tr_probe dumps what ds_read_b64_tr_b16 returns for lane-linear addresses (256 values).                 */
 void relnet_wgrad_debug_plain(int on);
+void relnet_wgrad_tune(int workgroups, int mode, int wave_rows);
 int relnet_debug_tr_probe(unsigned short* out256, void* stream);
 
 /* d pair_pos_fc1_{weight [16][64], bias [16]} += from dlog and the forward's fp32 bias (= log max(G,1e-6)):

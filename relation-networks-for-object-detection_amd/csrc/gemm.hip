@@ -1476,6 +1476,17 @@ static int pick_tile(long M, long N, long K, int batch, int out_dtype, int has_r
   // res4 expand convolutions (256 -> 1024 + shortcut, 23 per step): with the weights also available in fragment order the
   // panel kernel reads A once and never stages W in LDS: 219 -> 191..203 us (r02 tile table; every other shape is slower)
   if (cfg == 1 && has_resid && has_wf && K == 256 && batch == 1) cfg = 14;
+  // small problems (1 - 8 images per launch: the reference's BATCH_IMAGES = 1 protocol, the training step): a 256 x 256 grid
+  // of < 128 workgroups leaves half of the 256 CUs idle.  Measured per shape with tools/bench_tiles.py (r03): at 8 images
+  // res4 3x3 / reduce 73.5 / 38.9 us (75 workgroups of 256 x 256) -> 50.7 / 26.4 us on 128 x 64 tiles (600 workgroups);
+  // at 1 image 64 x 64 tiles win on every N >= 256 layer (res4 3x3 31.3 -> 21.6 us, rpn 3x3 120 -> 101 us): per-step
+  // convolution totals 5.60 -> 4.6 ms (8 images), 2.14 -> 1.7 ms (1 image).
+  auto wgs = [&](long bm, long bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long)batch; };
+  const int small = wgs(128, 64) >= 200 ? 4 : 5;
+  if ((cfg == 1 || cfg == 8) && wgs(256, 256) < 128) cfg = small;
+  else if (cfg == 2 && wgs(256, 128) < 128) cfg = small;
+  else if (cfg == 3 && wgs(128, 128) < 200) cfg = small;
+  else if (cfg == 4 && N > 64 && wgs(128, 64) < 200) cfg = 5;
   return cfg;
 }
 extern "C" int relnet_gemm_tile_count(void) { return GEMM_TILE_COUNT; }

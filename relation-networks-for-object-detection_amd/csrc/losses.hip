@@ -21,29 +21,39 @@ struct SoftmaxOutArgs {
   const float* label;     // [outer, inner] class index as float (MXNet labels are float32)
   float* prob;            // same layout as data
   float* grad;            // same layout as data, or nullptr
-  int* valid_count;       // device scalar (scratch): number of labels != ignore_label
+  int* valid_count;       // device scratch [groups]: number of labels != ignore_label per normalisation group
   long outer, inner;
+  long group;             // positions (outer * inner index) per normalisation group: 'valid' normalises per IMAGE in the
+                          // reference (one image per executor); a batched call passes the positions of one image
   int C, use_ignore;
   float ignore_label, grad_scale;
 };
 
 __global__ __launch_bounds__(256) void softmax_count_kernel(SoftmaxOutArgs g) {
   const long total = g.outer * g.inner;
-  int local = 0;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256)
-    local += (!g.use_ignore || g.label[idx] != g.ignore_label) ? 1 : 0;
+  // whole wavefronts walk the positions (an index past `total` only skips its own contribution)
+  for (long base = (long)blockIdx.x * 256 + (threadIdx.x & ~63); base < total; base += (long)gridDim.x * 256) {
+    const long idx = base + (threadIdx.x & 63);
+    const bool in = idx < total;
+    int local = (in && (!g.use_ignore || g.label[idx] != g.ignore_label)) ? 1 : 0;
+    const long grp = (in ? idx : total - 1) / g.group;
+    const long g0 = __shfl(grp, 0);
+    if (__all(grp == g0)) {                       // the usual case: one normalisation group per wavefront -> one atomic
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
-  if ((threadIdx.x & 63) == 0 && local) atomicAdd(g.valid_count, local);
+      for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+      if ((threadIdx.x & 63) == 0 && local) atomicAdd(g.valid_count + g0, local);
+    } else if (local) {
+      atomicAdd(g.valid_count + grp, 1);
+    }
+  }
 }
 
 // one thread per (outer, inner) position; C <= a few hundred
 __global__ __launch_bounds__(256) void softmax_output_kernel(SoftmaxOutArgs g) {
   const long total = g.outer * g.inner;
-  const int cnt = g.grad ? max(*g.valid_count, 1) : 1;
-  const float gs = g.grad_scale / (float)cnt;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const long o = idx / g.inner, i = idx % g.inner;
+    const float gs = g.grad ? g.grad_scale / (float)max(g.valid_count[idx / g.group], 1) : 0.f;
     const float* x = g.data + o * g.C * g.inner + i;
     float m = x[0];
     for (int c = 1; c < g.C; ++c) m = fmaxf(m, x[(long)c * g.inner]);
@@ -108,20 +118,30 @@ static inline unsigned grid1d(long n) {
 
 using namespace relnet;
 
-extern "C" int relnet_softmax_output(const float* data, const float* label, float* prob, float* grad,
-                                     int* valid_count_scratch, long outer, int C, long inner, int use_ignore,
-                                     float ignore_label, float grad_scale, void* stream) {
+extern "C" int relnet_softmax_output_ex(const float* data, const float* label, float* prob, float* grad,
+                                        int* valid_count_scratch, long outer, int C, long inner, int use_ignore,
+                                        float ignore_label, float grad_scale, long group_positions, void* stream) {
   RELNET_REQUIRE(data && prob, "relnet_softmax_output: null operand");
   RELNET_REQUIRE(outer > 0 && C > 0 && inner > 0, "relnet_softmax_output: bad shape");
   RELNET_REQUIRE(!grad || (label && valid_count_scratch), "relnet_softmax_output: the gradient needs label and the count scratch");
-  SoftmaxOutArgs g{data, label, prob, grad, valid_count_scratch, outer, inner, C, use_ignore, ignore_label, grad_scale};
+  const long total = outer * inner;
+  if (group_positions <= 0) group_positions = total;
+  RELNET_REQUIRE(total % group_positions == 0, "relnet_softmax_output: %ld positions do not split into groups of %ld", total, group_positions);
+  SoftmaxOutArgs g{data, label, prob, grad, valid_count_scratch, outer, inner, group_positions, C, use_ignore, ignore_label, grad_scale};
   hipStream_t s = (hipStream_t)stream;
   if (grad) {
-    if (hipMemsetAsync(valid_count_scratch, 0, sizeof(int), s) != hipSuccess) { set_error("relnet_softmax_output: memset failed"); return -2; }
+    if (hipMemsetAsync(valid_count_scratch, 0, sizeof(int) * (size_t)(total / group_positions), s) != hipSuccess) { set_error("relnet_softmax_output: memset failed"); return -2; }
     softmax_count_kernel<<<grid1d(outer * inner), 256, 0, s>>>(g);
   }
   softmax_output_kernel<<<grid1d(outer * inner), 256, 0, s>>>(g);
   return check_launch("relnet_softmax_output");
+}
+
+extern "C" int relnet_softmax_output(const float* data, const float* label, float* prob, float* grad,
+                                     int* valid_count_scratch, long outer, int C, long inner, int use_ignore,
+                                     float ignore_label, float grad_scale, void* stream) {
+  return relnet_softmax_output_ex(data, label, prob, grad, valid_count_scratch, outer, C, inner, use_ignore, ignore_label,
+                                  grad_scale, 0, stream);
 }
 
 extern "C" int relnet_smooth_l1_loss(const float* pred, const float* target, const float* weight, float* loss,

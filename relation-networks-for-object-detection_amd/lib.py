@@ -64,6 +64,7 @@ _SIGNATURES = {
     'relnet_fpn_roi_dispatch_ex': (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     'relnet_upsample2x_add': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'relnet_softmax_output': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _i, _l, _i, _f, _f, _vp]),
+    'relnet_softmax_output_ex': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _i, _l, _i, _f, _f, _l, _vp]),
     'relnet_smooth_l1_loss': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _vp]),
     'relnet_nms_loss': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _vp]),
     'relnet_transpose_2d': (C.c_int, [_vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _vp]),
@@ -80,8 +81,10 @@ _SIGNATURES = {
     'relnet_deformable_psroi_pool_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_f, _f, _i, _i, _i, _vp]),
     'relnet_roi_pool_fpn_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_wgrad_accumulate': (C.c_int, [_vp, _i, _l, _i, _vp, _vp, _vp]),
-    'relnet_wgrad': (C.c_int, [_vp, _l, _i, _vp, _l, _vp, _l, _vp] + [_i] * 12 + [_vp]),
+    'relnet_wgrad_grouped': (C.c_int, [_vp, _i, _vp, _vp]),
+    'relnet_wgrad_workspace_bytes': (C.c_long, [_i]),
     'relnet_wgrad_debug_plain': (None, [_i]),
+    'relnet_wgrad_tune': (None, [_i, _i, _i]),
     'relnet_debug_tr_probe': (C.c_int, [_vp, _vp]),
     'relnet_gemm_force_tile': (None, [_i]),
     'relnet_gemm_force_nloop': (None, [_i]),
@@ -106,6 +109,13 @@ _SIGNATURES = {
     'relnet_box_annotator_ohem': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'relnet_nms_multi_target': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
 }
+
+
+class WgradDesc(C.Structure):
+    """`relnet_wgrad_desc` of include/relnet_hip.h (one layer of a grouped weight-gradient launch)."""
+    _fields_ = [('dy', C.c_void_p), ('dy_ld', C.c_long), ('dy_cols', C.c_int), ('x', C.c_void_p), ('x_pix', C.c_long),
+                ('dw', C.c_void_p), ('dw_ld', C.c_long), ('row_scale', C.c_void_p)] + \
+               [(n, C.c_int) for n in ('P', 'Cout', 'Cin', 'ks', 'stride', 'dil', 'pad', 'B', 'Hout', 'Wout', 'Hin', 'Win')]
 
 
 def load():

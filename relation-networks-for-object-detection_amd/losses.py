@@ -15,9 +15,11 @@ from .ops import _chk, _ptr, _stream
 
 
 def softmax_output(data, label=None, multi_output=False, use_ignore=False, ignore_label=-1.0, grad_scale=1.0,
-                   normalization='valid', want_grad=True):
+                   normalization='valid', want_grad=True, group=None):
     """data [n, C] (or [B, C, ...] with multi_output: softmax over axis 1); label [n] / [B, ...] float class ids.
-    Returns (prob, grad) with grad = d(sum of cross entropies)/d(data) normalised like MXNet ('valid')."""
+    Returns (prob, grad) with grad = d(sum of cross entropies)/d(data) normalised like MXNet ('valid').
+    group: positions per normalisation group (default: the whole call).  The reference runs one image per executor, so its
+    'valid' count is per image: a batched call passes the positions of one image (rois per image, or A*h*w anchors)."""
     _chk(data, label)
     if normalization != 'valid':
         raise NotImplementedError("only normalization='valid' (the reference's setting) is built")
@@ -34,9 +36,11 @@ def softmax_output(data, label=None, multi_output=False, use_ignore=False, ignor
             raise ValueError("label has %d entries, expected %d" % (label.numel(), outer * inner))
     prob = torch.empty_like(data)
     grad = torch.empty_like(data) if want_grad else None
-    cnt = torch.empty(1, device=data.device, dtype=torch.int32) if want_grad else None
-    _lib.call('relnet_softmax_output', data.data_ptr(), _ptr(label), prob.data_ptr(), _ptr(grad), _ptr(cnt), outer, Cn,
-              inner, int(use_ignore), float(ignore_label), float(grad_scale), _stream())
+    total = outer * inner
+    group = total if not group else int(group)
+    cnt = torch.empty(total // group, device=data.device, dtype=torch.int32) if want_grad else None
+    _lib.call('relnet_softmax_output_ex', data.data_ptr(), _ptr(label), prob.data_ptr(), _ptr(grad), _ptr(cnt), outer, Cn,
+              inner, int(use_ignore), float(ignore_label), float(grad_scale), group, _stream())
     return prob, grad
 
 

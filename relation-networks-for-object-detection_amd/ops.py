@@ -788,39 +788,72 @@ def transpose_2d(x, out=None, pad_cols_to=1):
     return out
 
 
+class WgradQueue(object):
+    """Weight-gradient products collected for ONE grouped launch (csrc/wgrad.hip: stream-K over the (layer, tile, slab) units
+    of all queued layers).  `add` has the signature of `wgrad_tn`; `flush` launches what is queued.  The queue keeps the
+    operand tensors alive until the launch has been issued (stream order does the rest)."""
+
+    def __init__(self):
+        self.items, self.keep = [], []
+
+    def add(self, dy2d, x, out, row_scale=None, cout=None, conv=None):
+        _chk(dy2d, x, out, row_scale)
+        assert dy2d.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy2d.dim() == 2 and dy2d.stride(1) == 1
+        P = dy2d.shape[0]
+        cout = dy2d.shape[1] if cout is None else cout
+        if conv is None:
+            assert x.dim() == 2 and x.shape[0] == P and x.stride(1) == 1
+            cin, ks, stride, dil, pad = x.shape[1], 1, 1, 1, 0
+            B = Ho = Wo = Hin = Win = 1
+            x_pix = x.stride(0)
+        else:
+            ks, stride, dil, pad = conv
+            B, Hin, Win, cin = x.shape
+            assert x.stride(3) == 1 and x.stride(1) == Win * x.stride(2) and x.stride(0) == Hin * x.stride(1)
+            Ho = (Hin + 2 * pad - dil * (ks - 1) - 1) // stride + 1
+            Wo = (Win + 2 * pad - dil * (ks - 1) - 1) // stride + 1
+            assert B * Ho * Wo == P, (x.shape, conv, P)
+            x_pix = x.stride(2)
+        K = ks * ks * cin
+        assert out.dtype == torch.float32 and tuple(out.shape) == (cout, K) and out.stride(1) == 1
+        if row_scale is not None:
+            assert row_scale.dtype == torch.float32 and row_scale.numel() == cout and row_scale.is_contiguous()
+        d = _lib.WgradDesc(dy2d.data_ptr(), dy2d.stride(0), dy2d.shape[1], x.data_ptr(), x_pix, out.data_ptr(), out.stride(0),
+                           _ptr(row_scale) or None, P, cout, cin, ks, stride, dil, pad, B, Ho, Wo, Hin, Win)
+        self.items.append(d)
+        self.keep.append((dy2d, x, out, row_scale))
+
+    def __len__(self):
+        return len(self.items)
+
+    def flush(self):
+        n = len(self.items)
+        if n == 0:
+            return
+        arr = (_lib.WgradDesc * n)(*self.items)
+        lib = _lib.load()
+        ws = torch.empty(int(lib.relnet_wgrad_workspace_bytes(n)), device=self.keep[0][0].device, dtype=torch.uint8)
+        import ctypes
+        _lib.call('relnet_wgrad_grouped', ctypes.addressof(arr), n, ws.data_ptr(), _stream(), tag='n%d' % n)
+        self.items, self.keep = [], []
+        return ws          # the caller may hold on to it; stream order already protects it from reuse on this stream
+
+
 def wgrad_tn(dy2d, x, out=None, row_scale=None, cout=None, conv=None):
     """Weight gradient  out [Cout, K] fp32 += row_scale^2 * dy2d^T X  straight from the pixel-major operands (csrc/wgrad.hip:
-    LDS-transposed MFMA fragments, implicit im2col, split over the pixels with float atomics; no transposed copies).
+    LDS-transposed MFMA fragments, implicit im2col, stream-K over (tile, 64-pixel slab) units; no transposed copies).
     dy2d [P, >= Cout] bf16 (row stride a multiple of 8; columns >= cout must be zero padding).
     conv None: x [P, K] bf16 rows;  conv = (ksize, stride, dil, pad): x [B, Hin, Win, Cin] NHWC (any pixel stride) and
     dy2d the [B * Hout * Wout, Cout] gradient of that convolution's output, K = ksize^2 Cin in pack_conv_weight order.
-    out None: a fresh zero tensor is returned (otherwise accumulated into `out`, e.g. a view of the flat gradient buffer)."""
-    _chk(dy2d, x, out, row_scale)
-    assert dy2d.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy2d.dim() == 2 and dy2d.stride(1) == 1
-    P = dy2d.shape[0]
-    cout = dy2d.shape[1] if cout is None else cout
-    if conv is None:
-        assert x.dim() == 2 and x.shape[0] == P and x.stride(1) == 1
-        cin, ks, stride, dil, pad = x.shape[1], 1, 1, 1, 0
-        B = Ho = Wo = Hin = Win = 1
-        x_pix = x.stride(0)
-    else:
-        ks, stride, dil, pad = conv
-        B, Hin, Win, cin = x.shape
-        assert x.stride(3) == 1 and x.stride(1) == Win * x.stride(2) and x.stride(0) == Hin * x.stride(1)
-        Ho = (Hin + 2 * pad - dil * (ks - 1) - 1) // stride + 1
-        Wo = (Win + 2 * pad - dil * (ks - 1) - 1) // stride + 1
-        assert B * Ho * Wo == P, (x.shape, conv, P)
-        x_pix = x.stride(2)
-    K = ks * ks * cin
+    out None: a fresh zero tensor is returned (otherwise accumulated into `out`, e.g. a view of the flat gradient buffer).
+    One layer per launch; `WgradQueue` groups many layers into one."""
     if out is None:
-        out = torch.zeros((cout, K), device=dy2d.device, dtype=torch.float32)
-    assert out.dtype == torch.float32 and out.shape == (cout, K) and out.stride(1) == 1
-    if row_scale is not None:
-        assert row_scale.dtype == torch.float32 and row_scale.numel() == cout and row_scale.is_contiguous()
-    _lib.call('relnet_wgrad', dy2d.data_ptr(), dy2d.stride(0), dy2d.shape[1], x.data_ptr(), x_pix, out.data_ptr(), out.stride(0),
-              _ptr(row_scale), P, cout, cin, ks, stride, dil, pad, B, Ho, Wo, Hin, Win, _stream(),
-              tag='P%d_M%d_K%d_k%d' % (P, cout, K, ks))
+        cin = x.shape[-1]
+        k = 1 if conv is None else conv[0]
+        out = torch.zeros((dy2d.shape[1] if cout is None else cout, k * k * cin), device=dy2d.device, dtype=torch.float32)
+    q = WgradQueue()
+    q.add(dy2d, x, out, row_scale, cout, conv)
+    q.flush()
     return out
 
 

@@ -200,7 +200,14 @@ class Trainer(object):
         """(2-D fp32 view of `name`'s slice of the flat gradient buffer, folded-BatchNorm row factor | None): the target
         relnet_wgrad accumulates into (train_ops `wgrad_to` protocol)."""
         g = self.W.view(self.W.grad, name)
-        return g.view(g.shape[0], -1), scale_rows
+        if getattr(self, '_wq', None) is None:
+            self._wq = ops.WgradQueue()       # the products wait here for ONE grouped stream-K launch per gradient bucket
+        return g.view(g.shape[0], -1), scale_rows, self._wq
+
+    def _flush_wgrads(self):
+        """Launch the queued weight-gradient products (csrc/wgrad.hip, one grouped launch)."""
+        if getattr(self, '_wq', None) is not None:
+            self._wq.flush()
 
     def _add_bgrad(self, name, db):
         self.Bv.view(self.Bv.grad, name).add_(db.reshape(-1))
@@ -279,12 +286,11 @@ class Trainer(object):
             rpn_label, rpn_bbox_target, rpn_bbox_weight = self.rpn_targets(gt_boxes, num_gt, im_info, (h, wd_))
         # -- RPN losses (per image, like one image per device in the reference)
         score_nchw = rpn[..., :na2].permute(0, 3, 1, 2).contiguous()                                 # [B,2A,h,w]
-        d_score = torch.empty_like(score_nchw)
         out = {}
-        for b in range(B):
-            _, g = losses.softmax_output(score_nchw[b:b + 1].view(1, 2, -1), rpn_label[b:b + 1], multi_output=True,
-                                         use_ignore=True, ignore_label=-1.0)
-            d_score[b:b + 1] = g.view(1, na2, h, wd_)
+        # per-image 'valid' normalisation (one image per executor in the reference) in ONE launch: group = one image's anchors
+        _, d_score = losses.softmax_output(score_nchw.view(B, 2, -1), rpn_label, multi_output=True, use_ignore=True,
+                                           ignore_label=-1.0, group=(na2 // 2) * h * wd_)
+        d_score = d_score.view(B, na2, h, wd_)
         delta = rpn[..., na2:].contiguous()                                                          # NHWC [B,h,w,4A]
         tgt = rpn_bbox_target.permute(0, 2, 3, 1).contiguous()
         wgt = rpn_bbox_weight.permute(0, 2, 3, 1).contiguous()
@@ -416,10 +422,8 @@ class Trainer(object):
         nc = self.num_classes
         cls_score, bbox_pred = cb[:, :, :nc].contiguous(), cb[:, :, nc:].contiguous()
         labels_ohem, weights_ohem = ops.box_annotator_ohem(cls_score, bbox_pred, label, bbox_target, bbox_weight, c.batch_rois_ohem)
-        d_cls = torch.empty_like(cls_score)
-        for b in range(B):
-            _, g = losses.softmax_output(cls_score[b], labels_ohem[b], use_ignore=True, ignore_label=-1.0)
-            d_cls[b] = g
+        _, d_cls = losses.softmax_output(cls_score.view(B * R, -1), labels_ohem.reshape(-1), use_ignore=True, ignore_label=-1.0, group=R)
+        d_cls = d_cls.view(B, R, -1)
         l1, d_bbox = losses.smooth_l1_loss(bbox_pred, bbox_target, weights_ohem, 1.0, 1.0 / c.batch_rois_ohem)
         out['bbox_loss'] = l1.sum() / B
         out['num_ohem'] = (labels_ohem >= 0).sum()
@@ -649,6 +653,7 @@ class Trainer(object):
 
     def _bucket_ready(self, name):
         """Called by the backward pass when the last gradient of a bucket has been queued (no-op on one rank)."""
+        self._flush_wgrads()         # the bucket is complete only once its queued weight gradients have been launched
         bk = self._grad_buckets()
         idx = self._bucket_names.index(name)
         cut = getattr(self, '_capture_cut', None)

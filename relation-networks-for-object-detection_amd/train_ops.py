@@ -97,7 +97,7 @@ def linear_bwd(x2d, w, dy2d, need_dx=True, w_t=None, keep_splits=False, wgrad_to
         dx = ops.gemm_nt(dyp, w_t)
     db = dy2d.float().sum(0)
     if wgrad_to is not None and _tn_ok(dyp, x2d):
-        ops.wgrad_tn(dyp, x2d, out=wgrad_to[0], row_scale=wgrad_to[1], cout=N)
+        _wg_call(wgrad_to, dyp, x2d, cout=N)
         return dx, None, db
     dw = wgrad(dy2d, x2d, keep_splits)
     if wgrad_to is not None:
@@ -106,9 +106,18 @@ def linear_bwd(x2d, w, dy2d, need_dx=True, w_t=None, keep_splits=False, wgrad_to
     return dx, dw, db
 
 
+def _wg_call(wgrad_to, dy2d, x, cout=None, conv=None):
+    """wgrad_to = (grad view, row_scale | None[, ops.WgradQueue]): queue the product for the stage's grouped launch, or run it now."""
+    q = wgrad_to[2] if len(wgrad_to) > 2 else None
+    if q is not None:
+        q.add(dy2d, x, wgrad_to[0], wgrad_to[1], cout, conv)
+    else:
+        ops.wgrad_tn(dy2d, x, out=wgrad_to[0], row_scale=wgrad_to[1], cout=cout, conv=conv)
+
+
 def _accumulate(wgrad_to, dw):
     """Fallback of the `wgrad_to` protocol for operands relnet_wgrad does not take: split-K partial sums -> += into the view."""
-    g, scale = wgrad_to
+    g, scale = wgrad_to[0], wgrad_to[1]
     if dw.dim() == 3 and dw.is_contiguous() and dw.shape[1] * dw.shape[2] == g.numel() and g.shape[-1] % 4 == 0:
         wgrad_accumulate(dw, g, scale)
         return
@@ -153,9 +162,9 @@ def conv1x1_bwd(x, w_packed, dy, stride=1, need_dx=True, w_t=None, dx_add=None, 
             dx[:, ::stride, ::stride, :] = ops.gemm_nt(dyp, w_t).reshape(dy.shape[0], dy.shape[1], dy.shape[2], Cin)
     if tn:
         if stride == 1:
-            ops.wgrad_tn(dy2, x.reshape(P, Cin), out=wgrad_to[0], row_scale=wgrad_to[1])
+            _wg_call(wgrad_to, dy2, x.reshape(P, Cin))
         else:
-            ops.wgrad_tn(dy2, x, out=wgrad_to[0], row_scale=wgrad_to[1], conv=(1, stride, 1, 0))
+            _wg_call(wgrad_to, dy2, x, conv=(1, stride, 1, 0))
         return dx, None
     dw = wgrad(dy2, xs.reshape(P, Cin), keep_splits)
     if wgrad_to is not None:
@@ -178,7 +187,7 @@ def conv3x3_bwd(x, w_dgrad_packed, dy, dil=1, need_dx=True, keep_splits=False, w
         dx = ops.conv2d_nhwc(dy, w_dgrad_packed, None, ksize=3, stride=1, pad=dil, dil=dil)
     dy2 = dy.reshape(B * H * W, Cout)
     if wgrad_to is not None and _tn_ok(dy2, x) and x.is_contiguous():
-        ops.wgrad_tn(dy2, x, out=wgrad_to[0], row_scale=wgrad_to[1], cout=cout, conv=(3, 1, dil, dil))
+        _wg_call(wgrad_to, dy2, x, cout=cout, conv=(3, 1, dil, dil))
         return dx, None
     key = (B, H, W, x.device)
     if key not in _ZERO_OFF:

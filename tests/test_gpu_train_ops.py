@@ -170,3 +170,24 @@ def test_wgrad_tn_matches_float64(case):
         assert torch.equal(base[:, :8], base[:, :8]) and torch.isfinite(base).all()
     fresh = ops.wgrad_tn(dyb, xk, row_scale=scale, cout=want.shape[0], conv=conv)
     assert (fresh.double().cpu() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    # the same layer inside a grouped launch with two other layers (stream-K shares cut across layer boundaries), and with
+    # more / fewer persistent workgroups than work units
+    other = [(torch.randn(900, 64, generator=g).to(bf).cuda(), torch.randn(900, 96, generator=g).to(bf).cuda()),
+             (torch.randn(130, 320, generator=g).to(bf).cuda(), torch.randn(130, 264, generator=g).to(bf).cuda())]
+    for blocks in (0, 7, 1000):
+        L.load().relnet_wgrad_tune(blocks, 0, 0)
+        try:
+            q = ops.WgradQueue()
+            o0 = torch.zeros(64, 96, device='cuda'); o1 = torch.zeros(320, 264, device='cuda')
+            om = torch.zeros(want.shape, device='cuda')
+            q.add(other[0][0], other[0][1], o0)
+            q.add(dyb, xk, om, scale, want.shape[0], conv)
+            q.add(other[1][0], other[1][1], o1)
+            assert len(q) == 3
+            q.flush()
+        finally:
+            L.load().relnet_wgrad_tune(0, 0, 0)
+        assert (om.double().cpu() - want).abs().max().item() <= 2e-5 * want.abs().max().item(), (case, blocks)
+        for o, (dy_, x_) in ((o0, other[0]), (o1, other[1])):
+            w_ = dy_.double().t().cpu() @ x_.double().cpu()
+            assert (o.double().cpu() - w_).abs().max().item() <= 2e-5 * w_.abs().max().item(), (case, blocks)
