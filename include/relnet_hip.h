@@ -113,7 +113,7 @@ int relnet_stem_bias_relu_pool(const void* in, const float* bias, void* out, int
  * divisors8: HOST array, wave_length^(k/8) in fp32; bias [nmod,B,16,N,Mpad] fp32.
  * pos_mat [B,N,M,4] / pos_emb [B,N,M,64]: optional debug outputs (NULL to skip).                   */
 int relnet_geometry_bias(const float* boxes, int box_stride, int box_off, const float* wp_t, const float* bp,
-                         const float* divisors8, void* bias, int bias_half /* 0: float32 log G in the oracle's arithmetic (sin / cos / log correctly rounded, float64 accumulation: the parity path); 1: fp16 log2 G (bf16 throughput path, matrix cores); -1: float32 log G with float32 libm arithmetic (training recompute) */, float* pos_mat,
+                         const float* divisors8, void* bias, int bias_half /* 0: float32 log G in the oracle's arithmetic (sin / cos / log correctly rounded, float64 accumulation: the parity path); 1: fp16 log2 G (bf16 throughput path, matrix cores); 2: float32 ln G from the same matrix-core kernel (training backward: the G the forward saw); -1: float32 log G with float32 libm arithmetic */, float* pos_mat,
                          float* pos_emb, int B, int N, int M, int Mpad, int fc_dim, int nmod, void* stream);
 
 /* ---- SYM_REL:132-150: logits = bias + scale * Q K^T (`weighted_aff`), softmax over keys, value sum

@@ -40,6 +40,10 @@ template <typename TOUT> __device__ __forceinline__ float load_out(const TOUT* p
 template <> __device__ __forceinline__ float load_out<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float load_out<unsigned short>(const unsigned short* p) { return bf2f(*p); }
 
+// The residual operand of an epilogue: relu == 2 turns it into a ReLU MASK (backward of a fused conv + ReLU: the data gradient
+// is zeroed where the saved forward activation is not positive) instead of a summand.
+__device__ __forceinline__ float res_apply(float v, float r, int relu) { return relu == 2 ? (r > 0.f ? v : 0.f) : v + r; }
+
 template <typename TOUT>
 __device__ __forceinline__ void epilogue_tile(const GemmArgs& g, TOUT* C, const TOUT* R,
                                               const f32x16& acc, int row0, int col0, int lane) {
@@ -52,8 +56,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& g, TOUT* C, const 
     if (row < g.M) {
       float v = acc[r] + bcol;
       if (g.bias_mode == 2) v += g.bias[row];
-      if (R) v += load_out<TOUT>(R + (long)row * g.ldc + col);
-      if (g.relu) v = fmaxf(v, 0.f);
+      if (R) v = res_apply(v, load_out<TOUT>(R + (long)row * g.ldc + col), g.relu);
+      if (g.relu == 1) v = fmaxf(v, 0.f);
       store_out<TOUT>(C + (long)row * g.ldc + col, v);
     }
   }
@@ -87,16 +91,16 @@ __device__ __forceinline__ void epilogue_tile_t(const GemmArgs& g, TOUT* C, cons
       if constexpr (sizeof(TOUT) == 2) {
         if (rp) {
           const uint2 rv = *(const uint2*)rp;
-          v[0] += bf2f(rv.x & 0xffff); v[1] += bf2f(rv.x >> 16); v[2] += bf2f(rv.y & 0xffff); v[3] += bf2f(rv.y >> 16);
+          v[0] = res_apply(v[0], bf2f(rv.x & 0xffff), g.relu); v[1] = res_apply(v[1], bf2f(rv.x >> 16), g.relu); v[2] = res_apply(v[2], bf2f(rv.y & 0xffff), g.relu); v[3] = res_apply(v[3], bf2f(rv.y >> 16), g.relu);
         }
-        if (g.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (g.relu == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         *(uint2*)cp = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
       } else {
         if (rp) {
           const float4 rv = *(const float4*)rp;
-          v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+          v[0] = res_apply(v[0], rv.x, g.relu); v[1] = res_apply(v[1], rv.y, g.relu); v[2] = res_apply(v[2], rv.z, g.relu); v[3] = res_apply(v[3], rv.w, g.relu);
         }
-        if (g.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (g.relu == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
       }
     } else {
@@ -105,8 +109,8 @@ __device__ __forceinline__ void epilogue_tile_t(const GemmArgs& g, TOUT* C, cons
         if (n + e < g.N) {
           float x = v[e];
           if (g.bias_mode == 1) x += g.bias[n + e];
-          if (rp) x += load_out<TOUT>(rp + e);
-          if (g.relu) x = fmaxf(x, 0.f);
+          if (rp) x = res_apply(x, load_out<TOUT>(rp + e), g.relu);
+          if (g.relu == 1) x = fmaxf(x, 0.f);
           store_out<TOUT>(cp + e, x);
         }
       }
@@ -341,19 +345,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
           if (R) {
             const unsigned int rw[4] = {rpre[i][p].x, rpre[i][p].y, rpre[i][p].z, rpre[i][p].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f(rw[e] & 0xffff); v[2 * e + 1] += bf2f(rw[e] >> 16); }
+            for (int e = 0; e < 4; ++e) { v[2 * e] = res_apply(v[2 * e], bf2f(rw[e] & 0xffff), g.relu); v[2 * e + 1] = res_apply(v[2 * e + 1], bf2f(rw[e] >> 16), g.relu); }
           }
-          if (g.relu) {
+          if (g.relu == 1) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
           }
           *(uint4*)cp = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
         } else {
           if (R) {
-            v[0] += __uint_as_float(rpre[i][p].x); v[1] += __uint_as_float(rpre[i][p].y);
-            v[2] += __uint_as_float(rpre[i][p].z); v[3] += __uint_as_float(rpre[i][p].w);
+            v[0] = res_apply(v[0], __uint_as_float(rpre[i][p].x), g.relu); v[1] = res_apply(v[1], __uint_as_float(rpre[i][p].y), g.relu);
+            v[2] = res_apply(v[2], __uint_as_float(rpre[i][p].z), g.relu); v[3] = res_apply(v[3], __uint_as_float(rpre[i][p].w), g.relu);
           }
-          if (g.relu) {
+          if (g.relu == 1) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
           }
@@ -365,8 +369,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
         for (int e = 0; e < VEC; ++e) {
           if (n + e < g.N) {
             float x = v[e];
-            if (rp) x += load_out<TOUT>(rp + e);
-            if (g.relu) x = fmaxf(x, 0.f);
+            if (rp) x = res_apply(x, load_out<TOUT>(rp + e), g.relu);
+            if (g.relu == 1) x = fmaxf(x, 0.f);
             store_out<TOUT>(cp + e, x);
           }
         }
@@ -725,9 +729,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
               if constexpr (RDIR) if (R) {
                 const unsigned int rw[4] = {rdir[i][j][p].x, rdir[i][j][p].y, rdir[i][j][p].z, rdir[i][j][p].w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f(rw[e] & 0xffff); v[2 * e + 1] += bf2f(rw[e] >> 16); }
+                for (int e = 0; e < 4; ++e) { v[2 * e] = res_apply(v[2 * e], bf2f(rw[e] & 0xffff), g.relu); v[2 * e + 1] = res_apply(v[2 * e + 1], bf2f(rw[e] >> 16), g.relu); }
               }
-              if (g.relu) {
+              if (g.relu == 1) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
               }
@@ -739,8 +743,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
               for (int e = 0; e < 8; ++e) {
                 if (c + e < g.N) {
                   float x = v[e] + brow + (g.bias_mode == 1 ? g.bias[c + e] : 0.f);
-                  if (rp) x += load_out<TOUT>(rp + e);
-                  if (g.relu) x = fmaxf(x, 0.f);
+                  if (rp) x = res_apply(x, load_out<TOUT>(rp + e), g.relu);
+                  if (g.relu == 1) x = fmaxf(x, 0.f);
                   store_out<TOUT>(cp + e, x);
                 }
               }
@@ -760,16 +764,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
             for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e] + brow;
             if (vec_ok && c + 4 <= g.N) {
               if (g.bias_mode == 1) { const float4 b0 = *(const float4*)(g.bias + c); v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; }
-              if (rp) { const float4 r0 = *(const float4*)rp; v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; }
-              if (g.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+              if (rp) { const float4 r0 = *(const float4*)rp; v[0] = res_apply(v[0], r0.x, g.relu); v[1] = res_apply(v[1], r0.y, g.relu); v[2] = res_apply(v[2], r0.z, g.relu); v[3] = res_apply(v[3], r0.w, g.relu); }
+              if (g.relu == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
               *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
             } else {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 if (c + e < g.N) {
                   float x = v[e] + (g.bias_mode == 1 ? g.bias[c + e] : 0.f);
-                  if (rp) x += load_out<TOUT>(rp + e);
-                  if (g.relu) x = fmaxf(x, 0.f);
+                  if (rp) x = res_apply(x, load_out<TOUT>(rp + e), g.relu);
+                  if (g.relu == 1) x = fmaxf(x, 0.f);
                   store_out<TOUT>(cp + e, x);
                 }
               }
@@ -818,9 +822,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
           if constexpr (RESID) if (R) {
             const unsigned int rw[4] = {rpre[i][p].x, rpre[i][p].y, rpre[i][p].z, rpre[i][p].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f(rw[e] & 0xffff); v[2 * e + 1] += bf2f(rw[e] >> 16); }
+            for (int e = 0; e < 4; ++e) { v[2 * e] = res_apply(v[2 * e], bf2f(rw[e] & 0xffff), g.relu); v[2 * e + 1] = res_apply(v[2 * e + 1], bf2f(rw[e] >> 16), g.relu); }
           }
-          if (g.relu) {
+          if (g.relu == 1) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
           }
@@ -828,10 +832,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
           else *(uint4*)cp = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
         } else {
           if constexpr (RESID) if (R) {
-            v[0] += __uint_as_float(rpre[i][p].x); v[1] += __uint_as_float(rpre[i][p].y);
-            v[2] += __uint_as_float(rpre[i][p].z); v[3] += __uint_as_float(rpre[i][p].w);
+            v[0] = res_apply(v[0], __uint_as_float(rpre[i][p].x), g.relu); v[1] = res_apply(v[1], __uint_as_float(rpre[i][p].y), g.relu);
+            v[2] = res_apply(v[2], __uint_as_float(rpre[i][p].z), g.relu); v[3] = res_apply(v[3], __uint_as_float(rpre[i][p].w), g.relu);
           }
-          if (g.relu) {
+          if (g.relu == 1) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
           }
@@ -843,8 +847,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
         for (int e = 0; e < VEC; ++e) {
           if (n + e < g.N) {
             float x = v[e];
-            if (rp) x += load_out<TOUT>(rp + e);
-            if (g.relu) x = fmaxf(x, 0.f);
+            if (rp) x = res_apply(x, load_out<TOUT>(rp + e), g.relu);
+            if (g.relu == 1) x = fmaxf(x, 0.f);
             store_out<TOUT>(cp + e, x);
           }
         }
@@ -1028,9 +1032,9 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(GemmArgs g) {
           if constexpr (RESID) if (R) {
             const unsigned int rw[4] = {rcur[p][sw].x, rcur[p][sw].y, rcur[p][sw].z, rcur[p][sw].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f(rw[e] & 0xffff); v[2 * e + 1] += bf2f(rw[e] >> 16); }
+            for (int e = 0; e < 4; ++e) { v[2 * e] = res_apply(v[2 * e], bf2f(rw[e] & 0xffff), g.relu); v[2 * e + 1] = res_apply(v[2 * e + 1], bf2f(rw[e] >> 16), g.relu); }
           }
-          if (g.relu) {
+          if (g.relu == 1) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
           }
@@ -1040,8 +1044,8 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(GemmArgs g) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float x = v[e];
-            if (rp) x += bf2f(rp[e]);
-            if (g.relu) x = fmaxf(x, 0.f);
+            if (rp) x = res_apply(x, bf2f(rp[e]), g.relu);
+            if (g.relu == 1) x = fmaxf(x, 0.f);
             cp[e] = f2bf(x);
           }
         }
@@ -1187,9 +1191,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_panelw_kernel(GemmArgs g) {
           if constexpr (RESID) if (R) {
             const unsigned int rw[4] = {rcur[i][sw].x, rcur[i][sw].y, rcur[i][sw].z, rcur[i][sw].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f(rw[e] & 0xffff); v[2 * e + 1] += bf2f(rw[e] >> 16); }
+            for (int e = 0; e < 4; ++e) { v[2 * e] = res_apply(v[2 * e], bf2f(rw[e] & 0xffff), g.relu); v[2 * e + 1] = res_apply(v[2 * e + 1], bf2f(rw[e] >> 16), g.relu); }
           }
-          if (g.relu) {
+          if (g.relu == 1) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
           }
@@ -1199,8 +1203,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void gemm_panelw_kernel(GemmArgs g) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float x = v[e];
-            if (rp) x += bf2f(rp[e]);
-            if (g.relu) x = fmaxf(x, 0.f);
+            if (rp) x = res_apply(x, bf2f(rp[e]), g.relu);
+            if (g.relu == 1) x = fmaxf(x, 0.f);
             cp[e] = f2bf(x);
           }
         }

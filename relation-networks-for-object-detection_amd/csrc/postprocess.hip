@@ -78,6 +78,10 @@ struct ClsNmsArgs {
   int* pick_index;           // optional [B, C-1, N]: roi index of every pick (`keep` of nms.py:45-82)
 };
 
+// "absent / already picked / suppressed" marker of a candidate's score.  -inf, not -1: the lib/nms/nms.py twins accept any
+// float64 dets[:, 4] (raw logits, negative scores), which must stay distinguishable from removed slots.
+#define kGone (-INFINITY)
+
 // kPerLane * 64 >= N candidates per (image, class)
 template <int kPerLane>
 __global__ __launch_bounds__(64) void class_nms_kernel(ClsNmsArgs g) {
@@ -85,12 +89,12 @@ __global__ __launch_bounds__(64) void class_nms_kernel(ClsNmsArgs g) {
   const float* prob = g.cls_prob + (long)b * g.N * g.C;
   const double* bx = g.boxes + (long)b * g.N * 4;
   double x1[kPerLane], y1[kPerLane], x2[kPerLane], y2[kPerLane], area[kPerLane], sc[kPerLane];
-  // candidate slot s of lane l is roi index s*64 + l; sc < 0 marks "absent/picked"
+  // candidate slot s of lane l is roi index s*64 + l; sc == kGone marks "absent/picked"
   int n = 0;
 #pragma unroll
   for (int s = 0; s < kPerLane; ++s) {
     const int i = s * 64 + lane;
-    sc[s] = -1.0;
+    sc[s] = kGone;
     x1[s] = y1[s] = x2[s] = y2[s] = area[s] = 0.0;
     if (i < g.N) {
       const double p = g.scores64 ? g.scores64[(long)b * g.N + i] : (double)prob[(long)i * g.C + cls];
@@ -109,17 +113,17 @@ __global__ __launch_bounds__(64) void class_nms_kernel(ClsNmsArgs g) {
   const int n_it = n < g.max_picks ? n : g.max_picks;
   for (int it = 0; it < n_it; ++it) {
     // arg-max over remaining; ties -> larger roi index (argsort()[::-1] convention)
-    double best = -1.0; int bi = -1;
+    double best = kGone; int bi = -1;
 #pragma unroll
     for (int s = 0; s < kPerLane; ++s)
-      if (sc[s] > best || (sc[s] == best && sc[s] >= 0.0)) { best = sc[s]; bi = s * 64 + lane; }
+      if (sc[s] > best || (sc[s] == best && sc[s] > kGone)) { best = sc[s]; bi = s * 64 + lane; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const double ob = __shfl_xor(best, o);
       const int oi = __shfl_xor(bi, o);
       if (ob > best || (ob == best && oi > bi)) { best = ob; bi = oi; }
     }
-    if (best < 0.0) break;                     // everything suppressed (hard NMS)
+    if (!(best > kGone)) break;                     // everything suppressed (hard NMS)
     const int bl = bi & 63, bs = bi >> 6;
     double px1 = 0, py1 = 0, px2 = 0, py2 = 0, pa = 0;
 #pragma unroll
@@ -134,15 +138,15 @@ __global__ __launch_bounds__(64) void class_nms_kernel(ClsNmsArgs g) {
     ++picked;
 #pragma unroll
     for (int s = 0; s < kPerLane; ++s) {
-      if (s * 64 + lane == bi) { sc[s] = -1.0; continue; }
-      if (sc[s] < 0.0) continue;
+      if (s * 64 + lane == bi) { sc[s] = kGone; continue; }
+      if (!(sc[s] > kGone)) continue;
       const double w = fmax(0.0, fmin(px2, x2[s]) - fmax(px1, x1[s]) + 1);
       const double h = fmax(0.0, fmin(py2, y2[s]) - fmax(py1, y1[s]) + 1);
       const double inter = w * h;
       if (inter > 0.0) {     // disjoint boxes: ovr = 0 -> weight exp(0) = 1 / never suppressed; skipping them is exact
         const double ovr = inter / (pa + area[s] - inter);
         if (g.soft) sc[s] = sc[s] * exp(-(ovr * ovr) / g.nms_param);     // nms.py:92
-        else if (!(ovr <= g.nms_param)) sc[s] = -1.0;                     // nms.py:79
+        else if (!(ovr <= g.nms_param)) sc[s] = kGone;                     // nms.py:79
       }
     }
   }
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256) void class_nms_block_kernel(ClsNmsArgs g) {
 #pragma unroll
   for (int s = 0; s < kPerThread; ++s) {
     const int i = s * NT + tid;
-    sc[s] = -1.0;
+    sc[s] = kGone;
     x1[s] = y1[s] = x2[s] = y2[s] = area[s] = 0.0;
     if (i < g.N) {
       const double p = g.scores64 ? g.scores64[(long)b * g.N + i] : (double)prob[(long)i * g.C + cls];
@@ -190,10 +194,10 @@ __global__ __launch_bounds__(256) void class_nms_block_kernel(ClsNmsArgs g) {
   int picked = 0;
   const int n_it = n < g.max_picks ? n : g.max_picks;
   for (int it = 0; it < n_it; ++it) {
-    double best = -1.0; int bi = -1;
+    double best = kGone; int bi = -1;
 #pragma unroll
     for (int s = 0; s < kPerThread; ++s)
-      if (sc[s] > best || (sc[s] == best && sc[s] >= 0.0)) { best = sc[s]; bi = s * NT + tid; }
+      if (sc[s] > best || (sc[s] == best && sc[s] > kGone)) { best = sc[s]; bi = s * NT + tid; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const double ob = __shfl_xor(best, o);
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(256) void class_nms_block_kernel(ClsNmsArgs g) {
       const double ob = s_best[w]; const int oi = s_bi[w];
       if (ob > best || (ob == best && oi > bi)) { best = ob; bi = oi; }
     }
-    if (best < 0.0) break;                     // uniform: every thread read the same LDS values
+    if (!(best > kGone)) break;                     // uniform: every thread read the same LDS values
     if (tid == (bi % NT)) {
       const int bs = bi / NT;
 #pragma unroll
@@ -225,15 +229,15 @@ __global__ __launch_bounds__(256) void class_nms_block_kernel(ClsNmsArgs g) {
     ++picked;
 #pragma unroll
     for (int s = 0; s < kPerThread; ++s) {
-      if (s * NT + tid == bi) { sc[s] = -1.0; continue; }
-      if (sc[s] < 0.0) continue;
+      if (s * NT + tid == bi) { sc[s] = kGone; continue; }
+      if (!(sc[s] > kGone)) continue;
       const double w = fmax(0.0, fmin(px2, x2[s]) - fmax(px1, x1[s]) + 1);
       const double h = fmax(0.0, fmin(py2, y2[s]) - fmax(py1, y1[s]) + 1);
       const double inter = w * h;
       if (inter > 0.0) {
         const double ovr = inter / (pa + area[s] - inter);
         if (g.soft) sc[s] = sc[s] * exp(-(ovr * ovr) / g.nms_param);
-        else if (!(ovr <= g.nms_param)) sc[s] = -1.0;
+        else if (!(ovr <= g.nms_param)) sc[s] = kGone;
       }
     }
     __syncthreads();                           // s_best / s_box are rewritten in the next iteration

@@ -34,6 +34,7 @@ struct GeomArgs {
   float* pos_mat;          // optional [B, N, M, 4]
   float* pos_emb;          // optional [B, N, M, 64]
   int B, N, M, Mpad, nmod;
+  int out_f32;             // geometry_bias_mfma_kernel: store float32 ln(.) instead of fp16 log2(.) (training backward's recompute)
 };
 
 #pragma clang fp contract(off)
@@ -214,7 +215,9 @@ __global__ __launch_bounds__(256) void geometry_bias_mfma_kernel(GeomArgs g) {
       const int m = row >> 4, h = row & 15;
       const float v0 = __builtin_amdgcn_logf(fmaxf(acc[0][r], 1e-6f));        // relu, clamp (SYM_REL:116,139), log2
       const float v1 = __builtin_amdgcn_logf(fmaxf(acc[1][r], 1e-6f));
-      *(__half2*)(out + ((((long)m * g.B + b) * 16 + h) * g.N + i) * g.Mpad + j2) = __floats2half2_rn(v0, v1);
+      const long o = ((((long)m * g.B + b) * 16 + h) * g.N + i) * g.Mpad + j2;
+      if (g.out_f32) *(float2*)((float*)g.bias + o) = make_float2(v0 * 0.69314718055994530942f, v1 * 0.69314718055994530942f);
+      else *(__half2*)(out + o) = __floats2half2_rn(v0, v1);
     }
   }
 }
@@ -899,8 +902,10 @@ extern "C" int relnet_geometry_bias(const float* boxes, int box_stride, int box_
   hipStream_t s = (hipStream_t)stream;
   for (int k = 0; k < 8; ++k) g.c2[k] = (float)(0.69314718055994530942 * 100.0 / (6.283185307179586476925 * (double)divisors8[k]));
   const size_t key_lds = (size_t)((M + 63) / 64) * 64 * 16;
-  RELNET_REQUIRE(bias_half >= -1 && bias_half <= 1, "relnet_geometry_bias: bias_half %d (0: float32 exact, 1: fp16 log2, -1: float32 fast)", bias_half);
-  if (bias_half == 1 && !pos_mat && !pos_emb && key_lds <= 64 * 1024) {
+  RELNET_REQUIRE(bias_half >= -1 && bias_half <= 2, "relnet_geometry_bias: bias_half %d (0: float32 exact, 1: fp16 log2, 2: float32 ln from the matrix-core kernel, -1: float32 libm)", bias_half);
+  g.out_f32 = bias_half == 2 ? 1 : 0;
+  if (bias_half == 2 && (pos_mat || pos_emb || key_lds > 64 * 1024)) bias_half = -1;      // shapes the matrix-core kernel does not take
+  if ((bias_half == 1 || bias_half == 2) && !pos_mat && !pos_emb && key_lds <= 64 * 1024) {
     // throughput path: pair_pos_fc1 of all modules on the matrix cores, one wavefront per query
     dim3 g2((unsigned)((N + 3) / 4), B);
     geometry_bias_mfma_kernel<<<g2, 256, key_lds, s>>>(g);

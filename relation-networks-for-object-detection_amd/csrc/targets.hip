@@ -359,16 +359,24 @@ __global__ __launch_bounds__(256) void anchor_label_kernel(AnchorArgs g) {
 }
 
 // One workgroup per image.  which = 1: positives beyond num_fg, then which = 0: negatives beyond batch - #fg.
+// The `drop` smallest 64-bit (key, index) words are found by an 8-bit radix select (8 rounds of a 256-bin LDS histogram).
 __global__ __launch_bounds__(1024) void anchor_sample_kernel(AnchorArgs g) {
-  __shared__ int s_cnt[2];
+  __shared__ int s_hist[256];
   __shared__ int s_red[16];
+  __shared__ int s_pick[2];                          // chosen digit, remaining rank
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int total = g.A * g.fh * g.fw;
   float* lab = g.label + (long)b * total;
   const unsigned long long seed = g.seed + (g.seed_dev ? *g.seed_dev : 0ull);
-  auto block_count = [&](auto pred) -> int {       // number of positions with pred(pos) over the whole image
+  const int hw = g.fh * g.fw;
+  // position p (a, y, x order) <-> anchor index in (y, x, a) order, the index the keys are defined on
+  auto key_of = [&](int p) -> unsigned long long {
+    const int a = p / hw, k = p - a * hw, idx = k * g.A + a;
+    return ((unsigned long long)anchor_key(seed, b, idx) << 32) | (unsigned int)idx;
+  };
+  auto block_count = [&](float want) -> int {
     int c = 0;
-    for (int p = tid; p < total; p += 1024) c += pred(p) ? 1 : 0;
+    for (int p = tid; p < total; p += 1024) c += lab[p] == want ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
     __syncthreads();
@@ -378,43 +386,51 @@ __global__ __launch_bounds__(1024) void anchor_sample_kernel(AnchorArgs g) {
     for (int w = 0; w < 16; ++w) t += s_red[w];
     return t;
   };
-  // position p (a, y, x order) <-> anchor index in (y, x, a) order, the index the keys are defined on
-  auto key_of = [&](int p) -> unsigned long long {
-    const int hw = g.fh * g.fw, a = p / hw, k = p % hw, idx = k * g.A + a;
-    return ((unsigned long long)anchor_key(seed, b, idx) << 32) | (unsigned int)idx;
-  };
   for (int which = 1; which >= 0; --which) {
     const float want = (float)which;
-    const int n = block_count([&](int p) { return lab[p] == want; });
+    const int n = block_count(want);
     int keep = g.num_fg;
-    if (which == 0) keep = g.batch_size - block_count([&](int p) { return lab[p] == 1.f; });
+    if (which == 0) keep = g.batch_size - block_count(1.f);
     if (keep < 0) keep = 0;
     const int drop = n - keep;
-    if (drop > 0) {
-      // the `drop` smallest (key, index) words: radix select, most significant bit first
-      unsigned long long prefix = 0ull, mask = 0ull;
-      int need = drop;                                   // rank (1-based) of the threshold word among the matching ones
-      for (int bit = 63; bit >= 0; --bit) {
-        const unsigned long long m2 = mask | (1ull << bit);
-        const int zeros = block_count([&](int p) { return lab[p] == want && (key_of(p) & m2) == prefix; });
-        if (need > zeros) { need -= zeros; prefix |= (1ull << bit); }
-        mask = m2;
-      }
-      // prefix = the drop-th smallest word: everything <= it is switched off
+    if (drop <= 0) continue;                          // (uniform: n and keep are block-wide values)
+    unsigned long long prefix = 0ull, mask = 0ull;
+    int need = drop;                                  // rank (1-based) of the threshold word among the words matching `prefix`
+    for (int shift = 56; shift >= 0; shift -= 8) {
+      if (tid < 256) s_hist[tid] = 0;
       __syncthreads();
       for (int p = tid; p < total; p += 1024)
-        if (lab[p] == want && key_of(p) <= prefix) lab[p] = -1.f;
+        if (lab[p] == want) {
+          const unsigned long long k = key_of(p);
+          if ((k & mask) == prefix) atomicAdd(&s_hist[(int)((k >> shift) & 255ull)], 1);
+        }
+      __syncthreads();
+      if (tid == 0) {                                 // first digit whose cumulative count reaches the rank
+        int cum = 0, d = 0;
+        for (; d < 256; ++d) {
+          if (cum + s_hist[d] >= need) break;
+          cum += s_hist[d];
+        }
+        s_pick[0] = d; s_pick[1] = need - cum;
+      }
+      __syncthreads();
+      prefix |= (unsigned long long)s_pick[0] << shift;
+      mask |= 255ull << shift;
+      need = s_pick[1];
       __syncthreads();
     }
+    // prefix = the drop-th smallest word (words are unique): everything <= it is switched off
+    for (int p = tid; p < total; p += 1024)
+      if (lab[p] == want && key_of(p) <= prefix) lab[p] = -1.f;
+    __syncthreads();
   }
   // weights: RPN_BBOX_WEIGHTS (1, 1, 1, 1) on the surviving positives
-  const long hw = (long)g.fh * g.fw;
   for (int p = tid; p < total; p += 1024) {
-    const int a = p / (int)hw, k = p % (int)hw;
+    const int a = p / hw, k = p - a * hw;
     const float w = lab[p] == 1.f ? 1.f : 0.f;
-    float* bw = g.bbox_weight + ((long)b * 4 * g.A + 4 * a) * hw + k;
+    float* bw = g.bbox_weight + ((long)b * 4 * g.A + 4 * a) * (long)hw + k;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) bw[c * hw] = w;
+    for (int c = 0; c < 4; ++c) bw[(long)c * hw] = w;
   }
 }
 

@@ -5,8 +5,10 @@ called from `lib/dataset/coco.py:237-249`); that is a C / Cython extension which
 algorithm is restated: per (image, category) the detections, sorted by score, are matched greedily to the ground truth
 of highest IoU still available at each threshold (crowd boxes may be matched repeatedly and use intersection / detection
 area as their IoU; ignored ground truth is tried last), precision is made monotone and sampled at 101 recall points.
-PARITY UNPINNED against pycocotools itself (not importable offline); pinned by known-answer cases in
-tests/test_dataset.py.
+PINNED: tests/golden/cocoeval.npz holds the 12 statistics and the full precision / recall arrays produced by the reference's
+own `cocoeval.py` (executed by tests/golden/gen_golden.py through lib2to3, its C `mask.iou` replaced by a transcription of
+maskApi.c:98-109) on a synthetic problem with crowd boxes; tests/test_dataset.py holds this module to them at 1e-12, next to
+hand-made known-answer cases.
 """
 import numpy as np
 

@@ -1,7 +1,11 @@
 """Image pre-processing of `lib/utils/image.py:16-130`: read (BGR), optional mirror, resize so that the short side is
 SCALES[i][0] with the long side capped at SCALES[i][1], zero-pad to IMAGE_STRIDE, subtract PIXEL_MEANS and emit RGB-ordered
-[1, 3, H, W]; boxes are scaled, rounded and clipped.  cv2 is not installed here: decoding / bilinear resizing use Pillow
-(`Image.BILINEAR`; cv2.INTER_LINEAR differs in the last bit of some pixels -- unpinned), `.npy` arrays are read as is."""
+[1, 3, H, W]; boxes are scaled, rounded and clipped.  cv2 is not installed here: decoding uses Pillow, `.npy` arrays are read
+as is, and the resize is a numpy restatement of `cv2.resize(im, None, None, fx=s, fy=s, interpolation=cv2.INTER_LINEAR)`:
+plain 2-tap bilinear for up- AND down-scaling (no antialiasing support widening), source coordinate (d + 0.5) / s - 0.5
+clamped to the image, and uint8 images come back ROUNDED to uint8 like cv2's output (the mean is subtracted from the rounded
+values).  cv2 evaluates the taps in 11-bit fixed point: results can differ by one grey level on a fraction of the pixels --
+unpinned (no cv2 here to compare with)."""
 import os
 import random
 
@@ -19,18 +23,35 @@ def imread_bgr(path):
     return rgb[:, :, ::-1]
 
 
+def _bilinear_axis(n_src, n_dst, scale):
+    """cv2 INTER_LINEAR taps of one axis: (left index, right index, weight of the right tap) per destination position."""
+    f = (np.arange(n_dst, dtype=np.float64) + 0.5) / scale - 0.5
+    i0 = np.floor(f).astype(np.int64)
+    w1 = f - i0
+    lo = i0 < 0
+    i0[lo] = 0; w1[lo] = 0.0
+    hi = i0 >= n_src - 1
+    i0[hi] = n_src - 1; w1[hi] = 0.0
+    return i0, np.minimum(i0 + 1, n_src - 1), w1
+
+
 def resize(im, target_size, max_size, stride=0):
     """image.py:78-108.  Returns (resized [+ padded] float image, im_scale)."""
-    from PIL import Image
     h, w = im.shape[:2]
     size_min, size_max = min(h, w), max(h, w)
     im_scale = float(target_size) / float(size_min)
     if np.round(im_scale * size_max) > max_size:
         im_scale = float(max_size) / float(size_max)
     nw, nh = int(round(w * im_scale)), int(round(h * im_scale))
-    chans = [np.asarray(Image.fromarray(np.ascontiguousarray(im[:, :, c]).astype(np.float32), mode='F').resize((nw, nh), Image.BILINEAR))
-             for c in range(im.shape[2])]
-    out = np.stack(chans, axis=2)
+    x0, x1, wx = _bilinear_axis(w, nw, im_scale)
+    y0, y1, wy = _bilinear_axis(h, nh, im_scale)
+    src = im.astype(np.float64)
+    top = src[y0][:, x0] * (1.0 - wx)[None, :, None] + src[y0][:, x1] * wx[None, :, None]
+    bot = src[y1][:, x0] * (1.0 - wx)[None, :, None] + src[y1][:, x1] * wx[None, :, None]
+    out = top * (1.0 - wy)[:, None, None] + bot * wy[:, None, None]
+    if im.dtype == np.uint8:                  # cv2 returns the image in the input's type: rounded, saturated
+        out = np.clip(np.rint(out), 0, 255)
+    out = out.astype(np.float32)
     if stride == 0:
         return out, im_scale
     ph = int(np.ceil(out.shape[0] / float(stride)) * stride)

@@ -49,7 +49,7 @@ def _make_namespace(name):
         return f
     m.maximum = _two('_maximum', '_maximum_scalar')
     m.minimum = _two('_minimum', '_minimum_scalar')
-    m.pow = m.power = _two('_power', '_power_scalar')
+    m.pow = m.power = _two('_power', '_power_scalar', '_rpower_scalar')      # pow(2, sym) = 2 ** sym, not sym ** 2
     return m
 
 

@@ -101,6 +101,7 @@ class Symbol(object):
     __div__, __rdiv__ = __truediv__, __rtruediv__
     def __neg__(self): return self * -1.0
     def __pow__(self, o): return self._scalar_or_sym(o, '_power', '_power_scalar')
+    def __rpow__(self, o): return self._scalar_or_sym(o, '_power', '_power_scalar', '_rpower_scalar', rev=True)
 
     # ---- graph queries ----------------------------------------------------------------------------------
     def _topo(self):

@@ -147,8 +147,16 @@ def make(op, args, kwargs):
 # ---------------------------------------------------------------------------------------------------------
 def reshape_codes(in_shape, codes, reverse=False):
     """MXNet Reshape special codes 0 (copy), -1 (infer), -2 (copy the rest), -3 (merge two), -4 (split)."""
-    if reverse:
-        return tuple(reversed(reshape_codes(tuple(reversed(in_shape)), tuple(reversed(codes)))))
+    if reverse:       # match the codes from the right: reverse shape and codes, keeping every -4 with its two arguments
+        codes = [int(c) for c in codes]
+        units, k = [], 0
+        while k < len(codes):
+            if codes[k] == -4:
+                units.append([-4, codes[k + 2], codes[k + 1]]); k += 3        # the split's factors swap with the axis order
+            else:
+                units.append([codes[k]]); k += 1
+        rev = [c for u in reversed(units) for c in u]
+        return tuple(reversed(reshape_codes(tuple(reversed(in_shape)), tuple(rev))))
     out, i, infer, k = [], 0, None, 0
     codes = [int(c) for c in codes]
     while k < len(codes):
@@ -233,6 +241,7 @@ for _n, _f in (('_plus_scalar', lambda x, s: x + s), ('_minus_scalar', lambda x,
                ('_rminus_scalar', lambda x, s: s - x), ('_mul_scalar', lambda x, s: x * s),
                ('_div_scalar', lambda x, s: x / s), ('_rdiv_scalar', lambda x, s: s / x),
                ('_power_scalar', lambda x, s: torch.pow(x, s)),
+               ('_rpower_scalar', lambda x, s: torch.pow(torch.as_tensor(s, dtype=x.dtype, device=x.device), x)),
                ('_maximum_scalar', lambda x, s: torch.clamp(x, min=s)),
                ('_minimum_scalar', lambda x, s: torch.clamp(x, max=s))):
     defop(_n, ['data'], (lambda f: lambda a, x: f(x, a_float(a, 'scalar')))(_f))
@@ -298,7 +307,7 @@ def _broadcast_to(a, x):
 
 
 defop('broadcast_to', ['data'], _broadcast_to)
-defop('tile', ['data'], lambda a, x: x.repeat(*a_tuple(a, 'reps')))
+defop('tile', ['data'], lambda a, x: (lambda r: x.repeat(*((1,) * (x.dim() - len(r)) + tuple(r))))(a_tuple(a, 'reps')))     # MXNet left-pads reps with 1
 defop('reverse', ['data'], lambda a, x: torch.flip(x, dims=list(a_tuple(a, 'axis'))))
 defop('flip', ['data'], lambda a, x: torch.flip(x, dims=list(a_tuple(a, 'axis'))))
 defop('where', ['condition', 'x', 'y'], lambda a, c, x, y: torch.where(c != 0, x, y))

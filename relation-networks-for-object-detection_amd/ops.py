@@ -78,11 +78,12 @@ def embedding_divisors(feat_dim=64, wave_length=1000.0):
                      torch.tensor(8.0 / feat_dim, dtype=torch.float32) * k)
 
 
-def geometry_bias(boxes, wp_t, bp, M=None, divisors=None, debug=False, half=False, fast32=False):
+def geometry_bias(boxes, wp_t, bp, M=None, divisors=None, debug=False, half=False, fast32=False, mfma32=False):
     """boxes [B,N,4|5] fp32 (xyxy, or batch_idx + xyxy); wp_t [64, nmod*16]; bp [nmod*16]
     -> bias [nmod, B, 16, N, Mpad] fp32 = log(max(relu(E Wp^T + bp), 1e-6)) (the oracle's arithmetic: correctly rounded
-    sin / cos / log, float64 accumulation; fast32: float32 libm arithmetic, for the training recompute), or with half=True
-    fp16 log2(.) from the matrix-core kernel (bf16 throughput path).
+    sin / cos / log, float64 accumulation; fast32: float32 libm arithmetic; mfma32: float32 ln(.) from the matrix-core kernel,
+    the values the bf16 forward saw -- the training backward's recompute), or with half=True fp16 log2(.) from the
+    matrix-core kernel (bf16 throughput path).
     debug=True also returns (position_matrix [B,N,M,4], position_embedding [B,N,M,64])."""
     _chk(boxes, wp_t, bp)
     assert boxes.dtype == torch.float32 and boxes.is_contiguous()
@@ -99,7 +100,7 @@ def geometry_bias(boxes, wp_t, bp, M=None, divisors=None, debug=False, half=Fals
         pm = torch.empty((B, N, M, 4), device=boxes.device, dtype=torch.float32)
         pe = torch.empty((B, N, M, 64), device=boxes.device, dtype=torch.float32)
     _lib.call('relnet_geometry_bias', boxes.data_ptr(), bs, off, wp_t.data_ptr(), bp.data_ptr(),
-              div.data_ptr(), bias.data_ptr(), 1 if half else (-1 if fast32 else 0), _ptr(pm), _ptr(pe), B, N, M, Mpad, 16, nmod, _stream())
+              div.data_ptr(), bias.data_ptr(), 1 if half else (2 if mfma32 else (-1 if fast32 else 0)), _ptr(pm), _ptr(pe), B, N, M, Mpad, 16, nmod, _stream())
     if debug:
         return bias, pm, pe
     return bias

@@ -26,12 +26,69 @@ class _Loader(importlib.abc.SourceLoader):
         try:
             return compile(src, path, 'exec', dont_inherit=True, optimize=_optimize)
         except SyntaxError:
-            from lib2to3.refactor import RefactoringTool
-            src3 = str(RefactoringTool(['lib2to3.fixes.fix_print']).refactor_string(src if src.endswith('\n') else src + '\n', path))
-            return compile(src3, path, 'exec', dont_inherit=True, optimize=_optimize)
+            return compile(fix_print_statements(src, path), path, 'exec', dont_inherit=True, optimize=_optimize)
 
     def get_code(self, fullname):                                  # no bytecode cache next to the reference's files
         return self.source_to_code(self.get_data(self.path), self.path)
+
+
+def _fix_print_lines(src):
+    """Minimal Python-2 print-statement rewriter (`print a, b`, `print >>f, a`, trailing comma, bare `print`, arguments
+    continued over several lines inside brackets): the fallback when lib2to3 is gone (removed from the standard library in
+    Python 3.13)."""
+    import re
+
+    def depth(text):
+        d, q = 0, None
+        for ch in text:
+            if q:
+                q = None if ch == q else q
+            elif ch in '"\'':
+                q = ch
+            elif ch == '#':
+                break
+            elif ch in '([{':
+                d += 1
+            elif ch in ')]}':
+                d -= 1
+        return d
+
+    lines, out, i = src.split('\n'), [], 0
+    while i < len(lines):
+        line = lines[i]
+        m = re.match(r'^(\s*)print(?![\w(=.\[])\s*(.*?)\s*$', line)
+        if not m:
+            out.append(line); i += 1
+            continue
+        indent, rest = m.group(1), m.group(2)
+        while depth(rest) > 0 and i + 1 < len(lines):          # the argument list continues on the next line(s)
+            i += 1
+            rest += '\n' + lines[i].rstrip()
+        comment = ''
+        if '\n' not in rest and '#' in rest and rest.count('"') % 2 == 0 and rest.count("'") % 2 == 0:
+            rest, comment = rest[:rest.index('#')].rstrip(), '  ' + rest[rest.index('#'):]
+        kw = ''
+        if rest.startswith('>>'):
+            dest, _, rest = rest[2:].partition(',')
+            kw = ', file=%s' % dest.strip()
+            rest = rest.strip()
+        if rest.endswith(','):
+            rest, kw = rest[:-1].rstrip(), kw + ", end=' '"
+        args = rest + kw if rest else kw.lstrip(', ')
+        out.append('%sprint(%s)%s' % (indent, args, comment))
+        i += 1
+    return '\n'.join(out)
+
+
+def fix_print_statements(src, path='<source>'):
+    """Python-2 `print` statements -> calls, in memory: lib2to3's fix_print when the interpreter still ships it, else the
+    single-line rewriter above (enough for the reference's files: their only Python-3 problem is the print statement)."""
+    src = src if src.endswith('\n') else src + '\n'
+    try:
+        from lib2to3.refactor import RefactoringTool
+    except ImportError:
+        return _fix_print_lines(src)
+    return str(RefactoringTool(['lib2to3.fixes.fix_print']).refactor_string(src, path))
 
 
 class _Finder(importlib.abc.MetaPathFinder):

@@ -75,9 +75,11 @@ def fused_ok(dtype, M, heads=16):
     return dtype == torch.bfloat16 and heads == 16 and M <= ops.FUSED_MAX_KEYS
 
 
-def _module_forward(f, mod, bias, M, want_out, want_act, want_logits, vwt_buf=None, rois=None, key_count=None):
+def _module_forward(f, mod, bias, M, want_out, want_act, want_logits, vwt_buf=None, rois=None, key_count=None, cache=None):
     """`bias` None + `rois` given: fused geometry + attention kernel (no bias tensor, no logits output).
-    key_count [B] int32: per-image number of real keys among the first M rows (ops.relation_attention)."""
+    key_count [B] int32: per-image number of real keys among the first M rows (ops.relation_attention).
+    cache (dict, training): receives the projections qk [B,N,2d], vwt [B,d,Mpad] and (with want_out) the module output y, so
+    that attention_module_backward does not recompute the forward."""
     B, N, F = f.shape
     qk = ops.gemm_nt(f.reshape(B * N, F), mod.wqk, mod.bqk).reshape(B, N, -1)
     Mpad = bias.shape[-1] if bias is not None else ops.pad32(M)
@@ -92,9 +94,12 @@ def _module_forward(f, mod, bias, M, want_out, want_act, want_logits, vwt_buf=No
                                               bout=mod.bout, resid=f if want_act else None, M=M, want_out=want_out,
                                               want_act=want_act)
         return y, act, None
-    return ops.relation_attention(qk[:, :, :d], qk[:, :M, d:], vwt_buf, bias, bout=mod.bout,
-                                  resid=f if want_act else None, M=M, want_out=want_out,
-                                  want_act=want_act, want_logits=want_logits, key_count=key_count)
+    r = ops.relation_attention(qk[:, :, :d], qk[:, :M, d:], vwt_buf, bias, bout=mod.bout,
+                               resid=f if want_act else None, M=M, want_out=want_out,
+                               want_act=want_act, want_logits=want_logits, key_count=key_count)
+    if cache is not None:
+        cache.update(qk=qk, vwt=vwt_buf, y=r[0])
+    return r
 
 
 class RelationHead(object):
@@ -158,7 +163,8 @@ class RelationHead(object):
         return cls_score, bbox_pred, x2
 
 
-def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, index=1, dtype=None, packed=None, key_count=None):
+def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, index=1, dtype=None, packed=None, key_count=None,
+                              cache=None):
     """Gradient of `attention_module_multi_head` (the adjoint MXNet's autograd derives from SYM_REL:85-151).
 
     roi_feat [B,N,1024] (or [N,1024]), rois [..,N,4|5], d_out = d loss / d module output, same shape.
@@ -179,16 +185,21 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
     M = N if nongt_dim is None else nongt_dim
     mod = packed or RelationParams(params, index, dtype, f.device)
     wp_t, bp = pack_pair_pos([mod], f.device)
-    bias = ops.geometry_bias(bx, wp_t, bp, M, fast32=(dtype == torch.bfloat16))[0]   # fp32 log G  [B,16,N,Mpad]
+    # fp32 ln G [B,16,N,Mpad]: bf16 training recomputes it on the matrix cores (the G its forward saw), float32 exactly
+    bias = ops.geometry_bias(bx, wp_t, bp, M, mfma32=(dtype == torch.bfloat16))[0]
     Mpad = bias.shape[-1]
     d = mod.wqk.shape[0] // 2
     kpad = 64 if dtype == torch.bfloat16 else 16                        # GEMM K granularity
-    # ---- forward recompute
-    qk = ops.gemm_nt(f.reshape(B * N, Fd), mod.wqk, mod.bqk).reshape(B, N, 2 * d)
-    q, k = qk[:, :, :d], qk[:, :M, d:]
-    vwt = torch.zeros((B, d, Mpad), device=f.device, dtype=dtype)
-    ops.gemm_nt(mod.wout, f[:, :M, :], out=vwt, n_cols=M)
-    y, _, _ = ops.relation_attention(q, k, vwt, bias, bout=mod.bout, M=M, want_out=True, key_count=key_count)
+    # ---- forward values: kept by the training forward (`cache` of _module_forward), else recomputed
+    if cache is not None and cache.get('y') is not None and cache['vwt'].shape[-1] == Mpad:
+        qk, vwt, y = cache['qk'], cache['vwt'], cache['y']
+        q, k = qk[:, :, :d], qk[:, :M, d:]
+    else:
+        qk = ops.gemm_nt(f.reshape(B * N, Fd), mod.wqk, mod.bqk).reshape(B, N, 2 * d)
+        q, k = qk[:, :, :d], qk[:, :M, d:]
+        vwt = torch.zeros((B, d, Mpad), device=f.device, dtype=dtype)
+        ops.gemm_nt(mod.wout, f[:, :M, :], out=vwt, n_cols=M)
+        y, _, _ = ops.relation_attention(q, k, vwt, bias, bout=mod.bout, M=M, want_out=True, key_count=key_count)
     # ---- operand layouts of the backward kernels
     vw = ops.gemm_nt(f[:, :M, :].reshape(B * M, Fd) if M == N else f[:, :M, :].contiguous().reshape(B * M, Fd),
                      mod.wout).reshape(B, M, d)                          # F_K Wout^T, not transposed

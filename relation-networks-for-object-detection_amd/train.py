@@ -339,9 +339,8 @@ class Trainer(object):
         d_x, dw = T.conv1x1_bwd(conv5, self.w('conv_new_1'), g, keep_splits=True, wgrad_to=self._wg('conv_new_1'))
         self._add_bgrad('conv_new_1', g.float().sum((0, 1, 2)))
         # RPN head backward (joins the trunk at conv4)
-        d_r, dw = T.conv1x1_bwd(r, self.w('rpn_out'), d_rpn, keep_splits=True, wgrad_to=self._wg('rpn_out'))
+        g_r, dw = T.conv1x1_bwd(r, self.w('rpn_out'), d_rpn, keep_splits=True, wgrad_to=self._wg('rpn_out'), relu_mask=r)
         self._add_bgrad('rpn_out', d_rpn.float().sum((0, 1, 2)))
-        g_r = T.relu_bwd(d_r, r)
         d_conv4_rpn, dw = T.conv3x3_bwd(conv4, self._dgrad_w('rpn_conv_3x3', 512), g_r, dil=1, keep_splits=True, wgrad_to=self._wg('rpn_conv_3x3'))
         self._add_bgrad('rpn_conv_3x3', g_r.float().sum((0, 1, 2)))
         self._trunk_backward(saved, d_x, {'4b22': d_conv4_rpn})
@@ -373,8 +372,8 @@ class Trainer(object):
             if inject.get(nm) is not None:       # a second consumer of this unit's output (RPN head at conv4, FPN laterals)
                 d_x = inject[nm] if d_x is None else d_x + inject[nm]
             g_out = T.relu_bwd(d_x, o)
-            d_y2, dw = T.conv1x1_bwd(y2, self.w(nc_), g_out, keep_splits=True, wgrad_to=self._wg(nc_, self.bn_scale[nc_]))
-            g_y2 = T.relu_bwd(d_y2, y2)
+            # (ReLU masks of the two inner activations ride in the data-gradient kernels' epilogues)
+            g_y2, dw = T.conv1x1_bwd(y2, self.w(nc_), g_out, keep_splits=True, wgrad_to=self._wg(nc_, self.bn_scale[nc_]), relu_mask=y2)
             if off is not None:            # deformable branch2b: data + offset gradients, then the offset conv's own backward
                 gd, goff, dw = ops.deformable_conv_bwd(y1.permute(0, 3, 1, 2), off.permute(0, 3, 1, 2), self.w(nb),
                                                        g_y2.permute(0, 3, 1, 2), 3, 1, 2, 2, 4)
@@ -388,8 +387,10 @@ class Trainer(object):
                 self._add_wgrad(no, dwo.sum(0)[:72]); self._add_bgrad(no, goff.sum((0, 1, 2)))
                 d_y1 = (gd + d_off_in.float()).to(bt).contiguous()
             else:
-                d_y1, dw = T.conv3x3_bwd(y1, self._dgrad_w(nb, y2.shape[3]), g_y2, dil=dil, keep_splits=True, wgrad_to=self._wg(nb, self.bn_scale[nb]))
-            g_y1 = T.relu_bwd(d_y1, y1)
+                g_y1, dw = T.conv3x3_bwd(y1, self._dgrad_w(nb, y2.shape[3]), g_y2, dil=dil, keep_splits=True, wgrad_to=self._wg(nb, self.bn_scale[nb]),
+                                         relu_mask=y1)
+            if off is not None:
+                g_y1 = T.relu_bwd(d_y1, y1)
             first = (stage == 3 and proj)         # res3a: its input comes from the frozen res2 -> no data gradient
             if proj:
                 d_a, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, stride=stride, need_dx=not first, keep_splits=True, wgrad_to=self._wg(na, self.bn_scale[na]))
@@ -415,9 +416,10 @@ class Trainer(object):
         wp_t, bp = pack_pair_pos(mods, self.device)
         bias = ops.geometry_bias(rois_t, wp_t, bp, N, half=True)
         f1 = ops.gemm_nt(pooled2, self.w('fc_new_1'), self.b('fc_new_1')).reshape(B, R, -1)
-        _, x1, _ = _module_forward(f1, mods[0], bias[0], N, False, True, False, key_count=key_count)
+        caches = [{}, {}]           # projections + module outputs of the forward, reused by the backward
+        _, x1, _ = _module_forward(f1, mods[0], bias[0], N, True, True, False, key_count=key_count, cache=caches[0])
         f2 = ops.gemm_nt(x1.reshape(B * R, -1), self.w('fc_new_2'), self.b('fc_new_2')).reshape(B, R, -1)
-        _, x2, _ = _module_forward(f2, mods[1], bias[1], N, False, True, False, key_count=key_count)
+        _, x2, _ = _module_forward(f2, mods[1], bias[1], N, True, True, False, key_count=key_count, cache=caches[1])
         cb = ops.gemm_nt(x2.reshape(B * R, -1), self.w('cls_bbox'), self.b('cls_bbox'), out_dtype=torch.float32).reshape(B, R, -1)
         nc = self.num_classes
         cls_score, bbox_pred = cb[:, :, :nc].contiguous(), cb[:, :, nc:].contiguous()
@@ -440,10 +442,10 @@ class Trainer(object):
         if d_x2_lnms is not None:
             d_x2 = d_x2.reshape(B, R, -1)
             d_x2[:, :N] += d_x2_lnms.to(d_x2.dtype)
-        d_f2 = self._relation_bwd(2, mods[1], f2, x2, rois_t, d_x2.reshape(B, R, -1), N, key_count)
+        d_f2 = self._relation_bwd(2, mods[1], f2, x2, rois_t, d_x2.reshape(B, R, -1), N, key_count, caches[1])
         d_x1, dw, db = T.linear_bwd(x1.reshape(B * R, -1), self.w('fc_new_2'), d_f2.reshape(B * R, -1), keep_splits=True, wgrad_to=self._wg('fc_new_2'))
         self._add_bgrad('fc_new_2', db)
-        d_f1 = self._relation_bwd(1, mods[0], f1, x1, rois_t, d_x1.reshape(B, R, -1), N, key_count)
+        d_f1 = self._relation_bwd(1, mods[0], f1, x1, rois_t, d_x1.reshape(B, R, -1), N, key_count, caches[0])
         d_pool, dw, db = T.linear_bwd(pooled2, self.w('fc_new_1'), d_f1.reshape(B * R, -1), keep_splits=True, wgrad_to=self._wg('fc_new_1'))
         self._add_bgrad('fc_new_1', db)
         return d_pool, (x2, f1, cls_score, bbox_pred, labels_ohem, weights_ohem)
@@ -494,7 +496,8 @@ class Trainer(object):
         wp_t, bp = pack_pair_pos([mod], dev)
         cb = class_boxes.view(BC, F, 4)
         bias = ops.geometry_bias(cb, wp_t, bp, F, half=True)[0]
-        att, _, _ = _module_forward(xr, mod, bias, F, True, False, False)                       # [BC,F,1024]
+        lcache = {}
+        att, _, _ = _module_forward(xr, mod, bias, F, True, False, False, cache=lcache)         # [BC,F,1024]
         att128 = att.view(BC, F, 16, 64)[..., :8].reshape(BC, F, 128)
         allf = torch.relu(xr + att128).contiguous()
         w_logit = torch.zeros((64, 128), device=dev, dtype=bt); w_logit[:Tn] = self.w('nms_logit')
@@ -515,7 +518,7 @@ class Trainer(object):
         g = T.relu_bwd(d_allf, allf.view(BC * F, 128))                                          # [BC*F,128] bf16
         dY = torch.zeros((BC, F, 1024), device=dev, dtype=bt)
         dY.view(BC, F, 16, 64)[..., :8] = g.view(BC, F, 16, 8)
-        r = attention_module_backward(xr, cb, None, dY, nongt_dim=F, index=1, dtype=bt, packed=mod)
+        r = attention_module_backward(xr, cb, None, dY, nongt_dim=F, index=1, dtype=bt, packed=mod, cache=lcache)
         self._add_wgrad('nms_qk_1', torch.cat([r['query_1_weight'], r['key_1_weight']], 0))
         self._add_bgrad('nms_qk_1', torch.cat([r['query_1_bias'], r['key_1_bias']], 0))
         self._add_wgrad('nms_linear_out_1', r['linear_out_1_weight'].reshape(16, 64, 128)[:, :8].reshape(128, 128))
@@ -556,10 +559,11 @@ class Trainer(object):
         m.bp = self.b('pair_pos_fc1_%d' % i)
         return m
 
-    def _relation_bwd(self, i, mod, f, x_act, rois, d_x, N, key_count=None):
+    def _relation_bwd(self, i, mod, f, x_act, rois, d_x, N, key_count=None, cache=None):
         """x_act = relu(f + relation_i(f)); returns d f and accumulates the module's parameter gradients."""
         g = T.relu_bwd(d_x.contiguous(), x_act)
-        r = attention_module_backward(f, rois, None, g, nongt_dim=N, index=i, dtype=torch.bfloat16, packed=mod, key_count=key_count)
+        r = attention_module_backward(f, rois, None, g, nongt_dim=N, index=i, dtype=torch.bfloat16, packed=mod, key_count=key_count,
+                                      cache=cache)
         d = mod.wqk.shape[0] // 2
         self._add_wgrad('qk_%d' % i, torch.cat([r['query_%d_weight' % i], r['key_%d_weight' % i]], 0))
         self._add_bgrad('qk_%d' % i, torch.cat([r['query_%d_bias' % i], r['key_%d_bias' % i]], 0))

@@ -81,10 +81,11 @@ def _tn_ok(dy2d, x):
             dy2d.stride(0) % 8 == 0 and dy2d.shape[1] % 8 == 0 and x.shape[-1] % 8 == 0 and dy2d.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
 
 
-def linear_bwd(x2d, w, dy2d, need_dx=True, w_t=None, keep_splits=False, wgrad_to=None):
+def linear_bwd(x2d, w, dy2d, need_dx=True, w_t=None, keep_splits=False, wgrad_to=None, relu_mask=None):
     """y = x W^T + b  ->  (dx [P,K] in x's dtype | None, dW [N,K] fp32, db [N] fp32).
     wgrad_to = (grad [N,K] fp32 view, row_scale | None): the weight gradient is ACCUMULATED there by relnet_wgrad (one
-    kernel straight from the row-major operands) and None is returned in its place."""
+    kernel straight from the row-major operands) and None is returned in its place.
+    relu_mask [P,K] (x's dtype): dx is zeroed where relu_mask <= 0 inside the GEMM epilogue (x = relu(.) fused in the forward)."""
     dx = None
     gran = 64 if dy2d.dtype == torch.bfloat16 else 16
     N = dy2d.shape[1]
@@ -94,7 +95,7 @@ def linear_bwd(x2d, w, dy2d, need_dx=True, w_t=None, keep_splits=False, wgrad_to
         dyp[:, :N] = dy2d
     if need_dx:
         w_t = ops.transpose_2d(w, pad_cols_to=gran) if w_t is None else w_t      # [K, pad(N)], zero padded
-        dx = ops.gemm_nt(dyp, w_t)
+        dx = ops.gemm_nt(dyp, w_t) if relu_mask is None else ops.gemm_nt(dyp, w_t, resid=relu_mask, relu=2)
     db = dy2d.float().sum(0)
     if wgrad_to is not None and _tn_ok(dyp, x2d):
         _wg_call(wgrad_to, dyp, x2d, cout=N)
@@ -136,10 +137,11 @@ def pack_conv_dgrad_weight(w_oihw, dtype=torch.bfloat16, device='cuda'):
     return w.reshape(w.shape[0], -1).to(device=device, dtype=dtype).contiguous()
 
 
-def conv1x1_bwd(x, w_packed, dy, stride=1, need_dx=True, w_t=None, dx_add=None, keep_splits=False, wgrad_to=None):
+def conv1x1_bwd(x, w_packed, dy, stride=1, need_dx=True, w_t=None, dx_add=None, keep_splits=False, wgrad_to=None, relu_mask=None):
     """x [B,H,W,Cin], dy [B,Ho,Wo,Cout] NHWC; w_packed [Cout,Cin].  -> (dx [B,H,W,Cin] | None, dW fp32).
     dx_add (stride 1 only): a second gradient of x's shape added in the GEMM epilogue (the shortcut branch).
-    wgrad_to: see linear_bwd (the strided input rows are gathered inside relnet_wgrad: no sub-sampled copy of x)."""
+    wgrad_to: see linear_bwd (the strided input rows are gathered inside relnet_wgrad: no sub-sampled copy of x).
+    relu_mask (stride 1, instead of dx_add): x itself when x = relu(.) -- dx comes out already multiplied by (x > 0)."""
     B, H, W, Cin = x.shape
     Cout = w_packed.shape[0]
     P = dy.shape[0] * dy.shape[1] * dy.shape[2]
@@ -154,7 +156,10 @@ def conv1x1_bwd(x, w_packed, dy, stride=1, need_dx=True, w_t=None, dx_add=None, 
         if Cout % gran:                           # e.g. the RPN's 24 + 48 output channels
             dyp = torch.zeros((P, w_t.shape[1]), device=dy.device, dtype=dy.dtype)
             dyp[:, :Cout] = dy2
-        if stride == 1:
+        if stride == 1 and relu_mask is not None:
+            assert dx_add is None
+            dx = ops.gemm_nt(dyp, w_t, resid=relu_mask.reshape(P, Cin), relu=2).reshape(B, H, W, Cin)
+        elif stride == 1:
             dx = ops.gemm_nt(dyp, w_t, resid=None if dx_add is None else dx_add.reshape(P, Cin)).reshape(B, H, W, Cin)
         else:
             assert dx_add is None
@@ -176,15 +181,16 @@ def conv1x1_bwd(x, w_packed, dy, stride=1, need_dx=True, w_t=None, dx_add=None, 
 _ZERO_OFF = {}
 
 
-def conv3x3_bwd(x, w_dgrad_packed, dy, dil=1, need_dx=True, keep_splits=False, wgrad_to=None, cout=None):
+def conv3x3_bwd(x, w_dgrad_packed, dy, dil=1, need_dx=True, keep_splits=False, wgrad_to=None, cout=None, relu_mask=None):
     """3x3, stride 1, pad = dil.  x [B,H,W,Cin], dy [B,H,W,Cout]; w_dgrad_packed from pack_conv_dgrad_weight.
     -> (dx | None, dW [Cout, 9*Cin] fp32 in pack_conv_weight order).  wgrad_to: see linear_bwd (implicit im2col inside
     relnet_wgrad: the [pixels][9 Cin] patch matrix is never written); cout: real output channels when dy is zero padded."""
     B, H, W, Cin = x.shape
     Cout = dy.shape[3]
     dx = None
-    if need_dx:
-        dx = ops.conv2d_nhwc(dy, w_dgrad_packed, None, ksize=3, stride=1, pad=dil, dil=dil)
+    if need_dx:       # relu_mask: dx * (x > 0) in the convolution's epilogue (x = relu(.) of the forward)
+        dx = ops.conv2d_nhwc(dy, w_dgrad_packed, None, ksize=3, stride=1, pad=dil, dil=dil,
+                             relu=2 if relu_mask is not None else False, resid=relu_mask)
     dy2 = dy.reshape(B * H * W, Cout)
     if wgrad_to is not None and _tn_ok(dy2, x) and x.is_contiguous():
         _wg_call(wgrad_to, dy2, x, cout=cout, conv=(3, 1, dil, dil))

@@ -194,3 +194,36 @@ def rpn_gt_boxes(g, seed, im_h=IM_H, im_w=IM_W):
     bw, bh = rng.uniform(40, 400, g), rng.uniform(40, 400, g)
     x1, y1 = rng.uniform(0, im_w - 1 - bw), rng.uniform(0, im_h - 1 - bh)
     return np.stack([x1, y1, x1 + bw, y1 + bh, rng.integers(1, 81, g)], 1).astype(F32)
+
+
+def cocoeval_case(seed=71, n_images=6, n_cats=4):
+    """A synthetic detection problem for the COCO bbox evaluation: ground truth with crowd boxes and every area range, detections
+    that hit, miss, duplicate and drift, several per (image, category), distinct scores.  -> (gts, dts) lists of dicts in the
+    COCO json layout (bbox = [x, y, w, h])."""
+    rng = np.random.default_rng(seed)
+    gts, dts = [], []
+    gid = 1
+    for img in range(1, n_images + 1):
+        for cat in range(1, n_cats + 1):
+            ng = int(rng.integers(0, 5))
+            for _ in range(ng):
+                side = float(np.exp(rng.uniform(np.log(8), np.log(300))))
+                ar = float(np.exp(rng.uniform(-0.6, 0.6)))
+                w, h = min(side * ar, 590.0), min(side / ar, 390.0)
+                x, y = float(rng.uniform(0, 600 - w)), float(rng.uniform(0, 400 - h))
+                crowd = int(rng.random() < 0.12)
+                gts.append(dict(id=gid, image_id=img, category_id=cat, bbox=[x, y, w, h], area=w * h * float(rng.uniform(0.5, 1.0)),
+                                iscrowd=crowd))
+                gid += 1
+                for k in range(int(rng.integers(0, 4))):        # detections around this gt: jittered copies
+                    j = rng.normal(0, 0.08 + 0.1 * k, 4)
+                    dts.append(dict(image_id=img, category_id=cat, score=float(rng.random()),
+                                    bbox=[x + j[0] * w, y + j[1] * h, w * float(np.exp(j[2])), h * float(np.exp(j[3]))]))
+            for _ in range(int(rng.integers(0, 3))):            # false positives
+                w, h = float(rng.uniform(5, 200)), float(rng.uniform(5, 200))
+                dts.append(dict(image_id=img, category_id=cat, score=float(rng.random()) * 0.7,
+                                bbox=[float(rng.uniform(0, 600 - w)), float(rng.uniform(0, 400 - h)), w, h]))
+    for i, d in enumerate(dts):
+        d['id'] = i + 1
+        d['area'] = d['bbox'][2] * d['bbox'][3]
+    return gts, dts

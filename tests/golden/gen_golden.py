@@ -18,6 +18,8 @@ What runs from the reference, unchanged, imported from where it lies:
   relation_rcnn/core/rcnn.py              get_rcnn_testbatch (ROIDispatch: FPN level assignment + regrouping)
   lib/rpn/rpn.py                          assign_anchor (print statements rewritten in memory by lib2to3's fix_print)
   relation_rcnn/operator_py/proposal.py   ProposalOperator.forward (same print rewrite; gpu_nms -> the reference's py_nms)
+  lib/dataset/pycocotools/cocoeval.py     COCOeval.evaluate / evaluateImg / accumulate / summarize (print + tuple-parameter
+                                          rewrite; the C `mask.iou` -> a numpy transcription of maskApi.c:bbIou)
 
 Shims needed because the reference is Python-2 / numpy-1 / MXNet-1.1.0 code (none of
 them edits a reference file): `xrange`, `np.float`/`np.int` aliases, `cPickle`, stub
@@ -339,6 +341,72 @@ def gen_fpn(out):
     np.savez_compressed(os.path.join(out, 'fpn.npz'), **d)
 
 
+def gen_cocoeval(ref, out):
+    """The 12 COCO bbox statistics + the precision / recall arrays by the reference's own evaluation code
+    (lib/dataset/pycocotools/cocoeval.py: evaluate, evaluateImg, accumulate, summarize), read from where it lies and made
+    importable in memory by lib2to3's mechanical Python-2 fixers (print, tuple_params: `lambda (ind, g): ...`, filter / map / zip /
+    dict / xrange: list-returning builtins).  Its two dependencies are replaced:
+    `mask.iou` (the C extension, maskApi.c:98-109 bbIou) by a numpy transcription of those twelve lines, and the COCO index
+    object by a 30-line stand-in serving getImgIds / getCatIds / getAnnIds / loadAnns from the same annotation lists."""
+    from lib2to3.refactor import RefactoringTool
+    if not hasattr(np, 'float'):
+        np.float = float                              # numpy-1 alias the file uses (as in setup_reference)
+    path = os.path.join(ref, 'lib/dataset/pycocotools/cocoeval.py')
+    src = open(path).read()
+    src3 = str(RefactoringTool(['lib2to3.fixes.fix_' + f for f in ('print', 'tuple_params', 'filter', 'map', 'zip', 'dict', 'xrange')]).refactor_string(src + '\n', path))
+
+    def bb_iou(dt, gt, iscrowd):                      # maskApi.c:98-109 behind _mask.pyx:iou (:205-233): [len(dt), len(gt)],
+        if len(dt) == 0 or len(gt) == 0:              # and an empty LIST when either side is empty (:213-214)
+            return []
+        dt, gt = np.asarray(dt, np.float64).reshape(-1, 4), np.asarray(gt, np.float64).reshape(-1, 4)
+        o = np.zeros((len(dt), len(gt)))
+        for g in range(len(gt)):
+            ga = gt[g, 2] * gt[g, 3]
+            for d in range(len(dt)):
+                da = dt[d, 2] * dt[d, 3]
+                w = min(dt[d, 2] + dt[d, 0], gt[g, 2] + gt[g, 0]) - max(dt[d, 0], gt[g, 0])
+                if w <= 0:
+                    continue
+                h = min(dt[d, 3] + dt[d, 1], gt[g, 3] + gt[g, 1]) - max(dt[d, 1], gt[g, 1])
+                if h <= 0:
+                    continue
+                i = w * h
+                o[d, g] = i / (da if iscrowd[g] else da + ga - i)
+        return o
+
+    mask_stub = types.ModuleType('mask'); mask_stub.iou = bb_iou
+    sys.modules['mask'] = mask_stub
+    mod = types.ModuleType('ref_cocoeval'); mod.__file__ = path
+    exec(compile(src3, path, 'exec'), mod.__dict__)
+
+    class Index(object):                              # the slice of pycocotools.coco.COCO that cocoeval.py calls
+        def __init__(self, anns):
+            self.anns = {a['id']: a for a in anns}
+        def getImgIds(self): return sorted({a['image_id'] for a in self.anns.values()})
+        def getCatIds(self): return sorted({a['category_id'] for a in self.anns.values()})
+        def getAnnIds(self, imgIds=(), catIds=()):
+            imgIds, catIds = set(imgIds), set(catIds)
+            return [i for i, a in self.anns.items() if (not imgIds or a['image_id'] in imgIds) and (not catIds or a['category_id'] in catIds)]
+        def loadAnns(self, ids): return [self.anns[i] for i in ids]
+
+    import copy
+    gts, dts = cases.cocoeval_case()
+    gt_index = Index(copy.deepcopy(gts))
+    lin = np.linspace                                 # numpy-1 era call: np.linspace(.5, .95, np.round(...) + 1) with a FLOAT count
+    np.linspace = lambda a, b, num=50, **kw: lin(a, b, int(num), **kw)
+    try:
+        ev = mod.COCOeval(gt_index, Index(copy.deepcopy(dts)))
+    finally:
+        np.linspace = lin
+    ev.params.useSegm = 0                             # bbox evaluation (lib/dataset/coco.py:_do_python_eval)
+    ev.params.imgIds = sorted({a['image_id'] for a in gts + dts})
+    ev.params.catIds = sorted({a['category_id'] for a in gts + dts})
+    ev.evaluate(); ev.accumulate(); ev.summarize()
+    np.savez_compressed(os.path.join(out, 'cocoeval.npz'), stats=np.asarray(ev.stats, np.float64),
+                        precision=ev.eval['precision'], recall=ev.eval['recall'])
+    print('cocoeval stats', np.round(ev.stats, 4))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -359,6 +427,7 @@ def main():
     gen_fpn(a.out)
     gen_rpn_targets(a.ref, a.out)
     gen_proposal(a.ref, a.out)
+    gen_cocoeval(a.ref, a.out)
     for f in sorted(os.listdir(a.out)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(a.out, f)), 'bytes')

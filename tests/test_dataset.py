@@ -199,3 +199,23 @@ def test_evaluate_detections_writes_results_and_scores(tmp_path):
     res = json.load(open(os.path.join(db.result_path, 'results', 'detections_val2014_results.json')))
     assert len(res) == 18 and set(res[0]) == {'image_id', 'category_id', 'bbox', 'score'} and {r_['category_id'] for r_ in res} == {1, 3, 7}
     assert np.isclose(stats[0], 1.0, atol=1e-6) and np.isclose(stats[8], 1.0) and 'person' in info and 'AP50' in info
+
+
+def test_cocoeval_matches_the_reference_evaluation_code():
+    """dataset/cocoeval.py vs tests/golden/cocoeval.npz = the output of the reference's own lib/dataset/pycocotools/cocoeval.py
+    (evaluate / evaluateImg / accumulate / summarize, executed by tests/golden/gen_golden.py with its C `mask.iou` replaced by
+    a transcription of maskApi.c:bbIou) on a synthetic problem with crowd boxes, all area ranges, duplicates and misses:
+    the 12 statistics AND the full precision [T,R,K,A,M] / recall [T,K,A,M] arrays agree to 1e-12."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import cases
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cocoeval.npz'))
+    gts, dts = cases.cocoeval_case()
+    ev = cocoeval.COCOeval(gts, dts)
+    ev.evaluate(); ev.accumulate()
+    st = ev.summarize()
+    assert ev.eval['precision'].shape == g['precision'].shape and ev.eval['recall'].shape == g['recall'].shape
+    np.testing.assert_allclose(ev.eval['recall'], g['recall'], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(ev.eval['precision'], g['precision'], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(st, g['stats'], rtol=0, atol=1e-12)
+    assert 0.1 < st[0] < 0.9 and st[1] > st[0] > st[2]                # a non-degenerate problem

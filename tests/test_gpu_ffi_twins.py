@@ -56,6 +56,12 @@ def test_py_nms_and_softnms_wrappers_float64(twins, n):
         if max_dets == -1:                                                 # scores written back like nms.py:114
             np.testing.assert_allclose(np.sort(b[:, 4]), np.sort(want[:, 4]), rtol=1e-10, atol=1e-300)
     assert nms.soft_nms(np.zeros((0, 5)), 0.6, -1).shape == (0, 5) and nms.nms(np.zeros((0, 5)), 0.5) == []
+    # lib/nms/nms.py takes ANY float64 score column (raw logits, scores <= -1): nothing may be mistaken for a removed slot
+    dn = d.copy()
+    dn[:, 4] = np.random.default_rng(n).normal(-2.0, 3.0, n)
+    want = ONMS.py_nms(dn.copy(), 0.5)
+    got = nms.py_nms_wrapper(0.5)(dn.copy())
+    assert [int(i) for i in got] == [int(i) for i in want] and (dn[want, 4] < -1.0).any()
 
 
 def test_bbox_overlaps_cython(twins):

@@ -131,3 +131,25 @@ for name in C.EXPERIMENTS:
     r = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
     assert r.stdout.decode().count('built') == 10
+
+
+def test_operator_corner_cases_of_the_registry():
+    """pow(scalar, Symbol) / scalar ** Symbol is scalar ** x (an `_rpower_scalar` node), tile left-pads `reps` with 1 like MXNet,
+    and Reshape(reverse=True) keeps a -4 split together with its two arguments when the code list is reversed."""
+    import torch
+    from relnet_amd.mx import registry as R
+    mx.sym.reset_names()
+    x = mx.sym.Variable('x')
+    assert mx.sym.pow(2.0, x)._topo()[-1].op == '_rpower_scalar' and (2.0 ** x)._topo()[-1].op == '_rpower_scalar'
+    assert mx.sym.pow(x, 2.0)._topo()[-1].op == '_power_scalar' and (x ** 2.0)._topo()[-1].op == '_power_scalar'
+    assert mx.sym.pow(2.0, x).infer_shape(x=(3, 4))[1] == [(3, 4)]
+    t = torch.tensor([[1.0, 2.0], [3.0, 0.5]])
+    assert torch.allclose(R.OPS['_rpower_scalar'].fn({'scalar': '2.0'}, t), 2.0 ** t)
+    assert mx.sym.tile(x, reps=(2,)).infer_shape(x=(3, 4))[1] == [(3, 8)]          # reps (2,) == (1, 2)
+    assert mx.sym.tile(x, reps=(2, 1, 3)).infer_shape(x=(3, 4))[1] == [(2, 3, 12)]
+    # MXNet doc example: shape (10, 5, 4), Reshape(shape=(-1, 0), reverse=True) -> (50, 4); forward would give (40, 5)
+    assert R.reshape_codes((10, 5, 4), (-1, 0), reverse=True) == (50, 4) and R.reshape_codes((10, 5, 4), (-1, 0)) == (40, 5)
+    # -4 under reverse: the LAST axis is split, its factors keep their order
+    assert R.reshape_codes((6, 20), (0, -4, 4, 5), reverse=True) == (6, 4, 5)
+    assert R.reshape_codes((6, 20), (0, -4, -1, 5), reverse=True) == (6, 4, 5)
+    assert R.reshape_codes((20, 6), (-4, 4, 5, 0)) == (4, 5, 6)
