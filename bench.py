@@ -253,7 +253,7 @@ def main():
     ap.add_argument('--no-train-line', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--stem', default='hip', choices=['hip', 'miopen'], help='7x7 stem conv: MFMA implicit GEMM or library')
+    ap.add_argument('--stem', default='hip', choices=['hip', 'hip3', 'miopen'], help="stem: 'hip' one fused conv1 + ReLU + pool1 kernel, 'hip3' the three-launch form, 'miopen' library 7x7")
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of hipGraph replays')
     ap.add_argument('--shapes', action='store_true', help='print per-shape GEMM/conv times to stderr')
     ap.add_argument('--head-init-std', type=float, default=0.05,
@@ -455,8 +455,11 @@ def main():
         ta = argparse.Namespace(**vars(a))
         ta.batch, ta.learn_nms, ta.steps, ta.warmup = 8, True, min(a.steps, 10), 2
         tr_res = bench_train(ta, rank, world, D, emit=False)
+        ta.batch, ta.steps = 16, min(a.steps, 6)          # the same step at 16 images per GPU (larger GEMMs fill the chip better)
+        tr16 = bench_train(ta, rank, world, D, emit=False)
         if rank == 0:
             res['train'] = {k: tr_res[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'n_gpus', 'config', 'losses')}
+            res['train']['at_16_images_per_gpu'] = {k: tr16[k] for k in ('value', 'ms_per_step', 'steps')}
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

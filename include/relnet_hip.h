@@ -106,6 +106,12 @@ int relnet_stem_conv7(const void* packed, const void* w256, const float* bias, i
  * 30-36, fused into one pass over the NHWC stem output: out = relu(maxpool_ceil(in) + bias).        */
 int relnet_stem_bias_relu_pool(const void* in, const float* bias, void* out, int B, int H, int W, int C,
                                int ksize, int stride, void* stream);
+/* conv1 7x7/2 (pad 3) + folded-BN bias + ReLU + pool1 3x3/2 (pooling_convention='full') in ONE kernel, raw NCHW image ->
+ * pooled NHWC bf16 map (resnet_v1_101_rcnn_base.py:30-36): bit-identical to relnet_stem_pack_input + relnet_stem_conv7 +
+ * relnet_stem_bias_relu_pool without the conv map's HBM round trip.  data [B,3,H,W] (in_dtype 0 fp32 / 1 bf16),
+ * w256 [64][256] bf16 with k = ty*32 + tx*4 + c (zero for ty = 7, tx = 7, c = 3), bias [64] fp32, out [B,Hp,Wp,64].    */
+int relnet_stem_fused(const void* data, int in_dtype, const void* w256, const float* bias, void* out, int B, int H, int W,
+                      void* stream);
 
 /* ---- SYM_REL:46-83 extract_position_matrix + :29-44 extract_position_embedding + :109-116
  * pair_pos_fc1 + ReLU + the log(max(.,1e-6)) of :139, fused (the [N,M,64] embedding is never stored).

@@ -203,7 +203,10 @@ class Backbone(object):
 
     def _forward_hip(self, data, rpn_hook=None):
         if self.stem == 'hip':
-            # repack to padded NHWC4, 7x7/2 conv + bias + ReLU on the MFMA kernel, then pool1
+            # conv1 7x7/2 + bias + ReLU + pool1 in ONE kernel, raw NCHW image -> pooled NHWC map (no conv map in HBM)
+            x = ops.stem_fused(data, self.w_stem, self.b32['conv1'])
+        elif self.stem == 'hip3':
+            # the three-launch form: repack to padded NHWC4, 7x7/2 conv + bias + ReLU on the MFMA kernel, then pool1
             x = ops.stem_conv7(data, self.w_stem, self.b32['conv1'], relu=True)
             x = ops.stem_bias_relu_pool(x, self.zero_bias64)
         else:

@@ -400,7 +400,9 @@ __global__ __launch_bounds__(256) void geometry_bias_bwd_kernel(GeomBwdArgs g) {
   const int hh = l31 & 15;                       // head row supplied by this lane (rows >= 16 are zero)
   const float* Brow = g.bias + (((long)b * 16 + hh) * g.N + i) * g.Mpad;
   const float* Lrow = g.dlog + (((long)b * 16 + hh) * g.N + i) * g.Mpad;
-  const float kLogFloor = logf(1e-6f);
+  // clamped entries (relu(.) <= 1e-6 -> bias == ln 1e-6) carry no gradient.  The margin makes the test robust to how the
+  // forward produced ln 1e-6 (libm logf, or log2 x ln 2 from the matrix-core kernel: last-bit differences around -13.8155)
+  const float kLogFloor = logf(1e-6f) + 1e-3f;
   f32x16 c0, c1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
@@ -455,7 +457,9 @@ __global__ __launch_bounds__(256) void geometry_bias_bwd_mfma_kernel(GeomBwdArgs
   const int comp0 = l31 >> 4, comp1 = 2 + (l31 >> 4), sc = (l31 >> 3) & 1;
   const float rate = 100.0f / g.divisors[l31 & 7];
   const int hh = l31 & 15;
-  const float kLogFloor = logf(1e-6f);
+  // clamped entries (relu(.) <= 1e-6 -> bias == ln 1e-6) carry no gradient.  The margin makes the test robust to how the
+  // forward produced ln 1e-6 (libm logf, or log2 x ln 2 from the matrix-core kernel: last-bit differences around -13.8155)
+  const float kLogFloor = logf(1e-6f) + 1e-3f;
   f32x16 c0, c1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }

@@ -70,3 +70,171 @@ extern "C" int relnet_stem_bias_relu_pool(const void* in, const float* bias, voi
   stem_bias_relu_pool_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(g);
   return check_launch("relnet_stem_bias_relu_pool");
 }
+
+// ---------------------------------------------------------------------------------------
+// Fused stem: conv1 7x7 / 2 (pad 3, Cin = 3) + folded-BN bias + ReLU + pool1 3x3 / 2 (ceil mode) in ONE kernel, from the
+// raw NCHW image to the pooled NHWC bf16 map (reference graph: resnet_v1_101_rcnn_base.py:30-36).  The three-launch path
+// (relnet_stem_pack_input, relnet_stem_conv7, relnet_stem_bias_relu_pool) writes the 64 x 300 x 500 conv map to HBM
+// (1.04 GB at 54 images) and reads it back: 1.07 ms of a 22.4 ms step for 1 % of its FLOPs.  Here a workgroup owns a tile of
+// 8 x 14 POOLED pixels:
+//   * the 39 x 63 input window (17 x 29 conv pixels x stride 2 + 5) is converted to zero-padded NHWC4 bf16 in LDS (20 KB);
+//     K = 7 tap rows x 8 taps x 4 channels = 224 (tap 7 and channel 3 carry zero weights): the 8 k-values of an MFMA
+//     fragment are two neighbouring input pixels = 16 contiguous LDS bytes, so the pixel fragments are read straight from the
+//     window (no im2col image at all) and neighbouring lanes (conv pixels) read neighbouring 16-byte chunks;
+//   * the weights sit in LDS in fragment order (28 KB); D = W x A (lane <-> conv pixel, registers <-> channels) like the
+//     other convolution kernels, same k order as the three-launch path: bit-identical results;
+//   * bias + ReLU + bf16, conv tile -> LDS (64 KB, aliasing window + weights), 3 x 3 max over it, 16-byte stores.
+// ---------------------------------------------------------------------------------------
+namespace relnet {
+
+constexpr int kSfPY = 8, kSfPX = 14;                       // pooled tile
+constexpr int kSfCY = 2 * kSfPY + 1, kSfCX = 2 * kSfPX + 1; // conv tile 17 x 29 = 493 pixels (16 MFMA row tiles)
+constexpr int kSfIY = 2 * kSfCY + 5, kSfIX = 64;           // input window 39 rows x 63 (+1) columns
+constexpr int kSfKS = 14;                                  // k-steps of 16: (tap row 0..6) x (tap pair 0, 1)
+constexpr int kSfOutLd = 64 + 8;                           // conv tile row pitch in LDS (elements): 144 B
+
+struct StemFusedArgs {
+  const void* in; int in_bf16;        // [B, 3, H, W] NCHW fp32 / bf16
+  const unsigned short* w256;         // [64][256] bf16, k = ty * 32 + tx * 4 + c (ops.pack_stem_weight)
+  const float* bias;                  // [64]
+  unsigned short* out;                // [B, Hp, Wp, 64] bf16
+  int B, H, W, Hc, Wc, Hp, Wp, tiles_y, tiles_x;
+};
+
+__global__ __launch_bounds__(512) void stem_fused_kernel(StemFusedArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned short* sIn = (unsigned short*)smem;                                   // [39][64][4]
+  unsigned short* sW = (unsigned short*)(smem + kSfIY * kSfIX * 8);              // [14][2][64 lanes][8]
+  unsigned short* sOut = (unsigned short*)smem;                                  // [512][kSfOutLd] (after the MFMAs)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  int t = blockIdx.x;
+  const int tx = t % g.tiles_x; t /= g.tiles_x;
+  const int ty = t % g.tiles_y;
+  const int b = t / g.tiles_y;
+  const int cy0 = ty * 2 * kSfPY, cx0 = tx * 2 * kSfPX;          // first conv pixel of the tile
+  const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;                // first input pixel of the window (pad 3)
+
+  // ---- weights -> LDS in fragment order: frag (kk, nt), lane l <- W[32 nt + (l & 31)][ty * 32 + (kk & 1) * 16 + 8 (l >> 5) ..]
+  for (int c = tid; c < kSfKS * 2 * 64; c += 512) {
+    const int l = c & 63, nt = (c >> 6) & 1, kk = c >> 7;
+    const int k = (kk >> 1) * 32 + (kk & 1) * 16 + 8 * (l >> 5);
+    *(uint4*)(sW + (long)c * 8) = *(const uint4*)(g.w256 + (32 * nt + (l & 31)) * 256 + k);
+  }
+  // ---- input window -> zero-padded NHWC4 bf16
+  const long plane = (long)g.H * g.W;
+  for (int p = tid; p < kSfIY * kSfIX; p += 512) {
+    const int wy = p / kSfIX, wx = p - wy * kSfIX;
+    const int y = iy0 + wy, x = ix0 + wx;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (wx < kSfIX - 1 && y >= 0 && y < g.H && x >= 0 && x < g.W) {
+      const long o = (long)b * 3 * plane + (long)y * g.W + x;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        v[c] = g.in_bf16 ? bf2f(((const unsigned short*)g.in)[o + c * plane]) : ((const float*)g.in)[o + c * plane];
+    }
+    *(uint2*)(sIn + (long)p * 4) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], 0.f));
+  }
+  __syncthreads();
+
+  // ---- MFMAs: wave w owns conv pixels [64 w, 64 w + 64) (2 column tiles of 32 pixels) x 64 channels (2 row tiles)
+  f32x16 acc[2][2];                                              // [channel tile][pixel tile]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int pbase[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int m = wave * 64 + j * 32 + l31;
+    m = m < kSfCY * kSfCX ? m : 0;                               // rows past the tile: any valid pixel (never stored)
+    const int cy = m / kSfCX, cx = m - cy * kSfCX;
+    pbase[j] = ((2 * cy) * kSfIX + 2 * cx + 2 * half) * 4;       // element offset of tap (0, 2 half) of this conv pixel
+  }
+#pragma unroll
+  for (int kk = 0; kk < kSfKS; ++kk) {
+    const int tyy = kk >> 1, txo = (kk & 1) * 4;
+    bf16x8 wf[2], pf[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wf[i] = *(const bf16x8*)(sW + ((kk * 2 + i) * 64 + lane) * 8);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) pf[j] = *(const bf16x8*)(sIn + pbase[j] + (tyy * kSfIX + txo) * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], pf[j], acc[i][j], 0, 0, 0);
+  }
+  __syncthreads();                                               // window + weights are dead: the conv tile takes their place
+
+  // ---- bias + ReLU + bf16 -> conv tile in LDS.  acc[i][j][r]: channel 32 i + (r & 3) + 8 (r >> 2) + 4 half, pixel = this lane's
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = wave * 64 + j * 32 + l31;
+    const int cy = m / kSfCX, cx = m - cy * kSfCX;
+    const bool live = m < kSfCY * kSfCX && cy0 + cy < g.Hc && cx0 + cx < g.Wc;      // conv pixels outside the map pool as 0
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int ch = 32 * i + 8 * gq + 4 * half;
+        const float4 bv = *(const float4*)(g.bias + ch);
+        float v0 = fmaxf(acc[i][j][4 * gq] + bv.x, 0.f), v1 = fmaxf(acc[i][j][4 * gq + 1] + bv.y, 0.f);
+        float v2 = fmaxf(acc[i][j][4 * gq + 2] + bv.z, 0.f), v3 = fmaxf(acc[i][j][4 * gq + 3] + bv.w, 0.f);
+        if (!live) { v0 = v1 = v2 = v3 = 0.f; }
+        *(uint2*)(sOut + (long)m * kSfOutLd + ch) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      }
+  }
+  __syncthreads();
+
+  // ---- pool1: 3 x 3 / 2 max over the conv tile (all values >= 0: pixels outside the map were stored as 0), 16-byte stores
+  for (int it = tid; it < kSfPY * kSfPX * 8; it += 512) {
+    const int cg = it & 7, pp = it >> 3;
+    const int py = pp / kSfPX, px = pp - py * kSfPX;
+    const int oy = ty * kSfPY + py, ox = tx * kSfPX + px;
+    if (oy >= g.Hp || ox >= g.Wp) continue;
+    float best[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) best[e] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const uint4 v = *(const uint4*)(sOut + (long)((2 * py + dy) * kSfCX + 2 * px + dx) * kSfOutLd + cg * 8);
+        const unsigned int w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          best[2 * e] = fmaxf(best[2 * e], bf2f(w4[e] & 0xffff));
+          best[2 * e + 1] = fmaxf(best[2 * e + 1], bf2f(w4[e] >> 16));
+        }
+      }
+    *(uint4*)(g.out + (((long)b * g.Hp + oy) * g.Wp + ox) * 64 + cg * 8) =
+        make_uint4(pack_bf16x2(best[0], best[1]), pack_bf16x2(best[2], best[3]), pack_bf16x2(best[4], best[5]), pack_bf16x2(best[6], best[7]));
+  }
+}
+
+}  // namespace relnet
+
+// data [B,3,H,W] NCHW (fp32: in_dtype 0, bf16: 1), w256 = ops.pack_stem_weight image [64][256] bf16, bias [64] fp32
+// -> out [B,Hp,Wp,64] bf16 NHWC with Hc = (H + 6 - 7) / 2 + 1, Hp = ceil((Hc - 3) / 2) + 1 (last window starts inside).
+extern "C" int relnet_stem_fused(const void* data, int in_dtype, const void* w256, const float* bias, void* out, int B,
+                                 int H, int W, void* stream) {
+  RELNET_REQUIRE(data && w256 && bias && out, "relnet_stem_fused: null operand");
+  RELNET_REQUIRE(B > 0 && H >= 7 && W >= 7, "relnet_stem_fused: bad shape");
+  RELNET_REQUIRE(((uintptr_t)w256 & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)bias & 15) == 0, "relnet_stem_fused: operands must be 16-byte aligned");
+  StemFusedArgs g;
+  g.in = data; g.in_bf16 = in_dtype == 1; g.w256 = (const unsigned short*)w256; g.bias = bias; g.out = (unsigned short*)out;
+  g.B = B; g.H = H; g.W = W;
+  g.Hc = (H + 6 - 7) / 2 + 1; g.Wc = (W + 6 - 7) / 2 + 1;
+  g.Hp = (g.Hc - 3 + 1) / 2 + 1; g.Wp = (g.Wc - 3 + 1) / 2 + 1;
+  if ((g.Hp - 1) * 2 >= g.Hc) --g.Hp;
+  if ((g.Wp - 1) * 2 >= g.Wc) --g.Wp;
+  g.tiles_y = (g.Hp + kSfPY - 1) / kSfPY; g.tiles_x = (g.Wp + kSfPX - 1) / kSfPX;
+  const size_t lds = (size_t)512 * kSfOutLd * 2;            // 73 728 B: conv tile (>= window 19 968 + weights 28 672)
+  static relnet::PerDeviceOnce attr_once;
+  if (attr_once.first()) hipFuncSetAttribute((const void*)stem_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  stem_fused_kernel<<<(unsigned)((long)B * g.tiles_y * g.tiles_x), 512, lds, (hipStream_t)stream>>>(g);
+  return check_launch("relnet_stem_fused");
+}

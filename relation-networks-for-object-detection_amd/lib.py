@@ -100,6 +100,7 @@ _SIGNATURES = {
     'relnet_lnms_embed': (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_lnms_score': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp]),
+    'relnet_stem_fused': (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'relnet_stem_pack_input': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_stem_conv7': (C.c_int, [_vp, _vp, _vp, _i, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_proposal_target': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),

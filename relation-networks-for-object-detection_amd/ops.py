@@ -481,6 +481,24 @@ def stem_bias_relu_pool(x_nhwc, bias, ksize=3, stride=2):
     return out
 
 
+def stem_fused(data, w256, bias):
+    """data [B,3,H,W] fp32/bf16 NCHW -> relu(pool1(relu(conv1 7x7/2 + bias))) as NHWC bf16 [B,Hp,Wp,64] in ONE kernel
+    (csrc/stem.hip:stem_fused_kernel): bit-identical to stem_conv7(relu=True) + stem_bias_relu_pool(zero bias)."""
+    _chk(data, w256, bias)
+    data = data.contiguous()
+    B, Cin, H, W = data.shape
+    assert Cin == 3 and w256.shape == (64, 256) and w256.dtype == torch.bfloat16 and bias.dtype == torch.float32
+    Hc, Wc = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    Hp, Wp = -(-(Hc - 3) // 2) + 1, -(-(Wc - 3) // 2) + 1
+    if (Hp - 1) * 2 >= Hc:
+        Hp -= 1
+    if (Wp - 1) * 2 >= Wc:
+        Wp -= 1
+    out = torch.empty((B, Hp, Wp, 64), device=data.device, dtype=torch.bfloat16)
+    _lib.call('relnet_stem_fused', data.data_ptr(), _dt(data), w256.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, _stream())
+    return out
+
+
 def pack_stem_weight(w_oihw, dtype=torch.bfloat16, device='cuda'):
     """[Cout, 3, 7, 7] -> [Cout, 256] with k = ty*32 + tx*4 + c (zeros for ty = 7, tx = 7, c = 3)."""
     co = w_oihw.shape[0]

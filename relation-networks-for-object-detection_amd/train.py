@@ -222,8 +222,7 @@ class Trainer(object):
     def _trunk_forward(self, data):
         """Frozen stem + res2, then res3..res5 keeping every ReLU output.  Returns (conv5, conv4, saved units, stage ends)."""
         c = self.cfg
-        x = ops.stem_conv7(data, self.w_stem, self.b_stem, relu=True)
-        x = ops.stem_bias_relu_pool(x, self.zero_bias64)
+        x = ops.stem_fused(data, self.w_stem, self.b_stem)
         saved = []
         conv4 = None
         ends = {}

@@ -325,3 +325,20 @@ def test_benched_trunk_configuration_in_network(rn):
     for k in ('conv4', 'conv5'):
         d = (out['features'][k].float() - ref['features'][k].float()).abs().max().item()
         assert d <= 2e-2 * ref['features'][k].float().abs().max().item(), (k, d)
+
+
+@pytest.mark.parametrize('shape', [(2, 600, 1000), (1, 37, 52), (3, 121, 200), (1, 800, 1024)])
+def test_fused_stem_equals_the_three_launch_stem(rn, shape):
+    """conv1 7x7/2 + bias + ReLU + pool1 in one kernel (no conv map in HBM) == stem_conv7 + stem_bias_relu_pool bit for bit
+    (same k order of the products), incl. image sizes whose last pooling window is clipped; fp32 and bf16 input."""
+    ops, _, _ = rn
+    B, H, W = shape
+    g = torch.Generator().manual_seed(31 + H)
+    x = torch.randn(B, 3, H, W, generator=g).cuda()
+    w = ops.pack_stem_weight(torch.randn(64, 3, 7, 7, generator=g) * 0.1)
+    b = torch.randn(64, generator=g).cuda()
+    want = ops.stem_bias_relu_pool(ops.stem_conv7(x, w, b, relu=True), torch.zeros(64, device='cuda'))
+    got = ops.stem_fused(x, w, b)
+    assert got.shape == want.shape and torch.equal(got, want)
+    got16 = ops.stem_fused(x.to(torch.bfloat16), w, b)
+    assert torch.equal(got16, want)                     # the fp32 image is rounded to bf16 on the way in either way
