@@ -8,6 +8,8 @@ group, index)` (:85-151) and the fc_new_1 -> relation -> fc_new_2 -> relation ->
 [N, M, 64] position embedding is never materialised: the geometry kernel consumes the ROI
 boxes directly, so `position_embedding` is replaced by the rois themselves.
 """
+import math
+
 import torch
 
 from . import ops
@@ -78,8 +80,8 @@ def fused_ok(dtype, M, heads=16):
 def _module_forward(f, mod, bias, M, want_out, want_act, want_logits, vwt_buf=None, rois=None, key_count=None, cache=None):
     """`bias` None + `rois` given: fused geometry + attention kernel (no bias tensor, no logits output).
     key_count [B] int32: per-image number of real keys among the first M rows (ops.relation_attention).
-    cache (dict, training): receives the projections qk [B,N,2d], vwt [B,d,Mpad] and (with want_out) the module output y, so
-    that attention_module_backward does not recompute the forward."""
+    cache (dict, training): receives the projections qk [B,N,2d] and vwt [B,d,Mpad], which attention_module_backward reuses
+    (they do not depend on the geometry weight; the module output is recomputed there, see its comment)."""
     B, N, F = f.shape
     qk = ops.gemm_nt(f.reshape(B * N, F), mod.wqk, mod.bqk).reshape(B, N, -1)
     Mpad = bias.shape[-1] if bias is not None else ops.pad32(M)
@@ -98,7 +100,7 @@ def _module_forward(f, mod, bias, M, want_out, want_act, want_logits, vwt_buf=No
                                resid=f if want_act else None, M=M, want_out=want_out,
                                want_act=want_act, want_logits=want_logits, key_count=key_count)
     if cache is not None:
-        cache.update(qk=qk, vwt=vwt_buf, y=r[0])
+        cache.update(qk=qk, vwt=vwt_buf)
     return r
 
 
@@ -185,21 +187,26 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
     M = N if nongt_dim is None else nongt_dim
     mod = packed or RelationParams(params, index, dtype, f.device)
     wp_t, bp = pack_pair_pos([mod], f.device)
-    # fp32 ln G [B,16,N,Mpad]: bf16 training recomputes it on the matrix cores (the G its forward saw), float32 exactly
-    bias = ops.geometry_bias(bx, wp_t, bp, M, mfma32=(dtype == torch.bfloat16))[0]
+    # fp32 ln G [B,16,N,Mpad], recomputed with float32 libm arithmetic, and the module output y recomputed FROM IT (the
+    # softmax backward needs D = dY.(y - bout) consistent with the softmax weights it re-derives from this G).
+    # Measured and rejected (r03, tools/dbg_geom.py + tests/test_gpu_train_step.py::test_fpn_training_step...): taking G from the
+    # matrix-core kernel (fp16 products, hardware log / sin: |dG| <= 3e-4, 2e-5 on average) or from the forward's own fp16 bias
+    # moves the pair_pos_fc1 gradient by 50 % in norm on rows whose keys are all (nearly) clamped -- there Z = sum_j G_j e^a_j is
+    # ~1e-5 and d pre_j = e^a_j (ds_j - D) / Z turns an absolute G error of 1e-4 into an O(1) change; the reference's
+    # log(max(G, 1e-6)) is that ill-conditioned.  The projections Q|K and VW^T do not depend on G and are
+    # taken from the forward (`cache` of _module_forward).
+    bias = ops.geometry_bias(bx, wp_t, bp, M, fast32=(dtype == torch.bfloat16))[0]
     Mpad = bias.shape[-1]
     d = mod.wqk.shape[0] // 2
     kpad = 64 if dtype == torch.bfloat16 else 16                        # GEMM K granularity
-    # ---- forward values: kept by the training forward (`cache` of _module_forward), else recomputed
-    if cache is not None and cache.get('y') is not None and cache['vwt'].shape[-1] == Mpad:
-        qk, vwt, y = cache['qk'], cache['vwt'], cache['y']
-        q, k = qk[:, :, :d], qk[:, :M, d:]
+    if cache is not None and cache.get('qk') is not None and cache['vwt'].shape[-1] == Mpad:
+        qk, vwt = cache['qk'], cache['vwt']
     else:
         qk = ops.gemm_nt(f.reshape(B * N, Fd), mod.wqk, mod.bqk).reshape(B, N, 2 * d)
-        q, k = qk[:, :, :d], qk[:, :M, d:]
         vwt = torch.zeros((B, d, Mpad), device=f.device, dtype=dtype)
         ops.gemm_nt(mod.wout, f[:, :M, :], out=vwt, n_cols=M)
-        y, _, _ = ops.relation_attention(q, k, vwt, bias, bout=mod.bout, M=M, want_out=True, key_count=key_count)
+    q, k = qk[:, :, :d], qk[:, :M, d:]
+    y, _, _ = ops.relation_attention(q, k, vwt, bias, bout=mod.bout, M=M, want_out=True, key_count=key_count)
     # ---- operand layouts of the backward kernels
     vw = ops.gemm_nt(f[:, :M, :].reshape(B * M, Fd) if M == N else f[:, :M, :].contiguous().reshape(B * M, Fd),
                      mod.wout).reshape(B, M, d)                          # F_K Wout^T, not transposed

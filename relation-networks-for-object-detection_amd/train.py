@@ -415,10 +415,10 @@ class Trainer(object):
         wp_t, bp = pack_pair_pos(mods, self.device)
         bias = ops.geometry_bias(rois_t, wp_t, bp, N, half=True)
         f1 = ops.gemm_nt(pooled2, self.w('fc_new_1'), self.b('fc_new_1')).reshape(B, R, -1)
-        caches = [{}, {}]           # projections + module outputs of the forward, reused by the backward
-        _, x1, _ = _module_forward(f1, mods[0], bias[0], N, True, True, False, key_count=key_count, cache=caches[0])
+        caches = [{}, {}]           # Q|K and VW^T projections of the forward, reused by the backward
+        _, x1, _ = _module_forward(f1, mods[0], bias[0], N, False, True, False, key_count=key_count, cache=caches[0])
         f2 = ops.gemm_nt(x1.reshape(B * R, -1), self.w('fc_new_2'), self.b('fc_new_2')).reshape(B, R, -1)
-        _, x2, _ = _module_forward(f2, mods[1], bias[1], N, True, True, False, key_count=key_count, cache=caches[1])
+        _, x2, _ = _module_forward(f2, mods[1], bias[1], N, False, True, False, key_count=key_count, cache=caches[1])
         cb = ops.gemm_nt(x2.reshape(B * R, -1), self.w('cls_bbox'), self.b('cls_bbox'), out_dtype=torch.float32).reshape(B, R, -1)
         nc = self.num_classes
         cls_score, bbox_pred = cb[:, :, :nc].contiguous(), cb[:, :, nc:].contiguous()
