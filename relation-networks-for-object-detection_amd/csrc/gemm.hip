@@ -31,6 +31,7 @@ struct GemmArgs {
   int n_loop;              // column tiles walked by one workgroup (row-panel mode), >= 1
   int xcd_swizzle;         // 1: remap the linear workgroup id so that every XCD owns a contiguous run of tiles
   const void* Wf;          // optional: W pre-packed in MFMA fragment order (relnet_pack_w_frag), used by gemm_panelw_kernel
+  int korder;              // ring kernels, R*S > 1: 1 = walk k as (channel chunk, tap) instead of (tap, channel chunk) -- see launch_ring
 };
 
 template <typename TOUT> __device__ __forceinline__ void store_out(TOUT* p, float v);
@@ -126,6 +127,12 @@ __device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u
 
 typedef const __attribute__((address_space(1))) void* gas_ptr;
 typedef __attribute__((address_space(3))) void* las_ptr;
+// LDS-direct load issued from inline assembly: the compiler then tracks no LDS-DMA store, so it does not put its own
+// s_waitcnt vmcnt(0) in front of the first ds_read it cannot disambiguate from the DMA destination (which would drain a counted
+// multi-slab pipeline once per slab).  Ordering is entirely by hand at the call sites: counted vmcnt + barrier before a read.
+__device__ __forceinline__ void glds16_asm(const void* src, unsigned lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory", "m0");
+}
 
 // BM x BN workgroup tile, WM x WN waves (each wave: TM x TN MFMA tiles of 32x32), BK = 64,
 // two LDS stages filled by global_load_lds.
@@ -456,9 +463,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
   const unsigned short* arow[A_GROUPS];
   const unsigned short* brow[B_GROUPS];
   int ciy[A_GROUPS], cix[A_GROUPS];
+  // first tile row of staging instruction j of this wave.  SCHED = 2 stages HALF tiles: A half h = rows {wr' * 128 + h * 64 +
+  // [0, 64)} (the rows of quadrant row h of both wave rows), W half h = rows {wc' * 64 + h * 32 + [0, 32)}; instruction
+  // j = 2 h + ii covers rows (wave * 2 + ii) * 8 .. + 7 of the 128-row half.
+  auto a_base_row = [&](int j) {
+    if constexpr (SCHED == 2) { const int idx = (wave * 2 + (j & 1)) * RPI; return (idx >> 6) * 128 + (j >> 1) * 64 + (idx & 63); }
+    else return (wave * A_GROUPS + j) * RPI;
+  };
+  auto b_base_row = [&](int j) {
+    if constexpr (SCHED == 2) { const int idx = (wave * 2 + (j & 1)) * RPI; return (idx >> 5) * 64 + (j >> 1) * 32 + (idx & 31); }
+    else return (wave * B_GROUPS + j) * RPI;
+  };
 #pragma unroll
   for (int j = 0; j < A_GROUPS; ++j) {
-    const int tr_ = (wave * A_GROUPS + j) * RPI + lrow;            // row inside the tile
+    const int tr_ = a_base_row(j) + lrow;                          // row inside the tile
     const int lchunk = lslot ^ ring_swz<BK>(tr_);
     const int gr = m0 + tr_;
     if constexpr (CONV) {
@@ -479,23 +497,28 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
       arow[j] = (gr < g.M) ? A + (long)gr * g.lda + lchunk * 8 : nullptr;
     }
   }
-  for (int nt = 0; nt < g.n_loop; ++nt) {
-  const int n0 = (bx * g.n_loop + nt) * BN;
+  // (SCHED = 2 takes ONE column tile per workgroup: with the row-panel loop around it the epilogue's conditional bias loads are
+  //  still "pending" in the compiler's model at the back edge and it puts an s_waitcnt vmcnt(0) in front of the first ds_read
+  //  that reuses their registers -- inside the k-loop, draining the counted prefetch once per slab)
+  const int n_loop = SCHED == 2 ? 1 : g.n_loop;
+  for (int nt = 0; nt < n_loop; ++nt) {
+  const int n0 = (bx * n_loop + nt) * BN;
   if (n0 >= g.N) break;
   if (nt > 0) __syncthreads();
 #pragma unroll
   for (int j = 0; j < B_GROUPS; ++j) {
-    const int tr_ = (wave * B_GROUPS + j) * RPI + lrow;
+    const int tr_ = b_base_row(j) + lrow;
     const int gr = n0 + tr_;
     brow[j] = (gr < g.N) ? W + (long)gr * g.ldw + (lslot ^ ring_swz<BK>(tr_)) * 8 : nullptr;
   }
   auto stage = [&](int kt, int buf) {
     if constexpr (ABLATE == 2) { if (kt > 0) return; }
-    const int k0 = kt * BK;
+    int k0 = kt * BK;
     int tr = 0, ts = 0, ic0 = k0;
     if constexpr (CONV) {
-      const int tap = k0 / g.cCin;
-      ic0 = k0 - tap * g.cCin;
+      int tap;
+      if (g.korder) { const int nt_ = g.cR * g.cS, ch = kt / nt_; tap = kt - ch * nt_; ic0 = ch * BK; k0 = tap * g.cCin + ic0; }
+      else { tap = k0 / g.cCin; ic0 = k0 - tap * g.cCin; }
       tr = tap / g.cS; ts = tap - tr * g.cS;
     }
     unsigned char* la = lds + buf * STAGE + wave * (A_GROUPS * 1024);
@@ -611,6 +634,140 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
       if (kt + D < nk) stage(kt + D, (kt + D) % NSTAGE);
       compute(kt % NSTAGE);
     }
+  } else if constexpr (SCHED == 2) {
+    // Ping-pong schedule (the guide's 256 x 256 "8-phase" structure, rebuilt here for 32x32x16 MFMAs and implicit-GEMM A rows).
+    // A k-slab is consumed in FOUR phases, one quadrant (64 x 32 of the wave's 128 x 64 outputs, 8 MFMAs) each; a phase is
+    //   L: ds_read the register fragments the quadrant needs, issue ONE half-tile of prefetch (2 global_load_lds), s_waitcnt
+    //   s_barrier;  M: the 8 MFMAs at s_setprio 1;  s_barrier
+    // and the two wave rows (wr = 0 / 1: one wave of each on every SIMD) run half a phase apart (wr = 1 takes one extra barrier
+    // up front), so on every SIMD one wave is in M while the other is in L: LDS reads, address arithmetic and load issue hide
+    // behind the other wave's MFMAs instead of in front of this wave's own.
+    //   staging order S(n): slab n >> 2, kind n & 3 in {A half 0, W half 0, W half 1, A half 1}; phase p = 4 t + q stages
+    //   S(p + 7) -- the LDS holds two whole slabs and 3..6 half tiles (48 - 96 KB per CU) are in flight at any time;
+    //   RAW: the wait of phase 4 t + 3 (vmcnt 6 = the three youngest half tiles may still fly) retires slab t + 1, which is
+    //        first read one phase (two barriers) later;
+    //   WAR: S(p + 7) overwrites the slot of S(p - 1), last read in phase p - 1 at the latest; every phase waits lgkmcnt(0)
+    //        BEFORE its barrier, so those reads have returned on both wave rows before any wave issues phase p's stage.
+    static_assert(BM == 256 && BN == 256 && WM == 2 && WN == 4 && BK == 64 && NSTAGE == 2 && !RESID, "ping-pong schedule: 256 x 256 x 64, 2 x 4 waves");
+    bf16x8 fa[2][4], fb[2][4];                            // A half in use [row fragment][k-step]; both W halves [half][k-step]
+    bool pp_loop = false;                                 // (ablation only)
+    auto stage_half = [&](int t, auto kindc) {             // slab t, kind: 0 = A0, 1 = W0, 2 = W1, 3 = A1
+      constexpr int KIND = decltype(kindc)::value;
+      if (t >= nk) return;
+      if constexpr (ABLATE == 2) { if (pp_loop) return; }
+      int k0 = t * BK, tap_ = 0, ic0 = k0;
+      if constexpr (CONV) {
+        if (g.korder) { const int nt_ = g.cR * g.cS, ch = t / nt_; tap_ = t - ch * nt_; ic0 = ch * BK; k0 = tap_ * g.cCin + ic0; }
+        else { tap_ = k0 / g.cCin; ic0 = k0 - tap_ * g.cCin; }
+      }
+      const unsigned lbase = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(las_ptr)lds + (t & 1) * STAGE);
+      if constexpr (KIND == 0 || KIND == 3) {
+        constexpr int H = KIND == 3 ? 1 : 0;
+        int tr = 0, ts = 0;
+        if constexpr (CONV) { tr = tap_ / g.cS; ts = tap_ - tr * g.cS; }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int j = 2 * H + ii;
+          const void* src;
+          if constexpr (CONV) {
+            const int iy = ciy[j] + tr * g.cDil, ix = cix[j] + ts * g.cDil;
+            const bool ok = (iy >= 0) && (iy < g.cH) && (ix >= 0) && (ix < g.cW);
+            src = ok ? (const void*)(arow[j] + ((long)iy * g.cW + ix) * g.cPix + ic0) : (const void*)g_zero16;
+          } else if constexpr (STEM) {
+            src = (const void*)(arow[j] + (long)(2 * t) * g.cW * 4);
+          } else {
+            src = arow[j] ? (const void*)(arow[j] + k0) : (const void*)g_zero16;
+          }
+          glds16_asm(src, lbase + a_base_row(j) * ROWB);
+        }
+      } else {
+        constexpr int H = KIND - 1;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int j = 2 * H + ii;
+          const void* src = brow[j] ? (const void*)(brow[j] + k0) : (const void*)g_zero16;
+          glds16_asm(src, lbase + BM * ROWB + b_base_row(j) * ROWB);
+        }
+      }
+    };
+    auto read_a = [&](int t, int h) {
+      if constexpr (ABLATE == 1) return;
+      const unsigned char* la = lds + (t & 1) * STAGE;
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) {
+        const int row = wr * 128 + h * 64 + i2 * 32 + (lane & 31);
+        const unsigned char* rp = la + row * ROWB;
+        const int sw = ring_swz<BK>(row);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fa[i2][kk] = *(const bf16x8*)(rp + (((2 * kk + (lane >> 5)) ^ sw) << 4));
+      }
+    };
+    auto read_b = [&](int t, int h) {
+      if constexpr (ABLATE == 1) return;
+      const unsigned char* lb = lds + (t & 1) * STAGE + BM * ROWB;
+      const int row = wc * 64 + h * 32 + (lane & 31);
+      const unsigned char* rp = lb + row * ROWB;
+      const int sw = ring_swz<BK>(row);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) fb[h][kk] = *(const bf16x8*)(rp + (((2 * kk + (lane >> 5)) ^ sw) << 4));
+    };
+    auto quad = [&](auto ac, auto bc) {
+      constexpr int QA = decltype(ac)::value, QB = decltype(bc)::value;
+      if constexpr (ABLATE == 1) return;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+          acc[2 * QA + i2][QB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[QB][kk], fa[i2][kk], acc[2 * QA + i2][QB], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    using k0c = std::integral_constant<int, 0>;
+    using k1c = std::integral_constant<int, 1>;
+    using k2c = std::integral_constant<int, 2>;
+    using k3c = std::integral_constant<int, 3>;
+#define RELNET_PP_SYNC(WAIT)                                           \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    asm volatile(WAIT "\n\ts_barrier" ::: "memory");                   \
+    __builtin_amdgcn_sched_barrier(0);
+#define RELNET_PP_BAR()                                                \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    asm volatile("s_barrier" ::: "memory");                            \
+    __builtin_amdgcn_sched_barrier(0);
+    // prologue: S(0) .. S(6)
+    stage_half(0, k0c{}); stage_half(0, k1c{}); stage_half(0, k2c{}); stage_half(0, k3c{});
+    stage_half(1, k0c{}); stage_half(1, k1c{}); stage_half(1, k2c{});
+    if (nk >= 2) { RELNET_PP_SYNC("s_waitcnt vmcnt(6)") } else { RELNET_PP_SYNC("s_waitcnt vmcnt(0)") }
+    if (wr == 1) { RELNET_PP_BAR() }
+    pp_loop = true;
+    for (int t = 0; t < nk; ++t) {
+      // phase 0: quadrant (0, 0); stages A half 1 of slab t + 1
+      read_a(t, 0); read_b(t, 0);
+      stage_half(t + 1, k3c{});
+      RELNET_PP_SYNC("s_waitcnt lgkmcnt(0)")
+      quad(k0c{}, k0c{});
+      RELNET_PP_BAR()
+      // phase 1: quadrant (0, 1); stages A half 0 of slab t + 2
+      read_b(t, 1);
+      stage_half(t + 2, k0c{});
+      RELNET_PP_SYNC("s_waitcnt lgkmcnt(0)")
+      quad(k0c{}, k1c{});
+      RELNET_PP_BAR()
+      // phase 2: quadrant (1, 1); stages W half 0 of slab t + 2
+      read_a(t, 1);
+      stage_half(t + 2, k1c{});
+      RELNET_PP_SYNC("s_waitcnt lgkmcnt(0)")
+      quad(k1c{}, k1c{});
+      RELNET_PP_BAR()
+      // phase 3: quadrant (1, 0) from registers; stages W half 1 of slab t + 2; retires slab t + 1
+      stage_half(t + 2, k2c{});
+      if (t + 3 <= nk) { RELNET_PP_SYNC("s_waitcnt vmcnt(6)") } else { RELNET_PP_SYNC("s_waitcnt vmcnt(0)") }
+      quad(k1c{}, k0c{});
+      RELNET_PP_BAR()
+    }
+    if (wr == 0) { RELNET_PP_BAR() }
+#undef RELNET_PP_SYNC
+#undef RELNET_PP_BAR
   } else {
     constexpr int KK = BK / 16;
     static_assert(KK % 2 == 0, "two fragment sets alternate per k-step");
@@ -1321,6 +1478,8 @@ static int g_swizzle = 1;        // tuning knob: XCD-aware tile order (0 = plain
 extern "C" void relnet_gemm_force_tile(int t) { g_force_tile = t; }
 extern "C" void relnet_gemm_force_nloop(int n) { g_force_nloop = n; }
 extern "C" void relnet_gemm_set_swizzle(int on) { g_swizzle = on; }
+static int g_korder = 0;         // tuning knob: 1 = (channel chunk, tap) k order + XCD-contiguous row tiles for R*S > 1 ring launches
+extern "C" void relnet_gemm_debug_korder(int on) { g_korder = on; }
 
 template <int BM, int BN, int WM, int WN, int CONV>
 static void launch_cfg(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
@@ -1345,12 +1504,25 @@ static void launch_ring(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
   const int ntile = (g.N + BN - 1) / BN;
   int nloop = g_force_nloop > 0 ? g_force_nloop : g.n_loop;
   const bool swz = g_swizzle && batch == 1 && ntile > 1 && (long)ntile * ((g.M + BM - 1) / BM) >= 16;
-  if (swz && g_force_nloop == 0) nloop = 1;
+  if ((swz && g_force_nloop == 0) || SCHED == 2) nloop = 1;
   if (nloop < 1) nloop = 1;
   if (nloop > ntile) nloop = ntile;
   g.n_loop = nloop;
   dim3 grid((ntile + nloop - 1) / nloop, (g.M + BM - 1) / BM, batch);
   g.xcd_swizzle = (swz && grid.x > 1) ? 1 : 0;
+  g.korder = 0;
+  if constexpr (CONV == 1) {
+    // Spatial convolutions re-read every input pixel once per tap.  In (tap, channel chunk) order the re-reads of one workgroup are
+    // R * S k-slabs apart and the 32 resident workgroups of an XCD stream ~24 MB in between: the 4 MiB L2 has long dropped the
+    // lines and every tap is served by the Infinity Cache (the ~10 TB/s ceiling of the fill-only ablation).  In (channel chunk, tap)
+    // order the nine taps of a 64-channel chunk touch the same ~40 KB per workgroup back to back (1.3 MB per XCD: L2 hits), and with
+    // consecutive row tiles on one XCD neighbouring tiles share their halo rows in that L2 as well.  Same products, different fp32
+    // summation order.
+    if (g_korder && g.cR * g.cS > 1 && g.cCin % BK == 0) {
+      g.korder = 1;
+      if (g_swizzle && batch == 1 && grid.x == 1 && grid.y >= 16) g.xcd_swizzle = 1;
+    }
+  }
   const int nthr = 64 * WM * WN;
   if constexpr (CONV == 1) {
     if (g_ablate && g_ablate <= 2 && out_dtype == RELNET_BF16 && !g.resid) {
@@ -1397,7 +1569,10 @@ static void launch_ring(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
 //                                   15 = 14 with 64-row panels, two workgroups per CU
 // (measured and dropped: tile 8 with FOUR wavefronts of 128x128 -- 4x4 fragments, accumulators in AGPRs, half the LDS fragment
 //  reads per MFMA -- is 20-40 % slower on every layer shape: one wavefront per SIMD cannot cover the LDS / MFMA latencies)
-enum { GEMM_TILE_COUNT = 15 };
+//                                   16 = 8 with the ping-pong (two wave rows half a phase apart) schedule on shortcut-free layers
+// (measured and dropped, r03: 64x64 / 128x64 ring tiles with 3 / 2 k-slabs in flight for the small-batch steps: 20-50 % slower than
+//  tiles 5 / 4 at 1 and 8 images -- four to five resident 2-stage workgroups per CU already cover the load latency)
+enum { GEMM_TILE_COUNT = 16 };
 
 template <int CONV>
 static bool launch_panel(const GemmArgs& g0, int batch, int out_dtype, hipStream_t s, bool use_wf = false, bool occ2 = false) {
@@ -1519,6 +1694,7 @@ static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t
     case 10: launch_ring<256, 128, 4, 2, CONV, 64, 3, 1>(g, batch, out_dtype, s); break;
     case 11: launch_ring<256, 256, 2, 4, CONV, 64, 2, 0, 1>(g, batch, out_dtype, s); break;
     case 12: launch_ring<256, 256, 2, 4, CONV, 64, 2, 1>(g, batch, out_dtype, s); break;
+    case 16: launch_ring<256, 256, 2, 4, CONV, 64, 2, 2>(g, batch, out_dtype, s); break;
     case 13:
       if (!launch_panel<CONV>(g, batch, out_dtype, s)) launch_cfg<256, 256, 2, 4, CONV>(g, batch, out_dtype, s);
       break;
