@@ -653,6 +653,46 @@ struct PsroiBwdArgs {
   float* grad_trans;                                     // fp32 [R, 2*num_classes, part, part] += or nullptr
 };
 
+// One axis of a bin's sample grid: the samples' bilinear corner weights summed per feature cell.  The reference adds
+// (1-dx)(1-dy) diff, (1-dx) dy diff, ... per SAMPLE (deformable_psroi_pooling.cu:249-263); validity (:239-243), clamping and the
+// corner weights are all per axis, so the spp x spp sample sum factors into (sum over valid iw of the x weights) x (sum over valid
+// ih of the y weights): a bin touches n_x * n_y <= (2 spp)^2 distinct cells -- typically 2 x 2 or 3 x 3 -- instead of 4 spp^2
+// atomics.  Entries are kept in registers (static indices, predicated updates).
+struct AxisCells {
+  int cell[8];
+  float wt[8];
+  int n, valid;
+  __device__ __forceinline__ void add(int c, float w) {
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < n && cell[k] == c) { wt[k] += w; found = true; }
+    if (!found) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k == n) { cell[k] = c; wt[k] = w; }
+      ++n;
+    }
+  }
+  __device__ __forceinline__ void build(float start, float sub, int spp, float limit) {
+    n = 0; valid = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { cell[k] = 0; wt[k] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i >= spp) break;
+      float v = start + (float)i * sub;
+      if (v < -0.5f || v > limit - 0.5f) continue;
+      ++valid;
+      v = fminf(fmaxf(v, 0.f), limit - 1.f);
+      const int c0 = (int)floorf(v), c1 = (int)ceilf(v);
+      const float d = v - (float)c0;
+      add(c0, 1.f - d);
+      if (c1 != c0) add(c1, d);
+    }
+  }
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void deformable_psroi_pool_bwd_kernel(PsroiBwdArgs a) {
   const PsroiArgs& g = a.f;
@@ -680,7 +720,49 @@ __global__ __launch_bounds__(256) void deformable_psroi_pool_bwd_kernel(PsroiBwd
     int gh = (int)floorf((float)ph * (float)g.group / (float)g.P);
     gw = min(max(gw, 0), g.group - 1); gh = min(max(gh, 0), g.group - 1);
     const int c = (ctop * g.group + gh) * g.group + gw;
-    // first pass: the forward's sample count (top_count)
+    const T* pc = (const T*)g.data + (long)q.b * g.ds_b + (long)c * g.ds_c;
+    float* gd = a.grad_data + (long)q.b * a.gs_b + (long)c * a.gs_c;
+    const T* gop = (const T*)a.grad_out + (long)n * a.go_r + (long)ctop * a.go_c + (long)ph * a.go_ph + (long)pw * a.go_pw;
+    if (g.spp <= 4) {
+      AxisCells ax, ay;
+      ax.build(wstart, q.sub_w, g.spp, (float)g.W);
+      ay.build(hstart, q.sub_h, g.spp, (float)g.H);
+      const int count = ax.valid * ay.valid;                  // the forward's top_count
+      if (count == 0) continue;
+      const float diff = dld<T>(gop) / (float)count;
+#pragma unroll
+      for (int ky = 0; ky < 8; ++ky) {
+        if (ky >= ay.n) break;
+        float* grow = gd + (long)ay.cell[ky] * a.gs_h;
+        const float wy = ay.wt[ky] * diff;
+#pragma unroll
+        for (int kx = 0; kx < 8; ++kx) {
+          if (kx >= ax.n) break;
+          const float v = ax.wt[kx] * wy;
+          if (v != 0.f) atomicAdd(grow + (long)ax.cell[kx] * a.gs_w, v);
+        }
+      }
+      if (a.grad_trans) {
+        float dtx = 0.f, dty = 0.f;
+        for (int ih = 0; ih < g.spp; ++ih)
+          for (int iw = 0; iw < g.spp; ++iw) {
+            float w = wstart + (float)iw * q.sub_w, h = hstart + (float)ih * q.sub_h;
+            if (w < -0.5f || w > (float)g.W - 0.5f || h < -0.5f || h > (float)g.H - 0.5f) continue;
+            w = fminf(fmaxf(w, 0.f), (float)g.W - 1.f);
+            h = fminf(fmaxf(h, 0.f), (float)g.H - 1.f);
+            const int x0 = (int)floorf(w), x1 = (int)ceilf(w), y0 = (int)floorf(h), y1 = (int)ceilf(h);
+            const float dx = w - (float)x0, dy = h - (float)y0;
+            const float u00 = dld<T>(pc + (long)y0 * g.ds_h + (long)x0 * g.ds_w), u01 = dld<T>(pc + (long)y1 * g.ds_h + (long)x0 * g.ds_w);
+            const float u10 = dld<T>(pc + (long)y0 * g.ds_h + (long)x1 * g.ds_w), u11 = dld<T>(pc + (long)y1 * g.ds_h + (long)x1 * g.ds_w);
+            dtx += (u11 * dy + u10 * (1.f - dy) - u01 * dy - u00 * (1.f - dy)) * g.trans_std * diff * q.roi_w;
+            dty += (u11 * dx + u01 * (1.f - dx) - u10 * dx - u00 * (1.f - dx)) * g.trans_std * diff * q.roi_h;
+          }
+        atomicAdd(a.grad_trans + toff, dtx);
+        atomicAdd(a.grad_trans + toff + (long)g.part * g.part, dty);
+      }
+      continue;
+    }
+    // general sample counts: the reference's per-sample form
     int count = 0;
     for (int ih = 0; ih < g.spp; ++ih)
       for (int iw = 0; iw < g.spp; ++iw) {
@@ -688,10 +770,7 @@ __global__ __launch_bounds__(256) void deformable_psroi_pool_bwd_kernel(PsroiBwd
         if (!(w < -0.5f || w > (float)g.W - 0.5f || h < -0.5f || h > (float)g.H - 0.5f)) ++count;
       }
     if (count == 0) continue;
-    const float gout = dld<T>((const T*)a.grad_out + (long)n * a.go_r + (long)ctop * a.go_c + (long)ph * a.go_ph + (long)pw * a.go_pw);
-    const float diff = gout / (float)count;
-    const T* pc = (const T*)g.data + (long)q.b * g.ds_b + (long)c * g.ds_c;
-    float* gd = a.grad_data + (long)q.b * a.gs_b + (long)c * a.gs_c;
+    const float diff = dld<T>(gop) / (float)count;
     float dtx = 0.f, dty = 0.f;
     for (int ih = 0; ih < g.spp; ++ih)
       for (int iw = 0; iw < g.spp; ++iw) {
