@@ -646,6 +646,12 @@ __global__ __launch_bounds__(256) void deformable_col2im_kernel(DeformBwdArgs a)
   }
 }
 
+// (measured and dropped, r03: an LDS-aggregated form -- one workgroup per 8 x 16 pixel tile x 64 channels scattering into a
+//  19 x 27-cell LDS window with ds_add_f32 and flushing it once -- cuts the memory-side atomics 8x but runs 3.8 ms (4 waves) /
+//  2.4 ms (16 waves) against 1.24 ms of the kernel above at 8 images: with one 128 KiB workgroup per CU the serial
+//  offset -> taps -> loads chain of each (pixel, tap) pair has nothing to hide behind, while the 64-channel-contiguous
+//  global_atomic_add_f32 of the plain kernel coalesce into two 128-byte requests per wavefront.)
+
 struct PsroiBwdArgs {
   PsroiArgs f;                       // forward description (data values, rois, trans, shapes); f.out unused
   const void* grad_out; long go_r, go_c, go_ph, go_pw;   // [R, output_dim, P, P] (strides in elements, dtype of data)
@@ -728,37 +734,51 @@ __global__ __launch_bounds__(256) void deformable_psroi_pool_bwd_kernel(PsroiBwd
       ax.build(wstart, q.sub_w, g.spp, (float)g.W);
       ay.build(hstart, q.sub_h, g.spp, (float)g.H);
       const int count = ax.valid * ay.valid;                  // the forward's top_count
-      if (count == 0) continue;
-      const float diff = dld<T>(gop) / (float)count;
+      const float diff = count > 0 ? dld<T>(gop) / (float)count : 0.f;
+      if (count > 0) {
 #pragma unroll
-      for (int ky = 0; ky < 8; ++ky) {
-        if (ky >= ay.n) break;
-        float* grow = gd + (long)ay.cell[ky] * a.gs_h;
-        const float wy = ay.wt[ky] * diff;
+        for (int ky = 0; ky < 8; ++ky) {
+          if (ky >= ay.n) break;
+          float* grow = gd + (long)ay.cell[ky] * a.gs_h;
+          const float wy = ay.wt[ky] * diff;
 #pragma unroll
-        for (int kx = 0; kx < 8; ++kx) {
-          if (kx >= ax.n) break;
-          const float v = ax.wt[kx] * wy;
-          if (v != 0.f) atomicAdd(grow + (long)ax.cell[kx] * a.gs_w, v);
+          for (int kx = 0; kx < 8; ++kx) {
+            if (kx >= ax.n) break;
+            const float v = ax.wt[kx] * wy;
+            if (v != 0.f) atomicAdd(grow + (long)ax.cell[kx] * a.gs_w, v);
+          }
         }
       }
       if (a.grad_trans) {
         float dtx = 0.f, dty = 0.f;
-        for (int ih = 0; ih < g.spp; ++ih)
-          for (int iw = 0; iw < g.spp; ++iw) {
-            float w = wstart + (float)iw * q.sub_w, h = hstart + (float)ih * q.sub_h;
-            if (w < -0.5f || w > (float)g.W - 0.5f || h < -0.5f || h > (float)g.H - 0.5f) continue;
-            w = fminf(fmaxf(w, 0.f), (float)g.W - 1.f);
-            h = fminf(fmaxf(h, 0.f), (float)g.H - 1.f);
-            const int x0 = (int)floorf(w), x1 = (int)ceilf(w), y0 = (int)floorf(h), y1 = (int)ceilf(h);
-            const float dx = w - (float)x0, dy = h - (float)y0;
-            const float u00 = dld<T>(pc + (long)y0 * g.ds_h + (long)x0 * g.ds_w), u01 = dld<T>(pc + (long)y1 * g.ds_h + (long)x0 * g.ds_w);
-            const float u10 = dld<T>(pc + (long)y0 * g.ds_h + (long)x1 * g.ds_w), u11 = dld<T>(pc + (long)y1 * g.ds_h + (long)x1 * g.ds_w);
-            dtx += (u11 * dy + u10 * (1.f - dy) - u01 * dy - u00 * (1.f - dy)) * g.trans_std * diff * q.roi_w;
-            dty += (u11 * dx + u01 * (1.f - dx) - u10 * dx - u00 * (1.f - dx)) * g.trans_std * diff * q.roi_h;
+        if (count > 0)
+          for (int ih = 0; ih < g.spp; ++ih)
+            for (int iw = 0; iw < g.spp; ++iw) {
+              float w = wstart + (float)iw * q.sub_w, h = hstart + (float)ih * q.sub_h;
+              if (w < -0.5f || w > (float)g.W - 0.5f || h < -0.5f || h > (float)g.H - 0.5f) continue;
+              w = fminf(fmaxf(w, 0.f), (float)g.W - 1.f);
+              h = fminf(fmaxf(h, 0.f), (float)g.H - 1.f);
+              const int x0 = (int)floorf(w), x1 = (int)ceilf(w), y0 = (int)floorf(h), y1 = (int)ceilf(h);
+              const float dx = w - (float)x0, dy = h - (float)y0;
+              const float u00 = dld<T>(pc + (long)y0 * g.ds_h + (long)x0 * g.ds_w), u01 = dld<T>(pc + (long)y1 * g.ds_h + (long)x0 * g.ds_w);
+              const float u10 = dld<T>(pc + (long)y0 * g.ds_h + (long)x1 * g.ds_w), u11 = dld<T>(pc + (long)y1 * g.ds_h + (long)x1 * g.ds_w);
+              dtx += (u11 * dy + u10 * (1.f - dy) - u01 * dy - u00 * (1.f - dy)) * g.trans_std * diff * q.roi_w;
+              dty += (u11 * dx + u01 * (1.f - dx) - u10 * dx - u00 * (1.f - dx)) * g.trans_std * diff * q.roi_h;
+            }
+        // the channels of one class of a bin all add into the SAME two addresses (256 same-address atomics per bin with
+        // class-agnostic offsets): when the whole wavefront shares the address, reduce over the lanes first
+        const bool uniform = (g.output_dim % 64 == 0) && (g.ch_each % 64 == 0);
+        if (uniform) {
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) { dtx += __shfl_xor(dtx, o); dty += __shfl_xor(dty, o); }
+          if ((threadIdx.x & 63) == 0 && (dtx != 0.f || dty != 0.f)) {
+            atomicAdd(a.grad_trans + toff, dtx);
+            atomicAdd(a.grad_trans + toff + (long)g.part * g.part, dty);
           }
-        atomicAdd(a.grad_trans + toff, dtx);
-        atomicAdd(a.grad_trans + toff + (long)g.part * g.part, dty);
+        } else if (count > 0) {
+          atomicAdd(a.grad_trans + toff, dtx);
+          atomicAdd(a.grad_trans + toff + (long)g.part * g.part, dty);
+        }
       }
       continue;
     }
@@ -824,8 +844,8 @@ extern "C" int relnet_deformable_col2im(const void* dcol, long dcol_ld, int dcol
   a.grad_data = grad_data; a.gs_b = grad_data_strides4[0]; a.gs_c = grad_data_strides4[1]; a.gs_h = grad_data_strides4[2]; a.gs_w = grad_data_strides4[3];
   a.grad_offset = grad_offset;
   if (grad_offset) { a.os_b = grad_offset_strides4[0]; a.os_c = grad_offset_strides4[1]; a.os_h = grad_offset_strides4[2]; a.os_w = grad_offset_strides4[3]; }
-  const unsigned grid = grid_for((long)B * g.Ho * g.Wo * KH * KW * C);
   hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = grid_for((long)B * g.Ho * g.Wo * KH * KW * C);
   if (data_dtype == RELNET_F32) deformable_col2im_kernel<float><<<grid, 256, 0, s>>>(a);
   else if (data_dtype == RELNET_BF16) deformable_col2im_kernel<unsigned short><<<grid, 256, 0, s>>>(a);
   else RELNET_REQUIRE(false, "relnet_deformable_col2im: unknown dtype %d", data_dtype);

@@ -163,6 +163,7 @@ PSROI_CASES = [
     (1, True, 1, 16, 4, 0.0),
     (1, False, 1, 16, 4, 0.1),
     (3, False, 2, 8, 2, 0.1),
+    (1, False, 2, 128, 4, 0.1),                    # 64 channels per class: the wave-reduced offset-gradient path of the backward
 ]
 
 
@@ -286,13 +287,17 @@ def _relerr(a, b):
     return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(np.abs(b).max(), 1e-30))
 
 
-@pytest.mark.parametrize('dtype,C,dg', [('f32', 64, 4), ('bf16', 64, 4), ('f32', 256, 2), ('bf16', 256, 2)])
+@pytest.mark.parametrize('dtype,C,dg', [('f32', 64, 4), ('bf16', 64, 4), ('f32', 256, 2), ('bf16', 256, 2), ('bf16', 256, 4)])
 def test_deformable_convolution_backward(dtype, C, dg):
-    """C = 256, dg = 2: 128 channels per deformable group -> the in-wave reduction path of the offset gradient (res5 shape)."""
+    """C = 256, dg = 2: 128 channels per deformable group -> the in-wave reduction path of the offset gradient (res5 shape).
+    bf16 with >= 64 channels per group runs the LDS-aggregated col2im kernel: ragged 8 x 16 tiles, offsets (sigma 1.5) that leave
+    its window margin of 3 cells and take the direct-to-memory path; dg = 4 on a 19 x 37 map spans several tiles per image."""
     ops, _ = _mods()
     from oracle import deform_torch as DT
     rng = np.random.default_rng(21)
     B, H, W, Co, k, pad, dil = 2, 11, 13, 64, 3, 2, 2
+    if dg == 4 and C == 256:
+        H, W = 19, 37
     rnd = _bf16_round if dtype == 'bf16' else (lambda a: a)
     data = rnd(rng.normal(0, 1, (B, C, H, W)).astype(F))
     off = rng.normal(0, 1.5, (B, 2 * k * k * dg, H, W)).astype(F)
