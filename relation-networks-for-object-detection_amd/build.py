@@ -3,6 +3,7 @@
 hipcc cross-compiles without a GPU; the .so is kept in-tree (git-ignored) so that it
 travels to the GPU box with the repo snapshot.
 """
+import fcntl
 import glob
 import hashlib
 import os
@@ -35,6 +36,18 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:
         LAST_ACTION = 'reused'          # sources, flags and compiler unchanged since the library was linked
         return LIB
+    # one builder at a time: the N ranks of `bench.py --gpus N` all call build(); the first one compiles, the others find the
+    # stamp when they get the lock
+    with open(os.path.join(CSRC, '.build_lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:
+            LAST_ACTION = 'reused'
+            return LIB
+        return _compile(dig, verbose)
+
+
+def _compile(dig, verbose):
+    global LAST_ACTION
     LAST_ACTION = 'compiled'
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
@@ -50,10 +63,12 @@ def build(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode()))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    tmp = LIB + '.tmp%d' % os.getpid()
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stdout.decode())
+    os.replace(tmp, LIB)              # a process that has the old library mapped keeps its inode
     with open(STAMP, 'w') as f:
         f.write(dig)
     return LIB
