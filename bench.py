@@ -402,6 +402,31 @@ def main():
                     sys.stderr.write('%-60s calls/step %5.1f avg %8.1f us  per-step %8.3f ms\n' % (
                         k, v['calls'] / min(a.steps, 5), v['avg_ms'] * 1e3, v['total_ms'] / min(a.steps, 5)))
             res['kernels_ms'] = {k: round(v['avg_ms'], 5) for k, v in sorted(ks.items())}
+            # the kernels that decide images/s: per convolution shape of the step, the measured launch time against both roofs
+            # (2 M N K FLOPs on the 2.5 PFLOP/s bf16 MFMA peak; input + output + weight bytes once on 8 TB/s)
+            conv = []
+            n_timed = max(1, min(a.steps, 5))
+            for k, v in timer.summary(by_tag=True).items():
+                nm, _, tag = k.partition(':')
+                if not nm.startswith('relnet_conv2d_nhwc') or not tag.startswith('M'):
+                    continue
+                try:
+                    M_, N_, K_, ks_ = [int(x[1:]) for x in tag.split('_')]
+                except ValueError:
+                    continue
+                sec = v['avg_ms'] * 1e-3
+                byts = 2.0 * (M_ * (K_ // (ks_ * ks_)) + M_ * N_ + N_ * K_)
+                conv.append({'shape': tag, 'launches_per_step': round(v['calls'] / n_timed, 1), 'avg_us': round(v['avg_ms'] * 1e3, 1),
+                             'ms_per_step': round(v['total_ms'] / n_timed, 3), 'tflops': round(2.0 * M_ * N_ * K_ / sec / 1e12, 1),
+                             'mfma_frac': round(2.0 * M_ * N_ * K_ / sec / 1e12 / PEAK_TFLOPS[a.dtype], 3),
+                             'hbm_frac': round(byts / sec / 8e12, 3)})
+            conv.sort(key=lambda c: -c['ms_per_step'])
+            if conv:
+                res['conv_roofline'] = {'note': 'implicit-GEMM convolution launches of the step by shape (M = pixels, N = Cout, K = taps x Cin, k = '
+                                                'kernel size), HIP-event time of an eager re-run; mfma_frac on 2.5 PFLOP/s dense bf16, hbm_frac = '
+                                                '(input + output + weights once) / time / 8 TB/s; the expand / block-boundary layers run in '
+                                                'relnet_bottleneck_chain and are not listed; at >= 4 images the RPN head (N512_K9216) runs on a side stream BESIDE res5a / res5 / '
+                                                'conv_new_1, so those rows are timed while two full-GPU kernels share the CUs', 'top': conv[:8]}
             att = ks.get('relnet_relation_attention_kc') or ks.get('relnet_relation_attention')
             if att:
                 sec = att['avg_ms'] * 1e-3
