@@ -1478,7 +1478,7 @@ static int g_swizzle = 1;        // tuning knob: XCD-aware tile order (0 = plain
 extern "C" void relnet_gemm_force_tile(int t) { g_force_tile = t; }
 extern "C" void relnet_gemm_force_nloop(int n) { g_force_nloop = n; }
 extern "C" void relnet_gemm_set_swizzle(int on) { g_swizzle = on; }
-static int g_korder = 0;         // tuning knob: 1 = (channel chunk, tap) k order + XCD-contiguous row tiles for R*S > 1 ring launches
+static int g_korder = 1;         // tuning knob: 1 = (channel chunk, tap) k order + XCD-contiguous row tiles for R*S > 1 ring launches
 extern "C" void relnet_gemm_debug_korder(int on) { g_korder = on; }
 
 template <int BM, int BN, int WM, int WN, int CONV>

@@ -135,6 +135,11 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so is stale -> loud
         fn.restype = res
         fn.argtypes = args
+    # tuning knobs settable from the environment (A/B runs of the whole step without editing code)
+    if os.environ.get('RELNET_GEMM_KORDER'):
+        lib.relnet_gemm_debug_korder(int(os.environ['RELNET_GEMM_KORDER']))
+    if os.environ.get('RELNET_GEMM_FORCE_TILE'):
+        lib.relnet_gemm_force_tile(int(os.environ['RELNET_GEMM_FORCE_TILE']))
     _lib = lib
     return lib
 
