@@ -383,6 +383,18 @@ int relnet_nms_loss(const float* score, const float* target, float* pos_loss, fl
 int relnet_transpose_2d(const void* in, long in_ld, long in_bs, void* out, long out_ld, long out_bs, int rows,
                         int cols, int batch, int dtype, void* stream);
 
+/* The data-gradient layouts of ALL weights of a training step in ONE launch (MXNet's Convolution / FullyConnected backward
+ * transposes its filter inside the cuDNN / GEMM call; here the copies are refreshed once per step, after the SGD update):
+ *   dst[ci][(taps - 1 - tap) * dst_co + co] = src[co][tap * cin + ci]     bf16; taps = 1: W^T, taps = 9: tap-flipped 3x3 filter.
+ * table: DEVICE array of n descriptors; tile_start = exclusive prefix sum of taps * tiles_co * tiles_ci (64 x 64 tiles);
+ * total_tiles = the sum.  Pad columns co in [cout, dst_co) are never written (zero them once).                            */
+typedef struct relnet_relayout_desc {
+  const void* src; void* dst;
+  int cout, cin, taps, dst_ld;          /* dst_ld = taps * dst_co                                                        */
+  int dst_co, tiles_co, tiles_ci, tile_start;
+} relnet_relayout_desc;
+int relnet_weight_relayout(const void* table, int n, int total_tiles, void* stream);
+
 /* q [B][N][..], k [B][M][..] as in the forward; kt = K^T [B][H*64][>=Mpad] and qt = Q^T, dyt = dY^T
  * [B][H*64][>=Npad] zero padded; vw = F_K Wout^T [B][M][H*64] (not transposed); bias = fp32 log G of the forward;
  * dy / y = gradient / value of the module output [B][N][H*64] (y includes bout).  Writes prob (softmax) and dlog

@@ -85,6 +85,51 @@ __global__ __launch_bounds__(256) void wgrad_accumulate_kernel(const float* part
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// relnet_weight_relayout: the data-gradient layouts of ALL weights of the step in one launch.
+// The data gradient of y = conv(x, W) is a convolution of dy with the tap-flipped, (Cout, Cin)-transposed filter; round 2 / 3
+// produced those copies layer by layer inside the backward pass (87 transposes + ~30 flip / copy launches per step, ~1.2 ms at
+// 8 images).  The weights only change in the SGD kernel, so one grouped launch after it rewrites every copy:
+//   dst[ci][(taps - 1 - tap) * dst_co + co] = src[co][tap * cin + ci]        (taps = 1: a plain transpose, dst_co >= cout zero padded
+//   by the caller's initial memset -- the pad columns are never written)
+// One workgroup = one 64 (co) x 64 (ci) tile of one tap of one problem, found by binary search in the tile prefix of the table.
+// ---------------------------------------------------------------------------------------
+struct RelayoutProblem {            // mirrors relnet_relayout_desc
+  const unsigned short* src; unsigned short* dst;
+  int cout, cin, taps, dst_ld;      // dst_ld = taps * dst_co (elements)
+  int dst_co, tiles_co, tiles_ci, tile_start;
+};
+
+__global__ __launch_bounds__(256) void weight_relayout_kernel(const RelayoutProblem* tab, int n) {
+  __shared__ unsigned short tile[64][66];
+  int lo = 0, hi = n - 1;
+  const int bid = blockIdx.x;
+  while (lo < hi) {                                 // last problem with tile_start <= bid
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].tile_start <= bid) lo = mid; else hi = mid - 1;
+  }
+  const RelayoutProblem p = tab[lo];
+  int t = bid - p.tile_start;
+  const int tci = t % p.tiles_ci; t /= p.tiles_ci;
+  const int tco = t % p.tiles_co;
+  const int tap = t / p.tiles_co;
+  const int co0 = tco * 64, ci0 = tci * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long src_ld = (long)p.taps * p.cin;
+#pragma unroll
+  for (int r = ty; r < 64; r += 4) {
+    const int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < p.cout && ci < p.cin) ? p.src[(long)co * src_ld + (long)tap * p.cin + ci] : (unsigned short)0;
+  }
+  __syncthreads();
+  const int tapf = p.taps - 1 - tap;
+#pragma unroll
+  for (int r = ty; r < 64; r += 4) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < p.cin && co < p.cout) p.dst[(long)ci * p.dst_ld + (long)tapf * p.dst_co + co] = tile[tx][r];
+  }
+}
+
 }  // namespace relnet
 
 using namespace relnet;
@@ -121,4 +166,11 @@ extern "C" int relnet_wgrad_accumulate(const float* parts, int splits, long rows
   blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
   wgrad_accumulate_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(parts, splits, per_split, cols, row_scale, grad);
   return check_launch("relnet_wgrad_accumulate");
+}
+
+// table: DEVICE array of n relnet_relayout_desc (tile_start = exclusive prefix of taps * tiles_co * tiles_ci), total_tiles = their sum
+extern "C" int relnet_weight_relayout(const void* table, int n, int total_tiles, void* stream) {
+  RELNET_REQUIRE(table && n > 0 && total_tiles > 0, "relnet_weight_relayout: empty table");
+  weight_relayout_kernel<<<(unsigned)total_tiles, 256, 0, (hipStream_t)stream>>>((const relnet::RelayoutProblem*)table, n);
+  return relnet::check_launch("relnet_weight_relayout");
 }

@@ -89,6 +89,7 @@ _SIGNATURES = {
     'relnet_debug_tr_probe': (C.c_int, [_vp, _vp]),
     'relnet_gemm_force_tile': (None, [_i]),
     'relnet_gemm_force_nloop': (None, [_i]),
+    'relnet_weight_relayout': (C.c_int, [_vp, _i, _i, _vp]),
     'relnet_gemm_set_swizzle': (None, [_i]),
     'relnet_gemm_debug_korder': (None, [_i]),
     'relnet_gemm_debug_ablate': (None, [_i]),
@@ -112,6 +113,12 @@ _SIGNATURES = {
     'relnet_box_annotator_ohem': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'relnet_nms_multi_target': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
 }
+
+
+class RelayoutDesc(C.Structure):
+    """relnet_relayout_desc (include/relnet_hip.h)."""
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('cout', C.c_int), ('cin', C.c_int), ('taps', C.c_int), ('dst_ld', C.c_int),
+                ('dst_co', C.c_int), ('tiles_co', C.c_int), ('tiles_ci', C.c_int), ('tile_start', C.c_int)]
 
 
 class WgradDesc(C.Structure):

@@ -826,6 +826,60 @@ def transpose_2d(x, out=None, pad_cols_to=1):
     return out
 
 
+class WeightRelayout(object):
+    """Data-gradient copies of a set of bf16 weights, refreshed by ONE launch (relnet_weight_relayout).
+    add(name, w [Cout, taps*Cin], taps, pad_co) registers a weight VIEW (its storage must stay where it is: the trainer's flat
+    bf16 working copy); build() allocates the copies [Cin, taps * pad(Cout)] (zero: the pad columns stay zero) and uploads the
+    descriptor table; run() launches; get(name) returns the copy: W^T for taps = 1, the tap-flipped transposed 3x3 filter
+    ([Cin, 9 * Cout], what the implicit-GEMM convolution of dy needs) for taps = 9."""
+
+    def __init__(self, device):
+        self.device = device
+        self.items = []
+        self.views = {}
+        self.table = None
+
+    def add(self, name, w, taps=1, pad_co=64):
+        assert w.dtype == torch.bfloat16 and w.is_contiguous() and w.shape[1] % taps == 0
+        self.items.append((name, w, taps, pad_co))
+
+    def build(self):
+        if not self.items:
+            return
+        sizes = []
+        for name, w, taps, pad_co in self.items:
+            cout, cin = w.shape[0], w.shape[1] // taps
+            dst_co = (cout + pad_co - 1) // pad_co * pad_co
+            sizes.append((cout, cin, dst_co))
+        total = sum(cin * taps * dst_co for (_, _, taps, _), (cout, cin, dst_co) in zip(self.items, sizes))
+        self.flat = torch.zeros(total + 8 * len(self.items) + 64, device=self.device, dtype=torch.bfloat16)
+        arr = (_lib.RelayoutDesc * len(self.items))()
+        off = 0
+        tile = 0
+        for i, ((name, w, taps, pad_co), (cout, cin, dst_co)) in enumerate(zip(self.items, sizes)):
+            off = (off + 7) // 8 * 8                              # 16-byte aligned copies
+            n = cin * taps * dst_co
+            v = self.flat[off:off + n].view(cin, taps * dst_co)
+            self.views[name] = v
+            d = arr[i]
+            d.src, d.dst = w.data_ptr(), v.data_ptr()
+            d.cout, d.cin, d.taps, d.dst_ld, d.dst_co = cout, cin, taps, taps * dst_co, dst_co
+            d.tiles_co, d.tiles_ci, d.tile_start = (cout + 63) // 64, (cin + 63) // 64, tile
+            tile += taps * d.tiles_co * d.tiles_ci
+            off += n
+        self.total_tiles = tile
+        raw = bytes(memoryview(arr))
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self.n = len(self.items)
+
+    def run(self):
+        if self.table is not None:
+            _lib.call('relnet_weight_relayout', self.table.data_ptr(), self.n, self.total_tiles, _stream(), tag='n%d' % self.n)
+
+    def get(self, name):
+        return self.views.get(name)
+
+
 class WgradQueue(object):
     """Weight-gradient products collected for ONE grouped launch (csrc/wgrad.hip: stream-K over the (layer, tile, slab) units
     of all queued layers).  `add` has the signature of `wgrad_tn`; `flush` launches what is queued.  The queue keeps the

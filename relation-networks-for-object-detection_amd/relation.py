@@ -221,8 +221,10 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
     dqk[:, :, :d] = dq
     dqk[:, :M, d:] = dk
     dvw_t = dvw.to(dtype)
-    wqk_t = ops.transpose_2d(mod.wqk)                                    # [Fd, 2d]
-    wout_t = ops.transpose_2d(mod.wout)                                  # [Fd, d]
+    wqk_t = getattr(mod, 'wqk_t', None)                                  # [Fd, 2d]: the trainer's per-step copies when present
+    wout_t = getattr(mod, 'wout_t', None)                                # [Fd, d]
+    wqk_t = ops.transpose_2d(mod.wqk) if wqk_t is None else wqk_t
+    wout_t = ops.transpose_2d(mod.wout) if wout_t is None else wout_t
     d_f = ops.gemm_nt(dqk.reshape(B * N, 2 * d), wqk_t, out_dtype=torch.float32).reshape(B, N, Fd)
     d_fk = ops.gemm_nt(dvw_t.reshape(B * M, d), wout_t, out_dtype=torch.float32).reshape(B, M, Fd)
     d_f[:, :M] += d_fk

@@ -169,6 +169,16 @@ class Trainer(object):
         self.anchors_host = generate_anchors(c.feat_stride, c.anchor_ratios, c.anchor_scales)      # float64 [A,4], host (kernel argument)
         self.anchors = torch.as_tensor(self.anchors_host, dtype=torch.float64, device=dev)
         self.step_count = 0
+        # data-gradient copies of the weights (W^T, tap-flipped 3x3 filters): ONE grouped launch per step instead of a
+        # transpose / flip / copy per layer inside the backward pass
+        self._relayout = ops.WeightRelayout(dev)
+        for name in self.W.slices:
+            if name.startswith(('pair_pos_fc1', 'nms_pair_pos_fc1', 'nms_rank', 'nms_logit', 'nms_qk', 'nms_linear_out')) \
+                    or name.endswith('_offset'):
+                continue                                    # consumed in other layouts (relation_bwd kernels, padded DCN offset convs)
+            taps = 9 if self.ksize.get(name, 1) == 3 else 1
+            self._relayout.add(name, self.w(name), taps=taps, pad_co=1 if taps == 9 else 64)
+        self._relayout.build()
 
     # ---- accessors ----------------------------------------------------------------------------------------
     def w(self, name):          # bf16 working copy
@@ -176,6 +186,9 @@ class Trainer(object):
 
     def b(self, name):          # fp32 bias
         return self.Bv.view(self.Bv.master, name)
+
+    def wt(self, name):         # data-gradient layout of w(name), refreshed by _relayout.run() at the start of every step
+        return self._relayout.get(name)
 
     def num_trainable(self):
         return sum(int(np.prod(s)) for _, s in self.W.slices.values()) + sum(int(np.prod(s)) for _, s in self.Bv.slices.values())
@@ -275,6 +288,7 @@ class Trainer(object):
         B = data.shape[0]
         self._grad_buckets().reset()
         self.W.grad.zero_(); self.Bv.grad.zero_()
+        self._relayout.run()            # W^T / tap-flipped copies of the current weights for every data-gradient product
         conv5, conv4, saved, _ = self._trunk_forward(data)
         feat = self._conv(conv5, 'conv_new_1', relu=True, bias=self.b('conv_new_1'))
         r = self._conv(conv4, 'rpn_conv_3x3', pad=1, relu=True, bias=self.b('rpn_conv_3x3'))
@@ -325,7 +339,7 @@ class Trainer(object):
             gp = d_pool.view(B * R, 7, 7, -1).permute(0, 3, 1, 2)
             gd1, gtrans = ops.deformable_psroi_pool_bwd(gp, nchw(feat), r5, trans, sc_, feat.shape[3], 1, 7, 7,
                                                         c.dcn_sample_per_part, c.dcn_trans_std, False)
-            d_t0, dw, db = T.linear_bwd(t0f, self.w('offset'), gtrans.view(B * R, -1).to(bt), keep_splits=True, wgrad_to=self._wg('offset'))
+            d_t0, dw, db = T.linear_bwd(t0f, self.w('offset'), gtrans.view(B * R, -1).to(bt), w_t=self.wt('offset'), keep_splits=True, wgrad_to=self._wg('offset'))
             self._add_bgrad('offset', db)
             gd2, _ = ops.deformable_psroi_pool_bwd(d_t0.view(B * R, 7, 7, -1).permute(0, 3, 1, 2), nchw(feat), r5, None, sc_,
                                                    feat.shape[3], 1, 7, 7, c.dcn_sample_per_part, 0.0, True)
@@ -335,10 +349,10 @@ class Trainer(object):
                                       (B, feat.shape[3], feat.shape[1], feat.shape[2]), channels_last=True)
             d_feat = d_feat.permute(0, 2, 3, 1).to(bt)          # NHWC memory already: one conversion pass
         g = T.relu_bwd(d_feat, feat)
-        d_x, dw = T.conv1x1_bwd(conv5, self.w('conv_new_1'), g, keep_splits=True, wgrad_to=self._wg('conv_new_1'))
+        d_x, dw = T.conv1x1_bwd(conv5, self.w('conv_new_1'), g, w_t=self.wt('conv_new_1'), keep_splits=True, wgrad_to=self._wg('conv_new_1'))
         self._add_bgrad('conv_new_1', g.float().sum((0, 1, 2)))
         # RPN head backward (joins the trunk at conv4)
-        g_r, dw = T.conv1x1_bwd(r, self.w('rpn_out'), d_rpn, keep_splits=True, wgrad_to=self._wg('rpn_out'), relu_mask=r)
+        g_r, dw = T.conv1x1_bwd(r, self.w('rpn_out'), d_rpn, w_t=self.wt('rpn_out'), keep_splits=True, wgrad_to=self._wg('rpn_out'), relu_mask=r)
         self._add_bgrad('rpn_out', d_rpn.float().sum((0, 1, 2)))
         d_conv4_rpn, dw = T.conv3x3_bwd(conv4, self._dgrad_w('rpn_conv_3x3', 512), g_r, dil=1, keep_splits=True, wgrad_to=self._wg('rpn_conv_3x3'))
         self._add_bgrad('rpn_conv_3x3', g_r.float().sum((0, 1, 2)))
@@ -372,7 +386,7 @@ class Trainer(object):
                 d_x = inject[nm] if d_x is None else d_x + inject[nm]
             g_out = T.relu_bwd(d_x, o)
             # (ReLU masks of the two inner activations ride in the data-gradient kernels' epilogues)
-            g_y2, dw = T.conv1x1_bwd(y2, self.w(nc_), g_out, keep_splits=True, wgrad_to=self._wg(nc_, self.bn_scale[nc_]), relu_mask=y2)
+            g_y2, dw = T.conv1x1_bwd(y2, self.w(nc_), g_out, w_t=self.wt(nc_), keep_splits=True, wgrad_to=self._wg(nc_, self.bn_scale[nc_]), relu_mask=y2)
             if off is not None:            # deformable branch2b: data + offset gradients, then the offset conv's own backward
                 gd, goff, dw = ops.deformable_conv_bwd(y1.permute(0, 3, 1, 2), off.permute(0, 3, 1, 2), self.w(nb),
                                                        g_y2.permute(0, 3, 1, 2), 3, 1, 2, 2, 4)
@@ -392,12 +406,12 @@ class Trainer(object):
                 g_y1 = T.relu_bwd(d_y1, y1)
             first = (stage == 3 and proj)         # res3a: its input comes from the frozen res2 -> no data gradient
             if proj:
-                d_a, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, stride=stride, need_dx=not first, keep_splits=True, wgrad_to=self._wg(na, self.bn_scale[na]))
-                d_s, dw = T.conv1x1_bwd(x_in, self.w(n1), g_out, stride=stride, need_dx=not first,
+                d_a, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, stride=stride, need_dx=not first, w_t=self.wt(na), keep_splits=True, wgrad_to=self._wg(na, self.bn_scale[na]))
+                d_s, dw = T.conv1x1_bwd(x_in, self.w(n1), g_out, stride=stride, need_dx=not first, w_t=self.wt(n1),
                                         dx_add=d_a if (stride == 1 and not first) else None, keep_splits=True, wgrad_to=self._wg(n1, self.bn_scale[n1]))
                 d_x = None if first else (d_s if stride == 1 else d_s + d_a)
             else:
-                d_x, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, dx_add=g_out, keep_splits=True, wgrad_to=self._wg(na, self.bn_scale[na]))       # identity shortcut
+                d_x, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, dx_add=g_out, w_t=self.wt(na), keep_splits=True, wgrad_to=self._wg(na, self.bn_scale[na]))       # identity shortcut
         self._bucket_ready('res%d' % prev)
 
     def _head_forward_backward(self, pooled2, rois_t, N, label, bbox_target, bbox_weight, im_info, gt_boxes, num_gt, out,
@@ -436,16 +450,16 @@ class Trainer(object):
             out.update(lo)
         # ================= backward =================
         d_cb = torch.cat([d_cls, d_bbox], 2).reshape(B * R, -1).to(bt)
-        d_x2, dw, db = T.linear_bwd(x2.reshape(B * R, -1), self.w('cls_bbox'), d_cb, keep_splits=True, wgrad_to=self._wg('cls_bbox'))
+        d_x2, dw, db = T.linear_bwd(x2.reshape(B * R, -1), self.w('cls_bbox'), d_cb, w_t=self.wt('cls_bbox'), keep_splits=True, wgrad_to=self._wg('cls_bbox'))
         self._add_bgrad('cls_bbox', db)
         if d_x2_lnms is not None:
             d_x2 = d_x2.reshape(B, R, -1)
             d_x2[:, :N] += d_x2_lnms.to(d_x2.dtype)
         d_f2 = self._relation_bwd(2, mods[1], f2, x2, rois_t, d_x2.reshape(B, R, -1), N, key_count, caches[1])
-        d_x1, dw, db = T.linear_bwd(x1.reshape(B * R, -1), self.w('fc_new_2'), d_f2.reshape(B * R, -1), keep_splits=True, wgrad_to=self._wg('fc_new_2'))
+        d_x1, dw, db = T.linear_bwd(x1.reshape(B * R, -1), self.w('fc_new_2'), d_f2.reshape(B * R, -1), w_t=self.wt('fc_new_2'), keep_splits=True, wgrad_to=self._wg('fc_new_2'))
         self._add_bgrad('fc_new_2', db)
         d_f1 = self._relation_bwd(1, mods[0], f1, x1, rois_t, d_x1.reshape(B, R, -1), N, key_count, caches[0])
-        d_pool, dw, db = T.linear_bwd(pooled2, self.w('fc_new_1'), d_f1.reshape(B * R, -1), keep_splits=True, wgrad_to=self._wg('fc_new_1'))
+        d_pool, dw, db = T.linear_bwd(pooled2, self.w('fc_new_1'), d_f1.reshape(B * R, -1), w_t=self.wt('fc_new_1'), keep_splits=True, wgrad_to=self._wg('fc_new_1'))
         self._add_bgrad('fc_new_1', db)
         return d_pool, (x2, f1, cls_score, bbox_pred, labels_ohem, weights_ohem)
 
@@ -529,7 +543,7 @@ class Trainer(object):
         flat = (rank_idx.long() + (torch.arange(B, device=dev) * N).view(B, 1, 1)).view(-1)
         d_emb = torch.zeros((B * N, 128), device=dev, dtype=torch.float32)
         d_emb.index_add_(0, flat, d_x.reshape(-1, 128))                                         # take() backward
-        d_feat, dw, db = T.linear_bwd(feat2, self.w('roi_feat_embedding'), d_emb.to(bt), keep_splits=True, wgrad_to=self._wg('roi_feat_embedding'))
+        d_feat, dw, db = T.linear_bwd(feat2, self.w('roi_feat_embedding'), d_emb.to(bt), w_t=self.wt('roi_feat_embedding'), keep_splits=True, wgrad_to=self._wg('roi_feat_embedding'))
         self._add_bgrad('roi_feat_embedding', db)
         # sort / slice backward -> cls_prob -> softmax backward (background column has no direct gradient)
         d_prob = torch.zeros((B, N, C), device=dev, dtype=torch.float32)
@@ -544,6 +558,9 @@ class Trainer(object):
 
     def _dgrad_w(self, name, cout):
         """[Cout, 9*Cin] packed forward weights -> [Cin, 9*Cout] tap-flipped data-gradient weights."""
+        wt = self.wt(name)
+        if wt is not None:
+            return wt
         w = self.w(name)
         cin = w.shape[1] // 9
         return w.view(cout, 3, 3, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, 9 * cout).contiguous()
@@ -554,6 +571,7 @@ class Trainer(object):
         m = P()
         m.wqk, m.bqk = self.w('qk_%d' % i), self.b('qk_%d' % i)
         m.wout, m.bout = self.w('linear_out_%d' % i), self.b('linear_out_%d' % i)
+        m.wqk_t, m.wout_t = self.wt('qk_%d' % i), self.wt('linear_out_%d' % i)
         m.wp = self.W.view(self.W.master, 'pair_pos_fc1_%d' % i)
         m.bp = self.b('pair_pos_fc1_%d' % i)
         return m
@@ -777,6 +795,7 @@ class FPNTrainer(Trainer):
             raise ValueError("FPN images must be padded to IMAGE_STRIDE 32, got %s" % (tuple(data.shape),))
         self._grad_buckets().reset()
         self.W.grad.zero_(); self.Bv.grad.zero_()
+        self._relayout.run()            # W^T / tap-flipped copies of the current weights for every data-gradient product
         out = {}
         conv5, conv4, saved, ends = self._trunk_forward(data)
         # ---- neck: 1x1 laterals (+bias), nearest 2x upsampling + sum, 3x3 output convs
@@ -824,7 +843,7 @@ class FPNTrainer(Trainer):
             if lvl < 32:       # tops[lvl] = lateral + up2x(tops[2 lvl]): adjoint of nearest upsampling = 2x2 block sums
                 Bh, Hh, Wh, Ch = d_top.shape
                 d_tops[lvl * 2] = d_top.float().view(Bh, Hh // 2, 2, Wh // 2, 2, Ch).sum((2, 4))
-            d_src, dw = T.conv1x1_bwd(src[lvl], self.w(n1), d_top.contiguous(), need_dx=(lvl != 4), keep_splits=True, wgrad_to=self._wg(n1))   # res2c is frozen
+            d_src, dw = T.conv1x1_bwd(src[lvl], self.w(n1), d_top.contiguous(), need_dx=(lvl != 4), w_t=self.wt(n1), keep_splits=True, wgrad_to=self._wg(n1))   # res2c is frozen
             self._add_bgrad(n1, d_top.float().sum((0, 1, 2)))
             if lvl == 32:
                 d_c5 = d_src
