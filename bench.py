@@ -425,7 +425,7 @@ def main():
                 res['conv_roofline'] = {'note': 'implicit-GEMM convolution launches of the step by shape (M = pixels, N = Cout, K = taps x Cin, k = '
                                                 'kernel size), HIP-event time of an eager re-run; mfma_frac on 2.5 PFLOP/s dense bf16, hbm_frac = '
                                                 '(input + output + weights once) / time / 8 TB/s; the expand / block-boundary layers run in '
-                                                'relnet_bottleneck_chain and are not listed; at >= 4 images the RPN head (N512_K9216) runs on a side stream BESIDE res5a / res5 / '
+                                                'relnet_bottleneck_chain and are not listed; the RPN head (N512_K9216) runs on a side stream BESIDE res5a / res5 / '
                                                 'conv_new_1, so those rows are timed while two full-GPU kernels share the CUs', 'top': conv[:8]}
             att = ks.get('relnet_relation_attention_kc') or ks.get('relnet_relation_attention')
             if att:

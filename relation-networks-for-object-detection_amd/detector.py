@@ -7,6 +7,8 @@ Graph: relation_rcnn/symbols/resnet_v1_101_rcnn_attention_1024_pairwise_position
 head of BASELINE config 1) + core/tester.py:148-156,244-277.  Hyper-parameters default to
 experiments/relation_rcnn/cfgs/resnet_v1_101_coco_trainvalminus_rcnn_end2end_relation_8epoch.yaml.
 """
+import os
+
 import torch
 
 from . import ops
@@ -53,6 +55,7 @@ class Detector(object):
         self.cfg = cfg or Config()
         self.dtype, self.device, self.relation, self.im_hw = dtype, device, relation, im_hw
         self.overlap_rpn = True
+        self.overlap_min_images = int(os.environ.get('RELNET_OVERLAP_MIN_IMAGES', '1'))
         self.backbone = Backbone(params, dtype, device, stem=stem, dcn=self.cfg.dcn)
         if self.cfg.dcn:          # FC 12544 -> 2*7*7 offsets (SYM_DCN_RELNMS:1075), columns in (ph, pw, c) order
             self.w_offset = params['offset_weight'][:, fc1_channels_last_perm()].to(device, dtype).contiguous()
@@ -85,8 +88,9 @@ class Detector(object):
         propose = lambda cls, box: propose_batch(cls.float(), box.float(), im_info, self.anchors, c.feat_stride,
                                                  c.rpn_pre_nms_top_n, c.rpn_post_nms_top_n, c.rpn_nms_thresh, c.rpn_min_size,
                                                  im_hw=self.im_hw, softmax_pairs=True, want_num=True)
-        if self.overlap_rpn and self.backbone.impl == 'hip' and B >= 4:   # RPN head + proposal on a side stream, beside res5
-            # (measured: at one image per step the fork / join costs more than the overlap returns: 3.3 -> 4.5 ms)
+        if self.overlap_rpn and self.backbone.impl == 'hip' and B >= self.overlap_min_images:   # RPN head + proposal on a side stream, beside res5
+            # (under hipGraph replay the fork / join are graph edges: at one image per step 3.0 -> 2.75-2.80 ms, at two 3.63 -> 3.30 ms,
+            #  r03 A/B with RELNET_OVERLAP_MIN_IMAGES; round 2's eager-mode measurement had said the opposite)
             f = self.backbone.forward(data, rpn_hook=propose)
             rois, roi_scores, num_kept = f['rpn_hook']
         else:
