@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
   constexpr int STAGE = (BM + BN) * ROWB;
   constexpr int CLD = BN + 4;
   constexpr int BAND = 32 * WM;
-  constexpr int LDS_BYTES = (EPI == 1 || NSTAGE * STAGE > BAND * CLD * 4) ? NSTAGE * STAGE : BAND * CLD * 4;
+  constexpr int LDS_BYTES = SCHED == 4 ? 160 * 1024 : (EPI == 1 || NSTAGE * STAGE > BAND * CLD * 4) ? NSTAGE * STAGE : BAND * CLD * 4;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -633,6 +633,97 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
       else wait_vm_barrier<0>();
       if (kt + D < nk) stage(kt + D, (kt + D) % NSTAGE);
       compute(kt % NSTAGE);
+    }
+  } else if constexpr (SCHED == 4) {
+    // Window schedule for 3x3 / stride 1 layers (host checks the geometry): the k-loop runs (channel chunk, tap); the nine taps of a
+    // 64-channel chunk read the SAME input pixels shifted by ((r - 1) W + (s - 1)) dil, so the A operand of a chunk is staged ONCE
+    // as a window of the flattened pixel axis -- rows [m0 - halo, m0 + 256 + halo), halo = (W + 1) dil -- and every tap reads its
+    // fragments from the window at a row offset; lanes whose tap leaves the image take zeros (a 9-bit mask per fragment row).
+    // L2 -> LDS fill per chunk: 48 KB window + 9 x 32 KB filter slabs instead of 9 x 64 KB.
+    // LDS: window [2][384 rows][128 B] (double buffered over chunks) + filter slab [2][256][128 B] = 160 KB.
+    static_assert(SCHED != 4 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && BK == 64 && NSTAGE == 2 && !RESID && MODE == 1), "window schedule: 256 x 256 x 64 conv tile");
+    constexpr int WROWS = 384, WIN_BYTES = WROWS * ROWB, WSLAB = BN * ROWB;
+    unsigned char* const win = lds;
+    unsigned char* const wsl = lds + 2 * WIN_BYTES;
+    const int halo = (g.cW + 1) * g.cDil;
+    const int hw = g.cH * g.cW;
+    const unsigned short* wsrc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int w = (wave * 6 + j) * RPI + lrow;
+      long gp = (long)m0 - halo + w;
+      gp = gp < 0 ? 0 : (gp >= g.M ? (long)g.M - 1 : gp);              // rows outside the tensor are only ever read by masked taps
+      const int b = (int)(gp / hw), rem = (int)(gp - (long)b * hw);
+      wsrc[j] = A + (long)b * g.cImg + (long)rem * g.cPix + ((lslot ^ ring_swz<BK>(w)) * 8);
+    }
+    unsigned vmask[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int gr = m0 + wr * (BM / WM) + i * 32 + (lane & 31);
+      unsigned mk = 0;
+      if (gr < g.M) {
+        const int rem = gr % hw, oy = rem / g.cW, ox = rem - oy * g.cW;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = oy + (t / 3 - 1) * g.cDil, ix = ox + (t % 3 - 1) * g.cDil;
+          if (iy >= 0 && iy < g.cH && ix >= 0 && ix < g.cW) mk |= 1u << t;
+        }
+      }
+      vmask[i] = mk;
+    }
+    auto stage_win = [&](int chunk, int wb) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        __builtin_amdgcn_global_load_lds((gas_ptr)(wsrc[j] + chunk * BK), (las_ptr)(win + wb * WIN_BYTES + (wave * 6 + j) * 1024), 16, 0, 0);
+    };
+    auto stage_w = [&](int chunk, int tap, int buf) {
+      const int k0 = tap * g.cCin + chunk * BK;
+#pragma unroll
+      for (int j = 0; j < B_GROUPS; ++j) {
+        const void* src = brow[j] ? (const void*)(brow[j] + k0) : (const void*)g_zero16;
+        __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(wsl + buf * WSLAB + (wave * B_GROUPS + j) * 1024), 16, 0, 0);
+      }
+    };
+    auto compute_win = [&](int buf, int wb, int tap) {
+      const int tr = tap / 3, ts = tap - 3 * tr;
+      const int toff = ((tr - 1) * g.cW + (ts - 1)) * g.cDil + halo;
+      const unsigned char* wp = win + wb * WIN_BYTES;
+      const unsigned char* lb = wsl + buf * WSLAB;
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        bf16x8 af[TM], bfr[TN];
+        const int ch = 2 * kk + (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = wr * (BM / WM) + i * 32 + (lane & 31) + toff;
+          const bf16x8 v = *(const bf16x8*)(wp + row * ROWB + ((ch ^ ring_swz<BK>(row)) << 4));
+          const short m = (short)-(int)((vmask[i] >> tap) & 1u);
+          af[i] = v & m;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = wc * (BN / WN) + j * 32 + (lane & 31);
+          bfr[j] = *(const bf16x8*)(lb + row * ROWB + ((ch ^ ring_swz<BK>(row)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+    };
+    const int nchunk = g.cCin / BK;
+    stage_win(0, 0);
+    stage_w(0, 0, 0);
+    int kt = 0;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+      for (int tap = 0; tap < 9; ++tap, ++kt) {
+        wait_vm_barrier<0>();                 // this slab (and, at tap 0, this chunk's window) has landed; every wave is past slab kt - 1
+        if (tap < 8) stage_w(chunk, tap + 1, (kt + 1) & 1);
+        else if (chunk + 1 < nchunk) stage_w(chunk + 1, 0, (kt + 1) & 1);
+        if (tap == 0 && chunk + 1 < nchunk) stage_win(chunk + 1, (chunk + 1) & 1);   // that buffer was last read in chunk - 1
+        compute_win(kt & 1, chunk & 1, tap);
+      }
     }
   } else if constexpr (SCHED == 2) {
     // Ping-pong schedule (the guide's 256 x 256 "8-phase" structure, rebuilt here for 32x32x16 MFMAs and implicit-GEMM A rows).
@@ -1572,7 +1663,9 @@ static void launch_ring(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
 //                                   16 = 8 with the ping-pong (two wave rows half a phase apart) schedule on shortcut-free layers
 // (measured and dropped, r03: 64x64 / 128x64 ring tiles with 3 / 2 k-slabs in flight for the small-batch steps: 20-50 % slower than
 //  tiles 5 / 4 at 1 and 8 images -- four to five resident 2-stage workgroups per CU already cover the load latency)
-enum { GEMM_TILE_COUNT = 16 };
+//                                   17 = 8 with the A operand of 3x3 / stride-1 layers staged once per channel chunk as a pixel WINDOW shared by
+//                                        the nine taps (other shapes under 17 run configuration 8)
+enum { GEMM_TILE_COUNT = 17 };
 
 template <int CONV>
 static bool launch_panel(const GemmArgs& g0, int batch, int out_dtype, hipStream_t s, bool use_wf = false, bool occ2 = false) {
@@ -1695,6 +1788,16 @@ static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t
     case 11: launch_ring<256, 256, 2, 4, CONV, 64, 2, 0, 1>(g, batch, out_dtype, s); break;
     case 12: launch_ring<256, 256, 2, 4, CONV, 64, 2, 1>(g, batch, out_dtype, s); break;
     case 16: launch_ring<256, 256, 2, 4, CONV, 64, 2, 2>(g, batch, out_dtype, s); break;
+    case 17:
+      if constexpr (CONV == 1) {
+        if (!g.resid && batch == 1 && g.cR == 3 && g.cS == 3 && g.cStride == 1 && g.cPad == g.cDil && g.cCin % 64 == 0 &&
+            256 + 2 * (g.cW + 1) * g.cDil <= 384 && g.cImg % 8 == 0 && g.cHout == g.cH && g.cWout == g.cW) {
+          launch_ring<256, 256, 2, 4, CONV, 64, 2, 4>(g, batch, out_dtype, s);
+          break;
+        }
+      }
+      launch_ring<256, 256, 2, 4, CONV, 64, 2>(g, batch, out_dtype, s);
+      break;
     case 13:
       if (!launch_panel<CONV>(g, batch, out_dtype, s)) launch_cfg<256, 256, 2, 4, CONV>(g, batch, out_dtype, s);
       break;
