@@ -727,18 +727,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
     }
   } else if constexpr (SCHED == 2) {
     // Ping-pong schedule (the guide's 256 x 256 "8-phase" structure, rebuilt here for 32x32x16 MFMAs and implicit-GEMM A rows).
-    // A k-slab is consumed in FOUR phases, one quadrant (64 x 32 of the wave's 128 x 64 outputs, 8 MFMAs) each; a phase is
-    //   L: ds_read the register fragments the quadrant needs, issue ONE half-tile of prefetch (2 global_load_lds), s_waitcnt
-    //   s_barrier;  M: the 8 MFMAs at s_setprio 1;  s_barrier
+    // A k-slab is consumed in phases of one or two quadrants (64 x 32 of the wave's 128 x 64 outputs, 8 MFMAs each); a phase is
+    //   L: ds_read the register fragments it needs, issue its share of the prefetch (LDS-direct loads of half tiles), s_waitcnt,
+    //   s_barrier;  M: the MFMAs at s_setprio 1;  s_barrier
     // and the two wave rows (wr = 0 / 1: one wave of each on every SIMD) run half a phase apart (wr = 1 takes one extra barrier
     // up front), so on every SIMD one wave is in M while the other is in L: LDS reads, address arithmetic and load issue hide
     // behind the other wave's MFMAs instead of in front of this wave's own.
-    //   staging order S(n): slab n >> 2, kind n & 3 in {A half 0, W half 0, W half 1, A half 1}; phase p = 4 t + q stages
-    //   S(p + 7) -- the LDS holds two whole slabs and 3..6 half tiles (48 - 96 KB per CU) are in flight at any time;
-    //   RAW: the wait of phase 4 t + 3 (vmcnt 6 = the three youngest half tiles may still fly) retires slab t + 1, which is
-    //        first read one phase (two barriers) later;
-    //   WAR: S(p + 7) overwrites the slot of S(p - 1), last read in phase p - 1 at the latest; every phase waits lgkmcnt(0)
-    //        BEFORE its barrier, so those reads have returned on both wave rows before any wave issues phase p's stage.
+    //   staging order S(n): slab n >> 2, kind n & 3 in {A half 0, W half 0, W half 1, A half 1}; the LDS holds two whole slabs
+    //   and 3..4 half tiles are in flight at every wait (counted vmcnt, never 0 in steady state);
+    //   WAR: a slot is re-staged one phase after its last read at the earliest; every phase waits lgkmcnt(0) BEFORE its barrier,
+    //        so those reads have returned on both wave rows before any wave issues the next phase's stage.
     static_assert(BM == 256 && BN == 256 && WM == 2 && WN == 4 && BK == 64 && NSTAGE == 2 && !RESID, "ping-pong schedule: 256 x 256 x 64, 2 x 4 waves");
     bf16x8 fa[2][4], fb[2][4];                            // A half in use [row fragment][k-step]; both W halves [half][k-step]
     bool pp_loop = false;                                 // (ablation only)
@@ -825,35 +823,30 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);                                 \
     asm volatile("s_barrier" ::: "memory");                            \
     __builtin_amdgcn_sched_barrier(0);
-    // prologue: S(0) .. S(6)
+    // TWO phases per slab (16 MFMAs = 512 MFMA-pipe cycles each, against ~16 ds_reads + LDS latency of the other wave row's L part;
+    // the first version ran four 8-MFMA phases and its L parts were LONGER than the M parts: PMC, profiles/r03_conv3x3_pmc.json):
+    //   phase 2t    : L = A half 0 + both W halves of slab t (16 reads), stage S(4t + 6), S(4t + 7); M = quadrants (0,0), (0,1)
+    //   phase 2t + 1: L = A half 1 (8 reads),                           stage S(4t + 8), S(4t + 9); M = quadrants (1,0), (1,1)
+    // i.e. phase p stages S(2p + 6), S(2p + 7) into the slots of S(2p - 2), S(2p - 1), last read in phase p - 1 at the latest.
+    // RAW: even phases wait vmcnt(8) (A half 1 of this slab = S(4t + 3) must have landed, the four younger half tiles may fly),
+    //      odd phases vmcnt(6) (slab t + 1's A0 / W0 / W1 = S(4t + 4 .. 6) landed, three younger in flight).
     stage_half(0, k0c{}); stage_half(0, k1c{}); stage_half(0, k2c{}); stage_half(0, k3c{});
-    stage_half(1, k0c{}); stage_half(1, k1c{}); stage_half(1, k2c{});
+    stage_half(1, k0c{}); stage_half(1, k1c{});
     if (nk >= 2) { RELNET_PP_SYNC("s_waitcnt vmcnt(6)") } else { RELNET_PP_SYNC("s_waitcnt vmcnt(0)") }
     if (wr == 1) { RELNET_PP_BAR() }
     pp_loop = true;
     for (int t = 0; t < nk; ++t) {
-      // phase 0: quadrant (0, 0); stages A half 1 of slab t + 1
-      read_a(t, 0); read_b(t, 0);
-      stage_half(t + 1, k3c{});
-      RELNET_PP_SYNC("s_waitcnt lgkmcnt(0)")
+      read_a(t, 0); read_b(t, 0); read_b(t, 1);
+      stage_half(t + 1, k2c{}); stage_half(t + 1, k3c{});
+      if (t + 2 <= nk) { RELNET_PP_SYNC("s_waitcnt vmcnt(8) lgkmcnt(0)") } else { RELNET_PP_SYNC("s_waitcnt vmcnt(0) lgkmcnt(0)") }
       quad(k0c{}, k0c{});
-      RELNET_PP_BAR()
-      // phase 1: quadrant (0, 1); stages A half 0 of slab t + 2
-      read_b(t, 1);
-      stage_half(t + 2, k0c{});
-      RELNET_PP_SYNC("s_waitcnt lgkmcnt(0)")
       quad(k0c{}, k1c{});
       RELNET_PP_BAR()
-      // phase 2: quadrant (1, 1); stages W half 0 of slab t + 2
       read_a(t, 1);
-      stage_half(t + 2, k1c{});
-      RELNET_PP_SYNC("s_waitcnt lgkmcnt(0)")
-      quad(k1c{}, k1c{});
-      RELNET_PP_BAR()
-      // phase 3: quadrant (1, 0) from registers; stages W half 1 of slab t + 2; retires slab t + 1
-      stage_half(t + 2, k2c{});
-      if (t + 3 <= nk) { RELNET_PP_SYNC("s_waitcnt vmcnt(6)") } else { RELNET_PP_SYNC("s_waitcnt vmcnt(0)") }
+      stage_half(t + 2, k0c{}); stage_half(t + 2, k1c{});
+      if (t + 3 <= nk) { RELNET_PP_SYNC("s_waitcnt vmcnt(6) lgkmcnt(0)") } else { RELNET_PP_SYNC("s_waitcnt vmcnt(0) lgkmcnt(0)") }
       quad(k1c{}, k0c{});
+      quad(k1c{}, k1c{});
       RELNET_PP_BAR()
     }
     if (wr == 0) { RELNET_PP_BAR() }

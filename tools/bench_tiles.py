@@ -24,6 +24,8 @@ def timeit(fn, iters=8):
 def conv_case(H, W, Cin, Cout, k, dil, resid, stride=1):
     x = torch.randn(B, H, W, Cin, device='cuda').to(torch.bfloat16)
     w = (torch.randn(Cout, k * k * Cin, device='cuda') * 0.03).to(torch.bfloat16)
+    if os.environ.get('ZERO_OPERANDS'):          # data-dependent power: the same launches on all-zero operands
+        x.zero_(); w.zero_()
     b = torch.randn(Cout, device='cuda')
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     r = torch.randn(B, Ho, Wo, Cout, device='cuda').to(torch.bfloat16) if resid else None
