@@ -749,8 +749,12 @@ class CapturedStep(object):
                 self.out = trainer.forward_backward(*batch, **(kwargs or {}))
             finally:
                 trainer._capture_cut = None
-                cur[0].capture_end()
-            self.segments.append((cur[0], None))
+                import warnings
+                with warnings.catch_warnings(record=True) as caught:      # the tail after the last bucket is usually empty
+                    warnings.simplefilter('always')
+                    cur[0].capture_end()
+            if not any('Graph is empty' in str(w.message) for w in caught):
+                self.segments.append((cur[0], None))
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
 
