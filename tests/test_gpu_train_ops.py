@@ -191,3 +191,37 @@ def test_wgrad_tn_matches_float64(case):
         for o, (dy_, x_) in ((o0, other[0]), (o1, other[1])):
             w_ = dy_.double().t().cpu() @ x_.double().cpu()
             assert (o.double().cpu() - w_).abs().max().item() <= 2e-5 * w_.abs().max().item(), (case, blocks)
+
+
+def test_weight_relayout_one_launch_for_all_layers():
+    """relnet_weight_relayout (the data-gradient copies of every weight of a step in one grouped launch) against the torch
+    definition: taps = 1 -> W^T zero padded to 64 output channels ([Cin, pad(Cout)], what linear_bwd / conv1x1_bwd take as w_t),
+    taps = 9 -> the tap-flipped, (Cout, Cin)-transposed 3x3 filter [Cin, 9 * Cout] (what conv3x3_bwd convolves dy with).
+    Ragged shapes: 72 / 89 output channels (rpn_out, cls_score | bbox_pred), Cin not a multiple of 64, many problems so that
+    the tile -> problem binary search crosses every boundary; and a refresh after the source changed (views, not copies)."""
+    ops, _ = _mods()
+    torch.manual_seed(5)
+    shapes = [(256, 1024, 1), (72, 512, 1), (89, 1024, 1), (256, 256, 9), (512, 512, 9), (1024, 256, 1), (64, 96, 1),
+              (128, 128, 9), (2048, 512, 1), (24, 40, 9)]
+    flat = torch.randn(sum(co * ci * t for co, ci, t in shapes), device='cuda').to(torch.bfloat16)
+    rl = ops.WeightRelayout('cuda')
+    views, off = [], 0
+    for i, (co, ci, t) in enumerate(shapes):
+        v = flat[off:off + co * ci * t].view(co, t * ci); off += co * ci * t
+        views.append(v)
+        rl.add('w%d' % i, v, taps=t, pad_co=1 if t == 9 else 64)
+    rl.build()
+    for rnd in range(2):
+        if rnd == 1:
+            flat.copy_(torch.randn_like(flat.float()).to(torch.bfloat16))          # "SGD update": same storage, new values
+        rl.run()
+        for i, (co, ci, t) in enumerate(shapes):
+            got = rl.get('w%d' % i)
+            w = views[i]
+            if t == 1:
+                want = torch.zeros(ci, (co + 63) // 64 * 64, device='cuda', dtype=torch.bfloat16)
+                want[:, :co] = w.t()
+            else:
+                want = w.view(co, 3, 3, ci).flip(1, 2).permute(3, 1, 2, 0).reshape(ci, 9 * co)
+            assert got.shape == want.shape, (i, got.shape, want.shape)
+            assert torch.equal(got, want), (i, shapes[i], rnd)
