@@ -127,7 +127,11 @@ def test_detector_fp32_stagewise(rn, relation):
     if not has_tie:
         np.testing.assert_allclose(got, flat.astype(np.float32), rtol=1e-5)
     else:
-        assert not relation, "the relation head should separate co-quantised rois"
+        # co-quantised rois = two IDENTICAL probability rows (all 81 classes); a single equal fp32 value in one class among
+        # 100 rois x 80 classes is a coincidence (~2 M representable values in the spread of one class, ~4e5 pairs: it happens on
+        # some boxes / convolution algorithms) and only makes the order of those two entries unspecified
+        row_tie = len(np.unique(prob0, axis=0)) < len(prob0)
+        assert not (relation and row_tie), "the relation head should separate co-quantised rois"
         np.testing.assert_allclose(got[uniq][:, 1], flat[uniq][:, 1].astype(np.float32), rtol=1e-5)
 
 
