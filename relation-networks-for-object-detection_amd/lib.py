@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'librelnet_hip.so')
+LIB_PATH = os.environ.get('RELNET_LIB') or os.path.join(HERE, 'librelnet_hip.so')      # (RELNET_LIB: A/B against another build)
 
 F32, BF16 = 0, 1
 
