@@ -101,6 +101,9 @@ def _module_forward(f, mod, bias, M, want_out, want_act, want_logits, vwt_buf=No
                                want_act=want_act, want_logits=want_logits, key_count=key_count)
     if cache is not None:
         cache.update(qk=qk, vwt=vwt_buf)
+        if bias.dtype == torch.float32 and want_out and not want_logits:
+            # training forward on the float32 geometry: the backward reuses ln G and the module output instead of recomputing them
+            cache.update(bias=bias, y=r[0])
     return r
 
 
@@ -187,15 +190,17 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
     M = N if nongt_dim is None else nongt_dim
     mod = packed or RelationParams(params, index, dtype, f.device)
     wp_t, bp = pack_pair_pos([mod], f.device)
-    # fp32 ln G [B,16,N,Mpad], recomputed with float32 libm arithmetic, and the module output y recomputed FROM IT (the
-    # softmax backward needs D = dY.(y - bout) consistent with the softmax weights it re-derives from this G).
+    # fp32 ln G [B,16,N,Mpad] in float32 libm arithmetic and the module output y computed FROM IT (the softmax backward needs
+    # D = dY.(y - bout) consistent with the softmax weights it re-derives from this G): taken from the training forward when it ran
+    # on that geometry (`cache` holds bias / y / qk / vwt), recomputed otherwise.
     # Measured and rejected (r03, tools/dbg_geom.py + tests/test_gpu_train_step.py::test_fpn_training_step...): taking G from the
     # matrix-core kernel (fp16 products, hardware log / sin: |dG| <= 3e-4, 2e-5 on average) or from the forward's own fp16 bias
     # moves the pair_pos_fc1 gradient by 50 % in norm on rows whose keys are all (nearly) clamped -- there Z = sum_j G_j e^a_j is
     # ~1e-5 and d pre_j = e^a_j (ds_j - D) / Z turns an absolute G error of 1e-4 into an O(1) change; the reference's
     # log(max(G, 1e-6)) is that ill-conditioned.  The projections Q|K and VW^T do not depend on G and are
     # taken from the forward (`cache` of _module_forward).
-    bias = ops.geometry_bias(bx, wp_t, bp, M, fast32=(dtype == torch.bfloat16))[0]
+    have = cache is not None and cache.get('bias') is not None and cache.get('y') is not None and cache.get('qk') is not None
+    bias = cache['bias'] if have else ops.geometry_bias(bx, wp_t, bp, M, fast32=(dtype == torch.bfloat16))[0]
     Mpad = bias.shape[-1]
     d = mod.wqk.shape[0] // 2
     kpad = 64 if dtype == torch.bfloat16 else 16                        # GEMM K granularity
@@ -206,7 +211,7 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
         vwt = torch.zeros((B, d, Mpad), device=f.device, dtype=dtype)
         ops.gemm_nt(mod.wout, f[:, :M, :], out=vwt, n_cols=M)
     q, k = qk[:, :, :d], qk[:, :M, d:]
-    y, _, _ = ops.relation_attention(q, k, vwt, bias, bout=mod.bout, M=M, want_out=True, key_count=key_count)
+    y = cache['y'] if have else ops.relation_attention(q, k, vwt, bias, bout=mod.bout, M=M, want_out=True, key_count=key_count)[0]
     # ---- operand layouts of the backward kernels
     vw = ops.gemm_nt(f[:, :M, :].reshape(B * M, Fd) if M == N else f[:, :M, :].contiguous().reshape(B * M, Fd),
                      mod.wout).reshape(B, M, d)                          # F_K Wout^T, not transposed

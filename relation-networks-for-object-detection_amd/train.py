@@ -427,12 +427,14 @@ class Trainer(object):
         bt = torch.bfloat16
         mods = [self._rel_params(i) for i in (1, 2)]
         wp_t, bp = pack_pair_pos(mods, self.device)
-        bias = ops.geometry_bias(rois_t, wp_t, bp, N, half=True)
+        # float32 ln G for the training forward (not the fp16 matrix-core bias of inference): the backward needs exactly this G
+        # and the outputs computed from it (relation.attention_module_backward), so they are produced once, here
+        bias = ops.geometry_bias(rois_t, wp_t, bp, N, fast32=True)
         f1 = ops.gemm_nt(pooled2, self.w('fc_new_1'), self.b('fc_new_1')).reshape(B, R, -1)
         caches = [{}, {}]           # Q|K and VW^T projections of the forward, reused by the backward
-        _, x1, _ = _module_forward(f1, mods[0], bias[0], N, False, True, False, key_count=key_count, cache=caches[0])
+        _, x1, _ = _module_forward(f1, mods[0], bias[0], N, True, True, False, key_count=key_count, cache=caches[0])
         f2 = ops.gemm_nt(x1.reshape(B * R, -1), self.w('fc_new_2'), self.b('fc_new_2')).reshape(B, R, -1)
-        _, x2, _ = _module_forward(f2, mods[1], bias[1], N, False, True, False, key_count=key_count, cache=caches[1])
+        _, x2, _ = _module_forward(f2, mods[1], bias[1], N, True, True, False, key_count=key_count, cache=caches[1])
         cb = ops.gemm_nt(x2.reshape(B * R, -1), self.w('cls_bbox'), self.b('cls_bbox'), out_dtype=torch.float32).reshape(B, R, -1)
         nc = self.num_classes
         cls_score, bbox_pred = cb[:, :, :nc].contiguous(), cb[:, :, nc:].contiguous()
@@ -508,7 +510,7 @@ class Trainer(object):
         mod.bp = self.b('nms_pair_pos_fc1_1')
         wp_t, bp = pack_pair_pos([mod], dev)
         cb = class_boxes.view(BC, F, 4)
-        bias = ops.geometry_bias(cb, wp_t, bp, F, half=True)[0]
+        bias = ops.geometry_bias(cb, wp_t, bp, F, fast32=True)[0]
         lcache = {}
         att, _, _ = _module_forward(xr, mod, bias, F, True, False, False, cache=lcache)         # [BC,F,1024]
         att128 = att.view(BC, F, 16, 64)[..., :8].reshape(BC, F, 128)
