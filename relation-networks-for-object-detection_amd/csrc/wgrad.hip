@@ -125,6 +125,29 @@ __global__ __launch_bounds__(128 * WM) void wgrad_streamk_kernel(const WgradProb
     const int off_y = tap_r * a.dil - a.pad, off_x = tap_s * a.dil - a.pad;
 
     uint4 ra[kApass], rb[kBpass];
+    // implicit im2col rows: (image, y, x) of this thread's pixel of every pass, divided out ONCE per share and then advanced by
+    // 64 pixels per slab with adds / compares (two integer divisions per 16-byte load made the address stream of the 3x3
+    // problems cost as many VALU cycles as the slab's MFMAs)
+    int cimg[kBpass], cyx[kBpass];                           // y << 16 | x
+    const int step_y = kWgBP / a.Wout, step_x = kWgBP - step_y * a.Wout;
+    if (a.conv) {
+#pragma unroll
+      for (int i = 0; i < kBpass; ++i) {
+        const int p = p_begin + rb0 + kBrows * i;
+        const int bimg = p / hw, rem = p - bimg * hw;
+        const int y = rem / a.Wout;
+        cimg[i] = bimg; cyx[i] = (y << 16) | (rem - y * a.Wout);
+      }
+    }
+    auto advance = [&]() {
+#pragma unroll
+      for (int i = 0; i < kBpass; ++i) {
+        int y = (cyx[i] >> 16) + step_y, xx = (cyx[i] & 0xffff) + step_x;
+        if (xx >= a.Wout) { xx -= a.Wout; ++y; }
+        while (y >= a.Hout) { y -= a.Hout; ++cimg[i]; }
+        cyx[i] = (y << 16) | xx;
+      }
+    };
     auto fetch = [&](int p0) {
 #pragma unroll
       for (int i = 0; i < kApass; ++i) {
@@ -140,8 +163,7 @@ __global__ __launch_bounds__(128 * WM) void wgrad_streamk_kernel(const WgradProb
           if (!a.conv) {
             rb[i] = ldg16(a.x + (long)p * a.x_pix + cin);
           } else {
-            const int bimg = p / hw, rem = p - bimg * hw;
-            const int y = rem / a.Wout, xx = rem - y * a.Wout;
+            const int bimg = cimg[i], y = cyx[i] >> 16, xx = cyx[i] & 0xffff;
             const int sy = y * a.stride + off_y, sx = xx * a.stride + off_x;
             if ((unsigned)sy < (unsigned)a.Hin && (unsigned)sx < (unsigned)a.Win)
               rb[i] = ldg16(a.x + ((long)(bimg * a.Hin + sy) * a.Win + sx) * a.x_pix + cin);
@@ -168,16 +190,17 @@ __global__ __launch_bounds__(128 * WM) void wgrad_streamk_kernel(const WgradProb
 
     // prologue: slab 0 staged, slab 1 in flight.  (The barrier also protects the buffers against the previous tile's readers.)
     fetch(p_begin);
+    if (a.conv) advance();
     __syncthreads();
     stage(0);
-    if (p_begin + kWgBP < p_end) fetch(p_begin + kWgBP);
+    if (p_begin + kWgBP < p_end) { fetch(p_begin + kWgBP); if (a.conv) advance(); }
     __syncthreads();
     int buf = 0;
     for (int p0 = p_begin; p0 < p_end; p0 += kWgBP) {
       // slab s+1 (its loads were issued a whole slab ago) -> the other buffer; slab s+2's loads start now
       if (p0 + kWgBP < p_end) {
         stage(buf ^ 1);
-        if (p0 + 2 * kWgBP < p_end) fetch(p0 + 2 * kWgBP);
+        if (p0 + 2 * kWgBP < p_end) { fetch(p0 + 2 * kWgBP); if (a.conv) advance(); }
       }
       const unsigned short* sA = sA0 + buf * kWgBP * kLdA;
       const unsigned short* sB = sB0 + buf * kWgBP * kWgLdB;
