@@ -647,40 +647,42 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
     unsigned char* const wsl = lds + 2 * WIN_BYTES;
     const int halo = (g.cW + 1) * g.cDil;
     const int hw = g.cH * g.cW;
-    const unsigned short* wsrc[6];
+    unsigned wsrc[6], wofs[B_GROUPS];                                  // 32-bit element offsets (the maps are < 2^31 elements: host check)
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int w = (wave * 6 + j) * RPI + lrow;
       long gp = (long)m0 - halo + w;
       gp = gp < 0 ? 0 : (gp >= g.M ? (long)g.M - 1 : gp);              // rows outside the tensor are only ever read by masked taps
       const int b = (int)(gp / hw), rem = (int)(gp - (long)b * hw);
-      wsrc[j] = A + (long)b * g.cImg + (long)rem * g.cPix + ((lslot ^ ring_swz<BK>(w)) * 8);
+      wsrc[j] = (unsigned)((long)b * g.cImg + (long)rem * g.cPix + ((lslot ^ ring_swz<BK>(w)) * 8));
+    }
+#pragma unroll
+    for (int j = 0; j < B_GROUPS; ++j) {
+      const int tr_ = b_base_row(j) + lrow;
+      wofs[j] = (n0 + tr_ < g.N) ? (unsigned)((long)(n0 + tr_) * g.ldw + (lslot ^ ring_swz<BK>(tr_)) * 8) : 0xffffffffu;
     }
     unsigned vmask[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int gr = m0 + wr * (BM / WM) + i * 32 + (lane & 31);
-      unsigned mk = 0;
-      if (gr < g.M) {
-        const int rem = gr % hw, oy = rem / g.cW, ox = rem - oy * g.cW;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int iy = oy + (t / 3 - 1) * g.cDil, ix = ox + (t % 3 - 1) * g.cDil;
-          if (iy >= 0 && iy < g.cH && ix >= 0 && ix < g.cW) mk |= 1u << t;
-        }
-      }
-      vmask[i] = mk;
+      // branch free: 3 row bits x 3 column bits -> 9 tap bits (the per-bit select form spilled 36 registers to scratch)
+      const int grc = gr < g.M ? gr : g.M - 1;
+      const int rem = grc % hw, oy = rem / g.cW, ox = rem - oy * g.cW;
+      const unsigned my = (unsigned)(oy - g.cDil >= 0) | 2u | ((unsigned)(oy + g.cDil < g.cH) << 2);
+      const unsigned mx = (unsigned)(ox - g.cDil >= 0) | 2u | ((unsigned)(ox + g.cDil < g.cW) << 2);
+      const unsigned mk = (0u - (my & 1u)) & mx | ((0u - ((my >> 1) & 1u)) & (mx << 3)) | ((0u - ((my >> 2) & 1u)) & (mx << 6));
+      vmask[i] = gr < g.M ? mk : 0u;
     }
     auto stage_win = [&](int chunk, int wb) {
 #pragma unroll
       for (int j = 0; j < 6; ++j)
-        __builtin_amdgcn_global_load_lds((gas_ptr)(wsrc[j] + chunk * BK), (las_ptr)(win + wb * WIN_BYTES + (wave * 6 + j) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gas_ptr)(A + wsrc[j] + chunk * BK), (las_ptr)(win + wb * WIN_BYTES + (wave * 6 + j) * 1024), 16, 0, 0);
     };
     auto stage_w = [&](int chunk, int tap, int buf) {
       const int k0 = tap * g.cCin + chunk * BK;
 #pragma unroll
       for (int j = 0; j < B_GROUPS; ++j) {
-        const void* src = brow[j] ? (const void*)(brow[j] + k0) : (const void*)g_zero16;
+        const void* src = wofs[j] != 0xffffffffu ? (const void*)(W + wofs[j] + k0) : (const void*)g_zero16;
         __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(wsl + buf * WSLAB + (wave * B_GROUPS + j) * 1024), 16, 0, 0);
       }
     };
@@ -716,8 +718,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
     stage_win(0, 0);
     stage_w(0, 0, 0);
     int kt = 0;
+#pragma unroll 1
     for (int chunk = 0; chunk < nchunk; ++chunk) {
-      for (int tap = 0; tap < 9; ++tap, ++kt) {
+#pragma unroll 1
+      for (int tap = 0; tap < 9; ++tap, ++kt) {      // (not unrolled: the per-tap fragment addresses are loop invariant over the chunks and
+                                                     //  would be hoisted into ~40 live registers -> scratch spills)
         wait_vm_barrier<0>();                 // this slab (and, at tap 0, this chunk's window) has landed; every wave is past slab kt - 1
         if (tap < 8) stage_w(chunk, tap + 1, (kt + 1) & 1);
         else if (chunk + 1 < nchunk) stage_w(chunk + 1, 0, (kt + 1) & 1);
@@ -1784,7 +1789,8 @@ static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t
     case 17:
       if constexpr (CONV == 1) {
         if (!g.resid && batch == 1 && g.cR == 3 && g.cS == 3 && g.cStride == 1 && g.cPad == g.cDil && g.cCin % 64 == 0 &&
-            256 + 2 * (g.cW + 1) * g.cDil <= 384 && g.cImg % 8 == 0 && g.cHout == g.cH && g.cWout == g.cW) {
+            256 + 2 * (g.cW + 1) * g.cDil <= 384 && g.cImg % 8 == 0 && g.cHout == g.cH && g.cWout == g.cW &&
+            (long)g.M / ((long)g.cH * g.cW) * g.cImg < (1L << 31) && (long)g.N * g.ldw < (1L << 31)) {
           launch_ring<256, 256, 2, 4, CONV, 64, 2, 4>(g, batch, out_dtype, s);
           break;
         }
