@@ -160,6 +160,10 @@ def bench_train(a, rank, world, D, emit=True):
     cfg = train.TrainConfig()
     cfg.learn_nms = a.learn_nms
     cfg.dcn = a.dcn
+    # The reference's lr (0.0005) is tuned for its 4 x 1-image steps with SUMMED gradients (rescale_grad 1.0).  This bench sums
+    # world x B images per step; from RANDOM-INIT weights on synthetic images the unscaled rate diverges to non-finite weights
+    # within a handful of steps at >= 16 images (first seen in the 2-rank run).  Keep the reference's step size PER IMAGE.
+    cfg.lr = cfg.lr * 4.0 / float(world * B)
     tr = train.FPNTrainer(params, cfg) if a.fpn else train.Trainer(params, cfg, im_hw=(H, W))
     g = torch.Generator().manual_seed(1000 + rank)
     data = torch.randn(B, 3, H, W, generator=g).cuda()
@@ -222,7 +226,7 @@ def bench_train(a, rank, world, D, emit=True):
                                    ': forward + backward + summed all-reduce of %d gradients + SGD, 600x1000 images, '
                                    '300 proposals + 8 gt rows, OHEM 128, random-init weights' % tr.num_trainable(),
                        'images_per_gpu_per_step': B, 'launch': 'eager' if a.no_graph else 'hipGraph replay (forward+backward in %d segments cut at the gradient buckets)' % len(graph.segments),
-                       'parallelism': 'dp%d (RCCL all-reduce SUM)' % world},
+                       'parallelism': 'dp%d (RCCL all-reduce SUM)' % world, 'lr': cfg.lr},
             'losses': {k: float(out[k]) for k in ('bbox_loss', 'rpn_bbox_loss', 'nms_pos_loss', 'nms_neg_loss') if k in out}}
         if emit:
             print(json.dumps(res))
@@ -280,8 +284,12 @@ def main():
     from relnet_amd import dist as D
 
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(local)
-    rank, world, local = D.init(backend='nccl')          # 'nccl' = RCCL over xGMI
+    # test aid (one-GPU boxes): RELNET_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and exchanges over gloo, so that the whole N > 1
+    # code path -- launcher, rank count, per-rank graphs, fences, segmented training step with bucketed all-reduces, one JSON line
+    # from rank 0 -- runs without a second GPU; the numbers it prints are not N-GPU numbers and say so
+    one_dev = bool(os.environ.get('RELNET_BENCH_ONE_DEVICE'))
+    torch.cuda.set_device(0 if one_dev else local)
+    rank, world, local = D.init(backend='gloo' if one_dev else 'nccl')          # 'nccl' = RCCL over xGMI
     if world != a.gpus:
         raise SystemExit("bench.py: --gpus %d but %d rank(s) came up (WORLD_SIZE): refusing to report a %d-GPU number"
                          % (a.gpus, world, a.gpus))
@@ -393,7 +401,8 @@ def main():
                                       '2 relation modules (N=300, 16 heads, d=1024)' if not a.no_relation else 'plain 2FC head',
                                       'learn-NMS (first_n 100, 80 classes)' if a.learn_nms else 'soft-NMS(0.6)'),
                        'images_per_gpu_per_step': a.batch, 'launch': 'eager' if a.no_graph else 'hipGraph replay', 'parallelism': 'replicas x%d (no data-path collective)' % world,
-                       'ranks_seen_by_rccl': ranks_seen, 'head_init_std': a.head_init_std},
+                       'ranks_seen_by_rccl': ranks_seen, 'head_init_std': a.head_init_std,
+                       **({'one_device_test': 'all %d ranks share cuda:0 and exchange over gloo (RELNET_BENCH_ONE_DEVICE): a code-path check, NOT a multi-GPU number' % world} if one_dev else {})},
         }
         if timer is not None:
             ks = timer.summary()

@@ -1,0 +1,32 @@
+"""The N > 1 training exchange on a one-GPU box: two ranks share cuda:0 and exchange over gloo (tools/dist_check.py).
+With the same batch on both ranks the bucketed all-reduce must deliver world x the local gradients -- for the eager step (buckets
+announced from inside the backward pass, heads -> res5 -> res4 -> res3) and for train.CapturedStep (buckets between hipGraph
+segments).  Everything but the collective backend (gloo instead of RCCL) is the code path of `bench.py --gpus N --train`."""
+import ast
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+def test_two_ranks_on_one_device_sum_their_gradients():
+    from importlib import import_module
+    launch = import_module('relation-networks-for-object-detection_amd.launch')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes', '1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(launch.free_port()), os.path.join(ROOT, 'tools', 'dist_check.py')]
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = [l for l in out.splitlines() if l.startswith('DIST_CHECK')]
+    assert line, out[-2000:]
+    res = ast.literal_eval(line[-1][len('DIST_CHECK'):].strip())
+    assert res['finite']
+    assert res['eager_order'] == [3, 2, 1, 0] and res['captured_segments'][:4] == [3, 2, 1, 0]
+    # atomically accumulated fp32 gradients: the order of the adds differs between two passes
+    assert res['eager_max_rel_diff'] < 1e-3 and res['captured_max_rel_diff'] < 1e-3, res
+    assert res['eager_bias_exact']
