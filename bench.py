@@ -160,10 +160,6 @@ def bench_train(a, rank, world, D, emit=True):
     cfg = train.TrainConfig()
     cfg.learn_nms = a.learn_nms
     cfg.dcn = a.dcn
-    # The reference's lr (0.0005) is tuned for its 4 x 1-image steps with SUMMED gradients (rescale_grad 1.0).  This bench sums
-    # world x B images per step; from RANDOM-INIT weights on synthetic images the unscaled rate diverges to non-finite weights
-    # within a handful of steps at >= 16 images (first seen in the 2-rank run).  Keep the reference's step size PER IMAGE.
-    cfg.lr = cfg.lr * 4.0 / float(world * B)
     tr = train.FPNTrainer(params, cfg) if a.fpn else train.Trainer(params, cfg, im_hw=(H, W))
     g = torch.Generator().manual_seed(1000 + rank)
     data = torch.randn(B, 3, H, W, generator=g).cuda()

@@ -138,6 +138,10 @@ class BucketedAllReduce(object):
             self.ready(i)
         for w in self.pending:
             w.wait()                                        # CUDA: the current stream waits for the collective's stream
+        if self.pending and self.cuda and dist.get_backend() != 'nccl':
+            # gloo on device tensors (the one-GPU test path): its copy-back runs on private streams whose events may not be
+            # recorded yet when wait() returns -- order the device explicitly (RCCL's wait() is a proper stream dependency)
+            torch.cuda.synchronize()
         order = self.launch_order
         self.pending, self.done, self.launch_order = [], set(), []
         return order

@@ -53,6 +53,8 @@ def all_reduce_sum(*buffers):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         for b in buffers:
             dist.all_reduce(b, op=dist.ReduceOp.SUM)
+        if buffers and buffers[0].is_cuda and dist.get_backend() != 'nccl':
+            torch.cuda.synchronize()            # gloo on device tensors (one-GPU test path), see dist.BucketedAllReduce.finish
 
 
 class _Flat(object):
