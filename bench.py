@@ -205,7 +205,9 @@ def bench_train(a, rank, world, D, emit=True):
         elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, device='cuda')
     ok = bool(torch.isfinite(tr.W.master).all())
-    assert ok, "non-finite weights after training steps"
+    if not ok:          # reported, not fatal: the timing above is still that of the full step
+        sys.stderr.write('bench.py: WARNING rank %d: non-finite weights after the training steps\n' % rank)
+    ok = D.sum_over_ranks(float(ok), device='cuda') == float(world)
     res = None
     if rank == 0:
         images = world * B * a.steps
@@ -223,7 +225,8 @@ def bench_train(a, rank, world, D, emit=True):
                                    '300 proposals + 8 gt rows, OHEM 128, random-init weights' % tr.num_trainable(),
                        'images_per_gpu_per_step': B, 'launch': 'eager' if a.no_graph else 'hipGraph replay (forward+backward in %d segments cut at the gradient buckets)' % len(graph.segments),
                        'parallelism': 'dp%d (RCCL all-reduce SUM)' % world, 'lr': cfg.lr},
-            'losses': {k: float(out[k]) for k in ('bbox_loss', 'rpn_bbox_loss', 'nms_pos_loss', 'nms_neg_loss') if k in out}}
+            'losses': {k: float(out[k]) for k in ('bbox_loss', 'rpn_bbox_loss', 'nms_pos_loss', 'nms_neg_loss') if k in out},
+            'weights_finite_on_all_ranks': bool(ok)}
         if emit:
             print(json.dumps(res))
     del tr
