@@ -491,7 +491,7 @@ def main():
         ta.batch, ta.steps = 16, min(a.steps, 6)          # the same step at 16 images per GPU (larger GEMMs fill the chip better)
         tr16 = bench_train(ta, rank, world, D, emit=False)
         if rank == 0:
-            res['train'] = {k: tr_res[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'n_gpus', 'config', 'losses')}
+            res['train'] = {k: tr_res[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'n_gpus', 'config', 'losses', 'weights_finite_on_all_ranks')}
             res['train']['at_16_images_per_gpu'] = {k: tr16[k] for k in ('value', 'ms_per_step', 'steps')}
     if rank == 0:
         print(json.dumps(res))
