@@ -22,6 +22,8 @@ MI355X-first choices:
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -234,8 +236,9 @@ class Trainer(object):
         return ops.conv2d_nhwc(x, w, bias, ksize=self.ksize.get(name, 1), stride=stride, pad=pad, dil=dil, relu=relu,
                                resid=resid, out_dtype=out_dtype)
 
-    def _trunk_forward(self, data):
-        """Frozen stem + res2, then res3..res5 keeping every ReLU output.  Returns (conv5, conv4, saved units, stage ends)."""
+    def _trunk_forward(self, data, at_conv4=None):
+        """Frozen stem + res2, then res3..res5 keeping every ReLU output.  Returns (conv5, conv4, saved units, stage ends).
+        at_conv4(conv4): called once conv4 exists, before res5 is queued (the RPN branch forks there)."""
         c = self.cfg
         x = ops.stem_fused(data, self.w_stem, self.b_stem)
         saved = []
@@ -245,6 +248,8 @@ class Trainer(object):
             n1, na, nb, nc = 'res%s_branch1' % nm, 'res%s_branch2a' % nm, 'res%s_branch2b' % nm, 'res%s_branch2c' % nm
             if stage == 5 and conv4 is None:
                 conv4 = x
+                if at_conv4 is not None:
+                    at_conv4(conv4)
             if proj and stage > 2:
                 ends[stage - 1] = x
             if stage == 2:
@@ -291,35 +296,62 @@ class Trainer(object):
         self._grad_buckets().reset()
         self.W.grad.zero_(); self.Bv.grad.zero_()
         self._relayout.run()            # W^T / tap-flipped copies of the current weights for every data-gradient product
-        conv5, conv4, saved, _ = self._trunk_forward(data)
-        feat = self._conv(conv5, 'conv_new_1', relu=True, bias=self.b('conv_new_1'))
-        r = self._conv(conv4, 'rpn_conv_3x3', pad=1, relu=True, bias=self.b('rpn_conv_3x3'))
-        rpn = self._conv(r, 'rpn_out', bias=self.b('rpn_out'), out_dtype=torch.float32)             # [B,h,w,72]
-        h, wd_ = rpn.shape[1], rpn.shape[2]
-        na2 = self.na2
-        if rpn_label is None:
-            rpn_label, rpn_bbox_target, rpn_bbox_weight = self.rpn_targets(gt_boxes, num_gt, im_info, (h, wd_))
-        # -- RPN losses (per image, like one image per device in the reference)
-        score_nchw = rpn[..., :na2].permute(0, 3, 1, 2).contiguous()                                 # [B,2A,h,w]
+        # The RPN branch (head convolutions, anchor targets, losses, proposals, proposal targets: everything that hangs off conv4)
+        # runs on a side stream BESIDE res5 / conv_new_1 -- its top-k / sort / NMS / target kernels are one workgroup per image and
+        # leave the GPU idle on their own; fork when conv4 exists, join before ROI pooling (graph edges under capture).
         out = {}
-        # per-image 'valid' normalisation (one image per executor in the reference) in ONE launch: group = one image's anchors
-        _, d_score = losses.softmax_output(score_nchw.view(B, 2, -1), rpn_label, multi_output=True, use_ignore=True,
-                                           ignore_label=-1.0, group=(na2 // 2) * h * wd_)
-        d_score = d_score.view(B, na2, h, wd_)
-        delta = rpn[..., na2:].contiguous()                                                          # NHWC [B,h,w,4A]
-        tgt = rpn_bbox_target.permute(0, 2, 3, 1).contiguous()
-        wgt = rpn_bbox_weight.permute(0, 2, 3, 1).contiguous()
-        rpn_l1, d_delta = losses.smooth_l1_loss(delta, tgt, wgt, 3.0, 1.0 / c.rpn_batch_size)
-        out['rpn_bbox_loss'] = rpn_l1.sum() / B
-        d_rpn = torch.cat([d_score.permute(0, 2, 3, 1), d_delta], 3).to(torch.bfloat16).contiguous()
-        # -- proposals and their targets (no gradient: proposal.py:170-173, proposal_target.py:95-97)
+        br = {}
+        main = torch.cuda.current_stream()
         nchw = lambda t: t.permute(0, 3, 1, 2)
-        rois, _ = propose_batch(nchw(rpn[..., :na2]), nchw(rpn[..., na2:]), im_info, self.anchors, c.feat_stride,
-                                c.rpn_pre_nms_top_n, c.rpn_post_nms_top_n, c.rpn_nms_thresh, c.rpn_min_size,
-                                im_hw=self.im_hw, softmax_pairs=True)
-        N = rois.shape[1]
-        rois_t, label, bbox_target, bbox_weight = ops.proposal_target(rois, gt_boxes, num_gt)
-        R = rois_t.shape[1]
+
+        def rpn_branch(conv4):
+            r = self._conv(conv4, 'rpn_conv_3x3', pad=1, relu=True, bias=self.b('rpn_conv_3x3'))
+            rpn = self._conv(r, 'rpn_out', bias=self.b('rpn_out'), out_dtype=torch.float32)             # [B,h,w,72]
+            h, wd_ = rpn.shape[1], rpn.shape[2]
+            na2 = self.na2
+            lbl, tgt_in, wgt_in = rpn_label, rpn_bbox_target, rpn_bbox_weight
+            if lbl is None:
+                lbl, tgt_in, wgt_in = self.rpn_targets(gt_boxes, num_gt, im_info, (h, wd_))
+            # -- RPN losses (per image, like one image per device in the reference)
+            score_nchw = rpn[..., :na2].permute(0, 3, 1, 2).contiguous()                                 # [B,2A,h,w]
+            # per-image 'valid' normalisation (one image per executor in the reference) in ONE launch: group = one image's anchors
+            _, d_score = losses.softmax_output(score_nchw.view(B, 2, -1), lbl, multi_output=True, use_ignore=True,
+                                               ignore_label=-1.0, group=(na2 // 2) * h * wd_)
+            d_score = d_score.view(B, na2, h, wd_)
+            delta = rpn[..., na2:].contiguous()                                                          # NHWC [B,h,w,4A]
+            tgt = tgt_in.permute(0, 2, 3, 1).contiguous()
+            wgt = wgt_in.permute(0, 2, 3, 1).contiguous()
+            rpn_l1, d_delta = losses.smooth_l1_loss(delta, tgt, wgt, 3.0, 1.0 / c.rpn_batch_size)
+            out['rpn_bbox_loss'] = rpn_l1.sum() / B
+            d_rpn = torch.cat([d_score.permute(0, 2, 3, 1), d_delta], 3).to(torch.bfloat16).contiguous()
+            # -- proposals and their targets (no gradient: proposal.py:170-173, proposal_target.py:95-97)
+            rois, _ = propose_batch(nchw(rpn[..., :na2]), nchw(rpn[..., na2:]), im_info, self.anchors, c.feat_stride,
+                                    c.rpn_pre_nms_top_n, c.rpn_post_nms_top_n, c.rpn_nms_thresh, c.rpn_min_size,
+                                    im_hw=self.im_hw, softmax_pairs=True)
+            N = rois.shape[1]
+            rois_t, label, bbox_target, bbox_weight = ops.proposal_target(rois, gt_boxes, num_gt)
+            R = rois_t.shape[1]
+            br.update(r=r, d_rpn=d_rpn, rois_t=rois_t, label=label, bbox_target=bbox_target, bbox_weight=bbox_weight, N=N, R=R)
+
+        side = None
+        if getattr(self, 'overlap_rpn', os.environ.get('RELNET_TRAIN_OVERLAP', '1') != '0'):
+            if getattr(self, '_side', None) is None:
+                self._side = torch.cuda.Stream(device=data.device)
+            side = self._side
+
+            def fork(conv4):
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    rpn_branch(conv4)
+            conv5, conv4, saved, _ = self._trunk_forward(data, at_conv4=fork)
+        else:
+            conv5, conv4, saved, _ = self._trunk_forward(data)
+            rpn_branch(conv4)
+        feat = self._conv(conv5, 'conv_new_1', relu=True, bias=self.b('conv_new_1'))
+        if side is not None:
+            main.wait_stream(side)
+        r, d_rpn, rois_t, label, bbox_target, bbox_weight, N, R = (br[k] for k in ('r', 'd_rpn', 'rois_t', 'label', 'bbox_target',
+                                                                                      'bbox_weight', 'N', 'R'))
         r5 = rois_t.view(B * R, 5)
         if c.dcn:
             sc_ = 1.0 / c.feat_stride
