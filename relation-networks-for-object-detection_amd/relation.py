@@ -8,7 +8,6 @@ group, index)` (:85-151) and the fc_new_1 -> relation -> fc_new_2 -> relation ->
 [N, M, 64] position embedding is never materialised: the geometry kernel consumes the ROI
 boxes directly, so `position_embedding` is replaced by the rois themselves.
 """
-import math
 
 import torch
 

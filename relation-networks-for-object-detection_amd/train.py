@@ -20,7 +20,6 @@ MI355X-first choices:
   * activations are kept in HBM between forward and backward (~0.45 GB / image, bf16); the relation modules are
     recomputed from their inputs instead of storing [16, N, M] maps.
 """
-import math
 
 import os
 

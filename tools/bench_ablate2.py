@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import relnet_amd
 from relnet_amd import ops, lib
-from _bench_tiles import conv_case, timeit, L
+from bench_tiles import conv_case, timeit, L
 for name, args in (('res4 expand 256->1024', (38, 63, 256, 1024, 1, 1)), ('res5 expand 512->2048', (38, 63, 512, 2048, 1, 1)),
                    ('res2 expand 64->256', (150, 250, 64, 256, 1, 1)), ('res4 reduce 1024->256', (38, 63, 1024, 256, 1, 1))):
     for tile in (8, 1, 3):

@@ -2,7 +2,7 @@
 python tools/bench_swizzle.py [B]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import _bench_tiles as BT
+import bench_tiles as BT
 L = BT.L
 tot = {}
 for name, cnt, args in BT.CASES:
