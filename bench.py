@@ -126,27 +126,99 @@ def attention_isolated(batch, n_rois, dtype, launches=100, warm=10):
     return ms[len(ms) // 2]
 
 
-def _replay_rate(det, bsz, a, D):
-    """images/s of `det` at `bsz` images per step: warm-up, one hipGraph capture, a.steps timed replays."""
-    g = torch.Generator().manual_seed(4242 + bsz)
-    data = torch.randn(bsz, 3, 600, 1000, generator=g).cuda()
-    im_info = torch.tensor([[600.0, 1000.0, 1.0]] * bsz).cuda()
+def _timed_windows(replay, D, per_window, windows=5, warm_seconds=1.0):
+    """The measurement protocol of every side figure in the JSON line: >= `warm_seconds` of untimed replays (clock ramp, caches,
+    allocator), then `windows` timed windows of `per_window` replays, each between barrier + synchronize fences.
+    -> (median, min, max) seconds per replay."""
+    t_end = time.perf_counter() + warm_seconds
+    n_warm = 0
+    while time.perf_counter() < t_end or n_warm < 3:
+        replay(); n_warm += 1
+        if n_warm % 8 == 0:
+            torch.cuda.synchronize()
+    per = []
+    for _ in range(windows):
+        D.fence(device='cuda')
+        t0 = time.perf_counter()
+        for _ in range(per_window):
+            replay()
+        D.fence(device='cuda')
+        per.append((time.perf_counter() - t0) / per_window)
+    per.sort()
+    return per[len(per) // 2], per[0], per[-1]
+
+
+def _replay_rate(det, bsz, a, D, replays=200, windows=5, step=None):
+    """images/s of `det` at `bsz` images per step under hipGraph replay: one capture, 1 s of warm replays, then `windows` windows of
+    `replays / windows` replays each (>= 200 replays in total: a 136-launch graph of ~3 ms is host-launch and clock-ramp
+    sensitive, one 20-replay window is not a measurement); median window with min / max next to it."""
+    if step is None:
+        g = torch.Generator().manual_seed(4242 + bsz)
+        data = torch.randn(bsz, 3, 600, 1000, generator=g).cuda()
+        im_info = torch.tensor([[600.0, 1000.0, 1.0]] * bsz).cuda()
+        step = lambda: det.forward(data, im_info)
     with torch.no_grad():
         for _ in range(2):
-            det.forward(data, im_info)
+            step()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            det.forward(data, im_info)
-        graph.replay()
-        D.fence(device='cuda')
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            graph.replay()
-        D.fence(device='cuda')
-        dt = time.perf_counter() - t0
+            step()
+        per_window = max(1, replays // windows)
+        med, lo, hi = _timed_windows(graph.replay, D, per_window, windows)
     del graph
-    return {'images_per_s': bsz * a.steps / dt, 'ms_per_step': 1e3 * dt / a.steps}
+    return {'images_per_s': bsz / med, 'ms_per_step': 1e3 * med, 'ms_min': 1e3 * lo, 'ms_max': 1e3 * hi,
+            'images_per_s_min': bsz / hi, 'images_per_s_max': bsz / lo,
+            'protocol': '%d windows x %d replays after >= 1 s of warm replays; median window (min / max beside it)' % (windows, per_window)}
+
+
+def _fpn_proposals(batch, n_rois, im_h, im_w, g):
+    """Given proposals of the FPN graphs (HAS_RPN: false): log-uniform sizes over all pyramid levels."""
+    side = torch.exp(torch.empty(batch, n_rois).uniform_(math.log(16), math.log(640), generator=g))
+    ar = torch.exp(torch.empty(batch, n_rois).uniform_(-0.7, 0.7, generator=g))
+    bw, bh = (side * ar).clamp(max=im_w - 2), (side / ar).clamp(max=im_h - 2)
+    x1 = torch.rand(batch, n_rois, generator=g) * (im_w - 1 - bw)
+    y1 = torch.rand(batch, n_rois, generator=g) * (im_h - 1 - bh)
+    return torch.stack([x1, y1, x1 + bw, y1 + bh], 2).cuda()
+
+
+def other_configs(a, rank, world, D):
+    """BASELINE configs[3] / configs[4] AS WORDED (DCN / FPN + relation + learn-NMS), inference graph and training step, timed by
+    this process so that the driver's line carries them (rank 0 returns the block; every rank takes part in the training
+    all-reduce).  Short runs: they are side figures, each with its own protocol string."""
+    from relnet_amd import backbone, detector
+    out = {'note': 'BASELINE configs[3] (Deformable Faster-RCNN + relation + learn-NMS) and configs[4] (FPN + relation + learn-NMS, 1000 '
+                   'proposals, 800x1024) as worded; configs[4] says "fp16 MFMA stress": run here with bf16 operands (same MFMA rate on '
+                   'gfx950: v_mfma_f32_32x32x16_bf16 / _f16 are both 8-pass), fp16 is used for the geometry-bias operand of the attention kernel only'}
+    for key, dcn, fpn, bsz in (('configs3_dcn_relation_learn_nms_inference', True, False, 27),
+                               ('configs4_fpn_relation_learn_nms_inference', False, True, 8)):
+        params = backbone.init_params(seed=1, dcn_offset_std=0.01 if dcn else 0.0, fpn=fpn)
+        cfg = detector.Config(); cfg.learn_nms = True; cfg.dcn = dcn
+        g = torch.Generator().manual_seed(77 + rank)
+        im_h, im_w = (800, 1024) if fpn else (600, 1000)
+        data = torch.randn(bsz, 3, im_h, im_w, generator=g).cuda()
+        im_info = torch.tensor([[float(im_h), float(im_w), 1.0]] * bsz).cuda()
+        if fpn:
+            det = detector.FPNDetector(params, dtype=torch.bfloat16, device='cuda', cfg=cfg)
+            props = _fpn_proposals(bsz, 1000, im_h, im_w, g)
+            step = lambda: det.forward(data, props, im_info)
+        else:
+            det = detector.Detector(params, dtype=torch.bfloat16, device='cuda', cfg=cfg)
+            step = lambda: det.forward(data, im_info)
+        r = _replay_rate(det, bsz, a, D, replays=30, windows=3, step=step)
+        r.update(images_per_gpu_per_step=bsz, n_gpus=world, images_per_s_all_gpus=r['images_per_s'] * world)
+        out[key] = r
+        del det, step
+        torch.cuda.empty_cache()
+    for key, dcn, fpn, bsz in (('configs3_dcn_relation_learn_nms_training', True, False, 8),
+                               ('configs4_fpn_relation_learn_nms_training', False, True, 2)):
+        ta = argparse.Namespace(**vars(a))
+        ta.batch, ta.learn_nms, ta.dcn, ta.fpn, ta.steps, ta.warmup, ta.no_graph = bsz, True, dcn, fpn, 5, 2, False
+        tr = bench_train(ta, rank, world, D, emit=False)
+        if rank == 0:
+            out[key] = {k: tr[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'n_gpus', 'weights_finite_on_all_ranks')}
+            out[key]['images_per_gpu_per_step'] = bsz
+    return out if rank == 0 else None
 
 
 def bench_train(a, rank, world, D, emit=True):
@@ -205,9 +277,12 @@ def bench_train(a, rank, world, D, emit=True):
         elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, device='cuda')
     ok = bool(torch.isfinite(tr.W.master).all())
-    if not ok:          # reported, not fatal: the timing above is still that of the full step
-        sys.stderr.write('bench.py: WARNING rank %d: non-finite weights after the training steps\n' % rank)
+    if not ok:
+        sys.stderr.write('bench.py: rank %d: non-finite weights after the training steps\n' % rank)
     ok = D.sum_over_ranks(float(ok), device='cuda') == float(world)
+    if not ok and not os.environ.get('RELNET_BENCH_ONE_DEVICE'):
+        # a diverged run must not be recorded as a throughput number (every rank sees the same `ok`: they leave together)
+        raise SystemExit('bench.py: non-finite weights on at least one rank after %d training steps: refusing to report a rate' % a.steps)
     res = None
     if rank == 0:
         images = world * B * a.steps
@@ -254,6 +329,7 @@ def main():
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-batch-sweep', action='store_true')
     ap.add_argument('--no-train-line', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the configs[3] / configs[4] (+ learn-NMS) side figures of the default line')
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--stem', default='hip', choices=['hip', 'hip3', 'miopen'], help="stem: 'hip' one fused conv1 + ReLU + pool1 kernel, 'hip3' the three-launch form, 'miopen' library 7x7")
@@ -401,6 +477,13 @@ def main():
                                       'learn-NMS (first_n 100, 80 classes)' if a.learn_nms else 'soft-NMS(0.6)'),
                        'images_per_gpu_per_step': a.batch, 'launch': 'eager' if a.no_graph else 'hipGraph replay', 'parallelism': 'replicas x%d (no data-path collective)' % world,
                        'ranks_seen_by_rccl': ranks_seen, 'head_init_std': a.head_init_std,
+                       'precision': 'bf16 operands, fp32 accumulation (fp16 only for the log2 geometry bias read by the attention kernel); BASELINE '
+                                    'configs[4] words its FPN run as "fp16": it is run with bf16 operands here (v_mfma_f32_32x32x16_bf16 and _f16 '
+                                    'have the same rate on gfx950)',
+                       'scaling_figure': ('`value` is the replica-inference rate (no data-path collective: linear by construction). The 1 -> N GPU '
+                                          'scaling north_star targets is the TRAINING step with its RCCL gradient all-reduce: read `train.value` '
+                                          '(and other_configs.*_training.value) across N') if world > 1 else
+                                         'single GPU; at N > 1 the data-parallel scaling figure is train.value (training step incl. the RCCL all-reduce)',
                        **({'one_device_test': 'all %d ranks share cuda:0 and exchange over gloo (RELNET_BENCH_ONE_DEVICE): a code-path check, NOT a multi-GPU number' % world} if one_dev else {})},
         }
         if timer is not None:
@@ -493,6 +576,13 @@ def main():
         if rank == 0:
             res['train'] = {k: tr_res[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'n_gpus', 'config', 'losses', 'weights_finite_on_all_ranks')}
             res['train']['at_16_images_per_gpu'] = {k: tr16[k] for k in ('value', 'ms_per_step', 'steps')}
+    if plain_graph and not a.no_other_configs:
+        if 'det' in locals():
+            del det
+        torch.cuda.empty_cache()
+        oc = other_configs(a, rank, world, D)
+        if rank == 0:
+            res['other_configs'] = oc
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

@@ -2,9 +2,11 @@
 
   * `gpu_nms`  -- lib/nms/gpu_nms.pyx:18-33 + lib/nms/nms_kernel.cu:24-32 (fp32 IoU,
                   suppress when IoU > thresh) + :118-140 (greedy scan in score order).
-                  The CUDA file cannot run here: PARITY UNPINNED, except that its
-                  keep-set equals `py_nms` whenever no IoU sits within fp32 rounding of
-                  the threshold (asserted in tests against the reference's own nms.py).
+                  PINNED (round 4): lib/nms/nms_kernel.cu compiled unedited for gfx950
+                  (oracle/build_ref.py) and run on an MI355X gives the keep lists stored in
+                  tests/golden/ref_cuda.npz (duplicated boxes, 64 / 65-box block edges, one box);
+                  tests/test_oracle_refcuda.py holds `nms_sorted_f32` to them, and
+                  tests/test_gpu_refcuda.py the product's `_nms` to the reference's `_nms`.
   * `py_nms`   -- lib/nms/nms.py:45-82 (keep while ovr <= thresh).   Pinned.
   * `soft_nms` -- lib/nms/nms.py:85-141 (gaussian rescoring, re-sort each step). Pinned.
 """

@@ -58,6 +58,7 @@ def stagewise(det, data, im_info, params, images=None, relation=True, backbone=T
                roi_pool_mismatches=[], cls_score_max_rel_err=[], cls_prob_max_abs_err=[], bbox_pred_max_rel_err=[],
                detections_gpu=[], detections_oracle=[], detections_matched=[],
                same_forward_call=True, chain_kernel_units=getattr(det.backbone, 'last_chain_units', None),
+               stage_sub_batches=getattr(det.backbone, 'last_stage_split', None),
                rpn_side_stream=bool(getattr(det.backbone, 'last_side_stream', False)))
     if relation:
         res.update(attention_1_max_rel_err=[], attention_2_max_rel_err=[])

@@ -11,6 +11,7 @@ graph itself: the Caffe-style ResNet (stride on the FIRST 1x1 of a stage, :99,10
 Parameter names are the reference's (`res4b7_branch2a_weight`, `bn4b7_branch2a_gamma`, ...).
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -127,6 +128,11 @@ class Backbone(object):
                  fpn=False, chain=True):
         self.dtype, self.device, self.dcn, self.fpn = dtype, device, dcn, fpn
         self.use_chain = chain
+        env = os.environ.get('RELNET_STAGE_SPLIT')        # A/B knob: '4:2,5:4' = stage:sub-batches ('0' / unset: no split)
+        if env not in (None, '', '0'):
+            self.stage_split = {int(a): int(b) for a, b in (kv.split(':') for kv in env.split(','))}
+        if os.environ.get('RELNET_INPLACE_EXPAND') is not None:
+            self.inplace_expand = os.environ['RELNET_INPLACE_EXPAND'] not in ('', '0')
         self.impl = impl or ('hip' if dtype == torch.bfloat16 else 'miopen')
         self.stem = stem
         assert self.impl in ('hip', 'miopen') and (self.impl == 'miopen' or dtype == torch.bfloat16)
@@ -218,8 +224,11 @@ class Backbone(object):
         ends = {}
         y_next = None
         side, hooked = None, None
-        self.last_chain_units, self.last_side_stream = [], False      # what actually ran (reported by oracle/parity.py)
-        for stage, nm, ic, mc, oc, stride, dil, proj in self.units:
+        self.last_chain_units, self.last_side_stream, self.last_stage_split = [], False, {}      # what actually ran (reported by oracle/parity.py)
+        ui = 0
+        while ui < len(self.units):
+            unit = self.units[ui]
+            stage, proj = unit[0], unit[7]
             if stage == 5 and conv4 is None:
                 conv4 = x
                 if rpn_hook is not None and not self.fpn:      # fork: RPN head + hook next to res5
@@ -232,25 +241,15 @@ class Backbone(object):
                         hooked = hooked + (rpn_hook(hooked[0], hooked[1]),)
             if proj and stage > 2:
                 ends[stage - 1] = x
-            sc = self._hconv(x, 'res%s_branch1' % nm, stride=stride) if proj else x
-            y = y_next if y_next is not None else self._hconv(x, 'res%s_branch2a' % nm, stride=stride, relu=True)
-            y_next = None
-            if self.dcn and stage == 5:
-                y = self._deform_2b(y.permute(0, 3, 1, 2), 'res%s_branch2b' % nm,
-                                    self._hconv(y, 'res%s_branch2b_offset' % nm, pad=2, dil=2, out_dtype=torch.float32).permute(0, 3, 1, 2))
-                y = y.permute(0, 2, 3, 1)
-            elif ('res%s_branch2b' % nm) in self.halo3:
-                y = ops.conv3x3_halo(y.contiguous(), *self.halo3['res%s_branch2b' % nm], relu=True)
-            else:
-                y = self._hconv(y, 'res%s_branch2b' % nm, pad=dil, dil=dil, relu=True)
-            ch = self.chain.get(nm)
-            if ch is not None and not ops.chain_worthwhile(y.numel() // y.shape[-1], y.shape[-1]):
-                ch = None            # small maps (B = 1, late stages at small B): the tiled convolution kernels fill the GPU better
-            if ch is not None:       # expand + shortcut + ReLU and the next unit's reduce + ReLU in one pixel-wise kernel
-                self.last_chain_units.append(nm)
-                x, y_next = ops.bottleneck_chain(y, sc.contiguous(), *ch)
-            else:
-                x = self._hconv(y, 'res%s_branch2c' % nm, relu=True, resid=sc)     # relu(bn(conv) + shortcut)
+            nsplit = self._stage_split(stage, x, unit) if proj else 1
+            if nsplit > 1:
+                # Infinity-Cache-sized sub-batches (see _stage_split): all units of the stage on images [lo, hi), then the next range
+                stage_units = [u for u in self.units if u[0] == stage]
+                x = self._run_stage_split(x, stage_units, nsplit)
+                ui += len(stage_units)
+                continue
+            x, y_next = self._unit_hip(x, unit, y_next, inplace=self.inplace_expand)
+            ui += 1
         conv5 = x
         nchw = lambda t: t.permute(0, 3, 1, 2)
         if self.fpn:
@@ -269,6 +268,65 @@ class Backbone(object):
         else:
             out['rpn_cls_score'], out['rpn_bbox_pred'] = self._rpn_head(conv4)
         return out
+
+    #: stage -> sub-batches (default: none).  Measured in round 4 and NOT adopted: running the 23 res4 units on two 27-image halves so
+    #: that the 1024-channel activation (265 MB at 54 images, just over the 256 MB Infinity Cache) stays cache-resident.  The
+    #: memory-side cache does keep a rewritten buffer (in-place elementwise pass: 7.0-7.3 TB/s up to 256 MB against 6.0 TB/s
+    #: beyond), but that is only +20 % on the HBM rate, and half-size launches lose more at their seams: 21.8 / 22.05 ms unsplit
+    #: against 22.2 / 22.4 ms split on the same box (tools/llc_probe.py, tools/scripts/r04_ab_split.sh).  Kept as an A/B knob:
+    #: RELNET_STAGE_SPLIT=4:2.
+    stage_split = None
+    #: x_next written over the shortcut operand by the expand kernels (inference only: a unit's input is destroyed once its reduce
+    #: convolution has read it).  Halves the activation footprint of a stage; RELNET_INPLACE_EXPAND=0 for the A/B.
+    inplace_expand = True
+
+    def _stage_split(self, stage, x, unit):
+        return int(self.stage_split.get(stage, 1)) if self.stage_split else 1
+
+    def _run_stage_split(self, x, stage_units, nsplit):
+        B = x.shape[0]
+        stage = stage_units[0][0]
+        st, nm, ic, mc, oc, stride, dil, proj = stage_units[0]
+        Ho, Wo = (x.shape[1] - 1) // stride + 1, (x.shape[2] - 1) // stride + 1
+        out = torch.empty((B, Ho, Wo, oc), device=x.device, dtype=x.dtype)
+        bounds = [(B * i) // nsplit for i in range(nsplit + 1)]
+        self.last_stage_split[stage] = [hi - lo for lo, hi in zip(bounds, bounds[1:])]
+        for lo, hi in zip(bounds, bounds[1:]):
+            xs, ys = x[lo:hi], None
+            for unit in stage_units:
+                xs, ys = self._unit_hip(xs, unit, ys, sc_out=out[lo:hi] if unit[7] else None, inplace=self.inplace_expand, force_chain=True)
+            if xs.data_ptr() != out[lo:hi].data_ptr():
+                out[lo:hi].copy_(xs)
+        return out
+
+    def _unit_hip(self, x, unit, y_pre=None, sc_out=None, inplace=False, force_chain=False):
+        """One bottleneck unit (resnet_v1_101_rcnn_base.py: branch1 | branch2a -> 2b -> 2c, + shortcut, ReLU) on the HIP kernels.
+        y_pre: this unit's reduce output if the previous unit's chain kernel already produced it.  sc_out: where the projection
+        shortcut of a first unit is written.  inplace: the expand kernel may write x_next over its shortcut operand.
+        -> (x_next, reduce output of the NEXT unit | None)"""
+        stage, nm, ic, mc, oc, stride, dil, proj = unit
+        if proj:
+            w, b, k = self.wp['res%s_branch1' % nm]
+            sc = ops.conv2d_nhwc(x, w, b, ksize=k, stride=stride, out=sc_out)
+        else:
+            sc = x
+        y = y_pre if y_pre is not None else self._hconv(x, 'res%s_branch2a' % nm, stride=stride, relu=True)
+        if self.dcn and stage == 5:
+            y = self._deform_2b(y.permute(0, 3, 1, 2), 'res%s_branch2b' % nm,
+                                self._hconv(y, 'res%s_branch2b_offset' % nm, pad=2, dil=2, out_dtype=torch.float32).permute(0, 3, 1, 2))
+            y = y.permute(0, 2, 3, 1)
+        elif ('res%s_branch2b' % nm) in self.halo3:
+            y = ops.conv3x3_halo(y.contiguous(), *self.halo3['res%s_branch2b' % nm], relu=True)
+        else:
+            y = self._hconv(y, 'res%s_branch2b' % nm, pad=dil, dil=dil, relu=True)
+        ch = self.chain.get(nm)
+        if ch is not None and not force_chain and not ops.chain_worthwhile(y.numel() // y.shape[-1], y.shape[-1]):
+            ch = None            # small maps (B = 1, late stages at small B): the tiled convolution kernels fill the GPU better
+        if ch is not None:       # expand + shortcut + ReLU and the next unit's reduce + ReLU in one pixel-wise kernel
+            if nm not in self.last_chain_units:
+                self.last_chain_units.append(nm)  # (a split stage, `inplace`, is only entered when every CU gets a 256-pixel set)
+            return ops.bottleneck_chain(y, sc.contiguous(), *ch, inplace=inplace and sc.is_contiguous())
+        return self._hconv(y, 'res%s_branch2c' % nm, relu=True, resid=sc), None     # relu(bn(conv) + shortcut)
 
     def _rpn_head(self, conv4):
         r = self._hconv(conv4, 'rpn_conv_3x3', pad=1, relu=True)

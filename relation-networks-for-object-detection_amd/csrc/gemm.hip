@@ -405,6 +405,120 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
 // ---------------------------------------------------------------------------------------
 template <int BK> __device__ __forceinline__ int ring_swz(int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 
+// ---------------------------------------------------------------------------------------
+// SCHED = 5: hand-scheduled k-loop of the 256 x 256 x 64 ring tile (2 x 4 waves, 128 x 64 outputs per wave).
+// Why: the compiler's loop for SCHED = 0 (ISA read in round 4) (a) keeps ONE register set for the activation fragments and
+// waits lgkmcnt(0) right behind every ds_read -- each pair of MFMAs sits behind a full LDS round trip -- and (b) puts the
+// whole address arithmetic of the next slab's LDS-direct loads (13 VALU + two exec-mask branches per load) between the
+// barrier and the first MFMA of a slab, where neither wave of a SIMD has matrix work in flight.
+// Here one asm statement is one k-slab:
+//   * accumulators live in a[0:127] for the life of the k-loop (named literally; the compiler keeps no value there), the
+//     fragments in two register sets v[72:95] / v[96:119]: the reads of k-step kk+2 are issued into the set that k-step kk
+//     has just consumed, between the MFMAs of k-step kk+1, with counted lgkmcnt waits;
+//   * the next slab's eight LDS-direct loads are spread over the MFMAs of k-steps 0 and 1: a lane's source is its
+//     precomputed pixel pointer + ONE wave-uniform tap / chunk offset (SGPR pair), a padded tap or a row past M takes the
+//     16 zero bytes through a per-row tap bit mask (5 VALU per activation load, none per filter load);
+//   * one s_waitcnt vmcnt(0) + s_barrier per slab, as in SCHED = 0 (the ring has two buffers).
+// Hazards handled by hand (no compiler padding inside asm): an instruction separates every m0 write from its LDS-DMA,
+// a fragment register set is re-targeted by ds_read only after the last MFMA reading it has ISSUED (operands are read at
+// issue, LDS data returns >= 64 cycles later), 24 wait states separate the last MFMA from the accumulator read-out.
+#define RA_0 "a[0:15]"
+#define RA_1 "a[16:31]"
+#define RA_2 "a[32:47]"
+#define RA_3 "a[48:63]"
+#define RA_4 "a[64:79]"
+#define RA_5 "a[80:95]"
+#define RA_6 "a[96:111]"
+#define RA_7 "a[112:127]"
+// fragment set S (0 / 1): activation rows i = 0..3, filter rows j = 0..1
+#define RFA_0_0 "v[72:75]"
+#define RFA_0_1 "v[76:79]"
+#define RFA_0_2 "v[80:83]"
+#define RFA_0_3 "v[84:87]"
+#define RFB_0_0 "v[88:91]"
+#define RFB_0_1 "v[92:95]"
+#define RFA_1_0 "v[96:99]"
+#define RFA_1_1 "v[100:103]"
+#define RFA_1_2 "v[104:107]"
+#define RFA_1_3 "v[108:111]"
+#define RFB_1_0 "v[112:115]"
+#define RFB_1_1 "v[116:119]"
+#define RMF(S, I, J, ACC) "v_mfma_f32_32x32x16_bf16 " ACC ", " RFB_##S##_##J ", " RFA_##S##_##I ", " ACC "\n\t"
+// reads of one fragment set from the LDS address registers AREG (activations) / BREG (filters)
+#define RRD_A(S, AREG) "ds_read_b128 " RFA_##S##_0 ", " AREG "\n\tds_read_b128 " RFA_##S##_1 ", " AREG " offset:4096\n\t" \
+                       "ds_read_b128 " RFA_##S##_2 ", " AREG " offset:8192\n\tds_read_b128 " RFA_##S##_3 ", " AREG " offset:12288\n\t"
+#define RRD_B(S, BREG) "ds_read_b128 " RFB_##S##_0 ", " BREG " offset:32768\n\tds_read_b128 " RFB_##S##_1 ", " BREG " offset:36864\n\t"
+// next-slab activation load j through the address pair P (v[P:P+1]): mask test + pointer, select, destination, issue
+#define RLA_CALC(P, P1, J) "v_and_b32 v" #P ", %[tb], %[mk" #J "]\n\tv_cmp_ne_u32 vcc, 0, v" #P "\n\tv_lshl_add_u64 v[" #P ":" #P1 "], %[ab" #J "], 0, %[so]\n\t"
+#define RLA_SEL(P, P1, OFF) "v_cndmask_b32 v" #P ", %[zlo], v" #P ", vcc\n\tv_cndmask_b32 v" #P1 ", %[zhi], v" #P1 ", vcc\n\ts_add_u32 m0, %[ma], " #OFF "\n\t"
+#define RLA_GO(P, P1) "global_load_lds_dwordx4 v[" #P ":" #P1 "], off\n\t"
+#define RLW_M0(OFF) "s_add_u32 m0, %[mb], " #OFF "\n\t"
+#define RLW_GO(J) "global_load_lds_dwordx4 %[wo" #J "], %[wb]\n\t"
+
+#define RSLAB_HEAD                                                                        \
+  "s_waitcnt vmcnt(0)\n\ts_barrier\n\t"                                                   \
+  RRD_A(0, "%[la0]") RRD_B(0, "%[lb0]") RRD_A(1, "%[la1]") RRD_B(1, "%[lb1]")             \
+  "v_xor_b32 v120, 0x40, %[la0]\n\tv_xor_b32 v121, 0x40, %[la1]\n\t"                      \
+  "v_xor_b32 v122, 0x40, %[lb0]\n\tv_xor_b32 v123, 0x40, %[lb1]\n\t"
+// k-step on set S with one filler string behind each of its eight MFMAs
+#define RKSTEP(S, F0, F1, F2, F3, F4, F5, F6, F7)                                          \
+  RMF(S, 0, 0, RA_0) F0 RMF(S, 0, 1, RA_1) F1 RMF(S, 1, 0, RA_2) F2 RMF(S, 1, 1, RA_3) F3 \
+  RMF(S, 2, 0, RA_4) F4 RMF(S, 2, 1, RA_5) F5 RMF(S, 3, 0, RA_6) F6 RMF(S, 3, 1, RA_7) F7
+#define RSLAB_LOAD                                                                         \
+  RSLAB_HEAD RLA_CALC(124, 125, 0) "s_waitcnt lgkmcnt(6)\n\t"                              \
+  RKSTEP(0, RLA_SEL(124, 125, 0), RLA_GO(124, 125) RLA_CALC(126, 127, 1), RLA_SEL(126, 127, 1024), RLA_GO(126, 127) RLA_CALC(124, 125, 2), \
+            RLA_SEL(124, 125, 2048), RLA_GO(124, 125) RLA_CALC(126, 127, 3), RLA_SEL(126, 127, 3072), RLA_GO(126, 127))                     \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+  RKSTEP(1, "ds_read_b128 " RFA_0_0 ", v120\n\tds_read_b128 " RFA_0_1 ", v120 offset:4096\n\t",                                             \
+            "ds_read_b128 " RFA_0_2 ", v120 offset:8192\n\tds_read_b128 " RFA_0_3 ", v120 offset:12288\n\t",                                \
+            RRD_B(0, "v122"), RLW_M0(0), RLW_GO(0) RLW_M0(1024), RLW_GO(1) RLW_M0(2048), RLW_GO(2) RLW_M0(3072), RLW_GO(3))                 \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+  RKSTEP(0, "ds_read_b128 " RFA_1_0 ", v121\n\tds_read_b128 " RFA_1_1 ", v121 offset:4096\n\t",                                             \
+            "ds_read_b128 " RFA_1_2 ", v121 offset:8192\n\tds_read_b128 " RFA_1_3 ", v121 offset:12288\n\t",                                \
+            RRD_B(1, "v123"), "", "", "", "", "")                                          \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+  RKSTEP(1, "", "", "", "", "", "", "", "")
+#define RSLAB_LAST                                                                         \
+  RSLAB_HEAD "s_waitcnt lgkmcnt(6)\n\t"                                                    \
+  RKSTEP(0, "", "", "", "", "", "", "", "")                                                \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+  RKSTEP(1, "ds_read_b128 " RFA_0_0 ", v120\n\tds_read_b128 " RFA_0_1 ", v120 offset:4096\n\t",                                             \
+            "ds_read_b128 " RFA_0_2 ", v120 offset:8192\n\tds_read_b128 " RFA_0_3 ", v120 offset:12288\n\t",                                \
+            RRD_B(0, "v122"), "", "", "", "", "")                                          \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+  RKSTEP(0, "ds_read_b128 " RFA_1_0 ", v121\n\tds_read_b128 " RFA_1_1 ", v121 offset:4096\n\t",                                             \
+            "ds_read_b128 " RFA_1_2 ", v121 offset:8192\n\tds_read_b128 " RFA_1_3 ", v121 offset:12288\n\t",                                \
+            RRD_B(1, "v123"), "", "", "", "", "")                                          \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+  RKSTEP(1, "", "", "", "", "", "", "", "")                                                \
+  "s_nop 15\n\ts_nop 7\n\t"
+#define RCL_AGPR "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", RCL10(a, 1), RCL10(a, 2), RCL10(a, 3), RCL10(a, 4), RCL10(a, 5), \
+                 RCL10(a, 6), RCL10(a, 7), RCL10(a, 8), RCL10(a, 9), RCL10(a, 10), RCL10(a, 11), "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
+#define RCL10(P, B) #P #B "0", #P #B "1", #P #B "2", #P #B "3", #P #B "4", #P #B "5", #P #B "6", #P #B "7", #P #B "8", #P #B "9"
+#define RCL_VTMP "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", RCL10(v, 8), RCL10(v, 9), RCL10(v, 10), RCL10(v, 11), \
+                 "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+
+template <int N> __device__ __forceinline__ float agpr_read() {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(x) : "n"(N));
+  return x;
+}
+template <int B> __device__ __forceinline__ void agpr_read16(f32x16& t) {
+  t[0] = agpr_read<B + 0>(); t[1] = agpr_read<B + 1>(); t[2] = agpr_read<B + 2>(); t[3] = agpr_read<B + 3>();
+  t[4] = agpr_read<B + 4>(); t[5] = agpr_read<B + 5>(); t[6] = agpr_read<B + 6>(); t[7] = agpr_read<B + 7>();
+  t[8] = agpr_read<B + 8>(); t[9] = agpr_read<B + 9>(); t[10] = agpr_read<B + 10>(); t[11] = agpr_read<B + 11>();
+  t[12] = agpr_read<B + 12>(); t[13] = agpr_read<B + 13>(); t[14] = agpr_read<B + 14>(); t[15] = agpr_read<B + 15>();
+}
+#define RZ8(B) "v_accvgpr_write_b32 a" #B "0, 0\n\tv_accvgpr_write_b32 a" #B "1, 0\n\tv_accvgpr_write_b32 a" #B "2, 0\n\tv_accvgpr_write_b32 a" #B "3, 0\n\t" \
+               "v_accvgpr_write_b32 a" #B "4, 0\n\tv_accvgpr_write_b32 a" #B "5, 0\n\tv_accvgpr_write_b32 a" #B "6, 0\n\tv_accvgpr_write_b32 a" #B "7, 0\n\t"
+#define RZ10(B) RZ8(B) "v_accvgpr_write_b32 a" #B "8, 0\n\tv_accvgpr_write_b32 a" #B "9, 0\n\t"
+__device__ __forceinline__ void agpr_zero128() {
+  asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\t"
+               "v_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\t"
+               RZ10(1) RZ10(2) RZ10(3) RZ10(4) RZ10(5) RZ10(6) RZ10(7) RZ10(8) RZ10(9) RZ10(10) RZ10(11) RZ8(12)
+               ::: RCL_AGPR);
+}
+
 template <int N> __device__ __forceinline__ void wait_vm_barrier() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
@@ -634,6 +748,80 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
       if (kt + D < nk) stage(kt + D, (kt + D) % NSTAGE);
       compute(kt % NSTAGE);
     }
+  } else if constexpr (SCHED == 5) {
+    static_assert(SCHED != 5 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && BK == 64 && NSTAGE == 2 && !RESID && !STEM && EPI == 0 && ABLATE == 0),
+                  "hand-scheduled k-loop: 256 x 256 x 64 ring tile, 2 x 4 waves, no shortcut operand");
+    // (host side, launch_bf16 case 18: N % 256 == 0, K % 64 == 0, taps <= 32, filter offsets < 2^32, korder for R * S > 1)
+    const unsigned lds0 = (unsigned)(unsigned long)(las_ptr)lds;
+    const int l31 = lane & 31, hf = lane >> 5, sw = (lane >> 1) & 7;          // ring_swz<64>(row) depends on the lane only: rows are 32-aligned per fragment
+    const unsigned rowA = lds0 + (unsigned)((wr * (BM / WM) + l31) * ROWB), rowB = lds0 + (unsigned)((wc * (BN / WN) + l31) * ROWB);
+    const unsigned c0 = (unsigned)(((0 + hf) ^ sw) << 4), c1 = (unsigned)(((2 + hf) ^ sw) << 4);   // k-steps 0 / 1; 2 / 3 are these ^ 0x40
+    // per-lane sources of the four activation loads: pixel pointer of tap (0, 0) + validity bit per tap
+    const unsigned short* ab[A_GROUPS];
+    unsigned mk[A_GROUPS];
+#pragma unroll
+    for (int j = 0; j < A_GROUPS; ++j) {
+      if constexpr (CONV) {
+        ab[j] = arow[j] + ((long)ciy[j] * g.cW + cix[j]) * g.cPix;
+        unsigned m = 0;
+        for (int tr = 0; tr < g.cR; ++tr)
+          for (int ts = 0; ts < g.cS; ++ts) {
+            const int iy = ciy[j] + tr * g.cDil, ix = cix[j] + ts * g.cDil;
+            if (iy >= 0 && iy < g.cH && ix >= 0 && ix < g.cW) m |= 1u << (tr * g.cS + ts);
+          }
+        mk[j] = m;
+      } else {
+        ab[j] = arow[j] ? arow[j] : A;
+        mk[j] = arow[j] ? 1u : 0u;
+      }
+    }
+    unsigned wo[B_GROUPS];
+#pragma unroll
+    for (int j = 0; j < B_GROUPS; ++j) {
+      const int tr_ = b_base_row(j) + lrow;
+      wo[j] = (unsigned)((((long)(n0 + tr_) * g.ldw) + (lslot ^ ring_swz<BK>(tr_)) * 8) * 2);
+    }
+    const unsigned zlo = (unsigned)(unsigned long)(const void*)g_zero16, zhi = (unsigned)((unsigned long)(const void*)g_zero16 >> 32);
+    // wave-uniform part of a slab's sources, stepped from slab to slab with scalar adds (k order = (channel chunk, tap); the host
+    // admits only that order or single-tap layers): byte offset added to every activation pointer, filter pointer, tap bit
+    const int q_ntap = CONV ? g.cR * g.cS : 1, q_S = CONV ? g.cS : 1;
+    const long q_dp2 = CONV ? (long)g.cDil * g.cPix * 2 : 0;                         // one tap to the right
+    const long q_row = CONV ? ((long)g.cW - (q_S - 1)) * q_dp2 : 0;                   // last tap of a filter row -> first tap of the next
+    const long q_back = (long)BK * 2 - (CONV ? ((long)(g.cR - 1) * g.cW + (q_S - 1)) * q_dp2 : 0);   // last tap -> tap 0 of the next chunk
+    const long q_wtap = CONV ? g.cCin : 0, q_wback = (long)BK - (long)(q_ntap - 1) * q_wtap;
+    int q_tap = 0, q_ts = 0;
+    long so = 0; const unsigned short* wb = W; unsigned tb = 1u;
+    auto slab_next = [&]() {
+      if (++q_tap == q_ntap) { q_tap = 0; q_ts = 0; tb = 1u; so += q_back; wb += q_wback; }
+      else { tb <<= 1; wb += q_wtap; if (++q_ts == q_S) { q_ts = 0; so += q_row; } else so += q_dp2; }
+    };
+    stage(0, 0);
+    agpr_zero128();
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      const unsigned cur = (unsigned)(kt & 1) * STAGE, nxt = STAGE - cur;
+      const unsigned la0 = rowA + cur + c0, la1 = rowA + cur + c1, lb0 = rowB + cur + c0, lb1 = rowB + cur + c1;
+      const unsigned ma = __builtin_amdgcn_readfirstlane(lds0 + nxt + wave * (A_GROUPS * 1024));
+      const unsigned mb = __builtin_amdgcn_readfirstlane(lds0 + nxt + BM * ROWB + wave * (B_GROUPS * 1024));
+      slab_next();
+      asm volatile(RSLAB_LOAD
+                   :
+                   : [la0] "v"(la0), [la1] "v"(la1), [lb0] "v"(lb0), [lb1] "v"(lb1),
+                     [ab0] "v"(ab[0]), [ab1] "v"(ab[1]), [ab2] "v"(ab[2]), [ab3] "v"(ab[3]),
+                     [mk0] "v"(mk[0]), [mk1] "v"(mk[1]), [mk2] "v"(mk[2]), [mk3] "v"(mk[3]),
+                     [wo0] "v"(wo[0]), [wo1] "v"(wo[1]), [wo2] "v"(wo[2]), [wo3] "v"(wo[3]),
+                     [zlo] "v"(zlo), [zhi] "v"(zhi), [so] "s"(so), [wb] "s"(wb), [tb] "s"(tb), [ma] "s"(ma), [mb] "s"(mb)
+                   : "memory", "vcc", "scc", "m0", RCL_VTMP, RCL_AGPR);
+    }
+    {
+      const unsigned cur = (unsigned)((nk - 1) & 1) * STAGE;
+      const unsigned la0 = rowA + cur + c0, la1 = rowA + cur + c1, lb0 = rowB + cur + c0, lb1 = rowB + cur + c1;
+      asm volatile(RSLAB_LAST
+                   :
+                   : [la0] "v"(la0), [la1] "v"(la1), [lb0] "v"(lb0), [lb1] "v"(lb1)
+                   : "memory", RCL_VTMP, RCL_AGPR);
+    }
+    // (the accumulators stay in a[0:127]; the epilogue below fetches them one 32-row band at a time -- reading all 128 at once
+    //  made the compiler park some of the values in "free" AGPRs, i.e. in accumulators that had not been read yet)
   } else if constexpr (SCHED == 4) {
     // Window schedule for 3x3 / stride 1 layers (host checks the geometry): the k-loop runs (channel chunk, tap); the nine taps of a
     // 64-channel chunk read the SAME input pixels shifted by ((r - 1) W + (s - 1)) dil, so the A operand of a chunk is staged ONCE
@@ -1037,6 +1225,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
   for (int e = 0; e < VEC; ++e) bv[e] = (g.bias_mode == 1 && n + e < g.N) ? g.bias[n + e] : 0.f;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    if constexpr (SCHED == 5) {          // band i of the AGPR-resident accumulators (block i * TN + j = a[16 (2 i + j) ...])
+      switch (i) {
+        case 0: agpr_read16<0>(acc[0][0]); agpr_read16<16>(acc[0][1]); break;
+        case 1: agpr_read16<32>(acc[1][0]); agpr_read16<48>(acc[1][1]); break;
+        case 2: agpr_read16<64>(acc[2][0]); agpr_read16<80>(acc[2][1]); break;
+        default: agpr_read16<96>(acc[3][0]); agpr_read16<112>(acc[3][1]); break;
+      }
+    }
     if (i > 0) __syncthreads();
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -1569,6 +1765,8 @@ extern "C" void relnet_gemm_force_nloop(int n) { g_force_nloop = n; }
 extern "C" void relnet_gemm_set_swizzle(int on) { g_swizzle = on; }
 static int g_korder = 1;         // tuning knob: 1 = (channel chunk, tap) k order + XCD-contiguous row tiles for R*S > 1 ring launches
 extern "C" void relnet_gemm_debug_korder(int on) { g_korder = on; }
+static int g_asm = 1;            // tuning knob: 0 = pick_tile never chooses tile 18 (hand-scheduled k-loop)
+extern "C" void relnet_gemm_debug_asm(int on) { g_asm = on; }
 
 template <int BM, int BN, int WM, int WN, int CONV>
 static void launch_cfg(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
@@ -1615,8 +1813,9 @@ static void launch_ring(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
   const int nthr = 64 * WM * WN;
   if constexpr (CONV == 1) {
     if (g_ablate && g_ablate <= 2 && out_dtype == RELNET_BF16 && !g.resid) {
-      if (g_ablate == 1) gemm_ring_kernel<BM, BN, WM, WN, unsigned short, CONV, BK, NSTAGE, false, SCHED, 1><<<grid, nthr, 0, s>>>(g);
-      else gemm_ring_kernel<BM, BN, WM, WN, unsigned short, CONV, BK, NSTAGE, false, SCHED, 2><<<grid, nthr, 0, s>>>(g);
+      constexpr int ASCHED = SCHED == 5 ? 0 : SCHED;          // (the asm k-loop has no ablation forms)
+      if (g_ablate == 1) gemm_ring_kernel<BM, BN, WM, WN, unsigned short, CONV, BK, NSTAGE, false, ASCHED, 1><<<grid, nthr, 0, s>>>(g);
+      else gemm_ring_kernel<BM, BN, WM, WN, unsigned short, CONV, BK, NSTAGE, false, ASCHED, 2><<<grid, nthr, 0, s>>>(g);
       return;
     }
     if (g_ablate == 3 && out_dtype == RELNET_BF16) {           // no output stores
@@ -1663,7 +1862,8 @@ static void launch_ring(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
 //  tiles 5 / 4 at 1 and 8 images -- four to five resident 2-stage workgroups per CU already cover the load latency)
 //                                   17 = 8 with the A operand of 3x3 / stride-1 layers staged once per channel chunk as a pixel WINDOW shared by
 //                                        the nine taps (other shapes under 17 run configuration 8)
-enum { GEMM_TILE_COUNT = 17 };
+//                                   18 = 8 with the hand-scheduled (inline asm) k-loop on shortcut-free layers whose N is a multiple of 256
+enum { GEMM_TILE_COUNT = 18 };
 
 template <int CONV>
 static bool launch_panel(const GemmArgs& g0, int batch, int out_dtype, hipStream_t s, bool use_wf = false, bool occ2 = false) {
@@ -1743,6 +1943,10 @@ static int pick_tile(long M, long N, long K, int batch, int out_dtype, int has_r
   // shortcut-free 256x256 layers (3x3 / reduce convolutions, FC layers): the ring kernel's conflict-free LDS image and
   // residual-free register budget are worth 3-11 % (r02 tile table: res5 3x3 642 -> 574 us, rpn 3x3 1244 -> 1131 us)
   if (cfg == 1 && !has_resid) cfg = 8;
+  // ... and with K >= 2048 (res4 / res5 / RPN 3x3, res5 reduce, fc_new_1) the hand-scheduled k-loop of tile 18: the MFMA-bound layers
+  // gain 13-19 % (r04, 54 images, us per launch: res4 3x3 169 -> 147, res5 3x3 628 -> 512, rpn 3x3 1206 -> 975, res5 reduce 316 -> 290);
+  // the K = 1024 reduce layers are bound by the HBM fill of their activation rows and stay on tile 8 (97 vs 101 us)
+  if (cfg == 8 && K >= 2048 && N % 256 == 0 && g_asm) cfg = 18;
   // res4 expand convolutions (256 -> 1024 + shortcut, 23 per step): with the weights also available in fragment order the
   // panel kernel reads A once and never stages W in LDS: 219 -> 191..203 us (r02 tile table; every other shape is slower)
   if (cfg == 1 && has_resid && has_wf && K == 256 && batch == 1) cfg = 14;
@@ -1753,7 +1957,7 @@ static int pick_tile(long M, long N, long K, int batch, int out_dtype, int has_r
   // convolution totals 5.60 -> 4.6 ms (8 images), 2.14 -> 1.7 ms (1 image).
   auto wgs = [&](long bm, long bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long)batch; };
   const int small = wgs(128, 64) >= 200 ? 4 : 5;
-  if ((cfg == 1 || cfg == 8) && wgs(256, 256) < 128) cfg = small;
+  if ((cfg == 1 || cfg == 8 || cfg == 18) && wgs(256, 256) < 128) cfg = small;
   else if (cfg == 2 && wgs(256, 128) < 128) cfg = small;
   else if (cfg == 3 && wgs(128, 128) < 200) cfg = small;
   else if (cfg == 4 && N > 64 && wgs(128, 64) < 200) cfg = 5;
@@ -1794,6 +1998,14 @@ static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t
           launch_ring<256, 256, 2, 4, CONV, 64, 2, 4>(g, batch, out_dtype, s);
           break;
         }
+      }
+      launch_ring<256, 256, 2, 4, CONV, 64, 2>(g, batch, out_dtype, s);
+      break;
+    case 18:
+      if constexpr (CONV != 2) {
+        bool ok = !g.resid && g.N % 256 == 0 && g.K % 64 == 0 && (long)g.N * g.ldw * 2 < (1L << 32);
+        if constexpr (CONV == 1) ok = ok && g.cCin % 64 == 0 && g.cR * g.cS <= 32 && (g.cR * g.cS == 1 || g_korder);
+        if (ok) { launch_ring<256, 256, 2, 4, CONV, 64, 2, 5>(g, batch, out_dtype, s); break; }
       }
       launch_ring<256, 256, 2, 4, CONV, 64, 2>(g, batch, out_dtype, s);
       break;

@@ -55,7 +55,11 @@ class Detector(object):
         self.cfg = cfg or Config()
         self.dtype, self.device, self.relation, self.im_hw = dtype, device, relation, im_hw
         self.overlap_rpn = True
-        self.overlap_min_images = int(os.environ.get('RELNET_OVERLAP_MIN_IMAGES', '1'))
+        # RPN head + proposal beside res5 on a side stream: under hipGraph capture the fork / join are graph edges and it pays from one
+        # image (3.0 -> 2.75-2.80 ms, r03); launched eagerly at 1-2 images the extra events cost more than the overlap gives
+        # (3.3 -> 4.5 ms, r02), so eager calls fork from 3 images.  None = that rule; RELNET_OVERLAP_MIN_IMAGES overrides it.
+        env = os.environ.get('RELNET_OVERLAP_MIN_IMAGES')
+        self.overlap_min_images = int(env) if env else None
         self.backbone = Backbone(params, dtype, device, stem=stem, dcn=self.cfg.dcn)
         if self.cfg.dcn:          # FC 12544 -> 2*7*7 offsets (SYM_DCN_RELNMS:1075), columns in (ph, pw, c) order
             self.w_offset = params['offset_weight'][:, fc1_channels_last_perm()].to(device, dtype).contiguous()
@@ -88,7 +92,10 @@ class Detector(object):
         propose = lambda cls, box: propose_batch(cls.float(), box.float(), im_info, self.anchors, c.feat_stride,
                                                  c.rpn_pre_nms_top_n, c.rpn_post_nms_top_n, c.rpn_nms_thresh, c.rpn_min_size,
                                                  im_hw=self.im_hw, softmax_pairs=True, want_num=True)
-        if self.overlap_rpn and self.backbone.impl == 'hip' and B >= self.overlap_min_images:   # RPN head + proposal on a side stream, beside res5
+        min_images = self.overlap_min_images
+        if min_images is None:
+            min_images = 1 if torch.cuda.is_current_stream_capturing() else 3
+        if self.overlap_rpn and self.backbone.impl == 'hip' and B >= min_images:   # RPN head + proposal on a side stream, beside res5
             # (under hipGraph replay the fork / join are graph edges: at one image per step 3.0 -> 2.75-2.80 ms, at two 3.63 -> 3.30 ms,
             #  r03 A/B with RELNET_OVERLAP_MIN_IMAGES; round 2's eager-mode measurement had said the opposite)
             f = self.backbone.forward(data, rpn_hook=propose)

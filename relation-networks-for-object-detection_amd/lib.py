@@ -6,6 +6,7 @@ return code with the message recorded by the library.
 """
 import ctypes as C
 import os
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RELNET_LIB') or os.path.join(HERE, 'librelnet_hip.so')      # (RELNET_LIB: A/B against another build)
@@ -92,6 +93,7 @@ _SIGNATURES = {
     'relnet_weight_relayout': (C.c_int, [_vp, _i, _i, _vp]),
     'relnet_gemm_set_swizzle': (None, [_i]),
     'relnet_gemm_debug_korder': (None, [_i]),
+    'relnet_gemm_debug_asm': (None, [_i]),
     'relnet_gemm_debug_ablate': (None, [_i]),
     'relnet_gemm_tile_count': (C.c_int, []),
     'relnet_gemm_pick_tile': (C.c_int, [_i, _i, _i, _i, _i]),
@@ -142,11 +144,16 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so is stale -> loud
         fn.restype = res
         fn.argtypes = args
-    # tuning knobs settable from the environment (A/B runs of the whole step without editing code)
-    if os.environ.get('RELNET_GEMM_KORDER'):
-        lib.relnet_gemm_debug_korder(int(os.environ['RELNET_GEMM_KORDER']))
-    if os.environ.get('RELNET_GEMM_FORCE_TILE'):
-        lib.relnet_gemm_force_tile(int(os.environ['RELNET_GEMM_FORCE_TILE']))
+    # A/B knobs for whole-step measurements without editing code.  They change which kernels run, so they are honoured only
+    # together with RELNET_DEBUG_KNOBS=1 and every use is announced on stderr (a forced tile is a measured-slower configuration)
+    knobs = [(k, os.environ[k]) for k in ('RELNET_GEMM_KORDER', 'RELNET_GEMM_FORCE_TILE', 'RELNET_GEMM_ASM') if os.environ.get(k)]
+    if knobs and os.environ.get('RELNET_DEBUG_KNOBS') != '1':
+        sys.stderr.write('relnet: ignoring %s (set RELNET_DEBUG_KNOBS=1 to apply kernel-selection knobs)\n' % ', '.join(k for k, _ in knobs))
+    elif knobs:
+        sys.stderr.write('relnet: DEBUG kernel-selection knobs in effect: %s\n' % ', '.join('%s=%s' % kv for kv in knobs))
+        for k, v in knobs:
+            {'RELNET_GEMM_KORDER': lib.relnet_gemm_debug_korder, 'RELNET_GEMM_FORCE_TILE': lib.relnet_gemm_force_tile,
+             'RELNET_GEMM_ASM': lib.relnet_gemm_debug_asm}[k](int(v))
     _lib = lib
     return lib
 

@@ -422,17 +422,19 @@ def pack_chain_w1(w_packed):
     return w_packed[row, col].contiguous()
 
 
-def bottleneck_chain(mid2, x, w3_frag, w1_frag, b3, b1):
+def bottleneck_chain(mid2, x, w3_frag, w1_frag, b3, b1, inplace=False):
     """x_next = relu(conv1x1(mid2; W3, b3) + x); mid1_next = relu(conv1x1(x_next; W1n, b1n)) in one kernel (NHWC bf16).
     mid2 [.., mid], x [.., 4 mid] dense; w3_frag = pack_w_frag(W3), w1_frag = pack_chain_w1(W1n).  w1_frag = b1 = None (last unit
-    of a stage): only x_next is produced.  -> (x_next, mid1_next | None)"""
+    of a stage): only x_next is produced.  inplace: x_next is written over x (every wavefront reads a 32-pixel x 64-channel
+    slice of x before it stores the same slice of x_next, and no other wavefront touches those pixels).
+    -> (x_next, mid1_next | None)"""
     _chk(mid2, x, w3_frag, w1_frag, b3, b1)
     mid = mid2.shape[-1]
     assert mid2.is_contiguous() and x.is_contiguous() and x.shape[-1] == 4 * mid and x.shape[:-1] == mid2.shape[:-1]
     assert mid2.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and b3.dtype == torch.float32
     assert (w1_frag is None) == (b1 is None) and (b1 is None or b1.dtype == torch.float32)
     assert mid in (CHAIN_MIDS if w1_frag is not None else CHAIN_EXPAND_MIDS)
-    xn = torch.empty_like(x)
+    xn = x if inplace else torch.empty_like(x)
     m1 = torch.empty_like(mid2) if w1_frag is not None else None
     _lib.call('relnet_bottleneck_chain', mid2.data_ptr(), x.data_ptr(), w3_frag.data_ptr(), _ptr(w1_frag), b3.data_ptr(),
               _ptr(b1), xn.data_ptr(), _ptr(m1), mid2.numel() // mid, mid, _stream())

@@ -9,6 +9,7 @@ cross-correlation, FullyConnected = x W^T + b).  Checked two ways:
   * a sample of output rows (first / last rows, tile boundaries, random) against float64 numpy on the host, computed
     from the definition -- independent of any library and transpose-detecting (non-symmetric random operands)."""
 import itertools
+import os
 
 import numpy as np
 import pytest
@@ -30,6 +31,8 @@ def rn():
 def _variants(L, quick=False):
     nt = L.relnet_gemm_tile_count()
     tiles = range(1, nt + 1)
+    if os.environ.get('RELNET_TEST_TILES'):            # development aid: only these tile configurations
+        tiles = [int(t) for t in os.environ['RELNET_TEST_TILES'].split(',')]
     if quick:
         return [(t, s, 1) for t in tiles for s in (0, 1)]
     return [(t, s, nl) for t in tiles for s in (0, 1) for nl in (1, 2, 4)]
