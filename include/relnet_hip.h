@@ -83,7 +83,7 @@ void relnet_gemm_force_tile(int cfg);     /* tuning knob: 0 = auto, 1..5 = fixed
 void relnet_gemm_force_nloop(int n);      /* tuning knob: 0 = auto, n = column tiles per workgroup     */
 void relnet_gemm_set_swizzle(int on);     /* tuning knob: XCD-aware tile order (default 1)               */
 void relnet_gemm_debug_korder(int on);    /* tuning knob: (channel chunk, tap) k order of the spatial ring convolutions (default 1) */
-void relnet_gemm_debug_asm(int on);       /* tuning knob: 0 = the automatic tile choice never takes tile 18 (hand-scheduled k-loop); default 1 */
+void relnet_gemm_debug_asm(int on);       /* tuning knob: 0 = the automatic tile choice never takes tiles 18 / 19 (hand-scheduled k-loops); default 1 */
 void relnet_gemm_debug_ablate(int a);     /* measurement knob for tile 8: 1 = fill path only, 2 = LDS + MFMA only (garbage results) */
 int relnet_gemm_tile_count(void);         /* number of tile configurations (valid relnet_gemm_force_tile values 1..count) */
 int relnet_gemm_pick_tile(int M, int N, int K, int batch, int out_dtype);   /* the configuration `auto` selects */
@@ -206,6 +206,14 @@ int relnet_class_nms(const float* cls_prob, const double* boxes, double* dets, i
 int relnet_class_nms_ex(const float* cls_prob, const double* scores64, const double* boxes, double* dets, int* counts,
                         int* pick_index, int B, int N, int C, float score_thresh, double nms_param, int soft,
                         int max_picks, void* stream);
+/* relnet_class_nms with image-level pruning (tester.py:270-277): a class list stops as soon as its next pick cannot be among the
+ * top_k scores of its image.  Every pick of the image is counted in `hist` (B x relnet_class_nms_hist_bins() unsigned ints, ZEROED
+ * by the caller before every call); a class stops when its latest pick falls below the bin in which the count from the top reaches
+ * top_k.  The lists are prefixes of relnet_class_nms's and contain every pick >= the final image threshold, so relnet_image_topk
+ * returns the same detections; counts = picks produced.  N <= 512. */
+int relnet_class_nms_hist_bins(void);
+int relnet_class_nms_topk(const float* cls_prob, const double* boxes, double* dets, int* counts, void* hist, int B, int N, int C,
+                          float score_thresh, double nms_param, int soft, int max_picks, int top_k, void* stream);
 /* tester.py:270-277: image threshold = max_per_image-th largest score; out [B,max_out,6] =
  * (class, score, x1, y1, x2, y2), class-major in pick order.                                        */
 int relnet_image_topk(const double* dets, const int* counts, double* thresh, int* total, float* out,

@@ -492,12 +492,61 @@ template <int BK> __device__ __forceinline__ int ring_swz(int row) { return BK =
   "s_waitcnt lgkmcnt(0)\n\t"                                                               \
   RKSTEP(1, "", "", "", "", "", "", "", "")                                                \
   "s_nop 15\n\ts_nop 7\n\t"
+// SCHED = 6: the same hand-scheduled slab with an ASYMMETRIC ring for layers whose activation rows come from HBM (1x1 "reduce"
+// convolutions, K = 1024): activations through THREE 32 KB slots, fetched TWO slabs ahead, filters (L2-resident, short latency)
+// through two slots one slab ahead -- 3 x 32 + 2 x 32 KB = the whole 160 KB LDS.  Loads retire in order, so a slab issues its
+// filter loads first and the (younger) activation loads of slab kt + 2 last: the wait at the head of the next slab is
+// vmcnt(4) -- everything but those four activation loads -- and the HBM latency of a slab gets two slab times instead of one.
+#define RKSTEP_X(...) RKSTEP(__VA_ARGS__)          // (expands argument macros that carry commas first)
+#define RRD_B6(S, BREG) "ds_read_b128 " RFB_##S##_0 ", " BREG "\n\tds_read_b128 " RFB_##S##_1 ", " BREG " offset:4096\n\t"
+#define RSLAB6_HEAD(VM)                                                                   \
+  "s_waitcnt vmcnt(" #VM ")\n\ts_barrier\n\t"                                             \
+  RRD_A(0, "%[la0]") RRD_B6(0, "%[lb0]") RRD_A(1, "%[la1]") RRD_B6(1, "%[lb1]")           \
+  "v_xor_b32 v120, 0x40, %[la0]\n\tv_xor_b32 v121, 0x40, %[la1]\n\t"                      \
+  "v_xor_b32 v122, 0x40, %[lb0]\n\tv_xor_b32 v123, 0x40, %[lb1]\n\t"                      \
+  "s_waitcnt lgkmcnt(6)\n\t"
+#define RSLAB6_K1_READS                                                                    \
+  "ds_read_b128 " RFA_0_0 ", v120\n\tds_read_b128 " RFA_0_1 ", v120 offset:4096\n\t",      \
+  "ds_read_b128 " RFA_0_2 ", v120 offset:8192\n\tds_read_b128 " RFA_0_3 ", v120 offset:12288\n\t", \
+  RRD_B6(0, "v122")
+#define RSLAB6_TAIL(NOPS)                                                                  \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+  RKSTEP(0, "ds_read_b128 " RFA_1_0 ", v121\n\tds_read_b128 " RFA_1_1 ", v121 offset:4096\n\t",                                             \
+            "ds_read_b128 " RFA_1_2 ", v121 offset:8192\n\tds_read_b128 " RFA_1_3 ", v121 offset:12288\n\t",                                \
+            RRD_B6(1, "v123"), "", "", "", "", "")                                         \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+  RKSTEP(1, "", "", "", "", "", "", "", "") NOPS
+#define RSLAB6_FULL                                                                        \
+  RSLAB6_HEAD(4)                                                                           \
+  RKSTEP(0, RLW_M0(0), RLW_GO(0) RLW_M0(1024), RLW_GO(1) RLW_M0(2048), RLW_GO(2) RLW_M0(3072), RLW_GO(3) RLA_CALC(124, 125, 0),            \
+            RLA_SEL(124, 125, 0), RLA_GO(124, 125) RLA_CALC(126, 127, 1), RLA_SEL(126, 127, 1024))                                          \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+  RKSTEP_X(1, RSLAB6_K1_READS, RLA_GO(126, 127) RLA_CALC(124, 125, 2), RLA_SEL(124, 125, 2048), RLA_GO(124, 125) RLA_CALC(126, 127, 3),      \
+            RLA_SEL(126, 127, 3072), RLA_GO(126, 127))                                     \
+  RSLAB6_TAIL("")
+#define RSLAB6_WONLY                                                                       \
+  RSLAB6_HEAD(4)                                                                           \
+  RKSTEP(0, RLW_M0(0), RLW_GO(0) RLW_M0(1024), RLW_GO(1) RLW_M0(2048), RLW_GO(2) RLW_M0(3072), RLW_GO(3), "", "", "")                       \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+  RKSTEP_X(1, RSLAB6_K1_READS, "", "", "", "", "")                                           \
+  RSLAB6_TAIL("")
+#define RSLAB6_LAST                                                                        \
+  RSLAB6_HEAD(0)                                                                           \
+  RKSTEP(0, "", "", "", "", "", "", "", "")                                                \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+  RKSTEP_X(1, RSLAB6_K1_READS, "", "", "", "", "")                                           \
+  RSLAB6_TAIL("s_nop 15\n\ts_nop 7\n\t")
 #define RCL_AGPR "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", RCL10(a, 1), RCL10(a, 2), RCL10(a, 3), RCL10(a, 4), RCL10(a, 5), \
                  RCL10(a, 6), RCL10(a, 7), RCL10(a, 8), RCL10(a, 9), RCL10(a, 10), RCL10(a, 11), "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
 #define RCL10(P, B) #P #B "0", #P #B "1", #P #B "2", #P #B "3", #P #B "4", #P #B "5", #P #B "6", #P #B "7", #P #B "8", #P #B "9"
 #define RCL_VTMP "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", RCL10(v, 8), RCL10(v, 9), RCL10(v, 10), RCL10(v, 11), \
                  "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
 
+// a wave-uniform 64-bit value the compiler may have parked in VGPRs -> provably scalar (the "s" constraint of the slab statements)
+__device__ __forceinline__ unsigned long uniform64(unsigned long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((unsigned long)hi << 32) | lo;
+}
 template <int N> __device__ __forceinline__ float agpr_read() {
   float x;
   asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(x) : "n"(N));
@@ -554,7 +603,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
   constexpr int STAGE = (BM + BN) * ROWB;
   constexpr int CLD = BN + 4;
   constexpr int BAND = 32 * WM;
-  constexpr int LDS_BYTES = SCHED == 4 ? 160 * 1024 : (EPI == 1 || NSTAGE * STAGE > BAND * CLD * 4) ? NSTAGE * STAGE : BAND * CLD * 4;
+  constexpr int LDS_BYTES = (SCHED == 4 || SCHED == 6) ? 160 * 1024 : (EPI == 1 || NSTAGE * STAGE > BAND * CLD * 4) ? NSTAGE * STAGE : BAND * CLD * 4;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -822,6 +871,106 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
     }
     // (the accumulators stay in a[0:127]; the epilogue below fetches them one 32-row band at a time -- reading all 128 at once
     //  made the compiler park some of the values in "free" AGPRs, i.e. in accumulators that had not been read yet)
+  } else if constexpr (SCHED == 6) {
+    static_assert(SCHED != 6 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && BK == 64 && NSTAGE == 2 && !RESID && !STEM && EPI == 0 && ABLATE == 0),
+                  "asymmetric-ring k-loop: 256 x 256 x 64 tile, 2 x 4 waves, no shortcut operand");
+    constexpr unsigned SLOT = BM * ROWB, WBASE = 3 * SLOT;         // activation slots 0..2 at 0, filter slots 0..1 at 96 KB
+    const unsigned lds0 = (unsigned)(unsigned long)(las_ptr)lds;
+    const int l31 = lane & 31, hf = lane >> 5, sw = (lane >> 1) & 7;
+    const unsigned rowA = lds0 + (unsigned)((wr * (BM / WM) + l31) * ROWB), rowB = lds0 + WBASE + (unsigned)((wc * (BN / WN) + l31) * ROWB);
+    const unsigned c0 = (unsigned)(((0 + hf) ^ sw) << 4), c1 = (unsigned)(((2 + hf) ^ sw) << 4);
+    const unsigned short* ab[A_GROUPS];
+    unsigned mk[A_GROUPS];
+#pragma unroll
+    for (int j = 0; j < A_GROUPS; ++j) {
+      if constexpr (CONV) {
+        ab[j] = arow[j] + ((long)ciy[j] * g.cW + cix[j]) * g.cPix;
+        unsigned m = 0;
+        for (int tr = 0; tr < g.cR; ++tr)
+          for (int ts = 0; ts < g.cS; ++ts) {
+            const int iy = ciy[j] + tr * g.cDil, ix = cix[j] + ts * g.cDil;
+            if (iy >= 0 && iy < g.cH && ix >= 0 && ix < g.cW) m |= 1u << (tr * g.cS + ts);
+          }
+        mk[j] = m;
+      } else {
+        ab[j] = arow[j] ? arow[j] : A;
+        mk[j] = arow[j] ? 1u : 0u;
+      }
+    }
+    unsigned wo[B_GROUPS];
+#pragma unroll
+    for (int j = 0; j < B_GROUPS; ++j) {
+      const int tr_ = b_base_row(j) + lrow;
+      wo[j] = (unsigned)((((long)(n0 + tr_) * g.ldw) + (lslot ^ ring_swz<BK>(tr_)) * 8) * 2);
+    }
+    const unsigned zlo = (unsigned)(unsigned long)(const void*)g_zero16, zhi = (unsigned)((unsigned long)(const void*)g_zero16 >> 32);
+    // two scalar steppers over the k-slabs (k order = (channel chunk, tap)): the activation side runs one slab ahead of the filter side
+    const int q_ntap = CONV ? g.cR * g.cS : 1, q_S = CONV ? g.cS : 1;
+    const long q_dp2 = CONV ? (long)g.cDil * g.cPix * 2 : 0;
+    const long q_row = CONV ? ((long)g.cW - (q_S - 1)) * q_dp2 : 0;
+    const long q_back = (long)BK * 2 - (CONV ? ((long)(g.cR - 1) * g.cW + (q_S - 1)) * q_dp2 : 0);
+    const long q_wtap = CONV ? g.cCin : 0, q_wback = (long)BK - (long)(q_ntap - 1) * q_wtap;
+    // (plain statements, not mutating lambdas: with by-reference captures the compiler kept this state in scratch memory and put
+    //  a vmcnt(0) for its reloads into the k-loop, draining the counted LDS-DMA pipeline)
+    int a_tap = 0, a_ts = 0, w_tap = 0;
+    long so = 0; unsigned tb = 1u; const unsigned short* wb = W;
+#define RELNET_A_NEXT()                                                                      \
+    if (++a_tap == q_ntap) { a_tap = 0; a_ts = 0; tb = 1u; so += q_back; }                   \
+    else { tb <<= 1; if (++a_ts == q_S) { a_ts = 0; so += q_row; } else so += q_dp2; }
+#define RELNET_W_NEXT() if (++w_tap == q_ntap) { w_tap = 0; wb += q_wback; } else wb += q_wtap;
+    // prologue (compiler-issued LDS-direct loads, in the order the counted waits assume): A(0), W(0), A(1)
+#pragma unroll
+    for (int j = 0; j < A_GROUPS; ++j) {
+      const void* src = (mk[j] & 1u) ? (const void*)ab[j] : (const void*)g_zero16;
+      __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(lds + (wave * A_GROUPS + j) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < B_GROUPS; ++j)
+      __builtin_amdgcn_global_load_lds((gas_ptr)((const char*)W + wo[j]), (las_ptr)(lds + WBASE + (wave * B_GROUPS + j) * 1024), 16, 0, 0);
+    if (nk > 1) {
+      RELNET_A_NEXT()
+#pragma unroll
+      for (int j = 0; j < A_GROUPS; ++j) {
+        const void* src = (mk[j] & tb) ? (const void*)((const char*)ab[j] + so) : (const void*)g_zero16;
+        __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(lds + SLOT + (wave * A_GROUPS + j) * 1024), 16, 0, 0);
+      }
+    }
+    agpr_zero128();
+    unsigned aslot = 0;                                   // kt % 3
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned la0 = rowA + aslot * SLOT + c0, la1 = rowA + aslot * SLOT + c1;
+      const unsigned lb0 = rowB + (unsigned)(kt & 1) * SLOT + c0, lb1 = rowB + (unsigned)(kt & 1) * SLOT + c1;
+      const unsigned aslot2 = aslot == 0 ? 2u : aslot - 1u;                        // (kt + 2) % 3
+      if (kt + 2 < nk) {
+        RELNET_A_NEXT() RELNET_W_NEXT()                   // activation slab kt + 2, filter slab kt + 1
+        const unsigned ma = __builtin_amdgcn_readfirstlane(lds0 + aslot2 * SLOT + wave * (A_GROUPS * 1024));
+        const unsigned mb = __builtin_amdgcn_readfirstlane(lds0 + WBASE + (unsigned)((kt + 1) & 1) * SLOT + wave * (B_GROUPS * 1024));
+        asm volatile(RSLAB6_FULL
+                     :
+                     : [la0] "v"(la0), [la1] "v"(la1), [lb0] "v"(lb0), [lb1] "v"(lb1),
+                       [ab0] "v"(ab[0]), [ab1] "v"(ab[1]), [ab2] "v"(ab[2]), [ab3] "v"(ab[3]),
+                       [mk0] "v"(mk[0]), [mk1] "v"(mk[1]), [mk2] "v"(mk[2]), [mk3] "v"(mk[3]),
+                       [wo0] "v"(wo[0]), [wo1] "v"(wo[1]), [wo2] "v"(wo[2]), [wo3] "v"(wo[3]),
+                       [zlo] "v"(zlo), [zhi] "v"(zhi), [so] "s"(uniform64((unsigned long)so)), [wb] "s"(uniform64((unsigned long)wb)), [tb] "s"(__builtin_amdgcn_readfirstlane(tb)), [ma] "s"(ma), [mb] "s"(mb)
+                     : "memory", "vcc", "scc", "m0", RCL_VTMP, RCL_AGPR);
+      } else if (kt + 1 < nk) {
+        RELNET_W_NEXT()
+        const unsigned mb = __builtin_amdgcn_readfirstlane(lds0 + WBASE + (unsigned)((kt + 1) & 1) * SLOT + wave * (B_GROUPS * 1024));
+        asm volatile(RSLAB6_WONLY
+                     :
+                     : [la0] "v"(la0), [la1] "v"(la1), [lb0] "v"(lb0), [lb1] "v"(lb1),
+                       [wo0] "v"(wo[0]), [wo1] "v"(wo[1]), [wo2] "v"(wo[2]), [wo3] "v"(wo[3]), [wb] "s"(uniform64((unsigned long)wb)), [mb] "s"(mb)
+                     : "memory", "scc", "m0", RCL_VTMP, RCL_AGPR);
+      } else {
+        asm volatile(RSLAB6_LAST
+                     :
+                     : [la0] "v"(la0), [la1] "v"(la1), [lb0] "v"(lb0), [lb1] "v"(lb1)
+                     : "memory", RCL_VTMP, RCL_AGPR);
+      }
+      aslot = aslot == 2 ? 0u : aslot + 1u;
+    }
+#undef RELNET_A_NEXT
+#undef RELNET_W_NEXT
   } else if constexpr (SCHED == 4) {
     // Window schedule for 3x3 / stride 1 layers (host checks the geometry): the k-loop runs (channel chunk, tap); the nine taps of a
     // 64-channel chunk read the SAME input pixels shifted by ((r - 1) W + (s - 1)) dil, so the A operand of a chunk is staged ONCE
@@ -1225,7 +1374,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
   for (int e = 0; e < VEC; ++e) bv[e] = (g.bias_mode == 1 && n + e < g.N) ? g.bias[n + e] : 0.f;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    if constexpr (SCHED == 5) {          // band i of the AGPR-resident accumulators (block i * TN + j = a[16 (2 i + j) ...])
+    if constexpr (SCHED == 5 || SCHED == 6) {          // band i of the AGPR-resident accumulators (block i * TN + j = a[16 (2 i + j) ...])
       switch (i) {
         case 0: agpr_read16<0>(acc[0][0]); agpr_read16<16>(acc[0][1]); break;
         case 1: agpr_read16<32>(acc[1][0]); agpr_read16<48>(acc[1][1]); break;
@@ -1765,7 +1914,7 @@ extern "C" void relnet_gemm_force_nloop(int n) { g_force_nloop = n; }
 extern "C" void relnet_gemm_set_swizzle(int on) { g_swizzle = on; }
 static int g_korder = 1;         // tuning knob: 1 = (channel chunk, tap) k order + XCD-contiguous row tiles for R*S > 1 ring launches
 extern "C" void relnet_gemm_debug_korder(int on) { g_korder = on; }
-static int g_asm = 1;            // tuning knob: 0 = pick_tile never chooses tile 18 (hand-scheduled k-loop)
+static int g_asm = 1;            // tuning knob: 0 = pick_tile never chooses tiles 18 / 19 (hand-scheduled k-loops)
 extern "C" void relnet_gemm_debug_asm(int on) { g_asm = on; }
 
 template <int BM, int BN, int WM, int WN, int CONV>
@@ -1813,7 +1962,7 @@ static void launch_ring(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
   const int nthr = 64 * WM * WN;
   if constexpr (CONV == 1) {
     if (g_ablate && g_ablate <= 2 && out_dtype == RELNET_BF16 && !g.resid) {
-      constexpr int ASCHED = SCHED == 5 ? 0 : SCHED;          // (the asm k-loop has no ablation forms)
+      constexpr int ASCHED = (SCHED == 5 || SCHED == 6) ? 0 : SCHED;          // (the asm k-loops have no ablation forms)
       if (g_ablate == 1) gemm_ring_kernel<BM, BN, WM, WN, unsigned short, CONV, BK, NSTAGE, false, ASCHED, 1><<<grid, nthr, 0, s>>>(g);
       else gemm_ring_kernel<BM, BN, WM, WN, unsigned short, CONV, BK, NSTAGE, false, ASCHED, 2><<<grid, nthr, 0, s>>>(g);
       return;
@@ -1863,7 +2012,8 @@ static void launch_ring(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
 //                                   17 = 8 with the A operand of 3x3 / stride-1 layers staged once per channel chunk as a pixel WINDOW shared by
 //                                        the nine taps (other shapes under 17 run configuration 8)
 //                                   18 = 8 with the hand-scheduled (inline asm) k-loop on shortcut-free layers whose N is a multiple of 256
-enum { GEMM_TILE_COUNT = 18 };
+//                                   19 = 18 with the asymmetric ring (activations three slots / two slabs ahead, filters two slots)
+enum { GEMM_TILE_COUNT = 19 };
 
 template <int CONV>
 static bool launch_panel(const GemmArgs& g0, int batch, int out_dtype, hipStream_t s, bool use_wf = false, bool occ2 = false) {
@@ -1943,10 +2093,10 @@ static int pick_tile(long M, long N, long K, int batch, int out_dtype, int has_r
   // shortcut-free 256x256 layers (3x3 / reduce convolutions, FC layers): the ring kernel's conflict-free LDS image and
   // residual-free register budget are worth 3-11 % (r02 tile table: res5 3x3 642 -> 574 us, rpn 3x3 1244 -> 1131 us)
   if (cfg == 1 && !has_resid) cfg = 8;
-  // ... and with K >= 2048 (res4 / res5 / RPN 3x3, res5 reduce, fc_new_1) the hand-scheduled k-loop of tile 18: the MFMA-bound layers
-  // gain 13-19 % (r04, 54 images, us per launch: res4 3x3 169 -> 147, res5 3x3 628 -> 512, rpn 3x3 1206 -> 975, res5 reduce 316 -> 290);
-  // the K = 1024 reduce layers are bound by the HBM fill of their activation rows and stay on tile 8 (97 vs 101 us)
-  if (cfg == 8 && K >= 2048 && N % 256 == 0 && g_asm) cfg = 18;
+  // ... and from K = 512 the hand-scheduled k-loop with the asymmetric ring (tile 19; tile 18 = the same loop on the symmetric
+  // two-slab ring).  r04, 54 images, us per launch, tile 8 / 18 / 19: res4 3x3 165 / 148 / 143, res5 3x3 603 / 515 / 503,
+  // rpn 3x3 1157 / 972 / 950, res5 reduce 327 / 299 / 281, res4 reduce (K = 1024, HBM-fed) 97 / 99 / 90, conv_new_1 180 / 170 / 154
+  if (cfg == 8 && K >= 512 && N % 256 == 0 && g_asm) cfg = 19;
   // res4 expand convolutions (256 -> 1024 + shortcut, 23 per step): with the weights also available in fragment order the
   // panel kernel reads A once and never stages W in LDS: 219 -> 191..203 us (r02 tile table; every other shape is slower)
   if (cfg == 1 && has_resid && has_wf && K == 256 && batch == 1) cfg = 14;
@@ -1957,7 +2107,7 @@ static int pick_tile(long M, long N, long K, int batch, int out_dtype, int has_r
   // convolution totals 5.60 -> 4.6 ms (8 images), 2.14 -> 1.7 ms (1 image).
   auto wgs = [&](long bm, long bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long)batch; };
   const int small = wgs(128, 64) >= 200 ? 4 : 5;
-  if ((cfg == 1 || cfg == 8 || cfg == 18) && wgs(256, 256) < 128) cfg = small;
+  if ((cfg == 1 || cfg == 8 || cfg == 18 || cfg == 19) && wgs(256, 256) < 128) cfg = small;
   else if (cfg == 2 && wgs(256, 128) < 128) cfg = small;
   else if (cfg == 3 && wgs(128, 128) < 200) cfg = small;
   else if (cfg == 4 && N > 64 && wgs(128, 64) < 200) cfg = 5;
@@ -2002,9 +2152,11 @@ static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t
       launch_ring<256, 256, 2, 4, CONV, 64, 2>(g, batch, out_dtype, s);
       break;
     case 18:
+    case 19:
       if constexpr (CONV != 2) {
         bool ok = !g.resid && g.N % 256 == 0 && g.K % 64 == 0 && (long)g.N * g.ldw * 2 < (1L << 32);
         if constexpr (CONV == 1) ok = ok && g.cCin % 64 == 0 && g.cR * g.cS <= 32 && (g.cR * g.cS == 1 || g_korder);
+        if (ok && cfg == 19) { launch_ring<256, 256, 2, 4, CONV, 64, 2, 6>(g, batch, out_dtype, s); break; }
         if (ok) { launch_ring<256, 256, 2, 4, CONV, 64, 2, 5>(g, batch, out_dtype, s); break; }
       }
       launch_ring<256, 256, 2, 4, CONV, 64, 2>(g, batch, out_dtype, s);

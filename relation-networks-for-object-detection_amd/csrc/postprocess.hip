@@ -76,14 +76,33 @@ struct ClsNmsArgs {
   const double* scores64;    // optional [B, N] float64 scores of a SINGLE class (C == 2): used instead of cls_prob
                              // (the lib/nms/nms.py wrappers take float64 `dets`)
   int* pick_index;           // optional [B, C-1, N]: roi index of every pick (`keep` of nms.py:45-82)
+  unsigned int* hist;        // PRUNE kernels: [B, kHistBins] zero-initialised by the caller: histogram of the keys of all picks of an image
+  int top_k;                 // PRUNE kernels: max_per_image
 };
+
+// Image-level pruning of the per-class lists (tester.py:270-277 keeps, per image, the detections whose score is >= the top_k-th
+// largest over all classes).  A class's pick sequence is non-increasing (soft-NMS only lowers scores, every pick is the current
+// maximum), so once its LATEST pick lies below a lower bound of that final threshold, none of its later picks can be kept.
+// The bound: every pick of the image is counted in a shared histogram over the top 16 bits of its float64 score (sign, exponent,
+// 5 mantissa bits: 3 % resolution); t = the bin in which the count from the top reaches top_k.  Histograms of SUBSETS of the final
+// pick set can only give a lower t, so a stale or partial view (other classes still running, agent-scope relaxed reads) prunes
+// less, never wrongly: a class stops when bin(latest pick) < t.  The lists written are prefixes of the full lists and contain
+// every pick >= the final threshold, so relnet_image_topk returns the same detections; counts[] = picks actually produced.
+// With 80 similar classes (the benchmark's random-init heads: all 300 rois are candidates in every class) a class stops after
+// 2-3 picks instead of 100.
+constexpr int kHistBins = 384;                      // scores in [2^-11, 2): (exponent - 1012) * 32 + 5 mantissa bits
+__device__ __forceinline__ int score_bin(double sc) {
+  const long long bits = __double_as_longlong(sc);
+  const long long bin = (bits >> 47) - (1012LL << 5);
+  return bits <= 0 ? 0 : (bin < 0 ? 0 : (bin >= kHistBins ? kHistBins - 1 : (int)bin));
+}
 
 // "absent / already picked / suppressed" marker of a candidate's score.  -inf, not -1: the lib/nms/nms.py twins accept any
 // float64 dets[:, 4] (raw logits, negative scores), which must stay distinguishable from removed slots.
 #define kGone (-INFINITY)
 
 // kPerLane * 64 >= N candidates per (image, class)
-template <int kPerLane>
+template <int kPerLane, bool PRUNE = false>
 __global__ __launch_bounds__(64) void class_nms_kernel(ClsNmsArgs g) {
   const int cls = blockIdx.x + 1, b = blockIdx.y, lane = threadIdx.x;
   const float* prob = g.cls_prob + (long)b * g.N * g.C;
@@ -136,6 +155,28 @@ __global__ __launch_bounds__(64) void class_nms_kernel(ClsNmsArgs g) {
       if (g.pick_index) g.pick_index[((long)b * (g.C - 1) + (cls - 1)) * g.N + picked] = bi;
     }
     ++picked;
+    if constexpr (PRUNE) {
+      // count this pick, then look at the image's histogram: bins [6 lane, 6 lane + 6), count from the top bin down
+      unsigned int* hist = g.hist + (long)b * kHistBins;
+      const int mybin = score_bin(best);
+      if (lane == 0) __hip_atomic_fetch_add(hist + mybin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned int c[6], tot = 0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { c[q] = __hip_atomic_load(hist + lane * 6 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tot += c[q]; }
+      unsigned int suf = tot;                        // inclusive suffix sum over lanes: picks in bins >= 6 lane
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const unsigned int v = __shfl_down(suf, o); if (lane + o < 64) suf += v; }
+      const unsigned long long m = __ballot(suf >= (unsigned)g.top_k);
+      if (m) {
+        const int L = 63 - __clzll(m);               // highest lane whose suffix reaches top_k: the bound's bin is one of its six
+        unsigned int acc = suf - tot;                // picks in the lanes above
+        int t = lane * 6;
+#pragma unroll
+        for (int q = 5; q >= 0; --q) { acc += c[q]; if (acc >= (unsigned)g.top_k) { t = lane * 6 + q; break; } }
+        t = __shfl(t, L);
+        if (mybin < t) break;                        // every later pick of this class is <= this one: below the image cut for good
+      }
+    }
 #pragma unroll
     for (int s = 0; s < kPerLane; ++s) {
       if (s * 64 + lane == bi) { sc[s] = kGone; continue; }
@@ -371,7 +412,7 @@ extern "C" int relnet_class_nms_ex(const float* cls_prob, const double* scores64
   RELNET_REQUIRE(B > 0 && N > 0 && N <= 1024 && C > 1, "relnet_class_nms: need 0 < N <= 1024 (N=%d)", N);
   RELNET_REQUIRE(!scores64 || C == 2, "relnet_class_nms: float64 scores are one foreground class (C == 2), got C=%d", C);
   ClsNmsArgs g{cls_prob, boxes, dets, counts, N, C, score_thresh, nms_param, soft, max_picks > 0 ? max_picks : N,
-               scores64, pick_index};
+               scores64, pick_index, nullptr, 0};
   dim3 grid(C - 1, B);
   hipStream_t s = (hipStream_t)stream;
   if (N <= 320) class_nms_kernel<5><<<grid, 64, 0, s>>>(g);
@@ -385,6 +426,22 @@ extern "C" int relnet_class_nms(const float* cls_prob, const double* boxes, doub
                                 int max_picks, void* stream) {
   return relnet_class_nms_ex(cls_prob, nullptr, boxes, dets, counts, nullptr, B, N, C, score_thresh, nms_param, soft,
                              max_picks, stream);
+}
+
+// relnet_class_nms with image-level pruning (see kHistBins above): dets / counts as relnet_class_nms, but a class list stops as
+// soon as its next pick cannot be among the top_k scores of its image.  `hist`: B x relnet_class_nms_hist_bins() unsigned ints,
+// ZEROED by the caller before every call.  N <= 512.
+extern "C" int relnet_class_nms_hist_bins(void) { return kHistBins; }
+extern "C" int relnet_class_nms_topk(const float* cls_prob, const double* boxes, double* dets, int* counts, void* hist, int B, int N,
+                                     int C, float score_thresh, double nms_param, int soft, int max_picks, int top_k, void* stream) {
+  RELNET_REQUIRE(cls_prob && boxes && dets && counts && hist, "relnet_class_nms_topk: null operand");
+  RELNET_REQUIRE(B > 0 && N > 0 && N <= 512 && C > 1 && top_k > 0, "relnet_class_nms_topk: need 0 < N <= 512, top_k > 0 (N=%d top_k=%d)", N, top_k);
+  ClsNmsArgs g{cls_prob, boxes, dets, counts, N, C, score_thresh, nms_param, soft, max_picks > 0 ? max_picks : N, nullptr, nullptr,
+               (unsigned int*)hist, top_k};
+  dim3 grid(C - 1, B);
+  if (N <= 320) class_nms_kernel<5, true><<<grid, 64, 0, (hipStream_t)stream>>>(g);
+  else class_nms_kernel<8, true><<<grid, 64, 0, (hipStream_t)stream>>>(g);
+  return check_launch("relnet_class_nms_topk");
 }
 
 extern "C" int relnet_image_topk(const double* dets, const int* counts, double* thresh, int* total,

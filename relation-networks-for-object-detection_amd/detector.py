@@ -132,8 +132,10 @@ class Detector(object):
                                       rois.view(B * N, 5), im_info, N)
         out['cls_prob'], out['pred_boxes'] = prob.view(B, N, -1), boxes.view(B, N, 4)
         if post:
+            # (top_k: a class list stops once its next pick cannot reach the image's max_per_image best scores -- the lists are
+            #  prefixes of the full per-class lists that contain everything image_topk keeps: relnet_class_nms_topk)
             dets, counts = ops.class_nms(out['cls_prob'], out['pred_boxes'], c.score_thresh, c.nms, c.softnms,
-                                         max_picks=c.max_per_image)
+                                         max_picks=c.max_per_image, top_k=c.max_per_image)
             det, det_count, thresh, total = ops.image_topk(dets, counts, c.max_per_image)
             out.update(class_dets=dets, class_counts=counts, detections=det, num_detections=det_count,
                        image_thresh=thresh)
@@ -201,7 +203,7 @@ class FPNDetector(object):
         out['cls_prob'], out['pred_boxes'] = prob.view(B, N, -1), boxes.view(B, N, 4)
         if post:
             dets, cnts = ops.class_nms(out['cls_prob'], out['pred_boxes'], c.score_thresh, c.nms, c.softnms,
-                                       max_picks=c.max_per_image)
+                                       max_picks=c.max_per_image, top_k=c.max_per_image)
             det, det_count, thresh, total = ops.image_topk(dets, cnts, c.max_per_image)
             out.update(class_dets=dets, class_counts=cnts, detections=det, num_detections=det_count, image_thresh=thresh)
         return out

@@ -301,12 +301,14 @@ def detect_head(cls_score, bbox_pred, rois, im_info, rois_per_image, delta_off=4
 
 
 def class_nms(cls_prob, boxes, score_thresh=1e-3, nms_param=0.6, soft=True, max_picks=0, scores64=None,
-              want_index=False):
+              want_index=False, top_k=0):
     """cls_prob [B,N,C] fp32, boxes [B,N,4] float64 -> dets [B,C-1,N,5] float64 (pick order),
     counts [B,C-1] int32.  max_picks > 0 truncates every class list after that many picks
     (exactly the rows that can survive the image-level max_per_image cut).
     scores64 [B,N] float64 (one class; cls_prob None) is the `dets[:, 4]` form of lib/nms/nms.py;
-    want_index also returns pick_index [B,C-1,N] int32 (roi index of every pick)."""
+    want_index also returns pick_index [B,C-1,N] int32 (roi index of every pick).
+    top_k > 0 (the detector passes max_per_image): a class list additionally stops as soon as its next pick cannot be among the
+    top_k scores of its image (relnet_class_nms_topk) -- a prefix of the full lists that contains every pick image_topk keeps."""
     _chk(cls_prob, boxes, scores64)
     if scores64 is not None:
         assert cls_prob is None and scores64.dtype == torch.float64 and scores64.is_contiguous()
@@ -319,6 +321,11 @@ def class_nms(cls_prob, boxes, score_thresh=1e-3, nms_param=0.6, soft=True, max_
     dets = torch.zeros((B, Cn - 1, N, 5), device=boxes.device, dtype=torch.float64)
     counts = torch.empty((B, Cn - 1), device=boxes.device, dtype=torch.int32)
     index = torch.full((B, Cn - 1, N), -1, device=boxes.device, dtype=torch.int32) if want_index else None
+    if top_k > 0 and scores64 is None and not want_index and N <= 512:
+        hist = torch.zeros((B, _lib.load().relnet_class_nms_hist_bins()), device=boxes.device, dtype=torch.int32)
+        _lib.call('relnet_class_nms_topk', cls_prob.data_ptr(), boxes.data_ptr(), dets.data_ptr(), counts.data_ptr(), hist.data_ptr(),
+                  B, N, Cn, float(score_thresh), float(nms_param), int(soft), int(max_picks), int(top_k), _stream())
+        return dets, counts
     _lib.call('relnet_class_nms_ex', _ptr(cls_prob), _ptr(scores64), boxes.data_ptr(), dets.data_ptr(), counts.data_ptr(),
               _ptr(index), B, N, Cn, float(score_thresh), float(nms_param), int(soft), int(max_picks), _stream())
     return (dets, counts, index) if want_index else (dets, counts)

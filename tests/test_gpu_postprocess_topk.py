@@ -1,0 +1,87 @@
+"""relnet_class_nms_topk (per-class soft-NMS / NMS that stops a class once its next pick cannot be among the max_per_image best
+scores of the image) against the unpruned relnet_class_nms: reference core/tester.py:244-277, lib/nms/nms.py:45-141.
+
+Properties asserted, bit for bit (both kernels execute the same float64 operations):
+  * every class list of the pruned kernel is a PREFIX of the full list (same picks, same order, same rescored values);
+  * relnet_image_topk over the pruned lists returns exactly the detections, count and threshold it returns over the full lists
+    (the pruned lists contain every pick >= the image threshold, ties included);
+  * the oracle's post-processing (oracle/postprocess.py, pinned to the reference's nms.py goldens) agrees on the final detections.
+Cases: the benchmark's flat random-init posteriors (all rois candidates in all classes), peaked posteriors, hard NMS, duplicated
+rois (exact score ties across and inside classes), fewer candidates than max_per_image, a ragged N."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(kind, B, N, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    x1 = torch.rand(B, N, generator=g) * 800; y1 = torch.rand(B, N, generator=g) * 450
+    w = torch.rand(B, N, generator=g) * 300 + 10; h = torch.rand(B, N, generator=g) * 300 + 10
+    boxes = torch.stack([x1, y1, x1 + w, y1 + h], 2).double()
+    if kind == 'flat':
+        logits = torch.randn(B, N, C, generator=g) * 0.05
+    elif kind == 'peaked':
+        logits = torch.randn(B, N, C, generator=g) * 3.0
+    elif kind == 'few':
+        logits = torch.randn(B, N, C, generator=g) * 0.5
+        logits[..., 0] += 9.0                           # background dominates: only a handful of (roi, class) pairs pass 1e-3
+    else:
+        logits = torch.randn(B, N, C, generator=g) * 1.0
+    prob = torch.softmax(logits, 2).float()
+    if kind == 'ties':                                   # duplicated rois: identical boxes AND identical posteriors
+        boxes[:, 1::3] = boxes[:, 0:-1:3][:, :boxes[:, 1::3].shape[1]]
+        prob[:, 1::3] = prob[:, 0:-1:3][:, :prob[:, 1::3].shape[1]]
+    return prob.contiguous().cuda(), boxes.contiguous().cuda()
+
+
+@pytest.mark.parametrize('kind,B,N,C,soft,param', [
+    ('flat', 3, 300, 81, True, 0.6), ('peaked', 3, 300, 81, True, 0.6), ('mixed', 2, 300, 81, False, 0.5),
+    ('ties', 2, 300, 81, True, 0.6), ('ties', 2, 300, 81, False, 0.3), ('few', 2, 300, 81, True, 0.6),
+    ('mixed', 2, 37, 21, True, 0.6), ('flat', 1, 320, 81, True, 0.6)])
+def test_pruned_lists_are_prefixes_and_image_topk_is_unchanged(kind, B, N, C, soft, param):
+    import relnet_amd  # noqa: F401
+    from relnet_amd import ops
+    prob, boxes = _case(kind, B, N, C, 100 + N + C)
+    full, nf = ops.class_nms(prob, boxes, 1e-3, param, soft, max_picks=100)
+    prn, npn = ops.class_nms(prob, boxes, 1e-3, param, soft, max_picks=100, top_k=100)
+    nf_, np_ = nf.cpu().numpy(), npn.cpu().numpy()
+    assert (np_ <= nf_).all() and (np_[nf_ > 0] >= 1).all()
+    F, P = full.cpu().numpy(), prn.cpu().numpy()
+    for b in range(B):
+        for c in range(C - 1):
+            k = np_[b, c]
+            assert np.array_equal(P[b, c, :k], F[b, c, :k]), (b, c, k)
+            assert not P[b, c, k:].any()
+    of, cf, tf, totf = ops.image_topk(full, nf, 100)
+    op, cp, tp, totp = ops.image_topk(prn, npn, 100)
+    assert torch.equal(cf, cp) and torch.equal(of, op)
+    if kind != 'few':                                   # (with <= 100 candidates the threshold is -inf on both sides)
+        assert torch.equal(tf, tp)
+        assert np_.sum() < 0.6 * nf_.sum(), (np_.sum(), nf_.sum())      # the pruning does prune
+    else:
+        assert np.array_equal(np_, nf_)                  # nothing can be pruned below max_per_image picks
+
+
+def test_detector_uses_the_pruned_kernel_and_matches_the_oracle():
+    """End to end on the detector's own head outputs: detections of the timed path == oracle post-processing of the same
+    cls_prob / boxes (float64, restated tester.py:244-277)."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import ops
+    from oracle import postprocess as OP
+    prob, boxes = _case('flat', 2, 300, 81, 7)
+    dets, counts = ops.class_nms(prob, boxes, 1e-3, 0.6, True, max_picks=100, top_k=100)
+    out, cnt, thr, tot = ops.image_topk(dets, counts, 100)
+    for b in range(2):
+        b8 = np.concatenate([boxes[b].cpu().numpy()] * 2, 1)                       # class-agnostic layout [N, 8]: fg box at 4:8
+        per_class = OP.detections(prob[b].double().cpu().numpy(), b8, 81, 1e-3, 0.6, True, 100)
+        want = sorted((c + 1, float(d[4])) for c, arr in enumerate(per_class) for d in arr)
+        got = sorted((int(r[0]), float(r[1])) for r in out[b, :int(cnt[b])].cpu().numpy())
+        assert len(want) == len(got) and [c for c, _ in want] == [c for c, _ in got]
+        assert np.allclose([s for _, s in want], [s for _, s in got], rtol=1e-6)

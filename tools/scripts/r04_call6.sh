@@ -1,0 +1,13 @@
+#!/bin/bash
+O=gpurun_out/r04_6; mkdir -p $O
+RELNET_TEST_TILES=18,19 timeout 900 python -m pytest tests/test_gpu_gemm_tiles.py tests/test_gpu_postprocess_topk.py -x -q > $O/tests.log 2>&1; tail -8 $O/tests.log
+TILES=8,18,19,8,18,19 timeout 600 python tools/bench_tiles.py 54 > $O/bench_tiles_b54.txt 2>&1; cat $O/bench_tiles_b54.txt
+F="--no-cpu-baseline --no-train-line --no-other-configs"
+python bench.py $F > $O/bench.json 2> $O/bench.err; tail -3 $O/bench.err
+python - <<'P'
+import json
+r=json.loads(open('gpurun_out/r04_6/bench.json').read().strip().splitlines()[-1])
+print('value', r['value'], r['ms_per_step']); print('sweep', {k:(v['ms_per_step'] if isinstance(v,dict) else v) for k,v in r.get('batch_sweep').items() if k!='note'})
+print(r['kernels_ms'])
+print('parity', {k:v for k,v in r['parity'].items() if k in ('proposal_rows_identical','roi_pool_mismatches','detections_matched','detections_gpu','detections_oracle')})
+P
