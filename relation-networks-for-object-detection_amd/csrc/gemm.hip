@@ -536,6 +536,10 @@ template <int BK> __device__ __forceinline__ int ring_swz(int row) { return BK =
   "s_waitcnt lgkmcnt(0)\n\t"                                                               \
   RKSTEP_X(1, RSLAB6_K1_READS, "", "", "", "", "")                                           \
   RSLAB6_TAIL("s_nop 15\n\ts_nop 7\n\t")
+// (measured and dropped, r04: the same loop over a per-chunk activation WINDOW shared by the nine taps of a 3x3 layer -- tile 20, -42 % of
+//  the L2 -> LDS fill bytes, border taps zeroed by per-row masks -- parity-green and SLOWER: res4 3x3 152 vs 143 us, rpn 3x3 952 vs 955 us.
+//  With the hand-scheduled loop these layers run at ~1.07 PFLOP/s on random operands, 55 % MFMA-busy per slab; the fill bytes are not
+//  what is left)
 #define RCL_AGPR "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", RCL10(a, 1), RCL10(a, 2), RCL10(a, 3), RCL10(a, 4), RCL10(a, 5), \
                  RCL10(a, 6), RCL10(a, 7), RCL10(a, 8), RCL10(a, 9), RCL10(a, 10), RCL10(a, 11), "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
 #define RCL10(P, B) #P #B "0", #P #B "1", #P #B "2", #P #B "3", #P #B "4", #P #B "5", #P #B "6", #P #B "7", #P #B "8", #P #B "9"
@@ -2156,7 +2160,7 @@ static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t
       if constexpr (CONV != 2) {
         bool ok = !g.resid && g.N % 256 == 0 && g.K % 64 == 0 && (long)g.N * g.ldw * 2 < (1L << 32);
         if constexpr (CONV == 1) ok = ok && g.cCin % 64 == 0 && g.cR * g.cS <= 32 && (g.cR * g.cS == 1 || g_korder);
-        if (ok && cfg == 19) { launch_ring<256, 256, 2, 4, CONV, 64, 2, 6>(g, batch, out_dtype, s); break; }
+        if (ok && cfg != 18) { launch_ring<256, 256, 2, 4, CONV, 64, 2, 6>(g, batch, out_dtype, s); break; }
         if (ok) { launch_ring<256, 256, 2, 4, CONV, 64, 2, 5>(g, batch, out_dtype, s); break; }
       }
       launch_ring<256, 256, 2, 4, CONV, 64, 2>(g, batch, out_dtype, s);
