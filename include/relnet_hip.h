@@ -83,7 +83,6 @@ void relnet_gemm_force_tile(int cfg);     /* tuning knob: 0 = auto, 1..5 = fixed
 void relnet_gemm_force_nloop(int n);      /* tuning knob: 0 = auto, n = column tiles per workgroup     */
 void relnet_gemm_set_swizzle(int on);     /* tuning knob: XCD-aware tile order (default 1)               */
 void relnet_gemm_debug_korder(int on);    /* tuning knob: (channel chunk, tap) k order of the spatial ring convolutions (default 1) */
-void relnet_chain_debug_split(int on);    /* tuning knob: 1 = res4 expand (relnet_bottleneck_chain, mid 256, no reduce) as two 4-wave workgroups per CU; default 0 */
 void relnet_gemm_debug_asm(int on);       /* tuning knob: 0 = the automatic tile choice never takes tiles 18 / 19 (hand-scheduled k-loops); default 1 */
 void relnet_gemm_debug_ablate(int a);     /* measurement knob for tile 8: 1 = fill path only, 2 = LDS + MFMA only (garbage results) */
 int relnet_gemm_tile_count(void);         /* number of tile configurations (valid relnet_gemm_force_tile values 1..count) */

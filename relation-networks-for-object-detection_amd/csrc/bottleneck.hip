@@ -51,11 +51,11 @@ struct ChainArgs {
 // Nothing on the vector-memory path is issued inside the arithmetic (biases come from LDS): a load there would make the
 // compiler wait for the prefetch in front of it.
 // KSPLIT > 1 (MID = 512, res5; expand-only): the k range of a pass is cut in KSPLIT sub-steps so that a ring slot stays 32 KiB.
-// NW = wavefronts per workgroup (8; 4 for the two-workgroups-per-CU form of the streamed expand kernel: two lock-step groups that are
-// NOT in step with each other, so one group's per-pass memory drain overlaps the other's arithmetic).
-template <int MID, bool STREAM, bool REDUCE = true, int KSPLIT = 1, int NW = 8>       // REDUCE = false: only x_next (no next reduce)
-__global__ __launch_bounds__(64 * NW) void bottleneck_chain_kernel(ChainArgs a) {
-  constexpr int NT = 64 * NW;
+// (measured and dropped, r04: the res4 expand form as TWO 4-wave workgroups per CU -- 16 KB filter slots, the two groups out of step so
+//  that one group's per-pass vmcnt(0) drain overlaps the other's arithmetic -- bit-identical and slower, 163 vs 150 us at 54 images:
+//  the filter stream through L2 -> LDS doubles)
+template <int MID, bool STREAM, bool REDUCE = true, int KSPLIT = 1>       // REDUCE = false: only x_next (no next reduce)
+__global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
   static_assert(KSPLIT == 1 || (STREAM && !REDUCE), "k-split passes exist for the streamed expand-only form");
   constexpr int COUT = 4 * MID, KS = MID / 16, KSS = KS / KSPLIT, RT = MID / 32, NP = COUT / 64;
   constexpr int W3P = 2 * KSS * 1024, W1P = REDUCE ? 4 * RT * 1024 : 0;     // bytes of one (sub-)step's W3 / W1' slice
@@ -65,12 +65,12 @@ __global__ __launch_bounds__(64 * NW) void bottleneck_chain_kernel(ChainArgs a) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   unsigned char* stage = smem + WBYTES + wave * 8192;          // 2 x [32 px][128 B], chunk c of row r at c ^ ((r >> 1) & 7)
-  float* sB3 = (float*)(smem + WBYTES + NW * 8192);            // [COUT]
+  float* sB3 = (float*)(smem + WBYTES + 65536);                // [COUT]
   float* sB1 = sB3 + COUT;                                     // [MID]
-  for (int i = tid; i < COUT; i += NT) sB3[i] = a.b3[i];
-  if constexpr (REDUCE) for (int i = tid; i < MID; i += NT) sB1[i] = a.b1[i];
+  for (int i = tid; i < COUT; i += 512) sB3[i] = a.b3[i];
+  if constexpr (REDUCE) for (int i = tid; i < MID; i += 512) sB1[i] = a.b1[i];
   if constexpr (!STREAM) {                                      // resident layout: pass-major, [pass][W3 slice | W1' slice]
-    for (int i = tid; i < NP * (W3P + W1P) / 16; i += NT) {
+    for (int i = tid; i < NP * (W3P + W1P) / 16; i += 512) {
       const int p = i / ((W3P + W1P) / 16), r = i % ((W3P + W1P) / 16);
       uint4 v;
       if (r < W3P / 16 || !REDUCE) v = a.w3f[(long)p * (W3P / 16) + r];
@@ -97,8 +97,8 @@ __global__ __launch_bounds__(64 * NW) void bottleneck_chain_kernel(ChainArgs a) 
       const int p = st / KSPLIT, kh = st % KSPLIT;
       unsigned char* wb = smem + (st & 1) * (W3P + W1P);
 #pragma unroll
-      for (int i = 0; i < (2 * KSS + (REDUCE ? 4 * RT : 0)) / NW; ++i) {
-        const int q = wave + NW * i;
+      for (int i = 0; i < (2 * KSS + (REDUCE ? 4 * RT : 0)) / 8; ++i) {
+        const int q = wave + 8 * i;
         if (q < 2 * KSS) {
           const int ct = q / KSS, ks = q % KSS;
           __builtin_amdgcn_global_load_lds((gas_ptr)(a.w3f + ((long)((p * 2 + ct) * KS + kh * KSS + ks) * 64 + lane)), (las_ptr)(wb + q * 1024), 16, 0, 0);
@@ -122,9 +122,9 @@ __global__ __launch_bounds__(64 * NW) void bottleneck_chain_kernel(ChainArgs a) 
   };
 
   // tile sequence of this wavefront: independent tiles (resident) or lock-step sets of 8 tiles (streaming)
-  const int t_first = blockIdx.x * NW + wave;
-  const int t_step = gridDim.x * NW;
-  const int n_iter = STREAM ? ((ntile + NW - 1) / NW - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x
+  const int t_first = blockIdx.x * 8 + wave;
+  const int t_step = gridDim.x * 8;
+  const int n_iter = STREAM ? ((ntile + 7) / 8 - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x
                             : (ntile - t_first + t_step - 1) / t_step;      // (streaming: idle waves of the last set still take part)
   if (n_iter <= 0) return;
   issue_x(t_first * 32, 0);
@@ -236,9 +236,6 @@ using namespace relnet;
 // rows).  mid = 64 (res2: 64 -> 256 -> 64) or 128 (res3: 128 -> 512 -> 128).  w3f = relnet_pack_w_frag of W3 [4 mid][mid]; w1f = W1n [mid][4 mid] in the
 // accumulator-permuted fragment order (ops.pack_chain_w1).  Replaces two relnet_conv2d_nhwc launches
 // (resnet_v1_101_rcnn_base.py: res<s><u>_branch2c + shortcut + relu, res<s><u+1>_branch2a + relu).
-static int g_chain_split = 0;     // tuning knob (relnet_chain_debug_split): 1 = res4 expand as two 4-wave workgroups per CU
-extern "C" void relnet_chain_debug_split(int on) { g_chain_split = on; }
-
 extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const void* w3f, const void* w1f, const float* b3,
                                        const float* b1, void* x_next, void* mid1_next, long P, int mid, void* stream) {
   RELNET_REQUIRE(mid2 && x && w3f && b3 && x_next, "relnet_bottleneck_chain: null operand");
@@ -259,14 +256,6 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
   }
   const long ntile = (P + 31) / 32;
   const unsigned grid = (unsigned)(ntile < 8 * 256 ? (ntile + 7) / 8 : 256);     // persistent: one workgroup per CU
-  if (!mid1_next && mid == 256 && g_chain_split && ntile >= 4 * 512) {
-    // res4 expand: TWO 4-wave workgroups per CU (69 KB of LDS each: two 16 KB filter slots, 4 x 8 KB stage buffers, biases)
-    static relnet::PerDeviceOnce once2;
-    if (once2.first()) hipFuncSetAttribute((const void*)bottleneck_chain_kernel<256, true, false, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    const size_t lds2 = 32768 + 4 * 8192 + (size_t)5 * mid * 4;
-    bottleneck_chain_kernel<256, true, false, 2, 4><<<512, 256, lds2, (hipStream_t)stream>>>(a);
-    return check_launch("relnet_bottleneck_chain");
-  }
   const size_t lds = 65536 /* weights: resident (mid 64) or two ring slots (mid 128) */ + 65536 /* 8 x 2 stage buffers */ + (size_t)5 * mid * 4;
   if (mid1_next) {
     if (mid == 64) bottleneck_chain_kernel<64, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);

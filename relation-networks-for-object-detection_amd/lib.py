@@ -96,7 +96,6 @@ _SIGNATURES = {
     'relnet_gemm_set_swizzle': (None, [_i]),
     'relnet_gemm_debug_korder': (None, [_i]),
     'relnet_gemm_debug_asm': (None, [_i]),
-    'relnet_chain_debug_split': (None, [_i]),
     'relnet_gemm_debug_ablate': (None, [_i]),
     'relnet_gemm_tile_count': (C.c_int, []),
     'relnet_gemm_pick_tile': (C.c_int, [_i, _i, _i, _i, _i]),
@@ -149,14 +148,14 @@ def load():
         fn.argtypes = args
     # A/B knobs for whole-step measurements without editing code.  They change which kernels run, so they are honoured only
     # together with RELNET_DEBUG_KNOBS=1 and every use is announced on stderr (a forced tile is a measured-slower configuration)
-    knobs = [(k, os.environ[k]) for k in ('RELNET_GEMM_KORDER', 'RELNET_GEMM_FORCE_TILE', 'RELNET_GEMM_ASM', 'RELNET_CHAIN_SPLIT') if os.environ.get(k)]
+    knobs = [(k, os.environ[k]) for k in ('RELNET_GEMM_KORDER', 'RELNET_GEMM_FORCE_TILE', 'RELNET_GEMM_ASM') if os.environ.get(k)]
     if knobs and os.environ.get('RELNET_DEBUG_KNOBS') != '1':
         sys.stderr.write('relnet: ignoring %s (set RELNET_DEBUG_KNOBS=1 to apply kernel-selection knobs)\n' % ', '.join(k for k, _ in knobs))
     elif knobs:
         sys.stderr.write('relnet: DEBUG kernel-selection knobs in effect: %s\n' % ', '.join('%s=%s' % kv for kv in knobs))
         for k, v in knobs:
             {'RELNET_GEMM_KORDER': lib.relnet_gemm_debug_korder, 'RELNET_GEMM_FORCE_TILE': lib.relnet_gemm_force_tile,
-             'RELNET_GEMM_ASM': lib.relnet_gemm_debug_asm, 'RELNET_CHAIN_SPLIT': lib.relnet_chain_debug_split}[k](int(v))
+             'RELNET_GEMM_ASM': lib.relnet_gemm_debug_asm}[k](int(v))
     _lib = lib
     return lib
 
