@@ -303,18 +303,6 @@ int relnet_deformable_im2col(const void* data, const long* data_strides4, const 
                              const long* offset_strides4, void* col, long col_ld, int B, int C, int H, int W,
                              int KH, int KW, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
                              int dil_w, int num_deformable_group, int data_dtype, int col_dtype, void* stream);
-/* DeformableConvolutionOp::Forward (deformable_convolution-inl.h:91-143) as ONE kernel: the bilinear sampling of
- * nn/deformable_im2col.cuh:215-262 is the A-tile producer of the MFMA GEMM with the filter, so the [pixels][KH*KW*C] column
- * matrix is never written; sampled values are bit-identical to relnet_deformable_im2col.  data: logical [B,C,H,W] bf16 with
- * channels-last memory (data_strides4[1] == 1, C % 64 == 0), offset fp32 [B, 2*KH*KW*DG, Ho, Wo] (any strides),
- * w [Cout][KH*KW*C] bf16 (row pitch ldw, (tap, channel) order), bias fp32 [Cout] or NULL (folded BatchNorm), relu,
- * out [B*Ho*Wo][ldc] bf16.                                                                                            */
-int relnet_deformable_conv_fused(const void* data, const long* data_strides4, const float* offset,
-                                 const long* offset_strides4, const void* w, long ldw, const float* bias, int relu,
-                                 void* out, long ldc, int B, int C, int H, int W, int Cout, int KH, int KW, int pad_h,
-                                 int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int num_deformable_group,
-                                 void* stream);
-
 /* relation_rcnn/operator_cxx/deformable_psroi_pooling.cu:51-138 (DeformablePSROIPoolForwardKernel, called
  * from deformable_psroi_pooling-inl.h:64-95).  data logical [B, output_dim*group_size^2, H, W]; rois [R,5];
  * trans fp32 contiguous [R, 2*num_classes, part, part] or NULL (= no_trans); out / top_count logical

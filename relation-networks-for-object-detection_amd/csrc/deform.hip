@@ -131,176 +131,10 @@ __global__ __launch_bounds__(256) void deformable_im2col_cl_kernel(DeformColArgs
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// DeformableConvolutionOp::Forward as ONE kernel (deformable_convolution-inl.h:91-143: deformable_im2col, then a GEMM with
-// the filter): the bilinear sampling of nn/deformable_im2col.cuh:215-262 IS the A-tile producer of the MFMA GEMM, so the
-// [pixels][KH*KW*C] column matrix (22 MB per image and layer in res5) never exists in HBM.
-//   tile   128 output pixels x BN output channels (BN = all 512 of res5: every sampled value is produced once), 8 wavefronts
-//          (2 x 4, 64 x BN/4 each), k-slab = 64 channels of one kernel tap
-//   A      thread = (pixel, 8-channel chunk): offsets -> four corner addresses -> four 16-byte loads, issued one slab AHEAD
-//          and blended (the reference's fp32 operation order, contract off: bit-identical to relnet_deformable_im2col) into
-//          the LDS slab after the barrier that retires the previous slab
-//   W      [Cout][KH*KW*C] rows, 64-channel pieces by LDS-direct loads (global_load_lds) into two alternating buffers
-//   LDS    rows of 128 B, 16-byte chunk c of row r at slot c ^ ((r >> 1) & 7) (the conflict-free image of gemm.hip's ring
-//          kernel); fragments by ds_read_b128; D = W x A (lane <-> pixel): 8-byte stores of 4 consecutive channels
-// Epilogue: + bias (folded BatchNorm), ReLU, bf16.
-// ---------------------------------------------------------------------------------------------
-struct DeformFusedArgs {
-  DeformColArgs c;                   // data (channels last, ds_c == 1), offsets, geometry; col unused
-  const unsigned short* w; long ldw; // [Cout][KH*KW*C] bf16
-  const float* bias;                 // [Cout] or nullptr
-  unsigned short* out; long ldc;     // [B*Ho*Wo][ldc] bf16
-  int Cout, relu;
-};
+// (measured and removed, r03 / r04: a kernel with the bilinear sampling as the A-tile producer of the MFMA GEMM -- no column matrix in
+//  HBM -- took 0.54 ms per res5 layer at 27 images against 0.33 ms sampling + 0.23 ms GEMM, the four-corner gather through L2 being the
+//  bound of both forms; with the hand-scheduled GEMM loop of round 4 the two-kernel path is the faster one)
 
-__device__ __forceinline__ int dfz_swz(int row) { return (row >> 1) & 7; }
-
-template <int BN>
-__global__ __launch_bounds__(512) void deform_conv_fused_kernel(DeformFusedArgs f) {
-  constexpr int BM = 128, BK = 64, WTN = BN / 4, TN = WTN / 32;      // wave tile 64 x WTN
-  constexpr int WPT = BN * BK / 8 / 512;                               // 16-byte W chunks per thread per slab
-  extern __shared__ __attribute__((aligned(1024))) unsigned short dsm[];
-  unsigned short* sW0 = dsm;                   // [2][BN][64]: filled by LDS-direct loads, one slab ahead (no staging registers)
-  unsigned short* sA = dsm + 2 * BN * BK;      // [BM][64]
-  const DeformColArgs& g = f.c;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, half = lane >> 5;
-  const int wm = wave & 1, wn = wave >> 1;
-  const long P = (long)g.B * g.Ho * g.Wo;
-  const long m0 = (long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
-  const int cpg = g.C / g.DG;
-  const int nslab = g.KH * g.KW * (g.C / BK);
-
-  // A chunks of this thread: q = tid + 512 i -> pixel row q >> 3, channel chunk q & 7 (2 per slab)
-  int arow[2], acc_[2];
-  int pb[2], pho[2], pwo[2];
-  bool pok[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int q = tid + 512 * i;
-    arow[i] = q >> 3; acc_[i] = q & 7;
-    const long m = m0 + arow[i];
-    pok[i] = m < P;
-    const long mm = pok[i] ? m : 0;
-    pwo[i] = (int)(mm % g.Wo);
-    pho[i] = (int)((mm / g.Wo) % g.Ho);
-    pb[i] = (int)(mm / ((long)g.Wo * g.Ho));
-  }
-  uint4 cq[2][4];
-  float cw[2][4];
-  typedef const __attribute__((address_space(1))) void* gas_ptr;
-  typedef __attribute__((address_space(3))) void* las_ptr;
-  auto fetch = [&](int s) {
-    const int per_tap = g.C / BK;
-    const int tap = s / per_tap, c0 = (s - tap * per_tap) * BK;
-    const int ti = tap / g.KW, tj = tap - ti * g.KW;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = c0 + acc_[i] * 8;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { cq[i][k] = make_uint4(0u, 0u, 0u, 0u); cw[i][k] = 0.f; }
-      if (pok[i]) {
-        const Taps t = deform_taps(g, pb[i], pho[i], pwo[i], ti, tj, c / cpg);
-        if (t.inside) {
-          const unsigned short* p = (const unsigned short*)g.data + (long)pb[i] * g.ds_b + c;
-          cq[i][0] = *(const uint4*)(p + (long)t.ya * g.ds_h + (long)t.xa * g.ds_w);
-          cq[i][1] = *(const uint4*)(p + (long)t.ya * g.ds_h + (long)t.xb * g.ds_w);
-          cq[i][2] = *(const uint4*)(p + (long)t.yb * g.ds_h + (long)t.xa * g.ds_w);
-          cq[i][3] = *(const uint4*)(p + (long)t.yb * g.ds_h + (long)t.xb * g.ds_w);
-          cw[i][0] = t.w1; cw[i][1] = t.w2; cw[i][2] = t.w3; cw[i][3] = t.w4;
-        }
-      }
-    }
-    // W slab s -> buffer s & 1.  One LDS-direct instruction of a wave fills 1 KiB = 8 rows x 128 B (lane l: row l >> 3, slot
-    // l & 7); the chunk swizzle is applied on the SOURCE address (the destination is lane-linear by construction)
-    const long k0 = (long)tap * g.C + c0;
-    unsigned short* sWb = sW0 + (s & 1) * BN * BK;
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int row = (wave * WPT + i) * 8 + (lane >> 3), slot = lane & 7;
-      const unsigned short* src = f.w + (long)(n0 + row) * f.ldw + k0 + ((slot ^ dfz_swz(row)) << 3);
-      if (n0 + row >= f.Cout) src = f.w;            // rows past Cout: any valid address (their outputs are never stored)
-      __builtin_amdgcn_global_load_lds((gas_ptr)(const void*)src, (las_ptr)(void*)(sWb + (wave * WPT + i) * 8 * BK), 16, 0, 0);
-    }
-  };
-  auto stage = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      uint4 o;
-      unsigned int* po = (unsigned int*)&o;
-      const unsigned int* a1 = (const unsigned int*)&cq[i][0]; const unsigned int* a2 = (const unsigned int*)&cq[i][1];
-      const unsigned int* a3 = (const unsigned int*)&cq[i][2]; const unsigned int* a4 = (const unsigned int*)&cq[i][3];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {      // the reference's order: w1 v1 + w2 v2 + w3 v3 + w4 v4 (deformable_im2col.cuh:104-112)
-        const float lo = cw[i][0] * __uint_as_float(a1[k] << 16) + cw[i][1] * __uint_as_float(a2[k] << 16) +
-                         cw[i][2] * __uint_as_float(a3[k] << 16) + cw[i][3] * __uint_as_float(a4[k] << 16);
-        const float hi = cw[i][0] * __uint_as_float(a1[k] & 0xffff0000u) + cw[i][1] * __uint_as_float(a2[k] & 0xffff0000u) +
-                         cw[i][2] * __uint_as_float(a3[k] & 0xffff0000u) + cw[i][3] * __uint_as_float(a4[k] & 0xffff0000u);
-        po[k] = pack_bf16x2(lo, hi);
-      }
-      *(uint4*)(sA + arow[i] * BK + ((acc_[i] ^ dfz_swz(arow[i])) << 3)) = o;
-    }
-  };
-
-  f32x16 acc[TN][2];                           // [channel tile][pixel tile]
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-
-  fetch(0);
-  for (int s = 0; s < nslab; ++s) {
-    __syncthreads();                           // the previous slab has been consumed; W slab s has landed (vmcnt(0) at the barrier)
-    stage();
-    __syncthreads();
-    if (s + 1 < nslab) fetch(s + 1);           // next slab's offset / corner / weight loads fly under this slab's MFMAs
-    const unsigned short* sW = sW0 + (s & 1) * BN * BK;
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      const int ch = 2 * kk + half;
-      bf16x8 af[2], wf[TN];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = wm * 64 + i * 32 + l31;
-        af[i] = *(const bf16x8*)(sA + row * BK + ((ch ^ dfz_swz(row)) << 3));
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = wn * WTN + j * 32 + l31;
-        wf[j] = *(const bf16x8*)(sW + row * BK + ((ch ^ dfz_swz(row)) << 3));
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
-    }
-  }
-
-  // epilogue: acc[j][i][r] = out[pixel m0 + 64 wm + 32 i + l31][channel n0 + wn WTN + 32 j + (r & 3) + 8 (r >> 2) + 4 half]
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const long m = m0 + wm * 64 + i * 32 + l31;
-    if (m >= P) continue;
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int n = n0 + wn * WTN + j * 32 + 8 * gq + 4 * half;
-        if (n >= f.Cout) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[j][i][4 * gq + e] + (f.bias ? f.bias[n + e] : 0.f);
-          if (f.relu) v[e] = fmaxf(v[e], 0.f);
-        }
-        *(uint2*)(f.out + m * f.ldc + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-      }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 struct PsroiArgs {
@@ -489,49 +323,6 @@ extern "C" int relnet_deformable_im2col(const void* data, const long* data_strid
   else if (data_dtype == RELNET_BF16 && col_dtype == RELNET_F32) deformable_im2col_kernel<unsigned short, float><<<grid, 256, 0, s>>>(g);
   else RELNET_REQUIRE(false, "relnet_deformable_im2col: unknown dtype %d/%d", data_dtype, col_dtype);
   return check_launch("relnet_deformable_im2col");
-}
-
-// DeformableConvolution forward in one kernel: data logical [B,C,H,W] with channels-last memory (data_strides4[1] == 1,
-// bf16), offset fp32 [B, 2*KH*KW*DG, Ho, Wo] (any strides), w [Cout][KH*KW*C] bf16 (pack_conv_weight order), bias fp32 [Cout]
-// or NULL, out [B*Ho*Wo][ldc] bf16.  Needs C % 64 == 0, (C / DG) % 8 == 0, Cout % 4 == 0, 16-byte aligned rows.
-extern "C" int relnet_deformable_conv_fused(const void* data, const long* data_strides4, const float* offset,
-                                            const long* offset_strides4, const void* w, long ldw, const float* bias,
-                                            int relu, void* out, long ldc, int B, int C, int H, int W, int Cout, int KH,
-                                            int KW, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w,
-                                            int num_deformable_group, void* stream) {
-  RELNET_REQUIRE(data && offset && w && out && data_strides4 && offset_strides4, "relnet_deformable_conv_fused: null operand");
-  RELNET_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride_h > 0 && stride_w > 0 && dil_h > 0 && dil_w > 0,
-                 "relnet_deformable_conv_fused: bad shape");
-  RELNET_REQUIRE(num_deformable_group > 0 && C % num_deformable_group == 0 && (C / num_deformable_group) % 8 == 0,
-                 "relnet_deformable_conv_fused: channels per deformable group must be a multiple of 8");
-  RELNET_REQUIRE(data_strides4[1] == 1 && C % 64 == 0 && Cout % 4 == 0 && ldw % 8 == 0 && ldc % 4 == 0 &&
-                 data_strides4[0] % 8 == 0 && data_strides4[2] % 8 == 0 && data_strides4[3] % 8 == 0 &&
-                 (((uintptr_t)data | (uintptr_t)w) & 15) == 0 && ((uintptr_t)out & 7) == 0,
-                 "relnet_deformable_conv_fused: needs channels-last bf16 data, C %% 64 == 0 and 16-byte aligned rows");
-  DeformFusedArgs f;
-  DeformColArgs& g = f.c;
-  g.data = data; g.ds_b = data_strides4[0]; g.ds_c = data_strides4[1]; g.ds_h = data_strides4[2]; g.ds_w = data_strides4[3];
-  g.offset = offset; g.fs_b = offset_strides4[0]; g.fs_c = offset_strides4[1]; g.fs_h = offset_strides4[2]; g.fs_w = offset_strides4[3];
-  g.col = nullptr; g.col_ld = 0;
-  g.B = B; g.C = C; g.H = H; g.W = W; g.KH = KH; g.KW = KW; g.pad_h = pad_h; g.pad_w = pad_w;
-  g.stride_h = stride_h; g.stride_w = stride_w; g.dil_h = dil_h; g.dil_w = dil_w; g.DG = num_deformable_group;
-  g.Ho = (H + 2 * pad_h - (dil_h * (KH - 1) + 1)) / stride_h + 1;
-  g.Wo = (W + 2 * pad_w - (dil_w * (KW - 1) + 1)) / stride_w + 1;
-  f.w = (const unsigned short*)w; f.ldw = ldw; f.bias = bias; f.out = (unsigned short*)out; f.ldc = ldc; f.Cout = Cout; f.relu = relu;
-  const long P = (long)B * g.Ho * g.Wo;
-  static relnet::PerDeviceOnce attr_once;
-  if (attr_once.first()) {
-    hipFuncSetAttribute((const void*)deform_conv_fused_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)deform_conv_fused_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  }
-  if (Cout > 256) {
-    dim3 grid((unsigned)((P + 127) / 128), (unsigned)((Cout + 511) / 512));
-    deform_conv_fused_kernel<512><<<grid, 512, (128 + 2 * 512) * 64 * 2, (hipStream_t)stream>>>(f);
-  } else {
-    dim3 grid((unsigned)((P + 127) / 128), (unsigned)((Cout + 255) / 256));
-    deform_conv_fused_kernel<256><<<grid, 512, (128 + 2 * 256) * 64 * 2, (hipStream_t)stream>>>(f);
-  }
-  return check_launch("relnet_deformable_conv_fused");
 }
 
 extern "C" int relnet_deformable_psroi_pool_fwd(const void* data, const long* data_strides4, const float* rois,

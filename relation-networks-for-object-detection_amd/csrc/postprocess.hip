@@ -83,23 +83,50 @@ struct ClsNmsArgs {
 // Image-level pruning of the per-class lists (tester.py:270-277 keeps, per image, the detections whose score is >= the top_k-th
 // largest over all classes).  A class's pick sequence is non-increasing (soft-NMS only lowers scores, every pick is the current
 // maximum), so once its LATEST pick lies below a lower bound of that final threshold, none of its later picks can be kept.
-// The bound: every pick of the image is counted in a shared histogram over the top 16 bits of its float64 score (sign, exponent,
-// 5 mantissa bits: 3 % resolution); t = the bin in which the count from the top reaches top_k.  Histograms of SUBSETS of the final
-// pick set can only give a lower t, so a stale or partial view (other classes still running, agent-scope relaxed reads) prunes
-// less, never wrongly: a class stops when bin(latest pick) < t.  The lists written are prefixes of the full lists and contain
-// every pick >= the final threshold, so relnet_image_topk returns the same detections; counts[] = picks actually produced.
-// With 80 similar classes (the benchmark's random-init heads: all 300 rois are candidates in every class) a class stops after
-// 2-3 picks instead of 100.
+// The bound: every pick of the image is counted in a shared two-level histogram of its float64 score: 384 coarse bins (sign,
+// exponent, 5 mantissa bits: 3 %) and, per coarse bin, 32 fine bins (the next 5 mantissa bits: 0.1 % -- with flat posteriors a class's
+// pick sequence falls slowly, the coarse bin alone let 10-30 picks per class through).  (t, t2) = the coarse / fine bin in which the
+// count from the top reaches top_k.  Histograms of SUBSETS of the final pick set can only give a lower (t, t2), so a stale or partial
+// view (other classes still running, agent-scope relaxed reads) prunes less, never wrongly: a class stops when the bin pair of its
+// latest pick is below (t, t2).  The lists written are prefixes of the full lists and contain every pick >= the final threshold, so
+// relnet_image_topk returns the same detections; counts[] = picks actually produced.  With 80 similar classes (the benchmark's
+// random-init heads: all 300 rois are candidates in every class) a class stops after a few picks instead of 100.
 constexpr int kHistBins = 384;                      // scores in [2^-11, 2): (exponent - 1012) * 32 + 5 mantissa bits
-__device__ __forceinline__ int score_bin(double sc) {
+constexpr int kHistFine = 32;                       // fine bins per coarse bin (mantissa bits 6..10)
+constexpr int kHistWords = kHistBins * (1 + kHistFine);     // per image: [kHistBins] coarse, then [kHistBins][kHistFine]
+__device__ __forceinline__ int score_bin(double sc, int& fine) {
   const long long bits = __double_as_longlong(sc);
   const long long bin = (bits >> 47) - (1012LL << 5);
-  return bits <= 0 ? 0 : (bin < 0 ? 0 : (bin >= kHistBins ? kHistBins - 1 : (int)bin));
+  fine = (int)((bits >> 42) & (kHistFine - 1));
+  if (bits <= 0 || bin < 0) { fine = 0; return 0; }
+  if (bin >= kHistBins) { fine = kHistFine - 1; return kHistBins - 1; }
+  return (int)bin;
 }
 
 // "absent / already picked / suppressed" marker of a candidate's score.  -inf, not -1: the lib/nms/nms.py twins accept any
 // float64 dets[:, 4] (raw logits, negative scores), which must stay distinguishable from removed slots.
 #define kGone (-INFINITY)
+
+// Wave-wide maximum of a double without LDS traffic: four DPP steps inside each row of 16 lanes (quad_perm xor 1 / xor 2,
+// row_half_mirror, row_mirror: the maximum is idempotent, mirrored partners are as good as a butterfly), then the four row values
+// through v_readlane.  (__shfl_xor of a double is two ds_bpermute round trips per step; the per-pick arg-max chain of the
+// class-NMS kernels is latency bound.)  The result is the same in every lane.
+template <int CTRL> __device__ __forceinline__ double dpp_move_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+  v = fmax(v, dpp_move_f64<0xB1>(v));        // quad_perm [1,0,3,2]
+  v = fmax(v, dpp_move_f64<0x4E>(v));        // quad_perm [2,3,0,1]
+  v = fmax(v, dpp_move_f64<0x141>(v));       // row_half_mirror
+  v = fmax(v, dpp_move_f64<0x140>(v));       // row_mirror
+  return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
 
 // kPerLane * 64 >= N candidates per (image, class)
 template <int kPerLane, bool PRUNE = false>
@@ -131,24 +158,25 @@ __global__ __launch_bounds__(64) void class_nms_kernel(ClsNmsArgs g) {
   int picked = 0;
   const int n_it = n < g.max_picks ? n : g.max_picks;
   for (int it = 0; it < n_it; ++it) {
-    // arg-max over remaining; ties -> larger roi index (argsort()[::-1] convention)
-    double best = kGone; int bi = -1;
+    // arg-max over remaining; ties -> larger roi index (argsort()[::-1] convention): wave maximum, then the highest (slot, lane)
+    // holding it -- ballots, all on the scalar unit
+    double lbest = kGone;
 #pragma unroll
-    for (int s = 0; s < kPerLane; ++s)
-      if (sc[s] > best || (sc[s] == best && sc[s] > kGone)) { best = sc[s]; bi = s * 64 + lane; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const double ob = __shfl_xor(best, o);
-      const int oi = __shfl_xor(bi, o);
-      if (ob > best || (ob == best && oi > bi)) { best = ob; bi = oi; }
-    }
+    for (int s = 0; s < kPerLane; ++s) lbest = fmax(lbest, sc[s]);
+    const double best = wave_max_f64(lbest);
     if (!(best > kGone)) break;                     // everything suppressed (hard NMS)
+    int bi = -1;
+#pragma unroll
+    for (int s = kPerLane - 1; s >= 0; --s) {
+      const unsigned long long m = __ballot(sc[s] == best);
+      if (bi < 0 && m) bi = s * 64 + 63 - __clzll(m);
+    }
     const int bl = bi & 63, bs = bi >> 6;
     double px1 = 0, py1 = 0, px2 = 0, py2 = 0, pa = 0;
 #pragma unroll
     for (int s = 0; s < kPerLane; ++s)
       if (s == bs) { px1 = x1[s]; py1 = y1[s]; px2 = x2[s]; py2 = y2[s]; pa = area[s]; }
-    px1 = __shfl(px1, bl); py1 = __shfl(py1, bl); px2 = __shfl(px2, bl); py2 = __shfl(py2, bl); pa = __shfl(pa, bl);
+    px1 = readlane_f64(px1, bl); py1 = readlane_f64(py1, bl); px2 = readlane_f64(px2, bl); py2 = readlane_f64(py2, bl); pa = readlane_f64(pa, bl);
     if (lane == 0) {
       double* o = out + (long)picked * 5;
       o[0] = px1; o[1] = py1; o[2] = px2; o[3] = py2; o[4] = best;
@@ -157,24 +185,43 @@ __global__ __launch_bounds__(64) void class_nms_kernel(ClsNmsArgs g) {
     ++picked;
     if constexpr (PRUNE) {
       // count this pick, then look at the image's histogram: bins [6 lane, 6 lane + 6), count from the top bin down
-      unsigned int* hist = g.hist + (long)b * kHistBins;
-      const int mybin = score_bin(best);
-      if (lane == 0) __hip_atomic_fetch_add(hist + mybin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned int c[6], tot = 0;
+      unsigned int* hist = g.hist + (long)b * kHistWords;
+      unsigned int* hist2 = hist + kHistBins;
+      int myfine;
+      const int mybin = score_bin(best, myfine);
+      if (lane == 0) {
+        __hip_atomic_fetch_add(hist + mybin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(hist2 + mybin * kHistFine + myfine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // (the look-up is an L2 round trip on the serial path of the class: every pick for the first four, then every fourth)
+      if (picked <= 4 || !(picked & 3)) {
+        unsigned int c[6], tot = 0;
 #pragma unroll
-      for (int q = 0; q < 6; ++q) { c[q] = __hip_atomic_load(hist + lane * 6 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tot += c[q]; }
-      unsigned int suf = tot;                        // inclusive suffix sum over lanes: picks in bins >= 6 lane
+        for (int q = 0; q < 6; ++q) { c[q] = __hip_atomic_load(hist + lane * 6 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tot += c[q]; }
+        unsigned int suf = tot;                        // inclusive suffix sum over lanes: picks in bins >= 6 lane
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const unsigned int v = __shfl_down(suf, o); if (lane + o < 64) suf += v; }
-      const unsigned long long m = __ballot(suf >= (unsigned)g.top_k);
-      if (m) {
-        const int L = 63 - __clzll(m);               // highest lane whose suffix reaches top_k: the bound's bin is one of its six
-        unsigned int acc = suf - tot;                // picks in the lanes above
-        int t = lane * 6;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned int v = __shfl_down(suf, o); if (lane + o < 64) suf += v; }
+        const unsigned long long m = __ballot(suf >= (unsigned)g.top_k);
+        if (m) {
+          const int L = 63 - __clzll(m);               // highest lane whose suffix reaches top_k: the bound's coarse bin is one of its six
+          unsigned int acc = suf - tot;                // picks in the lanes above
+          int t = lane * 6;
+          unsigned int above = acc;                    // picks in coarse bins above t
 #pragma unroll
-        for (int q = 5; q >= 0; --q) { acc += c[q]; if (acc >= (unsigned)g.top_k) { t = lane * 6 + q; break; } }
-        t = __shfl(t, L);
-        if (mybin < t) break;                        // every later pick of this class is <= this one: below the image cut for good
+          for (int q = 5; q >= 0; --q) { if (acc + c[q] >= (unsigned)g.top_k) { t = lane * 6 + q; above = acc; break; } acc += c[q]; }
+          t = __shfl(t, L); above = __shfl(above, L);
+          if (mybin < t) break;                        // every later pick of this class is <= this one: below the image cut for good
+          if (mybin == t) {
+            // fine bins of coarse bin t: lane f < 32 holds fine bin f; count from the top fine bin down, on top of `above`
+            unsigned int f = lane < kHistFine ? __hip_atomic_load(hist2 + t * kHistFine + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            unsigned int fs = f;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) { const unsigned int v = __shfl_down(fs, o); if (lane + o < 32) fs += v; }
+            const unsigned long long m2 = __ballot(lane < kHistFine && above + fs >= (unsigned)g.top_k);
+            // (the fine counts may lag the coarse count they refine: no lane qualifying means "no fine bound yet")
+            if (m2 && myfine < 63 - __clzll(m2)) break;
+          }
+        }
       }
     }
 #pragma unroll
@@ -303,22 +350,37 @@ __device__ __forceinline__ unsigned long long dkey(double d) {
   return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
+constexpr int kTopkKeys = 6144;          // pick keys cached in LDS (48 KB); longer lists are re-read from global memory every pass
+
 __global__ __launch_bounds__(1024) void image_topk_kernel(ImgTopkArgs g) {
   __shared__ unsigned int hist[256];
   __shared__ unsigned long long s_prefix;
   __shared__ int s_remaining, s_total, s_out;
-  __shared__ int s_off[128];
+  __shared__ int s_off[129];                  // exclusive prefix of the class counts (the picks of an image as ONE list of `total` entries)
+  __shared__ unsigned long long s_keys[kTopkKeys];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int* cnt = g.counts + (long)b * g.NC;
   const double* dets = g.dets + (long)b * g.NC * g.N * 5;
   if (tid == 0) {
     int t = 0;
-    for (int c = 0; c < g.NC; ++c) t += cnt[c];
+    for (int c = 0; c < g.NC; ++c) { s_off[c] = t; t += cnt[c]; }
+    s_off[g.NC] = t;
     s_total = t; s_out = 0;
   }
   __syncthreads();
   const int total = s_total;
-  const long slots = (long)g.NC * g.N;
+  const bool cached = total <= kTopkKeys;
+  // entry i of the list -> its key (the lists are short once relnet_class_nms_topk has pruned them: the selection below walks
+  // `total` entries per pass, not NC x N slots)
+  auto key_of = [&](int i) {
+    int lo = 0, hi = g.NC;                    // last class whose offset is <= i
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid; }
+    return dkey(dets[((long)lo * g.N + (i - s_off[lo])) * 5 + 4]);
+  };
+  if (cached) {
+    for (int i = tid; i < total; i += 1024) s_keys[i] = key_of(i);
+    __syncthreads();
+  }
   unsigned long long kth = 0ull;
   if (total > g.max_per_image) {
     if (tid == 0) { s_prefix = 0ull; s_remaining = g.max_per_image; }
@@ -328,10 +390,8 @@ __global__ __launch_bounds__(1024) void image_topk_kernel(ImgTopkArgs g) {
       __syncthreads();
       const unsigned long long prefix = s_prefix;
       const int shift = pass * 8;
-      for (long i = tid; i < slots; i += 1024) {
-        const int c = (int)(i / g.N), k = (int)(i % g.N);
-        if (k >= cnt[c]) continue;
-        const unsigned long long key = dkey(dets[i * 5 + 4]);
+      for (int i = tid; i < total; i += 1024) {
+        const unsigned long long key = cached ? s_keys[i] : key_of(i);
         if (pass == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 0xff], 1u);
       }
       __syncthreads();
@@ -429,9 +489,9 @@ extern "C" int relnet_class_nms(const float* cls_prob, const double* boxes, doub
 }
 
 // relnet_class_nms with image-level pruning (see kHistBins above): dets / counts as relnet_class_nms, but a class list stops as
-// soon as its next pick cannot be among the top_k scores of its image.  `hist`: B x relnet_class_nms_hist_bins() unsigned ints,
+// soon as its next pick cannot be among the top_k scores of its image.  `hist`: B x relnet_class_nms_hist_bins() unsigned ints (coarse + fine),
 // ZEROED by the caller before every call.  N <= 512.
-extern "C" int relnet_class_nms_hist_bins(void) { return kHistBins; }
+extern "C" int relnet_class_nms_hist_bins(void) { return kHistWords; }
 extern "C" int relnet_class_nms_topk(const float* cls_prob, const double* boxes, double* dets, int* counts, void* hist, int B, int N,
                                      int C, float score_thresh, double nms_param, int soft, int max_picks, int top_k, void* stream) {
   RELNET_REQUIRE(cls_prob && boxes && dets && counts && hist, "relnet_class_nms_topk: null operand");

@@ -61,7 +61,6 @@ _SIGNATURES = {
     'relnet_pack_w_frag': (C.c_int, [_vp, _l, _vp, _i, _i, _vp]),
     'relnet_conv2d_nhwc_wf': (C.c_int, [_vp, _l, _l, _vp, _vp, _vp, _vp, _i, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_deformable_im2col': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l] + [_i] * 15 + [_vp]),
-    'relnet_deformable_conv_fused': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _vp, _l] + [_i] * 14 + [_vp]),
     'relnet_deformable_psroi_pool_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_f, _f, _i, _i, _i, _vp]),
     'relnet_roi_pool_fpn_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_fpn_roi_dispatch': (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

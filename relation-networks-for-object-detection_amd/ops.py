@@ -664,28 +664,11 @@ def deformable_im2col(data, offset, kernel=(3, 3), stride=(1, 1), dilate=(1, 1),
 
 
 def deformable_conv(data, offset, w_packed, bias=None, kernel=(3, 3), stride=(1, 1), dilate=(1, 1), pad=(0, 0),
-                    num_deformable_group=1, relu=False, out_dtype=None, fused=True):
+                    num_deformable_group=1, relu=False, out_dtype=None):
     """DeformableConvolutionOp::Forward (deformable_convolution-inl.h:91-143) with the bias (or folded BatchNorm) and ReLU
-    fused.  bf16 channels-last data with C % 64 == 0 (the res5 layers): ONE kernel, the sampling feeds the MFMA tiles
-    directly (relnet_deformable_conv_fused, no column matrix); otherwise sampling kernel + GEMM.
+    fused into the GEMM epilogue: sampling kernel (relnet_deformable_im2col, column matrix in (tap, channel) order) + NT GEMM
+    (the res5 shape, K = 4608, runs on the hand-scheduled ring kernel).
     w_packed [Cout, kh*kw*Cin] (pack_conv_weight order).  Returns logical [B, Cout, Ho, Wo] in channels-last memory."""
-    B, Cc, H, W = data.shape
-    if (fused and not os.environ.get('RELNET_DCN_UNFUSED') and data.dtype == torch.bfloat16 and w_packed.dtype == torch.bfloat16 and data.stride(1) == 1 and Cc % 64 == 0
-            and (Cc // num_deformable_group) % 8 == 0 and w_packed.shape[0] % 4 == 0 and out_dtype in (None, torch.bfloat16)
-            and all(st % 8 == 0 for st in (data.stride(0), data.stride(2), data.stride(3)))):
-        _chk(data, offset, w_packed, bias)
-        assert offset.dtype == torch.float32 and w_packed.is_contiguous()
-        kh, kw = _pair(kernel); sh, sw = _pair(stride); dh, dw = _pair(dilate); ph, pw = _pair(pad)
-        Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
-        Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
-        if tuple(offset.shape) != (B, 2 * kh * kw * num_deformable_group, Ho, Wo):
-            raise ValueError("offset shape %s, expected %s" % (tuple(offset.shape), (B, 2 * kh * kw * num_deformable_group, Ho, Wo)))
-        Cout = w_packed.shape[0]
-        y = torch.empty((B, Ho, Wo, Cout), device=data.device, dtype=torch.bfloat16)
-        _lib.call('relnet_deformable_conv_fused', data.data_ptr(), _strides4(data), offset.data_ptr(), _strides4(offset),
-                  w_packed.data_ptr(), w_packed.stride(0), _ptr(bias), int(relu), y.data_ptr(), Cout, B, Cc, H, W, Cout, kh, kw,
-                  ph, pw, sh, sw, dh, dw, num_deformable_group, _stream(), tag='B%d_C%d_%dx%d' % (B, Cc, Ho, Wo))
-        return y.permute(0, 3, 1, 2)
     col, (Ho, Wo) = deformable_im2col(data, offset, kernel, stride, dilate, pad, num_deformable_group,
                                       col_dtype=w_packed.dtype)
     y = gemm_nt(col, w_packed, bias, relu=relu, out_dtype=out_dtype)

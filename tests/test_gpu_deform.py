@@ -132,12 +132,11 @@ def test_zero_offsets_equal_own_convolution_full_size():
 
 
 @pytest.mark.parametrize("B,C,H,W,Co,dg,stride,sigma", [(2, 512, 38, 63, 512, 4, 1, 2.0), (1, 64, 19, 23, 36, 1, 1, 6.0),
-                                                       (3, 128, 21, 30, 256, 4, 2, 3.0), (1, 512, 7, 9, 512, 4, 1, 1.0)])
-def test_fused_deformable_conv_matches_sampling_plus_gemm(B, C, H, W, Co, dg, stride, sigma):
-    """relnet_deformable_conv_fused (sampling inside the GEMM's A producer) against the two-kernel path (the column matrix
-    pinned bit-exact to the oracle above, then the NT GEMM): same sampled bf16 values, same (tap, channel) K order, fp32
-    accumulation -- only the tile shape differs, so the outputs agree to 1 bf16 ulp of the output scale.  Ragged pixel
-    counts (not a multiple of the 128-pixel tile), a Cout that is not a tile multiple, stride 2, offsets that leave the map."""
+                                                       (3, 128, 21, 30, 256, 4, 2, 3.0)])
+def test_deformable_conv_bf16_channels_last_offsets_layouts(B, C, H, W, Co, dg, stride, sigma):
+    """The throughput form (bf16 channels-last sampling kernel + NT GEMM, the res5 shape on the hand-scheduled ring kernel) against
+    float32 torch on the column matrix pinned bit-exact above; offsets given in NCHW and in channels-last memory (the layout the
+    offset convolution's GEMM produces) must give the identical tensor."""
     ops, _ = _mods()
     torch.manual_seed(11)
     x = torch.randn(B, H, W, C, device='cuda').to(torch.bfloat16).permute(0, 3, 1, 2)
@@ -146,16 +145,15 @@ def test_fused_deformable_conv_matches_sampling_plus_gemm(B, C, H, W, Co, dg, st
     bias = torch.randn(Co, device='cuda') * 0.1
     Ho = (H + 4 - 5) // stride + 1; Wo = (W + 4 - 5) // stride + 1
     off = torch.randn(B, 18 * dg, Ho, Wo, device='cuda') * sigma
+    col, _ = ops.deformable_im2col(x, off, 3, stride, 2, 2, dg, col_dtype=torch.bfloat16)
     for relu in (True, False):
-        two = ops.deformable_conv(x, off, wp, bias, 3, stride, 2, 2, dg, relu=relu, fused=False)
-        one = ops.deformable_conv(x, off, wp, bias, 3, stride, 2, 2, dg, relu=relu, fused=True)
-        assert one.shape == two.shape == (B, Co, Ho, Wo)
-        d = (one.float() - two.float()).abs().max().item()
-        assert d <= 2 ** -7 * two.float().abs().max().item(), d
-    # offsets in channels-last memory (the layout the offset conv's GEMM produces)
+        got = ops.deformable_conv(x, off, wp, bias, 3, stride, 2, 2, dg, relu=relu)
+        want = col.float() @ wp.float().t() + bias
+        want = (want.relu() if relu else want).view(B, Ho, Wo, Co).permute(0, 3, 1, 2)
+        assert got.shape == (B, Co, Ho, Wo)
+        assert (got.float() - want).abs().max().item() <= 2 ** -7 * want.abs().max().item()
     off_cl = off.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
-    one_cl = ops.deformable_conv(x, off_cl, wp, bias, 3, stride, 2, 2, dg, relu=False)
-    assert torch.equal(one_cl, one)
+    assert torch.equal(ops.deformable_conv(x, off_cl, wp, bias, 3, stride, 2, 2, dg), ops.deformable_conv(x, off, wp, bias, 3, stride, 2, 2, dg))
 
 
 PSROI_CASES = [
