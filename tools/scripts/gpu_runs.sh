@@ -1,0 +1,60 @@
+#!/bin/bash
+# The gpurun command lines behind the numbers in DESIGN.md / profiles/ (one parametrised script instead of one scratch file per run):
+#     gpurun --timeout 2400 -- 'bash tools/scripts/gpu_runs.sh <what> [args]'        outputs under gpurun_out/r04_<what>/  (or TAG=...)
+#   suite      whole GPU test suite
+#   bench      the driver's default line (python bench.py), full JSON
+#   ab KNOB    same-box A/B of the default step with a kernel-selection knob off / on, twice
+#              (KNOB = RELNET_GEMM_ASM | RELNET_INPLACE_EXPAND | RELNET_STAGE_SPLIT=4:2 | RELNET_GEMM_KORDER)
+#   tiles T,.. parity tests of the forced tiles, then their per-layer times at 54 images (tools/bench_tiles.py), e.g. `tiles 8,18,19`
+#   numbers    every other graph's rate (plain 2FC, learn-NMS, DCN, FPN, training variants): one JSON line each
+#   prof       rocprofv3 --kernel-trace --stats of the default bench (54 images), the 1-image step and the training step
+#   pmc_attn   FETCH_SIZE / WRITE_SIZE / SQ counter passes on the relation-attention kernel (tools/attn_only.py) -> attention_pmc_raw.json
+#   golden     tests/golden/gen_golden_gpu.py (reference CUDA kernels compiled for gfx950) -> ref_cuda.npz
+#   probes     tools/llc_probe.py + tools/fill_probe.py
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+WHAT=$1; shift
+TAG=${TAG:-r04_$WHAT}
+O=$R/gpurun_out/$TAG; mkdir -p $O
+F="--no-cpu-baseline --no-train-line --no-other-configs --no-parity --no-batch-sweep"
+line() { python -c "import json,sys; d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{\"metric')][-1]); print(sys.argv[2], round(d['value'],1), 'img/s', round(d['ms_per_step'],3), 'ms', d['config'].get('images_per_gpu_per_step'))" "$1" "$2" 2>/dev/null || echo "$2 FAILED"; }
+case $WHAT in
+  suite) ( time timeout 1800 python -m pytest tests -x -q -m gpu ) > $O/pytest_gpu.log 2>&1; tail -6 $O/pytest_gpu.log ;;
+  bench) ( time python bench.py ) > $O/bench.json 2> $O/bench.err; tail -4 $O/bench.err; line $O/bench.json default ;;
+  ab)
+    KNOB=$1; NAME=${KNOB%%=*}; ON=${KNOB#*=}; [ "$ON" = "$KNOB" ] && ON=1
+    export RELNET_DEBUG_KNOBS=1
+    for i in 1 2; do
+      env $NAME=0 python bench.py $F > $O/off_$i.json 2>/dev/null; line $O/off_$i.json "$NAME=0"
+      env $NAME=$ON python bench.py $F > $O/on_$i.json 2>/dev/null; line $O/on_$i.json "$NAME=$ON"
+    done ;;
+  tiles)
+    RELNET_TEST_TILES=$1 timeout 900 python -m pytest tests/test_gpu_gemm_tiles.py -x -q > $O/tiles.log 2>&1; tail -3 $O/tiles.log
+    TILES=$1,$1 timeout 600 python tools/bench_tiles.py 54 > $O/bench_tiles_b54.txt 2>&1; cat $O/bench_tiles_b54.txt ;;
+  numbers)
+    G="--no-cpu-baseline --no-parity --no-batch-sweep --no-train-line --no-other-configs --no-kernel-timing"
+    run() { n=$1; shift; timeout 400 python bench.py "$@" > $O/$n.json 2> $O/$n.err; line $O/$n.json $n; }
+    run plain2fc $G --no-relation; run lnms27 $G --learn-nms --batch 27; run dcn27 $G --dcn --batch 27
+    run dcn_lnms27 $G --dcn --learn-nms --batch 27; run fpn8 $G --fpn --batch 8; run fpn_lnms8 $G --fpn --learn-nms --batch 8
+    run train8 --train --steps 10 --warmup 3; run train_lnms8 --train --learn-nms --steps 10 --warmup 3
+    run train_lnms16 --train --learn-nms --batch 16 --steps 6 --warmup 2; run train_lnms32 --train --learn-nms --batch 32 --steps 5 --warmup 2
+    run train_dcn_lnms8 --train --dcn --learn-nms --steps 6 --warmup 2; run train_fpn_lnms2 --train --fpn --learn-nms --batch 2 --steps 6 --warmup 2 ;;
+  prof)
+    cd /tmp && export TMPDIR=/tmp
+    P="--no-cpu-baseline --no-kernel-timing --no-parity --no-batch-sweep --no-train-line --no-other-configs"
+    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p54 -- python $R/bench.py $P > /tmp/p54.log 2>&1
+    cp $(find /tmp/p54 -name "*kernel_stats.csv" | head -1) $O/bench_b54_kernel_stats.csv
+    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python $R/bench.py $P --batch 1 --steps 50 > /tmp/p1.log 2>&1
+    cp $(find /tmp/p1 -name "*kernel_stats.csv" | head -1) $O/bench_b1_kernel_stats.csv
+    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -- python $R/bench.py --train --learn-nms --batch 8 --steps 10 --warmup 3 > /tmp/pt.log 2>&1
+    cp $(find /tmp/pt -name "*kernel_stats.csv" | head -1) $O/train_lnms_b8_kernel_stats.csv; ls -la $O ;;
+  pmc_attn)
+    cd /tmp && export TMPDIR=/tmp
+    for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY"; do
+      tag=$(echo $C | cut -d' ' -f1)
+      rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pa_$tag -- python $R/tools/attn_only.py 54 6 > /tmp/pa.log 2>&1; tail -1 /tmp/pa.log
+    done
+    python $R/tools/pmc_collect.py $O/attention_pmc_raw.json /tmp/pa_FETCH_SIZE /tmp/pa_WRITE_SIZE /tmp/pa_SQ_VALU_MFMA_BUSY_CYCLES ;;
+  golden) python tests/golden/gen_golden_gpu.py $O/ref_cuda.npz ;;
+  probes) python tools/llc_probe.py > $O/llc.json; python tools/fill_probe.py > $O/fill_probe.txt; cat $O/fill_probe.txt ;;
+  *) echo "unknown run '$WHAT'"; exit 2 ;;
+esac
