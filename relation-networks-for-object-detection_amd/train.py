@@ -172,6 +172,16 @@ class Trainer(object):
         self.anchors_host = generate_anchors(c.feat_stride, c.anchor_ratios, c.anchor_scales)      # float64 [A,4], host (kernel argument)
         self.anchors = torch.as_tensor(self.anchors_host, dtype=torch.float64, device=dev)
         self.step_count = 0
+        # state that used to be created on first use -- inside a hipGraph capture that turned into a captured fill / mid-capture
+        # stream and attribute calls: the device step counter of the anchor sampler, the RPN side stream, the queue of
+        # weight-gradient products
+        self._anchor_step = torch.zeros(1, device=dev, dtype=torch.int64)
+        self._side = torch.cuda.Stream(device=dev) if torch.cuda.is_available() and torch.device(dev).type == 'cuda' else None
+        self._wq = ops.WgradQueue()
+        # every data-parallel rank samples its own fg / bg anchor subsets (cfg.rank_in_anchor_seed = False: the same subsets on every
+        # rank, what the two-rank gradient-sum check needs)
+        self._rank, self._world = (0, 1) if not getattr(c, 'rank_in_anchor_seed', True) else ((torch.distributed.get_rank(), torch.distributed.get_world_size())
+                                   if torch.distributed.is_available() and torch.distributed.is_initialized() else (0, 1))
         # data-gradient copies of the weights (W^T, tap-flipped 3x3 filters): ONE grouped launch per step instead of a
         # transpose / flip / copy per layer inside the backward pass
         self._relayout = ops.WeightRelayout(dev)
@@ -216,14 +226,11 @@ class Trainer(object):
         """(2-D fp32 view of `name`'s slice of the flat gradient buffer, folded-BatchNorm row factor | None): the target
         relnet_wgrad accumulates into (train_ops `wgrad_to` protocol)."""
         g = self.W.view(self.W.grad, name)
-        if getattr(self, '_wq', None) is None:
-            self._wq = ops.WgradQueue()       # the products wait here for ONE grouped stream-K launch per gradient bucket
-        return g.view(g.shape[0], -1), scale_rows, self._wq
+        return g.view(g.shape[0], -1), scale_rows, self._wq       # the products wait there for ONE grouped stream-K launch per gradient bucket
 
     def _flush_wgrads(self):
         """Launch the queued weight-gradient products (csrc/wgrad.hip, one grouped launch)."""
-        if getattr(self, '_wq', None) is not None:
-            self._wq.flush()
+        self._wq.flush()
 
     def _add_bgrad(self, name, db):
         self.Bv.view(self.Bv.grad, name).add_(db.reshape(-1))
@@ -278,11 +285,9 @@ class Trainer(object):
         batch: one C-ABI call, no host round trip.  The random fg / bg subset is keyed by cfg.seed + a device step counter that
         is advanced here, i.e. also by every replay of a captured step."""
         c = self.cfg
-        if getattr(self, '_anchor_step', None) is None:
-            self._anchor_step = torch.zeros(1, device=gt_boxes.device, dtype=torch.int64)
         out = ops.assign_anchor(gt_boxes, num_gt, im_info, self.anchors_host, feat_hw, c.feat_stride, c.rpn_batch_size,
                                 getattr(c, 'rpn_fg_fraction', 0.5), getattr(c, 'rpn_negative_overlap', 0.3),
-                                getattr(c, 'rpn_positive_overlap', 0.7), seed=getattr(c, 'seed', 0), seed_dev=self._anchor_step)
+                                getattr(c, 'rpn_positive_overlap', 0.7), seed=getattr(c, 'seed', 0) * self._world + self._rank, seed_dev=self._anchor_step)
         self._anchor_step += 1
         return out
 
@@ -334,8 +339,6 @@ class Trainer(object):
 
         side = None
         if getattr(self, 'overlap_rpn', os.environ.get('RELNET_TRAIN_OVERLAP', '1') != '0'):
-            if getattr(self, '_side', None) is None:
-                self._side = torch.cuda.Stream(device=data.device)
             side = self._side
 
             def fork(conv4):
@@ -349,6 +352,12 @@ class Trainer(object):
         feat = self._conv(conv5, 'conv_new_1', relu=True, bias=self.b('conv_new_1'))
         if side is not None:
             main.wait_stream(side)
+            # the branch's tensors were allocated on the side stream and are consumed on the main one through the backward pass:
+            # tell the caching allocator, so that their blocks are not handed out again on the side stream while main still reads them
+            if not torch.cuda.is_current_stream_capturing():      # (a capture's private pool keeps its blocks for the graph's lifetime)
+                for v in br.values():
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(main)
         r, d_rpn, rois_t, label, bbox_target, bbox_weight, N, R = (br[k] for k in ('r', 'd_rpn', 'rois_t', 'label', 'bbox_target',
                                                                                       'bbox_weight', 'N', 'R'))
         r5 = rois_t.view(B * R, 5)
@@ -761,6 +770,10 @@ class CapturedStep(object):
 
     def __init__(self, trainer, batch, kwargs=None):
         self.tr = trainer
+        if trainer.step_count == 0:              # kernel attributes (hipFuncSetAttribute), allocator pools and caches must exist before a capture
+            with torch.no_grad():
+                trainer.forward_backward(*batch, **(kwargs or {}))
+            torch.cuda.synchronize()
         self.segments = []                       # [(hipGraph, bucket index or None)]
         pool = torch.cuda.graph_pool_handle()    # one private pool: tensors made in one segment stay valid in the next ones
         side = torch.cuda.Stream()
@@ -780,14 +793,20 @@ class CapturedStep(object):
         with torch.cuda.stream(side), torch.no_grad():
             begin()
             trainer._capture_cut = cut
+            import warnings
             try:
                 self.out = trainer.forward_backward(*batch, **(kwargs or {}))
-            finally:
+            except BaseException:
                 trainer._capture_cut = None
-                import warnings
-                with warnings.catch_warnings(record=True) as caught:      # the tail after the last bucket is usually empty
-                    warnings.simplefilter('always')
+                try:                              # leave capture mode, but let the ORIGINAL error propagate
                     cur[0].capture_end()
+                except Exception:
+                    pass
+                raise
+            trainer._capture_cut = None
+            with warnings.catch_warnings(record=True) as caught:      # the tail after the last bucket is usually empty
+                warnings.simplefilter('always')
+                cur[0].capture_end()
             if not any('Graph is empty' in str(w.message) for w in caught):
                 self.segments.append((cur[0], None))
         torch.cuda.current_stream().wait_stream(side)

@@ -16,6 +16,7 @@ rank, world, _ = D.init(backend='gloo')
 B, H, W, G = 2, 384, 512, 4
 params = backbone.init_params(seed=1)
 cfg = train.TrainConfig(); cfg.learn_nms = True
+cfg.rank_in_anchor_seed = False        # identical batches AND identical anchor subsets on both ranks: the sum must be 2 x local
 tr = train.Trainer(params, cfg, im_hw=(H, W))
 g = torch.Generator().manual_seed(7)
 data = torch.randn(B, 3, H, W, generator=g).cuda()
