@@ -773,6 +773,7 @@ class CapturedStep(object):
         if trainer.step_count == 0:              # kernel attributes (hipFuncSetAttribute), allocator pools and caches must exist before a capture
             with torch.no_grad():
                 trainer.forward_backward(*batch, **(kwargs or {}))
+                trainer.all_reduce()             # completes the bucket exchanges that pass announced (every rank does the same)
             torch.cuda.synchronize()
         self.segments = []                       # [(hipGraph, bucket index or None)]
         pool = torch.cuda.graph_pool_handle()    # one private pool: tensors made in one segment stay valid in the next ones
