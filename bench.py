@@ -395,7 +395,7 @@ def main():
     if a.no_chain:
         from relnet_amd import ops as _ops
         bb = det.backbone
-        bb.chain, bb.halo3 = {}, {}
+        bb.chain, bb.halo3, bb.chain_proj = {}, {}, {}
         for name, (w, _, k) in bb.wp.items():          # res4 expand layers back on the row-panel kernel (the pre-fusion state)
             if name.endswith('_branch2c') and k == 1 and w.shape[1] == 256 and w.shape[0] % 256 == 0:
                 bb.wf[name] = _ops.pack_w_frag(w)

@@ -168,6 +168,12 @@ int relnet_relation_attention_fused(const void* q, long q_ld, long q_bs, const v
  * NULL: only x_next (last unit of a stage).                                                                          */
 int relnet_bottleneck_chain(const void* mid2, const void* x, const void* w3f, const void* w1f, const float* b3,
                             const float* b1, void* x_next, void* mid1_next, long P, int mid, void* stream);
+/* First unit of res2 (1x1 projection shortcut, stride 1; resnet_v1_101_rcnn_base.py: res2a_branch1 / bn2a_branch1 + res2a_branch2c
+ * + shortcut + ReLU [+ res2b_branch2a + ReLU]): x_next = relu(conv1x1(mid2; W3) + conv1x1(x_in; Wp) + b3p) with b3p = b3 + bp, the
+ * projection being four more k-steps of the expand product (its 256-channel output is never written); mid1_next as in
+ * relnet_bottleneck_chain (or NULL).  mid = 64; w3f / wpf = relnet_pack_w_frag images of W3 / Wp [256][64]; x_in [P][64] dense bf16. */
+int relnet_bottleneck_chain_proj(const void* mid2, const void* x_in, const void* w3f, const void* wpf, const void* w1f,
+                                 const float* b3p, const float* b1, void* x_next, void* mid1_next, long P, int mid, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution + bias (+ ReLU) of a dense 64-channel NHWC bf16 tensor with the input tile and its halo
  * resident in LDS (res2*_branch2b + BN + ReLU, resnet_v1_101_rcnn_base.py:52-56): the input is fetched 1.33 x instead of once

@@ -172,7 +172,7 @@ class Backbone(object):
             self.zero_bias64 = torch.zeros(64, device=self.device, dtype=torch.float32)
         # block boundaries inside a stage (identity shortcut, stride 1) of the HBM-bound stages: expand + shortcut + ReLU of
         # unit u and reduce + ReLU of unit u+1 as one pixel-wise kernel (ops.bottleneck_chain); unit -> its operands
-        self.chain, self.halo3 = {}, {}
+        self.chain, self.halo3, self.chain_proj = {}, {}, {}
         if self.impl == 'hip' and chain:
             for (st, nm, ic, mc, oc, stride, dil, proj), nxt in zip(self.units, self.units[1:] + [None]):
                 if nxt is not None and nxt[0] == st and not nxt[7] and mc in ops.CHAIN_MIDS:
@@ -182,6 +182,12 @@ class Backbone(object):
                 elif mc in ops.CHAIN_EXPAND_MIDS:   # last unit of a stage, and every res4 unit: the kernel without the second product
                     w3, b3, _ = self.wp['res%s_branch2c' % nm]
                     self.chain[nm] = (ops.pack_w_frag(w3), None, b3, None)
+            # first unit of res2: its stride-1 projection shortcut rides in the expand product (ops.bottleneck_chain_proj)
+            for (st, nm, ic, mc, oc, stride, dil, proj) in self.units:
+                if proj and stride == 1 and mc == 64 and ic == 64 and nm in self.chain:
+                    w3f, w1f, b3, b1n = self.chain[nm]
+                    wp_, bp_, _ = self.wp['res%s_branch1' % nm]
+                    self.chain_proj[nm] = (w3f, ops.pack_w_frag(wp_), w1f, (b3 + bp_).contiguous(), b1n)
             # 64-channel 3x3 convolutions (res2 branch2b): halo tile resident in LDS instead of one LDS fill per tap
             for st, nm, ic, mc, oc, stride, dil, proj in self.units:
                 if mc in ops.HALO3_CHANNELS and dil == 1 and not (self.dcn and st == 5):
@@ -305,7 +311,11 @@ class Backbone(object):
         shortcut of a first unit is written.  inplace: the expand kernel may write x_next over its shortcut operand.
         -> (x_next, reduce output of the NEXT unit | None)"""
         stage, nm, ic, mc, oc, stride, dil, proj = unit
-        if proj:
+        fuse_proj = (nm in self.chain_proj and sc_out is None and x.is_contiguous()
+                     and (force_chain or ops.chain_worthwhile(x.numel() // x.shape[-1], mc)))
+        if fuse_proj:
+            sc = None                # res2a: the projection is computed inside the expand kernel
+        elif proj:
             w, b, k = self.wp['res%s_branch1' % nm]
             sc = ops.conv2d_nhwc(x, w, b, ksize=k, stride=stride, out=sc_out)
         else:
@@ -319,6 +329,10 @@ class Backbone(object):
             y = ops.conv3x3_halo(y.contiguous(), *self.halo3['res%s_branch2b' % nm], relu=True)
         else:
             y = self._hconv(y, 'res%s_branch2b' % nm, pad=dil, dil=dil, relu=True)
+        if fuse_proj:
+            if nm not in self.last_chain_units:
+                self.last_chain_units.append(nm)
+            return ops.bottleneck_chain_proj(y, x, *self.chain_proj[nm])
         ch = self.chain.get(nm)
         if ch is not None and not force_chain and not ops.chain_worthwhile(y.numel() // y.shape[-1], y.shape[-1]):
             ch = None            # small maps (B = 1, late stages at small B): the tiled convolution kernels fill the GPU better

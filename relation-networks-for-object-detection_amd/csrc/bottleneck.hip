@@ -35,6 +35,8 @@ struct ChainArgs {
   const uint4* w1f;           // W1' [MID][4 MID], fragment order with the accumulator permutation (ops.pack_chain_w1)
   const float* b3;            // [4 MID]
   const float* b1;            // [MID]
+  const unsigned short* xin;  // PROJ: [P][MID] input of the unit (its projection shortcut is computed here, no x operand)
+  const uint4* wpf;           // PROJ: Wp [4 MID][MID] (branch1) in fragment order
   unsigned short* xn;         // [P][4 MID]
   unsigned short* m1;         // [P][MID]
   int P;
@@ -54,27 +56,36 @@ struct ChainArgs {
 // (measured and dropped, r04: the res4 expand form as TWO 4-wave workgroups per CU -- 16 KB filter slots, the two groups out of step so
 //  that one group's per-pass vmcnt(0) drain overlaps the other's arithmetic -- bit-identical and slower, 163 vs 150 us at 54 images:
 //  the filter stream through L2 -> LDS doubles)
-template <int MID, bool STREAM, bool REDUCE = true, int KSPLIT = 1>       // REDUCE = false: only x_next (no next reduce)
+// PROJ (MID = 64, resident weights; the first unit of res2, whose shortcut is a 1x1 projection of the unit's 64-channel input):
+//   x_next = relu(W3 . mid2 + Wp . x_in + (b3 + bp)) -- the projection is four more k-steps of the same accumulators instead of a
+//   separate convolution that writes a 4 MID-channel map (1.04 GB at 54 images) for this kernel to read back; no shortcut slice,
+//   one stage buffer per wave (written, then flushed in the same pass).  The shortcut is not rounded to bf16 on the way.
+template <int MID, bool STREAM, bool REDUCE = true, int KSPLIT = 1, bool PROJ = false>       // REDUCE = false: only x_next (no next reduce)
 __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
+  static_assert(!PROJ || (!STREAM && KSPLIT == 1), "the projection form exists for the resident-weight kernel");
   static_assert(KSPLIT == 1 || (STREAM && !REDUCE), "k-split passes exist for the streamed expand-only form");
   constexpr int COUT = 4 * MID, KS = MID / 16, KSS = KS / KSPLIT, RT = MID / 32, NP = COUT / 64;
   constexpr int W3P = 2 * KSS * 1024, W1P = REDUCE ? 4 * RT * 1024 : 0;     // bytes of one (sub-)step's W3 / W1' slice
-  constexpr int WBYTES = STREAM ? 2 * (W3P + W1P) : NP * (W3P + W1P);
+  constexpr int WPP = PROJ ? W3P : 0;                                         // ... and of its Wp slice
+  constexpr int PASSB = W3P + WPP + W1P;
+  constexpr int STG = PROJ ? 4096 : 8192;                                     // stage bytes per wave
+  constexpr int WBYTES = STREAM ? 2 * PASSB : NP * PASSB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  unsigned char* stage = smem + WBYTES + wave * 8192;          // 2 x [32 px][128 B], chunk c of row r at c ^ ((r >> 1) & 7)
-  float* sB3 = (float*)(smem + WBYTES + 65536);                // [COUT]
+  unsigned char* stage = smem + WBYTES + wave * STG;           // 2 (PROJ: 1) x [32 px][128 B], chunk c of row r at c ^ ((r >> 1) & 7)
+  float* sB3 = (float*)(smem + WBYTES + 8 * STG);              // [COUT]
   float* sB1 = sB3 + COUT;                                     // [MID]
   for (int i = tid; i < COUT; i += 512) sB3[i] = a.b3[i];
   if constexpr (REDUCE) for (int i = tid; i < MID; i += 512) sB1[i] = a.b1[i];
   if constexpr (!STREAM) {                                      // resident layout: pass-major, [pass][W3 slice | W1' slice]
-    for (int i = tid; i < NP * (W3P + W1P) / 16; i += 512) {
-      const int p = i / ((W3P + W1P) / 16), r = i % ((W3P + W1P) / 16);
+    for (int i = tid; i < NP * PASSB / 16; i += 512) {
+      const int p = i / (PASSB / 16), r = i % (PASSB / 16);
       uint4 v;
-      if (r < W3P / 16 || !REDUCE) v = a.w3f[(long)p * (W3P / 16) + r];
-      else { const int q = (r - W3P / 16) >> 6, rt = q >> 2, kk = q & 3; v = a.w1f[((long)rt * (COUT / 16) + p * 4 + kk) * 64 + (r & 63)]; }
+      if (r < W3P / 16) v = a.w3f[(long)p * (W3P / 16) + r];
+      else if (r < (W3P + WPP) / 16) v = a.wpf[(long)p * (W3P / 16) + (r - W3P / 16)];
+      else { const int q = (r - (W3P + WPP) / 16) >> 6, rt = q >> 2, kk = q & 3; v = a.w1f[((long)rt * (COUT / 16) + p * 4 + kk) * 64 + (r & 63)]; }
       ((uint4*)smem)[i] = v;
     }
   }
@@ -83,6 +94,7 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
   const int drow = lane >> 3, dslot = lane & 7;                // DMA / coalesced-store role: row 8 i + drow, chunk slot dslot
   // shortcut slice of (tile base pixel p0, pass p) into stage buffer p & 1
   auto issue_x = [&](int p0, int p) {
+    if constexpr (PROJ) return;
     unsigned char* sb = stage + (p & 1) * 4096;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -95,7 +107,7 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
   auto issue_w = [&](int st) {
     if constexpr (STREAM) {
       const int p = st / KSPLIT, kh = st % KSPLIT;
-      unsigned char* wb = smem + (st & 1) * (W3P + W1P);
+      unsigned char* wb = smem + (st & 1) * PASSB;
 #pragma unroll
       for (int i = 0; i < (2 * KSS + (REDUCE ? 4 * RT : 0)) / 8; ++i) {
         const int q = wave + 8 * i;
@@ -111,7 +123,7 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
   };
   // stores of a finished 32 px x 64 channel slice of x_next from stage buffer p & 1
   auto flush = [&](int p0, int p) {
-    const unsigned char* sb = stage + (p & 1) * 4096 + lane * 16;
+    const unsigned char* sb = stage + (PROJ ? 0 : (p & 1) * 4096) + lane * 16;
     const uint4 v0 = *(const uint4*)sb, v1 = *(const uint4*)(sb + 1024), v2 = *(const uint4*)(sb + 2048), v3 = *(const uint4*)(sb + 3072);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     auto put = [&](int i, const uint4& v) {
@@ -135,6 +147,11 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
     bf16x8 m2f[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) m2f[ks] = *(const bf16x8*)(a.m2 + (long)px * MID + 16 * ks + 8 * half);
+    bf16x8 xf[PROJ ? KS : 1];
+    if constexpr (PROJ) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) xf[ks] = *(const bf16x8*)(a.xin + (long)px * MID + 16 * ks + 8 * half);
+    }
     f32x16 m1acc[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -147,15 +164,15 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
       for (int kh = 0; kh < KSPLIT; ++kh) {
         const int st = p * KSPLIT + kh;
         if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // step st landed everywhere; everyone left step st-1
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (!PROJ) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (PROJ: no LDS-DMA in flight; its stores need no wait)
         if (kh == 0) {
-          if (p > 0) flush(p0, p - 1);
+          if (!PROJ && p > 0) flush(p0, p - 1);
           if (p + 1 < NP) issue_x(p0, p + 1);
           else if (it + 1 < n_iter) issue_x(p0 + t_step * 32, 0);
         }
         if (st + 1 < NP * KSPLIT) issue_w(st + 1);
         else if (it + 1 < n_iter) issue_w(0);
-        const uint4* w3 = (const uint4*)(smem + (STREAM ? (st & 1) : st) * (W3P + W1P));
+        const uint4* w3 = (const uint4*)(smem + (STREAM ? (st & 1) : st) * PASSB);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
           if (kh == 0)
@@ -164,10 +181,16 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
 #pragma unroll
           for (int ks = 0; ks < KSS; ++ks)
             acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&w3[(ct * KSS + ks) * 64 + lane], m2f[kh * KSS + ks], acc[ct], 0, 0, 0);
+          if constexpr (PROJ) {
+            const uint4* wp = (const uint4*)((const unsigned char*)w3 + W3P);
+#pragma unroll
+            for (int ks = 0; ks < KSS; ++ks)
+              acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&wp[(ct * KSS + ks) * 64 + lane], xf[ks], acc[ct], 0, 0, 0);
+          }
         }
       }
-      const uint4* w1 = (const uint4*)(smem + (STREAM ? (p & 1) : p) * (W3P + W1P) + W3P);      // (REDUCE implies KSPLIT == 1: step == pass)
-      unsigned char* sb = stage + (p & 1) * 4096;
+      const uint4* w1 = (const uint4*)(smem + (STREAM ? (p & 1) : p) * PASSB + W3P + WPP);      // (REDUCE implies KSPLIT == 1: step == pass)
+      unsigned char* sb = stage + (PROJ ? 0 : (p & 1) * 4096);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         // bias + shortcut + ReLU in place; the packed values feed the second product directly
@@ -175,7 +198,7 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           uint2* sp = (uint2*)(sb + l31 * 128 + (((ct * 4 + g) ^ ((l31 >> 1) & 7)) << 4) + 8 * half);
-          const uint2 xv = *sp;
+          const uint2 xv = PROJ ? make_uint2(0u, 0u) : *sp;
           const float4 bv = *(const float4*)(sB3 + p * 64 + ct * 32 + 8 * g + 4 * half);
           const float v0 = fmaxf(acc[ct][4 * g + 0] + bv.x + bf2f(xv.x & 0xffff), 0.f), v1 = fmaxf(acc[ct][4 * g + 1] + bv.y + bf2f(xv.x >> 16), 0.f);
           const float v2 = fmaxf(acc[ct][4 * g + 2] + bv.z + bf2f(xv.y & 0xffff), 0.f), v3 = fmaxf(acc[ct][4 * g + 3] + bv.w + bf2f(xv.y >> 16), 0.f);
@@ -196,12 +219,13 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slice is complete in LDS (same-wave readers only)
       __builtin_amdgcn_wave_barrier();
+      if constexpr (PROJ) { flush(p0, p); __builtin_amdgcn_wave_barrier(); }      // single stage buffer: out before the next pass writes it
     }
-    flush(p0, NP - 1);
+    if constexpr (!PROJ) flush(p0, NP - 1);
     if constexpr (!REDUCE) continue;
     // mid1' = relu(. + b1), 64 channels at a time through the buffer that was just flushed (the other one is receiving
     // the next tile's first slice)
-    unsigned char* sb = stage + ((NP - 1) & 1) * 4096;
+    unsigned char* sb = stage + (PROJ ? 0 : ((NP - 1) & 1) * 4096);
 #pragma unroll
     for (int hc = 0; hc < RT / 2; ++hc) {
 #pragma unroll
@@ -245,6 +269,7 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
   ChainArgs a;
   a.m2 = (const unsigned short*)mid2; a.x = (const unsigned short*)x; a.w3f = (const uint4*)w3f; a.w1f = (const uint4*)w1f;
   a.b3 = b3; a.b1 = b1; a.xn = (unsigned short*)x_next; a.m1 = (unsigned short*)mid1_next; a.P = (int)P;
+  a.xin = nullptr; a.wpf = nullptr;
   static relnet::PerDeviceOnce attr_once;
   if (attr_once.first()) {
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -267,6 +292,34 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
     else bottleneck_chain_kernel<512, true, false, 2><<<grid, 512, lds, (hipStream_t)stream>>>(a);
   }
   return check_launch("relnet_bottleneck_chain");
+}
+
+// First unit of res2 (projection shortcut, stride 1): x_next = relu(conv1x1(mid2; W3) + conv1x1(x_in; Wp) + b3p), b3p = b3 + bp, and
+// (optionally) mid1_next = relu(conv1x1(x_next; W1n, b1n)) in one kernel: the branch1 convolution of the reference graph
+// (resnet_v1_101_rcnn_base.py: res2a_branch1 + bn2a_branch1) becomes four more k-steps of the expand product.  mid = 64 only;
+// w3f / wpf = relnet_pack_w_frag of W3 / Wp [256][64]; x_in [P][64] dense bf16.
+extern "C" int relnet_bottleneck_chain_proj(const void* mid2, const void* x_in, const void* w3f, const void* wpf, const void* w1f,
+                                            const float* b3p, const float* b1, void* x_next, void* mid1_next, long P, int mid,
+                                            void* stream) {
+  RELNET_REQUIRE(mid2 && x_in && w3f && wpf && b3p && x_next, "relnet_bottleneck_chain_proj: null operand");
+  RELNET_REQUIRE((w1f && b1 && mid1_next) || (!w1f && !b1 && !mid1_next), "relnet_bottleneck_chain_proj: w1f, b1 and mid1_next are given together (or all NULL)");
+  RELNET_REQUIRE(mid == 64, "relnet_bottleneck_chain_proj: mid = %d unsupported (64)", mid);
+  RELNET_REQUIRE(P > 0 && P < (1L << 31), "relnet_bottleneck_chain_proj: bad pixel count %ld", P);
+  ChainArgs a;
+  a.m2 = (const unsigned short*)mid2; a.x = nullptr; a.w3f = (const uint4*)w3f; a.w1f = (const uint4*)w1f;
+  a.b3 = b3p; a.b1 = b1; a.xn = (unsigned short*)x_next; a.m1 = (unsigned short*)mid1_next; a.P = (int)P;
+  a.xin = (const unsigned short*)x_in; a.wpf = (const uint4*)wpf;
+  static relnet::PerDeviceOnce attr_once;
+  if (attr_once.first()) {
+    hipFuncSetAttribute((const void*)bottleneck_chain_kernel<64, false, true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)bottleneck_chain_kernel<64, false, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  const long ntile = (P + 31) / 32;
+  const unsigned grid = (unsigned)(ntile < 8 * 256 ? (ntile + 7) / 8 : 256);
+  const size_t lds = (size_t)4 * (8192 + 8192 + (mid1_next ? 8192 : 0)) + 8 * 4096 + (size_t)5 * mid * 4;
+  if (mid1_next) bottleneck_chain_kernel<64, false, true, 1, true><<<grid, 512, lds, (hipStream_t)stream>>>(a);
+  else bottleneck_chain_kernel<64, false, false, 1, true><<<grid, 512, lds, (hipStream_t)stream>>>(a);
+  return check_launch("relnet_bottleneck_chain_proj");
 }
 
 // ---------------------------------------------------------------------------------------

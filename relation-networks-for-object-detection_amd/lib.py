@@ -39,6 +39,7 @@ _SIGNATURES = {
                                                   _vp, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l,
                                                   _i, _i, _i, _i, _i, _f, _vp]),
     'relnet_bottleneck_chain': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp]),
+    'relnet_bottleneck_chain_proj': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp]),
     'relnet_conv3x3_c64': (C.c_int, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     'relnet_proposal_decode': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_topk_sort': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

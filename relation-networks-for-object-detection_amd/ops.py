@@ -448,6 +448,22 @@ def bottleneck_chain(mid2, x, w3_frag, w1_frag, b3, b1, inplace=False):
     return xn, m1
 
 
+def bottleneck_chain_proj(mid2, x_in, w3_frag, wp_frag, w1_frag, b3p, b1):
+    """First unit of a stage whose shortcut is a stride-1 1x1 projection (res2a): x_next = relu(conv1x1(mid2; W3) + conv1x1(x_in; Wp)
+    + b3p), b3p = b3 + bp, and (w1_frag given) mid1_next = relu(conv1x1(x_next; W1n, b1n)) in one kernel -- the projection's
+    4 mid-channel output is never written or read back.  mid2, x_in [.., 64] dense bf16.  -> (x_next [.., 256], mid1_next | None)"""
+    _chk(mid2, x_in, w3_frag, wp_frag, w1_frag, b3p, b1)
+    mid = mid2.shape[-1]
+    assert mid == 64 and x_in.shape == mid2.shape and mid2.is_contiguous() and x_in.is_contiguous()
+    assert mid2.dtype == torch.bfloat16 and x_in.dtype == torch.bfloat16 and b3p.dtype == torch.float32
+    assert (w1_frag is None) == (b1 is None)
+    xn = torch.empty(mid2.shape[:-1] + (4 * mid,), device=mid2.device, dtype=torch.bfloat16)
+    m1 = torch.empty_like(mid2) if w1_frag is not None else None
+    _lib.call('relnet_bottleneck_chain_proj', mid2.data_ptr(), x_in.data_ptr(), w3_frag.data_ptr(), wp_frag.data_ptr(), _ptr(w1_frag),
+              b3p.data_ptr(), _ptr(b1), xn.data_ptr(), _ptr(m1), mid2.numel() // mid, mid, _stream())
+    return xn, m1
+
+
 def conv2d_nhwc(x, w_packed, bias, ksize=1, stride=1, pad=0, dil=1, relu=False, resid=None, out=None,
                 out_dtype=None, w_frag=None):
     """x [B,H,W,Cin] bf16 (last dim contiguous; pixel/image strides free), w_packed

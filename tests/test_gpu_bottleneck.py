@@ -49,6 +49,43 @@ def test_bottleneck_chain_vs_two_convolutions(shape, mid):
     assert (dx <= ulp(xn64) * 1.01 + 1e-6).all() and fx < 0.02     # (+ fp32 summation-order noise next to the ReLU threshold)
     assert (dm <= 4 * ulp(m164) + 1e-2).all() and fm < 0.05        # (a one-step difference of x_next times |W1|)
 
+@pytest.mark.parametrize('shape', [(1, 5, 7), (2, 38, 63), (3, 150, 250)])
+@pytest.mark.parametrize('reduce', [True, False])
+def test_bottleneck_chain_with_projection_shortcut(shape, reduce):
+    """relnet_bottleneck_chain_proj (res2a: the 1x1 projection shortcut as four more k-steps of the expand product) against a
+    float64 evaluation of the same bf16 operands: x_next = relu(W3 mid2 + Wp x_in + b3 + bp) is correctly rounded (no bf16
+    rounding of the shortcut on the way), mid1' as in the plain chain kernel; and against the three convolution launches it
+    replaces (which DO round the projection to bf16: within one bf16 step)."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import ops
+    B, H, W = shape
+    mid, cout = 64, 256
+    g = torch.Generator().manual_seed(B * 1000 + H + 7)
+    bf = torch.bfloat16
+    m2 = torch.relu(torch.randn(B, H, W, mid, generator=g)).to(bf).cuda()
+    xin = torch.relu(torch.randn(B, H, W, mid, generator=g)).to(bf).cuda()
+    w3 = (torch.randn(cout, mid, generator=g) * 0.1).to(bf).cuda()
+    wp = (torch.randn(cout, mid, generator=g) * 0.1).to(bf).cuda()
+    w1 = (torch.randn(mid, cout, generator=g) * 0.05).to(bf).cuda()
+    b3, bp = (torch.randn(cout, generator=g) * 0.1).cuda(), (torch.randn(cout, generator=g) * 0.1).cuda()
+    b1 = (torch.randn(mid, generator=g) * 0.1).cuda()
+    xn, m1 = ops.bottleneck_chain_proj(m2, xin, ops.pack_w_frag(w3), ops.pack_w_frag(wp), ops.pack_chain_w1(w1) if reduce else None,
+                                       (b3 + bp).contiguous(), b1 if reduce else None)
+    xn64 = torch.relu(m2.double() @ w3.double().t() + xin.double() @ wp.double().t() + (b3 + bp).double())
+    ulp = lambda t: torch.maximum(t.abs(), torch.tensor(2.0 ** -126, dtype=torch.float64, device=t.device)) * 2.0 ** -7
+    ex = (xn.double() - xn64).abs() - 0.5 * ulp(xn64)
+    assert ex.max().item() <= 4e-5, ex.max().item()
+    if reduce:
+        m164 = torch.relu(xn.double() @ w1.double().t() + b1.double())
+        em = (m1.double() - m164).abs() - 0.5 * ulp(m164)
+        assert em.max().item() <= 2e-5, em.max().item()
+    else:
+        assert m1 is None
+    sc = ops.conv2d_nhwc(xin, wp, bp)                                   # the launches of the unfused path
+    ref = ops.conv2d_nhwc(m2, w3, b3, relu=True, resid=sc)
+    assert ((xn.float() - ref.float()).abs().double() <= 1.01 * ulp(xn64) + 0.5 * ulp(sc.double()) + 1e-6).all()
+
+
 @pytest.mark.parametrize('mid,shape', [(256, (2, 38, 63)), (512, (2, 38, 63)), (256, (1, 5, 7)), (512, (3, 19, 32))])
 def test_expand_only_chain_wide(mid, shape):
     """res4 / res5 expand + shortcut + ReLU on the chain kernel (weights through the LDS ring, k split in two for mid = 512):
@@ -84,11 +121,18 @@ def test_backbone_with_and_without_chain_kernel():
     assert [k for k in sorted(a.chain) if k[0] in '23'] == ['2a', '2b', '2c', '3a', '3b1', '3b2', '3b3'] and a.chain['2c'][1] is None
     assert sum(k[0] == '4' for k in a.chain) == 23 and all(a.chain[k][1] is None for k in a.chain if k[0] in '45') and not b.chain
     assert sum(k[0] == '5' for k in a.chain) == 3
+    assert sorted(a.chain_proj) == ['2a'] and not b.chain_proj
+    ref = backbone.Backbone(p, dtype=torch.float32).forward(data)            # float32 trunk: the yardstick for both
     fa, fb = a.forward(data), b.forward(data)
+    assert a.last_chain_units[:3] == ['2a', '2b', '2c']
     for k in ('conv4', 'conv5', 'rpn_cls_score', 'rpn_bbox_pred'):
+        r = ref[k].float()
+        ea, eb = ((fa[k].float() - r).norm() / r.norm()).item(), ((fb[k].float() - r).norm() / r.norm()).item()
+        # measured (r04): 0.0086 - 0.0104 for both trunks; the fused one is never the worse of the two by more than rounding noise
+        assert ea <= 1.5e-2 and eb <= 1.5e-2 and ea <= eb * 1.05, (k, ea, eb)
         d = (fa[k].float() - fb[k].float()).abs().max().item()
         s = fb[k].float().abs().max().item()
-        assert d <= 2e-2 * s, (k, d, s)
+        assert d <= 3e-2 * s, (k, d, s)                # (the res2a projection is not rounded to bf16 in the fused trunk: 0.021 measured)
 
 
 @pytest.mark.parametrize('C', [64])

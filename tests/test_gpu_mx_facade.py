@@ -62,6 +62,9 @@ def test_relation_graph_bf16_matches_detector(rn):
     rois, cls_prob, bbox_pred, att1, att2 = [o.asnumpy() for o in outs]
     assert rois.shape == (300, 5) and cls_prob.shape == (1, 300, 81) and bbox_pred.shape == (1, 300, 8) and att1.shape == (300, 1024)
     det = detector.Detector(p, dtype=torch.bfloat16, im_hw=(H, W))
+    # the graph executor runs res2a's projection shortcut as its own convolution (bf16 map); the Detector's fused form keeps it
+    # in fp32 inside the expand kernel -- one rounding fewer, so a row-exact comparison needs the same form on both sides
+    det.backbone.chain_proj = {}
     ref = det.forward(data.cuda(), im_info.cuda())
     r_ref = _np(ref['rois'][0])
     same = (np.abs(rois - r_ref).max(axis=1) == 0)

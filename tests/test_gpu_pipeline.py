@@ -323,12 +323,14 @@ def test_benched_trunk_configuration_in_network(rn):
     assert w['proposal_rows_identical'] == 300 and w['roi_pool_mismatches'] == 0 and w['detections_all_matched'], rep
     assert w['cls_score_max_rel_err'] < 3e-2 and w['bbox_pred_max_rel_err'] < 3e-2, rep
     assert w['attention_1_max_rel_err'] < 3e-2 and w['attention_2_max_rel_err'] < 3e-2, rep
-    # the chain kernels are bit-identical to the tiled convolution kernels they replace (same products, same order)
+    # the chain kernels repeat the products of the tiled convolution kernels they replace in the same order; res2a's fused
+    # projection shortcut keeps the shortcut in fp32 (one bf16 rounding fewer), so the two trunks differ by bf16 rounding noise
     ref = det.forward(data, im_info, keep_features=True)
     assert ref['features'] is not out['features'] and len(det.backbone.last_chain_units) < 33
     for k in ('conv4', 'conv5'):
-        d = (out['features'][k].float() - ref['features'][k].float()).abs().max().item()
-        assert d <= 2e-2 * ref['features'][k].float().abs().max().item(), (k, d)
+        a, b = out['features'][k].float(), ref['features'][k].float()
+        d = (a - b).abs().max().item()
+        assert ((a - b).norm() / b.norm()).item() < 1e-2 and d <= 5e-2 * b.abs().max().item(), (k, d)
 
 
 @pytest.mark.parametrize('shape', [(2, 600, 1000), (1, 37, 52), (3, 121, 200), (1, 800, 1024)])
