@@ -216,8 +216,9 @@ int relnet_class_nms_ex(const float* cls_prob, const double* scores64, const dou
  * top_k scores of its image.  Every pick of the image is counted in `hist` (B x relnet_class_nms_hist_bins() unsigned ints, ZEROED
  * by the caller before every call); a class stops when its latest pick falls below the bin in which the count from the top reaches
  * top_k.  The lists are prefixes of relnet_class_nms's and contain every pick >= the final image threshold, so relnet_image_topk
- * returns the same detections; counts = picks produced.  N <= 512. */
+ * returns the same detections; counts = picks produced.  N <= 1024. */
 int relnet_class_nms_hist_bins(void);
+void relnet_class_nms_debug_form(int form);     /* tuning knob: 0 = automatic (by the number of (image, class) pairs), 1 = one roi per thread, 2 = one wavefront per class */
 int relnet_class_nms_topk(const float* cls_prob, const double* boxes, double* dets, int* counts, void* hist, int B, int N, int C,
                           float score_thresh, double nms_param, int soft, int max_picks, int top_k, void* stream);
 /* tester.py:270-277: image threshold = max_per_image-th largest score; out [B,max_out,6] =

@@ -1,7 +1,7 @@
 // Detection post-processing on device (reference: relation_rcnn/core/tester.py:148-156
 // im_detect decode, :244-268 per-class NMS / soft-NMS, :270-277 max_per_image; lib/nms/nms.py:
 // 45-82 `nms`, :85-141 `soft_nms`).  The reference runs this part in numpy float64 on one host
-// core (25 / 59 ms per image in its README); here every (image, class) pair is one wavefront.
+// core (25 / 59 ms per image in its README); here every (image, class) pair is one workgroup, one roi per thread.
 //
 //   detect_head_kernel      softmax over classes (SoftmaxActivation) + class-agnostic box
 //                           decode (bbox_transform.py:103-140, float64) + clip + 1/scale.
@@ -85,12 +85,13 @@ struct ClsNmsArgs {
 // maximum), so once its LATEST pick lies below a lower bound of that final threshold, none of its later picks can be kept.
 // The bound: every pick of the image is counted in a shared two-level histogram of its float64 score: 384 coarse bins (sign,
 // exponent, 5 mantissa bits: 3 %) and, per coarse bin, 32 fine bins (the next 5 mantissa bits: 0.1 % -- with flat posteriors a class's
-// pick sequence falls slowly, the coarse bin alone let 10-30 picks per class through).  (t, t2) = the coarse / fine bin in which the
-// count from the top reaches top_k.  Histograms of SUBSETS of the final pick set can only give a lower (t, t2), so a stale or partial
-// view (other classes still running, agent-scope relaxed reads) prunes less, never wrongly: a class stops when the bin pair of its
-// latest pick is below (t, t2).  The lists written are prefixes of the full lists and contain every pick >= the final threshold, so
-// relnet_image_topk returns the same detections; counts[] = picks actually produced.  With 80 similar classes (the benchmark's
-// random-init heads: all 300 rois are candidates in every class) a class stops after a few picks instead of 100.
+// pick sequence falls slowly, the coarse bin alone let 10-30 picks per class through).  A class stops when at least top_k picks of
+// the image lie in STRICTLY higher (coarse, fine) bins than its latest pick: those picks have strictly higher scores, so the image
+// threshold (the top_k-th largest score) is above everything this class can still produce.  Histograms of SUBSETS of the final pick
+// set only undercount (other classes still running, agent-scope relaxed reads, fine counts lagging the coarse ones), so a stale or
+// partial view prunes less, never wrongly.  The lists written are prefixes of the full lists and contain every pick >= the final
+// threshold, so relnet_image_topk returns the same detections; counts[] = picks actually produced.  With 80 similar classes (the
+// benchmark's random-init heads: all 300 rois are candidates in every class) a class stops after a few picks instead of 100.
 constexpr int kHistBins = 384;                      // scores in [2^-11, 2): (exponent - 1012) * 32 + 5 mantissa bits
 constexpr int kHistFine = 32;                       // fine bins per coarse bin (mantissa bits 6..10)
 constexpr int kHistWords = kHistBins * (1 + kHistFine);     // per image: [kHistBins] coarse, then [kHistBins][kHistFine]
@@ -128,105 +129,144 @@ __device__ __forceinline__ double wave_max_f64(double v) {
   return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
-// kPerLane * 64 >= N candidates per (image, class)
-template <int kPerLane, bool PRUNE = false>
-__global__ __launch_bounds__(64) void class_nms_kernel(ClsNmsArgs g) {
-  const int cls = blockIdx.x + 1, b = blockIdx.y, lane = threadIdx.x;
-  const float* prob = g.cls_prob + (long)b * g.N * g.C;
-  const double* bx = g.boxes + (long)b * g.N * 4;
-  double x1[kPerLane], y1[kPerLane], x2[kPerLane], y2[kPerLane], area[kPerLane], sc[kPerLane];
-  // candidate slot s of lane l is roi index s*64 + l; sc == kGone marks "absent/picked"
+// Wave-wide sum of an unsigned (same DPP pairing as wave_max_f64: every step adds two disjoint groups).
+__device__ __forceinline__ unsigned int wave_sum_u32(unsigned int v) {
+  v += (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, false);
+  v += (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, false);
+  v += (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, false);
+  v += (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, false);
+  return (unsigned int)__builtin_amdgcn_readlane((int)v, 0) + (unsigned int)__builtin_amdgcn_readlane((int)v, 16) +
+         (unsigned int)__builtin_amdgcn_readlane((int)v, 32) + (unsigned int)__builtin_amdgcn_readlane((int)v, 48);
+}
+
+// One workgroup of WAVES wavefronts per (image, class), PER candidates per thread (candidate s of thread t = roi s * 64 WAVES + t).
+// The per-pick chain is the serial path of the whole post-processing (a class that owns k of the image's max_per_image
+// detections makes k + 1 picks one after the other), so it is kept short:
+//   before the barrier  each wave: maximum of its 64 scores (DPP), highest lane holding it (ballot: ties -> larger roi index, the
+//                       argsort()[::-1] convention of nms.py), that lane's box through v_readlane -> one LDS slot per wave;
+//   after the barrier   every thread reads the WAVES slots (LDS broadcasts), takes the best (ties -> later wave = larger roi
+//                       index) and rescores its own candidate: one float64 division + exp per thread instead of five per lane
+//                       in the one-wave form of rounds 1-3 (2.7 us per pick there, the fp64 exp chains of five slots back to back).
+// One barrier per pick: the slots are double buffered by pick parity.
+// PRUNE: wave 0 counts the pick in the image's histogram and at once requests the counts it needs for the NEXT decision
+// (6 coarse bins per lane + the fine bins of the pick's coarse bin); they land while the candidates are rescored and are consumed
+// before the next barrier.  The class stops when at least top_k picks of the image lie in strictly higher (coarse, fine) bins than
+// its latest pick: A = picks in coarse bins above, F = picks in higher fine bins of the same coarse bin, stop <=> A + F >= top_k
+// (one masked wave sum).  The flag travels through LDS, so the whole workgroup leaves the loop at the same pick.
+template <int WAVES, int PER, bool PRUNE>
+__global__ __launch_bounds__(64 * WAVES) void class_nms_kernel(ClsNmsArgs g) {
+  constexpr int NT = 64 * WAVES;
+  struct Slot { double best, x1, y1, x2, y2, area; int bi, pad; };
+  __shared__ Slot s_slot[2][WAVES];
+  __shared__ int s_n[WAVES];
+  __shared__ int s_stop[2];
+  const int cls = blockIdx.x + 1, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double x1[PER], y1[PER], x2[PER], y2[PER], area[PER], sc[PER];      // candidate s of thread t is roi s NT + t; sc == kGone: absent / picked / suppressed
   int n = 0;
 #pragma unroll
-  for (int s = 0; s < kPerLane; ++s) {
-    const int i = s * 64 + lane;
+  for (int s = 0; s < PER; ++s) {
+    const int i = s * NT + tid;
     sc[s] = kGone;
     x1[s] = y1[s] = x2[s] = y2[s] = area[s] = 0.0;
     if (i < g.N) {
-      const double p = g.scores64 ? g.scores64[(long)b * g.N + i] : (double)prob[(long)i * g.C + cls];
+      const double p = g.scores64 ? g.scores64[(long)b * g.N + i] : (double)g.cls_prob[((long)b * g.N + i) * g.C + cls];
       if (p > (double)g.score_thresh) {
+        const double* bx = g.boxes + ((long)b * g.N + i) * 4;
         sc[s] = p;
-        x1[s] = bx[i * 4 + 0]; y1[s] = bx[i * 4 + 1]; x2[s] = bx[i * 4 + 2]; y2[s] = bx[i * 4 + 3];
+        x1[s] = bx[0]; y1[s] = bx[1]; x2[s] = bx[2]; y2[s] = bx[3];
         area[s] = (x2[s] - x1[s] + 1) * (y2[s] - y1[s] + 1);
-        ++n;
       }
     }
+    n += __popcll(__ballot(sc[s] > kGone));
   }
+  if constexpr (WAVES > 1) {
+    if (lane == 0) s_n[wave] = n;
+    if (tid < 2) s_stop[tid] = 0;
+    __syncthreads();
+    n = 0;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    for (int w = 0; w < WAVES; ++w) n += s_n[w];
+  }
   double* out = g.dets + (((long)b * (g.C - 1) + (cls - 1)) * g.N) * 5;
+  unsigned int* hist = PRUNE ? g.hist + (long)b * kHistWords : nullptr;
   int picked = 0;
   const int n_it = n < g.max_picks ? n : g.max_picks;
+  unsigned int hc[6] = {0u, 0u, 0u, 0u, 0u, 0u}, hf = 0u;       // wave 0: the counts requested after the previous pick
+  int mybin = 0, myfine = 0;
   for (int it = 0; it < n_it; ++it) {
-    // arg-max over remaining; ties -> larger roi index (argsort()[::-1] convention): wave maximum, then the highest (slot, lane)
-    // holding it -- ballots, all on the scalar unit
-    double lbest = kGone;
+    const int par = it & 1;
+    // this wave's best candidate: maximum (DPP), then the highest (slot, lane) holding it
+    double lbest = sc[0];
 #pragma unroll
-    for (int s = 0; s < kPerLane; ++s) lbest = fmax(lbest, sc[s]);
-    const double best = wave_max_f64(lbest);
-    if (!(best > kGone)) break;                     // everything suppressed (hard NMS)
+    for (int s = 1; s < PER; ++s) lbest = fmax(lbest, sc[s]);
+    double best = wave_max_f64(lbest);
     int bi = -1;
 #pragma unroll
-    for (int s = kPerLane - 1; s >= 0; --s) {
-      const unsigned long long m = __ballot(sc[s] == best);
-      if (bi < 0 && m) bi = s * 64 + 63 - __clzll(m);
+    for (int s = PER - 1; s >= 0; --s) {
+      const unsigned long long m = __ballot(sc[s] == best);         // (every lane of every slot when the wave has nothing left: harmless)
+      if (bi < 0 && m) bi = s * NT + wave * 64 + 63 - __clzll(m);
     }
-    const int bl = bi & 63, bs = bi >> 6;
     double px1 = 0, py1 = 0, px2 = 0, py2 = 0, pa = 0;
+    {
+      const int bs = bi / NT, bl = bi & 63;
 #pragma unroll
-    for (int s = 0; s < kPerLane; ++s)
-      if (s == bs) { px1 = x1[s]; py1 = y1[s]; px2 = x2[s]; py2 = y2[s]; pa = area[s]; }
-    px1 = readlane_f64(px1, bl); py1 = readlane_f64(py1, bl); px2 = readlane_f64(px2, bl); py2 = readlane_f64(py2, bl); pa = readlane_f64(pa, bl);
-    if (lane == 0) {
+      for (int s = 0; s < PER; ++s)
+        if (s == bs) { px1 = x1[s]; py1 = y1[s]; px2 = x2[s]; py2 = y2[s]; pa = area[s]; }
+      px1 = readlane_f64(px1, bl); py1 = readlane_f64(py1, bl); px2 = readlane_f64(px2, bl); py2 = readlane_f64(py2, bl); pa = readlane_f64(pa, bl);
+    }
+    bool stop = false;
+    if constexpr (PRUNE) {
+      if (wave == 0 && it > 0) {
+        unsigned int part = (lane < kHistFine && lane > myfine) ? hf : 0u;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) part += (lane * 6 + q > mybin) ? hc[q] : 0u;
+        stop = wave_sum_u32(part) >= (unsigned int)g.top_k;
+      }
+    }
+    if constexpr (WAVES > 1) {
+      if (lane == 0) {
+        Slot& sl = s_slot[par][wave];
+        sl.best = best; sl.x1 = px1; sl.y1 = py1; sl.x2 = px2; sl.y2 = py2; sl.area = pa; sl.bi = bi;
+        if (PRUNE && stop) s_stop[par] = 1;
+      }
+      __syncthreads();
+      if constexpr (PRUNE) stop = s_stop[par] != 0;
+      int ws = 0;
+      best = s_slot[par][0].best;
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) {
+        const double ob = s_slot[par][w].best;
+        const int oi = s_slot[par][w].bi, ci = s_slot[par][ws].bi;
+        if (ob > best || (ob == best && oi > ci)) { best = ob; ws = w; }
+      }
+      const Slot& sl = s_slot[par][ws];
+      px1 = sl.x1; py1 = sl.y1; px2 = sl.x2; py2 = sl.y2; pa = sl.area; bi = sl.bi;
+    }
+    if (stop) break;                                      // every later pick of this class is <= the last one: below the image cut for good
+    if (!(best > kGone)) break;                           // everything suppressed (hard NMS)
+    if (tid == 0) {
       double* o = out + (long)picked * 5;
       o[0] = px1; o[1] = py1; o[2] = px2; o[3] = py2; o[4] = best;
       if (g.pick_index) g.pick_index[((long)b * (g.C - 1) + (cls - 1)) * g.N + picked] = bi;
     }
     ++picked;
     if constexpr (PRUNE) {
-      // count this pick, then look at the image's histogram: bins [6 lane, 6 lane + 6), count from the top bin down
-      unsigned int* hist = g.hist + (long)b * kHistWords;
-      unsigned int* hist2 = hist + kHistBins;
-      int myfine;
-      const int mybin = score_bin(best, myfine);
-      if (lane == 0) {
-        __hip_atomic_fetch_add(hist + mybin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(hist2 + mybin * kHistFine + myfine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      // (the look-up is an L2 round trip on the serial path of the class: every pick for the first four, then every fourth)
-      if (picked <= 4 || !(picked & 3)) {
-        unsigned int c[6], tot = 0;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) { c[q] = __hip_atomic_load(hist + lane * 6 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tot += c[q]; }
-        unsigned int suf = tot;                        // inclusive suffix sum over lanes: picks in bins >= 6 lane
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const unsigned int v = __shfl_down(suf, o); if (lane + o < 64) suf += v; }
-        const unsigned long long m = __ballot(suf >= (unsigned)g.top_k);
-        if (m) {
-          const int L = 63 - __clzll(m);               // highest lane whose suffix reaches top_k: the bound's coarse bin is one of its six
-          unsigned int acc = suf - tot;                // picks in the lanes above
-          int t = lane * 6;
-          unsigned int above = acc;                    // picks in coarse bins above t
-#pragma unroll
-          for (int q = 5; q >= 0; --q) { if (acc + c[q] >= (unsigned)g.top_k) { t = lane * 6 + q; above = acc; break; } acc += c[q]; }
-          t = __shfl(t, L); above = __shfl(above, L);
-          if (mybin < t) break;                        // every later pick of this class is <= this one: below the image cut for good
-          if (mybin == t) {
-            // fine bins of coarse bin t: lane f < 32 holds fine bin f; count from the top fine bin down, on top of `above`
-            unsigned int f = lane < kHistFine ? __hip_atomic_load(hist2 + t * kHistFine + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            unsigned int fs = f;
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1) { const unsigned int v = __shfl_down(fs, o); if (lane + o < 32) fs += v; }
-            const unsigned long long m2 = __ballot(lane < kHistFine && above + fs >= (unsigned)g.top_k);
-            // (the fine counts may lag the coarse count they refine: no lane qualifying means "no fine bound yet")
-            if (m2 && myfine < 63 - __clzll(m2)) break;
-          }
+      if (wave == 0) {
+        mybin = score_bin(best, myfine);
+        unsigned int* hist2 = hist + kHistBins;
+        if (lane == 0) {
+          __hip_atomic_fetch_add(hist + mybin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(hist2 + mybin * kHistFine + myfine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) hc[q] = __hip_atomic_load(hist + lane * 6 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hf = lane < kHistFine ? __hip_atomic_load(hist2 + mybin * kHistFine + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
       }
     }
 #pragma unroll
-    for (int s = 0; s < kPerLane; ++s) {
-      if (s * 64 + lane == bi) { sc[s] = kGone; continue; }
+    for (int s = 0; s < PER; ++s) {
+      if (s * NT + tid == bi) { sc[s] = kGone; continue; }
       if (!(sc[s] > kGone)) continue;
       const double w = fmax(0.0, fmin(px2, x2[s]) - fmax(px1, x1[s]) + 1);
       const double h = fmax(0.0, fmin(py2, y2[s]) - fmax(py1, y1[s]) + 1);
@@ -237,98 +277,6 @@ __global__ __launch_bounds__(64) void class_nms_kernel(ClsNmsArgs g) {
         else if (!(ovr <= g.nms_param)) sc[s] = kGone;                     // nms.py:79
       }
     }
-  }
-  if (lane == 0) g.counts[(long)b * (g.C - 1) + (cls - 1)] = picked;
-}
-
-// N up to 1024 candidates (FPN graphs, TOP_ROIS 1000): four wavefronts share one (image, class), 4 candidates per
-// thread.  Same arithmetic and tie rule as the single-wave kernel above; the per-pick arg-max crosses the waves
-// through LDS.  (16 candidates per lane in ONE wave needs 6 x 16 doubles per lane and spills thousands of VGPRs.)
-template <int kPerThread>
-__global__ __launch_bounds__(256) void class_nms_block_kernel(ClsNmsArgs g) {
-  constexpr int NT = 256;
-  __shared__ double s_best[4];
-  __shared__ int s_bi[4];
-  __shared__ double s_box[5];
-  __shared__ int s_n;
-  const int cls = blockIdx.x + 1, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* prob = g.cls_prob + (long)b * g.N * g.C;
-  const double* bx = g.boxes + (long)b * g.N * 4;
-  double x1[kPerThread], y1[kPerThread], x2[kPerThread], y2[kPerThread], area[kPerThread], sc[kPerThread];
-  if (tid == 0) s_n = 0;
-  __syncthreads();
-  int n = 0;
-#pragma unroll
-  for (int s = 0; s < kPerThread; ++s) {
-    const int i = s * NT + tid;
-    sc[s] = kGone;
-    x1[s] = y1[s] = x2[s] = y2[s] = area[s] = 0.0;
-    if (i < g.N) {
-      const double p = g.scores64 ? g.scores64[(long)b * g.N + i] : (double)prob[(long)i * g.C + cls];
-      if (p > (double)g.score_thresh) {
-        sc[s] = p;
-        x1[s] = bx[i * 4 + 0]; y1[s] = bx[i * 4 + 1]; x2[s] = bx[i * 4 + 2]; y2[s] = bx[i * 4 + 3];
-        area[s] = (x2[s] - x1[s] + 1) * (y2[s] - y1[s] + 1);
-        ++n;
-      }
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
-  if (lane == 0) atomicAdd(&s_n, n);
-  __syncthreads();
-  n = s_n;
-  double* out = g.dets + (((long)b * (g.C - 1) + (cls - 1)) * g.N) * 5;
-  int picked = 0;
-  const int n_it = n < g.max_picks ? n : g.max_picks;
-  for (int it = 0; it < n_it; ++it) {
-    double best = kGone; int bi = -1;
-#pragma unroll
-    for (int s = 0; s < kPerThread; ++s)
-      if (sc[s] > best || (sc[s] == best && sc[s] > kGone)) { best = sc[s]; bi = s * NT + tid; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const double ob = __shfl_xor(best, o);
-      const int oi = __shfl_xor(bi, o);
-      if (ob > best || (ob == best && oi > bi)) { best = ob; bi = oi; }
-    }
-    if (lane == 0) { s_best[wave] = best; s_bi[wave] = bi; }
-    __syncthreads();
-    best = s_best[0]; bi = s_bi[0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      const double ob = s_best[w]; const int oi = s_bi[w];
-      if (ob > best || (ob == best && oi > bi)) { best = ob; bi = oi; }
-    }
-    if (!(best > kGone)) break;                     // uniform: every thread read the same LDS values
-    if (tid == (bi % NT)) {
-      const int bs = bi / NT;
-#pragma unroll
-      for (int s = 0; s < kPerThread; ++s)
-        if (s == bs) { s_box[0] = x1[s]; s_box[1] = y1[s]; s_box[2] = x2[s]; s_box[3] = y2[s]; s_box[4] = area[s]; }
-    }
-    __syncthreads();
-    const double px1 = s_box[0], py1 = s_box[1], px2 = s_box[2], py2 = s_box[3], pa = s_box[4];
-    if (tid == 0) {
-      double* o = out + (long)picked * 5;
-      o[0] = px1; o[1] = py1; o[2] = px2; o[3] = py2; o[4] = best;
-      if (g.pick_index) g.pick_index[((long)b * (g.C - 1) + (cls - 1)) * g.N + picked] = bi;
-    }
-    ++picked;
-#pragma unroll
-    for (int s = 0; s < kPerThread; ++s) {
-      if (s * NT + tid == bi) { sc[s] = kGone; continue; }
-      if (!(sc[s] > kGone)) continue;
-      const double w = fmax(0.0, fmin(px2, x2[s]) - fmax(px1, x1[s]) + 1);
-      const double h = fmax(0.0, fmin(py2, y2[s]) - fmax(py1, y1[s]) + 1);
-      const double inter = w * h;
-      if (inter > 0.0) {
-        const double ovr = inter / (pa + area[s] - inter);
-        if (g.soft) sc[s] = sc[s] * exp(-(ovr * ovr) / g.nms_param);
-        else if (!(ovr <= g.nms_param)) sc[s] = kGone;
-      }
-    }
-    __syncthreads();                           // s_best / s_box are rewritten in the next iteration
   }
   if (tid == 0) g.counts[(long)b * (g.C - 1) + (cls - 1)] = picked;
 }
@@ -352,35 +300,119 @@ __device__ __forceinline__ unsigned long long dkey(double d) {
 
 constexpr int kTopkKeys = 6144;          // pick keys cached in LDS (48 KB); longer lists are re-read from global memory every pass
 
+// One workgroup per image.  The picks of the image's classes are ONE list of `total` entries (class-major, pick order = the order
+// of the output).  total <= kTopkKeys (always, once relnet_class_nms_topk has pruned the lists): keys and class ids are fetched once
+// into LDS, the max_per_image-th largest key comes from an 8 x 8-bit radix select whose digit is found by one wavefront (suffix sums
+// over the 256 bins, 4 per lane), and the output positions are an exclusive block scan of the keep flags -- five global round trips
+// in all.  (Rounds 1-3 walked the class lists with one thread per class and scanned the bins with one thread: 70-130 us of
+// dependent loads per call, as long as the class NMS itself.)  Longer lists take the general path below it.
 __global__ __launch_bounds__(1024) void image_topk_kernel(ImgTopkArgs g) {
-  __shared__ unsigned int hist[256];
+  __shared__ __attribute__((aligned(16))) unsigned int hist[256];
   __shared__ unsigned long long s_prefix;
   __shared__ int s_remaining, s_total, s_out;
-  __shared__ int s_off[129];                  // exclusive prefix of the class counts (the picks of an image as ONE list of `total` entries)
+  __shared__ int s_off[129];                  // exclusive prefix of the class counts
+  __shared__ int s_wsum[16];
   __shared__ unsigned long long s_keys[kTopkKeys];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ unsigned char s_cls[kTopkKeys];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int* cnt = g.counts + (long)b * g.NC;
   const double* dets = g.dets + (long)b * g.NC * g.N * 5;
+  if (tid < g.NC) s_off[tid + 1] = cnt[tid];
+  __syncthreads();
   if (tid == 0) {
     int t = 0;
-    for (int c = 0; c < g.NC; ++c) { s_off[c] = t; t += cnt[c]; }
-    s_off[g.NC] = t;
+    s_off[0] = 0;
+    for (int c = 1; c <= g.NC; ++c) { t += s_off[c]; s_off[c] = t; }
     s_total = t; s_out = 0;
   }
   __syncthreads();
   const int total = s_total;
-  const bool cached = total <= kTopkKeys;
-  // entry i of the list -> its key (the lists are short once relnet_class_nms_topk has pruned them: the selection below walks
-  // `total` entries per pass, not NC x N slots)
-  auto key_of = [&](int i) {
-    int lo = 0, hi = g.NC;                    // last class whose offset is <= i
+  auto class_of = [&](int i) {                // last class whose offset is <= i
+    int lo = 0, hi = g.NC;
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid; }
-    return dkey(dets[((long)lo * g.N + (i - s_off[lo])) * 5 + 4]);
+    return lo;
   };
-  if (cached) {
-    for (int i = tid; i < total; i += 1024) s_keys[i] = key_of(i);
+  if (total <= kTopkKeys) {
+    for (int i = tid; i < total; i += 1024) {
+      const int c = class_of(i);
+      s_cls[i] = (unsigned char)c;
+      s_keys[i] = dkey(dets[((long)c * g.N + (i - s_off[c])) * 5 + 4]);
+    }
+    if (tid == 0) { s_prefix = 0ull; s_remaining = g.max_per_image; }
     __syncthreads();
+    unsigned long long kth = 0ull;
+    if (total > g.max_per_image) {
+      for (int pass = 7; pass >= 0; --pass) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix;
+        const int shift = pass * 8;
+        for (int i = tid; i < total; i += 1024) {
+          const unsigned long long key = s_keys[i];
+          if (pass == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 0xff], 1u);
+        }
+        __syncthreads();
+        if (wave == 0) {                      // digit = the highest bin d whose count from the top reaches `remaining` (0 if none)
+          const unsigned int rem = (unsigned int)s_remaining;
+          const uint4 h = ((const uint4*)hist)[lane];
+          const unsigned int tot = h.x + h.y + h.z + h.w;
+          unsigned int suf = tot;             // inclusive suffix sum over the lanes: keys in bins >= 4 lane
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) { const unsigned int v = __shfl_down(suf, o); if (lane + o < 64) suf += v; }
+          const unsigned long long m = __ballot(suf >= rem);
+          const int L = m ? 63 - __clzll(m) : 0;
+          if (lane == L) {
+            unsigned int r = rem - (suf - tot);       // still to find inside this lane's four bins
+            int d = 4 * L;
+            if (h.w >= r) d += 3;
+            else { r -= h.w; if (h.z >= r) d += 2; else { r -= h.z; if (h.y >= r) d += 1; else r -= h.y; } }
+            s_remaining = (int)r;
+            s_prefix = prefix | ((unsigned long long)d << shift);
+          }
+        }
+        __syncthreads();
+      }
+      kth = s_prefix;
+    }
+    if (tid == 0) {
+      g.total[b] = total;
+      double th = -INFINITY;
+      if (total > g.max_per_image) {
+        const unsigned long long u = (kth >> 63) ? (kth & 0x7fffffffffffffffull) : ~kth;
+        th = __longlong_as_double((long long)u);
+      }
+      g.thresh[b] = th;
+    }
+    // keep score >= threshold, class-major / pick order (tester.py:273-277): thread t owns entries [t E, (t + 1) E)
+    const int E = (total + 1023) / 1024;
+    const int i0 = tid * E, i1 = min(i0 + E, total);
+    int mine = 0;
+    for (int i = i0; i < i1; ++i) mine += (s_keys[i] >= kth) ? 1 : 0;
+    int inc = mine;                           // inclusive scan: wave, then the 16 wave totals
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    int base = inc - mine;
+    for (int w = 0; w < wave; ++w) base += s_wsum[w];
+    if (tid == 1023) g.out_count[b] = (base + mine) < g.max_out ? (base + mine) : g.max_out;
+    for (int i = i0; i < i1; ++i) {
+      if (s_keys[i] < kth) continue;
+      if (base < g.max_out) {
+        const int c = s_cls[i];
+        const double* d = dets + ((long)c * g.N + (i - s_off[c])) * 5;
+        float* o = g.out + ((long)b * g.max_out + base) * 6;
+        o[0] = (float)(c + 1); o[1] = (float)d[4]; o[2] = (float)d[0]; o[3] = (float)d[1]; o[4] = (float)d[2]; o[5] = (float)d[3];
+      }
+      ++base;
+    }
+    return;
   }
+  // ---- general path: the keys are re-read from global memory in every pass
+  auto key_of = [&](int i) {
+    const int c = class_of(i);
+    return dkey(dets[((long)c * g.N + (i - s_off[c])) * 5 + 4]);
+  };
   unsigned long long kth = 0ull;
   if (total > g.max_per_image) {
     if (tid == 0) { s_prefix = 0ull; s_remaining = g.max_per_image; }
@@ -391,7 +423,7 @@ __global__ __launch_bounds__(1024) void image_topk_kernel(ImgTopkArgs g) {
       const unsigned long long prefix = s_prefix;
       const int shift = pass * 8;
       for (int i = tid; i < total; i += 1024) {
-        const unsigned long long key = cached ? s_keys[i] : key_of(i);
+        const unsigned long long key = key_of(i);
         if (pass == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 0xff], 1u);
       }
       __syncthreads();
@@ -405,7 +437,6 @@ __global__ __launch_bounds__(1024) void image_topk_kernel(ImgTopkArgs g) {
     }
     kth = s_prefix;
   }
-  // keep score >= threshold, class-major / pick order (tester.py:273-277)
   if (tid == 0) {
     g.total[b] = total;
     double th = -INFINITY;
@@ -415,7 +446,8 @@ __global__ __launch_bounds__(1024) void image_topk_kernel(ImgTopkArgs g) {
     }
     g.thresh[b] = th;
   }
-  // per-class kept counts -> offsets (keeps are a prefix of each pick-ordered class list)
+  __syncthreads();                            // (s_off is rewritten below: every class_of() above is done)
+  // per-class kept counts -> offsets
   for (int c = tid; c < g.NC; c += 1024) {
     int kc = 0;
     for (int k = 0; k < cnt[c]; ++k) kc += (dkey(dets[((long)c * g.N + k) * 5 + 4]) >= kth) ? 1 : 0;
@@ -465,6 +497,23 @@ extern "C" int relnet_detect_head(const float* cls_score, long cs_ld, const floa
                                delta_off, nullptr, stream);
 }
 
+// Latency form (one candidate per thread, the smallest workgroup that holds N of them) while the launch leaves the chip mostly
+// empty; throughput form (one wavefront per class, N / 64 candidates per lane: half the instructions per pick, the max / ballot /
+// readlane part is not repeated per wave) from kNmsWideGroups (image, class) pairs up.
+static int g_nms_form = 0;               // tuning knob: 0 auto, 1 latency form, 2 throughput form
+extern "C" void relnet_class_nms_debug_form(int f) { g_nms_form = f; }
+constexpr long kNmsWideGroups = 1536;
+template <bool PRUNE>
+static void launch_class_nms(const ClsNmsArgs& g, int B, hipStream_t s) {
+  dim3 grid(g.C - 1, B);
+  const bool wide = g_nms_form ? g_nms_form == 1 : (long)(g.C - 1) * B < kNmsWideGroups;
+  if (g.N <= 64) class_nms_kernel<1, 1, PRUNE><<<grid, 64, 0, s>>>(g);
+  else if (g.N <= 128) class_nms_kernel<2, 1, PRUNE><<<grid, 128, 0, s>>>(g);
+  else if (g.N <= 320) { if (wide) class_nms_kernel<5, 1, PRUNE><<<grid, 320, 0, s>>>(g); else class_nms_kernel<1, 5, PRUNE><<<grid, 64, 0, s>>>(g); }
+  else if (g.N <= 512) { if (wide) class_nms_kernel<8, 1, PRUNE><<<grid, 512, 0, s>>>(g); else class_nms_kernel<1, 8, PRUNE><<<grid, 64, 0, s>>>(g); }
+  else { if (wide) class_nms_kernel<16, 1, PRUNE><<<grid, 1024, 0, s>>>(g); else class_nms_kernel<4, 4, PRUNE><<<grid, 256, 0, s>>>(g); }
+}
+
 extern "C" int relnet_class_nms_ex(const float* cls_prob, const double* scores64, const double* boxes, double* dets,
                                    int* counts, int* pick_index, int B, int N, int C, float score_thresh,
                                    double nms_param, int soft, int max_picks, void* stream) {
@@ -473,11 +522,7 @@ extern "C" int relnet_class_nms_ex(const float* cls_prob, const double* scores64
   RELNET_REQUIRE(!scores64 || C == 2, "relnet_class_nms: float64 scores are one foreground class (C == 2), got C=%d", C);
   ClsNmsArgs g{cls_prob, boxes, dets, counts, N, C, score_thresh, nms_param, soft, max_picks > 0 ? max_picks : N,
                scores64, pick_index, nullptr, 0};
-  dim3 grid(C - 1, B);
-  hipStream_t s = (hipStream_t)stream;
-  if (N <= 320) class_nms_kernel<5><<<grid, 64, 0, s>>>(g);
-  else if (N <= 512) class_nms_kernel<8><<<grid, 64, 0, s>>>(g);
-  else class_nms_block_kernel<4><<<grid, 256, 0, s>>>(g);
+  launch_class_nms<false>(g, B, (hipStream_t)stream);
   return check_launch("relnet_class_nms");
 }
 
@@ -490,17 +535,15 @@ extern "C" int relnet_class_nms(const float* cls_prob, const double* boxes, doub
 
 // relnet_class_nms with image-level pruning (see kHistBins above): dets / counts as relnet_class_nms, but a class list stops as
 // soon as its next pick cannot be among the top_k scores of its image.  `hist`: B x relnet_class_nms_hist_bins() unsigned ints (coarse + fine),
-// ZEROED by the caller before every call.  N <= 512.
+// ZEROED by the caller before every call.  N <= 1024.
 extern "C" int relnet_class_nms_hist_bins(void) { return kHistWords; }
 extern "C" int relnet_class_nms_topk(const float* cls_prob, const double* boxes, double* dets, int* counts, void* hist, int B, int N,
                                      int C, float score_thresh, double nms_param, int soft, int max_picks, int top_k, void* stream) {
   RELNET_REQUIRE(cls_prob && boxes && dets && counts && hist, "relnet_class_nms_topk: null operand");
-  RELNET_REQUIRE(B > 0 && N > 0 && N <= 512 && C > 1 && top_k > 0, "relnet_class_nms_topk: need 0 < N <= 512, top_k > 0 (N=%d top_k=%d)", N, top_k);
+  RELNET_REQUIRE(B > 0 && N > 0 && N <= 1024 && C > 1 && top_k > 0, "relnet_class_nms_topk: need 0 < N <= 1024, top_k > 0 (N=%d top_k=%d)", N, top_k);
   ClsNmsArgs g{cls_prob, boxes, dets, counts, N, C, score_thresh, nms_param, soft, max_picks > 0 ? max_picks : N, nullptr, nullptr,
                (unsigned int*)hist, top_k};
-  dim3 grid(C - 1, B);
-  if (N <= 320) class_nms_kernel<5, true><<<grid, 64, 0, (hipStream_t)stream>>>(g);
-  else class_nms_kernel<8, true><<<grid, 64, 0, (hipStream_t)stream>>>(g);
+  launch_class_nms<true>(g, B, (hipStream_t)stream);
   return check_launch("relnet_class_nms_topk");
 }
 

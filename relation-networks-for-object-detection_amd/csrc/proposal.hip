@@ -86,63 +86,99 @@ struct TopkArgs {
   int n, K;
 };
 
+// One workgroup per image; thread t keeps the score keys of anchors t, t + 1024, ... (PER of them: n <= 1024 PER) in REGISTERS for
+// the whole kernel -- the scores are read from memory once, in one batch of independent loads (rounds 1-3 re-read them in each
+// of the seven passes, one dependent L2 round trip per element: 240-440 us per call, all latency).
+//   radix select   the K-th largest 48-bit composite key in six 8-bit passes.  Histogram updates are aggregated per wavefront for the
+//                  digit of its first matching lane (objectness scores share their top bits: a plain LDS atomic would serialise
+//                  64 ways), the rest go in as plain atomics; the digit is found by one wavefront (suffix sums over 4 bins per lane);
+//   compaction     one LDS counter update per wavefront (ballot + prefix popcount);
+//   bitonic sort   all threads busy in every stage (thread = pair index, not element index).
+template <int PER>
 __global__ __launch_bounds__(kSortThreads) void topk_sort_kernel(TopkArgs g) {
   __shared__ unsigned long long keys[kSortCap];
-  __shared__ unsigned int hist[256];
+  __shared__ __attribute__((aligned(16))) unsigned int hist[256];
   __shared__ unsigned long long s_prefix;
-  __shared__ int s_remaining, s_count;
-  const int tid = threadIdx.x, b = blockIdx.x;
+  __shared__ int s_remaining, s_count, s_valid;
+  const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* sc = g.scores + (long)b * g.n;
   const int K = g.K < g.n ? g.K : g.n;
-  // ---- radix select: find the K-th largest 48-bit composite key --------------------
-  if (tid == 0) { s_prefix = 0ull; s_remaining = K; }
+  unsigned int fk[PER];
+#pragma unroll
+  for (int s = 0; s < PER; ++s) {
+    const int i = s * kSortThreads + tid;
+    fk[s] = i < g.n ? fkey(sc[i]) : 0u;
+  }
+  // ---- radix select: find the K-th largest composite key (fkey << 16 | index) --------------------
+  if (tid == 0) { s_prefix = 0ull; s_remaining = K; s_count = 0; s_valid = 0; }
+  for (int i = tid; i < kSortCap; i += kSortThreads) keys[i] = 0ull;
   __syncthreads();
   for (int pass = 5; pass >= 0; --pass) {
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
     const unsigned long long prefix = s_prefix;
     const int shift = pass * 8;
-    for (int i = tid; i < g.n; i += kSortThreads) {
-      const unsigned long long ck = ((unsigned long long)fkey(sc[i]) << 16) | (unsigned int)i;
-      if (pass == 5 || (ck >> (shift + 8)) == (prefix >> (shift + 8)))
-        atomicAdd(&hist[(ck >> shift) & 0xff], 1u);
+#pragma unroll
+    for (int s = 0; s < PER; ++s) {
+      const int i = s * kSortThreads + tid;
+      const unsigned long long ck = ((unsigned long long)fk[s] << 16) | (unsigned int)i;
+      const bool match = i < g.n && (pass == 5 || (ck >> (shift + 8)) == (prefix >> (shift + 8)));
+      const int d = (int)((ck >> shift) & 0xff);
+      const unsigned long long mm = __ballot(match);
+      if (mm) {
+        const int lead = __builtin_ctzll(mm);
+        const int dl = __builtin_amdgcn_readlane(d, lead);
+        const unsigned long long peers = __ballot(match && d == dl);
+        if (lane == lead) atomicAdd(&hist[dl], (unsigned int)__popcll(peers));
+        else if (match && d != dl) atomicAdd(&hist[d], 1u);
+      }
     }
     __syncthreads();
-    if (tid == 0) {
-      int rem = s_remaining, d = 255;
-      for (; d > 0; --d) {
-        if ((int)hist[d] >= rem) break;
-        rem -= hist[d];
+    if (wave == 0) {                      // digit = the highest bin whose count from the top reaches `remaining` (0 if none)
+      const unsigned int rem = (unsigned int)s_remaining;
+      const uint4 h = ((const uint4*)hist)[lane];
+      const unsigned int tot = h.x + h.y + h.z + h.w;
+      unsigned int suf = tot;             // inclusive suffix sum over the lanes: keys in bins >= 4 lane
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const unsigned int v = __shfl_down(suf, o); if (lane + o < 64) suf += v; }
+      const unsigned long long m = __ballot(suf >= rem);
+      const int L = m ? 63 - __clzll(m) : 0;
+      if (lane == L) {
+        unsigned int r = rem - (suf - tot);
+        int d = 4 * L;
+        if (h.w >= r) d += 3;
+        else { r -= h.w; if (h.z >= r) d += 2; else { r -= h.z; if (h.y >= r) d += 1; else r -= h.y; } }
+        s_remaining = (int)r;
+        s_prefix = prefix | ((unsigned long long)d << shift);
       }
-      s_remaining = rem;
-      s_prefix = prefix | ((unsigned long long)d << shift);
     }
     __syncthreads();
   }
   const unsigned long long kth = s_prefix;      // exactly K composite keys are >= kth
-  if (tid == 0) s_count = 0;
-  for (int i = tid; i < kSortCap; i += kSortThreads) keys[i] = 0ull;
-  __syncthreads();
-  for (int i = tid; i < g.n; i += kSortThreads) {
-    const unsigned long long ck = ((unsigned long long)fkey(sc[i]) << 16) | (unsigned int)i;
-    if (ck >= kth) {
-      const int slot = atomicAdd(&s_count, 1);
-      keys[slot] = ck;
+#pragma unroll
+  for (int s = 0; s < PER; ++s) {
+    const int i = s * kSortThreads + tid;
+    const unsigned long long ck = ((unsigned long long)fk[s] << 16) | (unsigned int)i;
+    const bool take = i < g.n && ck >= kth;
+    const unsigned long long mm = __ballot(take);
+    if (mm) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_count, __popcll(mm));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (take) keys[base + __popcll(mm & ((1ull << lane) - 1ull))] = ck;
     }
   }
   __syncthreads();
-  // ---- bitonic sort, descending, over the next power of two >= K ---------------------
+  // ---- bitonic sort, descending, over the next power of two >= K: thread = pair (i, i | j) ---------------------
   int np2 = 1;
   while (np2 < K) np2 <<= 1;
   for (int k = 2; k <= np2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < np2; i += kSortThreads) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long a = keys[i], c = keys[ixj];
-          const bool desc = (i & k) == 0;
-          if (desc ? (a < c) : (a > c)) { keys[i] = c; keys[ixj] = a; }
-        }
+      for (int p = tid; p < (np2 >> 1); p += kSortThreads) {
+        const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), ixj = i | j;
+        const unsigned long long a = keys[i], c = keys[ixj];
+        const bool desc = (i & k) == 0;
+        if (desc ? (a < c) : (a > c)) { keys[i] = c; keys[ixj] = a; }
       }
       __syncthreads();
     }
@@ -160,10 +196,9 @@ __global__ __launch_bounds__(kSortThreads) void topk_sort_kernel(TopkArgs g) {
     valid += (s > -INFINITY) ? 1 : 0;
   }
   // count of finite-score entries (filtered boxes carry -inf and sort last)
-  __shared__ int s_valid;
-  if (tid == 0) s_valid = 0;
-  __syncthreads();
-  atomicAdd(&s_valid, valid);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) valid += __shfl_xor(valid, o);
+  if (lane == 0 && valid) atomicAdd(&s_valid, valid);
   __syncthreads();
   if (tid == 0) g.out_count[b] = s_valid;
 }
@@ -343,13 +378,20 @@ __global__ __launch_bounds__(64 * kGreedyWaves) void nms_greedy_kernel(GreedyArg
   if (tid == 0) s_total = 0;
   __syncthreads();
   const int nblk = (n + 63) / 64;
+  float cn[4] = {0.f, 0.f, 0.f, 0.f};                  // the NEXT block's boxes: requested one block ahead of their use
+  if (lane < n) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cn[k] = bx[(long)lane * 5 + k];
+  }
   for (int blk = 0; blk < nblk; ++blk) {
     const int i = blk * 64 + lane;
     const int bsize = min(n - blk * 64, 64);
-    float c[4] = {0.f, 0.f, 0.f, 0.f};
-    if (i < n) {
+    float c[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) c[k] = bx[(long)i * 5 + k];
+    for (int k = 0; k < 4; ++k) { c[k] = cn[k]; cn[k] = 0.f; }
+    if (i + 64 < n) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cn[k] = bx[(long)(i + 64) * 5 + k];
     }
     const int total = s_total;
     if (tid < 64) s_diag[tid] = 0ull;
@@ -380,13 +422,18 @@ __global__ __launch_bounds__(64 * kGreedyWaves) void nms_greedy_kernel(GreedyArg
       alive = ~alive;
       if (bsize < 64) alive &= (1ull << bsize) - 1ull;
       const unsigned long long diag = s_diag[lane];
-      unsigned long long cur = alive, km = 0ull;
-      int tot = total;
+      const int dlo = (int)(unsigned int)diag, dhi = (int)(unsigned int)(diag >> 32);
+      // the walk over the block is wave-uniform: kept on the scalar unit (row t0 of the in-block matrix through v_readlane)
+      unsigned long long cur = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(alive >> 32)) << 32) |
+                               (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)alive);
+      unsigned long long km = 0ull;
+      int tot = __builtin_amdgcn_readfirstlane(total);
       while (cur != 0ull && tot < g.post) {
         const int t0 = __builtin_ctzll(cur);
         km |= 1ull << t0;
         ++tot;
-        const unsigned long long d0 = __shfl(diag, t0);
+        const unsigned long long d0 = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(dhi, t0) << 32) |
+                                      (unsigned int)__builtin_amdgcn_readlane(dlo, t0);
         cur &= ~d0;
         cur &= ~(1ull << t0);
       }
@@ -445,7 +492,8 @@ extern "C" int relnet_topk_sort(const float* scores, const float* boxes, float* 
   RELNET_REQUIRE(scores && boxes && out_boxes5 && out_index && out_count, "relnet_topk_sort: null operand");
   RELNET_REQUIRE(B > 0 && n > 0 && n < 65536 && K > 0 && K <= kSortCap, "relnet_topk_sort: need 0 < n < 65536 and 0 < K <= %d (n=%d K=%d)", kSortCap, n, K);
   TopkArgs g{scores, boxes, out_boxes5, out_index, out_count, n, K};
-  topk_sort_kernel<<<B, kSortThreads, 0, (hipStream_t)stream>>>(g);
+  if (n <= 32 * kSortThreads) topk_sort_kernel<32><<<B, kSortThreads, 0, (hipStream_t)stream>>>(g);
+  else topk_sort_kernel<64><<<B, kSortThreads, 0, (hipStream_t)stream>>>(g);
   return check_launch("relnet_topk_sort");
 }
 

@@ -321,7 +321,7 @@ def class_nms(cls_prob, boxes, score_thresh=1e-3, nms_param=0.6, soft=True, max_
     dets = torch.zeros((B, Cn - 1, N, 5), device=boxes.device, dtype=torch.float64)
     counts = torch.empty((B, Cn - 1), device=boxes.device, dtype=torch.int32)
     index = torch.full((B, Cn - 1, N), -1, device=boxes.device, dtype=torch.int32) if want_index else None
-    if top_k > 0 and scores64 is None and not want_index and N <= 512:
+    if top_k > 0 and scores64 is None and not want_index and N <= 1024:
         hist = torch.zeros((B, _lib.load().relnet_class_nms_hist_bins()), device=boxes.device, dtype=torch.int32)
         _lib.call('relnet_class_nms_topk', cls_prob.data_ptr(), boxes.data_ptr(), dets.data_ptr(), counts.data_ptr(), hist.data_ptr(),
                   B, N, Cn, float(score_thresh), float(nms_param), int(soft), int(max_picks), int(top_k), _stream())
