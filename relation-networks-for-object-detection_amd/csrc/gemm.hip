@@ -136,7 +136,7 @@ __device__ __forceinline__ void glds16_asm(const void* src, unsigned lds_byte_ad
 
 // BM x BN workgroup tile, WM x WN waves (each wave: TM x TN MFMA tiles of 32x32), BK = 64,
 // two LDS stages filled by global_load_lds.
-template <int BM, int BN, int WM, int WN, typename TOUT, int MODE>
+template <int BM, int BN, int WM, int WN, typename TOUT, int MODE, int KU = 1>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) {
   constexpr bool CONV = MODE == 1;       // NHWC implicit GEMM, Cin % 64 == 0
   constexpr bool STEM = MODE == 2;       // 7x7/2 stem on a zero-padded NHWC4 image (see relnet_stem_conv7)
@@ -145,10 +145,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
   constexpr int A_GROUPS = BM / (8 * NW), B_GROUPS = BN / (8 * NW);   // 8-row (1 KiB) groups per wave
   static_assert(TM >= 1 && TN >= 1 && A_GROUPS >= 1 && B_GROUPS >= 1, "tile too small for the wave grid");
-  constexpr int STAGE = (BM + BN) * BK * 2;            // bytes per pipeline stage
+  constexpr int STAGE = (BM + BN) * BK * 2;            // bytes of one k-slab; a pipeline stage holds KU of them
   constexpr int CLD = BN + 4;                          // padded fp32 row of the epilogue band
   constexpr int BAND = 32 * WM;                        // rows written per epilogue pass
-  constexpr int LDS_BYTES = (2 * STAGE > BAND * CLD * 4) ? 2 * STAGE : BAND * CLD * 4;
+  constexpr int LDS_BYTES = (2 * KU * STAGE > BAND * CLD * 4) ? 2 * KU * STAGE : BAND * CLD * 4;
   // ONE shared array (a second __shared__ object makes hipcc drain vmcnt before every ds_read)
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
 
@@ -215,7 +215,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
     const int gr = n0 + (wave * B_GROUPS + j) * 8 + lrow;
     brow[j] = (gr < g.N) ? W + (long)gr * g.ldw + lchunk * 8 : nullptr;
   }
-  auto stage = [&](int kt, int buf) {
+  auto stage = [&](int kt, int slot) {                  // k-slab kt into slab slot `slot` (= stage * KU + position in the stage)
+    const int buf = slot;
     const int k0 = kt * BK;
     int tr = 0, ts = 0, ic0 = k0;
     if constexpr (CONV) {
@@ -282,13 +283,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
       }
   }
 
+  // KU k-slabs per barrier: with less than one workgroup per CU (the 1-image step) a k-step costs one L2 round trip whatever it
+  // carries, so two slabs per step halve the k-loop (res4 3x3 at 2 394 pixels: 36 round trips -> 18)
   const int nk = g.K / BK;
-  stage(0, 0);
+#pragma unroll
+  for (int h = 0; h < KU; ++h)
+    if (h < nk) stage(h, h);
   __syncthreads();                                   // (drains the LDS-direct loads: vmcnt(0))
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) stage(kt + 1, buf ^ 1);         // async: lands while this tile is multiplied
-    const unsigned char* la = lds + buf * STAGE;
+  for (int kt0 = 0; kt0 < nk; kt0 += KU) {
+    const int sb = (kt0 / KU) & 1;
+#pragma unroll
+    for (int h = 0; h < KU; ++h)
+      if (kt0 + KU + h < nk) stage(kt0 + KU + h, (sb ^ 1) * KU + h);      // async: lands while this stage is multiplied
+#pragma unroll
+    for (int h = 0; h < KU; ++h) {
+    if (KU > 1 && kt0 + h >= nk) break;
+    const unsigned char* la = lds + (sb * KU + h) * STAGE;
     const unsigned char* lb = la + BM * BK * 2;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -309,6 +319,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // D = W x A: lane <-> output row
+    }
     }
     __syncthreads();
   }
@@ -1921,7 +1932,7 @@ extern "C" void relnet_gemm_debug_korder(int on) { g_korder = on; }
 static int g_asm = 1;            // tuning knob: 0 = pick_tile never chooses tiles 18 / 19 (hand-scheduled k-loops)
 extern "C" void relnet_gemm_debug_asm(int on) { g_asm = on; }
 
-template <int BM, int BN, int WM, int WN, int CONV>
+template <int BM, int BN, int WM, int WN, int CONV, int KU = 1>
 static void launch_cfg(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
   const int ntile = (g.N + BN - 1) / BN;
   int nloop = g_force_nloop > 0 ? g_force_nloop : g.n_loop;
@@ -1935,8 +1946,8 @@ static void launch_cfg(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
   g.n_loop = nloop;
   dim3 grid((ntile + nloop - 1) / nloop, (g.M + BM - 1) / BM, batch);
   g.xcd_swizzle = (swz && grid.x > 1) ? 1 : 0;
-  if (out_dtype == RELNET_BF16) gemm_nt_bf16_kernel<BM, BN, WM, WN, unsigned short, CONV><<<grid, 64 * WM * WN, 0, s>>>(g);
-  else gemm_nt_bf16_kernel<BM, BN, WM, WN, float, CONV><<<grid, 64 * WM * WN, 0, s>>>(g);
+  if (out_dtype == RELNET_BF16) gemm_nt_bf16_kernel<BM, BN, WM, WN, unsigned short, CONV, KU><<<grid, 64 * WM * WN, 0, s>>>(g);
+  else gemm_nt_bf16_kernel<BM, BN, WM, WN, float, CONV, KU><<<grid, 64 * WM * WN, 0, s>>>(g);
 }
 
 template <int BM, int BN, int WM, int WN, int CONV, int BK, int NSTAGE, int SCHED = 0, int EPI = 0>
@@ -2017,7 +2028,9 @@ static void launch_ring(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
 //                                        the nine taps (other shapes under 17 run configuration 8)
 //                                   18 = 8 with the hand-scheduled (inline asm) k-loop on shortcut-free layers whose N is a multiple of 256
 //                                   19 = 18 with the asymmetric ring (activations three slots / two slabs ahead, filters two slots)
-enum { GEMM_TILE_COUNT = 19 };
+//                                   20 = 5 with two k-slabs per barrier (launches of less than one workgroup per CU: the 1-image step)
+//                                   21 = 5 with four
+enum { GEMM_TILE_COUNT = 21 };
 
 template <int CONV>
 static bool launch_panel(const GemmArgs& g0, int batch, int out_dtype, hipStream_t s, bool use_wf = false, bool occ2 = false) {
@@ -2115,6 +2128,10 @@ static int pick_tile(long M, long N, long K, int batch, int out_dtype, int has_r
   else if (cfg == 2 && wgs(256, 128) < 128) cfg = small;
   else if (cfg == 3 && wgs(128, 128) < 200) cfg = small;
   else if (cfg == 4 && N > 64 && wgs(128, 64) < 200) cfg = 5;
+  // less than one 64 x 64 workgroup per CU: every k-step is an exposed round trip -> two (tile 20) / four (tile 21, K >= 2048) slabs per
+  // step.  r04, same box, one image per step: 2.38-2.40 -> 2.11-2.17 ms (tile 20) -> 2.08-2.12 ms; with more workgroups than CUs
+  // (two images: 300) it loses 1-3 %
+  if (cfg == 5 && wgs(64, 64) <= 256 && K >= 256) cfg = K >= 2048 ? 21 : 20;
   return cfg;
 }
 extern "C" int relnet_gemm_tile_count(void) { return GEMM_TILE_COUNT; }
@@ -2130,6 +2147,14 @@ static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t
     case 3: launch_cfg<128, 128, 2, 2, CONV>(g, batch, out_dtype, s); break;
     case 4: launch_cfg<128, 64, 2, 2, CONV>(g, batch, out_dtype, s); break;
     case 5: launch_cfg<64, 64, 2, 2, CONV>(g, batch, out_dtype, s); break;
+    case 20:
+      if constexpr (CONV == 2) launch_cfg<64, 64, 2, 2, CONV>(g, batch, out_dtype, s);
+      else launch_cfg<64, 64, 2, 2, CONV, 2>(g, batch, out_dtype, s);
+      break;
+    case 21:
+      if constexpr (CONV == 2) launch_cfg<64, 64, 2, 2, CONV>(g, batch, out_dtype, s);
+      else launch_cfg<64, 64, 2, 2, CONV, 4>(g, batch, out_dtype, s);
+      break;
     case 6:
       if constexpr (CONV == 2) launch_cfg<256, 256, 2, 4, CONV>(g, batch, out_dtype, s);      // stem slabs are 64 deep
       else launch_ring<256, 256, 2, 4, CONV, 32, 4>(g, batch, out_dtype, s);
