@@ -84,6 +84,9 @@ void relnet_gemm_force_nloop(int n);      /* tuning knob: 0 = auto, n = column t
 void relnet_gemm_set_swizzle(int on);     /* tuning knob: XCD-aware tile order (default 1)               */
 void relnet_gemm_debug_korder(int on);    /* tuning knob: (channel chunk, tap) k order of the spatial ring convolutions (default 1) */
 void relnet_gemm_debug_asm(int on);       /* tuning knob: 0 = the automatic tile choice never takes tiles 18 / 19 (hand-scheduled k-loops); default 1 */
+void relnet_gemm_debug_phase_ts(void* buf); /* measurement knob: the ring kernels (tiles 6 - 12, 16 - 19) write, per workgroup, 8 int64 words into buf --
+                                             * wall clock (100 MHz) at entry / k-loop start / k-loop end / exit, [4] = shader cycles entry -> k-loop end;
+                                             * NULL (default) = off.  tools/tile_phase_probe.py */
 void relnet_gemm_debug_ablate(int a);     /* measurement knob for tile 8: 1 = fill path only, 2 = LDS + MFMA only (garbage results) */
 int relnet_gemm_tile_count(void);         /* number of tile configurations (valid relnet_gemm_force_tile values 1..count) */
 int relnet_gemm_pick_tile(int M, int N, int K, int batch, int out_dtype);   /* the configuration `auto` selects */

@@ -174,8 +174,10 @@ class Backbone(object):
         # unit u and reduce + ReLU of unit u+1 as one pixel-wise kernel (ops.bottleneck_chain); unit -> its operands
         self.chain, self.halo3, self.chain_proj = {}, {}, {}
         if self.impl == 'hip' and chain:
+            # (A/B knob: RELNET_CHAIN_REDUCE256=0 keeps res4's reduce layers as their own launches, the round-3 form)
+            reduce_mids = tuple(m for m in ops.CHAIN_MIDS if m != 256 or os.environ.get('RELNET_CHAIN_REDUCE256', '1') != '0')
             for (st, nm, ic, mc, oc, stride, dil, proj), nxt in zip(self.units, self.units[1:] + [None]):
-                if nxt is not None and nxt[0] == st and not nxt[7] and mc in ops.CHAIN_MIDS:
+                if nxt is not None and nxt[0] == st and not nxt[7] and mc in reduce_mids:
                     w3, b3, _ = self.wp['res%s_branch2c' % nm]
                     w1n, b1n, _ = self.wp['res%s_branch2a' % nxt[1]]
                     self.chain[nm] = (ops.pack_w_frag(w3), ops.pack_chain_w1(w1n), b3, b1n)

@@ -53,6 +53,10 @@ struct ChainArgs {
 // Nothing on the vector-memory path is issued inside the arithmetic (biases come from LDS): a load there would make the
 // compiler wait for the prefetch in front of it.
 // KSPLIT > 1 (MID = 512, res5; expand-only): the k range of a pass is cut in KSPLIT sub-steps so that a ring slot stays 32 KiB.
+// MID = 256 with the second product (res4, r04): a pass's weights would be 32 KiB of W3 + 32 KiB of W1' per ring slot; the pass is cut in
+// two CHANNEL halves instead (step = 32 output channels of the expand product and the 32 matching contraction values of the reduce
+// product: 16 + 16 KiB per slot), the shortcut slice and the store of the finished slice stay per pass.  mid1' accumulates in 128
+// registers per wavefront over the 32 steps of a tile.
 // (measured and dropped, r04: the res4 expand form as TWO 4-wave workgroups per CU -- 16 KB filter slots, the two groups out of step so
 //  that one group's per-pass vmcnt(0) drain overlaps the other's arithmetic -- bit-identical and slower, 163 vs 150 us at 54 images:
 //  the filter stream through L2 -> LDS doubles)
@@ -65,7 +69,9 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
   static_assert(!PROJ || (!STREAM && KSPLIT == 1), "the projection form exists for the resident-weight kernel");
   static_assert(KSPLIT == 1 || (STREAM && !REDUCE), "k-split passes exist for the streamed expand-only form");
   constexpr int COUT = 4 * MID, KS = MID / 16, KSS = KS / KSPLIT, RT = MID / 32, NP = COUT / 64;
-  constexpr int W3P = 2 * KSS * 1024, W1P = REDUCE ? 4 * RT * 1024 : 0;     // bytes of one (sub-)step's W3 / W1' slice
+  constexpr int CS = (REDUCE && MID == 256) ? 2 : 1;                          // channel-split steps per pass (see above)
+  static_assert(CS == 1 || (STREAM && KSPLIT == 1 && !PROJ), "channel-split steps exist for the streamed two-product form");
+  constexpr int W3P = 2 * KSS * 1024 / CS, W1P = REDUCE ? 4 * RT * 1024 / CS : 0;     // bytes of one (sub-)step's W3 / W1' slice
   constexpr int WPP = PROJ ? W3P : 0;                                         // ... and of its Wp slice
   constexpr int PASSB = W3P + WPP + W1P;
   constexpr int STG = PROJ ? 4096 : 8192;                                     // stage bytes per wave
@@ -99,13 +105,27 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = 8 * i + drow;
-      const unsigned short* src = a.x + (long)min(p0 + row, a.P - 1) * COUT + p * 64 + ((dslot ^ ((row >> 1) & 7)) << 3);
-      __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(sb + i * 1024), 16, 0, 0);
+      // (32-bit byte offsets from the tensor base -- the host checks P * COUT * 2 < 2^32: half the address registers per row)
+      const unsigned off = ((unsigned)min(p0 + row, a.P - 1) * COUT + p * 64 + ((dslot ^ ((row >> 1) & 7)) << 3)) * 2u;
+      __builtin_amdgcn_global_load_lds((gas_ptr)((const unsigned char*)a.x + off), (las_ptr)(sb + i * 1024), 16, 0, 0);
     }
   };
   // (STREAM) this wave's share of the weights of step st = pass * KSPLIT + k-part into ring slot st & 1
   auto issue_w = [&](int st) {
-    if constexpr (STREAM) {
+    if constexpr (CS == 2) {           // step (pass p, half ct): 32 rows of W3 (KS fragments) + the 32 matching k-values of W1' (2 k-steps x RT row tiles)
+      const int p = st >> 1, ct = st & 1;
+      unsigned char* wb = smem + (st & 1) * PASSB;
+#pragma unroll
+      for (int i = 0; i < (KS + 2 * RT) / 8; ++i) {
+        const int q = wave + 8 * i;
+        if (q < KS) {
+          __builtin_amdgcn_global_load_lds((gas_ptr)((const unsigned char*)a.w3f + ((unsigned)(((p * 2 + ct) * KS + q) * 1024) + lane * 16u)), (las_ptr)(wb + q * 1024), 16, 0, 0);
+        } else {
+          const int q1 = q - KS, rt = q1 >> 1, j = q1 & 1;
+          __builtin_amdgcn_global_load_lds((gas_ptr)((const unsigned char*)a.w1f + ((unsigned)((rt * (COUT / 16) + p * 4 + ct * 2 + j) * 1024) + lane * 16u)), (las_ptr)(wb + W3P + q1 * 1024), 16, 0, 0);
+        }
+      }
+    } else if constexpr (STREAM) {
       const int p = st / KSPLIT, kh = st % KSPLIT;
       unsigned char* wb = smem + (st & 1) * PASSB;
 #pragma unroll
@@ -128,7 +148,7 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     auto put = [&](int i, const uint4& v) {
       const int row = 8 * i + drow;
-      if (p0 + row < a.P) *(uint4*)(a.xn + (long)(p0 + row) * COUT + p * 64 + ((dslot ^ ((row >> 1) & 7)) << 3)) = v;
+      if (p0 + row < a.P) *(uint4*)((unsigned char*)a.xn + ((unsigned)(p0 + row) * COUT + p * 64 + ((dslot ^ ((row >> 1) & 7)) << 3)) * 2u) = v;
     };
     put(0, v0); put(1, v1); put(2, v2); put(3, v3);
   };
@@ -159,6 +179,54 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
       for (int r = 0; r < 16; ++r) m1acc[rt][r] = 0.f;
 #pragma unroll 1
     for (int p = 0; p < NP; ++p) {
+      if constexpr (CS == 2) {
+        // two steps per pass: channels [64 p, +32) and [64 p + 32, +32) of x_next, each with its own weight slices; the shortcut slice /
+        // the store of the previous slice stay per PASS (128-byte rows), issued with the first step
+        unsigned char* sb = stage + (p & 1) * 4096;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const int st = 2 * p + ct;
+          asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+          if (ct == 0) {
+            if (p > 0) flush(p0, p - 1);
+            if (p + 1 < NP) issue_x(p0, p + 1);
+            else if (it + 1 < n_iter) issue_x(p0 + t_step * 32, 0);
+          }
+          if (st + 1 < 2 * NP) issue_w(st + 1);
+          else if (it + 1 < n_iter) issue_w(0);
+          const uint4* w3 = (const uint4*)(smem + (st & 1) * PASSB);
+          const uint4* w1 = (const uint4*)((const unsigned char*)w3 + W3P);
+          f32x16 ac;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ac[r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+            ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&w3[ks * 64 + lane], m2f[ks], ac, 0, 0, 0);
+          uint2 pk[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            uint2* sp = (uint2*)(sb + l31 * 128 + (((ct * 4 + g) ^ ((l31 >> 1) & 7)) << 4) + 8 * half);
+            const uint2 xv = *sp;
+            const float4 bv = *(const float4*)(sB3 + p * 64 + ct * 32 + 8 * g + 4 * half);
+            const float v0 = fmaxf(ac[4 * g + 0] + bv.x + bf2f(xv.x & 0xffff), 0.f), v1 = fmaxf(ac[4 * g + 1] + bv.y + bf2f(xv.x >> 16), 0.f);
+            const float v2 = fmaxf(ac[4 * g + 2] + bv.z + bf2f(xv.y & 0xffff), 0.f), v3 = fmaxf(ac[4 * g + 3] + bv.w + bf2f(xv.y >> 16), 0.f);
+            pk[g] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            *sp = pk[g];
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            bf16x8 xf;
+            *(uint2*)&xf = pk[2 * j];
+            *((uint2*)&xf + 1) = pk[2 * j + 1];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+              m1acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&w1[(rt * 2 + j) * 64 + lane], xf, m1acc[rt], 0, 0, 0);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slice is complete in LDS (same-wave readers only)
+        __builtin_amdgcn_wave_barrier();
+        continue;
+      }
       f32x16 acc[2];
 #pragma unroll
       for (int kh = 0; kh < KSPLIT; ++kh) {
@@ -264,8 +332,8 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
                                        const float* b1, void* x_next, void* mid1_next, long P, int mid, void* stream) {
   RELNET_REQUIRE(mid2 && x && w3f && b3 && x_next, "relnet_bottleneck_chain: null operand");
   RELNET_REQUIRE((w1f && b1 && mid1_next) || (!w1f && !b1 && !mid1_next), "relnet_bottleneck_chain: w1f, b1 and mid1_next are given together (or all NULL: expand + shortcut + ReLU only)");
-  RELNET_REQUIRE(mid == 64 || mid == 128 || ((mid == 256 || mid == 512) && !mid1_next), "relnet_bottleneck_chain: mid = %d unsupported (64, 128; 256 / 512 without the reduce product)", mid);
-  RELNET_REQUIRE(P > 0 && P < (1L << 31), "relnet_bottleneck_chain: bad pixel count %ld", P);
+  RELNET_REQUIRE(mid == 64 || mid == 128 || mid == 256 || (mid == 512 && !mid1_next), "relnet_bottleneck_chain: mid = %d unsupported (64, 128, 256; 512 without the reduce product)", mid);
+  RELNET_REQUIRE(P > 0 && P * 8 * mid < (1L << 32), "relnet_bottleneck_chain: bad pixel count %ld (the 4 mid-channel map must stay below 4 GiB)", P);
   ChainArgs a;
   a.m2 = (const unsigned short*)mid2; a.x = (const unsigned short*)x; a.w3f = (const uint4*)w3f; a.w1f = (const uint4*)w1f;
   a.b3 = b3; a.b1 = b1; a.xn = (unsigned short*)x_next; a.m1 = (unsigned short*)mid1_next; a.P = (int)P;
@@ -278,13 +346,15 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<128, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<256, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<512, true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)bottleneck_chain_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const long ntile = (P + 31) / 32;
   const unsigned grid = (unsigned)(ntile < 8 * 256 ? (ntile + 7) / 8 : 256);     // persistent: one workgroup per CU
   const size_t lds = 65536 /* weights: resident (mid 64) or two ring slots (mid 128) */ + 65536 /* 8 x 2 stage buffers */ + (size_t)5 * mid * 4;
   if (mid1_next) {
     if (mid == 64) bottleneck_chain_kernel<64, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);
-    else bottleneck_chain_kernel<128, true><<<grid, 512, lds, (hipStream_t)stream>>>(a);
+    else if (mid == 128) bottleneck_chain_kernel<128, true><<<grid, 512, lds, (hipStream_t)stream>>>(a);
+    else bottleneck_chain_kernel<256, true><<<grid, 512, lds, (hipStream_t)stream>>>(a);
   } else {
     if (mid == 64) bottleneck_chain_kernel<64, false, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);
     else if (mid == 128) bottleneck_chain_kernel<128, true, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);

@@ -31,6 +31,8 @@ struct GemmArgs {
   int n_loop;              // column tiles walked by one workgroup (row-panel mode), >= 1
   int xcd_swizzle;         // 1: remap the linear workgroup id so that every XCD owns a contiguous run of tiles
   const void* Wf;          // optional: W pre-packed in MFMA fragment order (relnet_pack_w_frag), used by gemm_panelw_kernel
+  long long* phase_ts;     // debug (relnet_gemm_debug_phase_ts): per workgroup 8 words -- wall clock (100 MHz) at entry, k-loop start, k-loop end,
+                           // exit, and the shader cycles entry -> k-loop end; nullptr = off
   int korder;              // ring kernels, R*S > 1: 1 = walk k as (channel chunk, tap) instead of (tap, channel chunk) -- see launch_ring
 };
 
@@ -621,6 +623,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
   constexpr int LDS_BYTES = (SCHED == 4 || SCHED == 6) ? 160 * 1024 : (EPI == 1 || NSTAGE * STAGE > BAND * CLD * 4) ? NSTAGE * STAGE : BAND * CLD * 4;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
 
+  const long long ts_in = g.phase_ts ? wall_clock64() : 0, cy_in = g.phase_ts ? (long long)__builtin_readcyclecounter() : 0;
+  long long ts_loop = ts_in;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
@@ -652,15 +656,33 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
     if constexpr (SCHED == 2) { const int idx = (wave * 2 + (j & 1)) * RPI; return (idx >> 5) * 64 + (j >> 1) * 32 + (idx & 31); }
     else return (wave * B_GROUPS + j) * RPI;
   };
+  // (image, oy, ox) of a tile row: one pair of integer divisions for this lane's first row, the other staging instructions of the
+  // wave are RPI rows further each -- stepped with carries (the divisions of all A_GROUPS rows and the tap-mask loops below were
+  // 4.3 - 4.9 us of every workgroup's 70 us at 54 images: relnet_gemm_debug_phase_ts)
+  int pb = 0, poy = 0, pox = 0;
+  if constexpr (CONV && SCHED != 2) {
+    const int gr0 = m0 + a_base_row(0) + lrow, hw = g.cHout * g.cWout;
+    pb = gr0 / hw;
+    const int rem = gr0 - pb * hw;
+    poy = rem / g.cWout; pox = rem - poy * g.cWout;
+  }
 #pragma unroll
   for (int j = 0; j < A_GROUPS; ++j) {
     const int tr_ = a_base_row(j) + lrow;                          // row inside the tile
     const int lchunk = lslot ^ ring_swz<BK>(tr_);
     const int gr = m0 + tr_;
     if constexpr (CONV) {
-      const int hw = g.cHout * g.cWout;
-      const int b = gr / hw, rem = gr - b * hw;
-      const int oy = rem / g.cWout, ox = rem - oy * g.cWout;
+      int b, oy, ox;
+      if constexpr (SCHED != 2) {
+        b = pb; oy = poy; ox = pox;
+        pox += RPI;                                                // -> row of instruction j + 1
+        while (pox >= g.cWout) { pox -= g.cWout; if (++poy == g.cHout) { poy = 0; ++pb; } }
+      } else {
+        const int hw = g.cHout * g.cWout;
+        b = gr / hw;
+        const int rem = gr - b * hw;
+        oy = rem / g.cWout; ox = rem - oy * g.cWout;
+      }
       arow[j] = A + (long)b * g.cImg + lchunk * 8;
       ciy[j] = (gr < g.M) ? oy * g.cStride - g.cPad : -(1 << 28);
       cix[j] = ox * g.cStride - g.cPad;
@@ -827,12 +849,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
     for (int j = 0; j < A_GROUPS; ++j) {
       if constexpr (CONV) {
         ab[j] = arow[j] + ((long)ciy[j] * g.cW + cix[j]) * g.cPix;
-        unsigned m = 0;
-        for (int tr = 0; tr < g.cR; ++tr)
-          for (int ts = 0; ts < g.cS; ++ts) {
-            const int iy = ciy[j] + tr * g.cDil, ix = cix[j] + ts * g.cDil;
-            if (iy >= 0 && iy < g.cH && ix >= 0 && ix < g.cW) m |= 1u << (tr * g.cS + ts);
-          }
+        unsigned cm = 0, m = 0;                              // tap (tr, ts) in bounds <=> row tr and column ts are: column bits, replicated per valid row
+        for (int ts = 0; ts < g.cS; ++ts) { const int ix = cix[j] + ts * g.cDil; if (ix >= 0 && ix < g.cW) cm |= 1u << ts; }
+        for (int tr = 0; tr < g.cR; ++tr) { const int iy = ciy[j] + tr * g.cDil; if (iy >= 0 && iy < g.cH) m |= cm << (tr * g.cS); }
         mk[j] = m;
       } else {
         ab[j] = arow[j] ? arow[j] : A;
@@ -860,6 +879,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
       else { tb <<= 1; wb += q_wtap; if (++q_ts == q_S) { q_ts = 0; so += q_row; } else so += q_dp2; }
     };
     stage(0, 0);
+    if (g.phase_ts) ts_loop = wall_clock64();
     agpr_zero128();
     for (int kt = 0; kt + 1 < nk; ++kt) {
       const unsigned cur = (unsigned)(kt & 1) * STAGE, nxt = STAGE - cur;
@@ -900,12 +920,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
     for (int j = 0; j < A_GROUPS; ++j) {
       if constexpr (CONV) {
         ab[j] = arow[j] + ((long)ciy[j] * g.cW + cix[j]) * g.cPix;
-        unsigned m = 0;
-        for (int tr = 0; tr < g.cR; ++tr)
-          for (int ts = 0; ts < g.cS; ++ts) {
-            const int iy = ciy[j] + tr * g.cDil, ix = cix[j] + ts * g.cDil;
-            if (iy >= 0 && iy < g.cH && ix >= 0 && ix < g.cW) m |= 1u << (tr * g.cS + ts);
-          }
+        unsigned cm = 0, m = 0;                              // tap (tr, ts) in bounds <=> row tr and column ts are: column bits, replicated per valid row
+        for (int ts = 0; ts < g.cS; ++ts) { const int ix = cix[j] + ts * g.cDil; if (ix >= 0 && ix < g.cW) cm |= 1u << ts; }
+        for (int tr = 0; tr < g.cR; ++tr) { const int iy = ciy[j] + tr * g.cDil; if (iy >= 0 && iy < g.cH) m |= cm << (tr * g.cS); }
         mk[j] = m;
       } else {
         ab[j] = arow[j] ? arow[j] : A;
@@ -950,6 +967,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
         __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(lds + SLOT + (wave * A_GROUPS + j) * 1024), 16, 0, 0);
       }
     }
+    if (g.phase_ts) ts_loop = wall_clock64();
     agpr_zero128();
     unsigned aslot = 0;                                   // kt % 3
     for (int kt = 0; kt < nk; ++kt) {
@@ -1297,6 +1315,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
     }
 #undef RELNET_KSTEP
   }
+  if (g.phase_ts && tid == 0) {
+    long long* d = g.phase_ts + ((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8;
+    d[0] = ts_in; d[1] = ts_loop; d[2] = wall_clock64(); d[4] = (long long)__builtin_readcyclecounter() - cy_in;
+  }
   if constexpr (EPI == 1) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -1463,6 +1485,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
   }
   }   // EPI
   }   // nt (row-panel loop)
+  if (g.phase_ts && threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    g.phase_ts[((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 + 3] = wall_clock64();
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1929,6 +1955,8 @@ extern "C" void relnet_gemm_force_nloop(int n) { g_force_nloop = n; }
 extern "C" void relnet_gemm_set_swizzle(int on) { g_swizzle = on; }
 static int g_korder = 1;         // tuning knob: 1 = (channel chunk, tap) k order + XCD-contiguous row tiles for R*S > 1 ring launches
 extern "C" void relnet_gemm_debug_korder(int on) { g_korder = on; }
+static long long* g_phase_ts = nullptr;   // measurement knob: ring kernels write their phase timestamps there (8 words per workgroup)
+extern "C" void relnet_gemm_debug_phase_ts(void* buf) { g_phase_ts = (long long*)buf; }
 static int g_asm = 1;            // tuning knob: 0 = pick_tile never chooses tiles 18 / 19 (hand-scheduled k-loops)
 extern "C" void relnet_gemm_debug_asm(int on) { g_asm = on; }
 
@@ -1962,6 +1990,7 @@ static void launch_ring(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
   dim3 grid((ntile + nloop - 1) / nloop, (g.M + BM - 1) / BM, batch);
   g.xcd_swizzle = (swz && grid.x > 1) ? 1 : 0;
   g.korder = 0;
+  g.phase_ts = g_phase_ts;
   if constexpr (CONV == 1) {
     // Spatial convolutions re-read every input pixel once per tap.  In (tap, channel chunk) order the re-reads of one workgroup are
     // R * S k-slabs apart and the 32 resident workgroups of an XCD stream ~24 MB in between: the 4 MiB L2 has long dropped the

@@ -97,6 +97,7 @@ _SIGNATURES = {
     'relnet_gemm_set_swizzle': (None, [_i]),
     'relnet_gemm_debug_korder': (None, [_i]),
     'relnet_gemm_debug_asm': (None, [_i]),
+    'relnet_gemm_debug_phase_ts': (None, [_vp]),
     'relnet_gemm_debug_ablate': (None, [_i]),
     'relnet_gemm_tile_count': (C.c_int, []),
     'relnet_gemm_pick_tile': (C.c_int, [_i, _i, _i, _i, _i]),

@@ -398,7 +398,7 @@ def conv3x3_c64(x, w_frag, bias, relu=True):
     return conv3x3_halo(x, w_frag, bias, relu)
 
 
-CHAIN_MIDS = (64, 128)      # bottleneck widths relnet_bottleneck_chain is built for (res2: weights LDS-resident; res3: streamed per pass)
+CHAIN_MIDS = (64, 128, 256)      # bottleneck widths relnet_bottleneck_chain is built for (res2: weights LDS-resident; res3 / res4: streamed per pass)
 CHAIN_EXPAND_MIDS = (64, 128, 256, 512)      # ... and for its expand + shortcut + ReLU form without the second product (res4, res5 too)
 
 

@@ -7,7 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('mid', [64, 128])
+@pytest.mark.parametrize('mid', [64, 128, 256])
 @pytest.mark.parametrize('shape', [(1, 5, 7), (2, 38, 63), (3, 150, 250)])
 def test_bottleneck_chain_vs_two_convolutions(shape, mid):
     import relnet_amd  # noqa: F401
@@ -15,6 +15,8 @@ def test_bottleneck_chain_vs_two_convolutions(shape, mid):
     B, H, W = shape
     if mid == 128 and H == 150:
         H, W = 75, 125                     # the res3 map of a 600 x 1000 image
+    if mid == 256 and H == 150:
+        B, H, W = 9, 38, 63                # res4 maps: more than one lock-step set per workgroup on some CUs
     cout = 4 * mid
     g = torch.Generator().manual_seed(B * 1000 + H + mid)
     bf = torch.bfloat16
@@ -119,7 +121,8 @@ def test_backbone_with_and_without_chain_kernel():
     a = backbone.Backbone(p, dtype=torch.bfloat16, chain=True)
     b = backbone.Backbone(p, dtype=torch.bfloat16, chain=False)
     assert [k for k in sorted(a.chain) if k[0] in '23'] == ['2a', '2b', '2c', '3a', '3b1', '3b2', '3b3'] and a.chain['2c'][1] is None
-    assert sum(k[0] == '4' for k in a.chain) == 23 and all(a.chain[k][1] is None for k in a.chain if k[0] in '45') and not b.chain
+    assert sum(k[0] == '4' for k in a.chain) == 23 and all(a.chain[k][1] is None for k in a.chain if k[0] == '5' or k == '4b22') and not b.chain
+    assert all(a.chain[k][1] is not None for k in a.chain if k[0] == '4' and k != '4b22')        # res4: expand + the next unit's reduce (r04)
     assert sum(k[0] == '5' for k in a.chain) == 3
     assert sorted(a.chain_proj) == ['2a'] and not b.chain_proj
     ref = backbone.Backbone(p, dtype=torch.float32).forward(data)            # float32 trunk: the yardstick for both
