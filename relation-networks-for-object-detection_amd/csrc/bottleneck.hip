@@ -57,6 +57,8 @@ struct ChainArgs {
 // two CHANNEL halves instead (step = 32 output channels of the expand product and the 32 matching contraction values of the reduce
 // product: 16 + 16 KiB per slot), the shortcut slice and the store of the finished slice stay per pass.  mid1' accumulates in 128
 // registers per wavefront over the 32 steps of a tile.
+// (measured and dropped: FOUR wavefronts with two tiles each -- 512 registers per wavefront, every weight fragment feeding two MFMAs:
+//  the compiler spills ~240 registers into the step loop in that form; the eight-wave form spills ~60, outside the MFMA chains)
 // (measured and dropped, r04: the res4 expand form as TWO 4-wave workgroups per CU -- 16 KB filter slots, the two groups out of step so
 //  that one group's per-pass vmcnt(0) drain overlaps the other's arithmetic -- bit-identical and slower, 163 vs 150 us at 54 images:
 //  the filter stream through L2 -> LDS doubles)
@@ -115,9 +117,10 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
     if constexpr (CS == 2) {           // step (pass p, half ct): 32 rows of W3 (KS fragments) + the 32 matching k-values of W1' (2 k-steps x RT row tiles)
       const int p = st >> 1, ct = st & 1;
       unsigned char* wb = smem + (st & 1) * PASSB;
+      if (wave >= 4) return;                                   // (role split: see the step loop)
 #pragma unroll
-      for (int i = 0; i < (KS + 2 * RT) / 8; ++i) {
-        const int q = wave + 8 * i;
+      for (int i = 0; i < (KS + 2 * RT) / 4; ++i) {
+        const int q = wave + 4 * i;
         if (q < KS) {
           __builtin_amdgcn_global_load_lds((gas_ptr)((const unsigned char*)a.w3f + ((unsigned)(((p * 2 + ct) * KS + q) * 1024) + lane * 16u)), (las_ptr)(wb + q * 1024), 16, 0, 0);
         } else {
@@ -159,7 +162,36 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
   const int n_iter = STREAM ? ((ntile + 7) / 8 - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x
                             : (ntile - t_first + t_step - 1) / t_step;      // (streaming: idle waves of the last set still take part)
   if (n_iter <= 0) return;
-  issue_x(t_first * 32, 0);
+  // (CS == 2) vector-memory roles: wavefronts 0..3 stream the weights, wavefronts 4..7 move the activations of ALL eight tiles (two
+  // tiles each: shortcut slices in, finished slices out).  The mid-pass step then only has to wait for weights -- which the
+  // activation movers never have in flight -- so the HBM loads / stores of a pass stay in flight across both of its steps (with one
+  // role per wavefront every step top drained them: one step, half a pass, to cover an HBM round trip)
+  auto tile_stage = [&](int T) { return smem + WBYTES + T * STG; };
+  auto issue_x_t = [&](int T, int p0, int p) {
+    unsigned char* sb = tile_stage(T) + (p & 1) * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 8 * i + drow;
+      const unsigned off = ((unsigned)min(p0 + row, a.P - 1) * COUT + p * 64 + ((dslot ^ ((row >> 1) & 7)) << 3)) * 2u;
+      __builtin_amdgcn_global_load_lds((gas_ptr)((const unsigned char*)a.x + off), (las_ptr)(sb + i * 1024), 16, 0, 0);
+    }
+  };
+  auto flush_t = [&](int T, int p0, int p) {
+    const unsigned char* sb = tile_stage(T) + (p & 1) * 4096 + lane * 16;
+    const uint4 v0 = *(const uint4*)sb, v1 = *(const uint4*)(sb + 1024), v2 = *(const uint4*)(sb + 2048), v3 = *(const uint4*)(sb + 3072);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    auto put = [&](int i, const uint4& v) {
+      const int row = 8 * i + drow;
+      if (p0 + row < a.P) *(uint4*)((unsigned char*)a.xn + ((unsigned)(p0 + row) * COUT + p * 64 + ((dslot ^ ((row >> 1) & 7)) << 3)) * 2u) = v;
+    };
+    put(0, v0); put(1, v1); put(2, v2); put(3, v3);
+  };
+  if constexpr (CS == 2) {
+    if (wave >= 4) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) { const int T = 2 * (wave - 4) + tt; issue_x_t(T, (blockIdx.x * 8 + T) * 32, 0); }
+    }
+  } else issue_x(t_first * 32, 0);
   issue_w(0);
   for (int it = 0; it < n_iter; ++it) {
     const int p0 = (t_first + it * t_step) * 32;               // >= P for idle waves: loads clamp, stores are masked
@@ -186,11 +218,17 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
           const int st = 2 * p + ct;
-          asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-          if (ct == 0) {
-            if (p > 0) flush(p0, p - 1);
-            if (p + 1 < NP) issue_x(p0, p + 1);
-            else if (it + 1 < n_iter) issue_x(p0 + t_step * 32, 0);
+          if (ct == 0 || wave < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (mid-pass: only the weight streamers wait)
+          asm volatile("s_barrier" ::: "memory");
+          if (ct == 0 && wave >= 4) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+              const int T = 2 * (wave - 4) + tt;
+              const int q0 = (blockIdx.x * 8 + T + it * t_step) * 32;            // tile T of this set
+              if (p > 0) flush_t(T, q0, p - 1);
+              if (p + 1 < NP) issue_x_t(T, q0, p + 1);
+              else if (it + 1 < n_iter) issue_x_t(T, q0 + t_step * 32, 0);
+            }
           }
           if (st + 1 < 2 * NP) issue_w(st + 1);
           else if (it + 1 < n_iter) issue_w(0);
@@ -319,6 +357,8 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
     }
   }
 }
+
+
 
 }  // namespace relnet
 
