@@ -28,6 +28,13 @@ namespace relnet {
 typedef const __attribute__((address_space(1))) void* gas_ptr;
 typedef __attribute__((address_space(3))) void* las_ptr;
 
+// LDS-direct load issued from inline assembly: the compiler tracks no LDS-DMA store for it, so it does not put its own
+// s_waitcnt vmcnt(0) in front of the next ds_read (which would drain the prefetched slices at once).  Ordering by hand at the call
+// sites: counted vmcnt + barrier before a read (same helper as in gemm.hip).
+__device__ __forceinline__ void chain_glds16(const void* src, unsigned lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory", "m0");
+}
+
 struct ChainArgs {
   const unsigned short* m2;   // [P][MID]   3x3 output of block n (bf16)
   const unsigned short* x;    // [P][4 MID] shortcut = input of block n
@@ -53,15 +60,7 @@ struct ChainArgs {
 // Nothing on the vector-memory path is issued inside the arithmetic (biases come from LDS): a load there would make the
 // compiler wait for the prefetch in front of it.
 // KSPLIT > 1 (MID = 512, res5; expand-only): the k range of a pass is cut in KSPLIT sub-steps so that a ring slot stays 32 KiB.
-// MID = 256 with the second product (res4, r04): a pass's weights would be 32 KiB of W3 + 32 KiB of W1' per ring slot; the pass is cut in
-// two CHANNEL halves instead (step = 32 output channels of the expand product and the 32 matching contraction values of the reduce
-// product: 16 + 16 KiB per slot), the shortcut slice and the store of the finished slice stay per pass.  mid1' accumulates in 128
-// registers per wavefront over the 32 steps of a tile.
-// (measured and dropped: FOUR wavefronts with two tiles each -- 512 registers per wavefront, every weight fragment feeding two MFMAs:
-//  the compiler spills ~240 registers into the step loop in that form; the eight-wave form spills ~60, outside the MFMA chains)
-// (measured and dropped, r04: the res4 expand form as TWO 4-wave workgroups per CU -- 16 KB filter slots, the two groups out of step so
-//  that one group's per-pass vmcnt(0) drain overlaps the other's arithmetic -- bit-identical and slower, 163 vs 150 us at 54 images:
-//  the filter stream through L2 -> LDS doubles)
+// MID = 256 with the second product (res4): chain256_roles_kernel below.
 // PROJ (MID = 64, resident weights; the first unit of res2, whose shortcut is a 1x1 projection of the unit's 64-channel input):
 //   x_next = relu(W3 . mid2 + Wp . x_in + (b3 + bp)) -- the projection is four more k-steps of the same accumulators instead of a
 //   separate convolution that writes a 4 MID-channel map (1.04 GB at 54 images) for this kernel to read back; no shortcut slice,
@@ -71,9 +70,8 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
   static_assert(!PROJ || (!STREAM && KSPLIT == 1), "the projection form exists for the resident-weight kernel");
   static_assert(KSPLIT == 1 || (STREAM && !REDUCE), "k-split passes exist for the streamed expand-only form");
   constexpr int COUT = 4 * MID, KS = MID / 16, KSS = KS / KSPLIT, RT = MID / 32, NP = COUT / 64;
-  constexpr int CS = (REDUCE && MID == 256) ? 2 : 1;                          // channel-split steps per pass (see above)
-  static_assert(CS == 1 || (STREAM && KSPLIT == 1 && !PROJ), "channel-split steps exist for the streamed two-product form");
-  constexpr int W3P = 2 * KSS * 1024 / CS, W1P = REDUCE ? 4 * RT * 1024 / CS : 0;     // bytes of one (sub-)step's W3 / W1' slice
+  static_assert(!REDUCE || MID <= 128, "MID = 256 with the second product is chain256_roles_kernel");
+  constexpr int W3P = 2 * KSS * 1024, W1P = REDUCE ? 4 * RT * 1024 : 0;     // bytes of one (sub-)step's W3 / W1' slice
   constexpr int WPP = PROJ ? W3P : 0;                                         // ... and of its Wp slice
   constexpr int PASSB = W3P + WPP + W1P;
   constexpr int STG = PROJ ? 4096 : 8192;                                     // stage bytes per wave
@@ -114,21 +112,7 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
   };
   // (STREAM) this wave's share of the weights of step st = pass * KSPLIT + k-part into ring slot st & 1
   auto issue_w = [&](int st) {
-    if constexpr (CS == 2) {           // step (pass p, half ct): 32 rows of W3 (KS fragments) + the 32 matching k-values of W1' (2 k-steps x RT row tiles)
-      const int p = st >> 1, ct = st & 1;
-      unsigned char* wb = smem + (st & 1) * PASSB;
-      if (wave >= 4) return;                                   // (role split: see the step loop)
-#pragma unroll
-      for (int i = 0; i < (KS + 2 * RT) / 4; ++i) {
-        const int q = wave + 4 * i;
-        if (q < KS) {
-          __builtin_amdgcn_global_load_lds((gas_ptr)((const unsigned char*)a.w3f + ((unsigned)(((p * 2 + ct) * KS + q) * 1024) + lane * 16u)), (las_ptr)(wb + q * 1024), 16, 0, 0);
-        } else {
-          const int q1 = q - KS, rt = q1 >> 1, j = q1 & 1;
-          __builtin_amdgcn_global_load_lds((gas_ptr)((const unsigned char*)a.w1f + ((unsigned)((rt * (COUT / 16) + p * 4 + ct * 2 + j) * 1024) + lane * 16u)), (las_ptr)(wb + W3P + q1 * 1024), 16, 0, 0);
-        }
-      }
-    } else if constexpr (STREAM) {
+    if constexpr (STREAM) {
       const int p = st / KSPLIT, kh = st % KSPLIT;
       unsigned char* wb = smem + (st & 1) * PASSB;
 #pragma unroll
@@ -162,36 +146,7 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
   const int n_iter = STREAM ? ((ntile + 7) / 8 - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x
                             : (ntile - t_first + t_step - 1) / t_step;      // (streaming: idle waves of the last set still take part)
   if (n_iter <= 0) return;
-  // (CS == 2) vector-memory roles: wavefronts 0..3 stream the weights, wavefronts 4..7 move the activations of ALL eight tiles (two
-  // tiles each: shortcut slices in, finished slices out).  The mid-pass step then only has to wait for weights -- which the
-  // activation movers never have in flight -- so the HBM loads / stores of a pass stay in flight across both of its steps (with one
-  // role per wavefront every step top drained them: one step, half a pass, to cover an HBM round trip)
-  auto tile_stage = [&](int T) { return smem + WBYTES + T * STG; };
-  auto issue_x_t = [&](int T, int p0, int p) {
-    unsigned char* sb = tile_stage(T) + (p & 1) * 4096;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = 8 * i + drow;
-      const unsigned off = ((unsigned)min(p0 + row, a.P - 1) * COUT + p * 64 + ((dslot ^ ((row >> 1) & 7)) << 3)) * 2u;
-      __builtin_amdgcn_global_load_lds((gas_ptr)((const unsigned char*)a.x + off), (las_ptr)(sb + i * 1024), 16, 0, 0);
-    }
-  };
-  auto flush_t = [&](int T, int p0, int p) {
-    const unsigned char* sb = tile_stage(T) + (p & 1) * 4096 + lane * 16;
-    const uint4 v0 = *(const uint4*)sb, v1 = *(const uint4*)(sb + 1024), v2 = *(const uint4*)(sb + 2048), v3 = *(const uint4*)(sb + 3072);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    auto put = [&](int i, const uint4& v) {
-      const int row = 8 * i + drow;
-      if (p0 + row < a.P) *(uint4*)((unsigned char*)a.xn + ((unsigned)(p0 + row) * COUT + p * 64 + ((dslot ^ ((row >> 1) & 7)) << 3)) * 2u) = v;
-    };
-    put(0, v0); put(1, v1); put(2, v2); put(3, v3);
-  };
-  if constexpr (CS == 2) {
-    if (wave >= 4) {
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) { const int T = 2 * (wave - 4) + tt; issue_x_t(T, (blockIdx.x * 8 + T) * 32, 0); }
-    }
-  } else issue_x(t_first * 32, 0);
+  issue_x(t_first * 32, 0);
   issue_w(0);
   for (int it = 0; it < n_iter; ++it) {
     const int p0 = (t_first + it * t_step) * 32;               // >= P for idle waves: loads clamp, stores are masked
@@ -211,60 +166,6 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
       for (int r = 0; r < 16; ++r) m1acc[rt][r] = 0.f;
 #pragma unroll 1
     for (int p = 0; p < NP; ++p) {
-      if constexpr (CS == 2) {
-        // two steps per pass: channels [64 p, +32) and [64 p + 32, +32) of x_next, each with its own weight slices; the shortcut slice /
-        // the store of the previous slice stay per PASS (128-byte rows), issued with the first step
-        unsigned char* sb = stage + (p & 1) * 4096;
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          const int st = 2 * p + ct;
-          if (ct == 0 || wave < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (mid-pass: only the weight streamers wait)
-          asm volatile("s_barrier" ::: "memory");
-          if (ct == 0 && wave >= 4) {
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-              const int T = 2 * (wave - 4) + tt;
-              const int q0 = (blockIdx.x * 8 + T + it * t_step) * 32;            // tile T of this set
-              if (p > 0) flush_t(T, q0, p - 1);
-              if (p + 1 < NP) issue_x_t(T, q0, p + 1);
-              else if (it + 1 < n_iter) issue_x_t(T, q0 + t_step * 32, 0);
-            }
-          }
-          if (st + 1 < 2 * NP) issue_w(st + 1);
-          else if (it + 1 < n_iter) issue_w(0);
-          const uint4* w3 = (const uint4*)(smem + (st & 1) * PASSB);
-          const uint4* w1 = (const uint4*)((const unsigned char*)w3 + W3P);
-          f32x16 ac;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) ac[r] = 0.f;
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks)
-            ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&w3[ks * 64 + lane], m2f[ks], ac, 0, 0, 0);
-          uint2 pk[4];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            uint2* sp = (uint2*)(sb + l31 * 128 + (((ct * 4 + g) ^ ((l31 >> 1) & 7)) << 4) + 8 * half);
-            const uint2 xv = *sp;
-            const float4 bv = *(const float4*)(sB3 + p * 64 + ct * 32 + 8 * g + 4 * half);
-            const float v0 = fmaxf(ac[4 * g + 0] + bv.x + bf2f(xv.x & 0xffff), 0.f), v1 = fmaxf(ac[4 * g + 1] + bv.y + bf2f(xv.x >> 16), 0.f);
-            const float v2 = fmaxf(ac[4 * g + 2] + bv.z + bf2f(xv.y & 0xffff), 0.f), v3 = fmaxf(ac[4 * g + 3] + bv.w + bf2f(xv.y >> 16), 0.f);
-            pk[g] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-            *sp = pk[g];
-          }
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            bf16x8 xf;
-            *(uint2*)&xf = pk[2 * j];
-            *((uint2*)&xf + 1) = pk[2 * j + 1];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-              m1acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&w1[(rt * 2 + j) * 64 + lane], xf, m1acc[rt], 0, 0, 0);
-          }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slice is complete in LDS (same-wave readers only)
-        __builtin_amdgcn_wave_barrier();
-        continue;
-      }
       f32x16 acc[2];
 #pragma unroll
       for (int kh = 0; kh < KSPLIT; ++kh) {
@@ -360,6 +261,208 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
 
 
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// res4 form of the two-product chain (MID = 256: 256 -> 1024 + shortcut + ReLU, then the next unit's 1024 -> 256 + ReLU), r04,
+// with ONE ROLE PER WAVEFRONT.  Every wavefront doing everything (bottleneck_chain_kernel's structure with the passes cut in two
+// 32-channel steps so that the weight slots stay 32 KB: built and measured first) needs 64 (mid2 fragments) + 128 (mid1'
+// accumulators) + 16 registers of essential state per wavefront of 256: the compiler spilled the address arithmetic of the activation
+// loads into the step loop
+// (a scratch reload -> s_waitcnt vmcnt(0) between every two HBM loads) and had one register set left for weight fragments (ds_read ->
+// lgkmcnt(0) -> MFMA, 32 times per step): 21.6 ms per 54-image step against 20.0 ms with this kernel on the same box (the two
+// separate launches: 22.0).  Here a workgroup walks sets of FOUR 32-pixel tiles; tile T belongs to two wavefronts:
+//   A-wave T      expand product of step g (16 MFMAs: W3 rows [32 g', +32) x mid2 fragments in registers), bias + shortcut + ReLU into
+//                 the tile's stage buffer, and the stores of finished slices (they drain in the background: an A-wave never waits on vmcnt
+//                 except for its mid2 fragments once per tile);
+//   B-wave T + 4  reduce product of step g - 1 (16 MFMAs: the 32 channels the A-wave finished one step earlier, read back from the
+//                 stage buffer, x the matching W1' fragments) into 128 accumulator registers; mid1' out once per tile.
+// B-waves 4, 5 also stream the weights (W3 of step g + 1 and W1' of step g into the slot not in use: vmcnt(0) per step, L2 hits);
+// B-waves 6, 7 load the shortcut slices of all four tiles TWO passes ahead into a four-deep stage ring per tile and wait with a
+// COUNTED vmcnt (only loads in their queue: in-order), so HBM loads have two passes and HBM stores unlimited time to complete.
+// One s_barrier per step (32 channels); same passes, rounding points and results as the one-role form.
+// LDS: weights 2 x 32 KB | stage 4 tiles x 4 x 4 KB | mid1' staging 4 x 4 KB | biases 5 KB = 149 KB.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void chain256_roles_kernel(ChainArgs a) {
+  constexpr int MID = 256, COUT = 4 * MID, KS = MID / 16, RT = MID / 32, NP = COUT / 64, NSTEP = 2 * NP, NTL = 4, NBUF = 4;
+  constexpr int W3P = KS * 1024, W1P = 2 * RT * 1024, SLOT = W3P + W1P, WBYTES = 2 * SLOT;
+  constexpr int STG = NBUF * 4096, M1S = WBYTES + NTL * STG, BIAS = M1S + NTL * 4096;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31, drow = lane >> 3, dslot = lane & 7;
+  const unsigned lds0 = (unsigned)(unsigned long)(las_ptr)smem;
+  float* sB3 = (float*)(smem + BIAS);
+  float* sB1 = sB3 + COUT;
+  for (int i = tid; i < COUT; i += 512) sB3[i] = a.b3[i];
+  for (int i = tid; i < MID; i += 512) sB1[i] = a.b1[i];
+  const int ntile = (a.P + 31) / 32, nset = (ntile + NTL - 1) / NTL;
+  const int n_iter = (nset - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // (idle tiles of the last set still take part)
+  if (n_iter <= 0) return;
+  const int G = n_iter * NSTEP, NPASS = n_iter * NP;            // steps / passes of this workgroup
+  auto tile_p0 = [&](int it, int T) { return (((int)blockIdx.x + it * (int)gridDim.x) * NTL + T) * 32; };     // >= P for idle tiles: loads clamp, stores are masked
+  // shortcut slice of global pass Pg for tile T -> stage buffer Pg % NBUF
+  auto issue_x = [&](int T, int Pg) {
+    const int p0 = tile_p0(Pg / NP, T), p = Pg % NP;
+    unsigned char* sb = smem + WBYTES + T * STG + (Pg % NBUF) * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 8 * i + drow;
+      const unsigned off = ((unsigned)min(p0 + row, a.P - 1) * COUT + p * 64 + ((dslot ^ ((row >> 1) & 7)) << 3)) * 2u;
+      chain_glds16((const unsigned char*)a.x + off, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(sb - smem) + i * 1024));
+    }
+  };
+  // weights of the slot step g + 1 reads: W3 rows of step g + 1 (fragments 0..15) and W1' k-steps of step g (fragments 16..31); loader l of 2
+  auto issue_w = [&](int g, int l) {
+    unsigned char* wb = smem + ((g + 1) & 1) * SLOT;
+    const int s3 = (g + 1) % NSTEP, s1 = g % NSTEP;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int q = l + 2 * i;
+      if (q < KS) {
+        if (g + 1 < G)
+          chain_glds16((const unsigned char*)a.w3f + ((unsigned)((s3 * KS + q) * 1024) + lane * 16u), __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wb - smem) + q * 1024));
+      } else if (g >= 0 && g < G) {
+        const int q1 = q - KS, rt = q1 >> 1, j = q1 & 1;
+        chain_glds16((const unsigned char*)a.w1f + ((unsigned)((rt * (COUT / 16) + (s1 >> 1) * 4 + (s1 & 1) * 2 + j) * 1024) + lane * 16u), __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wb - smem) + W3P + q1 * 1024));
+      }
+    }
+  };
+  // prologue: W3 of step 0 (both weight loaders: their share of slot 0), shortcut slices of passes 0 and 1
+  if (wave == 4 || wave == 5) issue_w(-1, wave - 4);
+  if (wave >= 6) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) { issue_x(2 * (wave - 6) + tt, 0); }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) { issue_x(2 * (wave - 6) + tt, 1); }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");       // biases in LDS (this also drains the prologue loads once)
+
+  if (wave < 4) {
+    // ================================================= A-wave: tile T = wave =================================================
+    const int T = wave;
+    unsigned char* const stg = smem + WBYTES + T * STG;
+    bf16x8 m2f[KS];
+#pragma unroll 1
+    for (int g = 0; g <= G + 1; ++g) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (this wave's stage writes of the previous step are in LDS)
+      if (g < G) {
+        const int st = g % NSTEP, p = st >> 1, ct = st & 1, Pg = g >> 1;
+        if (st == 0) {
+          const int px = min(tile_p0(g / NSTEP, T) + l31, a.P - 1);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) m2f[ks] = *(const bf16x8*)(a.m2 + (long)px * MID + 16 * ks + 8 * half);
+          __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) HERE, once per tile, as a real instruction the compiler's wait-count pass sees: left to it (or
+                                                   // hidden in an asm statement) counted vmcnt waits land on the main path of every step and drain the stores
+        }
+        const uint4* w3 = (const uint4*)(smem + (g & 1) * SLOT);
+        f32x16 ac;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ac[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&w3[ks * 64 + lane], m2f[ks], ac, 0, 0, 0);
+        unsigned char* sb = stg + (Pg % NBUF) * 4096;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          uint2* sp = (uint2*)(sb + l31 * 128 + (((ct * 4 + gq) ^ ((l31 >> 1) & 7)) << 4) + 8 * half);
+          const uint2 xv = *sp;
+          const float4 bv = *(const float4*)(sB3 + p * 64 + ct * 32 + 8 * gq + 4 * half);
+          const float v0 = fmaxf(ac[4 * gq + 0] + bv.x + bf2f(xv.x & 0xffff), 0.f), v1 = fmaxf(ac[4 * gq + 1] + bv.y + bf2f(xv.x >> 16), 0.f);
+          const float v2 = fmaxf(ac[4 * gq + 2] + bv.z + bf2f(xv.y & 0xffff), 0.f), v3 = fmaxf(ac[4 * gq + 3] + bv.w + bf2f(xv.y >> 16), 0.f);
+          *sp = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+        }
+      }
+      if ((g & 1) && g >= 3) {
+        // slice Pf is complete (A: step 2 Pf + 1) and consumed (B: step 2 Pf + 2): out, 16-byte coalesced rows
+        const int Pf = (g - 3) >> 1, p0 = tile_p0(Pf / NP, T), p = Pf % NP;
+        const unsigned char* sb = stg + (Pf % NBUF) * 4096 + lane * 16;
+        const uint4 v0 = *(const uint4*)sb, v1 = *(const uint4*)(sb + 1024), v2 = *(const uint4*)(sb + 2048), v3 = *(const uint4*)(sb + 3072);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        auto put = [&](int i, const uint4& v) {
+          const int row = 8 * i + drow;
+          if (p0 + row < a.P) *(uint4*)((unsigned char*)a.xn + ((unsigned)(p0 + row) * COUT + p * 64 + ((dslot ^ ((row >> 1) & 7)) << 3)) * 2u) = v;
+        };
+        put(0, v0); put(1, v1); put(2, v2); put(3, v3);
+      }
+    }
+  } else {
+    // ================================================= B-wave: tile T = wave - 4 =============================================
+    const int T = wave - 4;
+    const unsigned char* const stg = smem + WBYTES + T * STG;
+    unsigned char* const m1s = smem + M1S + T * 4096;
+    f32x16 m1acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m1acc[rt][r] = 0.f;
+    bool drain = false;                      // this wave has stores in its queue (mid1' rows): the next counted wait must be a full one
+#pragma unroll 1
+    for (int g = 0; g <= G + 1; ++g) {
+      if (wave < 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // weights of step g (and of B's step g - 1) landed
+      else if (!(g & 1) && (g >> 1) < NPASS) {                                           // slice of pass g / 2 landed; the next one may be in flight
+        if (!drain && (g >> 1) + 1 < NPASS) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        drain = false;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (wave < 6) issue_w(g, wave - 4);
+      else if (!(g & 1) && (g >> 1) + 2 < NPASS) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) issue_x(2 * (wave - 6) + tt, (g >> 1) + 2);
+      }
+      if (g >= 1 && g <= G) {
+        const int h = g - 1, st = h % NSTEP, ct = st & 1, Pg = h >> 1;                 // the step the A-wave finished before this barrier
+        const uint4* w1 = (const uint4*)(smem + (g & 1) * SLOT + W3P);
+        const unsigned char* sb = stg + (Pg % NBUF) * 4096;
+        bf16x8 xf[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          *(uint2*)&xf[j] = *(const uint2*)(sb + l31 * 128 + (((ct * 4 + 2 * j) ^ ((l31 >> 1) & 7)) << 4) + 8 * half);
+          *((uint2*)&xf[j] + 1) = *(const uint2*)(sb + l31 * 128 + (((ct * 4 + 2 * j + 1) ^ ((l31 >> 1) & 7)) << 4) + 8 * half);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            m1acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&w1[(rt * 2 + j) * 64 + lane], xf[j], m1acc[rt], 0, 0, 0);
+        if (st == NSTEP - 1) {
+          // mid1' = relu(. + b1) of the tile that just ended, 64 channels at a time through this wave's staging buffer
+          const int p0 = tile_p0(h / NSTEP, T);
+#pragma unroll
+          for (int hc = 0; hc < RT / 2; ++hc) {
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+              for (int gq = 0; gq < 4; ++gq) {
+                const int rt = 2 * hc + r2;
+                const float4 bv = *(const float4*)(sB1 + rt * 32 + 8 * gq + 4 * half);
+                const float v0 = fmaxf(m1acc[rt][4 * gq + 0] + bv.x, 0.f), v1 = fmaxf(m1acc[rt][4 * gq + 1] + bv.y, 0.f);
+                const float v2 = fmaxf(m1acc[rt][4 * gq + 2] + bv.z, 0.f), v3 = fmaxf(m1acc[rt][4 * gq + 3] + bv.w, 0.f);
+                *(uint2*)(m1s + l31 * 128 + (((r2 * 4 + gq) ^ ((l31 >> 1) & 7)) << 4) + 8 * half) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+              }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const unsigned char* sl = m1s + lane * 16;
+            const uint4 v0 = *(const uint4*)sl, v1 = *(const uint4*)(sl + 1024), v2 = *(const uint4*)(sl + 2048), v3 = *(const uint4*)(sl + 3072);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            auto put = [&](int i, const uint4& v) {
+              const int row = 8 * i + drow;
+              if (p0 + row < a.P) *(uint4*)(a.m1 + (long)(p0 + row) * MID + hc * 64 + ((dslot ^ ((row >> 1) & 7)) << 3)) = v;
+            };
+            put(0, v0); put(1, v1); put(2, v2); put(3, v3);
+          }
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m1acc[rt][r] = 0.f;
+          drain = true;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace relnet
 
 using namespace relnet;
@@ -386,7 +489,7 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<128, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<256, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<512, true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)bottleneck_chain_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)chain256_roles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const long ntile = (P + 31) / 32;
   const unsigned grid = (unsigned)(ntile < 8 * 256 ? (ntile + 7) / 8 : 256);     // persistent: one workgroup per CU
@@ -394,7 +497,10 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
   if (mid1_next) {
     if (mid == 64) bottleneck_chain_kernel<64, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);
     else if (mid == 128) bottleneck_chain_kernel<128, true><<<grid, 512, lds, (hipStream_t)stream>>>(a);
-    else bottleneck_chain_kernel<256, true><<<grid, 512, lds, (hipStream_t)stream>>>(a);
+    else {
+      const long nset = (ntile + 3) / 4;
+      chain256_roles_kernel<<<(unsigned)(nset < 256 ? nset : 256), 512, 152576, (hipStream_t)stream>>>(a);
+    }
   } else {
     if (mid == 64) bottleneck_chain_kernel<64, false, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);
     else if (mid == 128) bottleneck_chain_kernel<128, true, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);
