@@ -280,6 +280,10 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
 // B-waves 6, 7 load the shortcut slices of all four tiles TWO passes ahead into a four-deep stage ring per tile and wait with a
 // COUNTED vmcnt (only loads in their queue: in-order), so HBM loads have two passes and HBM stores unlimited time to complete.
 // One s_barrier per step (32 channels); same passes, rounding points and results as the one-role form.
+// What bounds it (r04, 54 images, 209 us per launch = 1.63 us per step): the L2 -> LDS fill path.  Every workgroup streams the full
+// 1 MB of W3 + W1' per set of four tiles -- 1.0 GB per launch, + 0.27 GB of shortcut slices through the same path -- at the 5.5 - 6 TB/s
+// that path sustains (tools/fill_probe.py); HBM carries 0.66 GB (3.2 TB/s).  Eight tiles per set would halve the weight stream, but
+// their mid1' accumulators alone are all the registers four B-waves have.
 // LDS: weights 2 x 32 KB | stage 4 tiles x 4 x 4 KB | mid1' staging 4 x 4 KB | biases 5 KB = 149 KB.
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void chain256_roles_kernel(ChainArgs a) {
@@ -355,20 +359,28 @@ __global__ __launch_bounds__(512) void chain256_roles_kernel(ChainArgs a) {
                                                    // hidden in an asm statement) counted vmcnt waits land on the main path of every step and drain the stores
         }
         const uint4* w3 = (const uint4*)(smem + (g & 1) * SLOT);
+        // all sixteen weight fragments of the step up front (64 registers this role has to spare): the expand product is ONE dependent
+        // MFMA chain (measured: the step time does not depend on it -- see the bound below -- but the MFMA pipe is released earlier)
+        bf16x8 wf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wf[ks] = *(const bf16x8*)&w3[ks * 64 + lane];
+        unsigned char* sb = stg + (Pg % NBUF) * 4096;
+        uint2 xv[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) xv[gq] = *(const uint2*)(sb + l31 * 128 + (((ct * 4 + gq) ^ ((l31 >> 1) & 7)) << 4) + 8 * half);
+        __builtin_amdgcn_sched_barrier(0);                   // (the scheduler otherwise sinks the reads back between the MFMAs)
         f32x16 ac;
 #pragma unroll
         for (int r = 0; r < 16; ++r) ac[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-          ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&w3[ks * 64 + lane], m2f[ks], ac, 0, 0, 0);
-        unsigned char* sb = stg + (Pg % NBUF) * 4096;
+          ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], m2f[ks], ac, 0, 0, 0);
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           uint2* sp = (uint2*)(sb + l31 * 128 + (((ct * 4 + gq) ^ ((l31 >> 1) & 7)) << 4) + 8 * half);
-          const uint2 xv = *sp;
           const float4 bv = *(const float4*)(sB3 + p * 64 + ct * 32 + 8 * gq + 4 * half);
-          const float v0 = fmaxf(ac[4 * gq + 0] + bv.x + bf2f(xv.x & 0xffff), 0.f), v1 = fmaxf(ac[4 * gq + 1] + bv.y + bf2f(xv.x >> 16), 0.f);
-          const float v2 = fmaxf(ac[4 * gq + 2] + bv.z + bf2f(xv.y & 0xffff), 0.f), v3 = fmaxf(ac[4 * gq + 3] + bv.w + bf2f(xv.y >> 16), 0.f);
+          const float v0 = fmaxf(ac[4 * gq + 0] + bv.x + bf2f(xv[gq].x & 0xffff), 0.f), v1 = fmaxf(ac[4 * gq + 1] + bv.y + bf2f(xv[gq].x >> 16), 0.f);
+          const float v2 = fmaxf(ac[4 * gq + 2] + bv.z + bf2f(xv[gq].y & 0xffff), 0.f), v3 = fmaxf(ac[4 * gq + 3] + bv.w + bf2f(xv[gq].y >> 16), 0.f);
           *sp = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
         }
       }
@@ -420,11 +432,17 @@ __global__ __launch_bounds__(512) void chain256_roles_kernel(ChainArgs a) {
           *(uint2*)&xf[j] = *(const uint2*)(sb + l31 * 128 + (((ct * 4 + 2 * j) ^ ((l31 >> 1) & 7)) << 4) + 8 * half);
           *((uint2*)&xf[j] + 1) = *(const uint2*)(sb + l31 * 128 + (((ct * 4 + 2 * j + 1) ^ ((l31 >> 1) & 7)) << 4) + 8 * half);
         }
+        bf16x8 wf[2][RT];                                      // (all sixteen fragments up front, as in the A-wave)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) wf[j][rt] = *(const bf16x8*)&w1[(rt * 2 + j) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
-            m1acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&w1[(rt * 2 + j) * 64 + lane], xf[j], m1acc[rt], 0, 0, 0);
+            m1acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][rt], xf[j], m1acc[rt], 0, 0, 0);
         if (st == NSTEP - 1) {
           // mid1' = relu(. + b1) of the tile that just ended, 64 channels at a time through this wave's staging buffer
           const int p0 = tile_p0(h / NSTEP, T);
