@@ -1982,7 +1982,11 @@ template <int BM, int BN, int WM, int WN, int CONV, int BK, int NSTAGE, int SCHE
 static void launch_ring(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
   const int ntile = (g.N + BN - 1) / BN;
   int nloop = g_force_nloop > 0 ? g_force_nloop : g.n_loop;
-  const bool swz = g_swizzle && batch == 1 && ntile > 1 && (long)ntile * ((g.M + BM - 1) / BM) >= 16;
+  bool swz = g_swizzle && batch == 1 && ntile > 1 && (long)ntile * ((g.M + BM - 1) / BM) >= 16;
+  // ... unless the filters alone fill an XCD's L2 (res5a's projection, 1024 -> 2048: 4 MB): the XCD-aware order then re-streams them per
+  // row panel; in plain order column tile c runs on XCD c % 8 and its 512 KB filter tile stays put while the row panels stream past
+  // (tools/swizzle_probe.py, 54 images: 727 -> 645 us; the two-column-tile layers are indifferent)
+  if (g_swizzle == 1 && ntile >= 8 && (long)g.N * g.K * 2 >= (4L << 20)) swz = false;
   if ((swz && g_force_nloop == 0) || SCHED == 2) nloop = 1;
   if (nloop < 1) nloop = 1;
   if (nloop > ntile) nloop = ntile;
