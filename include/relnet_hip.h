@@ -167,8 +167,9 @@ int relnet_relation_attention_fused(const void* q, long q_ld, long q_bs, const v
  *   x_next = relu(W3 . mid2 + b3 + x),  mid1_next = relu(W1n . x_next + b1n)        (BN folded into W / b)
  * mid2 [P][mid], x / x_next [P][4 mid], mid1_next [P][mid] bf16, dense pixel rows.  w3f = relnet_pack_w_frag(W3 [4 mid][mid]);
  * w1f = W1n [mid][4 mid] in the accumulator-permuted fragment order: block (rt, ks) = 64 lanes x 8 values, lane (l31, half)
- * slot t <- W1n[32 rt + l31][16 ks + 8 (t >> 2) + 4 half + (t & 3)].  mid = 64 (res2) or 128 (res3).  w1f = b1 = mid1_next =
- * NULL: only x_next (last unit of a stage).                                                                          */
+ * slot t <- W1n[32 rt + l31][16 ks + 8 (t >> 2) + 4 half + (t & 3)].  mid = 64 (res2), 128 (res3) or 256 (res4).  w1f = b1 =
+ * mid1_next = NULL: only x_next (last unit of a stage; also mid = 512, res5).  x_next may alias x (in place).  The 4 mid-channel
+ * map must stay below 4 GiB (32-bit byte offsets).                                                                   */
 int relnet_bottleneck_chain(const void* mid2, const void* x, const void* w3f, const void* w1f, const float* b3,
                             const float* b1, void* x_next, void* mid1_next, long P, int mid, void* stream);
 /* First unit of res2 (1x1 projection shortcut, stride 1; resnet_v1_101_rcnn_base.py: res2a_branch1 / bn2a_branch1 + res2a_branch2c
@@ -221,7 +222,6 @@ int relnet_class_nms_ex(const float* cls_prob, const double* scores64, const dou
  * top_k.  The lists are prefixes of relnet_class_nms's and contain every pick >= the final image threshold, so relnet_image_topk
  * returns the same detections; counts = picks produced.  N <= 1024. */
 int relnet_class_nms_hist_bins(void);
-void relnet_class_nms_debug_form(int form);     /* tuning knob: 0 = automatic (by the number of (image, class) pairs), 1 = one roi per thread, 2 = one wavefront per class */
 int relnet_class_nms_topk(const float* cls_prob, const double* boxes, double* dets, int* counts, void* hist, int B, int N, int C,
                           float score_thresh, double nms_param, int soft, int max_picks, int top_k, void* stream);
 /* tester.py:270-277: image threshold = max_per_image-th largest score; out [B,max_out,6] =

@@ -497,21 +497,18 @@ extern "C" int relnet_detect_head(const float* cls_score, long cs_ld, const floa
                                delta_off, nullptr, stream);
 }
 
-// Latency form (one candidate per thread, the smallest workgroup that holds N of them) while the launch leaves the chip mostly
-// empty; throughput form (one wavefront per class, N / 64 candidates per lane: half the instructions per pick, the max / ballot /
-// readlane part is not repeated per wave) from kNmsWideGroups (image, class) pairs up.
-static int g_nms_form = 0;               // tuning knob: 0 auto, 1 latency form, 2 throughput form
-extern "C" void relnet_class_nms_debug_form(int f) { g_nms_form = f; }
-constexpr long kNmsWideGroups = 1536;
+// One candidate per thread, the smallest workgroup that holds N of them (300 rois: 5 waves; FPN's 1000 + 4: 16).  (The one-wave form --
+// N / 64 candidates per lane, half the instructions per pick -- was kept for launches of >= 1536 (image, class) pairs at first: faster
+// in isolation at 54 images, 206 vs 242 us, but inside the step the multi-wave form wins or ties at every batch size, 19.19 vs
+// 19.22-19.39 ms at 54 images: the step ends with this kernel, and its tail is the deepest class's serial picks.)
 template <bool PRUNE>
 static void launch_class_nms(const ClsNmsArgs& g, int B, hipStream_t s) {
   dim3 grid(g.C - 1, B);
-  const bool wide = g_nms_form ? g_nms_form == 1 : (long)(g.C - 1) * B < kNmsWideGroups;
   if (g.N <= 64) class_nms_kernel<1, 1, PRUNE><<<grid, 64, 0, s>>>(g);
   else if (g.N <= 128) class_nms_kernel<2, 1, PRUNE><<<grid, 128, 0, s>>>(g);
-  else if (g.N <= 320) { if (wide) class_nms_kernel<5, 1, PRUNE><<<grid, 320, 0, s>>>(g); else class_nms_kernel<1, 5, PRUNE><<<grid, 64, 0, s>>>(g); }
-  else if (g.N <= 512) { if (wide) class_nms_kernel<8, 1, PRUNE><<<grid, 512, 0, s>>>(g); else class_nms_kernel<1, 8, PRUNE><<<grid, 64, 0, s>>>(g); }
-  else { if (wide) class_nms_kernel<16, 1, PRUNE><<<grid, 1024, 0, s>>>(g); else class_nms_kernel<4, 4, PRUNE><<<grid, 256, 0, s>>>(g); }
+  else if (g.N <= 320) class_nms_kernel<5, 1, PRUNE><<<grid, 320, 0, s>>>(g);
+  else if (g.N <= 512) class_nms_kernel<8, 1, PRUNE><<<grid, 512, 0, s>>>(g);
+  else class_nms_kernel<16, 1, PRUNE><<<grid, 1024, 0, s>>>(g);
 }
 
 extern "C" int relnet_class_nms_ex(const float* cls_prob, const double* scores64, const double* boxes, double* dets,

@@ -56,7 +56,6 @@ _SIGNATURES = {
     'relnet_class_nms_ex': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, C.c_double, _i, _i, _vp]),
     'relnet_class_nms_topk': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, C.c_double, _i, _i, _i, _vp]),
     'relnet_class_nms_hist_bins': (C.c_int, []),
-    'relnet_class_nms_debug_form': (None, [_i]),
     'relnet_bbox_overlaps': (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),
     'relnet_image_topk': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'relnet_conv2d_nhwc': (C.c_int, [_vp, _l, _l, _vp, _vp, _vp, _i, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -51,8 +51,6 @@ def detector_case():
     params = backbone.init_params(seed=1)
     det = detector.Detector(params, dtype=torch.bfloat16, device='cuda')
     g = torch.Generator().manual_seed(0)
-    from relnet_amd import lib
-    L = lib.load()
     for B in (1, 4, 8, 16, 54):
         Bd = min(B, 6)
         data = torch.randn(Bd, 3, 600, 1000, generator=g).cuda()
@@ -62,12 +60,6 @@ def detector_case():
         prob = out['cls_prob'].repeat(rep, 1, 1)[:B].contiguous()
         boxes = out['pred_boxes'].repeat(rep, 1, 1)[:B].contiguous()
         c = out['class_counts'].float()
-        for form in (1, 2):
-            L.relnet_class_nms_debug_form(form)
-            t = timeit(lambda: ops.class_nms(prob, boxes, 1e-3, 0.6, True, max_picks=100, top_k=100))
-            tf = timeit(lambda: ops.class_nms(prob, boxes, 1e-3, 0.6, True, max_picks=100))
-            print('  B %d form %d: pruned %.1f us, full(100) %.1f us' % (B, form, t, tf), flush=True)
-        L.relnet_class_nms_debug_form(0)
         pr = prob[..., 1:]
         uniq = [int(torch.unique(pr[b]).numel()) for b in range(B)]
         t_p = timeit(lambda: ops.class_nms(prob, boxes, 1e-3, 0.6, True, max_picks=100, top_k=100))
