@@ -402,14 +402,16 @@ CHAIN_MIDS = (64, 128, 256)      # bottleneck widths relnet_bottleneck_chain is 
 CHAIN_EXPAND_MIDS = (64, 128, 256, 512)      # ... and for its expand + shortcut + ReLU form without the second product (res4, res5 too)
 
 
-CHAIN_MIN_PIXELS = {64: 16384, 'streamed': 98304}     # tests lower these to run the chain kernels on small maps
+CHAIN_MIN_PIXELS = {64: 16384, 256: 8192, 'streamed': 98304}     # tests lower these to run the chain kernels on small maps
 
 
 def chain_worthwhile(pixels, mid):
     """The chain kernels are persistent with one workgroup per CU; the streamed forms (mid >= 128) walk lock-step sets of
     8 x 32 pixels, so they need >= ~1.5 sets per CU (256 CUs) to beat the tiled convolution kernels (measured: B = 1 / B = 8
-    steps are slower with them on the small late-stage maps)."""
-    return pixels >= CHAIN_MIN_PIXELS[64 if mid == 64 else 'streamed']
+    steps are slower with them on the small late-stage maps).  mid = 256 (res4: expand + next reduce in one role-specialised launch,
+    sets of four tiles) replaces two launches and wins from 4 images of 600 x 1000 up (r04, same box, ms per step with / without:
+    2 images 3.17 / 2.87, 4 images 4.17 / 4.52, 8: 5.13 / 5.44, 27: 10.72 / 11.53, 40: 15.92 / 17.49)."""
+    return pixels >= CHAIN_MIN_PIXELS[mid if mid in CHAIN_MIN_PIXELS else 'streamed']
 
 
 def pack_chain_w1(w_packed):
