@@ -44,7 +44,7 @@ def _case(kind, B, N, C, seed):
 @pytest.mark.parametrize('kind,B,N,C,soft,param', [
     ('flat', 3, 300, 81, True, 0.6), ('peaked', 3, 300, 81, True, 0.6), ('mixed', 2, 300, 81, False, 0.5),
     ('ties', 2, 300, 81, True, 0.6), ('ties', 2, 300, 81, False, 0.3), ('few', 2, 300, 81, True, 0.6),
-    ('mixed', 2, 37, 21, True, 0.6), ('flat', 1, 320, 81, True, 0.6)])
+    ('mixed', 2, 37, 21, True, 0.6), ('flat', 1, 320, 81, True, 0.6), ('mixed', 1, 1004, 81, True, 0.6), ('flat', 2, 500, 81, False, 0.5)])
 def test_pruned_lists_are_prefixes_and_image_topk_is_unchanged(kind, B, N, C, soft, param):
     import relnet_amd  # noqa: F401
     from relnet_amd import ops
