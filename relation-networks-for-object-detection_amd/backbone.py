@@ -215,6 +215,18 @@ class Backbone(object):
         return ops.conv2d_nhwc(x, w, b, ksize=k, stride=stride, pad=pad, dil=dil, relu=relu, resid=resid,
                                out_dtype=out_dtype, w_frag=self.wf.get(name))
 
+    def forward_res2(self, data):
+        """Stem + res2 only (the part the reference freezes in training: cfgs/*.yaml FIXED_PARAMS conv1 / res2): raw NCHW image ->
+        res2c output, NHWC bf16, on the inference kernels (fused stem, halo 3x3, chain kernels incl. res2a's in-kernel projection)."""
+        x = ops.stem_fused(data, self.w_stem, self.b32['conv1'])
+        y_next = None
+        self.last_chain_units = []
+        for unit in self.units:
+            if unit[0] != 2:
+                break
+            x, y_next = self._unit_hip(x, unit, y_next)
+        return x
+
     def _forward_hip(self, data, rpn_hook=None):
         if self.stem == 'hip':
             # conv1 7x7/2 + bias + ReLU + pool1 in ONE kernel, raw NCHW image -> pooled NHWC map (no conv map in HBM)

@@ -100,6 +100,12 @@ class Trainer(object):
         w1, b1 = fold_bn(params['conv1_weight'], params['bn_conv1_gamma'], params['bn_conv1_beta'],
                          params['bn_conv1_moving_mean'], params['bn_conv1_moving_var'])
         self.w_stem, self.b_stem = ops.pack_stem_weight(w1, torch.bfloat16, dev), f32(b1)
+        # conv1 + res2 never change: they run on the inference kernels (fused stem, halo 3x3, chain kernels) of a Backbone built from the
+        # same parameters (cfg.frozen_on_inference_kernels = False keeps the per-layer convolution launches)
+        self._frozen_backbone = None
+        if getattr(c, 'frozen_on_inference_kernels', True) and torch.device(dev).type == 'cuda':
+            from .backbone import Backbone
+            self._frozen_backbone = Backbone(params, dtype=torch.bfloat16, device=dev, dcn=bool(getattr(c, 'dcn', False)), fpn=self.fpn)
         self.zero_bias64 = torch.zeros(64, device=dev, dtype=torch.float32)
         weights, biases = [], []
         self.bn_scale, self.conv_bias, self.ksize = {}, {}, {'rpn_conv_3x3': 3, 'rpn_out': 1, 'conv_new_1': 1}
@@ -246,7 +252,8 @@ class Trainer(object):
         """Frozen stem + res2, then res3..res5 keeping every ReLU output.  Returns (conv5, conv4, saved units, stage ends).
         at_conv4(conv4): called once conv4 exists, before res5 is queued (the RPN branch forks there)."""
         c = self.cfg
-        x = ops.stem_fused(data, self.w_stem, self.b_stem)
+        fb = self._frozen_backbone
+        x = fb.forward_res2(data) if fb is not None else ops.stem_fused(data, self.w_stem, self.b_stem)
         saved = []
         conv4 = None
         ends = {}
@@ -258,6 +265,8 @@ class Trainer(object):
                     at_conv4(conv4)
             if proj and stage > 2:
                 ends[stage - 1] = x
+            if stage == 2 and fb is not None:
+                continue                   # (ran inside forward_res2)
             if stage == 2:
                 fw = lambda n: self.frozen[n]
                 sc = self._conv(x, n1, stride=stride, w=fw(n1)) if proj else x
