@@ -460,6 +460,9 @@ int relnet_geometry_bias_bwd(const float* boxes, int box_stride, int box_off, co
 int relnet_relu_bwd(const void* dy, const void* y, const void* add /*or NULL*/, void* dx, long n, int dtype,
                     void* stream);
 
+/* out[c] += sum_r x[r, c]: the gradient of a bias (`FullyConnected` / `Convolution` bias, mx autograd) from the upstream gradient
+ * [rows, cols] (dtype: 0 fp32, 1 bf16; row stride ld elements), accumulated in fp32 (atomic per column and row chunk).               */
+int relnet_colsum_add(const void* x, long ld, long rows, int cols, int dtype, float* out, void* stream);
 /* mx.optimizer.SGD as set up in relation_rcnn/train_end2end.py:163-168 (momentum, wd, rescale_grad 1.0, no
  * clipping): mom = momentum*mom - lr*(rescale*grad + wd*w); w += mom.  fp32 master weights; w_bf16 (may be
  * NULL) receives the rounded copy the MFMA kernels read.                                                    */

@@ -2,6 +2,7 @@
 //  * relnet_relu_bwd    gradient through mx.symbol.Activation(act_type='relu') (and through the fused
 //                       conv + bias + [residual] + ReLU epilogues of the forward kernels): dx = dy * (y > 0),
 //                       optionally + an accumulated second gradient (the bottleneck's shortcut branch).
+//  * relnet_colsum_add  bias gradients: column sums of an upstream gradient accumulated into the flat gradient buffer.
 //  * relnet_sgd_update  mx.optimizer.SGD as configured by relation_rcnn/train_end2end.py:163-168
 //                       (momentum 0.9, wd 5e-4, rescale_grad 1.0, no gradient clipping):
 //                         mom = momentum * mom - lr * (rescale * grad + wd * w);  w += mom
@@ -46,6 +47,26 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const T* dy, const T* y, 
       else { g = bf2f(dy[i]); o = bf2f(y[i]); if (add) a = bf2f(add[i]); dx[i] = f2bf((o > 0.f ? g : 0.f) + a); }
     }
   }
+}
+
+// out[c] += sum over rows of x[r, c]  (bias gradients: the column sum of an upstream gradient [rows, cols], bf16 or fp32, row stride ld,
+// accumulated in fp32 into the flat gradient buffer).  Block = 64 columns x 4 row lanes over one chunk of rows; one fp32 atomic per
+// column per block.  Replaces `.float().sum(0)` + `add_` (a conversion, a reduction and an accumulation launch per bias).
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_add_kernel(const T* x, long ld, long rows, int cols, long rows_per_block, float* out) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, rows);
+  float acc = 0.f;
+  if (c < cols) {
+    for (long r = r0 + rl; r < r1; r += 4) {
+      if constexpr (sizeof(T) == 4) acc += x[r * ld + c];
+      else acc += bf2f(x[r * ld + c]);
+    }
+  }
+  part[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && c < cols) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 struct SgdArgs {
@@ -144,6 +165,19 @@ extern "C" int relnet_relu_bwd(const void* dy, const void* y, const void* add, v
   else if (dtype == RELNET_BF16) relu_bwd_kernel<unsigned short><<<(unsigned)blocks, 256, 0, s>>>((const unsigned short*)dy, (const unsigned short*)y, (const unsigned short*)add, (unsigned short*)dx, n);
   else RELNET_REQUIRE(false, "relnet_relu_bwd: unknown dtype %d", dtype);
   return check_launch("relnet_relu_bwd");
+}
+
+extern "C" int relnet_colsum_add(const void* x, long ld, long rows, int cols, int dtype, float* out, void* stream) {
+  RELNET_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "relnet_colsum_add: bad operand");
+  long nchunk = (rows + 511) / 512;
+  nchunk = nchunk < 1 ? 1 : (nchunk > 128 ? 128 : nchunk);
+  const long rpb = (rows + nchunk - 1) / nchunk;
+  dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + rpb - 1) / rpb));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == RELNET_F32) colsum_add_kernel<float><<<grid, 256, 0, s>>>((const float*)x, ld, rows, cols, rpb, out);
+  else if (dtype == RELNET_BF16) colsum_add_kernel<unsigned short><<<grid, 256, 0, s>>>((const unsigned short*)x, ld, rows, cols, rpb, out);
+  else RELNET_REQUIRE(false, "relnet_colsum_add: unknown dtype %d", dtype);
+  return check_launch("relnet_colsum_add");
 }
 
 extern "C" int relnet_sgd_update(float* w, float* mom, const float* grad, void* w_bf16, long n, float lr, float momentum,

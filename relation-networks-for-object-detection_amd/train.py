@@ -239,7 +239,12 @@ class Trainer(object):
         self._wq.flush()
 
     def _add_bgrad(self, name, db):
-        self.Bv.view(self.Bv.grad, name).add_(db.reshape(-1))
+        if db is not None:          # (None: already accumulated by T.colsum_add through _bg(name))
+            self.Bv.view(self.Bv.grad, name).add_(db.reshape(-1))
+
+    def _bg(self, name):
+        """fp32 view of `name`'s slice of the flat bias-gradient buffer: the target T.colsum_add / linear_bwd(bgrad_to=) accumulate into."""
+        return self.Bv.view(self.Bv.grad, name).view(-1)
 
     # ---- forward -------------------------------------------------------------------------------------------
     def _conv(self, x, name, stride=1, pad=0, dil=1, relu=False, resid=None, bias=None, out_dtype=None, w=None):
@@ -401,12 +406,12 @@ class Trainer(object):
             d_feat = d_feat.permute(0, 2, 3, 1).to(bt)          # NHWC memory already: one conversion pass
         g = T.relu_bwd(d_feat, feat)
         d_x, dw = T.conv1x1_bwd(conv5, self.w('conv_new_1'), g, w_t=self.wt('conv_new_1'), keep_splits=True, wgrad_to=self._wg('conv_new_1'))
-        self._add_bgrad('conv_new_1', g.float().sum((0, 1, 2)))
+        T.colsum_add(g, self._bg('conv_new_1'))
         # RPN head backward (joins the trunk at conv4)
         g_r, dw = T.conv1x1_bwd(r, self.w('rpn_out'), d_rpn, w_t=self.wt('rpn_out'), keep_splits=True, wgrad_to=self._wg('rpn_out'), relu_mask=r)
-        self._add_bgrad('rpn_out', d_rpn.float().sum((0, 1, 2)))
+        T.colsum_add(d_rpn, self._bg('rpn_out'))
         d_conv4_rpn, dw = T.conv3x3_bwd(conv4, self._dgrad_w('rpn_conv_3x3', 512), g_r, dil=1, keep_splits=True, wgrad_to=self._wg('rpn_conv_3x3'))
-        self._add_bgrad('rpn_conv_3x3', g_r.float().sum((0, 1, 2)))
+        T.colsum_add(g_r, self._bg('rpn_conv_3x3'))
         self._trunk_backward(saved, d_x, {'4b22': d_conv4_rpn})
         out['rois'] = rois_t
         out['label'] = labels_ohem
@@ -503,16 +508,16 @@ class Trainer(object):
             out.update(lo)
         # ================= backward =================
         d_cb = torch.cat([d_cls, d_bbox], 2).reshape(B * R, -1).to(bt)
-        d_x2, dw, db = T.linear_bwd(x2.reshape(B * R, -1), self.w('cls_bbox'), d_cb, w_t=self.wt('cls_bbox'), keep_splits=True, wgrad_to=self._wg('cls_bbox'))
+        d_x2, dw, db = T.linear_bwd(x2.reshape(B * R, -1), self.w('cls_bbox'), d_cb, w_t=self.wt('cls_bbox'), keep_splits=True, wgrad_to=self._wg('cls_bbox'), bgrad_to=self._bg('cls_bbox'))
         self._add_bgrad('cls_bbox', db)
         if d_x2_lnms is not None:
             d_x2 = d_x2.reshape(B, R, -1)
             d_x2[:, :N] += d_x2_lnms.to(d_x2.dtype)
         d_f2 = self._relation_bwd(2, mods[1], f2, x2, rois_t, d_x2.reshape(B, R, -1), N, key_count, caches[1])
-        d_x1, dw, db = T.linear_bwd(x1.reshape(B * R, -1), self.w('fc_new_2'), d_f2.reshape(B * R, -1), w_t=self.wt('fc_new_2'), keep_splits=True, wgrad_to=self._wg('fc_new_2'))
+        d_x1, dw, db = T.linear_bwd(x1.reshape(B * R, -1), self.w('fc_new_2'), d_f2.reshape(B * R, -1), w_t=self.wt('fc_new_2'), keep_splits=True, wgrad_to=self._wg('fc_new_2'), bgrad_to=self._bg('fc_new_2'))
         self._add_bgrad('fc_new_2', db)
         d_f1 = self._relation_bwd(1, mods[0], f1, x1, rois_t, d_x1.reshape(B, R, -1), N, key_count, caches[0])
-        d_pool, dw, db = T.linear_bwd(pooled2, self.w('fc_new_1'), d_f1.reshape(B * R, -1), w_t=self.wt('fc_new_1'), keep_splits=True, wgrad_to=self._wg('fc_new_1'))
+        d_pool, dw, db = T.linear_bwd(pooled2, self.w('fc_new_1'), d_f1.reshape(B * R, -1), w_t=self.wt('fc_new_1'), keep_splits=True, wgrad_to=self._wg('fc_new_1'), bgrad_to=self._bg('fc_new_1'))
         self._add_bgrad('fc_new_1', db)
         return d_pool, (x2, f1, cls_score, bbox_pred, labels_ohem, weights_ohem)
 
@@ -596,7 +601,7 @@ class Trainer(object):
         flat = (rank_idx.long() + (torch.arange(B, device=dev) * N).view(B, 1, 1)).view(-1)
         d_emb = torch.zeros((B * N, 128), device=dev, dtype=torch.float32)
         d_emb.index_add_(0, flat, d_x.reshape(-1, 128))                                         # take() backward
-        d_feat, dw, db = T.linear_bwd(feat2, self.w('roi_feat_embedding'), d_emb.to(bt), w_t=self.wt('roi_feat_embedding'), keep_splits=True, wgrad_to=self._wg('roi_feat_embedding'))
+        d_feat, dw, db = T.linear_bwd(feat2, self.w('roi_feat_embedding'), d_emb.to(bt), w_t=self.wt('roi_feat_embedding'), keep_splits=True, wgrad_to=self._wg('roi_feat_embedding'), bgrad_to=self._bg('roi_feat_embedding'))
         self._add_bgrad('roi_feat_embedding', db)
         # sort / slice backward -> cls_prob -> softmax backward (background column has no direct gradient)
         d_prob = torch.zeros((B, N, C), device=dev, dtype=torch.float32)

@@ -28,6 +28,15 @@ def relu_bwd(dy, y, add=None, out=None):
     return out
 
 
+def colsum_add(x, out):
+    """out[c] += sum over all leading dims of x[..., c]  (bias gradient accumulated in place; x bf16 / fp32 with a dense last dim,
+    out fp32 [C] -- a view of the flat gradient buffer)."""
+    C = x.shape[-1]
+    assert out.dtype == torch.float32 and out.numel() == C and out.is_contiguous() and x.stride(-1) == 1
+    x2 = x.reshape(-1, C)
+    _lib.call('relnet_colsum_add', x2.data_ptr(), x2.stride(0), x2.shape[0], C, _dt(x2), out.data_ptr(), _stream())
+
+
 def sgd_update(w, mom, grad, lr, momentum=0.9, wd=0.0005, rescale_grad=1.0, w_bf16=None):
     """In place on fp32 `w` / `mom`; optional bf16 copy refreshed in the same pass."""
     _chk(w, mom, grad, w_bf16)
@@ -81,7 +90,7 @@ def _tn_ok(dy2d, x):
             dy2d.stride(0) % 8 == 0 and dy2d.shape[1] % 8 == 0 and x.shape[-1] % 8 == 0 and dy2d.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
 
 
-def linear_bwd(x2d, w, dy2d, need_dx=True, w_t=None, keep_splits=False, wgrad_to=None, relu_mask=None):
+def linear_bwd(x2d, w, dy2d, need_dx=True, w_t=None, keep_splits=False, wgrad_to=None, relu_mask=None, bgrad_to=None):
     """y = x W^T + b  ->  (dx [P,K] in x's dtype | None, dW [N,K] fp32, db [N] fp32).
     wgrad_to = (grad [N,K] fp32 view, row_scale | None): the weight gradient is ACCUMULATED there by relnet_wgrad (one
     kernel straight from the row-major operands) and None is returned in its place.
@@ -96,7 +105,11 @@ def linear_bwd(x2d, w, dy2d, need_dx=True, w_t=None, keep_splits=False, wgrad_to
     if need_dx:
         w_t = ops.transpose_2d(w, pad_cols_to=gran) if w_t is None else w_t      # [K, pad(N)], zero padded
         dx = ops.gemm_nt(dyp, w_t) if relu_mask is None else ops.gemm_nt(dyp, w_t, resid=relu_mask, relu=2)
-    db = dy2d.float().sum(0)
+    db = None
+    if bgrad_to is not None:            # bias gradient accumulated straight into its slice of the flat buffer (one kernel)
+        colsum_add(dy2d, bgrad_to)
+    else:
+        db = dy2d.float().sum(0)
     if wgrad_to is not None and _tn_ok(dyp, x2d):
         _wg_call(wgrad_to, dyp, x2d, cout=N)
         return dx, None, db
