@@ -225,3 +225,24 @@ def test_weight_relayout_one_launch_for_all_layers():
                 want = w.view(co, 3, 3, ci).flip(1, 2).permute(3, 1, 2, 0).reshape(ci, 9 * co)
             assert got.shape == want.shape, (i, got.shape, want.shape)
             assert torch.equal(got, want), (i, shapes[i], rnd)
+
+
+@pytest.mark.parametrize('shape,dt', [((8, 38, 63, 256), torch.bfloat16), ((2464, 89), torch.float32), ((3, 5, 7, 72), torch.bfloat16),
+                                      ((70000, 64), torch.bfloat16), ((1, 1024), torch.float32)])
+def test_colsum_add_accumulates_bias_gradients(shape, dt):
+    """relnet_colsum_add: out[c] += sum over the leading dims of x[..., c] (bias gradient into the flat buffer) against a float64 sum
+    of the same (bf16-rounded) values; accumulates on top of what is there; a row-strided (sliced) 2-D operand."""
+    ops, T = _mods()
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g).to(dt).cuda()
+    C = shape[-1]
+    out = torch.full((C,), 0.5, device='cuda')
+    T.colsum_add(x, out)
+    want = x.double().reshape(-1, C).sum(0) + 0.5
+    scale = x.double().abs().reshape(-1, C).sum(0).max().item()
+    assert (out.double() - want).abs().max().item() <= 2e-6 * scale + 1e-5
+    if len(shape) == 2 and C > 8:
+        xs = x[:, :C - 8]                                # row stride > columns
+        out2 = torch.zeros(C - 8, device='cuda')
+        T.colsum_add(xs, out2)
+        assert (out2.double() - xs.double().sum(0)).abs().max().item() <= 2e-6 * scale + 1e-5
