@@ -69,6 +69,35 @@ __global__ __launch_bounds__(256) void colsum_add_kernel(const T* x, long ld, lo
   if (rl == 0 && c < cols) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+// bf16 rows with cols % 8 == 0 and 16-byte aligned rows: 16-byte loads, thread = (8-column group, row lane); block = 32 groups x 8 row lanes
+__global__ __launch_bounds__(256) void colsum_add_bf16x8_kernel(const unsigned short* x, long ld, long rows, int cols, long rows_per_block, float* out) {
+  __shared__ float part[8][32][9];
+  const int gq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = (blockIdx.x * 32 + gq) * 8;
+  const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, rows);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < cols) {
+    for (long r = r0 + rl; r < r1; r += 8) {
+      const uint4 v = *(const uint4*)(x + r * ld + c);
+      const unsigned int w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[2 * e] += __uint_as_float(w4[e] << 16); acc[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u); }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[rl][gq][e] = acc[e];
+  __syncthreads();
+  if (rl == 0 && c < cols) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += part[k][gq][e];
+      atomicAdd(out + c + e, t);
+    }
+  }
+}
+
 struct SgdArgs {
   float* w; float* mom; const float* grad; unsigned short* w_bf16;
   long n;
@@ -174,6 +203,11 @@ extern "C" int relnet_colsum_add(const void* x, long ld, long rows, int cols, in
   const long rpb = (rows + nchunk - 1) / nchunk;
   dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + rpb - 1) / rpb));
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == RELNET_BF16 && cols % 8 == 0 && ld % 8 == 0 && ((uintptr_t)x & 15) == 0) {
+    dim3 g8((unsigned)((cols / 8 + 31) / 32), grid.y);
+    colsum_add_bf16x8_kernel<<<g8, 256, 0, s>>>((const unsigned short*)x, ld, rows, cols, rpb, out);
+    return check_launch("relnet_colsum_add");
+  }
   if (dtype == RELNET_F32) colsum_add_kernel<float><<<grid, 256, 0, s>>>((const float*)x, ld, rows, cols, rpb, out);
   else if (dtype == RELNET_BF16) colsum_add_kernel<unsigned short><<<grid, 256, 0, s>>>((const unsigned short*)x, ld, rows, cols, rpb, out);
   else RELNET_REQUIRE(false, "relnet_colsum_add: unknown dtype %d", dtype);
