@@ -60,6 +60,9 @@ struct ChainArgs {
 // Nothing on the vector-memory path is issued inside the arithmetic (biases come from LDS): a load there would make the
 // compiler wait for the prefetch in front of it.
 // KSPLIT > 1 (MID = 512, res5; expand-only): the k range of a pass is cut in KSPLIT sub-steps so that a ring slot stays 32 KiB.
+// (measured and dropped, r04: vector-memory roles per wavefront for this form -- four wavefronts stream weights, four move the activations
+//  of all eight tiles, the mid-pass step only drains weight loads: 19.62 vs 19.59 ms per 54-image step, no gain; res5's expand is bound
+//  by its 2 MB weight stream per 256 pixels through the L2 -> LDS fill path)
 // MID = 256 with the second product (res4): chain256_roles_kernel below.
 // PROJ (MID = 64, resident weights; the first unit of res2, whose shortcut is a 1x1 projection of the unit's 64-channel input):
 //   x_next = relu(W3 . mid2 + Wp . x_in + (b3 + bp)) -- the projection is four more k-steps of the same accumulators instead of a
