@@ -289,10 +289,12 @@ __global__ __launch_bounds__(512) void bottleneck_chain_kernel(ChainArgs a) {
 // their mid1' accumulators alone are all the registers four B-waves have.
 // LDS: weights 2 x 32 KB | stage 4 tiles x 4 x 4 KB | mid1' staging 4 x 4 KB | biases 5 KB = 149 KB.
 // ---------------------------------------------------------------------------------------------------------------------------
+constexpr int kRolesLdsBytes = 2 * 32768 + 4 * 4 * 4096 + 4 * 4096 + (1024 + 256) * 4;      // weights | stage rings | mid1' staging | biases
 __global__ __launch_bounds__(512) void chain256_roles_kernel(ChainArgs a) {
   constexpr int MID = 256, COUT = 4 * MID, KS = MID / 16, RT = MID / 32, NP = COUT / 64, NSTEP = 2 * NP, NTL = 4, NBUF = 4;
   constexpr int W3P = KS * 1024, W1P = 2 * RT * 1024, SLOT = W3P + W1P, WBYTES = 2 * SLOT;
   constexpr int STG = NBUF * 4096, M1S = WBYTES + NTL * STG, BIAS = M1S + NTL * 4096;
+  static_assert(BIAS + (COUT + MID) * 4 == kRolesLdsBytes, "host launch and kernel disagree on the LDS layout");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -520,7 +522,7 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
     else if (mid == 128) bottleneck_chain_kernel<128, true><<<grid, 512, lds, (hipStream_t)stream>>>(a);
     else {
       const long nset = (ntile + 3) / 4;
-      chain256_roles_kernel<<<(unsigned)(nset < 256 ? nset : 256), 512, 152576, (hipStream_t)stream>>>(a);
+      chain256_roles_kernel<<<(unsigned)(nset < 256 ? nset : 256), 512, relnet::kRolesLdsBytes, (hipStream_t)stream>>>(a);
     }
   } else {
     if (mid == 64) bottleneck_chain_kernel<64, false, false><<<grid, 512, lds, (hipStream_t)stream>>>(a);

@@ -29,6 +29,9 @@ def test_bottleneck_chain_vs_two_convolutions(shape, mid):
     xn, m1 = ops.bottleneck_chain(m2, x, ops.pack_w_frag(w3), ops.pack_chain_w1(w1), b3, b1)
     xe, none = ops.bottleneck_chain(m2, x, ops.pack_w_frag(w3), None, b3, None)        # expand-only form: same x_next bits
     assert none is None and torch.equal(xe, xn)
+    xi = x.clone()                                                                      # in place over the shortcut operand: same bits again
+    xn_i, m1_i = ops.bottleneck_chain(m2, xi, ops.pack_w_frag(w3), ops.pack_chain_w1(w1), b3, b1, inplace=True)
+    assert xn_i.data_ptr() == xi.data_ptr() and torch.equal(xn_i, xn) and torch.equal(m1_i, m1)
     # (a) the two launches of the unfused path
     xn_ref = ops.conv2d_nhwc(m2, w3, b3, relu=True, resid=x)
     m1_ref = ops.conv2d_nhwc(xn_ref, w1, b1, relu=True)
