@@ -314,7 +314,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (default 54; 8 with --train)')
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (default 108 for the headline graph, 54 for the other inference graphs; 8 with --train)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-overlap', action='store_true', help='A/B: RPN head + proposal on the main stream instead of beside res5')
     ap.add_argument('--no-chain', action='store_true', help='A/B: res2 block boundaries as two convolution launches instead of relnet_bottleneck_chain')
@@ -341,7 +341,9 @@ def main():
     ap.add_argument('--stub', action='store_true', help='launcher dry run: gloo ranks on CPU, a stub step instead of the detector')
     a = ap.parse_args()
     if a.batch is None:
-        a.batch = 8 if a.train else 54
+        # 108 images: 1010 row tiles of 256 on the res4 maps = 3.95 rounds over 256 CUs (54: 505 = 1.97 rounds) and half the per-launch
+        # ramps per image: +2 % images/s over 54 on the same box (r04); the other graphs keep 54 (27 / 8 in other_configs)
+        a.batch = 8 if a.train else (108 if not (a.dcn or a.fpn or a.learn_nms or a.no_relation) else 54)
 
     # `python bench.py --gpus N` with no torchrun environment: start the N ranks ourselves (one process per GPU, RCCL over
     # xGMI) -- the reference trains over len(ctx) devices from one command too (train_end2end.py:69-71)
@@ -557,7 +559,7 @@ def main():
         if world == 1 and plain and not a.no_batch_sweep:
             res['batch_sweep'] = {'note': 'images/s of the same step at other images-per-GPU-per-step settings (hipGraph replay); '
                                           '1 = the reference protocol (BATCH_IMAGES: 1, SURVEY 8d)'}
-            for bsz in (1, 8):
+            for bsz in (1, 8, 54):
                 if bsz == a.batch:
                     continue
                 res['batch_sweep'][str(bsz)] = _replay_rate(det, bsz, a, D)

@@ -15,7 +15,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 WHAT=$1; shift
 TAG=${TAG:-r04_$WHAT}
 O=$R/gpurun_out/$TAG; mkdir -p $O
-F="--no-cpu-baseline --no-train-line --no-other-configs --no-parity --no-batch-sweep"
+F="--no-cpu-baseline --no-train-line --no-other-configs --no-parity --no-batch-sweep --batch 54"
 line() { python -c "import json,sys; d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{\"metric')][-1]); print(sys.argv[2], round(d['value'],1), 'img/s', round(d['ms_per_step'],3), 'ms', d['config'].get('images_per_gpu_per_step'))" "$1" "$2" 2>/dev/null || echo "$2 FAILED"; }
 case $WHAT in
   suite) ( time timeout 1800 python -m pytest tests -x -q -m gpu ) > $O/pytest_gpu.log 2>&1; tail -6 $O/pytest_gpu.log ;;
@@ -41,7 +41,7 @@ case $WHAT in
   prof)
     cd /tmp && export TMPDIR=/tmp
     P="--no-cpu-baseline --no-kernel-timing --no-parity --no-batch-sweep --no-train-line --no-other-configs"
-    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p54 -- python $R/bench.py $P > /tmp/p54.log 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p54 -- python $R/bench.py $P --batch 54 > /tmp/p54.log 2>&1
     cp $(find /tmp/p54 -name "*kernel_stats.csv" | head -1) $O/bench_b54_kernel_stats.csv
     rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python $R/bench.py $P --batch 1 --steps 50 > /tmp/p1.log 2>&1
     cp $(find /tmp/p1 -name "*kernel_stats.csv" | head -1) $O/bench_b1_kernel_stats.csv
