@@ -402,7 +402,7 @@ CHAIN_MIDS = (64, 128, 256)      # bottleneck widths relnet_bottleneck_chain is 
 CHAIN_EXPAND_MIDS = (64, 128, 256, 512)      # ... and for its expand + shortcut + ReLU form without the second product (res4, res5 too)
 
 
-CHAIN_MIN_PIXELS = {64: 16384, 256: 8192, 'streamed': 98304}     # tests lower these to run the chain kernels on small maps
+CHAIN_MIN_PIXELS = {64: 16384, 128: 65536, 256: 8192, 512: 49152, 'streamed': 98304}     # tests lower these to run the chain kernels on small maps
 
 
 def chain_worthwhile(pixels, mid):
@@ -410,7 +410,8 @@ def chain_worthwhile(pixels, mid):
     8 x 32 pixels, so they need >= ~1.5 sets per CU (256 CUs) to beat the tiled convolution kernels (measured: B = 1 / B = 8
     steps are slower with them on the small late-stage maps).  mid = 256 (res4: expand + next reduce in one role-specialised launch,
     sets of four tiles) replaces two launches and wins from 4 images of 600 x 1000 up (r04, same box, ms per step with / without:
-    2 images 3.17 / 2.87, 4 images 4.17 / 4.52, 8: 5.13 / 5.44, 27: 10.72 / 11.53, 40: 15.92 / 17.49)."""
+    2 images 3.17 / 2.87, 4 images 4.17 / 4.52, 8: 5.13 / 5.44, 27: 10.72 / 11.53, 40: 15.92 / 17.49).  res3 (mid 128) from ~7 images
+    (8 images: +0.7 %), res5's expand (mid 512) from ~21 (27 images: 11.00 -> 10.62 ms; at 8 images it loses 1.4 %)."""
     return pixels >= CHAIN_MIN_PIXELS[mid if mid in CHAIN_MIN_PIXELS else 'streamed']
 
 

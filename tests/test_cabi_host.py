@@ -232,4 +232,5 @@ def test_chain_weight_fragment_order_matches_the_header():
     assert ops.chain_worthwhile(54 * 150 * 250, 64) and ops.chain_worthwhile(54 * 38 * 63, 256)
     # (res4's role-specialised kernel replaces two launches and pays off from 4 images of 600 x 1000; the lock-step kernels need ~1.5 sets per CU)
     assert not ops.chain_worthwhile(38 * 63, 256) and not ops.chain_worthwhile(2 * 38 * 63, 256) and ops.chain_worthwhile(8 * 38 * 63, 256)
-    assert not ops.chain_worthwhile(75 * 125, 128) and not ops.chain_worthwhile(8 * 38 * 63, 512)
+    assert not ops.chain_worthwhile(75 * 125, 128) and ops.chain_worthwhile(8 * 75 * 125, 128)
+    assert not ops.chain_worthwhile(8 * 38 * 63, 512) and ops.chain_worthwhile(27 * 38 * 63, 512)

@@ -309,7 +309,7 @@ def test_benched_trunk_configuration_in_network(rn):
     det = detector.Detector(p, dtype=torch.bfloat16, im_hw=(H, W))
     saved = dict(ops.CHAIN_MIN_PIXELS)
     try:
-        ops.CHAIN_MIN_PIXELS.update({64: 0, 256: 0, 'streamed': 0})
+        ops.CHAIN_MIN_PIXELS.update({k: 0 for k in ops.CHAIN_MIN_PIXELS})
         rep = OPAR.stagewise(det, data, im_info, p, images=[0, 3])
         out = det.forward(data, im_info, keep_features=True)
     finally:
