@@ -3,7 +3,7 @@
 
   python bench.py --gpus N --steps K --warmup W         (N>1: launched by torch.distributed.run)
 
-One step = one pass of the hot path over a batch of `--batch` synthetic 600x1000 images per
+One step = one pass of the hot path over a batch of `--batch` (default 108) synthetic 600x1000 images per
 GPU: ResNet-101 conv1..conv5 + RPN -> proposal (300 rois) -> ROIPooling -> 2FC + 2 relation
 modules (16 heads, d=1024) -> cls/bbox -> decode -> per-class soft-NMS -> top-100
 (BASELINE.json configs[1], bf16).  Inputs are resident in HBM before the timed region.
@@ -21,7 +21,7 @@ The JSON line also carries
   parity        the timed detector, on images of the timed batch, checked stage by stage against the oracle
                 (oracle/parity.py): identical proposal rows, ROIPooling mismatches, max |cls_prob| error,
                 detection-set agreement (N = 1 only).
-  batch_sweep   images/s of the same step at 1 (the reference's BATCH_IMAGES) and 8 images per GPU per step.
+  batch_sweep   images/s of the same step at 1 (the reference's BATCH_IMAGES), 8 and 54 (the default of rounds 1-4) images per GPU per step.
   train         BASELINE configs[2] on the same N GPUs: training step of relation + learn-NMS end2end with ONE
                 summed RCCL all-reduce of the 68.3 M gradients per step (the path the 1 -> 8 GPU scaling target
                 is stated on; `value` stays the inference figure so that the N = 1..8 curve is one metric).
