@@ -234,3 +234,23 @@ def test_chain_weight_fragment_order_matches_the_header():
     assert not ops.chain_worthwhile(38 * 63, 256) and not ops.chain_worthwhile(2 * 38 * 63, 256) and ops.chain_worthwhile(8 * 38 * 63, 256)
     assert not ops.chain_worthwhile(75 * 125, 128) and ops.chain_worthwhile(8 * 75 * 125, 128)
     assert not ops.chain_worthwhile(8 * 38 * 63, 512) and ops.chain_worthwhile(27 * 38 * 63, 512)
+
+
+def test_tile_selection_rules_without_a_gpu():
+    """relnet_gemm_pick_tile is pure host logic (csrc/gemm.hip:pick_tile): the benchmark's layer shapes land on the tiles DESIGN.md
+    section 4 names -- the asm ring tile (19) for the shortcut-free 256-column layers of a 54-image step, 128 x 64 tiles at 8 images,
+    64 x 64 tiles with two / four k-slabs per barrier (20 / 21) when a launch has fewer workgroups than CUs (one image per step)."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import lib
+    L = lib.load()
+    assert L.relnet_gemm_tile_count() == 21
+    bf16 = 1
+    px = lambda b: b * 38 * 63
+    pick = lambda M, N, K: L.relnet_gemm_pick_tile(M, N, K, 1, bf16)
+    assert pick(px(54), 256, 2304) == 19 and pick(px(54), 512, 4608) == 19 and pick(px(54), 512, 9216) == 19      # res4 / res5 / RPN 3x3
+    assert pick(px(54), 256, 1024) == 19 and pick(px(108), 256, 2304) == 19
+    assert pick(px(8), 256, 2304) == 4 and pick(px(8), 256, 1024) == 4                                               # 75 tiles of 256 x 256 would idle most CUs
+    assert pick(px(1), 256, 2304) == 21 and pick(px(1), 256, 1024) == 20          # 152 workgroups of 64 x 64: two (K < 2048) / four slabs per barrier
+    assert pick(px(1), 512, 9216) == 5                                               # 304 workgroups: more than CUs
+    assert pick(px(2), 256, 2304) == 5                                                                               # 300 workgroups: the plain 64 x 64 tile
+    assert pick(54 * 75 * 125, 128, 1152) == 3                                                                       # res3 3x3: 128 columns
