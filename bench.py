@@ -172,6 +172,22 @@ def _replay_rate(det, bsz, a, D, replays=200, windows=5, step=None):
             'protocol': '%d windows x %d replays after >= 1 s of warm replays; median window (min / max beside it)' % (windows, per_window)}
 
 
+def _side_figure(fn, what):
+    """Run one SIDE figure of the default line (training rates, other configs).  An exception there -- out of memory, a collective
+    error, a diverged 5-step random-init run -- is recorded as {'error': ...} under the figure's key instead of losing the headline
+    line.  Every rank calls the same sequence of side figures, so a failure that every rank sees (the reduced
+    non-finite check) leaves them in step; a one-rank failure inside a collective cannot be repaired from here."""
+    try:
+        return fn()
+    except (Exception, SystemExit) as ex:          # noqa: BLE001 -- the line must survive any side figure
+        sys.stderr.write('bench.py: side figure %s failed: %s: %s\n' % (what, type(ex).__name__, str(ex)[:300]))
+        try:
+            torch.cuda.empty_cache()
+        except Exception:
+            pass
+        return {'error': '%s: %s' % (type(ex).__name__, str(ex)[:300])}
+
+
 def _fpn_proposals(batch, n_rois, im_h, im_w, g):
     """Given proposals of the FPN graphs (HAS_RPN: false): log-uniform sizes over all pyramid levels."""
     side = torch.exp(torch.empty(batch, n_rois).uniform_(math.log(16), math.log(640), generator=g))
@@ -205,8 +221,9 @@ def other_configs(a, rank, world, D):
         else:
             det = detector.Detector(params, dtype=torch.bfloat16, device='cuda', cfg=cfg)
             step = lambda: det.forward(data, im_info)
-        r = _replay_rate(det, bsz, a, D, replays=30, windows=3, step=step)
-        r.update(images_per_gpu_per_step=bsz, n_gpus=world, images_per_s_all_gpus=r['images_per_s'] * world)
+        r = _side_figure(lambda: _replay_rate(det, bsz, a, D, replays=30, windows=3, step=step), key)
+        if 'error' not in r:
+            r.update(images_per_gpu_per_step=bsz, n_gpus=world, images_per_s_all_gpus=r['images_per_s'] * world)
         out[key] = r
         del det, step
         torch.cuda.empty_cache()
@@ -214,14 +231,15 @@ def other_configs(a, rank, world, D):
                                ('configs4_fpn_relation_learn_nms_training', False, True, 2)):
         ta = argparse.Namespace(**vars(a))
         ta.batch, ta.learn_nms, ta.dcn, ta.fpn, ta.steps, ta.warmup, ta.no_graph = bsz, True, dcn, fpn, 5, 2, False
-        tr = bench_train(ta, rank, world, D, emit=False)
+        tr = _side_figure(lambda: bench_train(ta, rank, world, D, emit=False, fatal=False), key)
         if rank == 0:
-            out[key] = {k: tr[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'n_gpus', 'weights_finite_on_all_ranks')}
-            out[key]['images_per_gpu_per_step'] = bsz
+            out[key] = tr if (tr is None or 'error' in tr) else {k: tr[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'n_gpus', 'weights_finite_on_all_ranks')}
+            if out[key] is not None:
+                out[key]['images_per_gpu_per_step'] = bsz
     return out if rank == 0 else None
 
 
-def bench_train(a, rank, world, D, emit=True):
+def bench_train(a, rank, world, D, emit=True, fatal=True):
     """Training throughput of the relation end2end graph (reference config ..._end2end_relation_8epoch.yaml): one step =
     forward + backward over `batch` images per GPU, ONE summed all-reduce of the 67.7 M trainable gradients, SGD."""
     import numpy as np
@@ -271,7 +289,7 @@ def bench_train(a, rank, world, D, emit=True):
                 graph.replay()
             else:
                 out = tr.forward_backward(*batch)
-            tr.all_reduce()
+            tr.all_reduce(wait=False)      # launches the buckets the backward pass has not announced; update() waits bucket by bucket
             tr.update()
         fence()
         elapsed = time.perf_counter() - t0
@@ -281,8 +299,15 @@ def bench_train(a, rank, world, D, emit=True):
         sys.stderr.write('bench.py: rank %d: non-finite weights after the training steps\n' % rank)
     ok = D.sum_over_ranks(float(ok), device='cuda') == float(world)
     if not ok and not os.environ.get('RELNET_BENCH_ONE_DEVICE'):
-        # a diverged run must not be recorded as a throughput number (every rank sees the same `ok`: they leave together)
-        raise SystemExit('bench.py: non-finite weights on at least one rank after %d training steps: refusing to report a rate' % a.steps)
+        # a diverged run must not be recorded as a throughput number (every rank sees the same `ok`: they leave together).  The
+        # stand-alone --train run exits non-zero; a SIDE figure of the default line (fatal=False) is dropped with the reason recorded,
+        # so that it cannot take the headline line down with it
+        msg = 'non-finite weights on at least one rank after %d training steps: refusing to report a rate' % a.steps
+        if fatal:
+            raise SystemExit('bench.py: ' + msg)
+        del tr
+        torch.cuda.empty_cache()
+        return {'error': msg} if rank == 0 else None
     res = None
     if rank == 0:
         images = world * B * a.steps
@@ -571,18 +596,30 @@ def main():
         del det
         torch.cuda.empty_cache()
         ta = argparse.Namespace(**vars(a))
-        ta.batch, ta.learn_nms, ta.steps, ta.warmup = 8, True, min(a.steps, 10), 2
-        tr_res = bench_train(ta, rank, world, D, emit=False)
-        ta.batch, ta.steps = 16, min(a.steps, 6)          # the same step at 16 images per GPU (larger GEMMs fill the chip better)
-        tr16 = bench_train(ta, rank, world, D, emit=False)
+        keys = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'n_gpus', 'config', 'losses', 'weights_finite_on_all_ranks')
+        sub = ('value', 'ms_per_step', 'steps')
+
+        def train_at(bsz, steps):
+            ta.batch, ta.learn_nms, ta.steps, ta.warmup = bsz, True, steps, 2
+            return _side_figure(lambda: bench_train(ta, rank, world, D, emit=False, fatal=False), 'train@%d' % bsz)
+        tr_res = train_at(8, min(a.steps, 10))
+        tr16 = train_at(16, min(a.steps, 6))          # the same step at 16 images per GPU (larger GEMMs fill the chip better)
+        # ... and at ONE image per GPU: the reference's own training protocol (BATCH_IMAGES: 1 per device,
+        # cfgs/resnet_v1_101_coco_trainvalminus_rcnn_end2end_relation_learn_nms_8epoch.yaml:80, train_end2end.py:70-71)
+        tr1 = train_at(1, min(a.steps, 10))
         if rank == 0:
-            res['train'] = {k: tr_res[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'n_gpus', 'config', 'losses', 'weights_finite_on_all_ranks')}
-            res['train']['at_16_images_per_gpu'] = {k: tr16[k] for k in ('value', 'ms_per_step', 'steps')}
+            pick = lambda r, ks: r if (r is None or 'error' in r) else {k: r[k] for k in ks}
+            res['train'] = pick(tr_res, keys) or {}
+            res['train']['at_16_images_per_gpu'] = pick(tr16, sub)
+            res['train']['at_1_image_per_gpu'] = pick(tr1, sub)
+            if tr1 is not None and 'error' not in tr1:
+                res['train']['at_1_image_per_gpu']['note'] = ("the reference's own protocol: BATCH_IMAGES 1 per device (cfgs/..._rcnn_end2end_relation_"
+                                                               "learn_nms_8epoch.yaml:80); ~700 launches of a few microseconds each, launch / latency bound")
     if plain_graph and not a.no_other_configs:
         if 'det' in locals():
             del det
         torch.cuda.empty_cache()
-        oc = other_configs(a, rank, world, D)
+        oc = _side_figure(lambda: other_configs(a, rank, world, D), 'other_configs')
         if rank == 0:
             res['other_configs'] = oc
     if rank == 0:

@@ -402,6 +402,34 @@ typedef struct relnet_relayout_desc {
 } relnet_relayout_desc;
 int relnet_weight_relayout(const void* table, int n, int total_tiles, void* stream);
 
+/* The MFMA-fragment-order copies of the TRAINED weights that relnet_bottleneck_chain reads, all layers in one launch per step
+ * (the training-time twin of relnet_pack_w_frag, which inference runs once at load time; SYM_BASE res3..res5 branch2c / branch2a).
+ * mode 0: relnet_pack_w_frag order (W3 of the expand product); mode 1: the accumulator-permuted order of the next unit's reduce weights
+ * (lane l, slot t <- W[32 nb + (l & 31)][16 kb + 8 (t >> 2) + 4 (l >> 5) + (t & 3)]).  N % 32 == 0, K % 16 == 0, ldw % 8 == 0.
+ * table: DEVICE array; block_start = exclusive prefix of ceil((N / 32) (K / 16) 64 / 256); total_blocks = the sum.                 */
+typedef struct relnet_fragpack_desc {
+  const void* src; void* dst;
+  long ldw;
+  int N, K, mode, block_start;
+} relnet_fragpack_desc;
+int relnet_weight_fragpack(const void* table, int n, int total_blocks, void* stream);
+
+/* C = (A W^T + resid) where mask > 0, else 0 (bf16 in / out, batch 1): the data gradient through `relu(conv1x1(.) + shortcut)` of a
+ * residual unit (autograd of resnet_v1_101_rcnn_base.py res*_relu after broadcast_add) in one launch.  resid (may be NULL) and mask
+ * have C's layout (row stride ldc); K % 64 == 0, N % 8 == 0, 16-byte aligned rows.                                                  */
+int relnet_gemm_nt_mask(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const void* resid, const void* mask,
+                        int M, int N, int K, void* stream);
+
+/* Backward of the relation module's projections (autograd of SYM_REL:120-129,146-150): the fp32 gradients of the attention backward --
+ * dq [B][N][d], dk and dvw [B][M][d], M <= N -- rounded to bf16 into ONE operand out [B][N][3 d] = (dQ | dK | dVW), key blocks zero for
+ * rows >= M: dF = out . [Wq; Wk; Wout] and d[Wq; Wk; Wout] = out^T F are then one GEMM and one weight-gradient product.  d % 8 == 0.  */
+int relnet_relation_bwd_pack(const float* dq, const float* dk, const float* dvw, void* out, int B, int N, int M, int d, void* stream);
+
+/* Adjoint of the learn-NMS head's per-class sort + take (symbols/..._learn_nms.py:438-446):
+ * d_prob[b][rank_idx[b][c][f]][c] += d_sorted[b][f][c]; d_prob [B][N][C] fp32 zeroed by the caller, rank_idx [B][C][F] int32
+ * (negative = padding, skipped), d_sorted [B][F][C].                                                                               */
+int relnet_lnms_scatter_bwd(const float* d_sorted, const int* rank_idx, float* d_prob, int B, int N, int C, int F, void* stream);
+
 /* q [B][N][..], k [B][M][..] as in the forward; kt = K^T [B][H*64][>=Mpad] and qt = Q^T, dyt = dY^T
  * [B][H*64][>=Npad] zero padded; vw = F_K Wout^T [B][M][H*64] (not transposed); bias = fp32 log G of the forward;
  * dy / y = gradient / value of the module output [B][N][H*64] (y includes bout).  Writes prob (softmax) and dlog

@@ -125,8 +125,12 @@ class Backbone(object):
     in torch.nn.functional.conv2d (used for the float32 parity path)."""
 
     def __init__(self, params, dtype=torch.bfloat16, device='cuda', channels_last=True, impl=None, stem='hip', dcn=False,
-                 fpn=False, chain=True):
+                 fpn=False, chain=True, frozen_only=False):
+        """frozen_only: pack conv1 + res2 only (what `forward_res2` runs): the part the training step never updates
+        (cfgs/*.yaml FIXED_PARAMS) -- the Trainer keeps res3 .. heads in its own flat buffers, a second bf16 copy of them here would
+        be a few hundred MB of stale weights."""
         self.dtype, self.device, self.dcn, self.fpn = dtype, device, dcn, fpn
+        self.frozen_only = frozen_only
         self.use_chain = chain
         env = os.environ.get('RELNET_STAGE_SPLIT')        # A/B knob: '4:2,5:4' = stage:sub-batches ('0' / unset: no split)
         if env not in (None, '', '0'):
@@ -134,6 +138,8 @@ class Backbone(object):
         if os.environ.get('RELNET_INPLACE_EXPAND') is not None:
             self.inplace_expand = os.environ['RELNET_INPLACE_EXPAND'] not in ('', '0')
         self.impl = impl or ('hip' if dtype == torch.bfloat16 else 'miopen')
+        if self.impl == 'hip' and torch.device(device).type == 'cuda':
+            ops.asm_selfcheck()          # tile 19 (AGPR accumulators across asm statements) against the compiler-scheduled tile, once per process
         self.stem = stem
         assert self.impl in ('hip', 'miopen') and (self.impl == 'miopen' or dtype == torch.bfloat16)
         self.mf = torch.channels_last if channels_last else torch.contiguous_format
@@ -142,10 +148,14 @@ class Backbone(object):
         self.wf = {}          # name -> fragment-order weight copy (panel kernel)
         self.b32 = {}
         for conv, bn, oc, ic, k in conv_bn_names():
+            if frozen_only and not conv.startswith(('conv1', 'res2')):
+                continue
             w, b = fold_bn(params[conv + '_weight'], params[bn + '_gamma'], params[bn + '_beta'],
                            params[bn + '_moving_mean'], params[bn + '_moving_var'])
             self._put(conv, w, b)
-        if fpn:     # FPN neck instead of the RPN head / conv_new_1 (HAS_RPN: false in the FPN relation configs)
+        if frozen_only:
+            pass
+        elif fpn:     # FPN neck instead of the RPN head / conv_new_1 (HAS_RPN: false in the FPN relation configs)
             for lvl in (32, 16, 8, 4):
                 for k in ('1x1', '3x3'):
                     name = 'fpn_ft%d_%s' % (lvl, k)
@@ -156,9 +166,9 @@ class Backbone(object):
             # both 1x1 RPN outputs in one convolution: 24 score + 48 delta channels
             self._put('rpn_out', torch.cat([params['rpn_cls_score_weight'], params['rpn_bbox_pred_weight']], 0),
                       torch.cat([params['rpn_cls_score_bias'], params['rpn_bbox_pred_bias']], 0))
-        self.units = unit_names(fpn)
+        self.units = [u for u in unit_names(fpn) if not frozen_only or u[0] == 2]
         self.wp_dcn = {}
-        if dcn:     # res5{a,b,c}_branch2b become DeformableConvolution(num_deformable_group=4) fed by a 72-channel offset conv
+        if dcn and not frozen_only:     # res5{a,b,c}_branch2b become DeformableConvolution(num_deformable_group=4) fed by a 72-channel offset conv
             for u in 'abc':
                 name = 'res5%s_branch2b' % u
                 self._put(name + '_offset', params[name + '_offset_weight'], params[name + '_offset_bias'])

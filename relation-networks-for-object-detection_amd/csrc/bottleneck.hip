@@ -543,7 +543,7 @@ extern "C" int relnet_bottleneck_chain_proj(const void* mid2, const void* x_in, 
   RELNET_REQUIRE(mid2 && x_in && w3f && wpf && b3p && x_next, "relnet_bottleneck_chain_proj: null operand");
   RELNET_REQUIRE((w1f && b1 && mid1_next) || (!w1f && !b1 && !mid1_next), "relnet_bottleneck_chain_proj: w1f, b1 and mid1_next are given together (or all NULL)");
   RELNET_REQUIRE(mid == 64, "relnet_bottleneck_chain_proj: mid = %d unsupported (64)", mid);
-  RELNET_REQUIRE(P > 0 && P < (1L << 31), "relnet_bottleneck_chain_proj: bad pixel count %ld", P);
+  RELNET_REQUIRE(P > 0 && P * 8 * mid < (1L << 32), "relnet_bottleneck_chain_proj: bad pixel count %ld (x_next is addressed with 32-bit byte offsets: the 4 mid-channel map must stay below 4 GiB)", P);
   ChainArgs a;
   a.m2 = (const unsigned short*)mid2; a.x = nullptr; a.w3f = (const uint4*)w3f; a.w1f = (const uint4*)w1f;
   a.b3 = b3p; a.b1 = b1; a.xn = (unsigned short*)x_next; a.m1 = (unsigned short*)mid1_next; a.P = (int)P;

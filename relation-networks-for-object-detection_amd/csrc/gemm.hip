@@ -34,6 +34,9 @@ struct GemmArgs {
   long long* phase_ts;     // debug (relnet_gemm_debug_phase_ts): per workgroup 8 words -- wall clock (100 MHz) at entry, k-loop start, k-loop end,
                            // exit, and the shader cycles entry -> k-loop end; nullptr = off
   int korder;              // ring kernels, R*S > 1: 1 = walk k as (channel chunk, tap) instead of (tap, channel chunk) -- see launch_ring
+  const void* mask;        // relu == 3 (relnet_gemm_nt_mask, MASK instantiations of gemm_nt_bf16_kernel only): C = (A W^T + resid) where mask > 0, else 0;
+                           // same layout / dtype as C (bf16).  The backward of `x_next = relu(conv(..) + x)`: the shortcut gradient rides as
+                           // `resid`, the saved forward activation as `mask` -- one launch instead of GEMM + relnet_relu_bwd
 };
 
 template <typename TOUT> __device__ __forceinline__ void store_out(TOUT* p, float v);
@@ -138,7 +141,7 @@ __device__ __forceinline__ void glds16_asm(const void* src, unsigned lds_byte_ad
 
 // BM x BN workgroup tile, WM x WN waves (each wave: TM x TN MFMA tiles of 32x32), BK = 64,
 // two LDS stages filled by global_load_lds.
-template <int BM, int BN, int WM, int WN, typename TOUT, int MODE, int KU = 1>
+template <int BM, int BN, int WM, int WN, typename TOUT, int MODE, int KU = 1, bool MASK = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) {
   constexpr bool CONV = MODE == 1;       // NHWC implicit GEMM, Cin % 64 == 0
   constexpr bool STEM = MODE == 2;       // 7x7/2 stem on a zero-padded NHWC4 image (see relnet_stem_conv7)
@@ -344,6 +347,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
         *(float4*)(ct + row * CLD + col) = make_float4(acc[i][j][4 * gq], acc[i][j][4 * gq + 1],
                                                        acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]);
       }
+    // MASK: the band's mask rows are requested before the barrier, so their latency overlaps the accumulator hand-over through LDS
+    uint4 mpre[MASK ? NP : 1];
+    if constexpr (MASK) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int m = out_row(i, p);
+        mpre[p] = (m >= 0 && n + VEC <= g.N) ? *(const uint4*)((const TOUT*)g.mask + (long)m * g.ldc + n) : make_uint4(0, 0, 0, 0);
+      }
+    }
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -370,6 +382,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
           if (g.relu == 1) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if constexpr (MASK) {
+            const unsigned int mw[4] = {mpre[p].x, mpre[p].y, mpre[p].z, mpre[p].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[2 * e] = bf2f(mw[e] & 0xffff) > 0.f ? v[2 * e] : 0.f;
+              v[2 * e + 1] = bf2f(mw[e] >> 16) > 0.f ? v[2 * e + 1] : 0.f;
+            }
           }
           *(uint4*)cp = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
         } else {
@@ -2258,6 +2278,43 @@ extern "C" int relnet_gemm_nt(const void* A, long lda, long strideA, const void*
     RELNET_REQUIRE(false, "relnet_gemm_nt: unknown in_dtype %d", in_dtype);
   }
   return check_launch("relnet_gemm_nt");
+}
+
+// C = (A W^T + resid) masked by (mask > 0): the data gradient through `x_next = relu(conv1x1(.) + x)` of a residual unit in ONE launch --
+// `resid` = the gradient that arrives over the identity shortcut, `mask` = the saved forward activation whose ReLU the gradient passes
+// (MXNet's autograd of Activation('relu') after broadcast_add, resnet_v1_101_rcnn_base.py: res*_relu).  bf16 in / out, batch 1;
+// resid (may be NULL) and mask share C's layout.  Runs on the LDS-tiled kernel's MASK instantiations (the tile pick_tile would choose for a
+// residual GEMM of this shape); replaces relnet_gemm_nt(resid) + relnet_relu_bwd (one more pass over three [M, N] maps).
+template <int BM, int BN, int WM, int WN>
+static void launch_cfg_mask(GemmArgs g, hipStream_t s) {
+  const int ntile = (g.N + BN - 1) / BN;
+  const bool swz = g_swizzle && ntile > 1 && (long)ntile * ((g.M + BM - 1) / BM) >= 16;
+  g.n_loop = 1;
+  dim3 grid(ntile, (g.M + BM - 1) / BM, 1);
+  g.xcd_swizzle = swz ? 1 : 0;
+  gemm_nt_bf16_kernel<BM, BN, WM, WN, unsigned short, 0, 1, true><<<grid, 64 * WM * WN, 0, s>>>(g);
+}
+
+extern "C" int relnet_gemm_nt_mask(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const void* resid,
+                                   const void* mask, int M, int N, int K, void* stream) {
+  RELNET_REQUIRE(A && W && C && mask, "relnet_gemm_nt_mask: null operand");
+  RELNET_REQUIRE(M > 0 && N > 0 && K > 0, "relnet_gemm_nt_mask: bad shape M=%d N=%d K=%d", M, N, K);
+  RELNET_REQUIRE(K % 64 == 0 && lda % 8 == 0 && ldw % 8 == 0 && N % 8 == 0 && ldc % 8 == 0,
+                 "relnet_gemm_nt_mask: K %% 64, N %% 8 and ld %% 8 required (N=%d K=%d lda=%ld ldw=%ld ldc=%ld)", N, K, lda, ldw, ldc);
+  RELNET_REQUIRE((((uintptr_t)C | (uintptr_t)mask | (uintptr_t)resid) & 15) == 0, "relnet_gemm_nt_mask: C, resid and mask must be 16-byte aligned");
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.resid = resid; g.mask = mask;
+  g.M = M; g.N = N; g.K = K; g.bias_mode = 0; g.relu = 3;
+  hipStream_t s = (hipStream_t)stream;
+  int cfg = g_force_tile;
+  if (!(cfg >= 1 && cfg <= 5)) cfg = pick_tile(M, N, K, 1, RELNET_BF16, 1);
+  switch (cfg) {
+    case 1: launch_cfg_mask<256, 256, 2, 4>(g, s); break;
+    case 4: launch_cfg_mask<128, 64, 2, 2>(g, s); break;
+    case 5: case 20: case 21: launch_cfg_mask<64, 64, 2, 2>(g, s); break;
+    default: launch_cfg_mask<128, 128, 2, 2>(g, s); break;
+  }
+  return check_launch("relnet_gemm_nt_mask");
 }
 
 // NHWC convolution as an implicit GEMM on the bf16 MFMA kernel (reference: the Convolution

@@ -180,6 +180,91 @@ __global__ __launch_bounds__(256) void weight_relayout_kernel(const RelayoutProb
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// relnet_weight_fragpack: the MFMA-fragment-order copies of the TRAINED weights the chain kernels read (csrc/bottleneck.hip), all
+// layers in one launch per step -- the training-time twin of relnet_pack_w_frag / ops.pack_chain_w1, which inference runs once at
+// load time.  Thread = one 16-byte fragment slot:
+//   mode 0 (W3, expand product; relnet_pack_w_frag order)   block (n / 32, k / 16), lane l <- W[32 nb + (l & 31)][16 kb + 8 (l >> 5) + 0..7]
+//   mode 1 (W1', the next unit's reduce; ops.pack_chain_w1)  block (n / 32, k / 16), lane l, slot t <- W[32 nb + (l & 31)][16 kb + 8 (t >> 2) + 4 (l >> 5) + (t & 3)]
+//          (the contraction index in the order the accumulator registers of the expand product hold it)
+// table: DEVICE array; block_start = exclusive prefix of ceil(slots / 256).
+// ---------------------------------------------------------------------------------------
+struct FragPackProblem {            // mirrors relnet_fragpack_desc
+  const unsigned short* src; uint4* dst;
+  long ldw;
+  int N, K, mode, block_start;
+};
+
+__global__ __launch_bounds__(256) void weight_fragpack_kernel(const FragPackProblem* tab, int n) {
+  int lo = 0, hi = n - 1;
+  const int bid = blockIdx.x;
+  while (lo < hi) {                                 // last problem with block_start <= bid
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].block_start <= bid) lo = mid; else hi = mid - 1;
+  }
+  const FragPackProblem p = tab[lo];
+  const long t = (long)(bid - p.block_start) * 256 + threadIdx.x;
+  const int kblocks = p.K / 16;
+  const long total = (long)(p.N / 32) * kblocks * 64;
+  if (t >= total) return;
+  const int l = (int)(t & 63);
+  const long blk = t >> 6;
+  const int kb = (int)(blk % kblocks), nb = (int)(blk / kblocks);
+  const unsigned short* row = p.src + (long)(nb * 32 + (l & 31)) * p.ldw + kb * 16;
+  if (p.mode == 0) {
+    p.dst[t] = *(const uint4*)(row + 8 * (l >> 5));
+  } else {
+    const uint2 a = *(const uint2*)(row + 4 * (l >> 5)), b = *(const uint2*)(row + 8 + 4 * (l >> 5));
+    p.dst[t] = make_uint4(a.x, a.y, b.x, b.y);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// relnet_relation_bwd_pack: the three fp32 gradients the attention backward kernels produce -- dQ [B][N][d], dK and dVW [B][M][d]
+// (M <= N keys = the first M rows) -- rounded to bf16 into ONE row-major operand A3 [B][N][3 d] = (dQ | dK | dVW), rows >= M of the
+// key blocks zero.  With it the projections' backward is one GEMM and one weight-gradient product:
+//   dF = A3 . [Wq; Wk; Wout]  (K = 3 d; the residual gradient rides in the epilogue),   d[Wq; Wk; Wout] = A3^T F
+// instead of two GEMMs, two products and ~10 elementwise launches (zero fill, two strided copies, conversions, adds).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relation_bwd_pack_kernel(const float* dq, const float* dk, const float* dvw, unsigned short* out,
+                                                                int N, int M, int d, long total8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
+    const int per_row = 3 * d / 8;
+    const long row = i / per_row;                     // b * N + n
+    const int c = (int)(i - row * per_row) * 8;       // column in [0, 3 d)
+    const int n = (int)(row % N);
+    const long b = row / N;
+    const int blk = c / d, cc = c - blk * d;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (blk == 0) {
+      const float* s = dq + row * d + cc;
+      v0 = *(const float4*)s; v1 = *(const float4*)(s + 4);
+    } else if (n < M) {
+      const float* s = (blk == 1 ? dk : dvw) + (b * M + n) * (long)d + cc;
+      v0 = *(const float4*)s; v1 = *(const float4*)(s + 4);
+    }
+    *(uint4*)(out + row * 3 * d + c) = make_uint4(pack_bf16x2(v0.x, v0.y), pack_bf16x2(v0.z, v0.w), pack_bf16x2(v1.x, v1.y), pack_bf16x2(v1.z, v1.w));
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// relnet_lnms_scatter_bwd: adjoint of the learn-NMS head's per-class sort + slice (symbols/..._learn_nms.py:438-446: argsort of the
+// class scores, take of the first_n rows):  d_prob[b][rank_idx[b][c][f]][c] += d_sorted[b][f][c].  One thread per (b, c, f);
+// replaces torch's index_put_(accumulate=True), which sorts its 64 000 indices first (~12 launches).  Entries with a negative
+// rank (padding of a short proposal list) are skipped.  d_prob must be zeroed by the caller.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lnms_scatter_bwd_kernel(const float* d_sorted, const int* rank_idx, float* d_prob, int B, int N, int C, int F) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * C * F) return;
+  const int f = (int)(i % F);
+  const int c = (int)((i / F) % C);
+  const long b = i / ((long)F * C);
+  const int r = rank_idx[i];
+  if (r < 0 || r >= N) return;
+  atomicAdd(d_prob + (b * N + r) * C + c, d_sorted[(b * F + f) * C + c]);
+}
+
 }  // namespace relnet
 
 using namespace relnet;
@@ -241,4 +326,30 @@ extern "C" int relnet_weight_relayout(const void* table, int n, int total_tiles,
   RELNET_REQUIRE(table && n > 0 && total_tiles > 0, "relnet_weight_relayout: empty table");
   weight_relayout_kernel<<<(unsigned)total_tiles, 256, 0, (hipStream_t)stream>>>((const relnet::RelayoutProblem*)table, n);
   return relnet::check_launch("relnet_weight_relayout");
+}
+
+// table: DEVICE array of n relnet_fragpack_desc, total_blocks = sum of ceil((N / 32) (K / 16) 64 / 256) over the table
+extern "C" int relnet_weight_fragpack(const void* table, int n, int total_blocks, void* stream) {
+  RELNET_REQUIRE(table && n > 0 && total_blocks > 0, "relnet_weight_fragpack: empty table");
+  weight_fragpack_kernel<<<(unsigned)total_blocks, 256, 0, (hipStream_t)stream>>>((const relnet::FragPackProblem*)table, n);
+  return relnet::check_launch("relnet_weight_fragpack");
+}
+
+extern "C" int relnet_relation_bwd_pack(const float* dq, const float* dk, const float* dvw, void* out, int B, int N, int M, int d,
+                                        void* stream) {
+  RELNET_REQUIRE(dq && dk && dvw && out && B > 0 && N > 0 && M > 0 && M <= N && d > 0 && d % 8 == 0,
+                 "relnet_relation_bwd_pack: bad arguments (B=%d N=%d M=%d d=%d)", B, N, M, d);
+  RELNET_REQUIRE((((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dvw | (uintptr_t)out) & 15) == 0, "relnet_relation_bwd_pack: operands must be 16-byte aligned");
+  const long total8 = (long)B * N * (3 * d / 8);
+  long blocks = (total8 + 255) / 256;
+  blocks = blocks > 8192 ? 8192 : blocks;
+  relation_bwd_pack_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(dq, dk, dvw, (unsigned short*)out, N, M, d, total8);
+  return relnet::check_launch("relnet_relation_bwd_pack");
+}
+
+extern "C" int relnet_lnms_scatter_bwd(const float* d_sorted, const int* rank_idx, float* d_prob, int B, int N, int C, int F, void* stream) {
+  RELNET_REQUIRE(d_sorted && rank_idx && d_prob && B > 0 && N > 0 && C > 0 && F > 0, "relnet_lnms_scatter_bwd: bad arguments");
+  const long total = (long)B * C * F;
+  lnms_scatter_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_sorted, rank_idx, d_prob, B, N, C, F);
+  return relnet::check_launch("relnet_lnms_scatter_bwd");
 }

@@ -97,7 +97,7 @@ class BucketedAllReduce(object):
         self.n = len(self.bounds) - 1
         self.cuda = flat.is_cuda
         self.stream = torch.cuda.Stream(device=flat.device) if self.cuda else None
-        self.pending, self.done, self.launch_order = [], set(), []
+        self.pending, self.done, self.launch_order = {}, set(), []
 
     @staticmethod
     def active():
@@ -124,24 +124,68 @@ class BucketedAllReduce(object):
                 work = dist.all_reduce(self.bucket(i), op=dist.ReduceOp.SUM, async_op=True)
         else:
             work = dist.all_reduce(self.bucket(i), op=dist.ReduceOp.SUM, async_op=True)
-        self.pending.append(work)
+        self.pending[i] = work
 
     def reset(self):
         """Start of a new backward pass: nothing announced yet (collectives of an abandoned pass are waited for first)."""
-        for w in self.pending:
+        for w in self.pending.values():
             w.wait()
-        self.pending, self.done, self.launch_order = [], set(), []
+        self.pending, self.done, self.launch_order = {}, set(), []
+
+    def launch_rest(self):
+        """Launch the buckets nobody announced (in backward order) WITHOUT waiting; returns the launch order so far."""
+        for i in reversed(range(self.n)):
+            self.ready(i)
+        return list(self.launch_order)
+
+    def pending_order(self):
+        """Buckets whose collective was launched and not yet waited for, in launch order."""
+        return [i for i in self.launch_order if i in self.pending]
+
+    def is_completed(self, i):
+        w = self.pending.get(i)
+        return True if w is None else bool(w.is_completed())
+
+    def wait(self, i):
+        """The caller's stream waits for bucket i's collective only (RCCL: a stream dependency, the host does not block)."""
+        w = self.pending.pop(i, None)
+        if w is None:
+            return
+        w.wait()
+        if self.cuda and dist.get_backend() != 'nccl':
+            torch.cuda.synchronize()                        # gloo on device tensors (one-GPU test path), see finish()
+
+    def clear(self):
+        """End of a step whose buckets were waited for one by one."""
+        assert not self.pending, sorted(self.pending)
+        self.done, self.launch_order = set(), []
 
     def finish(self):
         """Launch the buckets nobody announced (in backward order) and wait: after this the flat buffer holds the sums."""
         for i in reversed(range(self.n)):
             self.ready(i)
-        for w in self.pending:
+        had = bool(self.pending)
+        for w in self.pending.values():
             w.wait()                                        # CUDA: the current stream waits for the collective's stream
-        if self.pending and self.cuda and dist.get_backend() != 'nccl':
+        if had and self.cuda and dist.get_backend() != 'nccl':
             # gloo on device tensors (the one-GPU test path): its copy-back runs on private streams whose events may not be
             # recorded yet when wait() returns -- order the device explicitly (RCCL's wait() is a proper stream dependency)
             torch.cuda.synchronize()
         order = self.launch_order
-        self.pending, self.done, self.launch_order = [], set(), []
+        self.pending, self.done, self.launch_order = {}, set(), []
         return order
+
+
+def all_reduce_async(buf):
+    """SUM all-reduce of `buf` launched asynchronously (None without a process group)."""
+    if not BucketedAllReduce.active():
+        return None
+    return dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+
+
+def wait_work(work, buf=None):
+    if work is None:
+        return
+    work.wait()
+    if buf is not None and buf.is_cuda and dist.get_backend() != 'nccl':
+        torch.cuda.synchronize()

@@ -94,6 +94,10 @@ _SIGNATURES = {
     'relnet_gemm_force_tile': (None, [_i]),
     'relnet_gemm_force_nloop': (None, [_i]),
     'relnet_weight_relayout': (C.c_int, [_vp, _i, _i, _vp]),
+    'relnet_weight_fragpack': (C.c_int, [_vp, _i, _i, _vp]),
+    'relnet_relation_bwd_pack': (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'relnet_lnms_scatter_bwd': (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'relnet_gemm_nt_mask': (C.c_int, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _vp]),
     'relnet_gemm_set_swizzle': (None, [_i]),
     'relnet_gemm_debug_korder': (None, [_i]),
     'relnet_gemm_debug_asm': (None, [_i]),
@@ -125,6 +129,12 @@ class RelayoutDesc(C.Structure):
     """relnet_relayout_desc (include/relnet_hip.h)."""
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('cout', C.c_int), ('cin', C.c_int), ('taps', C.c_int), ('dst_ld', C.c_int),
                 ('dst_co', C.c_int), ('tiles_co', C.c_int), ('tiles_ci', C.c_int), ('tile_start', C.c_int)]
+
+
+class FragPackDesc(C.Structure):
+    """relnet_fragpack_desc (include/relnet_hip.h)."""
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('ldw', C.c_long), ('N', C.c_int), ('K', C.c_int), ('mode', C.c_int),
+                ('block_start', C.c_int)]
 
 
 class WgradDesc(C.Structure):

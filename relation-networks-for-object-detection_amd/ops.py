@@ -71,6 +71,59 @@ def gemm_nt(a, w, bias=None, bias_mode=1, resid=None, relu=False, out=None, out_
     return out
 
 
+_ASM_SELFCHECK = None
+
+
+def asm_selfcheck(force=False):
+    """Runtime twin of build.py's ISA guard for the hand-scheduled k-loop (gemm.hip tiles 18 / 19: accumulators in literal AGPRs
+    across asm statements -- correct only as long as the compiler leaves those registers alone): once per process, on the first
+    Backbone / Trainer built on a GPU, one 768 x 512 x 1024 product on tile 19 is compared with the compiler-scheduled ring tile 8.
+    On a mismatch the asm tiles are switched off for the process (relnet_gemm_debug_asm(0): pick_tile then never chooses them)
+    and the fact is announced on stderr.  -> True (match / not checked yet on this device) or False."""
+    global _ASM_SELFCHECK
+    if _ASM_SELFCHECK is not None and not force:
+        return _ASM_SELFCHECK
+    if not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+        return True
+    if os.environ.get('RELNET_DEBUG_KNOBS') == '1' and (os.environ.get('RELNET_GEMM_FORCE_TILE') or os.environ.get('RELNET_GEMM_ASM')):
+        return True                         # an A/B run pinned the tile choice by hand
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(19)
+    a = torch.randn(768, 1024, generator=g).cuda().to(torch.bfloat16)
+    w = torch.randn(512, 1024, generator=g).cuda().to(torch.bfloat16)
+    try:
+        lib.relnet_gemm_force_tile(19); y19 = gemm_nt(a, w).float()
+        lib.relnet_gemm_force_tile(8); y8 = gemm_nt(a, w).float()
+    finally:
+        lib.relnet_gemm_force_tile(0)
+    err, scale = float((y19 - y8).abs().max()), float(y8.abs().max())
+    _ASM_SELFCHECK = bool(err <= 1e-2 * scale) and bool(torch.isfinite(y19).all())
+    if not _ASM_SELFCHECK:
+        import sys
+        lib.relnet_gemm_debug_asm(0)
+        sys.stderr.write('relnet: hand-scheduled GEMM tile 19 disagrees with tile 8 (max |diff| %.3g of %.3g): asm tiles DISABLED for this '
+                         'process (compiler-scheduled ring tile instead)\n' % (err, scale))
+    return _ASM_SELFCHECK
+
+
+def gemm_nt_mask(a, w, mask, resid=None, out=None):
+    """out = (a @ w^T + resid) where mask > 0, else 0 (bf16; a [M,K], w [N,K], resid / mask / out [M,N] with one row stride):
+    the data gradient through `relu(conv1x1(.) + shortcut)` in one launch (relnet_gemm_nt_mask)."""
+    _chk(a, w, mask, resid, out)
+    M, K = a.shape
+    N = w.shape[0]
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and mask.dtype == torch.bfloat16
+    assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1 and tuple(mask.shape) == (M, N) and mask.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.bfloat16)
+    assert out.stride(1) == 1 and mask.stride(0) == out.stride(0)
+    if resid is not None:
+        assert resid.dtype == torch.bfloat16 and tuple(resid.shape) == (M, N) and resid.stride() == out.stride()
+    _lib.call('relnet_gemm_nt_mask', a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
+              _ptr(resid), mask.data_ptr(), M, N, K, _stream(), tag='M%d_N%d_K%d' % (M, N, K))
+    return out
+
+
 def embedding_divisors(feat_dim=64, wave_length=1000.0):
     """fp32 dim_mat of the reference graph (SYM_REL:32-35): wave_length ** ((8/feat_dim) k),
     evaluated in float32 like MXNet's arange / broadcast_power."""
@@ -412,7 +465,9 @@ def chain_worthwhile(pixels, mid):
     sets of four tiles) replaces two launches and wins from 4 images of 600 x 1000 up (r04, same box, ms per step with / without:
     2 images 3.17 / 2.87, 4 images 4.17 / 4.52, 8: 5.13 / 5.44, 27: 10.72 / 11.53, 40: 15.92 / 17.49).  res3 (mid 128) from ~7 images
     (8 images: +0.7 %), res5's expand (mid 512) from ~21 (27 images: 11.00 -> 10.62 ms; at 8 images it loses 1.4 %)."""
-    return pixels >= CHAIN_MIN_PIXELS[mid if mid in CHAIN_MIN_PIXELS else 'streamed']
+    # upper bound: the chain kernels address x / x_next with 32-bit byte offsets (4 mid channels x 2 bytes per pixel must stay below
+    # 4 GiB: ~223 images of 600 x 1000 in res4); beyond it the trunk falls back to the tiled convolution kernels instead of raising
+    return pixels >= CHAIN_MIN_PIXELS[mid if mid in CHAIN_MIN_PIXELS else 'streamed'] and pixels * 8 * mid < (1 << 32)
 
 
 def pack_chain_w1(w_packed):
@@ -850,34 +905,54 @@ class WeightRelayout(object):
         self.views = {}
         self.table = None
 
-    def add(self, name, w, taps=1, pad_co=64):
+    def add(self, name, w, taps=1, pad_co=64, group=None):
+        """group = (group name, column offset): the copy is written into columns [offset, offset + pad(Cout)) of a buffer shared by
+        the group's members (taps = 1, equal Cin) -- e.g. [Wq; Wk]^T | Wout^T side by side = the [Fd, 3 d] operand of the one-GEMM
+        projection backward of a relation module; get(group name) returns the whole buffer, get(name) the member's columns."""
         assert w.dtype == torch.bfloat16 and w.is_contiguous() and w.shape[1] % taps == 0
-        self.items.append((name, w, taps, pad_co))
+        assert group is None or taps == 1
+        self.items.append((name, w, taps, pad_co, group))
 
     def build(self):
         if not self.items:
             return
         sizes = []
-        for name, w, taps, pad_co in self.items:
+        groups = {}                                               # group name -> [cin, total columns]
+        for name, w, taps, pad_co, group in self.items:
             cout, cin = w.shape[0], w.shape[1] // taps
             dst_co = (cout + pad_co - 1) // pad_co * pad_co
             sizes.append((cout, cin, dst_co))
-        total = sum(cin * taps * dst_co for (_, _, taps, _), (cout, cin, dst_co) in zip(self.items, sizes))
+            if group is not None:
+                gi = groups.setdefault(group[0], [cin, 0])
+                assert gi[0] == cin and group[1] % 8 == 0, (name, group)
+                gi[1] = max(gi[1], group[1] + dst_co)
+        total = sum(cin * taps * dst_co for (_, _, taps, _, group), (cout, cin, dst_co) in zip(self.items, sizes) if group is None)
+        total += sum(cin * cols + 8 for cin, cols in groups.values())
         self.flat = torch.zeros(total + 8 * len(self.items) + 64, device=self.device, dtype=torch.bfloat16)
         arr = (_lib.RelayoutDesc * len(self.items))()
         off = 0
         tile = 0
-        for i, ((name, w, taps, pad_co), (cout, cin, dst_co)) in enumerate(zip(self.items, sizes)):
-            off = (off + 7) // 8 * 8                              # 16-byte aligned copies
-            n = cin * taps * dst_co
-            v = self.flat[off:off + n].view(cin, taps * dst_co)
+        for gname, (cin, cols) in groups.items():
+            off = (off + 7) // 8 * 8
+            self.views[gname] = self.flat[off:off + cin * cols].view(cin, cols)
+            off += cin * cols
+        for i, ((name, w, taps, pad_co, group), (cout, cin, dst_co)) in enumerate(zip(self.items, sizes)):
+            if group is not None:
+                gbuf = self.views[group[0]]
+                v = gbuf[:, group[1]:group[1] + dst_co]           # strided member view: rows of the group buffer
+                dst_ld = gbuf.shape[1]
+            else:
+                off = (off + 7) // 8 * 8                          # 16-byte aligned copies
+                n = cin * taps * dst_co
+                v = self.flat[off:off + n].view(cin, taps * dst_co)
+                dst_ld = taps * dst_co
+                off += n
             self.views[name] = v
             d = arr[i]
             d.src, d.dst = w.data_ptr(), v.data_ptr()
-            d.cout, d.cin, d.taps, d.dst_ld, d.dst_co = cout, cin, taps, taps * dst_co, dst_co
+            d.cout, d.cin, d.taps, d.dst_ld, d.dst_co = cout, cin, taps, dst_ld, dst_co
             d.tiles_co, d.tiles_ci, d.tile_start = (cout + 63) // 64, (cin + 63) // 64, tile
             tile += taps * d.tiles_co * d.tiles_ci
-            off += n
         self.total_tiles = tile
         raw = bytes(memoryview(arr))
         self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
@@ -889,6 +964,70 @@ class WeightRelayout(object):
 
     def get(self, name):
         return self.views.get(name)
+
+
+class FragRepack(object):
+    """MFMA-fragment-order copies of a set of bf16 weights, refreshed by ONE launch per step (relnet_weight_fragpack): what
+    relnet_bottleneck_chain reads (pack_w_frag order for a unit's expand weights W3, pack_chain_w1 order for the next unit's reduce
+    weights W1').  add(key, w [N, K] view of the trainer's flat bf16 working copy, mode) -> build() -> run() -> get(key)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.items, self.views, self.table = [], {}, None
+
+    def add(self, key, w, mode):
+        assert w.dtype == torch.bfloat16 and w.is_contiguous() and w.dim() == 2 and w.shape[0] % 32 == 0 and w.shape[1] % 16 == 0
+        assert mode in (0, 1)
+        self.items.append((key, w, mode))
+
+    def build(self):
+        if not self.items:
+            return
+        total = sum(w.numel() for _, w, _ in self.items)
+        self.flat = torch.zeros(total + 8, device=self.device, dtype=torch.bfloat16)
+        arr = (_lib.FragPackDesc * len(self.items))()
+        off = blk = 0
+        for i, (key, w, mode) in enumerate(self.items):
+            N, K = w.shape
+            v = self.flat[off:off + N * K]
+            self.views[key] = v
+            d = arr[i]
+            d.src, d.dst, d.ldw, d.N, d.K, d.mode, d.block_start = w.data_ptr(), v.data_ptr(), w.stride(0), N, K, mode, blk
+            blk += ((N // 32) * (K // 16) * 64 + 255) // 256
+            off += N * K
+        self.total_blocks, self.n = blk, len(self.items)
+        self.table = torch.frombuffer(bytearray(bytes(memoryview(arr))), dtype=torch.uint8).to(self.device)
+
+    def run(self):
+        if self.table is not None:
+            _lib.call('relnet_weight_fragpack', self.table.data_ptr(), self.n, self.total_blocks, _stream(), tag='n%d' % self.n)
+
+    def get(self, key):
+        return self.views.get(key)
+
+
+def relation_bwd_pack(dq, dk, dvw, out=None):
+    """dq [B,N,d], dk / dvw [B,M,d] fp32 -> out [B,N,3d] bf16 = (dQ | dK | dVW), rows >= M of the key blocks zero."""
+    _chk(dq, dk, dvw, out)
+    B, N, d = dq.shape
+    M = dk.shape[1]
+    assert dq.dtype == torch.float32 and dk.shape == (B, M, d) and dvw.shape == (B, M, d) and dq.is_contiguous() and dk.is_contiguous() and dvw.is_contiguous()
+    if out is None:
+        out = torch.empty((B, N, 3 * d), device=dq.device, dtype=torch.bfloat16)
+    assert out.is_contiguous() and out.shape == (B, N, 3 * d) and out.dtype == torch.bfloat16
+    _lib.call('relnet_relation_bwd_pack', dq.data_ptr(), dk.data_ptr(), dvw.data_ptr(), out.data_ptr(), B, N, M, d, _stream())
+    return out
+
+
+def lnms_scatter_bwd(d_sorted, rank_idx, N):
+    """d_sorted [B,F,C] fp32, rank_idx [B,C,F] int32 -> d_prob [B,N,C] fp32 with d_prob[b, rank_idx[b,c,f], c] += d_sorted[b,f,c]."""
+    _chk(d_sorted, rank_idx)
+    B, F, Cn = d_sorted.shape
+    assert rank_idx.shape == (B, Cn, F) and rank_idx.dtype == torch.int32 and rank_idx.is_contiguous()
+    assert d_sorted.dtype == torch.float32 and d_sorted.is_contiguous()
+    d_prob = torch.zeros((B, N, Cn), device=d_sorted.device, dtype=torch.float32)
+    _lib.call('relnet_lnms_scatter_bwd', d_sorted.data_ptr(), rank_idx.data_ptr(), d_prob.data_ptr(), B, N, Cn, F, _stream())
+    return d_prob
 
 
 class WgradQueue(object):
@@ -984,15 +1123,21 @@ def relation_attention_bwd(q, k, kt, vw, bias, dy, y, bout, qt, dyt, M, heads=16
     return dq, dk, dvw, prob, dlog
 
 
-def geometry_bias_bwd(boxes, bias, dlog, M, divisors=None, fast=False):
-    """boxes [B,N,4|5]; bias / dlog [B,16,N,Mpad] fp32 -> (d pair_pos_fc1 weight [16,64], d bias [16]) fp32."""
+def geometry_bias_bwd(boxes, bias, dlog, M, divisors=None, fast=False, out=None):
+    """boxes [B,N,4|5]; bias / dlog [B,16,N,Mpad] fp32 -> (d pair_pos_fc1 weight [16,64], d bias [16]) fp32.
+    out = (dwp, dbp): contiguous fp32 tensors the kernel ACCUMULATES into (atomic adds; e.g. views of a flat gradient buffer)."""
     _chk(boxes, bias, dlog)
     assert boxes.dtype == torch.float32 and boxes.is_contiguous()
     B, N, bs = boxes.shape
     assert bias.shape == dlog.shape and bias.shape[:3] == (B, 16, N) and bias.is_contiguous() and dlog.is_contiguous()
     div = (embedding_divisors() if divisors is None else divisors).to(torch.float32).cpu().contiguous()
-    dwp = torch.zeros((16, 64), device=boxes.device, dtype=torch.float32)
-    dbp = torch.zeros((16,), device=boxes.device, dtype=torch.float32)
+    if out is not None:
+        dwp, dbp = out
+        assert dwp.dtype == torch.float32 and dbp.dtype == torch.float32 and dwp.is_contiguous() and dbp.is_contiguous()
+        assert dwp.numel() == 16 * 64 and dbp.numel() == 16
+    else:
+        dwp = torch.zeros((16, 64), device=boxes.device, dtype=torch.float32)
+        dbp = torch.zeros((16,), device=boxes.device, dtype=torch.float32)
     _lib.call('relnet_geometry_bias_bwd', boxes.data_ptr(), bs, 1 if bs == 5 else 0, bias.data_ptr(), dlog.data_ptr(),
               div.data_ptr(), dwp.data_ptr(), dbp.data_ptr(), B, N, M, bias.shape[-1], int(fast), _stream())
     return dwp, dbp

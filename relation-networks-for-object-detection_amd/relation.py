@@ -167,8 +167,26 @@ class RelationHead(object):
         return cls_score, bbox_pred, x2
 
 
+class GradSink(object):
+    """Where a trainer wants the gradients of one relation module (attention_module_backward(sink=...)): instead of returning fp32
+    tensors that the caller concatenates and adds into its buffers (~20 elementwise launches per module), the backward writes
+
+      wcat_t   [Fd, 3 d] bf16  ([Wq; Wk]^T | Wout^T side by side: ops.WeightRelayout group) -- operand of the ONE projection-backward GEMM
+      resid    [B, N, Fd] bf16  gradient that bypasses the module (the residual path), added in that GEMM's epilogue
+      wgrad    callable(dy2d [P, 3 d] bf16, x2d [P, Fd] bf16): accumulate d[Wq; Wk; Wout] = dy2d^T x2d (the trainer queues it for its
+               grouped stream-K launch, straight into the flat gradient buffer)
+      b_qk     fp32 view [2 d], b_out fp32 view [d]: bias gradients, accumulated by relnet_colsum_add
+      dwp, dbp fp32 views [16, 64] / [16] of pair_pos_fc1's gradient: the geometry backward accumulates into them atomically
+      scratch  callable(name, shape, dtype) -> persistent ZERO-initialised buffer (pad columns of the transposed operands stay zero
+               from step to step: no per-step fill)"""
+
+    def __init__(self, wcat_t, resid, wgrad, b_qk, b_out, dwp, dbp, scratch):
+        self.wcat_t, self.resid, self.wgrad, self.b_qk, self.b_out, self.dwp, self.dbp, self.scratch = \
+            wcat_t, resid, wgrad, b_qk, b_out, dwp, dbp, scratch
+
+
 def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, index=1, dtype=None, packed=None, key_count=None,
-                              cache=None):
+                              cache=None, sink=None):
     """Gradient of `attention_module_multi_head` (the adjoint MXNet's autograd derives from SYM_REL:85-151).
 
     roi_feat [B,N,1024] (or [N,1024]), rois [..,N,4|5], d_out = d loss / d module output, same shape.
@@ -188,7 +206,6 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
     B, N, Fd = f.shape
     M = N if nongt_dim is None else nongt_dim
     mod = packed or RelationParams(params, index, dtype, f.device)
-    wp_t, bp = pack_pair_pos([mod], f.device)
     # fp32 ln G [B,16,N,Mpad] in float32 libm arithmetic and the module output y computed FROM IT (the softmax backward needs
     # D = dY.(y - bout) consistent with the softmax weights it re-derives from this G): taken from the training forward when it ran
     # on that geometry (`cache` holds bias / y / qk / vwt), recomputed otherwise.
@@ -199,7 +216,11 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
     # log(max(G, 1e-6)) is that ill-conditioned.  The projections Q|K and VW^T do not depend on G and are
     # taken from the forward (`cache` of _module_forward).
     have = cache is not None and cache.get('bias') is not None and cache.get('y') is not None and cache.get('qk') is not None
-    bias = cache['bias'] if have else ops.geometry_bias(bx, wp_t, bp, M, fast32=(dtype == torch.bfloat16))[0]
+    if have:
+        bias = cache['bias']
+    else:
+        wp_t, bp = pack_pair_pos([mod], f.device)
+        bias = ops.geometry_bias(bx, wp_t, bp, M, fast32=(dtype == torch.bfloat16))[0]
     Mpad = bias.shape[-1]
     d = mod.wqk.shape[0] // 2
     kpad = 64 if dtype == torch.bfloat16 else 16                        # GEMM K granularity
@@ -214,11 +235,30 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
     # ---- operand layouts of the backward kernels
     vw = ops.gemm_nt(f[:, :M, :].reshape(B * M, Fd) if M == N else f[:, :M, :].contiguous().reshape(B * M, Fd),
                      mod.wout).reshape(B, M, d)                          # F_K Wout^T, not transposed
-    kt = torch.zeros((B, d, Mpad), device=f.device, dtype=dtype)
-    ops.transpose_2d(k, out=kt)
-    qt = ops.transpose_2d(q, pad_cols_to=32)
-    dyt = ops.transpose_2d(dY, pad_cols_to=32)
+    if sink is not None:           # persistent zero-padded buffers: the transposes below write [:, :, :rows], the pad columns stay zero
+        Npad = ops.pad_to(N, 32)
+        kt = sink.scratch('kt', (B, d, Mpad), dtype)
+        qt = sink.scratch('qt', (B, d, Npad), dtype)
+        dyt = sink.scratch('dyt', (B, d, Npad), dtype)
+        ops.transpose_2d(k, out=kt); ops.transpose_2d(q, out=qt); ops.transpose_2d(dY, out=dyt)
+    else:
+        kt = torch.zeros((B, d, Mpad), device=f.device, dtype=dtype)
+        ops.transpose_2d(k, out=kt)
+        qt = ops.transpose_2d(q, pad_cols_to=32)
+        dyt = ops.transpose_2d(dY, pad_cols_to=32)
     dq, dk, dvw, prob, dlog = ops.relation_attention_bwd(q, k, kt, vw, bias, dY, y, mod.bout, qt, dyt, M, key_count=key_count)
+    if sink is not None and dtype == torch.bfloat16:
+        # ---- gradients straight into the trainer's buffers (GradSink): one pack kernel, ONE projection-backward GEMM with the residual
+        # gradient in its epilogue, ONE queued weight-gradient product for [Wq; Wk; Wout], two column-sum kernels for the biases
+        ops.geometry_bias_bwd(bx, bias, dlog, M, fast=True, out=(sink.dwp, sink.dbp))
+        a3 = ops.relation_bwd_pack(dq, dk, dvw)                              # [B, N, 3 d] bf16 = (dQ | dK | dVW), key blocks zero past M
+        a3_2d = a3.view(B * N, 3 * d)
+        d_f = ops.gemm_nt(a3_2d, sink.wcat_t, resid=None if sink.resid is None else sink.resid.reshape(B * N, Fd)).reshape(B, N, Fd)
+        sink.wgrad(a3_2d, f.reshape(B * N, Fd))
+        from . import train_ops as _T
+        _T.colsum_add(a3_2d[:, :2 * d], sink.b_qk)
+        _T.colsum_add(dY.reshape(B * N, d), sink.b_out)
+        return {'d_roi_feat': d_f[0] if squeeze else d_f}
     dwp, dbp = ops.geometry_bias_bwd(bx, bias, dlog, M, fast=(dtype == torch.bfloat16))
     # ---- projections: Q|K = F [Wq;Wk]^T + b,  VW = F_K Wout^T
     dqk = torch.zeros((B, N, 2 * d), device=f.device, dtype=dtype)

@@ -29,7 +29,7 @@ import torch
 from . import ops, losses, train_ops as T
 from . import dist as D
 from .backbone import unit_names, conv_bn_names, fold_bn, EPS
-from .relation import attention_module_backward, _module_forward, pack_pair_pos
+from .relation import attention_module_backward, _module_forward, pack_pair_pos, GradSink
 from .detector import Config, fc1_channels_last_perm
 from .operator_py.proposal import generate_anchors, propose_batch
 
@@ -90,6 +90,8 @@ class Trainer(object):
         dev = device
         f32 = lambda t: torch.as_tensor(t).to(dev, torch.float32).contiguous()
         self.fpn = bool(getattr(c, 'fpn', False))
+        if torch.device(dev).type == 'cuda':
+            ops.asm_selfcheck()
         self.units = unit_names(self.fpn)
         # the tensors this step never changes (frozen by name, cfgs/*.yaml:23-29, and the BatchNorm running statistics):
         # kept on the host under the reference's names so that a checkpoint holds the complete arg / aux dictionaries
@@ -105,7 +107,7 @@ class Trainer(object):
         self._frozen_backbone = None
         if getattr(c, 'frozen_on_inference_kernels', True) and torch.device(dev).type == 'cuda':
             from .backbone import Backbone
-            self._frozen_backbone = Backbone(params, dtype=torch.bfloat16, device=dev, dcn=bool(getattr(c, 'dcn', False)), fpn=self.fpn)
+            self._frozen_backbone = Backbone(params, dtype=torch.bfloat16, device=dev, fpn=self.fpn, frozen_only=True)
         self.zero_bias64 = torch.zeros(64, device=dev, dtype=torch.float32)
         weights, biases = [], []
         self.bn_scale, self.conv_bias, self.ksize = {}, {}, {'rpn_conv_3x3': 3, 'rpn_out': 1, 'conv_new_1': 1}
@@ -196,8 +198,41 @@ class Trainer(object):
                     or name.endswith('_offset'):
                 continue                                    # consumed in other layouts (relation_bwd kernels, padded DCN offset convs)
             taps = 9 if self.ksize.get(name, 1) == 3 else 1
-            self._relayout.add(name, self.w(name), taps=taps, pad_co=1 if taps == 9 else 64)
+            group = None
+            if name.startswith(('qk_', 'linear_out_')):     # [Wq; Wk]^T | Wout^T side by side: the [1024, 3072] operand of the ONE
+                i = name.rsplit('_', 1)[1]                  # projection-backward GEMM of relation module i (relation.GradSink)
+                group = ('rel_cat_' + i, 0 if name.startswith('qk_') else self.W.slices['qk_' + i][1][0])
+            self._relayout.add(name, self.w(name), taps=taps, pad_co=1 if taps == 9 else 64, group=group)
         self._relayout.build()
+        # ---- res3 .. res5 block boundaries on the inference chain kernels (csrc/bottleneck.hip): expand + shortcut + ReLU of unit u
+        # and reduce + ReLU of unit u + 1 in one launch.  They read the weights in MFMA-fragment order; the trained weights change every
+        # step, so ONE grouped launch per step (ops.FragRepack) rewrites those copies next to the data-gradient layouts above.
+        # cfg.train_chain = False keeps the per-layer convolution launches (the round-4 form).
+        self._fragpack = ops.FragRepack(dev)
+        self.chain_units = {}                               # unit -> (has_next_reduce, next unit)
+        if getattr(c, 'train_chain', os.environ.get('RELNET_TRAIN_CHAIN', '1') != '0') and torch.device(dev).type == 'cuda':
+            trainable = [u for u in self.units if u[0] >= 3]
+            for (st, nm, ic, mc, oc, stride, dil, proj), nxt in zip(trainable, trainable[1:] + [None]):
+                if c.dcn and st == 5:
+                    continue
+                with_reduce = nxt is not None and nxt[0] == st and not nxt[7] and mc in ops.CHAIN_MIDS
+                if not with_reduce and mc not in ops.CHAIN_EXPAND_MIDS:
+                    continue
+                self._fragpack.add('w3:' + nm, self.w('res%s_branch2c' % nm), 0)
+                if with_reduce:
+                    self._fragpack.add('w1:' + nxt[1], self.w('res%s_branch2a' % nxt[1]), 1)
+                self.chain_units[nm] = (with_reduce, nxt[1] if with_reduce else None)
+            self._fragpack.build()
+        # data gradient through `relu(expand + shortcut)` with the ReLU mask in the GEMM epilogue (relnet_gemm_nt_mask) instead of a
+        # separate relnet_relu_bwd pass over three [pixels, 4 mid] maps per unit
+        self.mask_epilogue = getattr(c, 'mask_epilogue', os.environ.get('RELNET_TRAIN_MASK_EPI', '1') != '0')
+        # weight-gradient products of the trunk launched on a side stream every `wgrad_overlap` units (0: one grouped launch per
+        # gradient bucket on the main stream, the round-4 form): the persistent stream-K kernel then fills the CUs that the
+        # data-gradient GEMMs of a 19 152-pixel map leave idle (75 - 300 workgroups for 256 CUs)
+        self.wgrad_overlap = int(getattr(c, 'wgrad_overlap', os.environ.get('RELNET_WGRAD_OVERLAP', '4')))
+        self._wgrad_side = torch.cuda.Stream(device=dev) if (self.wgrad_overlap > 0 and self._side is not None) else None
+        self._wgrad_keep, self._wgrad_pending = [], False
+        self._scratch_bufs = {}
 
     # ---- accessors ----------------------------------------------------------------------------------------
     def w(self, name):          # bf16 working copy
@@ -234,9 +269,34 @@ class Trainer(object):
         g = self.W.view(self.W.grad, name)
         return g.view(g.shape[0], -1), scale_rows, self._wq       # the products wait there for ONE grouped stream-K launch per gradient bucket
 
-    def _flush_wgrads(self):
-        """Launch the queued weight-gradient products (csrc/wgrad.hip, one grouped launch)."""
-        self._wq.flush()
+    def _flush_wgrads(self, final=True):
+        """Launch the queued weight-gradient products (csrc/wgrad.hip, one grouped launch).  With a weight-gradient side stream the
+        launch goes there (fork: side waits for everything queued on the current stream); final=True also joins -- the current stream
+        waits for every product launched on the side stream since the last join (a gradient bucket is complete only then).  The
+        operand tensors stay referenced until the join: their blocks must not be handed out again on the main stream while the
+        side stream still reads them."""
+        side = self._wgrad_side
+        if side is None:
+            self._wq.flush()
+            return
+        main = torch.cuda.current_stream()
+        if len(self._wq):
+            side.wait_stream(main)
+            self._wgrad_keep.append(list(self._wq.keep))
+            with torch.cuda.stream(side):
+                self._wgrad_keep.append(self._wq.flush())
+            self._wgrad_pending = True
+        if final and self._wgrad_pending:
+            main.wait_stream(side)
+            self._wgrad_pending = False
+            self._wgrad_keep = []
+
+    def _scratch(self, name, shape, dtype):
+        """Persistent zero-initialised work buffer (created on first use, i.e. in the eager warm-up step, never inside a capture)."""
+        key = (name, tuple(shape), dtype)
+        if key not in self._scratch_bufs:
+            self._scratch_bufs[key] = torch.zeros(shape, device=self.device, dtype=dtype)
+        return self._scratch_bufs[key]
 
     def _add_bgrad(self, name, db):
         if db is not None:          # (None: already accumulated by T.colsum_add through _bg(name))
@@ -262,6 +322,7 @@ class Trainer(object):
         saved = []
         conv4 = None
         ends = {}
+        y_pre = None               # reduce output of the coming unit when the previous unit's chain kernel already produced it
         for stage, nm, ic, mc, oc, stride, dil, proj in self.units:
             n1, na, nb, nc = 'res%s_branch1' % nm, 'res%s_branch2a' % nm, 'res%s_branch2b' % nm, 'res%s_branch2c' % nm
             if stage == 5 and conv4 is None:
@@ -280,7 +341,8 @@ class Trainer(object):
                 x = self._conv(y, nc, relu=True, resid=sc, w=fw(nc))
                 continue
             sc = self._conv(x, n1, stride=stride) if proj else x
-            y1 = self._conv(x, na, stride=stride, relu=True)
+            y1 = y_pre if y_pre is not None else self._conv(x, na, stride=stride, relu=True)
+            y_pre = None
             off = None
             if c.dcn and stage == 5:       # 72-channel offset conv -> DeformableConvolution(num_deformable_group=4) + BN + ReLU
                 off = self._conv(y1, nb + '_offset', pad=2, dil=2, bias=self.b(nb + '_offset'), out_dtype=torch.float32)
@@ -288,7 +350,15 @@ class Trainer(object):
                                          3, 1, 2, 2, 4, relu=True).permute(0, 2, 3, 1)
             else:
                 y2 = self._conv(y1, nb, pad=dil, dil=dil, relu=True)
-            out = self._conv(y2, nc, relu=True, resid=sc)
+            ch = self.chain_units.get(nm)
+            if ch is not None and ops.chain_worthwhile(y2.numel() // y2.shape[-1], mc):
+                # expand + shortcut + ReLU and (inside a stage) the NEXT unit's reduce + ReLU in one pixel-wise kernel; every activation
+                # the backward needs (x_next, mid1_next) is still written, nothing is overwritten in place
+                w1f = self._fragpack.get('w1:' + ch[1]) if ch[0] else None
+                b1 = self.conv_bias['res%s_branch2a' % ch[1]] if ch[0] else None
+                out, y_pre = ops.bottleneck_chain(y2, sc.contiguous(), self._fragpack.get('w3:' + nm), w1f, self.conv_bias[nc], b1)
+            else:
+                out = self._conv(y2, nc, relu=True, resid=sc)
             saved.append((stage, nm, stride, dil, proj, x, y1, y2, out, off))
             x = out
         ends[5] = x
@@ -314,6 +384,7 @@ class Trainer(object):
         self._grad_buckets().reset()
         self.W.grad.zero_(); self.Bv.grad.zero_()
         self._relayout.run()            # W^T / tap-flipped copies of the current weights for every data-gradient product
+        self._fragpack.run()            # ... and the fragment-order copies the chain kernels of the forward read
         # The RPN branch (head convolutions, anchor targets, losses, proposals, proposal targets: everything that hangs off conv4)
         # runs on a side stream BESIDE res5 / conv_new_1 -- its top-k / sort / NMS / target kernels are one workgroup per image and
         # leave the GPU idle on their own; fork when conv4 exists, join before ROI pooling (graph edges under capture).
@@ -428,19 +499,27 @@ class Trainer(object):
         # convolutions live in the heads bucket, which is then complete only after res5): dist.BucketedAllReduce overlaps
         # each bucket's all-reduce with the rest of the backward pass
         dcn = self.cfg.dcn
+        self._grad_buckets()
         if not dcn:
             self._bucket_ready('heads')
-        prev = None
-        for stage, nm, stride, dil, proj, x_in, y1, y2, o, off in reversed(saved):
-            if prev is not None and stage != prev:
-                self._bucket_ready('res%d' % prev)
-                if dcn and prev == 5:
+        prev_bucket = None
+        masked = False            # d_x already carries the ReLU mask of the unit's output (relnet_gemm_nt_mask of the unit after it)
+        since_flush = 0
+        order = list(reversed(saved))
+        for pos, (stage, nm, stride, dil, proj, x_in, y1, y2, o, off) in enumerate(order):
+            bucket = self._unit_bucket[nm]
+            if prev_bucket is not None and bucket != prev_bucket:
+                self._bucket_ready(prev_bucket)
+                if dcn and prev_bucket == 'res5':
                     self._bucket_ready('heads')
-            prev = stage
+                since_flush = 0
+            prev_bucket = bucket
             n1, na, nb, nc_ = 'res%s_branch1' % nm, 'res%s_branch2a' % nm, 'res%s_branch2b' % nm, 'res%s_branch2c' % nm
             if inject.get(nm) is not None:       # a second consumer of this unit's output (RPN head at conv4, FPN laterals)
+                assert not masked
                 d_x = inject[nm] if d_x is None else d_x + inject[nm]
-            g_out = T.relu_bwd(d_x, o)
+            g_out = d_x if masked else T.relu_bwd(d_x, o)
+            masked = False
             # (ReLU masks of the two inner activations ride in the data-gradient kernels' epilogues)
             g_y2, dw = T.conv1x1_bwd(y2, self.w(nc_), g_out, w_t=self.wt(nc_), keep_splits=True, wgrad_to=self._wg(nc_, self.bn_scale[nc_]), relu_mask=y2)
             if off is not None:            # deformable branch2b: data + offset gradients, then the offset conv's own backward
@@ -467,8 +546,18 @@ class Trainer(object):
                                         dx_add=d_a if (stride == 1 and not first) else None, keep_splits=True, wgrad_to=self._wg(n1, self.bn_scale[n1]))
                 d_x = None if first else (d_s if stride == 1 else d_s + d_a)
             else:
-                d_x, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, dx_add=g_out, w_t=self.wt(na), keep_splits=True, wgrad_to=self._wg(na, self.bn_scale[na]))       # identity shortcut
-        self._bucket_ready('res%d' % prev)
+                # identity shortcut: d x_in = g_y1 W1 + g_out; x_in is the previous unit's ReLU output, so its mask can ride in this GEMM's
+                # epilogue -- unless that output has a second consumer whose gradient must be added before the mask (inject)
+                prev_nm = order[pos + 1][1] if pos + 1 < len(order) else None
+                can_mask = self.mask_epilogue and prev_nm is not None and inject.get(prev_nm) is None
+                d_x, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, dx_add=g_out, w_t=self.wt(na), keep_splits=True, wgrad_to=self._wg(na, self.bn_scale[na]),
+                                        out_mask=x_in if can_mask else None)
+                masked = can_mask
+            since_flush += 1
+            if self._wgrad_side is not None and since_flush >= self.wgrad_overlap:
+                self._flush_wgrads(final=False)       # this group of weight gradients starts now, beside the next units' data gradients
+                since_flush = 0
+        self._bucket_ready(prev_bucket)
 
     def _head_forward_backward(self, pooled2, rois_t, N, label, bbox_target, bbox_weight, im_info, gt_boxes, num_gt, out,
                                key_count=None):
@@ -604,11 +693,7 @@ class Trainer(object):
         d_feat, dw, db = T.linear_bwd(feat2, self.w('roi_feat_embedding'), d_emb.to(bt), w_t=self.wt('roi_feat_embedding'), keep_splits=True, wgrad_to=self._wg('roi_feat_embedding'), bgrad_to=self._bg('roi_feat_embedding'))
         self._add_bgrad('roi_feat_embedding', db)
         # sort / slice backward -> cls_prob -> softmax backward (background column has no direct gradient)
-        d_prob = torch.zeros((B, N, C), device=dev, dtype=torch.float32)
-        cidx = torch.arange(C, device=dev).view(1, C, 1).expand(B, C, F)
-        bidx = torch.arange(B, device=dev).view(B, 1, 1).expand(B, C, F)
-        d_prob.index_put_((bidx.reshape(-1), rank_idx.long().reshape(-1), cidx.reshape(-1)),
-                          d_sorted.permute(0, 2, 1).reshape(-1), accumulate=True)
+        d_prob = ops.lnms_scatter_bwd(d_sorted.contiguous(), rank_idx, N)      # d_prob[b, rank_idx[b,c,f], c] += d_sorted[b,f,c]
         p_bg = 1.0 - prob.sum(2, keepdim=True)
         inner = (prob * d_prob).sum(2, keepdim=True)
         d_cls = torch.cat([-p_bg * inner, prob * (d_prob - inner)], 2)
@@ -635,11 +720,24 @@ class Trainer(object):
         return m
 
     def _relation_bwd(self, i, mod, f, x_act, rois, d_x, N, key_count=None, cache=None):
-        """x_act = relu(f + relation_i(f)); returns d f and accumulates the module's parameter gradients."""
+        """x_act = relu(f + relation_i(f)); returns d f (bf16, residual path + module path) and accumulates the module's parameter
+        gradients straight into the flat buffers (relation.GradSink: one pack kernel, one projection-backward GEMM with the residual
+        gradient in its epilogue, one queued weight-gradient product for [Wq; Wk; Wout], column-sum kernels for the biases)."""
         g = T.relu_bwd(d_x.contiguous(), x_act)
+        d = mod.wqk.shape[0] // 2
+        oq, sq = self.W.slices['qk_%d' % i]
+        oo, so = self.W.slices['linear_out_%d' % i]
+        wcat_t = self._relayout.get('rel_cat_%d' % i)
+        if wcat_t is not None and oo == oq + sq[0] * sq[1] and getattr(self.cfg, 'relation_sink', os.environ.get('RELNET_REL_SINK', '1') != '0'):
+            g3 = self.W.grad[oq:oq + (sq[0] + so[0]) * sq[1]].view(sq[0] + so[0], sq[1])      # d[Wq; Wk; Wout], adjacent slices of the flat buffer
+            sink = GradSink(wcat_t, g, lambda dy2d, x2d: T._wg_call((g3, None, self._wq), dy2d, x2d),
+                            self._bg('qk_%d' % i), self._bg('linear_out_%d' % i),
+                            self.W.view(self.W.grad, 'pair_pos_fc1_%d' % i), self._bg('pair_pos_fc1_%d' % i), self._scratch)
+            r = attention_module_backward(f, rois, None, g, nongt_dim=N, index=i, dtype=torch.bfloat16, packed=mod, key_count=key_count,
+                                          cache=cache, sink=sink)
+            return r['d_roi_feat']
         r = attention_module_backward(f, rois, None, g, nongt_dim=N, index=i, dtype=torch.bfloat16, packed=mod, key_count=key_count,
                                       cache=cache)
-        d = mod.wqk.shape[0] // 2
         self._add_wgrad('qk_%d' % i, torch.cat([r['query_%d_weight' % i], r['key_%d_weight' % i]], 0))
         self._add_bgrad('qk_%d' % i, torch.cat([r['query_%d_bias' % i], r['key_%d_bias' % i]], 0))
         self._add_wgrad('linear_out_%d' % i, r['linear_out_%d_weight' % i].reshape(d, -1))
@@ -718,21 +816,40 @@ class Trainer(object):
 
     # ---- optimizer ----------------------------------------------------------------------------------------
     def _grad_buckets(self):
-        """Weight-gradient buckets in buffer (= forward) order: res3 | res4 | res5 | everything after the trunk (RPN,
-        conv_new_1 / FPN neck, 2FC + relation + learn-NMS heads).  The backward pass completes them last to first."""
+        """Weight-gradient buckets in buffer (= forward) order: res3 | res4 (first half) | res4 (second half) | res5 | everything after
+        the trunk (RPN, conv_new_1 / FPN neck, 2FC + relation + learn-NMS heads).  The backward pass completes them last to first.
+        res4's 104 MB are two buckets (cut at unit b11): its second half travels while the first half is still being differentiated,
+        and what is left exposed after the last backward kernel is res3 (4.9 MB) plus the tail of a 47 MB message instead of 104 MB."""
         if getattr(self, '_buckets', None) is None:
             trunk = [n for n in self.W.slices if n in self.bn_scale]            # BN-folded res3..res5 convolutions
             first = lambda pre: min(self.W.slices[n][0] for n in trunk if n.startswith(pre))
             trunk_end = max(self.W.slices[n][0] + (int(np.prod(self.W.slices[n][1])) + 63) // 64 * 64 for n in trunk)
-            cuts = [0, first('res4'), first('res5'), trunk_end, self.W.size]
-            self._bucket_names = ('res3', 'res4', 'res5', 'heads')
+            res4 = [u[1] for u in self.units if u[0] == 4]
+            half = res4[len(res4) // 2]                                        # '4b11' of 4a, 4b1 .. 4b22
+            cuts = [0, first('res4'), first('res' + half + '_'), first('res5'), trunk_end, self.W.size]
+            self._bucket_names = ('res3', 'res4_lo', 'res4_hi', 'res5', 'heads')
+            if getattr(self.cfg, 'split_res4_bucket', True) is False:
+                cuts = [0, first('res4'), first('res5'), trunk_end, self.W.size]
+                self._bucket_names = ('res3', 'res4_lo', 'res5', 'heads')
+                half = None
             assert cuts == sorted(set(cuts)), cuts
+            self._bucket_cuts = cuts
+            self._unit_bucket = {}
+            hi = False
+            for u in self.units:
+                if u[0] < 3:
+                    continue
+                if u[0] == 4:
+                    hi = hi or (u[1] == half)
+                    self._unit_bucket[u[1]] = 'res4_hi' if hi else 'res4_lo'
+                else:
+                    self._unit_bucket[u[1]] = 'res%d' % u[0]
             self._buckets = D.BucketedAllReduce(self.W.grad, cuts)
         return self._buckets
 
     def _bucket_ready(self, name):
         """Called by the backward pass when the last gradient of a bucket has been queued (no-op on one rank)."""
-        self._flush_wgrads()         # the bucket is complete only once its queued weight gradients have been launched
+        self._flush_wgrads()         # the bucket is complete only once its queued weight gradients have been launched (and joined)
         bk = self._grad_buckets()
         idx = self._bucket_names.index(name)
         cut = getattr(self, '_capture_cut', None)
@@ -741,31 +858,56 @@ class Trainer(object):
             return
         bk.ready(idx)
 
-    def all_reduce(self):
-        """Summed all-reduce of the gradients over RCCL (MXNet kvstore 'device' + rescale_grad 1.0 semantics): the four
-        weight buckets -- those the backward pass has not already launched -- and the 0.1 MB bias buffer."""
-        order = self._grad_buckets().finish()
+    def all_reduce(self, wait=True):
+        """Summed all-reduce of the gradients over RCCL (MXNet kvstore 'device' + rescale_grad 1.0 semantics): the weight
+        buckets -- those the backward pass has not already launched -- and the 0.1 MB bias buffer.  wait=False only LAUNCHES what is
+        missing: `update()` then waits bucket by bucket, in the order they were launched, and runs SGD on a bucket as soon as ITS
+        sum has landed -- the optimizer of the heads / res5 buckets overlaps the all-reduce of res4 / res3 still in flight."""
+        bk = self._grad_buckets()
+        if not wait and bk.active():
+            order = bk.launch_rest()
+            self._bias_work = D.all_reduce_async(self.Bv.grad)
+            return order
+        order = bk.finish()
         all_reduce_sum(self.Bv.grad)
+        self._bias_work = None
         return order
 
+    def _sgd(self, buf, lo, hi, lr, wd, bf16=True):
+        if hi > lo:
+            T.sgd_update(buf.master[lo:hi], buf.mom[lo:hi], buf.grad[lo:hi], lr, self.cfg.momentum, wd, 1.0,
+                         w_bf16=buf.work[lo:hi] if bf16 else None)
+
     def update(self, lr=None):
+        """mx.optimizer.SGD over the flat buffers.  One rank (or everything already waited for): one launch for the weights, one for
+        the biases.  With bucket all-reduces in flight (all_reduce(wait=False)): per bucket, in launch order, wait + SGD on its slice."""
         c = self.cfg
         lr = c.lr if lr is None else lr
-        if self.lr_mult_tail is None:
-            T.sgd_update(self.W.master, self.W.mom, self.W.grad, lr, c.momentum, c.wd, 1.0, w_bf16=self.W.work)
-            T.sgd_update(self.Bv.master, self.Bv.mom, self.Bv.grad, lr, c.momentum, 0.0, 1.0)
-        else:                  # parameters with lr_mult != 1 sit at the tail of both flat buffers
-            wo, bo, mult = self.lr_mult_tail
-            W, Bv = self.W, self.Bv
-            T.sgd_update(W.master[:wo], W.mom[:wo], W.grad[:wo], lr, c.momentum, c.wd, 1.0, w_bf16=W.work[:wo])
-            T.sgd_update(W.master[wo:], W.mom[wo:], W.grad[wo:], lr * mult, c.momentum, c.wd, 1.0, w_bf16=W.work[wo:])
-            T.sgd_update(Bv.master[:bo], Bv.mom[:bo], Bv.grad[:bo], lr, c.momentum, 0.0, 1.0)
-            T.sgd_update(Bv.master[bo:], Bv.mom[bo:], Bv.grad[bo:], lr * mult, c.momentum, 0.0, 1.0)
+        W, Bv = self.W, self.Bv
+        wo, bo, mult = self.lr_mult_tail if self.lr_mult_tail is not None else (W.size, Bv.size, 1.0)
+        bk = self._grad_buckets()
+        pending = bk.pending_order() if bk.active() else []
+        self.update_order = []                      # (bucket index, its collective had completed when SGD was queued) -- test hook
+        ranges = [(self._bucket_cuts[i], self._bucket_cuts[i + 1], i) for i in pending] if pending else [(0, W.size, None)]
+        for lo, hi, i in ranges:
+            if i is not None:
+                self.update_order.append((i, bk.is_completed(i)))
+                bk.wait(i)
+            # parameters with lr_mult != 1 (DCN `offset` FC) sit at the tail of both flat buffers
+            self._sgd(W, lo, min(hi, wo), lr, c.wd)
+            self._sgd(W, max(lo, wo), hi, lr * mult, c.wd)
+        if pending:
+            bk.clear()
+        if getattr(self, '_bias_work', None) is not None:
+            D.wait_work(self._bias_work, self.Bv.grad)
+            self._bias_work = None
+        self._sgd(Bv, 0, bo, lr, 0.0, bf16=False)
+        self._sgd(Bv, bo, Bv.size, lr * mult, 0.0, bf16=False)
         self.step_count += 1
 
     def step(self, *batch, **kw):
         out = self.forward_backward(*batch, **kw)
-        self.all_reduce()
+        self.all_reduce(wait=False)
         self.update()
         return out
 
@@ -869,6 +1011,7 @@ class FPNTrainer(Trainer):
         self._grad_buckets().reset()
         self.W.grad.zero_(); self.Bv.grad.zero_()
         self._relayout.run()            # W^T / tap-flipped copies of the current weights for every data-gradient product
+        self._fragpack.run()            # ... and the fragment-order copies the chain kernels of the forward read
         out = {}
         conv5, conv4, saved, ends = self._trunk_forward(data)
         # ---- neck: 1x1 laterals (+bias), nearest 2x upsampling + sum, 3x3 output convs

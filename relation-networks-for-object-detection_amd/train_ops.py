@@ -150,11 +150,14 @@ def pack_conv_dgrad_weight(w_oihw, dtype=torch.bfloat16, device='cuda'):
     return w.reshape(w.shape[0], -1).to(device=device, dtype=dtype).contiguous()
 
 
-def conv1x1_bwd(x, w_packed, dy, stride=1, need_dx=True, w_t=None, dx_add=None, keep_splits=False, wgrad_to=None, relu_mask=None):
+def conv1x1_bwd(x, w_packed, dy, stride=1, need_dx=True, w_t=None, dx_add=None, keep_splits=False, wgrad_to=None, relu_mask=None,
+                out_mask=None):
     """x [B,H,W,Cin], dy [B,Ho,Wo,Cout] NHWC; w_packed [Cout,Cin].  -> (dx [B,H,W,Cin] | None, dW fp32).
     dx_add (stride 1 only): a second gradient of x's shape added in the GEMM epilogue (the shortcut branch).
     wgrad_to: see linear_bwd (the strided input rows are gathered inside relnet_wgrad: no sub-sampled copy of x).
-    relu_mask (stride 1, instead of dx_add): x itself when x = relu(.) -- dx comes out already multiplied by (x > 0)."""
+    relu_mask (stride 1, instead of dx_add): x itself when x = relu(.) -- dx comes out already multiplied by (x > 0).
+    out_mask (stride 1, WITH dx_add): dx = (dy W + dx_add) * (out_mask > 0) in one launch (relnet_gemm_nt_mask): the unit's input is the
+    previous unit's ReLU output, so the result is that unit's masked output gradient (no separate relu_bwd pass)."""
     B, H, W, Cin = x.shape
     Cout = w_packed.shape[0]
     P = dy.shape[0] * dy.shape[1] * dy.shape[2]
@@ -169,7 +172,10 @@ def conv1x1_bwd(x, w_packed, dy, stride=1, need_dx=True, w_t=None, dx_add=None, 
         if Cout % gran:                           # e.g. the RPN's 24 + 48 output channels
             dyp = torch.zeros((P, w_t.shape[1]), device=dy.device, dtype=dy.dtype)
             dyp[:, :Cout] = dy2
-        if stride == 1 and relu_mask is not None:
+        if stride == 1 and out_mask is not None:
+            assert relu_mask is None and out_mask.shape == x.shape and out_mask.is_contiguous()
+            dx = ops.gemm_nt_mask(dyp, w_t, out_mask.reshape(P, Cin), resid=None if dx_add is None else dx_add.reshape(P, Cin)).reshape(B, H, W, Cin)
+        elif stride == 1 and relu_mask is not None:
             assert dx_add is None
             dx = ops.gemm_nt(dyp, w_t, resid=relu_mask.reshape(P, Cin), relu=2).reshape(B, H, W, Cin)
         elif stride == 1:

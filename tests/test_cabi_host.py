@@ -254,3 +254,25 @@ def test_tile_selection_rules_without_a_gpu():
     assert pick(px(1), 512, 9216) == 5                                               # 304 workgroups: more than CUs
     assert pick(px(2), 256, 2304) == 5                                                                               # 300 workgroups: the plain 64 x 64 tile
     assert pick(54 * 75 * 125, 128, 1152) == 3                                                                       # res3 3x3: 128 columns
+
+
+def test_asm_agpr_guard_ran_for_the_linked_library_and_flags_violations(tmp_path):
+    """The hand-scheduled k-loops (gemm.hip tiles 18 / 19) keep their accumulators in literal AGPRs across asm statements; build.py
+    checks the device assembly of the SAME sources and flags: no instruction outside the asm blocks of those kernels may touch an
+    AGPR.  (a) the report next to the linked library belongs to the current sources and is clean; (b) the scanner does flag a
+    compiler-placed accumulator write."""
+    import json
+    from importlib import import_module
+    b = import_module('relation-networks-for-object-detection_amd.build')
+    b.build()
+    rep = json.load(open(b.GUARD))
+    assert rep['digest'] == b._digest() and rep['kernels_checked'] >= 4 and rep['asm_blocks'] > 100 and rep['offenders'] == {}
+    k = '_ZN6relnet16gemm_ring_kernelILi256ELi256ELi2ELi4EtLi1ELi64ELi2ELb0ELi6ELi0ELi0EEEvNS_8GemmArgsE'
+    other = '_ZN6relnet16gemm_ring_kernelILi256ELi256ELi2ELi4EtLi1ELi64ELi2ELb0ELi0ELi0ELi0EEEvNS_8GemmArgsE'
+    asm = '\n'.join([k + ':', '\tv_mov_b32 v1, v2', '\t;;#ASMSTART', '\tv_mfma_f32_32x32x16_bf16 a[0:15], v[72:75], v[80:83], a[0:15]',
+                     '\t;;#ASMEND', '\tv_accvgpr_write_b32 a5, v3   ; a spill the compiler parked in an accumulator', '\ts_endpgm',
+                     other + ':', '\tv_accvgpr_read_b32 v0, a1', '\ts_endpgm', ''])
+    f = tmp_path / 'k.s'
+    f.write_text(asm)
+    r = b.asm_agpr_guard(str(f))
+    assert r['kernels_checked'] == 1 and list(r['offenders']) == [k] and 'a5' in r['offenders'][k][0]

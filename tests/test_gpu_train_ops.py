@@ -246,3 +246,82 @@ def test_colsum_add_accumulates_bias_gradients(shape, dt):
         out2 = torch.zeros(C - 8, device='cuda')
         T.colsum_add(xs, out2)
         assert (out2.double() - xs.double().sum(0)).abs().max().item() <= 2e-6 * scale + 1e-5
+
+
+@pytest.mark.parametrize('tile', [0, 1, 3, 4, 5])
+def test_gemm_nt_mask_is_gemm_plus_shortcut_times_relu_mask(tile):
+    """relnet_gemm_nt_mask: (A W^T + resid) where mask > 0, else 0, on every LDS-tiled configuration it may run on (tile 0 = the one
+    pick_tile chooses) -- against float64 on the same bf16 operands; ragged M (not a multiple of any tile)."""
+    ops, T = _mods()
+    from relnet_amd import lib
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 2394 + 37, 1024, 256
+    a = _bf(torch.randn(M, K, generator=g)); w = _bf(torch.randn(N, K, generator=g) * 0.06)
+    r = _bf(torch.randn(M, N, generator=g)); mk = _bf(torch.randn(M, N, generator=g).clamp(min=0))      # ~half the mask is exactly 0 (a ReLU output)
+    want = (a.double() @ w.double().t() + r.double()) * (mk > 0).double()
+    c = lambda t: t.cuda().to(torch.bfloat16)
+    L = lib.load()
+    try:
+        L.relnet_gemm_force_tile(tile)
+        got = ops.gemm_nt_mask(c(a), c(w), c(mk), resid=c(r))
+        got0 = ops.gemm_nt_mask(c(a), c(w), c(mk))                           # without a shortcut operand
+    finally:
+        L.relnet_gemm_force_tile(0)
+    assert _rel(got, want.float()) <= 1e-2
+    assert bool((got.float().cpu()[mk <= 0] == 0).all())                     # masked entries are exact zeros
+    assert _rel(got0, ((a.double() @ w.double().t()) * (mk > 0).double()).float()) <= 1e-2
+    # ... and through the training building block: the identity-shortcut unit's data gradient, already masked for the previous unit
+    B, H, W_ = 1, 33, 73
+    P = B * H * W_
+    x = c(mk[:P]).view(B, H, W_, N)                                          # the unit's input = previous unit's ReLU output
+    dy = c(a[:P]).view(B, H, W_, K)
+    wp = c(w.t().contiguous())                                               # forward weight [Cout = K, Cin = N]
+    dx, _ = T.conv1x1_bwd(x, wp, dy, dx_add=c(r[:P]).view(B, H, W_, N), out_mask=x)
+    assert _rel(dx.reshape(P, N), want[:P].float()) <= 1e-2
+
+
+def test_weight_fragpack_equals_the_load_time_packers():
+    """relnet_weight_fragpack (one grouped launch per training step) == relnet_pack_w_frag / ops.pack_chain_w1 (inference, load time),
+    bit for bit, for every bottleneck width the chain kernels are built for."""
+    ops, _ = _mods()
+    g = torch.Generator().manual_seed(5)
+    fp = ops.FragRepack('cuda')
+    ws = {}
+    for mid in (64, 128, 256, 512):
+        w3 = (torch.randn(4 * mid, mid, generator=g) * 0.1).cuda().to(torch.bfloat16)
+        w1 = (torch.randn(mid, 4 * mid, generator=g) * 0.1).cuda().to(torch.bfloat16)
+        ws[mid] = (w3, w1)
+        fp.add(('w3', mid), w3, 0); fp.add(('w1', mid), w1, 1)
+    fp.build(); fp.run()
+    torch.cuda.synchronize()
+    for mid, (w3, w1) in ws.items():
+        assert torch.equal(fp.get(('w3', mid)).view(-1), ops.pack_w_frag(w3, panel_only=False).view(-1)), mid
+        assert torch.equal(fp.get(('w1', mid)).view(-1), ops.pack_chain_w1(w1).view(-1)), mid
+    # the copies follow the weights: a second run after an in-place update
+    ws[128][0].mul_(2)
+    fp.run()
+    assert torch.equal(fp.get(('w3', 128)).view(-1), ops.pack_w_frag(ws[128][0], panel_only=False).view(-1))
+
+
+def test_relation_bwd_pack_and_lnms_scatter():
+    ops, _ = _mods()
+    g = torch.Generator().manual_seed(9)
+    B, N, M, d = 3, 44, 40, 128
+    dq, dk, dvw = torch.randn(B, N, d, generator=g), torch.randn(B, M, d, generator=g), torch.randn(B, M, d, generator=g)
+    a3 = ops.relation_bwd_pack(dq.cuda(), dk.cuda(), dvw.cuda()).cpu()
+    want = torch.zeros(B, N, 3 * d)
+    want[:, :, :d] = dq; want[:, :M, d:2 * d] = dk; want[:, :M, 2 * d:] = dvw
+    assert torch.equal(a3, want.to(torch.bfloat16))
+    # adjoint of the per-class sort + take of the learn-NMS head
+    Bn, Nn, C, F = 2, 50, 7, 12
+    rank = torch.stack([torch.stack([torch.randperm(Nn, generator=g)[:F] for _ in range(C)]) for _ in range(Bn)]).to(torch.int32)     # [B,C,F]
+    rank[1, 3, -2:] = -1                                                      # padding entries are skipped
+    ds = torch.randn(Bn, F, C, generator=g)
+    got = ops.lnms_scatter_bwd(ds.cuda(), rank.cuda(), Nn).cpu()
+    ref = torch.zeros(Bn, Nn, C)
+    for b in range(Bn):
+        for c in range(C):
+            for f in range(F):
+                if rank[b, c, f] >= 0:
+                    ref[b, rank[b, c, f], c] += ds[b, f, c]
+    assert torch.allclose(got, ref, atol=1e-6)

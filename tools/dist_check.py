@@ -63,6 +63,23 @@ with torch.no_grad():
     res['captured_max_rel_diff'] = ((tr.W.grad - pg_world * local).abs().max().item() / (pg_world * den))
     res['captured_segments'] = [i for _, i in step.segments]
     res['finite'] = bool(torch.isfinite(tr.W.grad).all())
+    # the path bench.py times: replay (buckets announced between the graph segments), all_reduce(wait=False) launches whatever is
+    # missing WITHOUT waiting, update() then waits bucket by bucket in launch order and runs SGD on each slice as soon as its own
+    # sum has landed (the optimizer of the early buckets overlaps the collectives still in flight)
+    same_sample()
+    w_before = tr.W.master.clone()
+    step.replay()
+    res['overlap_launch_order'] = tr.all_reduce(wait=False)
+    last = res['overlap_launch_order'][-1]
+    res['last_bucket_done_when_update_starts'] = bool(tr._grad_buckets().is_completed(last))
+    tr.update(); torch.cuda.synchronize()
+    res['update_order'] = [i for i, _ in tr.update_order]
+    res['weights_moved'] = bool((tr.W.master != w_before).any()) and bool(torch.isfinite(tr.W.master).all())
+    # same batch, same weights, summed gradients: the two ranks must hold bit-identical weights after the step
+    chk = tr.W.master.double().sum().reshape(1).clone()
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    res['weights_equal_across_ranks'] = bool((lo == hi).all())
 if rank == 0:
     print('DIST_CHECK', res)
 dist.barrier(); dist.destroy_process_group()

@@ -13,7 +13,7 @@
 #   probes     tools/llc_probe.py + tools/fill_probe.py
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 WHAT=$1; shift
-TAG=${TAG:-r04_$WHAT}
+TAG=${TAG:-r05_$WHAT}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 F="--no-cpu-baseline --no-train-line --no-other-configs --no-parity --no-batch-sweep --batch 54"
 line() { python -c "import json,sys; d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{\"metric')][-1]); print(sys.argv[2], round(d['value'],1), 'img/s', round(d['ms_per_step'],3), 'ms', d['config'].get('images_per_gpu_per_step'))" "$1" "$2" 2>/dev/null || echo "$2 FAILED"; }
@@ -54,6 +54,18 @@ case $WHAT in
       rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pa_$tag -- python $R/tools/attn_only.py 54 6 > /tmp/pa.log 2>&1; tail -1 /tmp/pa.log
     done
     python $R/tools/pmc_collect.py $O/attention_pmc_raw.json /tmp/pa_FETCH_SIZE /tmp/pa_WRITE_SIZE /tmp/pa_SQ_VALU_MFMA_BUSY_CYCLES ;;
+  trainsuite)   # the tests of the training step and its building blocks (round 5: chain forward, mask epilogue, GradSink, buckets)
+    ( time timeout 1500 python -m pytest tests/test_gpu_train_ops.py tests/test_gpu_train_step.py tests/test_gpu_relation_bwd.py tests/test_gpu_two_ranks.py tests/test_gpu_bottleneck.py -q -m gpu ) > $O/pytest_train.log 2>&1; tail -15 $O/pytest_train.log ;;
+  trainab)      # same-box A/B of the configs[2] training step (8 images): every round-5 form switched off one at a time, then all off
+    T="--train --learn-nms --steps ${STEPS:-10} --warmup 3 --batch ${BATCH:-8}"
+    run() { n=$1; shift; env "$@" timeout 400 python bench.py $T > $O/$n.json 2> $O/$n.err; line $O/$n.json $n; }
+    run all_on A=1; run no_chain RELNET_TRAIN_CHAIN=0; run no_mask RELNET_TRAIN_MASK_EPI=0; run no_overlap RELNET_WGRAD_OVERLAP=0
+    run overlap1 RELNET_WGRAD_OVERLAP=1; run overlap2 RELNET_WGRAD_OVERLAP=2; run overlap8 RELNET_WGRAD_OVERLAP=8
+    run all_off RELNET_TRAIN_CHAIN=0 RELNET_TRAIN_MASK_EPI=0 RELNET_WGRAD_OVERLAP=0 RELNET_REL_SINK=0; run all_on_again A=1 ;;
+  proftrain)
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -- python $R/bench.py --train --learn-nms --batch ${BATCH:-8} --steps 10 --warmup 3 > /tmp/pt.log 2>&1
+    cp $(find /tmp/pt -name "*kernel_stats.csv" | head -1) $O/train_lnms_b${BATCH:-8}_kernel_stats.csv; tail -2 /tmp/pt.log; ls -la $O ;;
   golden) python tests/golden/gen_golden_gpu.py $O/ref_cuda.npz ;;
   probes) python tools/llc_probe.py > $O/llc.json; python tools/fill_probe.py > $O/fill_probe.txt; cat $O/fill_probe.txt ;;
   *) echo "unknown run '$WHAT'"; exit 2 ;;
