@@ -922,10 +922,10 @@ class WeightRelayout(object):
             cout, cin = w.shape[0], w.shape[1] // taps
             dst_co = (cout + pad_co - 1) // pad_co * pad_co
             sizes.append((cout, cin, dst_co))
-            if group is not None:
+            if group is not None:                                 # (group name, column offset[, total columns of the group buffer])
                 gi = groups.setdefault(group[0], [cin, 0])
                 assert gi[0] == cin and group[1] % 8 == 0, (name, group)
-                gi[1] = max(gi[1], group[1] + dst_co)
+                gi[1] = max(gi[1], group[1] + dst_co, group[2] if len(group) > 2 else 0)
         total = sum(cin * taps * dst_co for (_, _, taps, _, group), (cout, cin, dst_co) in zip(self.items, sizes) if group is None)
         total += sum(cin * cols + 8 for cin, cols in groups.values())
         self.flat = torch.zeros(total + 8 * len(self.items) + 64, device=self.device, dtype=torch.bfloat16)

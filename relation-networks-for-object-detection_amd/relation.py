@@ -175,7 +175,7 @@ class GradSink(object):
       resid    [B, N, Fd] bf16  gradient that bypasses the module (the residual path), added in that GEMM's epilogue
       wgrad    callable(dy2d [P, 3 d] bf16, x2d [P, Fd] bf16): accumulate d[Wq; Wk; Wout] = dy2d^T x2d (the trainer queues it for its
                grouped stream-K launch, straight into the flat gradient buffer)
-      b_qk     fp32 view [2 d], b_out fp32 view [d]: bias gradients, accumulated by relnet_colsum_add
+      b_qk     fp32 view [2 d], b_out fp32 view [d] (or None: the caller sums it): bias gradients, accumulated by relnet_colsum_add
       dwp, dbp fp32 views [16, 64] / [16] of pair_pos_fc1's gradient: the geometry backward accumulates into them atomically
       scratch  callable(name, shape, dtype) -> persistent ZERO-initialised buffer (pad columns of the transposed operands stay zero
                from step to step: no per-step fill)"""
@@ -257,7 +257,8 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
         sink.wgrad(a3_2d, f.reshape(B * N, Fd))
         from . import train_ops as _T
         _T.colsum_add(a3_2d[:, :2 * d], sink.b_qk)
-        _T.colsum_add(dY.reshape(B * N, d), sink.b_out)
+        if sink.b_out is not None:
+            _T.colsum_add(dY.reshape(B * N, d), sink.b_out)
         return {'d_roi_feat': d_f[0] if squeeze else d_f}
     dwp, dbp = ops.geometry_bias_bwd(bx, bias, dlog, M, fast=(dtype == torch.bfloat16))
     # ---- projections: Q|K = F [Wq;Wk]^T + b,  VW = F_K Wout^T

@@ -194,11 +194,16 @@ class Trainer(object):
         # transpose / flip / copy per layer inside the backward pass
         self._relayout = ops.WeightRelayout(dev)
         for name in self.W.slices:
-            if name.startswith(('pair_pos_fc1', 'nms_pair_pos_fc1', 'nms_rank', 'nms_logit', 'nms_qk', 'nms_linear_out')) \
-                    or name.endswith('_offset'):
-                continue                                    # consumed in other layouts (relation_bwd kernels, padded DCN offset convs)
             taps = 9 if self.ksize.get(name, 1) == 3 else 1
             group = None
+            if name == 'nms_qk_1':                           # learn-NMS module: [Wq; Wk]^T | padded Wout^T (8 real of 64 columns per head)
+                self._relayout.add(name, self.w(name), taps=1, pad_co=64, group=('rel_cat_nms', 0, 3 * 1024))
+                wo = self.w('nms_linear_out_1')
+                for h in range(16):
+                    self._relayout.add('nms_lo_h%d' % h, wo[8 * h:8 * h + 8], taps=1, pad_co=8, group=('rel_cat_nms', 2048 + 64 * h, 3 * 1024))
+                continue
+            if name.startswith(('pair_pos_fc1', 'nms_')) or name.endswith('_offset'):
+                continue                                    # consumed in other layouts (relation_bwd kernels, padded DCN offset convs)
             if name.startswith(('qk_', 'linear_out_')):     # [Wq; Wk]^T | Wout^T side by side: the [1024, 3072] operand of the ONE
                 i = name.rsplit('_', 1)[1]                  # projection-backward GEMM of relation module i (relation.GradSink)
                 group = ('rel_cat_' + i, 0 if name.startswith('qk_') else self.W.slices['qk_' + i][1][0])
@@ -226,10 +231,12 @@ class Trainer(object):
         # data gradient through `relu(expand + shortcut)` with the ReLU mask in the GEMM epilogue (relnet_gemm_nt_mask) instead of a
         # separate relnet_relu_bwd pass over three [pixels, 4 mid] maps per unit
         self.mask_epilogue = getattr(c, 'mask_epilogue', os.environ.get('RELNET_TRAIN_MASK_EPI', '1') != '0')
-        # weight-gradient products of the trunk launched on a side stream every `wgrad_overlap` units (0: one grouped launch per
-        # gradient bucket on the main stream, the round-4 form): the persistent stream-K kernel then fills the CUs that the
-        # data-gradient GEMMs of a 19 152-pixel map leave idle (75 - 300 workgroups for 256 CUs)
-        self.wgrad_overlap = int(getattr(c, 'wgrad_overlap', os.environ.get('RELNET_WGRAD_OVERLAP', '4')))
+        # weight-gradient products of the trunk launched on a side stream every `wgrad_overlap` units (0, the default: one grouped
+        # launch per gradient bucket on the main stream): built to let the persistent stream-K kernel fill the CUs that the
+        # data-gradient GEMMs of a 19 152-pixel map leave idle.  Measured (r05, same box, 8 images, ms per step): off 20.27, every
+        # 8 units 20.37, 4: 20.52, 2: 20.95, 1: 21.71 -- the co-resident workgroups slow the GEMMs by more than the overlap returns
+        # and smaller groups lose stream-K efficiency; kept as a knob (cfg.wgrad_overlap / RELNET_WGRAD_OVERLAP)
+        self.wgrad_overlap = int(getattr(c, 'wgrad_overlap', os.environ.get('RELNET_WGRAD_OVERLAP', '0')))
         self._wgrad_side = torch.cuda.Stream(device=dev) if (self.wgrad_overlap > 0 and self._side is not None) else None
         self._wgrad_keep, self._wgrad_pending = [], False
         self._scratch_bufs = {}
@@ -647,9 +654,9 @@ class Trainer(object):
         mod = M_()
         mod.wqk, mod.bqk = self.w('nms_qk_1'), self.b('nms_qk_1')
         wo, bo = self.w('nms_linear_out_1'), self.b('nms_linear_out_1')
-        mod.wout = torch.zeros((1024, 128), device=dev, dtype=bt)
+        mod.wout = self._scratch('nms_wout_pad', (1024, 128), bt)           # persistent: the 56 pad rows of every head stay zero
         mod.wout.view(16, 64, 128)[:, :8] = wo.view(16, 8, 128)
-        mod.bout = torch.zeros(1024, device=dev, dtype=torch.float32)
+        mod.bout = self._scratch('nms_bout_pad', (1024,), torch.float32)
         mod.bout.view(16, 64)[:, :8] = bo.view(16, 8)
         mod.wp = self.W.view(self.W.master, 'nms_pair_pos_fc1_1')
         mod.bp = self.b('nms_pair_pos_fc1_1')
@@ -676,20 +683,39 @@ class Trainer(object):
         d_allf, dw, db = T.linear_bwd(allf.view(BC * F, 128), w_logit, d_logit_p, w_t=None, keep_splits=True)
         self._add_wgrad('nms_logit', dw.sum(0)[:Tn]); self._add_bgrad('nms_logit', db[:Tn])
         g = T.relu_bwd(d_allf, allf.view(BC * F, 128))                                          # [BC*F,128] bf16
-        dY = torch.zeros((BC, F, 1024), device=dev, dtype=bt)
+        dY = self._scratch('nms_dy_pad', (BC, F, 1024), bt)                   # persistent: columns 8 .. 63 of every head stay zero
         dY.view(BC, F, 16, 64)[..., :8] = g.view(BC, F, 16, 8)
-        r = attention_module_backward(xr, cb, None, dY, nongt_dim=F, index=1, dtype=bt, packed=mod, cache=lcache)
-        self._add_wgrad('nms_qk_1', torch.cat([r['query_1_weight'], r['key_1_weight']], 0))
-        self._add_bgrad('nms_qk_1', torch.cat([r['query_1_bias'], r['key_1_bias']], 0))
-        self._add_wgrad('nms_linear_out_1', r['linear_out_1_weight'].reshape(16, 64, 128)[:, :8].reshape(128, 128))
-        self._add_bgrad('nms_linear_out_1', r['linear_out_1_bias'].view(16, 64)[:, :8].reshape(128))
-        self._add_wgrad('nms_pair_pos_fc1_1', r['pair_pos_fc1_1_weight']); self._add_bgrad('nms_pair_pos_fc1_1', r['pair_pos_fc1_1_bias'])
-        d_x = (r['d_roi_feat'] + g.view(BC, F, 128).float()).view(B, C, F, 128)                 # residual + module
-        d_rank = d_x.sum((0, 1))                                                                # [F,128]
+        wcat_t = self._relayout.get('rel_cat_nms')
+        if wcat_t is not None and getattr(c, 'relation_sink', os.environ.get('RELNET_REL_SINK', '1') != '0'):
+            # gradients through relation.GradSink: [dQ | dK | dVW] packed once, ONE projection-backward GEMM (K = 3072) with the residual
+            # gradient g in its epilogue; the [Wq; Wk] product goes straight into the flat buffer, the padded Wout product through a
+            # [1024, 128] scratch whose 8 real rows per head are then added to the compact [128, 128] gradient
+            gq = self.W.view(self.W.grad, 'nms_qk_1')
+            glo = self._scratch('nms_dwout_pad', (1024, 128), torch.float32)
+            glo.zero_()
+
+            def wg(dy2d, x2d):
+                ops.wgrad_tn(dy2d[:, :2048], x2d, out=gq.view(2048, 128))
+                ops.wgrad_tn(dy2d[:, 2048:], x2d, out=glo)
+            sink = GradSink(wcat_t, g.view(BC, F, 128), wg, self._bg('nms_qk_1'), None,
+                            self.W.view(self.W.grad, 'nms_pair_pos_fc1_1'), self._bg('nms_pair_pos_fc1_1'), self._scratch)
+            r = attention_module_backward(xr, cb, None, dY, nongt_dim=F, index=1, dtype=bt, packed=mod, cache=lcache, sink=sink)
+            self.W.view(self.W.grad, 'nms_linear_out_1').view(16, 8, 128).add_(glo.view(16, 64, 128)[:, :8])
+            T.colsum_add(g.view(BC * F, 128), self._bg('nms_linear_out_1'))    # (dY's real columns are g's columns)
+            d_x = r['d_roi_feat'].view(B, C, F, 128)                            # bf16: residual + module
+        else:
+            r = attention_module_backward(xr, cb, None, dY, nongt_dim=F, index=1, dtype=bt, packed=mod, cache=lcache)
+            self._add_wgrad('nms_qk_1', torch.cat([r['query_1_weight'], r['key_1_weight']], 0))
+            self._add_bgrad('nms_qk_1', torch.cat([r['query_1_bias'], r['key_1_bias']], 0))
+            self._add_wgrad('nms_linear_out_1', r['linear_out_1_weight'].reshape(16, 64, 128)[:, :8].reshape(128, 128))
+            self._add_bgrad('nms_linear_out_1', r['linear_out_1_bias'].view(16, 64)[:, :8].reshape(128))
+            self._add_wgrad('nms_pair_pos_fc1_1', r['pair_pos_fc1_1_weight']); self._add_bgrad('nms_pair_pos_fc1_1', r['pair_pos_fc1_1_bias'])
+            d_x = (r['d_roi_feat'] + g.view(BC, F, 128).float()).view(B, C, F, 128)             # residual + module
+        d_rank = d_x.sum((0, 1), dtype=torch.float32)                                           # [F,128] (fp32 accumulation whatever d_x's dtype)
         self._add_wgrad('nms_rank', T.wgrad(d_rank.to(bt), self.rank_emb)); self._add_bgrad('nms_rank', d_rank.sum(0))
         flat = (rank_idx.long() + (torch.arange(B, device=dev) * N).view(B, 1, 1)).view(-1)
         d_emb = torch.zeros((B * N, 128), device=dev, dtype=torch.float32)
-        d_emb.index_add_(0, flat, d_x.reshape(-1, 128))                                         # take() backward
+        d_emb.index_add_(0, flat, d_x.reshape(-1, 128).float())                                 # take() backward (a roi is ranked in up to 80 classes: fp32 sums)
         d_feat, dw, db = T.linear_bwd(feat2, self.w('roi_feat_embedding'), d_emb.to(bt), w_t=self.wt('roi_feat_embedding'), keep_splits=True, wgrad_to=self._wg('roi_feat_embedding'), bgrad_to=self._bg('roi_feat_embedding'))
         self._add_bgrad('roi_feat_embedding', db)
         # sort / slice backward -> cls_prob -> softmax backward (background column has no direct gradient)
@@ -944,7 +970,10 @@ class CapturedStep(object):
         def cut(idx):
             cur[0].capture_end()
             self.segments.append((cur[0], idx))
-            begin()
+            if idx == 0:                 # bucket 0 (res3) is announced by the last kernel of the backward pass: nothing follows, so no
+                cur[0] = None            # further capture is opened (an empty hipGraph used to be captured here and warned about on stderr)
+            else:
+                begin()
 
         torch.cuda.synchronize()
         with torch.cuda.stream(side), torch.no_grad():
@@ -956,16 +985,18 @@ class CapturedStep(object):
             except BaseException:
                 trainer._capture_cut = None
                 try:                              # leave capture mode, but let the ORIGINAL error propagate
-                    cur[0].capture_end()
+                    if cur[0] is not None:
+                        cur[0].capture_end()
                 except Exception:
                     pass
                 raise
             trainer._capture_cut = None
-            with warnings.catch_warnings(record=True) as caught:      # the tail after the last bucket is usually empty
-                warnings.simplefilter('always')
-                cur[0].capture_end()
-            if not any('Graph is empty' in str(w.message) for w in caught):
-                self.segments.append((cur[0], None))
+            if cur[0] is not None:       # (a trainer whose backward did not end with bucket 0: keep its tail)
+                with warnings.catch_warnings(record=True) as caught:
+                    warnings.simplefilter('always')
+                    cur[0].capture_end()
+                if not any('Graph is empty' in str(w.message) for w in caught):
+                    self.segments.append((cur[0], None))
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
 

@@ -398,58 +398,51 @@ def test_captured_step_in_bucket_segments_equals_eager():
         assert torch.isfinite(tr.W.master).all()
 
 
-def test_round5_trunk_paths_agree_with_the_per_layer_form():
-    """The round-5 forms of the trunk's training pass -- res3 / res4 block boundaries on the chain kernels (fragment-order weight
-    copies from one grouped launch per step), the ReLU mask of a unit's output gradient in the data-gradient GEMM's epilogue, weight
-    gradients on a side stream every few units -- against the per-layer round-4 form: same input, same upstream gradient, no discrete
-    decision in between, so every res3 .. res5 weight gradient agrees to bf16 rounding (cosine >= 0.999, norm within 2 %).
-    (The relation.GradSink path is the default of test_training_step_gradients_match_autograd.)"""
+def test_round5_trunk_backward_forms_agree():
+    """Backward of the trunk from the SAME saved activations (forward on the chain kernels, thresholds lowered for this small map)
+    in its two forms: round 5 (ReLU mask of a unit's output gradient in the data-gradient GEMM's epilogue -- relnet_gemm_nt_mask --,
+    weight gradients on a side stream every few units) against round 4 (GEMM + relnet_relu_bwd, one grouped weight-gradient launch
+    per bucket on the main stream).  No forward difference, no discrete decision: the gradients agree up to the order of the
+    fp32 atomic adds (cosine >= 0.99999, norm within 0.1 %).  The chain forward itself is checked against float64 autograd by
+    test_training_step_gradients_match_autograd[chain] and unit by unit by test_gpu_bottleneck.py."""
     import relnet_amd  # noqa: F401
     from relnet_amd import ops
     H, W, G = 256, 320, 4
     p, cfg, data, gt, L, Tg, Wg, train = _setup(H, W, G, 52)
+    cfg.wgrad_overlap = 3
     data2 = torch.cat([data, data.flip(3)]).cuda()
-    gsd = torch.Generator().manual_seed(3)
-
-    def run(tr):
-        tr._grad_buckets().reset()
-        tr.W.grad.zero_(); tr.Bv.grad.zero_()
-        tr._relayout.run(); tr._fragpack.run()
-        conv5, conv4, saved, _ = tr._trunk_forward(data2)
-        d_x = (torch.randn(conv5.shape, generator=torch.Generator().manual_seed(3)) * 0.01).cuda().to(torch.bfloat16)
-        inj = (torch.randn(conv4.shape, generator=torch.Generator().manual_seed(4)) * 0.01).cuda().to(torch.bfloat16)
-        tr._trunk_backward(saved, d_x, {'4b22': inj})
-        torch.cuda.synchronize()
-        return conv5, saved
-
     old_min = dict(ops.CHAIN_MIN_PIXELS)
     try:
         for k in ops.CHAIN_MIN_PIXELS:
             ops.CHAIN_MIN_PIXELS[k] = 1                       # run the chain kernels on this small map (res4: 2 x 16 x 20 pixels)
-        new = train.Trainer(p, cfg, im_hw=(H, W))
-        assert new.chain_units and new.mask_epilogue and new._wgrad_side is not None
-        c5_new, saved_new = run(new)
+        tr = train.Trainer(p, cfg, im_hw=(H, W))
+        assert tr.chain_units and tr.mask_epilogue and tr._wgrad_side is not None
+        tr._relayout.run(); tr._fragpack.run()
+        conv5, conv4, saved, _ = tr._trunk_forward(data2)
     finally:
         ops.CHAIN_MIN_PIXELS.update(old_min)
-    cfg2 = train.TrainConfig()
-    cfg2.rpn_post_nms_top_n = cfg.rpn_post_nms_top_n
-    cfg2.train_chain, cfg2.mask_epilogue, cfg2.wgrad_overlap = False, False, 0
-    ref = train.Trainer(p, cfg2, im_hw=(H, W))
-    assert not ref.chain_units and ref._wgrad_side is None and not ref.mask_epilogue
-    c5_ref, saved_ref = run(ref)
-    # forward: the chain kernels round where the per-layer launches round (bf16 after every ReLU); fp32 summation order may differ
-    rel = float((c5_new.float() - c5_ref.float()).abs().max() / c5_ref.float().abs().max())
-    assert rel <= 2e-2, rel
-    for sn, sr in zip(saved_new, saved_ref):
-        for t_new, t_ref in zip(sn[5:9], sr[5:9]):            # x_in, y1 (from the previous unit's chain kernel), y2, out
-            assert float((t_new.float() - t_ref.float()).abs().max()) <= 2e-2 * float(t_ref.float().abs().max()) + 1e-6, sn[1]
+    d_x = (torch.randn(conv5.shape, generator=torch.Generator().manual_seed(3)) * 0.01).cuda().to(torch.bfloat16)
+    inj = (torch.randn(conv4.shape, generator=torch.Generator().manual_seed(4)) * 0.01).cuda().to(torch.bfloat16)
+
+    def backward():
+        tr._grad_buckets().reset()
+        tr.W.grad.zero_(); tr.Bv.grad.zero_()
+        tr._trunk_backward(saved, d_x, {'4b22': inj})
+        torch.cuda.synchronize()
+        return tr.W.grad.clone()
+
+    g_new = backward()
+    side, tr.mask_epilogue, tr._wgrad_side = tr._wgrad_side, False, None
+    g_old = backward()
+    tr.mask_epilogue, tr._wgrad_side = True, side
+    assert torch.isfinite(g_new).all() and float(g_old.norm()) > 0
     bad = []
-    for name in ref.W.slices:
+    for name in tr.W.slices:
         if not name.startswith('res'):
             continue
-        a, b = new.W.view(new.W.grad, name).double().flatten(), ref.W.view(ref.W.grad, name).double().flatten()
+        a, b = tr.W.view(g_new, name).double().flatten(), tr.W.view(g_old, name).double().flatten()
         na, nb = float(a.norm()), float(b.norm())
         cos = float((a * b).sum() / max(na * nb, 1e-300))
-        if nb > 1e-12 and (cos < 0.999 or abs(na / nb - 1) > 0.02):
-            bad.append('%s cos %.5f norm ratio %.4f' % (name, cos, na / nb))
+        if nb > 1e-12 and (cos < 0.99999 or abs(na / nb - 1) > 1e-3):
+            bad.append('%s cos %.6f norm ratio %.5f' % (name, cos, na / nb))
     assert not bad, '\n'.join(bad)

@@ -50,6 +50,18 @@ CASES = [  # name, count per step, args
     ('res2 reduce 256->64', 2, (150, 250, 256, 64, 1, 1, False)),
     ('conv_new_1 2048->256', 1, (38, 63, 2048, 256, 1, 1, False)),
 ]
+if os.environ.get('TRAIN_CASES'):      # the data-gradient shapes of the training step (same kernels: a 3x3 / 1x1 convolution of dY with a shortcut or mask operand)
+    CASES += [
+        ('res4 3x3 dgrad +mask', 23, (38, 63, 256, 256, 3, 1, True)),
+        ('res4 expand-dgrad 1024->256 +mask', 23, (38, 63, 1024, 256, 1, 1, True)),
+        ('res4 reduce-dgrad 256->1024 +res', 23, (38, 63, 256, 1024, 1, 1, True)),
+        ('res3 3x3 dgrad +mask', 4, (75, 125, 128, 128, 3, 1, True)),
+        ('res3 expand-dgrad 512->128 +mask', 4, (75, 125, 512, 128, 1, 1, True)),
+        ('res5 3x3 dgrad +mask d2', 3, (38, 63, 512, 512, 3, 2, True)),
+        ('res5 expand-dgrad 2048->512 +mask', 3, (38, 63, 2048, 512, 1, 1, True)),
+        ('res5 reduce-dgrad 512->2048 +res', 3, (38, 63, 512, 2048, 1, 1, True)),
+        ('rpn 3x3 dgrad 512->1024', 1, (38, 63, 512, 1024, 3, 1, False)),
+    ]
 TILES = [int(x) for x in os.environ.get('TILES', '0,1,8,14').split(',')]
 
 
