@@ -204,8 +204,11 @@ def other_configs(a, rank, world, D):
     all-reduce).  Short runs: they are side figures, each with its own protocol string."""
     from relnet_amd import backbone, detector
     out = {'note': 'BASELINE configs[3] (Deformable Faster-RCNN + relation + learn-NMS) and configs[4] (FPN + relation + learn-NMS, 1000 '
-                   'proposals, 800x1024) as worded; configs[4] says "fp16 MFMA stress": run here with bf16 operands (same MFMA rate on '
-                   'gfx950: v_mfma_f32_32x32x16_bf16 / _f16 are both 8-pass), fp16 is used for the geometry-bias operand of the attention kernel only'}
+                   'proposals, 800x1024) as worded; configs[4] says "fp16 MFMA stress": run here with bf16 operands -- MEASURED (r05, '
+                   'profiles/r05_notes/fp16_vs_bf16.txt, relnet_gemm_nt_f16): the same kernel with fp16 operands (v_mfma_f32_32x32x16_f16, same 8-pass '
+                   'instruction) runs 8-13 % slower on dense random data (power-limited pipes, 10 toggling mantissa bits against 7), so bf16 is the faster '
+                   '16-bit format here; fp16 is used for the geometry-bias operand of the attention kernel only',
+           'operand_dtype': 'bf16 (fp16 twin of the GEMM kernel measured 8-13 % slower: profiles/r05_notes/fp16_vs_bf16.txt)'}
     for key, dcn, fpn, bsz in (('configs3_dcn_relation_learn_nms_inference', True, False, 27),
                                ('configs4_fpn_relation_learn_nms_inference', False, True, 8)):
         params = backbone.init_params(seed=1, dcn_offset_std=0.01 if dcn else 0.0, fpn=fpn)
@@ -505,8 +508,8 @@ def main():
                        'images_per_gpu_per_step': a.batch, 'launch': 'eager' if a.no_graph else 'hipGraph replay', 'parallelism': 'replicas x%d (no data-path collective)' % world,
                        'ranks_seen_by_rccl': ranks_seen, 'head_init_std': a.head_init_std,
                        'precision': 'bf16 operands, fp32 accumulation (fp16 only for the log2 geometry bias read by the attention kernel); BASELINE '
-                                    'configs[4] words its FPN run as "fp16": it is run with bf16 operands here (v_mfma_f32_32x32x16_bf16 and _f16 '
-                                    'have the same rate on gfx950)',
+                                    'configs[4] words its FPN run as "fp16": it is run with bf16 operands here -- the fp16 twin of the GEMM kernel was '
+                                    'measured 8-13 % SLOWER on gfx950 (same 8-pass MFMA, power-limited pipes; profiles/r05_notes/fp16_vs_bf16.txt)',
                        'scaling_figure': ('`value` is the replica-inference rate (no data-path collective: linear by construction). The 1 -> N GPU '
                                           'scaling north_star targets is the TRAINING step with its RCCL gradient all-reduce: read `train.value` '
                                           '(and other_configs.*_training.value) across N') if world > 1 else

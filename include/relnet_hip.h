@@ -88,6 +88,7 @@ void relnet_gemm_debug_phase_ts(void* buf); /* measurement knob: the ring kernel
                                              * wall clock (100 MHz) at entry / k-loop start / k-loop end / exit, [4] = shader cycles entry -> k-loop end;
                                              * NULL (default) = off.  tools/tile_phase_probe.py */
 void relnet_gemm_debug_ablate(int a);     /* measurement knob for tile 8: 1 = fill path only, 2 = LDS + MFMA only (garbage results) */
+void relnet_chain_debug(int flags);        /* measurement knob for chain256_roles_kernel (garbage results while non-zero): 1 = half of the weight loads, 2 = none, 4 = no shortcut-slice loads, 8 = no global stores */
 int relnet_gemm_tile_count(void);         /* number of tile configurations (valid relnet_gemm_force_tile values 1..count) */
 int relnet_gemm_pick_tile(int M, int N, int K, int batch, int out_dtype);   /* the configuration `auto` selects */
 
@@ -419,6 +420,12 @@ int relnet_weight_fragpack(const void* table, int n, int total_blocks, void* str
  * have C's layout (row stride ldc); K % 64 == 0, N % 8 == 0, 16-byte aligned rows.                                                  */
 int relnet_gemm_nt_mask(const void* A, long lda, const void* W, long ldw, void* C, long ldc, const void* resid, const void* mask,
                         int M, int N, int K, void* stream);
+
+/* C (fp32) = A W^T with IEEE-half (fp16) operands, v_mfma_f32_32x32x16_f16 on the LDS-tiled kernel (tile 2 = 256 x 128, 3 = 128 x 128): the fp16
+ * twin of relnet_gemm_nt(bf16 in, fp32 out).  BASELINE configs[4] words its FPN run as "fp16 MFMA stress"; the reference itself is fp32
+ * (experiments/relation_rcnn/cfgs/..._fpn_relation_learn_nms_8epoch.yaml) -- this entry is what measures that fp16 and bf16 operands run
+ * at the same rate on gfx950 (tools/fp16_rate.py, profiles/r05_notes/fp16_vs_bf16.txt).  K % 64 == 0, lda / ldw % 8 == 0.            */
+int relnet_gemm_nt_f16(const void* A, long lda, const void* W, long ldw, float* C, long ldc, int M, int N, int K, int tile, void* stream);
 
 /* Backward of the relation module's projections (autograd of SYM_REL:120-129,146-150): the fp32 gradients of the attention backward --
  * dq [B][N][d], dk and dvw [B][M][d], M <= N -- rounded to bf16 into ONE operand out [B][N][3 d] = (dQ | dK | dVW), key blocks zero for

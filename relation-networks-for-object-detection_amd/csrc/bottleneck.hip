@@ -47,6 +47,8 @@ struct ChainArgs {
   unsigned short* xn;         // [P][4 MID]
   unsigned short* m1;         // [P][MID]
   int P;
+  int dbg;                    // timing ablations of chain256_roles_kernel (relnet_chain_debug; results are then WRONG): 1 = half of the weight
+                              // loads, 2 = no weight loads, 4 = no shortcut-slice loads, 8 = no global stores
 };
 
 // One kernel for both widths, in passes of 64 output channels of the expand product:
@@ -311,6 +313,7 @@ __global__ __launch_bounds__(512) void chain256_roles_kernel(ChainArgs a) {
   auto tile_p0 = [&](int it, int T) { return (((int)blockIdx.x + it * (int)gridDim.x) * NTL + T) * 32; };     // >= P for idle tiles: loads clamp, stores are masked
   // shortcut slice of global pass Pg for tile T -> stage buffer Pg % NBUF
   auto issue_x = [&](int T, int Pg) {
+    if (a.dbg & 4) return;
     const int p0 = tile_p0(Pg / NP, T), p = Pg % NP;
     unsigned char* sb = smem + WBYTES + T * STG + (Pg % NBUF) * 4096;
 #pragma unroll
@@ -322,10 +325,12 @@ __global__ __launch_bounds__(512) void chain256_roles_kernel(ChainArgs a) {
   };
   // weights of the slot step g + 1 reads: W3 rows of step g + 1 (fragments 0..15) and W1' k-steps of step g (fragments 16..31); loader l of 2
   auto issue_w = [&](int g, int l) {
+    if (a.dbg & 2) return;
     unsigned char* wb = smem + ((g + 1) & 1) * SLOT;
     const int s3 = (g + 1) % NSTEP, s1 = g % NSTEP;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
+      if ((a.dbg & 1) && (i & 1)) continue;
       const int q = l + 2 * i;
       if (q < KS) {
         if (g + 1 < G)
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(512) void chain256_roles_kernel(ChainArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         auto put = [&](int i, const uint4& v) {
           const int row = 8 * i + drow;
-          if (p0 + row < a.P) *(uint4*)((unsigned char*)a.xn + ((unsigned)(p0 + row) * COUT + p * 64 + ((dslot ^ ((row >> 1) & 7)) << 3)) * 2u) = v;
+          if (p0 + row < a.P && !(a.dbg & 8)) *(uint4*)((unsigned char*)a.xn + ((unsigned)(p0 + row) * COUT + p * 64 + ((dslot ^ ((row >> 1) & 7)) << 3)) * 2u) = v;
         };
         put(0, v0); put(1, v1); put(2, v2); put(3, v3);
       }
@@ -471,7 +476,7 @@ __global__ __launch_bounds__(512) void chain256_roles_kernel(ChainArgs a) {
             __builtin_amdgcn_wave_barrier();
             auto put = [&](int i, const uint4& v) {
               const int row = 8 * i + drow;
-              if (p0 + row < a.P) *(uint4*)(a.m1 + (long)(p0 + row) * MID + hc * 64 + ((dslot ^ ((row >> 1) & 7)) << 3)) = v;
+              if (p0 + row < a.P && !(a.dbg & 8)) *(uint4*)(a.m1 + (long)(p0 + row) * MID + hc * 64 + ((dslot ^ ((row >> 1) & 7)) << 3)) = v;
             };
             put(0, v0); put(1, v1); put(2, v2); put(3, v3);
           }
@@ -494,6 +499,9 @@ using namespace relnet;
 // rows).  mid = 64 (res2: 64 -> 256 -> 64) or 128 (res3: 128 -> 512 -> 128).  w3f = relnet_pack_w_frag of W3 [4 mid][mid]; w1f = W1n [mid][4 mid] in the
 // accumulator-permuted fragment order (ops.pack_chain_w1).  Replaces two relnet_conv2d_nhwc launches
 // (resnet_v1_101_rcnn_base.py: res<s><u>_branch2c + shortcut + relu, res<s><u+1>_branch2a + relu).
+static int g_chain_dbg = 0;        // timing ablations of chain256_roles_kernel (ChainArgs::dbg): results are wrong while it is non-zero
+extern "C" void relnet_chain_debug(int flags) { g_chain_dbg = flags; }
+
 extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const void* w3f, const void* w1f, const float* b3,
                                        const float* b1, void* x_next, void* mid1_next, long P, int mid, void* stream) {
   RELNET_REQUIRE(mid2 && x && w3f && b3 && x_next, "relnet_bottleneck_chain: null operand");
@@ -503,7 +511,7 @@ extern "C" int relnet_bottleneck_chain(const void* mid2, const void* x, const vo
   ChainArgs a;
   a.m2 = (const unsigned short*)mid2; a.x = (const unsigned short*)x; a.w3f = (const uint4*)w3f; a.w1f = (const uint4*)w1f;
   a.b3 = b3; a.b1 = b1; a.xn = (unsigned short*)x_next; a.m1 = (unsigned short*)mid1_next; a.P = (int)P;
-  a.xin = nullptr; a.wpf = nullptr;
+  a.xin = nullptr; a.wpf = nullptr; a.dbg = g_chain_dbg;
   static relnet::PerDeviceOnce attr_once;
   if (attr_once.first()) {
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -547,7 +555,7 @@ extern "C" int relnet_bottleneck_chain_proj(const void* mid2, const void* x_in, 
   ChainArgs a;
   a.m2 = (const unsigned short*)mid2; a.x = nullptr; a.w3f = (const uint4*)w3f; a.w1f = (const uint4*)w1f;
   a.b3 = b3p; a.b1 = b1; a.xn = (unsigned short*)x_next; a.m1 = (unsigned short*)mid1_next; a.P = (int)P;
-  a.xin = (const unsigned short*)x_in; a.wpf = (const uint4*)wpf;
+  a.xin = (const unsigned short*)x_in; a.wpf = (const uint4*)wpf; a.dbg = 0;
   static relnet::PerDeviceOnce attr_once;
   if (attr_once.first()) {
     hipFuncSetAttribute((const void*)bottleneck_chain_kernel<64, false, true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

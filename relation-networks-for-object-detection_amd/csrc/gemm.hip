@@ -141,7 +141,11 @@ __device__ __forceinline__ void glds16_asm(const void* src, unsigned lds_byte_ad
 
 // BM x BN workgroup tile, WM x WN waves (each wave: TM x TN MFMA tiles of 32x32), BK = 64,
 // two LDS stages filled by global_load_lds.
-template <int BM, int BN, int WM, int WN, typename TOUT, int MODE, int KU = 1, bool MASK = false>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// F16: the 16-bit operands are IEEE half instead of bfloat16 (v_mfma_f32_32x32x16_f16 -- same 8-pass instruction, same staging, same
+// LDS image; fp32 outputs only).  Exists for BASELINE configs[4]'s "fp16 MFMA stress" wording: relnet_gemm_nt_f16 measures that an
+// fp16 layer runs at the rate of its bf16 twin on gfx950, which is why the FPN configuration is timed with bf16 operands.
+template <int BM, int BN, int WM, int WN, typename TOUT, int MODE, int KU = 1, bool MASK = false, bool F16 = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) {
   constexpr bool CONV = MODE == 1;       // NHWC implicit GEMM, Cin % 64 == 0
   constexpr bool STEM = MODE == 2;       // 7x7/2 stem on a zero-padded NHWC4 image (see relnet_stem_conv7)
@@ -323,7 +327,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // D = W x A: lane <-> output row
+          if constexpr (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bfr[j]), __builtin_bit_cast(f16x8, af[i]), acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // D = W x A: lane <-> output row
     }
     }
     __syncthreads();
@@ -2315,6 +2320,25 @@ extern "C" int relnet_gemm_nt_mask(const void* A, long lda, const void* W, long 
     default: launch_cfg_mask<128, 128, 2, 2>(g, s); break;
   }
   return check_launch("relnet_gemm_nt_mask");
+}
+
+// C (fp32) = A W^T with IEEE-half operands on the LDS-tiled kernel (tile: 2 = 256 x 128, 3 = 128 x 128, anything else = 256 x 128):
+// the fp16 twin of relnet_gemm_nt(bf16 in, fp32 out), for the fp16-vs-bf16 rate measurement of tools/fp16_rate.py and its parity test.
+extern "C" int relnet_gemm_nt_f16(const void* A, long lda, const void* W, long ldw, float* C, long ldc, int M, int N, int K, int tile,
+                                  void* stream) {
+  RELNET_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "relnet_gemm_nt_f16: bad operands");
+  RELNET_REQUIRE(K % 64 == 0 && lda % 8 == 0 && ldw % 8 == 0, "relnet_gemm_nt_f16: K %% 64 and ld %% 8 required (K=%d lda=%ld ldw=%ld)", K, lda, ldw);
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.n_loop = 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (tile == 3) {
+    dim3 grid((N + 127) / 128, (M + 127) / 128, 1);
+    gemm_nt_bf16_kernel<128, 128, 2, 2, float, 0, 1, false, true><<<grid, 256, 0, s>>>(g);
+  } else {
+    dim3 grid((N + 127) / 128, (M + 255) / 256, 1);
+    gemm_nt_bf16_kernel<256, 128, 4, 2, float, 0, 1, false, true><<<grid, 512, 0, s>>>(g);
+  }
+  return check_launch("relnet_gemm_nt_f16");
 }
 
 // NHWC convolution as an implicit GEMM on the bf16 MFMA kernel (reference: the Convolution

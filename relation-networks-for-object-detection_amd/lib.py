@@ -98,11 +98,13 @@ _SIGNATURES = {
     'relnet_relation_bwd_pack': (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'relnet_lnms_scatter_bwd': (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'relnet_gemm_nt_mask': (C.c_int, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _vp]),
+    'relnet_gemm_nt_f16': (C.c_int, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _vp]),
     'relnet_gemm_set_swizzle': (None, [_i]),
     'relnet_gemm_debug_korder': (None, [_i]),
     'relnet_gemm_debug_asm': (None, [_i]),
     'relnet_gemm_debug_phase_ts': (None, [_vp]),
     'relnet_gemm_debug_ablate': (None, [_i]),
+    'relnet_chain_debug': (None, [_i]),
     'relnet_gemm_tile_count': (C.c_int, []),
     'relnet_gemm_pick_tile': (C.c_int, [_i, _i, _i, _i, _i]),
     'relnet_nms_greedy': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),

@@ -185,3 +185,22 @@ def test_auto_selection_covers_the_benchmark_tiles(rn):
                                   (1024, 300, 1024, 54, 1), (129276, 72, 512, 1, 0), (2304, 256, 129276 // 64 * 64, 1, 0)):
         picks.add(L.relnet_gemm_pick_tile(M, N, K, batch, odt))
     assert picks <= set(range(1, L.relnet_gemm_tile_count() + 1)) and len(picks) >= 3, picks
+
+
+@pytest.mark.parametrize('tile', [2, 3])
+def test_gemm_nt_f16_matches_float64(tile):
+    """relnet_gemm_nt_f16 (IEEE-half operands, v_mfma_f32_32x32x16_f16, fp32 out): the measurement twin of the bf16 GEMM -- against
+    float64 on the same fp16-rounded operands, ragged M / N."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import lib
+    g = torch.Generator().manual_seed(tile)
+    M, N, K = 777, 320, 448
+    a = torch.randn(M, K, generator=g).to(torch.float16)
+    w = (torch.randn(N, K, generator=g) * 0.1).to(torch.float16)
+    want = a.double() @ w.double().t()
+    ad, wd = a.cuda(), w.cuda()
+    out = torch.zeros(M, N, device='cuda', dtype=torch.float32)
+    lib.call('relnet_gemm_nt_f16', ad.data_ptr(), ad.stride(0), wd.data_ptr(), wd.stride(0), out.data_ptr(), out.stride(0), M, N, K, tile,
+             torch.cuda.current_stream().cuda_stream)
+    err = (out.cpu().double() - want).abs().max().item() / want.abs().max().item()
+    assert err <= 2e-5, err               # fp16 products are exact in fp32; only the fp32 accumulation order differs

@@ -66,6 +66,31 @@ case $WHAT in
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -- python $R/bench.py --train --learn-nms --batch ${BATCH:-8} --steps 10 --warmup 3 > /tmp/pt.log 2>&1
     cp $(find /tmp/pt -name "*kernel_stats.csv" | head -1) $O/train_lnms_b${BATCH:-8}_kernel_stats.csv; tail -2 /tmp/pt.log; ls -la $O ;;
+  pmc_trunk)    # round 5: counters of the asm ring tile (res4 3x3, res5 3x3) and of chain256_roles_kernel, 54 images, separate passes per group
+    cd /tmp && export TMPDIR=/tmp
+    for K in ${KERNELS:-res4_3x3 res5_3x3 chain256}; do
+      i=0
+      for C in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum"; do
+        i=$((i+1))
+        timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pk_${K}_$i -- python $R/tools/kernel_pmc.py $K ${IMAGES:-54} 4 > /tmp/pk.log 2>&1 || echo "pass $K/$i ($C) failed: $(tail -2 /tmp/pk.log)"
+      done
+      python $R/tools/pmc_collect.py $O/${K}_pmc_raw.json /tmp/pk_${K}_*
+      # kernel durations of the same launches (from the kernel trace of pass 1)
+      python - $O/${K}_pmc_raw.json /tmp/pk_${K}_1 <<'PY'
+import csv, glob, json, os, sys
+out, d = sys.argv[1], sys.argv[2]
+j = json.load(open(out))
+dur = {}
+for f in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur.setdefault(r['Kernel_Name'], []).append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+for k, v in dur.items():
+    if k in j:
+        v = sorted(v)
+        j[k]['duration_ns'] = {'launches': len(v), 'median': v[len(v) // 2], 'min': v[0], 'max': v[-1]}
+json.dump(j, open(out, 'w'), indent=1, sort_keys=True)
+PY
+    done; ls -la $O ;;
   golden) python tests/golden/gen_golden_gpu.py $O/ref_cuda.npz ;;
   probes) python tools/llc_probe.py > $O/llc.json; python tools/fill_probe.py > $O/fill_probe.txt; cat $O/fill_probe.txt ;;
   *) echo "unknown run '$WHAT'"; exit 2 ;;
