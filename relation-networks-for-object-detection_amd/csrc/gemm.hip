@@ -2183,6 +2183,11 @@ static int pick_tile(long M, long N, long K, int batch, int out_dtype, int has_r
   auto wgs = [&](long bm, long bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long)batch; };
   const int small = wgs(128, 64) >= 200 ? 4 : 5;
   if ((cfg == 1 || cfg == 8 || cfg == 18 || cfg == 19) && wgs(256, 256) < 128) cfg = small;
+  // shortcut / mask layers (HBM-bound, K <= 512: four to eight k-slabs) on fewer than three rounds of 256 x 256 workgroups -- the training step's
+  // 19 152-pixel maps: 300 workgroups = 1.17 rounds -- run better on 128 x 64 tiles whose 2 400 workgroups keep every CU's load queue full.
+  // r05, 8 images, us per launch, tile 1 / tile 4 (profiles/r05_notes/tiles_b8_train_shapes.txt): res4 reduce-dgrad + shortcut 48.9 / 36.7,
+  // res4 expand + shortcut 50.2 / 38.1, res5 expand 98.3 / 86.0, res5 reduce-dgrad 98.0 / 85.9
+  else if (cfg == 1 && has_resid && K <= 512 && wgs(256, 256) < 768) cfg = 4;
   else if (cfg == 2 && wgs(256, 128) < 128) cfg = small;
   else if (cfg == 3 && wgs(128, 128) < 200) cfg = small;
   else if (cfg == 4 && N > 64 && wgs(128, 64) < 200) cfg = 5;

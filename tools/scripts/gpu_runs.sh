@@ -41,6 +41,8 @@ case $WHAT in
   prof)
     cd /tmp && export TMPDIR=/tmp
     P="--no-cpu-baseline --no-kernel-timing --no-parity --no-batch-sweep --no-train-line --no-other-configs"
+    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p108 -- python $R/bench.py $P --batch 108 > /tmp/p108.log 2>&1
+    cp $(find /tmp/p108 -name "*kernel_stats.csv" | head -1) $O/bench_b108_kernel_stats.csv
     rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p54 -- python $R/bench.py $P --batch 54 > /tmp/p54.log 2>&1
     cp $(find /tmp/p54 -name "*kernel_stats.csv" | head -1) $O/bench_b54_kernel_stats.csv
     rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python $R/bench.py $P --batch 1 --steps 50 > /tmp/p1.log 2>&1
@@ -49,11 +51,13 @@ case $WHAT in
     cp $(find /tmp/pt -name "*kernel_stats.csv" | head -1) $O/train_lnms_b8_kernel_stats.csv; ls -la $O ;;
   pmc_attn)
     cd /tmp && export TMPDIR=/tmp
-    for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY"; do
-      tag=$(echo $C | cut -d' ' -f1)
-      rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pa_$tag -- python $R/tools/attn_only.py 54 6 > /tmp/pa.log 2>&1; tail -1 /tmp/pa.log
-    done
-    python $R/tools/pmc_collect.py $O/attention_pmc_raw.json /tmp/pa_FETCH_SIZE /tmp/pa_WRITE_SIZE /tmp/pa_SQ_VALU_MFMA_BUSY_CYCLES ;;
+    for NB in ${ATTN_BATCHES:-108 54}; do
+      for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE"; do
+        tag=$(echo $C | cut -d' ' -f1)
+        rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pa${NB}_$tag -- python $R/tools/attn_only.py $NB 6 > /tmp/pa.log 2>&1; tail -1 /tmp/pa.log
+      done
+      python $R/tools/pmc_collect.py $O/attention_pmc_raw_b$NB.json /tmp/pa${NB}_FETCH_SIZE /tmp/pa${NB}_WRITE_SIZE /tmp/pa${NB}_SQ_VALU_MFMA_BUSY_CYCLES
+    done; ls -la $O ;;
   trainsuite)   # the tests of the training step and its building blocks (round 5: chain forward, mask epilogue, GradSink, buckets)
     ( time timeout 1500 python -m pytest tests/test_gpu_train_ops.py tests/test_gpu_train_step.py tests/test_gpu_relation_bwd.py tests/test_gpu_two_ranks.py tests/test_gpu_bottleneck.py -q -m gpu ) > $O/pytest_train.log 2>&1; tail -15 $O/pytest_train.log ;;
   trainab)      # same-box A/B of the configs[2] training step (8 images): every round-5 form switched off one at a time, then all off
