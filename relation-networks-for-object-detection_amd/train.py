@@ -516,9 +516,10 @@ class Trainer(object):
         for pos, (stage, nm, stride, dil, proj, x_in, y1, y2, o, off) in enumerate(order):
             bucket = self._unit_bucket[nm]
             if prev_bucket is not None and bucket != prev_bucket:
-                self._bucket_ready(prev_bucket)
                 if dcn and prev_bucket == 'res5':
-                    self._bucket_ready('heads')
+                    self._bucket_ready('res5', 'heads')        # both complete at this point: one cut, two collectives
+                else:
+                    self._bucket_ready(prev_bucket)
                 since_flush = 0
             prev_bucket = bucket
             n1, na, nb, nc_ = 'res%s_branch1' % nm, 'res%s_branch2a' % nm, 'res%s_branch2b' % nm, 'res%s_branch2c' % nm
@@ -873,16 +874,17 @@ class Trainer(object):
             self._buckets = D.BucketedAllReduce(self.W.grad, cuts)
         return self._buckets
 
-    def _bucket_ready(self, name):
-        """Called by the backward pass when the last gradient of a bucket has been queued (no-op on one rank)."""
+    def _bucket_ready(self, *names):
+        """Called by the backward pass when the last gradient of a bucket (or of several at once) has been queued (no-op on one rank)."""
         self._flush_wgrads()         # the bucket is complete only once its queued weight gradients have been launched (and joined)
         bk = self._grad_buckets()
-        idx = self._bucket_names.index(name)
+        idxs = [self._bucket_names.index(n) for n in names]
         cut = getattr(self, '_capture_cut', None)
-        if cut is not None:          # CapturedStep: close the current hipGraph here; the collective goes between two graphs
-            cut(idx)
+        if cut is not None:          # CapturedStep: close the current hipGraph here; the collective(s) go between two graphs
+            cut(idxs[0] if len(idxs) == 1 else tuple(idxs))
             return
-        bk.ready(idx)
+        for idx in idxs:
+            bk.ready(idx)
 
     def all_reduce(self, wait=True):
         """Summed all-reduce of the gradients over RCCL (MXNet kvstore 'device' + rescale_grad 1.0 semantics): the weight
@@ -970,7 +972,7 @@ class CapturedStep(object):
         def cut(idx):
             cur[0].capture_end()
             self.segments.append((cur[0], idx))
-            if idx == 0:                 # bucket 0 (res3) is announced by the last kernel of the backward pass: nothing follows, so no
+            if idx == 0 or (isinstance(idx, tuple) and 0 in idx):   # bucket 0 (res3) is announced by the last kernel of the backward pass: nothing follows, so no
                 cur[0] = None            # further capture is opened (an empty hipGraph used to be captured here and warned about on stderr)
             else:
                 begin()
@@ -1006,8 +1008,8 @@ class CapturedStep(object):
         bk.reset()
         for graph, idx in self.segments:
             graph.replay()
-            if idx is not None:
-                bk.ready(idx)
+            for i in (() if idx is None else idx if isinstance(idx, tuple) else (idx,)):
+                bk.ready(i)
         return self.out
 
 
