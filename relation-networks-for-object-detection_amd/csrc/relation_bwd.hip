@@ -186,6 +186,17 @@ __device__ __forceinline__ void store_rows(float* orow, const f32x16 (&o)[2], in
     }
 }
 
+// ... the same rows rounded to bf16 (the [dQ | dK | dVW] operand of the projection backward)
+__device__ __forceinline__ void store_rows_bf16(unsigned short* orow, const f32x16 (&o)[2], int half, float mul) {
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int dv = 32 * d + 8 * gq + 4 * half;
+      *(uint2*)(orow + dv) = make_uint2(pack_bf16x2(o[d][4 * gq] * mul, o[d][4 * gq + 1] * mul), pack_bf16x2(o[d][4 * gq + 2] * mul, o[d][4 * gq + 3] * mul));
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void relation_attention_bwd_q_kernel(AttnBwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -332,6 +343,207 @@ __global__ __launch_bounds__(256) void relation_attention_bwd_kv_kernel(AttnBwdA
   if (key < a.M) {
     store_rows(a.dvw + ((long)b * a.M + key) * (a.H * 64) + h * 64, ov, half, 1.0f);
     store_rows(a.dk + ((long)b * a.M + key) * (a.H * 64) + h * 64, ok, half, a.scale);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Small-N form (round 5): q part and kv part of the backward for ONE (image, head) in ONE workgroup, for N, Mpad <= 128 -- the
+// learn-NMS head's relation module (symbols/..._learn_nms.py:480-486: 100 ranked rois per (image, class), 640 pseudo-images at 8
+// images per step).  The two-kernel form above spends its time on L2 round trips and on the fp32 S / dL maps
+// ([640][16][100][128] x 4 B = 524 MB each: written by the q kernel, gathered column-wise by the kv kernel): 1.05 + 0.55 ms per
+// step.  Here K, VW and K^T of the (image, head) are staged in LDS once (53 KB), every query tile's wavefront reads its
+// fragments from there, S and dL go to LDS as the bf16 values the kv products round them to anyway (70 KB) and are read back
+// row-major by the key tiles' wavefronts after one barrier; only dL still goes to HBM (fp32, for the geometry backward).
+// dY^T and Q^T (the kv part's A operands) are staged too and the q part's log G rows are read into registers before the first
+// barrier: with one 4-wave workgroup per CU (155 KB of LDS) no other wavefront hides a load, so no global read sits inside the loops
+// (first version, loads in the loops: 1.50 ms per learn-NMS launch = no gain over the two kernels' 1.05 + 0.55).
+// Arithmetic and rounding points are those of the two-kernel form: same dq / dk / dvw / dlog bit for bit.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kSmK = 72, kSmT = 136;                                     // LDS row pitches (elements): 4 x odd words -> conflict-free fragment reads
+constexpr int kSmallLdsBytes = 2 * 128 * kSmK * 2 + 3 * 64 * kSmT * 2 + 2 * 128 * kSmT * 2;  // K | VW | K^T, dY^T, Q^T | S | dL = 158 720 B
+
+// PACK: dQ / dK / dVW leave as bf16 straight into the [B][N][3 H 64] operand of the projection backward (dQ | dK | dVW column blocks: what
+// relnet_relation_bwd_pack builds from the fp32 outputs otherwise -- 786 MB written and read back at the learn-NMS head); a.dq then points to
+// that buffer, whose key blocks must be zero for rows >= M (the kernel never writes them).
+template <bool PACK>
+__global__ __launch_bounds__(256) void relation_attention_bwd_small_kernel(AttnBwdArgs a, int Npad) {
+  typedef unsigned short T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
+  T* sK = (T*)smem_s;                       // [128][kSmK]
+  T* sVW = sK + 128 * kSmK;                 // [128][kSmK]
+  T* sKT = sVW + 128 * kSmK;                // [64][kSmT]
+  T* sDYT = sKT + 64 * kSmT;                // [64][kSmT]    dY^T (queries contiguous)
+  T* sQT = sDYT + 64 * kSmT;                // [64][kSmT]    Q^T
+  T* sP = sQT + 64 * kSmT;                  // [128][kSmT]   S  (bf16)
+  T* sL = sP + 128 * kSmT;                  // [128][kSmT]   dL (bf16)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const T* Kb = (const T*)a.k + (long)b * a.k_bs + h * 64;
+  const T* VWb = (const T*)a.vw + (long)b * a.vw_bs + h * 64;
+  const T* KTb = (const T*)a.kt + (long)b * a.kt_bs + (long)(h * 64) * a.kt_ld;
+  const T* DYT = (const T*)a.dyt + (long)b * a.dyt_bs + (long)(h * 64) * a.dyt_ld;
+  const T* QT = (const T*)a.qt + (long)b * a.qt_bs + (long)(h * 64) * a.qt_ld;
+  const int nqt = (a.N + 31) / 32, nkt = (a.M + 31) / 32;
+  // ---- this lane's log G row (the q part's only other global operand), all key tiles up front: with one 4-wave workgroup per CU nothing else
+  // hides a load, so every global read of the kernel is issued before the first barrier (one wave per SIMD: 512 registers to hold them)
+  const int q_ = wave * 32 + l31, qc_ = q_ < a.N ? q_ : a.N - 1;
+  const float* Bq_ = a.bias + (long)b * a.bias_bs + ((long)h * a.N + qc_) * a.Mpad;
+  float4 bq[4][4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+      bq[kt][gq] = (wave < nqt && kt < nkt) ? *(const float4*)(Bq_ + kt * 32 + 8 * gq + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // ---- stage K, VW (rows >= M: the last row, as the clamped loads of the two-kernel form), K^T, dY^T and Q^T (zero padded by the caller; columns
+  // past the buffers' padded width are zero filled here).  Fixed trip counts, all 20 16-byte loads of a thread issued before the first LDS write:
+  // a loop of load -> write iterations costs one L2 round trip per iteration (measured: 1.39 ms per learn-NMS launch with such loops).
+  {
+    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+    uint4 tv[12], kv[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i, d = c >> 4, ch = c & 15;            // row d of a transposed operand, 8 consecutive keys / queries
+      tv[i] = ch * 8 < a.Mpad ? *(const uint4*)(KTb + (long)d * a.kt_ld + ch * 8) : z4;
+      tv[4 + i] = ch * 8 < Npad ? *(const uint4*)(DYT + (long)d * a.dyt_ld + ch * 8) : z4;
+      tv[8 + i] = ch * 8 < Npad ? *(const uint4*)(QT + (long)d * a.qt_ld + ch * 8) : z4;
+      const int r = c >> 3, cc = c & 7, rr = r < a.M ? r : a.M - 1;
+      kv[i] = *(const uint4*)(Kb + (long)rr * a.k_ld + cc * 8);
+      kv[4 + i] = *(const uint4*)(VWb + (long)rr * a.vw_ld + cc * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i, d = c >> 4, ch = c & 15, r = c >> 3, cc = c & 7;
+      *(uint4*)(sKT + d * kSmT + ch * 8) = tv[i];
+      *(uint4*)(sDYT + d * kSmT + ch * 8) = tv[4 + i];
+      *(uint4*)(sQT + d * kSmT + ch * 8) = tv[8 + i];
+      *(uint4*)(sK + r * kSmK + cc * 8) = kv[i];
+      *(uint4*)(sVW + r * kSmK + cc * 8) = kv[4 + i];
+    }
+  }
+  __syncthreads();
+  const int Mb = a.key_count ? min(max(a.key_count[b], 1), a.M) : a.M;
+  if (wave < nqt) {
+    // ================= q part: this wavefront = 32 queries (relation_attention_bwd_q_kernel with the operands in LDS) =================
+    const int q = wave * 32 + l31;
+    const int qc = q < a.N ? q : a.N - 1;
+    const T* Qr = (const T*)a.q + (long)b * a.q_bs + (long)qc * a.q_ld + h * 64;
+    const T* dYr = (const T*)a.dy + (long)b * a.dy_bs + (long)qc * a.dy_ld + h * 64;
+    const T* Yr = (const T*)a.y + (long)b * a.y_bs + (long)qc * a.y_ld + h * 64;
+    float* Lq = (float*)a.dlog + (((long)b * a.H + h) * a.N + qc) * a.Mpad;
+    Frag<T> qf, dyf;
+    qf.load(Qr, half);
+    dyf.load(dYr, half);
+    float D = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bf16x8 yv = *(const bf16x8*)(Yr + 16 * kk + 8 * half);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int d = 16 * kk + 8 * half + j;
+        D += dyf.get(kk, j) * (bf2f((unsigned short)yv[j]) - (a.bout ? a.bout[h * 64 + d] : 0.f));
+      }
+    }
+    D += __shfl_xor(D, 32);
+    float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {                                    // pass 1: row maximum and normaliser
+      if (kt >= nkt) break;
+      const int key0 = kt * 32;
+      f32x16 s = dot64<T>(sK + (key0 + l31) * kSmK, qf, half);
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int kbase = key0 + 8 * gq + 4 * half;
+        const float4 bv = bq[kt][gq];
+        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = bb[e] + a.scale * s[4 * gq + e];
+          v = (kbase + e < Mb) ? v : -INFINITY;
+          s[4 * gq + e] = v;
+          tmax = fmaxf(tmax, v);
+        }
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m_run, tmax);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) psum += expf(s[r] - m_new);
+      l_run = l_run * expf(m_run - m_new) + psum;
+      m_run = m_new;
+    }
+    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+    f32x16 o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {                                    // pass 2: S, dS, dL, dQ
+      if (kt >= nkt) break;
+      const int key0 = kt * 32;
+      f32x16 s = dot64<T>(sK + (key0 + l31) * kSmK, qf, half);
+      const f32x16 ds = dot64<T>(sVW + (key0 + l31) * kSmK, dyf, half);
+      f32x16 dl;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int kbase = key0 + 8 * gq + 4 * half;
+        const float4 bv = bq[kt][gq];
+        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+        float pv[4], lv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * gq + e;
+          const float v = bb[e] + a.scale * s[r];
+          pv[e] = (kbase + e < Mb) ? expf(v - m_run) * inv : 0.f;
+          lv[e] = pv[e] * (ds[r] - D);
+          dl[r] = lv[e];
+        }
+        // S / dL for the key tiles' wavefronts: bf16 in LDS (exactly what acc_pv packs them to); dL for the geometry backward: fp32 in HBM
+        *(uint2*)(sP + q * kSmT + kbase) = make_uint2(pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]));
+        *(uint2*)(sL + q * kSmT + kbase) = make_uint2(pack_bf16x2(lv[0], lv[1]), pack_bf16x2(lv[2], lv[3]));
+        if (q < a.N) *(float4*)(Lq + kbase) = make_float4(lv[0], lv[1], lv[2], lv[3]);
+      }
+      acc_pv<T>(o, sKT + key0 + 4 * half, kSmT, l31, dl);
+    }
+    if (q < a.N) {
+      if constexpr (PACK) store_rows_bf16((unsigned short*)a.dq + ((long)b * a.N + q) * (3 * a.H * 64) + h * 64, o, half, a.scale);
+      else store_rows(a.dq + ((long)b * a.N + q) * (a.H * 64) + h * 64, o, half, a.scale);
+    }
+  }
+  __syncthreads();
+  if (wave < nkt) {
+    // ================= kv part: this wavefront = 32 keys (relation_attention_bwd_kv_kernel with S / dL from LDS) =================
+    const int key = wave * 32 + l31;
+    f32x16 ov[2], ok[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { ov[d][r] = 0.f; ok[d][r] = 0.f; }
+    for (int t = 0; t < nqt; ++t) {
+      const int q0 = t * 32;
+      f32x16 p, dl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qq = q0 + 8 * (r >> 2) + 4 * half + (r & 3);
+        const bool okq = qq < a.N;
+        p[r] = okq ? bf2f(sP[qq * kSmT + key]) : 0.f;
+        dl[r] = okq ? bf2f(sL[qq * kSmT + key]) : 0.f;
+      }
+      acc_pv<T>(ov, sDYT + q0 + 4 * half, kSmT, l31, p);
+      acc_pv<T>(ok, sQT + q0 + 4 * half, kSmT, l31, dl);
+    }
+    if (key < a.M) {
+      if constexpr (PACK) {
+        unsigned short* row = (unsigned short*)a.dq + ((long)b * a.N + key) * (3 * a.H * 64) + h * 64;
+        store_rows_bf16(row + a.H * 64, ok, half, a.scale);              // dK block
+        store_rows_bf16(row + 2 * a.H * 64, ov, half, 1.0f);             // dVW block
+      } else {
+        store_rows(a.dvw + ((long)b * a.M + key) * (a.H * 64) + h * 64, ov, half, 1.0f);
+        store_rows(a.dk + ((long)b * a.M + key) * (a.H * 64) + h * 64, ok, half, a.scale);
+      }
+    }
   }
 }
 
@@ -575,8 +787,12 @@ extern "C" int relnet_relation_attention_bwd_kc(
     const void* y, long y_ld, long y_bs, const float* bout, const void* qt, long qt_ld, long qt_bs, const void* dyt,
     long dyt_ld, long dyt_bs, float* prob, float* dlog, float* dq, float* dk, float* dvw, int B, int H, int N, int M,
     int Mpad, int Npad, float scale, int dtype, const int* key_count, void* stream) {
-  RELNET_REQUIRE(q && k && kt && vw && bias && dy && y && qt && dyt && prob && dlog && dq && dk && dvw,
-                 "relnet_relation_attention_bwd: null operand");
+  RELNET_REQUIRE(q && k && kt && vw && bias && dy && y && qt && dyt && dlog && dq, "relnet_relation_attention_bwd: null operand");
+  // dk == dvw == NULL (with prob == NULL): dq is the bf16 [B][N][3 H 64] operand of the projection backward and receives (dQ | dK | dVW)
+  RELNET_REQUIRE((dk && dvw) || (!dk && !dvw && !prob), "relnet_relation_attention_bwd: dk and dvw are given together, or both NULL with prob NULL (packed bf16 output in dq)");
+  // prob == NULL selects the one-workgroup-per-(image, head) form (relation_attention_bwd_small_kernel): bf16, N and Mpad <= 128
+  RELNET_REQUIRE(prob || (dtype == RELNET_BF16 && N <= 128 && Mpad <= 128),
+                 "relnet_relation_attention_bwd: prob may be NULL only for bf16 operands with N, Mpad <= 128 (N=%d Mpad=%d dtype=%d)", N, Mpad, dtype);
   RELNET_REQUIRE(B > 0 && H > 0 && N > 0 && M > 0 && M <= N && Mpad >= M && Mpad % 32 == 0 && Npad >= N && Npad % 32 == 0,
                  "relnet_relation_attention_bwd: bad shape (N=%d M=%d Mpad=%d Npad=%d)", N, M, Mpad, Npad);
   RELNET_REQUIRE(kt_ld >= Mpad && qt_ld >= Npad && dyt_ld >= Npad, "relnet_relation_attention_bwd: transposed operands must be padded");
@@ -588,6 +804,19 @@ extern "C" int relnet_relation_attention_bwd_kc(
   a.B = B; a.H = H; a.N = N; a.M = M; a.Mpad = Mpad; a.scale = scale; a.key_count = key_count;
   hipStream_t s = (hipStream_t)stream;
   dim3 gq((unsigned)(((N + 31) / 32 + 3) / 4), H, B), gk((unsigned)(((M + 31) / 32 + 3) / 4), H, B);
+  if (!prob) {
+    RELNET_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && kt_ld % 8 == 0 && vw_ld % 8 == 0 && dy_ld % 8 == 0 && y_ld % 8 == 0 && qt_ld % 8 == 0 && dyt_ld % 8 == 0 &&
+                   kt_bs % 8 == 0 && qt_bs % 8 == 0 && dyt_bs % 8 == 0 && (((uintptr_t)kt | (uintptr_t)qt | (uintptr_t)dyt | (uintptr_t)k | (uintptr_t)vw) & 15) == 0,
+                   "relnet_relation_attention_bwd(bf16, small-N form): rows of every operand must be 16-byte aligned");
+    static relnet::PerDeviceOnce attr_once;
+    if (attr_once.first()) {
+      hipFuncSetAttribute((const void*)relation_attention_bwd_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute((const void*)relation_attention_bwd_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if (dk) relation_attention_bwd_small_kernel<false><<<dim3(H, B), 256, relnet::kSmallLdsBytes, s>>>(a, Npad);
+    else relation_attention_bwd_small_kernel<true><<<dim3(H, B), 256, relnet::kSmallLdsBytes, s>>>(a, Npad);
+    return check_launch("relnet_relation_attention_bwd");
+  }
   if (dtype == RELNET_F32) {
     RELNET_REQUIRE(q_ld % 4 == 0 && k_ld % 4 == 0 && kt_ld % 4 == 0 && vw_ld % 4 == 0 && dy_ld % 4 == 0 && qt_ld % 4 == 0 && dyt_ld % 4 == 0,
                    "relnet_relation_attention_bwd(f32): rows must be 16-byte aligned");

@@ -1099,8 +1099,14 @@ def wgrad_tn(dy2d, x, out=None, row_scale=None, cout=None, conv=None):
     return out
 
 
-def relation_attention_bwd(q, k, kt, vw, bias, dy, y, bout, qt, dyt, M, heads=16, key_count=None):
-    """Adjoint of relation_attention: -> (dq [B,N,H*64], dk [B,M,H*64], dvw [B,M,H*64], prob, dlog [B,H,N,Mpad]), fp32."""
+def relation_bwd_small_ok(dtype, N, Mpad):
+    """The one-workgroup-per-(image, head) backward (relation_attention_bwd_small_kernel) covers bf16 operands with N, Mpad <= 128."""
+    return dtype == torch.bfloat16 and N <= 128 and Mpad <= 128 and os.environ.get('RELNET_REL_BWD_SMALL', '1') != '0'
+
+
+def relation_attention_bwd(q, k, kt, vw, bias, dy, y, bout, qt, dyt, M, heads=16, key_count=None, packed_out=None):
+    """Adjoint of relation_attention: -> (dq [B,N,H*64], dk [B,M,H*64], dvw [B,M,H*64], prob | None, dlog [B,H,N,Mpad]), fp32
+    (prob is None on the small-N path: S never leaves LDS there)."""
     _chk(q, k, kt, vw, bias, dy, y, bout, qt, dyt, key_count)
     B, N = q.shape[0], q.shape[1]
     H = heads
@@ -1108,18 +1114,27 @@ def relation_attention_bwd(q, k, kt, vw, bias, dy, y, bout, qt, dyt, M, heads=16
     assert bias.dtype == torch.float32 and bias.shape == (B, H, N, Mpad) and bias.is_contiguous()
     assert kt.shape[1] == H * 64 and kt.shape[2] >= Mpad and dyt.shape == qt.shape and qt.shape[1] == H * 64
     dev = q.device
-    prob = torch.empty((B, H, N, Mpad), device=dev, dtype=torch.float32)
+    # N, Mpad <= 128 (the learn-NMS head's module): one workgroup per (image, head) does the q and the kv part with S / dL in LDS --
+    # no `prob` map at all (prob = NULL selects that kernel); RELNET_REL_BWD_SMALL=0 keeps the two-kernel form for the A/B
+    small = relation_bwd_small_ok(q.dtype, N, Mpad)
+    prob = None if small else torch.empty((B, H, N, Mpad), device=dev, dtype=torch.float32)
     dlog = torch.empty((B, H, N, Mpad), device=dev, dtype=torch.float32)
-    dq = torch.empty((B, N, H * 64), device=dev, dtype=torch.float32)
-    dk = torch.empty((B, M, H * 64), device=dev, dtype=torch.float32)
-    dvw = torch.empty((B, M, H * 64), device=dev, dtype=torch.float32)
+    if packed_out is not None:
+        # packed_out [B, N, 3 H 64] bf16 with zero key blocks past row M (a persistent buffer): the small-N kernel writes (dQ | dK | dVW) there
+        # as bf16 -- the operand of the projection backward -- and no fp32 dq / dk / dvw exist; -> (packed_out, None, None, None, dlog)
+        assert small and packed_out.dtype == torch.bfloat16 and packed_out.is_contiguous() and tuple(packed_out.shape) == (B, N, 3 * H * 64)
+        dq, dk, dvw = packed_out, None, None
+    else:
+        dq = torch.empty((B, N, H * 64), device=dev, dtype=torch.float32)
+        dk = torch.empty((B, M, H * 64), device=dev, dtype=torch.float32)
+        dvw = torch.empty((B, M, H * 64), device=dev, dtype=torch.float32)
     _lib.call('relnet_relation_attention_bwd_kc',
               q.data_ptr(), q.stride(1), q.stride(0), k.data_ptr(), k.stride(1), k.stride(0),
               kt.data_ptr(), kt.stride(1), kt.stride(0), vw.data_ptr(), vw.stride(1), vw.stride(0),
               bias.data_ptr(), bias.stride(0), dy.data_ptr(), dy.stride(1), dy.stride(0),
               y.data_ptr(), y.stride(1), y.stride(0), _ptr(bout), qt.data_ptr(), qt.stride(1), qt.stride(0),
-              dyt.data_ptr(), dyt.stride(1), dyt.stride(0), prob.data_ptr(), dlog.data_ptr(), dq.data_ptr(),
-              dk.data_ptr(), dvw.data_ptr(), B, H, N, M, Mpad, Npad, 1.0 / math.sqrt(64.0), _dt(q), _ptr(key_count), _stream())
+              dyt.data_ptr(), dyt.stride(1), dyt.stride(0), _ptr(prob), dlog.data_ptr(), dq.data_ptr(),
+              _ptr(dk), _ptr(dvw), B, H, N, M, Mpad, Npad, 1.0 / math.sqrt(64.0), _dt(q), _ptr(key_count), _stream())
     return dq, dk, dvw, prob, dlog
 
 

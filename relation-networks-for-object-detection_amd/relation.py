@@ -246,12 +246,17 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
         ops.transpose_2d(k, out=kt)
         qt = ops.transpose_2d(q, pad_cols_to=32)
         dyt = ops.transpose_2d(dY, pad_cols_to=32)
-    dq, dk, dvw, prob, dlog = ops.relation_attention_bwd(q, k, kt, vw, bias, dY, y, mod.bout, qt, dyt, M, key_count=key_count)
+    packed = None
+    if sink is not None and dtype == torch.bfloat16 and ops.relation_bwd_small_ok(dtype, N, Mpad):
+        # small-N form (the learn-NMS head's module): the backward kernel writes (dQ | dK | dVW) as bf16 straight into the projection
+        # backward's operand; its key blocks past row M are never written and stay zero in the persistent buffer
+        packed = sink.scratch('a3_%d' % index, (B, N, 3 * d), dtype)       # per module: the trainer's QUEUED weight-gradient product reads it after this call returns
+    dq, dk, dvw, prob, dlog = ops.relation_attention_bwd(q, k, kt, vw, bias, dY, y, mod.bout, qt, dyt, M, key_count=key_count, packed_out=packed)
     if sink is not None and dtype == torch.bfloat16:
         # ---- gradients straight into the trainer's buffers (GradSink): one pack kernel, ONE projection-backward GEMM with the residual
         # gradient in its epilogue, ONE queued weight-gradient product for [Wq; Wk; Wout], two column-sum kernels for the biases
         ops.geometry_bias_bwd(bx, bias, dlog, M, fast=True, out=(sink.dwp, sink.dbp))
-        a3 = ops.relation_bwd_pack(dq, dk, dvw)                              # [B, N, 3 d] bf16 = (dQ | dK | dVW), key blocks zero past M
+        a3 = packed if packed is not None else ops.relation_bwd_pack(dq, dk, dvw)   # [B, N, 3 d] bf16 = (dQ | dK | dVW), key blocks zero past M
         a3_2d = a3.view(B * N, 3 * d)
         d_f = ops.gemm_nt(a3_2d, sink.wcat_t, resid=None if sink.resid is None else sink.resid.reshape(B * N, Fd)).reshape(B, N, Fd)
         sink.wgrad(a3_2d, f.reshape(B * N, Fd))

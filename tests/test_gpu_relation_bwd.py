@@ -138,3 +138,42 @@ def test_key_count_masks_padding_rows(dtype):
             continue
         e = _rel(g[k].double().cpu().numpy().reshape(want.shape), want)
         assert e <= 10 * tol, (k, e)
+
+
+@pytest.mark.parametrize('n,m,kc', [(100, 100, False), (128, 96, False), (37, 37, False), (70, 70, True)])
+def test_small_n_fused_backward_equals_the_two_kernel_form(n, m, kc, monkeypatch):
+    """N, Mpad <= 128 (the learn-NMS head's relation module: 100 ranked rois per (image, class)): relation_attention_bwd_small_kernel -- q part and kv
+    part of one (image, head) in one workgroup, K / VW / K^T staged in LDS, S and dL handed over through LDS as the bf16 MFMA operands they become
+    anyway -- against the two-kernel form (fp32 S / dL maps through HBM) on the same operands: same rounding points, so dQ, dK, dVW and dL agree bit for bit."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import ops
+    g = torch.Generator().manual_seed(n * 7 + m)
+    B, H, d = 5, 16, 1024
+    bt = torch.bfloat16
+    mpad, npad = ops.pad32(m), ops.pad32(n)
+    qk = (torch.randn(B, n, 2 * d, generator=g) * 0.3).cuda().to(bt)
+    q, k = qk[:, :, :d], qk[:, :m, d:]
+    vw = (torch.randn(B, m, d, generator=g) * 0.3).cuda().to(bt)
+    dy = torch.randn(B, n, d, generator=g).cuda().to(bt)
+    y = torch.randn(B, n, d, generator=g).cuda().to(bt)
+    bout = torch.randn(d, generator=g).cuda()
+    bias = (torch.randn(B, H, n, mpad, generator=g) - 2.0).cuda()
+    kt = torch.zeros(B, d, mpad, device='cuda', dtype=bt); ops.transpose_2d(k, out=kt)
+    qt = ops.transpose_2d(q, pad_cols_to=32); dyt = ops.transpose_2d(dy, pad_cols_to=32)
+    key_count = torch.tensor([m, max(1, m // 2), m - 3, 1, m], dtype=torch.int32).cuda() if kc else None
+    res = {}
+    for small in ('1', '0'):
+        monkeypatch.setenv('RELNET_REL_BWD_SMALL', small)
+        res[small] = ops.relation_attention_bwd(q, k, kt, vw, bias, dy, y, bout, qt, dyt, m, key_count=key_count)
+    assert res['1'][3] is None and res['0'][3] is not None              # the fused form never writes the S map
+    for i, name in ((0, 'dq'), (1, 'dk'), (2, 'dvw')):
+        assert torch.equal(res['1'][i], res['0'][i]), name
+    assert torch.equal(res['1'][4][..., :m], res['0'][4][..., :m])       # dL (columns >= M are padding in both)
+    assert torch.isfinite(res['1'][0]).all() and float(res['1'][1].abs().max()) > 0
+    # packed output: the kernel writes bf16 (dQ | dK | dVW) straight into the projection backward's operand = relnet_relation_bwd_pack of the above
+    monkeypatch.setenv('RELNET_REL_BWD_SMALL', '1')
+    a3 = torch.zeros(B, n, 3 * d, device='cuda', dtype=bt)
+    out = ops.relation_attention_bwd(q, k, kt, vw, bias, dy, y, bout, qt, dyt, m, key_count=key_count, packed_out=a3)
+    assert out[0] is a3 and out[1] is None and out[2] is None
+    assert torch.equal(a3, ops.relation_bwd_pack(res['1'][0], res['1'][1], res['1'][2]))
+    assert torch.equal(out[4][..., :m], res['1'][4][..., :m])
