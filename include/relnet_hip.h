@@ -441,8 +441,9 @@ int relnet_lnms_scatter_bwd(const float* d_sorted, const int* rank_idx, float* d
  * [B][H*64][>=Npad] zero padded; vw = F_K Wout^T [B][M][H*64] (not transposed); bias = fp32 log G of the forward;
  * dy / y = gradient / value of the module output [B][N][H*64] (y includes bout).  Writes prob (softmax) and dlog
  * (d loss / d logits) [B][H][N][Mpad], dq [B][N][H*64], dk and dvw [B][M][H*64].
- * prob == NULL (bf16 operands, N and Mpad <= 128, 16-byte aligned rows): the one-workgroup-per-(image, head) form -- K, VW, K^T, dY^T, Q^T
- * staged in LDS, S and dL handed from the query tiles to the key tiles through LDS, no S map in HBM; same results bit for bit.  With
+ * prob == NULL (bf16 operands, N and Mpad <= 128, 16-byte aligned rows): the one-workgroup-per-(image, head) form -- the rows of K, VW, Q, dY
+ * staged in LDS (their transposes are read from there: kt / qt / dyt are not used and may be NULL), S and dL handed from the query tiles to the
+ * key tiles through LDS, no S map in HBM; same results bit for bit.  With
  * dk == dvw == NULL as well, dq is a bf16 [B][N][3 H 64] buffer that receives (dQ | dK | dVW) -- the operand relnet_relation_bwd_pack
  * would build -- and whose key blocks must already be zero for rows >= M.                                                       */
 int relnet_relation_attention_bwd(const void* q, long q_ld, long q_bs, const void* k, long k_ld, long k_bs,

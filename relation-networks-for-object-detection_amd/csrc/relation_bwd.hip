@@ -93,6 +93,14 @@ struct AttnBwdArgs {
   const int* key_count;                    // optional [B]: keys >= key_count[b] of image b are masked (as in the forward kernels)
 };
 
+// exp of the softmax recompute: libm expf on the float32 parity path; the hardware exponential (v_exp_f32, ~1 ulp) on the bf16 training path,
+// where a wavefront evaluates ~34 of them per key tile and the ~40-instruction libm sequence made the backward kernels VALU bound
+// (round 5: the small-N kernel with one wavefront per SIMD spent ~10 of its 30 us per workgroup in expf).
+template <typename T> __device__ __forceinline__ float sm_exp(float x) {
+  if constexpr (sizeof(T) == 2) return __expf(x);
+  else return expf(x);
+}
+
 template <typename T> struct Frag;
 template <> struct Frag<unsigned short> {           // 64 contraction values of one row as 4 bf16x8 fragments
   bf16x8 f[4];
@@ -267,8 +275,8 @@ __global__ __launch_bounds__(256) void relation_attention_bwd_q_kernel(AttnBwdAr
     const float m_new = fmaxf(m_run, tmax);
     float psum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) psum += expf(s[r] - m_new);
-    l_run = l_run * expf(m_run - m_new) + psum;
+    for (int r = 0; r < 16; ++r) psum += sm_exp<T>(s[r] - m_new);
+    l_run = l_run * sm_exp<T>(m_run - m_new) + psum;
     m_run = m_new;
   }
   const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(256) void relation_attention_bwd_q_kernel(AttnBwdAr
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * gq + e;
         const float v = bb[e] + a.scale * s[r];
-        pv[e] = (kbase + e < Mb) ? expf(v - m_run) * inv : 0.f;
+        pv[e] = (kbase + e < Mb) ? sm_exp<T>(v - m_run) * inv : 0.f;
         lv[e] = pv[e] * (ds[r] - D);
         dl[r] = lv[e];
       }
@@ -351,199 +359,237 @@ __global__ __launch_bounds__(256) void relation_attention_bwd_kv_kernel(AttnBwdA
 // learn-NMS head's relation module (symbols/..._learn_nms.py:480-486: 100 ranked rois per (image, class), 640 pseudo-images at 8
 // images per step).  The two-kernel form above spends its time on L2 round trips and on the fp32 S / dL maps
 // ([640][16][100][128] x 4 B = 524 MB each: written by the q kernel, gathered column-wise by the kv kernel): 1.05 + 0.55 ms per
-// step.  Here K, VW and K^T of the (image, head) are staged in LDS once (53 KB), every query tile's wavefront reads its
+// step.  Here the 64-channel rows of K, VW, Q and dY of the (image, head) are staged in LDS once (72 KB), every query tile's wavefront reads its
 // fragments from there, S and dL go to LDS as the bf16 values the kv products round them to anyway (70 KB) and are read back
 // row-major by the key tiles' wavefronts after one barrier; only dL still goes to HBM (fp32, for the geometry backward).
-// dY^T and Q^T (the kv part's A operands) are staged too and the q part's log G rows are read into registers before the first
-// barrier: with one 4-wave workgroup per CU (155 KB of LDS) no other wavefront hides a load, so no global read sits inside the loops
-// (first version, loads in the loops: 1.50 ms per learn-NMS launch = no gain over the two kernels' 1.05 + 0.55).
+// The transposed A operands of the dQ / dK / dVW products (K^T, Q^T, dY^T) are read from those row-major images on the fly (acc_pv_rm): no
+// transposed copies are built or staged (the two-kernel form needs three transpose launches per module).  The q part's log G rows are read
+// into registers before the first barrier: with one 4-wave workgroup per CU (140 KB of LDS) no other wavefront hides a load, so no global
+// read sits inside the loops (first version, loads in the loops: 1.50 ms per learn-NMS launch = no gain over the two kernels' 1.05 + 0.55).
 // Arithmetic and rounding points are those of the two-kernel form: same dq / dk / dvw / dlog bit for bit.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kSmK = 72, kSmT = 136;                                     // LDS row pitches (elements): 4 x odd words -> conflict-free fragment reads
-constexpr int kSmallLdsBytes = 2 * 128 * kSmK * 2 + 3 * 64 * kSmT * 2 + 2 * 128 * kSmT * 2;  // K | VW | K^T, dY^T, Q^T | S | dL = 158 720 B
+constexpr int kSmallLdsBytes = 4 * 128 * kSmK * 2 + 2 * 128 * kSmT * 2;  // K | VW | Q | dY (row-major [row][64]) | S | dL = 143 360 B
+
+// acc_pv with the A operand TRANSPOSED ON THE FLY from a row-major LDS image rm[x][kSmK] (x = key or query, 64 channels per row):
+// o[d] += A^T[32 d + l31][x0 ...] * p, A^T[ch][x] = rm[x][ch].  Eight 2-byte LDS reads per fragment (lanes = consecutive channels of one row: 64
+// contiguous bytes, conflict-free) instead of two 8-byte reads of a pre-transposed copy -- which costs a transpose launch and a second staged
+// array per operand (K^T, Q^T, dY^T: 3 x 168 MB written and read back at the learn-NMS head, 0.28 ms of transposes per step).
+__device__ __forceinline__ void acc_pv_rm(f32x16 (&o)[2], const unsigned short* rm, int x0, int l31, int half, const f32x16& p) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    bf16x8 pf;
+    unsigned int* pw = (unsigned int*)&pf;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) pw[t] = pack_bf16x2(p[8 * ks + 2 * t], p[8 * ks + 2 * t + 1]);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const unsigned short* col = rm + (x0 + 4 * half + 16 * ks) * kSmK + 32 * d + l31;
+      bf16x8 af;
+      unsigned int* aw = (unsigned int*)&af;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int xa = (t < 2 ? 0 : 8) + 2 * (t & 1);                  // k-slots 0-3 <-> x + 0..3, slots 4-7 <-> x + 8..11 (as acc_pv)
+        aw[t] = (unsigned int)col[xa * kSmK] | ((unsigned int)col[(xa + 1) * kSmK] << 16);
+      }
+      o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf, o[d], 0, 0, 0);
+    }
+  }
+}
 
 // PACK: dQ / dK / dVW leave as bf16 straight into the [B][N][3 H 64] operand of the projection backward (dQ | dK | dVW column blocks: what
 // relnet_relation_bwd_pack builds from the fp32 outputs otherwise -- 786 MB written and read back at the learn-NMS head); a.dq then points to
 // that buffer, whose key blocks must be zero for rows >= M (the kernel never writes them).
 template <bool PACK>
-__global__ __launch_bounds__(256) void relation_attention_bwd_small_kernel(AttnBwdArgs a, int Npad) {
+__global__ __launch_bounds__(256) void relation_attention_bwd_small_kernel(AttnBwdArgs a) {
   typedef unsigned short T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
-  T* sK = (T*)smem_s;                       // [128][kSmK]
-  T* sVW = sK + 128 * kSmK;                 // [128][kSmK]
-  T* sKT = sVW + 128 * kSmK;                // [64][kSmT]
-  T* sDYT = sKT + 64 * kSmT;                // [64][kSmT]    dY^T (queries contiguous)
-  T* sQT = sDYT + 64 * kSmT;                // [64][kSmT]    Q^T
-  T* sP = sQT + 64 * kSmT;                  // [128][kSmT]   S  (bf16)
+  T* sK = (T*)smem_s;                       // [128][kSmK]   K rows  (keys)
+  T* sVW = sK + 128 * kSmK;                 // [128][kSmK]   VW rows (keys)
+  T* sQ = sVW + 128 * kSmK;                 // [128][kSmK]   Q rows  (queries)
+  T* sDY = sQ + 128 * kSmK;                 // [128][kSmK]   dY rows (queries)
+  T* sP = sDY + 128 * kSmK;                 // [128][kSmT]   S  (bf16)
   T* sL = sP + 128 * kSmT;                  // [128][kSmT]   dL (bf16)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int h = blockIdx.x, b = blockIdx.y;
-  const T* Kb = (const T*)a.k + (long)b * a.k_bs + h * 64;
-  const T* VWb = (const T*)a.vw + (long)b * a.vw_bs + h * 64;
-  const T* KTb = (const T*)a.kt + (long)b * a.kt_bs + (long)(h * 64) * a.kt_ld;
-  const T* DYT = (const T*)a.dyt + (long)b * a.dyt_bs + (long)(h * 64) * a.dyt_ld;
-  const T* QT = (const T*)a.qt + (long)b * a.qt_bs + (long)(h * 64) * a.qt_ld;
   const int nqt = (a.N + 31) / 32, nkt = (a.M + 31) / 32;
-  // ---- this lane's log G row (the q part's only other global operand), all key tiles up front: with one 4-wave workgroup per CU nothing else
-  // hides a load, so every global read of the kernel is issued before the first barrier (one wave per SIMD: 512 registers to hold them)
-  const int q_ = wave * 32 + l31, qc_ = q_ < a.N ? q_ : a.N - 1;
-  const float* Bq_ = a.bias + (long)b * a.bias_bs + ((long)h * a.N + qc_) * a.Mpad;
+  const int q = wave * 32 + l31, qc = q < a.N ? q : a.N - 1;
+  const int npair = a.H * a.B;
+  // Persistent over the (image, head) pairs with the NEXT pair's operands in flight: one 4-wave workgroup per CU (140 KB of LDS) means no other
+  // wavefront hides a load -- counters of the non-persistent form: 58 % of the wave cycles parked in s_waitcnt / barriers, 20 % VALU.  So every
+  // global read of a pair (16 staging chunks, the 16 float4 of this lane's log G row, its Y row) is issued while the PREVIOUS pair is being
+  // computed and held in registers (one wave per SIMD: 512 registers).
+  uint4 kK0, kK1, kK2, kK3, kV0, kV1, kV2, kV3, kQ0, kQ1, kQ2, kQ3, kD0, kD1, kD2, kD3;      // (named scalars: a loop-carried uint4[16] stayed in scratch)
   float4 bq[4][4];
-#pragma unroll
-  for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq)
-      bq[kt][gq] = (wave < nqt && kt < nkt) ? *(const float4*)(Bq_ + kt * 32 + 8 * gq + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
-  // ---- stage K, VW (rows >= M: the last row, as the clamped loads of the two-kernel form), K^T, dY^T and Q^T (zero padded by the caller; columns
-  // past the buffers' padded width are zero filled here).  Fixed trip counts, all 20 16-byte loads of a thread issued before the first LDS write:
-  // a loop of load -> write iterations costs one L2 round trip per iteration (measured: 1.39 ms per learn-NMS launch with such loops).
-  {
-    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-    uint4 tv[12], kv[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * i, d = c >> 4, ch = c & 15;            // row d of a transposed operand, 8 consecutive keys / queries
-      tv[i] = ch * 8 < a.Mpad ? *(const uint4*)(KTb + (long)d * a.kt_ld + ch * 8) : z4;
-      tv[4 + i] = ch * 8 < Npad ? *(const uint4*)(DYT + (long)d * a.dyt_ld + ch * 8) : z4;
-      tv[8 + i] = ch * 8 < Npad ? *(const uint4*)(QT + (long)d * a.qt_ld + ch * 8) : z4;
-      const int r = c >> 3, cc = c & 7, rr = r < a.M ? r : a.M - 1;
-      kv[i] = *(const uint4*)(Kb + (long)rr * a.k_ld + cc * 8);
-      kv[4 + i] = *(const uint4*)(VWb + (long)rr * a.vw_ld + cc * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * i, d = c >> 4, ch = c & 15, r = c >> 3, cc = c & 7;
-      *(uint4*)(sKT + d * kSmT + ch * 8) = tv[i];
-      *(uint4*)(sDYT + d * kSmT + ch * 8) = tv[4 + i];
-      *(uint4*)(sQT + d * kSmT + ch * 8) = tv[8 + i];
-      *(uint4*)(sK + r * kSmK + cc * 8) = kv[i];
-      *(uint4*)(sVW + r * kSmK + cc * 8) = kv[4 + i];
-    }
+  bf16x8 yv[4];
+  // (a macro, not a lambda: with the arrays captured by reference the compiler kept kv[] in scratch -- and a scratch reload waits on vmcnt,
+  //  i.e. for the very prefetch it belongs to)
+#define RELNET_SMALL_LD(I)                                                                                                            \
+  {                                                                                                                                   \
+    const int c = tid + 256 * I, r = c >> 3, cc = c & 7;                                                                              \
+    const int rk = r < a.M ? r : a.M - 1, rq = r < a.N ? r : a.N - 1;                                                                 \
+    kK##I = *(const uint4*)(Kb + (long)rk * a.k_ld + cc * 8);                                                                         \
+    kV##I = *(const uint4*)(VWb + (long)rk * a.vw_ld + cc * 8);                                                                       \
+    kQ##I = *(const uint4*)(Qb + (long)rq * a.q_ld + cc * 8);                                                                         \
+    kD##I = *(const uint4*)(DYb + (long)rq * a.dy_ld + cc * 8);                                                                       \
   }
-  __syncthreads();
-  const int Mb = a.key_count ? min(max(a.key_count[b], 1), a.M) : a.M;
-  if (wave < nqt) {
-    // ================= q part: this wavefront = 32 queries (relation_attention_bwd_q_kernel with the operands in LDS) =================
-    const int q = wave * 32 + l31;
-    const int qc = q < a.N ? q : a.N - 1;
-    const T* Qr = (const T*)a.q + (long)b * a.q_bs + (long)qc * a.q_ld + h * 64;
-    const T* dYr = (const T*)a.dy + (long)b * a.dy_bs + (long)qc * a.dy_ld + h * 64;
-    const T* Yr = (const T*)a.y + (long)b * a.y_bs + (long)qc * a.y_ld + h * 64;
-    float* Lq = (float*)a.dlog + (((long)b * a.H + h) * a.N + qc) * a.Mpad;
-    Frag<T> qf, dyf;
-    qf.load(Qr, half);
-    dyf.load(dYr, half);
-    float D = 0.f;
+#define RELNET_SMALL_ST(I)                                                                                                            \
+  {                                                                                                                                   \
+    const int c = tid + 256 * I, r = c >> 3, cc = c & 7;                                                                              \
+    *(uint4*)(sK + r * kSmK + cc * 8) = kK##I;                                                                                        \
+    *(uint4*)(sVW + r * kSmK + cc * 8) = kV##I;                                                                                       \
+    *(uint4*)(sQ + r * kSmK + cc * 8) = kQ##I;                                                                                        \
+    *(uint4*)(sDY + r * kSmK + cc * 8) = kD##I;                                                                                       \
+  }
+#define RELNET_SMALL_ISSUE(PAIR)                                                                                                      \
+  {                                                                                                                                   \
+    const int h_ = (PAIR) % a.H, b_ = (PAIR) / a.H;                                                                                   \
+    const T* Kb = (const T*)a.k + (long)b_ * a.k_bs + h_ * 64;                                                                        \
+    const T* VWb = (const T*)a.vw + (long)b_ * a.vw_bs + h_ * 64;                                                                     \
+    const T* Qb = (const T*)a.q + (long)b_ * a.q_bs + h_ * 64;                                                                        \
+    const T* DYb = (const T*)a.dy + (long)b_ * a.dy_bs + h_ * 64;                                                                     \
+    RELNET_SMALL_LD(0) RELNET_SMALL_LD(1) RELNET_SMALL_LD(2) RELNET_SMALL_LD(3)                                                       \
+    const float* Bq_ = a.bias + (long)b_ * a.bias_bs + ((long)h_ * a.N + qc) * a.Mpad;                                               \
+    _Pragma("unroll") for (int kt = 0; kt < 4; ++kt)                                                                                  \
+      _Pragma("unroll") for (int gq = 0; gq < 4; ++gq)                                                                                \
+        bq[kt][gq] = (wave < nqt && kt < nkt) ? *(const float4*)(Bq_ + kt * 32 + 8 * gq + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f); \
+    const T* Yr = (const T*)a.y + (long)b_ * a.y_bs + (long)qc * a.y_ld + h_ * 64;                                                    \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) yv[kk] = *(const bf16x8*)(Yr + 16 * kk + 8 * half);                              \
+  }
+  int pair = blockIdx.x;
+  RELNET_SMALL_ISSUE(min(pair, npair - 1))
+  for (; pair < npair; pair += gridDim.x) {
+    const int h = pair % a.H, b = pair / a.H;
+    // ---- this pair's operands: registers -> LDS (everyone left the previous pair's kv part at the barrier that ends the loop body)
+    RELNET_SMALL_ST(0) RELNET_SMALL_ST(1) RELNET_SMALL_ST(2) RELNET_SMALL_ST(3)
+    float4 bc[4][4];
+    bf16x8 yc[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const bf16x8 yv = *(const bf16x8*)(Yr + 16 * kk + 8 * half);
+    for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int d = 16 * kk + 8 * half + j;
-        D += dyf.get(kk, j) * (bf2f((unsigned short)yv[j]) - (a.bout ? a.bout[h * 64 + d] : 0.f));
+      for (int gq = 0; gq < 4; ++gq) bc[kt][gq] = bq[kt][gq];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) yc[kk] = yv[kk];
+    __syncthreads();
+    RELNET_SMALL_ISSUE(min(pair + (int)gridDim.x, npair - 1))           // in flight during this pair's arithmetic (unconditional: the last round re-reads
+                                                                        // a valid pair -- a conditional refill keeps the arrays out of registers)
+    const int Mb = a.key_count ? min(max(a.key_count[b], 1), a.M) : a.M;
+    if (wave < nqt) {
+      // ================= q part: this wavefront = 32 queries (relation_attention_bwd_q_kernel with the operands in LDS) =================
+      float* Lq = (float*)a.dlog + (((long)b * a.H + h) * a.N + qc) * a.Mpad;
+      Frag<T> qf, dyf;
+      qf.load(sQ + q * kSmK, half);                                     // (row q < 128 of the staged image: rows >= N hold the last row, like qc)
+      dyf.load(sDY + q * kSmK, half);
+      float D = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int d = 16 * kk + 8 * half + j;
+          D += dyf.get(kk, j) * (bf2f((unsigned short)yc[kk][j]) - (a.bout ? a.bout[h * 64 + d] : 0.f));
+        }
+      D += __shfl_xor(D, 32);
+      float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {                                  // pass 1: row maximum and normaliser
+        if (kt >= nkt) break;
+        const int key0 = kt * 32;
+        f32x16 s = dot64<T>(sK + (key0 + l31) * kSmK, qf, half);
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int kbase = key0 + 8 * gq + 4 * half;
+          const float4 bv = bc[kt][gq];
+          const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = bb[e] + a.scale * s[4 * gq + e];
+            v = (kbase + e < Mb) ? v : -INFINITY;
+            s[4 * gq + e] = v;
+            tmax = fmaxf(tmax, v);
+          }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) psum += sm_exp<T>(s[r] - m_new);
+        l_run = l_run * sm_exp<T>(m_run - m_new) + psum;
+        m_run = m_new;
+      }
+      const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+      f32x16 o[2];
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {                                  // pass 2: S, dS, dL, dQ
+        if (kt >= nkt) break;
+        const int key0 = kt * 32;
+        f32x16 s = dot64<T>(sK + (key0 + l31) * kSmK, qf, half);
+        const f32x16 ds = dot64<T>(sVW + (key0 + l31) * kSmK, dyf, half);
+        f32x16 dl;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int kbase = key0 + 8 * gq + 4 * half;
+          const float4 bv = bc[kt][gq];
+          const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+          float pv[4], lv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * gq + e;
+            const float v = bb[e] + a.scale * s[r];
+            pv[e] = (kbase + e < Mb) ? sm_exp<T>(v - m_run) * inv : 0.f;
+            lv[e] = pv[e] * (ds[r] - D);
+            dl[r] = lv[e];
+          }
+          // S / dL for the key tiles' wavefronts: bf16 in LDS (exactly what acc_pv packs them to); dL for the geometry backward: fp32 in HBM
+          *(uint2*)(sP + q * kSmT + kbase) = make_uint2(pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]));
+          *(uint2*)(sL + q * kSmT + kbase) = make_uint2(pack_bf16x2(lv[0], lv[1]), pack_bf16x2(lv[2], lv[3]));
+          if (q < a.N) *(float4*)(Lq + kbase) = make_float4(lv[0], lv[1], lv[2], lv[3]);
+        }
+        acc_pv_rm(o, sK, key0, l31, half, dl);                          // dQ += dL K  (K^T read from the row-major image)
+      }
+      if (q < a.N) {
+        if constexpr (PACK) store_rows_bf16((unsigned short*)a.dq + ((long)b * a.N + q) * (3 * a.H * 64) + h * 64, o, half, a.scale);
+        else store_rows(a.dq + ((long)b * a.N + q) * (a.H * 64) + h * 64, o, half, a.scale);
       }
     }
-    D += __shfl_xor(D, 32);
-    float m_run = -INFINITY, l_run = 0.f;
+    __syncthreads();
+    if (wave < nkt) {
+      // ================= kv part: this wavefront = 32 keys (relation_attention_bwd_kv_kernel with S / dL from LDS) =================
+      const int key = wave * 32 + l31;
+      f32x16 ov[2], ok[2];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {                                    // pass 1: row maximum and normaliser
-      if (kt >= nkt) break;
-      const int key0 = kt * 32;
-      f32x16 s = dot64<T>(sK + (key0 + l31) * kSmK, qf, half);
-      float tmax = -INFINITY;
+      for (int d = 0; d < 2; ++d)
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int kbase = key0 + 8 * gq + 4 * half;
-        const float4 bv = bq[kt][gq];
-        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+        for (int r = 0; r < 16; ++r) { ov[d][r] = 0.f; ok[d][r] = 0.f; }
+      for (int t = 0; t < nqt; ++t) {
+        const int q0 = t * 32;
+        f32x16 p, dl;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = bb[e] + a.scale * s[4 * gq + e];
-          v = (kbase + e < Mb) ? v : -INFINITY;
-          s[4 * gq + e] = v;
-          tmax = fmaxf(tmax, v);
+        for (int r = 0; r < 16; ++r) {
+          const int qq = q0 + 8 * (r >> 2) + 4 * half + (r & 3);
+          const bool okq = qq < a.N;
+          p[r] = okq ? bf2f(sP[qq * kSmT + key]) : 0.f;
+          dl[r] = okq ? bf2f(sL[qq * kSmT + key]) : 0.f;
+        }
+        acc_pv_rm(ov, sDY, q0, l31, half, p);                           // dVW += S^T dY
+        acc_pv_rm(ok, sQ, q0, l31, half, dl);                           // dK  += dL^T Q
+      }
+      if (key < a.M) {
+        if constexpr (PACK) {
+          unsigned short* row = (unsigned short*)a.dq + ((long)b * a.N + key) * (3 * a.H * 64) + h * 64;
+          store_rows_bf16(row + a.H * 64, ok, half, a.scale);            // dK block
+          store_rows_bf16(row + 2 * a.H * 64, ov, half, 1.0f);           // dVW block
+        } else {
+          store_rows(a.dvw + ((long)b * a.M + key) * (a.H * 64) + h * 64, ov, half, 1.0f);
+          store_rows(a.dk + ((long)b * a.M + key) * (a.H * 64) + h * 64, ok, half, a.scale);
         }
       }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-      const float m_new = fmaxf(m_run, tmax);
-      float psum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) psum += expf(s[r] - m_new);
-      l_run = l_run * expf(m_run - m_new) + psum;
-      m_run = m_new;
     }
-    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
-    f32x16 o[2];
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {                                    // pass 2: S, dS, dL, dQ
-      if (kt >= nkt) break;
-      const int key0 = kt * 32;
-      f32x16 s = dot64<T>(sK + (key0 + l31) * kSmK, qf, half);
-      const f32x16 ds = dot64<T>(sVW + (key0 + l31) * kSmK, dyf, half);
-      f32x16 dl;
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int kbase = key0 + 8 * gq + 4 * half;
-        const float4 bv = bq[kt][gq];
-        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-        float pv[4], lv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * gq + e;
-          const float v = bb[e] + a.scale * s[r];
-          pv[e] = (kbase + e < Mb) ? expf(v - m_run) * inv : 0.f;
-          lv[e] = pv[e] * (ds[r] - D);
-          dl[r] = lv[e];
-        }
-        // S / dL for the key tiles' wavefronts: bf16 in LDS (exactly what acc_pv packs them to); dL for the geometry backward: fp32 in HBM
-        *(uint2*)(sP + q * kSmT + kbase) = make_uint2(pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]));
-        *(uint2*)(sL + q * kSmT + kbase) = make_uint2(pack_bf16x2(lv[0], lv[1]), pack_bf16x2(lv[2], lv[3]));
-        if (q < a.N) *(float4*)(Lq + kbase) = make_float4(lv[0], lv[1], lv[2], lv[3]);
-      }
-      acc_pv<T>(o, sKT + key0 + 4 * half, kSmT, l31, dl);
-    }
-    if (q < a.N) {
-      if constexpr (PACK) store_rows_bf16((unsigned short*)a.dq + ((long)b * a.N + q) * (3 * a.H * 64) + h * 64, o, half, a.scale);
-      else store_rows(a.dq + ((long)b * a.N + q) * (a.H * 64) + h * 64, o, half, a.scale);
-    }
-  }
-  __syncthreads();
-  if (wave < nkt) {
-    // ================= kv part: this wavefront = 32 keys (relation_attention_bwd_kv_kernel with S / dL from LDS) =================
-    const int key = wave * 32 + l31;
-    f32x16 ov[2], ok[2];
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { ov[d][r] = 0.f; ok[d][r] = 0.f; }
-    for (int t = 0; t < nqt; ++t) {
-      const int q0 = t * 32;
-      f32x16 p, dl;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qq = q0 + 8 * (r >> 2) + 4 * half + (r & 3);
-        const bool okq = qq < a.N;
-        p[r] = okq ? bf2f(sP[qq * kSmT + key]) : 0.f;
-        dl[r] = okq ? bf2f(sL[qq * kSmT + key]) : 0.f;
-      }
-      acc_pv<T>(ov, sDYT + q0 + 4 * half, kSmT, l31, p);
-      acc_pv<T>(ok, sQT + q0 + 4 * half, kSmT, l31, dl);
-    }
-    if (key < a.M) {
-      if constexpr (PACK) {
-        unsigned short* row = (unsigned short*)a.dq + ((long)b * a.N + key) * (3 * a.H * 64) + h * 64;
-        store_rows_bf16(row + a.H * 64, ok, half, a.scale);              // dK block
-        store_rows_bf16(row + 2 * a.H * 64, ov, half, 1.0f);             // dVW block
-      } else {
-        store_rows(a.dvw + ((long)b * a.M + key) * (a.H * 64) + h * 64, ov, half, 1.0f);
-        store_rows(a.dk + ((long)b * a.M + key) * (a.H * 64) + h * 64, ok, half, a.scale);
-      }
-    }
+    __syncthreads();                                                    // the LDS images are free for the next pair
   }
 }
 
@@ -787,7 +833,8 @@ extern "C" int relnet_relation_attention_bwd_kc(
     const void* y, long y_ld, long y_bs, const float* bout, const void* qt, long qt_ld, long qt_bs, const void* dyt,
     long dyt_ld, long dyt_bs, float* prob, float* dlog, float* dq, float* dk, float* dvw, int B, int H, int N, int M,
     int Mpad, int Npad, float scale, int dtype, const int* key_count, void* stream) {
-  RELNET_REQUIRE(q && k && kt && vw && bias && dy && y && qt && dyt && dlog && dq, "relnet_relation_attention_bwd: null operand");
+  RELNET_REQUIRE(q && k && vw && bias && dy && y && dlog && dq, "relnet_relation_attention_bwd: null operand");
+  RELNET_REQUIRE((kt && qt && dyt) || !prob, "relnet_relation_attention_bwd: the transposed operands kt / qt / dyt may be NULL only for the small-N form (prob NULL)");
   // dk == dvw == NULL (with prob == NULL): dq is the bf16 [B][N][3 H 64] operand of the projection backward and receives (dQ | dK | dVW)
   RELNET_REQUIRE((dk && dvw) || (!dk && !dvw && !prob), "relnet_relation_attention_bwd: dk and dvw are given together, or both NULL with prob NULL (packed bf16 output in dq)");
   // prob == NULL selects the one-workgroup-per-(image, head) form (relation_attention_bwd_small_kernel): bf16, N and Mpad <= 128
@@ -795,7 +842,7 @@ extern "C" int relnet_relation_attention_bwd_kc(
                  "relnet_relation_attention_bwd: prob may be NULL only for bf16 operands with N, Mpad <= 128 (N=%d Mpad=%d dtype=%d)", N, Mpad, dtype);
   RELNET_REQUIRE(B > 0 && H > 0 && N > 0 && M > 0 && M <= N && Mpad >= M && Mpad % 32 == 0 && Npad >= N && Npad % 32 == 0,
                  "relnet_relation_attention_bwd: bad shape (N=%d M=%d Mpad=%d Npad=%d)", N, M, Mpad, Npad);
-  RELNET_REQUIRE(kt_ld >= Mpad && qt_ld >= Npad && dyt_ld >= Npad, "relnet_relation_attention_bwd: transposed operands must be padded");
+  RELNET_REQUIRE(!prob || (kt_ld >= Mpad && qt_ld >= Npad && dyt_ld >= Npad), "relnet_relation_attention_bwd: transposed operands must be padded");
   AttnBwdArgs a;
   a.q = q; a.q_ld = q_ld; a.q_bs = q_bs; a.k = k; a.k_ld = k_ld; a.k_bs = k_bs; a.kt = kt; a.kt_ld = kt_ld; a.kt_bs = kt_bs;
   a.vw = vw; a.vw_ld = vw_ld; a.vw_bs = vw_bs; a.bias = bias; a.bias_bs = bias_bs; a.dy = dy; a.dy_ld = dy_ld; a.dy_bs = dy_bs;
@@ -805,16 +852,17 @@ extern "C" int relnet_relation_attention_bwd_kc(
   hipStream_t s = (hipStream_t)stream;
   dim3 gq((unsigned)(((N + 31) / 32 + 3) / 4), H, B), gk((unsigned)(((M + 31) / 32 + 3) / 4), H, B);
   if (!prob) {
-    RELNET_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && kt_ld % 8 == 0 && vw_ld % 8 == 0 && dy_ld % 8 == 0 && y_ld % 8 == 0 && qt_ld % 8 == 0 && dyt_ld % 8 == 0 &&
-                   kt_bs % 8 == 0 && qt_bs % 8 == 0 && dyt_bs % 8 == 0 && (((uintptr_t)kt | (uintptr_t)qt | (uintptr_t)dyt | (uintptr_t)k | (uintptr_t)vw) & 15) == 0,
+    RELNET_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && vw_ld % 8 == 0 && dy_ld % 8 == 0 && y_ld % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && vw_bs % 8 == 0 &&
+                   dy_bs % 8 == 0 && (((uintptr_t)q | (uintptr_t)dy | (uintptr_t)k | (uintptr_t)vw) & 15) == 0,
                    "relnet_relation_attention_bwd(bf16, small-N form): rows of every operand must be 16-byte aligned");
     static relnet::PerDeviceOnce attr_once;
     if (attr_once.first()) {
       hipFuncSetAttribute((const void*)relation_attention_bwd_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipFuncSetAttribute((const void*)relation_attention_bwd_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    if (dk) relation_attention_bwd_small_kernel<false><<<dim3(H, B), 256, relnet::kSmallLdsBytes, s>>>(a, Npad);
-    else relation_attention_bwd_small_kernel<true><<<dim3(H, B), 256, relnet::kSmallLdsBytes, s>>>(a, Npad);
+    const unsigned grid = (unsigned)((long)H * B < 256 ? (long)H * B : 256);      // persistent: one workgroup per CU walks the (image, head) pairs
+    if (dk) relation_attention_bwd_small_kernel<false><<<grid, 256, relnet::kSmallLdsBytes, s>>>(a);
+    else relation_attention_bwd_small_kernel<true><<<grid, 256, relnet::kSmallLdsBytes, s>>>(a);
     return check_launch("relnet_relation_attention_bwd");
   }
   if (dtype == RELNET_F32) {

@@ -1110,13 +1110,18 @@ def relation_attention_bwd(q, k, kt, vw, bias, dy, y, bout, qt, dyt, M, heads=16
     _chk(q, k, kt, vw, bias, dy, y, bout, qt, dyt, key_count)
     B, N = q.shape[0], q.shape[1]
     H = heads
-    Mpad, Npad = bias.shape[-1], qt.shape[-1]
+    Mpad = bias.shape[-1]
     assert bias.dtype == torch.float32 and bias.shape == (B, H, N, Mpad) and bias.is_contiguous()
-    assert kt.shape[1] == H * 64 and kt.shape[2] >= Mpad and dyt.shape == qt.shape and qt.shape[1] == H * 64
     dev = q.device
     # N, Mpad <= 128 (the learn-NMS head's module): one workgroup per (image, head) does the q and the kv part with S / dL in LDS --
     # no `prob` map at all (prob = NULL selects that kernel); RELNET_REL_BWD_SMALL=0 keeps the two-kernel form for the A/B
     small = relation_bwd_small_ok(q.dtype, N, Mpad)
+    if small:          # that kernel transposes K / Q / dY on the fly from their row-major images in LDS: kt / qt / dyt are not read (may be None)
+        kt = qt = dyt = None
+        Npad = pad32(N)
+    else:
+        Npad = qt.shape[-1]
+        assert kt.shape[1] == H * 64 and kt.shape[2] >= Mpad and dyt.shape == qt.shape and qt.shape[1] == H * 64
     prob = None if small else torch.empty((B, H, N, Mpad), device=dev, dtype=torch.float32)
     dlog = torch.empty((B, H, N, Mpad), device=dev, dtype=torch.float32)
     if packed_out is not None:
@@ -1130,10 +1135,10 @@ def relation_attention_bwd(q, k, kt, vw, bias, dy, y, bout, qt, dyt, M, heads=16
         dvw = torch.empty((B, M, H * 64), device=dev, dtype=torch.float32)
     _lib.call('relnet_relation_attention_bwd_kc',
               q.data_ptr(), q.stride(1), q.stride(0), k.data_ptr(), k.stride(1), k.stride(0),
-              kt.data_ptr(), kt.stride(1), kt.stride(0), vw.data_ptr(), vw.stride(1), vw.stride(0),
+              _ptr(kt), kt.stride(1) if kt is not None else 0, kt.stride(0) if kt is not None else 0, vw.data_ptr(), vw.stride(1), vw.stride(0),
               bias.data_ptr(), bias.stride(0), dy.data_ptr(), dy.stride(1), dy.stride(0),
-              y.data_ptr(), y.stride(1), y.stride(0), _ptr(bout), qt.data_ptr(), qt.stride(1), qt.stride(0),
-              dyt.data_ptr(), dyt.stride(1), dyt.stride(0), _ptr(prob), dlog.data_ptr(), dq.data_ptr(),
+              y.data_ptr(), y.stride(1), y.stride(0), _ptr(bout), _ptr(qt), qt.stride(1) if qt is not None else 0, qt.stride(0) if qt is not None else 0,
+              _ptr(dyt), dyt.stride(1) if dyt is not None else 0, dyt.stride(0) if dyt is not None else 0, _ptr(prob), dlog.data_ptr(), dq.data_ptr(),
               _ptr(dk), _ptr(dvw), B, H, N, M, Mpad, Npad, 1.0 / math.sqrt(64.0), _dt(q), _ptr(key_count), _stream())
     return dq, dk, dvw, prob, dlog
 

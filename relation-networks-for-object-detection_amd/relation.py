@@ -235,7 +235,9 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
     # ---- operand layouts of the backward kernels
     vw = ops.gemm_nt(f[:, :M, :].reshape(B * M, Fd) if M == N else f[:, :M, :].contiguous().reshape(B * M, Fd),
                      mod.wout).reshape(B, M, d)                          # F_K Wout^T, not transposed
-    if sink is not None:           # persistent zero-padded buffers: the transposes below write [:, :, :rows], the pad columns stay zero
+    if ops.relation_bwd_small_ok(dtype, N, Mpad):
+        kt = qt = dyt = None       # the small-N backward kernel transposes K / Q / dY on the fly from LDS: no transposed copies
+    elif sink is not None:         # persistent zero-padded buffers: the transposes below write [:, :, :rows], the pad columns stay zero
         Npad = ops.pad_to(N, 32)
         kt = sink.scratch('kt', (B, d, Mpad), dtype)
         qt = sink.scratch('qt', (B, d, Npad), dtype)
