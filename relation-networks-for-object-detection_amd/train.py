@@ -585,9 +585,11 @@ class Trainer(object):
         bias = ops.geometry_bias(rois_t, wp_t, bp, N, fast32=True)
         f1 = ops.gemm_nt(pooled2, self.w('fc_new_1'), self.b('fc_new_1')).reshape(B, R, -1)
         caches = [{}, {}]           # Q|K and VW^T projections of the forward, reused by the backward
-        _, x1, _ = _module_forward(f1, mods[0], bias[0], N, True, True, False, key_count=key_count, cache=caches[0])
+        # (VW^T buffers: persistent -- only columns [:N] are written, the pad columns stay zero from step to step: no per-step fill)
+        vw_ = lambda i: self._scratch('vwt_%d_%d' % (i, N), (B, mods[0].wout.shape[0], bias.shape[-1]), bt)     # keyed on N: a smaller N in the same padded width would inherit stale columns
+        _, x1, _ = _module_forward(f1, mods[0], bias[0], N, True, True, False, vwt_buf=vw_(1), key_count=key_count, cache=caches[0])
         f2 = ops.gemm_nt(x1.reshape(B * R, -1), self.w('fc_new_2'), self.b('fc_new_2')).reshape(B, R, -1)
-        _, x2, _ = _module_forward(f2, mods[1], bias[1], N, True, True, False, key_count=key_count, cache=caches[1])
+        _, x2, _ = _module_forward(f2, mods[1], bias[1], N, True, True, False, vwt_buf=vw_(2), key_count=key_count, cache=caches[1])
         cb = ops.gemm_nt(x2.reshape(B * R, -1), self.w('cls_bbox'), self.b('cls_bbox'), out_dtype=torch.float32).reshape(B, R, -1)
         nc = self.num_classes
         cls_score, bbox_pred = cb[:, :, :nc].contiguous(), cb[:, :, nc:].contiguous()
@@ -665,7 +667,8 @@ class Trainer(object):
         cb = class_boxes.view(BC, F, 4)
         bias = ops.geometry_bias(cb, wp_t, bp, F, fast32=True)[0]
         lcache = {}
-        att, _, _ = _module_forward(xr, mod, bias, F, True, False, False, cache=lcache)         # [BC,F,1024]
+        att, _, _ = _module_forward(xr, mod, bias, F, True, False, False, vwt_buf=self._scratch('vwt_nms_%d' % F, (BC, 1024, bias.shape[-1]), bt),
+                                    cache=lcache)                                               # [BC,F,1024]
         att128 = att.view(BC, F, 16, 64)[..., :8].reshape(BC, F, 128)
         allf = torch.relu(xr + att128).contiguous()
         w_logit = torch.zeros((64, 128), device=dev, dtype=bt); w_logit[:Tn] = self.w('nms_logit')
