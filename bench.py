@@ -162,7 +162,7 @@ def _replay_rate(det, bsz, a, D, replays=200, windows=5, step=None):
             step()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):      # (thread_local: RCCL's watchdog thread may poll events meanwhile)
             step()
         per_window = max(1, replays // windows)
         med, lo, hi = _timed_windows(graph.replay, D, per_window, windows)
@@ -463,7 +463,7 @@ def main():
             # the Python/ctypes launch path costs ~50 us per kernel, i.e. ~10 ms per step eager
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                 out = step()
             graph.replay()
         fence()
@@ -506,6 +506,7 @@ def main():
                                       '2 relation modules (N=300, 16 heads, d=1024)' if not a.no_relation else 'plain 2FC head',
                                       'learn-NMS (first_n 100, 80 classes)' if a.learn_nms else 'soft-NMS(0.6)'),
                        'images_per_gpu_per_step': a.batch, 'launch': 'eager' if a.no_graph else 'hipGraph replay', 'parallelism': 'replicas x%d (no data-path collective)' % world,
+                       'cross_round_figure': "`value` is quoted at %d images per GPU per step (the default since the end of round 4); rounds 1-3 quoted 54: compare those with batch_sweep['54']" % a.batch,
                        'ranks_seen_by_rccl': ranks_seen, 'head_init_std': a.head_init_std,
                        'precision': 'bf16 operands, fp32 accumulation (fp16 only for the log2 geometry bias read by the attention kernel); BASELINE '
                                     'configs[4] words its FPN run as "fp16": it is run with bf16 operands here -- the fp16 twin of the GEMM kernel was '

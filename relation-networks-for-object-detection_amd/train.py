@@ -970,7 +970,9 @@ class CapturedStep(object):
 
         def begin():
             cur[0] = torch.cuda.CUDAGraph()
-            cur[0].capture_begin(pool=pool)
+            # thread_local: with a process group up, RCCL's watchdog thread polls events while this thread captures; in the default 'global'
+            # capture mode a CUDA call from ANOTHER thread invalidates the capture (never an issue on one rank / over gloo)
+            cur[0].capture_begin(pool=pool, capture_error_mode='thread_local')
 
         def cut(idx):
             cur[0].capture_end()
