@@ -475,9 +475,20 @@ __global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) bcur[gq] = *(const uint2*)(Bq + kc0 + 8 * gq + 4 * half);
     // ---- stage K rows [kc0, kc0+clen) and VW^T columns of this head --------------------------
-    for (int c = tid; c < clen * 8; c += nthr) {
-      const int row = c >> 3, ch = c & 7;
-      *(uint4*)(sK + row * 128 + ((ch ^ (row & 7)) << 4)) = *(const uint4*)(Kb + (long)(kc0 + row) * a.k_ld + ch * 8);
+    // (batches of 2 / 4 loads issued before their LDS writes -- more would spill at the 128 registers of a 1024-thread launch bound: a load -> write loop costs one L2 round trip per iteration, and with 124 VGPRs only ONE
+    //  10-wave workgroup is resident per CU, so nothing else runs meanwhile -- r05: the staging was ~2/3 of a workgroup's 30 us)
+    for (int c0 = tid; c0 < clen * 8; c0 += 2 * nthr) {
+      uint4 kq[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = min(c0 + i * nthr, clen * 8 - 1), row = c >> 3, ch = c & 7;          // (clamped, unconditional: a guarded refill keeps kq in scratch)
+        kq[i] = *(const uint4*)(Kb + (long)(kc0 + row) * a.k_ld + ch * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = c0 + i * nthr, row = c >> 3, ch = c & 7;
+        if (c < clen * 8) *(uint4*)(sK + row * 128 + ((ch ^ (row & 7)) << 4)) = kq[i];
+      }
     }
     const int v4 = (clen + 3) >> 2;                   // 4-key groups per row
     // zero what the masked tail of the last tile may touch (P is 0 there, but 0 x NaN is not)
@@ -488,9 +499,18 @@ __global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a
       }
       if (tid < 16) *(uint2*)(sV + 64 * vld + 4 * tid) = make_uint2(0, 0);
     }
-    for (int c = tid; c < 64 * v4; c += nthr) {
-      const int row = c / v4, c4 = c - row * v4;
-      *(uint2*)(sV + row * vld + 4 * c4) = *(const uint2*)(Vb + (long)row * a.vwt_ld + kc0 + 4 * c4);   // pad cols are 0
+    for (int c0 = tid; c0 < 64 * v4; c0 += 4 * nthr) {
+      uint2 vq[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = min(c0 + i * nthr, 64 * v4 - 1), row = c / v4, c4 = c - row * v4;
+        vq[i] = *(const uint2*)(Vb + (long)row * a.vwt_ld + kc0 + 4 * c4);   // pad cols are 0
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = c0 + i * nthr, row = c / v4, c4 = c - row * v4;
+        if (c < 64 * v4) *(uint2*)(sV + row * vld + 4 * c4) = vq[i];
+      }
     }
     __syncthreads();
     if (wave_on) {
@@ -626,6 +646,7 @@ __global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a
     }
   }
 }
+
 
 
 // ---------------------------------------------------------------------------------------
