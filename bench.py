@@ -253,6 +253,11 @@ def bench_train(a, rank, world, D, emit=True, fatal=True):
     cfg = train.TrainConfig()
     cfg.learn_nms = a.learn_nms
     cfg.dcn = a.dcn
+    # the gradient is SUMMED over every image of the step (rescale_grad 1.0, train_end2end.py:167) and the yaml's lr 0.0005 is quoted
+    # for 4 images per step on ImageNet-initialised weights.  The benchmark's weights are random-init: beyond 16 summed images
+    # (the largest step measured finite at the yaml's lr) the rate is scaled down linearly so that B x world images move the
+    # weights as far as 16 do -- the arithmetic of a step does not depend on the value of lr
+    cfg.lr = cfg.lr * min(1.0, 16.0 / (a.batch * world))
     tr = train.FPNTrainer(params, cfg) if a.fpn else train.Trainer(params, cfg, im_hw=(H, W))
     g = torch.Generator().manual_seed(1000 + rank)
     data = torch.randn(B, 3, H, W, generator=g).cuda()
@@ -327,7 +332,8 @@ def bench_train(a, rank, world, D, emit=True, fatal=True):
                                    ': forward + backward + summed all-reduce of %d gradients + SGD, 600x1000 images, '
                                    '300 proposals + 8 gt rows, OHEM 128, random-init weights' % tr.num_trainable(),
                        'images_per_gpu_per_step': B, 'launch': 'eager' if a.no_graph else 'hipGraph replay (forward+backward in %d segments cut at the gradient buckets)' % len(graph.segments),
-                       'parallelism': 'dp%d (RCCL all-reduce SUM)' % world, 'lr': cfg.lr},
+                       'parallelism': 'dp%d (RCCL all-reduce SUM)' % world, 'lr': cfg.lr,
+                       'lr_rule': 'yaml lr 0.0005 x min(1, 16 / images summed per step)'},
             'losses': {k: float(out[k]) for k in ('bbox_loss', 'rpn_bbox_loss', 'nms_pos_loss', 'nms_neg_loss') if k in out},
             'weights_finite_on_all_ranks': bool(ok)}
         if emit:
