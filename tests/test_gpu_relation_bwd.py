@@ -140,15 +140,15 @@ def test_key_count_masks_padding_rows(dtype):
         assert e <= 10 * tol, (k, e)
 
 
-@pytest.mark.parametrize('n,m,kc', [(100, 100, False), (128, 96, False), (37, 37, False), (70, 70, True)])
-def test_small_n_fused_backward_equals_the_two_kernel_form(n, m, kc, monkeypatch):
+@pytest.mark.parametrize('n,m,kc,B', [(100, 100, False, 5), (128, 96, False, 5), (37, 37, False, 5), (70, 70, True, 5), (100, 100, True, 21)])
+def test_small_n_fused_backward_equals_the_two_kernel_form(n, m, kc, B, monkeypatch):
     """N, Mpad <= 128 (the learn-NMS head's relation module: 100 ranked rois per (image, class)): relation_attention_bwd_small_kernel -- q part and kv
     part of one (image, head) in one workgroup, K / VW / K^T staged in LDS, S and dL handed over through LDS as the bf16 MFMA operands they become
     anyway -- against the two-kernel form (fp32 S / dL maps through HBM) on the same operands: same rounding points, so dQ, dK, dVW and dL agree bit for bit."""
     import relnet_amd  # noqa: F401
     from relnet_amd import ops
     g = torch.Generator().manual_seed(n * 7 + m)
-    B, H, d = 5, 16, 1024
+    H, d = 16, 1024                 # B = 21: 336 (image, head) pairs on 256 persistent workgroups -- the loop with the next pair's operands prefetched
     bt = torch.bfloat16
     mpad, npad = ops.pad32(m), ops.pad32(n)
     qk = (torch.randn(B, n, 2 * d, generator=g) * 0.3).cuda().to(bt)
@@ -160,7 +160,7 @@ def test_small_n_fused_backward_equals_the_two_kernel_form(n, m, kc, monkeypatch
     bias = (torch.randn(B, H, n, mpad, generator=g) - 2.0).cuda()
     kt = torch.zeros(B, d, mpad, device='cuda', dtype=bt); ops.transpose_2d(k, out=kt)
     qt = ops.transpose_2d(q, pad_cols_to=32); dyt = ops.transpose_2d(dy, pad_cols_to=32)
-    key_count = torch.tensor([m, max(1, m // 2), m - 3, 1, m], dtype=torch.int32).cuda() if kc else None
+    key_count = torch.tensor(([m, max(1, m // 2), m - 3, 1, m] * ((B + 4) // 5))[:B], dtype=torch.int32).cuda() if kc else None
     res = {}
     for small in ('1', '0'):
         monkeypatch.setenv('RELNET_REL_BWD_SMALL', small)
