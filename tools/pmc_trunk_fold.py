@@ -40,8 +40,23 @@ def derive(c, flop, algo_read, algo_write):
     return d
 
 
-def trunk(src, out):
-    res = {'round': 5,
+def kernels_at(images, tile4):
+    """The same three kernels at another images-per-launch setting (round 5: 8 = the training step, where pick_tile runs the 3x3 on 128 x 64 tiles)."""
+    P = images * 2394
+    k = {key: dict(v) for key, v in KERNELS.items()}
+    k['res4_3x3'].update(flop=2.0 * P * 256 * 2304, algo_read=P * 256 * 2 + 256 * 2304 * 2, algo_write=P * 256 * 2,
+                         what='res4 3x3 / 256 -> 256 convolution, %d images, %s' % (images, 'gemm_nt_bf16_kernel<128, 64> (tile 4: what pick_tile runs at this size)' if tile4 else 'asm ring tile 19'))
+    if tile4:
+        k['res4_3x3']['match'] = 'gemm_nt_bf16_kernel<128, 64'
+    k['res5_3x3'].update(flop=2.0 * P * 512 * 4608, algo_read=P * 512 * 2 + 512 * 4608 * 2, algo_write=P * 512 * 2, what='res5 3x3 dilated / 512 -> 512 convolution, %d images, asm ring tile 19' % images)
+    k['chain256'].update(flop=2.0 * 2 * P * 256 * 1024, algo_read=P * (256 + 1024) * 2 + 2 * 1024 * 256 * 2, algo_write=P * (1024 + 256) * 2,
+                         what='res4 expand 256 -> 1024 + shortcut + ReLU and next reduce 1024 -> 256 + ReLU, %d images (chain256_roles_kernel, out of place)' % images)
+    return k
+
+
+def trunk(src, out, kernels=None, images=54):
+    kernels = kernels or KERNELS
+    res = {'round': 5, 'images_per_launch': images,
            'command': 'cd /tmp && export TMPDIR=/tmp; rocprofv3 --pmc <GROUP> --kernel-trace --output-format csv -- python tools/kernel_pmc.py <kernel> 54 4   '
                       '(six passes per kernel: GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_BUSY_CYCLES | SQ_WAIT_ANY SQ_WAIT_INST_ANY '
                       'SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU | FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum | TCP_TCC_READ_REQ_sum '
@@ -51,7 +66,7 @@ def trunk(src, out):
                    '(= 32 cycles x MFMA instructions per SIMD).  Four isolated launches run at 1.8 - 2.15 GHz; inside the 54-image step the same kernels were '
                    'timestamped at 1.48 - 1.75 GHz (profiles/r04_notes/tile_phase_probe_b54.txt): the counters are the less throttled case.',
            'kernels': {}}
-    for key, meta in KERNELS.items():
+    for key, meta in kernels.items():
         f = os.path.join(src, key + '_pmc_raw.json')
         if not os.path.exists(f):
             continue
@@ -99,4 +114,7 @@ def attn(src, out):
 
 
 if __name__ == '__main__':
-    {'trunk': trunk, 'attn': attn}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    if sys.argv[1] == 'trunk8':          # python tools/pmc_trunk_fold.py trunk8 gpurun_out/r05_pmc_trunk8 profiles/r05_train_shapes_pmc.json  (IMAGES=8 TILE=4 runs)
+        trunk(sys.argv[2], sys.argv[3], kernels_at(8, True), images=8)
+    else:
+        {'trunk': trunk, 'attn': attn}[sys.argv[1]](sys.argv[2], sys.argv[3])
