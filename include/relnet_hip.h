@@ -79,7 +79,7 @@ int relnet_roi_pool_bwd(const void* grad_out, const int* argmax, const long* out
 int relnet_gemm_nt(const void* A, long lda, long strideA, const void* W, long ldw, long strideW, void* C,
                    long ldc, long strideC, const float* bias, int bias_mode, const void* resid, int relu,
                    int M, int N, int K, int batch, int in_dtype, int out_dtype, void* stream);
-void relnet_gemm_force_tile(int cfg);     /* tuning knob: 0 = auto, 1..5 = fixed tile configuration */
+void relnet_gemm_force_tile(int cfg);     /* tuning knob: 0 = auto, 1..relnet_gemm_tile_count() = fixed tile configuration */
 void relnet_gemm_force_nloop(int n);      /* tuning knob: 0 = auto, n = column tiles per workgroup     */
 void relnet_gemm_set_swizzle(int on);     /* tuning knob: XCD-aware tile order (default 1)               */
 void relnet_gemm_debug_korder(int on);    /* tuning knob: (channel chunk, tap) k order of the spatial ring convolutions (default 1) */

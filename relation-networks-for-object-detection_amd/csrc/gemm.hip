@@ -2088,7 +2088,7 @@ static void launch_ring(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
 //                                   19 = 18 with the asymmetric ring (activations three slots / two slabs ahead, filters two slots)
 //                                   20 = 5 with two k-slabs per barrier (launches of less than one workgroup per CU: the 1-image step)
 //                                   21 = 5 with four
-enum { GEMM_TILE_COUNT = 21 };
+enum { GEMM_TILE_COUNT = 22 };
 
 template <int CONV>
 static bool launch_panel(const GemmArgs& g0, int batch, int out_dtype, hipStream_t s, bool use_wf = false, bool occ2 = false) {
@@ -2190,6 +2190,7 @@ static int pick_tile(long M, long N, long K, int batch, int out_dtype, int has_r
   else if (cfg == 1 && has_resid && K <= 512 && wgs(256, 256) < 768) cfg = 4;
   else if (cfg == 2 && wgs(256, 128) < 128) cfg = small;
   else if (cfg == 3 && wgs(128, 128) < 200) cfg = small;
+  else if (cfg == 3 && N == 128 && K >= 1024 && wgs(192, 128) >= 200) cfg = 22;      // res3 3x3 (K = 1152), forward and data gradient
   else if (cfg == 4 && N > 64 && wgs(128, 64) < 200) cfg = 5;
   // less than one 64 x 64 workgroup per CU: every k-step is an exposed round trip -> two (tile 20) / four (tile 21, K >= 2048) slabs per
   // step.  r04, same box, one image per step: 2.38-2.40 -> 2.11-2.17 ms (tile 20) -> 2.08-2.12 ms; with more workgroups than CUs
@@ -2217,6 +2218,14 @@ static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t
     case 21:
       if constexpr (CONV == 2) launch_cfg<64, 64, 2, 2, CONV>(g, batch, out_dtype, s);
       else launch_cfg<64, 64, 2, 2, CONV, 4>(g, batch, out_dtype, s);
+      break;
+    // 22 (r05): 192 x 128 (2 x 2 waves, 96 x 64 outputs each) for the 128-column 3x3 layers of res3: one column tile, so a taller tile only cuts
+    // the filter re-reads (fill bytes per output -17 % against 128 x 128).  us per launch, tile 3 / 22: 54 images 215.8 / 200.7, 8 images 47.8 / 40.3
+    // (forward), 52.0 / 43.5 (data gradient + mask).  Two k-slabs per barrier on this or the 128 x 128 / 160 x 128 tiles (one resident workgroup
+    // per CU) were measured too: 56 - 84 us against 52 for res4 3x3 at 8 images -- slower, not kept
+    case 22:
+      if constexpr (CONV == 2) launch_cfg<128, 128, 2, 2, CONV>(g, batch, out_dtype, s);
+      else launch_cfg<192, 128, 2, 2, CONV>(g, batch, out_dtype, s);
       break;
     case 6:
       if constexpr (CONV == 2) launch_cfg<256, 256, 2, 4, CONV>(g, batch, out_dtype, s);      // stem slabs are 64 deep
