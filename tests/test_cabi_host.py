@@ -253,7 +253,8 @@ def test_tile_selection_rules_without_a_gpu():
     assert pick(px(1), 256, 2304) == 21 and pick(px(1), 256, 1024) == 20          # 152 workgroups of 64 x 64: two (K < 2048) / four slabs per barrier
     assert pick(px(1), 512, 9216) == 5                                               # 304 workgroups: more than CUs
     assert pick(px(2), 256, 2304) == 5                                                                               # 300 workgroups: the plain 64 x 64 tile
-    assert pick(54 * 75 * 125, 128, 1152) == 22 and pick(54 * 75 * 125, 128, 512) == 3                               # res3 3x3: 192 x 128 (r05); res3 reduce: 128 x 128
+    assert pick(54 * 75 * 125, 128, 1152) == 22 and pick(54 * 75 * 125, 128, 512) == 22 and pick(54 * 75 * 125, 128, 256) == 3     # res3 3x3 / reduce: 192 x 128 (r05)
+    assert pick(3 * 75 * 125, 128, 1152) != 22                                                                        # ... from 200 workgroups of 192 x 128
 
 
 def test_asm_agpr_guard_ran_for_the_linked_library_and_flags_violations(tmp_path):

@@ -248,7 +248,7 @@ def test_colsum_add_accumulates_bias_gradients(shape, dt):
         assert (out2.double() - xs.double().sum(0)).abs().max().item() <= 2e-6 * scale + 1e-5
 
 
-@pytest.mark.parametrize('tile', [0, 1, 3, 4, 5])
+@pytest.mark.parametrize('tile', [0, 1, 3, 4, 5, 22])
 def test_gemm_nt_mask_is_gemm_plus_shortcut_times_relu_mask(tile):
     """relnet_gemm_nt_mask: (A W^T + resid) where mask > 0, else 0, on every LDS-tiled configuration it may run on (tile 0 = the one
     pick_tile chooses) -- against float64 on the same bf16 operands; ragged M (not a multiple of any tile)."""
