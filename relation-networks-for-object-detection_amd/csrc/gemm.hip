@@ -2192,7 +2192,7 @@ static int pick_tile(long M, long N, long K, int batch, int out_dtype, int has_r
   else if (cfg == 3 && wgs(128, 128) < 200) cfg = small;
   else if (cfg == 3 && N == 128 && K >= 512 && wgs(192, 128) >= 200) cfg = 22;       // res3 3x3 (K = 1152) and reduce / expand-dgrad (K = 512)
   // masked data gradients of res5 at the training step's size (N = 512, K = 2048 / 4608, 150 workgroups of 256 x 256): 142 -> 129 us, 73 -> 66 us
-  else if (cfg == 1 && has_resid && K > 512 && wgs(256, 256) < 256) cfg = 22;
+  else if (cfg == 1 && has_resid && N == 512 && K > 512 && wgs(256, 256) < 256) cfg = 22;      // (N = 512: only these layers were measured)
   else if (cfg == 4 && N > 64 && wgs(128, 64) < 200) cfg = 5;
   // less than one 64 x 64 workgroup per CU: every k-step is an exposed round trip -> two (tile 20) / four (tile 21, K >= 2048) slabs per
   // step.  r04, same box, one image per step: 2.38-2.40 -> 2.11-2.17 ms (tile 20) -> 2.08-2.12 ms; with more workgroups than CUs
