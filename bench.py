@@ -242,6 +242,15 @@ def other_configs(a, rank, world, D):
     return out if rank == 0 else None
 
 
+def bench_lr(yaml_lr, images_per_gpu, world):
+    """Learning rate of the training benchmark.  The gradient is SUMMED over every image of the step (rescale_grad 1.0,
+    train_end2end.py:167) and the yaml's lr is quoted for 4 images per step on ImageNet-initialised weights.  The benchmark's
+    weights are random-init: beyond 16 summed images (the largest step measured finite at the yaml's lr; 4 ranks x 8 images were
+    not) the rate is scaled down linearly so that B x world images move the weights as far as 16 do.  The arithmetic of a step
+    does not depend on the value."""
+    return yaml_lr * min(1.0, 16.0 / float(images_per_gpu * world))
+
+
 def bench_train(a, rank, world, D, emit=True, fatal=True):
     """Training throughput of the relation end2end graph (reference config ..._end2end_relation_8epoch.yaml): one step =
     forward + backward over `batch` images per GPU, ONE summed all-reduce of the 67.7 M trainable gradients, SGD."""
@@ -253,11 +262,7 @@ def bench_train(a, rank, world, D, emit=True, fatal=True):
     cfg = train.TrainConfig()
     cfg.learn_nms = a.learn_nms
     cfg.dcn = a.dcn
-    # the gradient is SUMMED over every image of the step (rescale_grad 1.0, train_end2end.py:167) and the yaml's lr 0.0005 is quoted
-    # for 4 images per step on ImageNet-initialised weights.  The benchmark's weights are random-init: beyond 16 summed images
-    # (the largest step measured finite at the yaml's lr) the rate is scaled down linearly so that B x world images move the
-    # weights as far as 16 do -- the arithmetic of a step does not depend on the value of lr
-    cfg.lr = cfg.lr * min(1.0, 16.0 / (a.batch * world))
+    cfg.lr = bench_lr(cfg.lr, a.batch, world)
     tr = train.FPNTrainer(params, cfg) if a.fpn else train.Trainer(params, cfg, im_hw=(H, W))
     g = torch.Generator().manual_seed(1000 + rank)
     data = torch.randn(B, 3, H, W, generator=g).cuda()

@@ -80,3 +80,13 @@ def test_symbol_base_class_reports_every_bad_parameter():
         s.check_parameter_shapes({'w': np.zeros((4, 3, 1, 1))}, {}, {'data': (1, 3, 8, 8)}, is_train=False)
     msg = str(e.value)
     assert 'shape inconsistent for w' in msg and 'b not initialized' in msg and 'mean not initialized' in msg
+
+
+def test_training_benchmark_lr_rule():
+    """bench.bench_lr: the yaml's rate up to 16 summed images per step, then inversely proportional to the images summed over all
+    ranks (the gradient is a SUM, train_end2end.py:167; random-init weights went non-finite at 4 ranks x 8 images at the yaml's rate)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.bench_lr(0.0005, 1, 1) == 0.0005 and bench.bench_lr(0.0005, 8, 1) == 0.0005 and bench.bench_lr(0.0005, 16, 1) == 0.0005
+    assert bench.bench_lr(0.0005, 8, 4) == pytest.approx(0.00025) and bench.bench_lr(0.0005, 8, 8) == pytest.approx(0.000125)
+    assert bench.bench_lr(0.0005, 1, 8) == 0.0005
