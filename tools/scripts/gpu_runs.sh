@@ -68,8 +68,9 @@ case $WHAT in
     run all_off RELNET_TRAIN_CHAIN=0 RELNET_TRAIN_MASK_EPI=0 RELNET_WGRAD_OVERLAP=0 RELNET_REL_SINK=0; run all_on_again A=1 ;;
   proftrain)
     cd /tmp && export TMPDIR=/tmp
-    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -- python $R/bench.py --train --learn-nms --batch ${BATCH:-8} --steps 10 --warmup 3 > /tmp/pt.log 2>&1
-    cp $(find /tmp/pt -name "*kernel_stats.csv" | head -1) $O/train_lnms_b${BATCH:-8}_kernel_stats.csv; tail -2 /tmp/pt.log; ls -la $O ;;
+    # EXTRA="--dcn" (configs[3]) / EXTRA="--fpn" BATCH=2 (configs[4]) profile the other training graphs: NAME=train_dcn_lnms ...
+    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -- python $R/bench.py --train --learn-nms $EXTRA --batch ${BATCH:-8} --steps 10 --warmup 3 > /tmp/pt.log 2>&1
+    cp $(find /tmp/pt -name "*kernel_stats.csv" | head -1) $O/${NAME:-train_lnms}_b${BATCH:-8}_kernel_stats.csv; tail -2 /tmp/pt.log; ls -la $O ;;
   pmc_trunk)    # round 5: counters of the asm ring tile (res4 3x3, res5 3x3) and of chain256_roles_kernel, 54 images, separate passes per group
                 # (the training step's shapes: TAG=r05_pmc_trunk8 IMAGES=8 TILE=4 KERNELS="res4_3x3 chain256" ... pmc_trunk, folded with `pmc_trunk_fold.py trunk8`)
     cd /tmp && export TMPDIR=/tmp
