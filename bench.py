@@ -198,13 +198,20 @@ def _fpn_proposals(batch, n_rois, im_h, im_w, g):
     return torch.stack([x1, y1, x1 + bw, y1 + bh], 2).cuda()
 
 
+#: (dcn, fpn) -> the experiment file whose values the run takes (relnet_amd/config.py:EXPERIMENTS; all three are the relation + learn-NMS rows)
+EXPERIMENT_OF = {(False, False): 'rcnn_end2end_relation_learn_nms_8epoch', (True, False): 'rcnn_dcn_end2end_relation_learn_nms_8epoch',
+                 (False, True): 'rcnn_fpn_relation_learn_nms_8epoch'}
+
+
 def other_configs(a, rank, world, D):
     """BASELINE configs[3] / configs[4] AS WORDED (DCN / FPN + relation + learn-NMS), inference graph and training step, timed by
     this process so that the driver's line carries them (rank 0 returns the block; every rank takes part in the training
     all-reduce).  Short runs: they are side figures, each with its own protocol string."""
     from relnet_amd import backbone, detector
     out = {'note': 'BASELINE configs[3] (Deformable Faster-RCNN + relation + learn-NMS) and configs[4] (FPN + relation + learn-NMS, 1000 '
-                   'proposals, 800x1024) as worded; configs[4] says "fp16 MFMA stress": run here with bf16 operands -- MEASURED (r05, '
+                   'proposals, 800x1024) with the hyper-parameters of their experiment files (config.EXPERIMENTS -> Config.from_experiment: '
+                   'configs[4] = FIRST_N 150, LEARN_NMS_CLASS_SCORE_TH 0.05, BATCH_ROIS_OHEM 512, ..._rcnn_fpn_relation_learn_nms_8epoch.yaml:92,141,166-167; '
+                   'configs[3] = FIRST_N 100, 0.01, OHEM 128); configs[4] says "fp16 MFMA stress": run here with bf16 operands -- MEASURED (r05, '
                    'profiles/r05_notes/fp16_vs_bf16.txt, relnet_gemm_nt_f16): the same kernel with fp16 operands (v_mfma_f32_32x32x16_f16, same 8-pass '
                    'instruction) runs 8-13 % slower on dense random data (power-limited pipes, 10 toggling mantissa bits against 7), so bf16 is the faster '
                    '16-bit format here; fp16 is used for the geometry-bias operand of the attention kernel only',
@@ -212,7 +219,8 @@ def other_configs(a, rank, world, D):
     for key, dcn, fpn, bsz in (('configs3_dcn_relation_learn_nms_inference', True, False, 27),
                                ('configs4_fpn_relation_learn_nms_inference', False, True, 8)):
         params = backbone.init_params(seed=1, dcn_offset_std=0.01 if dcn else 0.0, fpn=fpn)
-        cfg = detector.Config(); cfg.learn_nms = True; cfg.dcn = dcn
+        cfg = detector.Config.from_experiment(EXPERIMENT_OF[(dcn, fpn)])
+        assert cfg.learn_nms and cfg.dcn == dcn
         g = torch.Generator().manual_seed(77 + rank)
         im_h, im_w = (800, 1024) if fpn else (600, 1000)
         data = torch.randn(bsz, 3, im_h, im_w, generator=g).cuda()
@@ -226,7 +234,8 @@ def other_configs(a, rank, world, D):
             step = lambda: det.forward(data, im_info)
         r = _side_figure(lambda: _replay_rate(det, bsz, a, D, replays=30, windows=3, step=step), key)
         if 'error' not in r:
-            r.update(images_per_gpu_per_step=bsz, n_gpus=world, images_per_s_all_gpus=r['images_per_s'] * world)
+            r.update(images_per_gpu_per_step=bsz, n_gpus=world, images_per_s_all_gpus=r['images_per_s'] * world,
+                     experiment=cfg.experiment, first_n=cfg.first_n, class_thresh=cfg.learn_nms_class_thresh)
         out[key] = r
         del det, step
         torch.cuda.empty_cache()
@@ -236,7 +245,8 @@ def other_configs(a, rank, world, D):
         ta.batch, ta.learn_nms, ta.dcn, ta.fpn, ta.steps, ta.warmup, ta.no_graph = bsz, True, dcn, fpn, 5, 2, False
         tr = _side_figure(lambda: bench_train(ta, rank, world, D, emit=False, fatal=False), key)
         if rank == 0:
-            out[key] = tr if (tr is None or 'error' in tr) else {k: tr[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'n_gpus', 'weights_finite_on_all_ranks')}
+            out[key] = tr if (tr is None or 'error' in tr) else dict({k: tr[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'n_gpus', 'weights_finite_on_all_ranks')},
+                                                                     **{k: tr['config'][k] for k in ('experiment', 'first_n', 'ohem', 'lr', 'lr_rule', 'relation_bwd_of_the_learn_nms_head')})
             if out[key] is not None:
                 out[key]['images_per_gpu_per_step'] = bsz
     return out if rank == 0 else None
@@ -259,9 +269,14 @@ def bench_train(a, rank, world, D, emit=True, fatal=True):
     H, W, G = (800, 1024, 8) if a.fpn else (600, 1000, 8)
     B = a.batch
     params = backbone.init_params(seed=1, dcn_offset_std=0.005 if a.dcn else 0.0, fpn=a.fpn)
-    cfg = train.TrainConfig()
-    cfg.learn_nms = a.learn_nms
-    cfg.dcn = a.dcn
+    if a.learn_nms:     # the experiment file's own values: FPN = FIRST_N 150 / OHEM 512 / lr 0.00125, C4 and DCN = 100 / 128 / 0.0005
+        cfg = train.TrainConfig.from_experiment(EXPERIMENT_OF[(bool(a.dcn), bool(a.fpn))], train=True)
+        assert cfg.learn_nms and cfg.dcn == bool(a.dcn)
+    else:
+        cfg = train.TrainConfig()
+        cfg.experiment = 'rcnn_end2end_relation_8epoch'
+        cfg.dcn = a.dcn
+    yaml_lr = cfg.lr
     cfg.lr = bench_lr(cfg.lr, a.batch, world)
     tr = train.FPNTrainer(params, cfg) if a.fpn else train.Trainer(params, cfg, im_hw=(H, W))
     g = torch.Generator().manual_seed(1000 + rank)
@@ -334,11 +349,17 @@ def bench_train(a, rank, world, D, emit=True, fatal=True):
                                     'head end2end (..._rcnn_end2end_relation_learn_nms_8epoch.yaml)' if a.learn_nms else
                                     'TRAINING step of ResNet-101 Faster-RCNN + 2 relation modules end2end '
                                     '(..._rcnn_end2end_relation_8epoch.yaml)') +
-                                   ': forward + backward + summed all-reduce of %d gradients + SGD, 600x1000 images, '
-                                   '300 proposals + 8 gt rows, OHEM 128, random-init weights' % tr.num_trainable(),
+                                   ': forward + backward + summed all-reduce of %d gradients + SGD, %dx%d images, '
+                                   '%d proposals + 8 gt rows, OHEM %d, learn-NMS first_n %d, random-init weights'
+                                   % (tr.num_trainable(), H, W, 1000 if a.fpn else 300, cfg.batch_rois_ohem, cfg.first_n),
+                       'experiment': cfg.experiment, 'first_n': cfg.first_n, 'ohem': cfg.batch_rois_ohem,
+                       'relation_bwd_of_the_learn_nms_head': ('one workgroup per (image, class, head), S / dL in LDS (relation_attention_bwd_small_kernel: first_n <= 128)'
+                                                             if cfg.first_n <= 128 else
+                                                             'two-kernel form with fp32 S / dL maps in HBM (first_n %d -> Mpad %d is past the small kernel\'s 128)' % (cfg.first_n, (cfg.first_n + 31) // 32 * 32))
+                                                            if a.learn_nms else None,
                        'images_per_gpu_per_step': B, 'launch': 'eager' if a.no_graph else 'hipGraph replay (forward+backward in %d segments cut at the gradient buckets)' % len(graph.segments),
                        'parallelism': 'dp%d (RCCL all-reduce SUM)' % world, 'lr': cfg.lr,
-                       'lr_rule': 'yaml lr 0.0005 x min(1, 16 / images summed per step)'},
+                       'lr_rule': 'yaml lr %g x min(1, 16 / images summed per step over all ranks)' % yaml_lr},
             'losses': {k: float(out[k]) for k in ('bbox_loss', 'rpn_bbox_loss', 'nms_pos_loss', 'nms_neg_loss') if k in out},
             'weights_finite_on_all_ranks': bool(ok)}
         if emit:
@@ -424,9 +445,11 @@ def main():
         gh = torch.Generator().manual_seed(5)
         for k in ('cls_score_weight', 'bbox_pred_weight'):
             params[k] = torch.randn(params[k].shape, generator=gh) * a.head_init_std
-    cfg = detector.Config()
-    cfg.learn_nms = a.learn_nms
-    cfg.dcn = a.dcn
+    if a.learn_nms:
+        cfg = detector.Config.from_experiment(EXPERIMENT_OF[(bool(a.dcn), bool(a.fpn))])
+    else:
+        cfg = detector.Config()
+        cfg.dcn = a.dcn
     if a.fpn:
         det = detector.FPNDetector(params, dtype=tdt, device='cuda', relation=not a.no_relation, cfg=cfg, stem=a.stem)
     else:
@@ -515,7 +538,7 @@ def main():
                                       ('inference graph of BASELINE configs[3] (DCN): deformable ' if a.dcn else
                                        'inference graph of BASELINE configs[4] (FPN, 800x1024 images, 1000 given proposals): ' if a.fpn else ''),
                                       '2 relation modules (N=300, 16 heads, d=1024)' if not a.no_relation else 'plain 2FC head',
-                                      'learn-NMS (first_n 100, 80 classes)' if a.learn_nms else 'soft-NMS(0.6)'),
+                                      'learn-NMS (first_n %d, class_thresh %g, 80 classes)' % (cfg.first_n, cfg.learn_nms_class_thresh) if a.learn_nms else 'soft-NMS(0.6)'),
                        'images_per_gpu_per_step': a.batch, 'launch': 'eager' if a.no_graph else 'hipGraph replay', 'parallelism': 'replicas x%d (no data-path collective)' % world,
                        'cross_round_figure': "`value` is quoted at %d images per GPU per step (the default since the end of round 4); rounds 1-3 quoted 54: compare those with batch_sweep['54']" % a.batch,
                        'ranks_seen_by_rccl': ranks_seen, 'head_init_std': a.head_init_std,

@@ -40,6 +40,44 @@ class Config(object):
     dcn_sample_per_part = 4
     dcn_trans_std = 0.1
 
+    @classmethod
+    def from_experiment(cls, name, train=False):
+        """The hyper-parameters of one shipped experiment file (config.EXPERIMENTS key = the YAML stem without
+        `resnet_v1_101_coco_trainvalminus_`), e.g. 'rcnn_fpn_relation_learn_nms_8epoch' -> first_n 150, learn_nms_class_thresh 0.05,
+        and for a TrainConfig batch_rois_ohem 512, lr 0.00125 (..._rcnn_fpn_relation_learn_nms_8epoch.yaml:62,92,141,166-167).
+        train=True reads TRAIN.FIRST_N / TRAIN.LEARN_NMS where the test graph reads TEST.*."""
+        from .config import experiment
+        e = experiment(name)
+        c = cls()
+        n, t, te = e.network, e.TRAIN, e.TEST
+        c.experiment = name
+        c.symbol = e.symbol
+        c.feat_stride = n.RPN_FEAT_STRIDE
+        c.anchor_scales, c.anchor_ratios = tuple(n.ANCHOR_SCALES), tuple(n.ANCHOR_RATIOS)
+        c.num_classes = e.dataset.NUM_CLASSES
+        c.nms_target_thresh = tuple(float(v) for v in str(n.NMS_TARGET_THRESH).split(','))
+        src = t if train else te
+        c.rpn_pre_nms_top_n, c.rpn_post_nms_top_n = src.RPN_PRE_NMS_TOP_N, src.RPN_POST_NMS_TOP_N
+        c.rpn_nms_thresh, c.rpn_min_size = src.RPN_NMS_THRESH, src.RPN_MIN_SIZE
+        c.nms, c.softnms, c.max_per_image = te.NMS, te.SOFTNMS, te.max_per_image
+        c.learn_nms = bool(t.LEARN_NMS if train else te.LEARN_NMS)
+        c.first_n = (t.FIRST_N if train else te.FIRST_N) or cls.first_n
+        c.learn_nms_class_thresh = te.LEARN_NMS_CLASS_SCORE_TH
+        c.merge_method = te.MERGE_METHOD
+        c.dcn = '_dcn' in e.symbol
+        c.fpn = '_fpn' in e.symbol
+        c.top_rois = t.TOP_ROIS if train else te.TOP_ROIS          # proposals per image of the HAS_RPN: false (FPN) graphs
+        c.scales = tuple(e.SCALES[0])
+        if hasattr(cls, 'batch_rois_ohem'):                          # a TrainConfig
+            c.batch_rois_ohem, c.enable_ohem = t.BATCH_ROIS_OHEM, bool(t.ENABLE_OHEM)
+            c.joint_training = bool(t.JOINT_TRAINING) or not t.LEARN_NMS
+            c.lr, c.momentum, c.wd = t.lr, t.momentum, t.wd
+            c.rpn_batch_size = t.RPN_BATCH_SIZE
+            c.nms_loss_scale, c.nms_pos_scale = t.nms_loss_scale, t.nms_pos_scale
+            c.bbox_means, c.bbox_stds = tuple(t.BBOX_MEANS), tuple(t.BBOX_STDS)
+            c.fixed_params = list(n.FIXED_PARAMS)
+        return c
+
 
 def fc1_channels_last_perm(c=256, ph=7, pw=7):
     """Column permutation of fc_new_1_weight for pooled features stored (ph, pw, c):

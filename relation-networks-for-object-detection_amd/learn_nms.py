@@ -82,10 +82,14 @@ class LearnNMS(object):
         class_max = torch.empty((B, C), device=dev, dtype=torch.float32)
         _lib.call('relnet_lnms_sort', prob.data_ptr(), boxes.data_ptr(), rank_idx.data_ptr(), sorted_score.data_ptr(),
                   sorted_bbox.data_ptr(), class_boxes.data_ptr(), class_max.data_ptr(), B, N, C, F, s)
-        roi_emb = ops.gemm_nt(feat.reshape(B * N, -1).to(self.dtype), self.w_emb, self.b_emb)          # [B*N,128]
+        # (feat may carry rows past N -- the gt rows of a training graph: learn_nms.py:335-339 embeds fc_all_2_relu unsliced and
+        #  takes rows by rank, so the ranks only ever address its first N rows)
+        Nf = feat.shape[1]
+        assert Nf >= N
+        roi_emb = ops.gemm_nt(feat.reshape(B * Nf, -1).to(self.dtype), self.w_emb, self.b_emb)         # [B*Nf,128]
         x = torch.empty((B, C, F, 128), device=dev, dtype=self.dtype)
         _lib.call('relnet_lnms_embed', roi_emb.data_ptr(), self.rank_feat.data_ptr(), rank_idx.data_ptr(), x.data_ptr(),
-                  B, N, C, F, 128, ops._dt(x), s)
+                  B, Nf, C, F, 128, ops._dt(x), s)
         BC = B * C
         xr = x.view(BC, F, 128)
         qk = ops.gemm_nt(xr.reshape(BC * F, 128), self.wqk, self.bqk).view(BC, F, 2048)

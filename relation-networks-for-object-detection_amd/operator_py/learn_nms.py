@@ -18,15 +18,21 @@ class LearnNmsOperator(CustomOp):
                  nongt_dim=None, has_non_gt_index=False):
         super(LearnNmsOperator, self).__init__()
         assert class_agnostic, "class-specific regression is not used by any shipped cfg"
-        assert not has_non_gt_index, "non_gt_index (FPN training graphs) is outside this path"
         self.num_fg_classes, self.first_n, self.num_thresh = num_fg_classes, first_n, num_thresh
         self.bbox_means, self.bbox_stds, self.class_thresh, self.nongt_dim = bbox_means, bbox_stds, class_thresh, nongt_dim
+        self.has_non_gt_index = has_non_gt_index
         self._impl, self._key = None, None
 
     def forward(self, is_train, req, in_data, out_data, aux):
         cls_score, bbox_pred, rois, im_info, feat = in_data[:5]
         if self.nongt_dim is not None:                     # learn_nms.py:265-267, 282-283
             cls_score, bbox_pred, rois, feat = (t[:self.nongt_dim] for t in (cls_score, bbox_pred, rois, feat))
+        elif self.has_non_gt_index:
+            # learn_nms.py:268-270, 284-285: nd.take of the non-gt rows of cls_score / bbox_pred / rois (FPN training graphs).  As in the
+            # reference (:335-339) the roi feature embedding is NOT gathered: the ranks index fc_all_2_relu's own rows, which is the
+            # same thing whenever the non-gt rows are a prefix (they are in every graph the reference builds this operator into)
+            idx = in_data[19].long()
+            cls_score, bbox_pred, rois = (t.index_select(0, idx) for t in (cls_score, bbox_pred, rois))
         key = tuple(t.data_ptr() for t in in_data[5:19])
         if self._impl is None or key != self._key:
             params = dict(zip(ARGS[5:], in_data[5:19]))

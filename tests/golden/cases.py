@@ -104,6 +104,21 @@ LEARN_NMS_CASES = {
     'lnms_n60_c6_f20': (60, 6, 20, 21),
 }
 
+#: the learn-NMS head AS THE FPN YAML WORDS IT (experiments/relation_rcnn/cfgs/..._rcnn_fpn_relation_learn_nms_8epoch.yaml:141,166-167:
+#: TOP_ROIS 1000, FIRST_N 150, LEARN_NMS_CLASS_SCORE_TH 0.05); stored in tests/golden/learn_nms_fpn.npz
+LEARN_NMS_FPN_CASES = {
+    # name: (n_rois, num_fg_classes, first_n, seed, class_thresh)
+    'lnms_n1000_c80_f150_th05': (1000, 80, 150, 23, 0.05),
+}
+
+
+def learn_nms_fpn_case(n, num_fg, seed):
+    """learn_nms_case with every fourth class pushed down by 5 logits: 9 of the 80 class maxima fall below 0.01 and another 9
+    between 0.01 and 0.05, so the yaml's 0.05 valid-class rule and the default 0.01 give different class sets."""
+    cls_score, bbox_pred, rois, im_info, feat, p = learn_nms_case(n, num_fg, seed)
+    cls_score[:, 1 + np.arange(0, num_fg, 4)] -= F32(5.0)
+    return cls_score, bbox_pred, rois, im_info, feat, p
+
 
 def dets_case(n, seed):
     """[n,5] fp32 detections with distinct scores for NMS tests."""

@@ -214,6 +214,27 @@ def gen_relation_large(rel, lnms, out):
     np.savez_compressed(os.path.join(out, 'relation_large.npz'), **d)
 
 
+def gen_learn_nms_fpn(lnms, out):
+    """LearnNmsOperator.forward at the FPN experiment's values (1000 rois, 80 classes, first_n 150, class_thresh 0.05;
+    symbols/..._fpn_..._learn_nms.py:1328-1362 passes nongt_dim=None and, at test time, no non_gt_index)."""
+    import mxnet as mx
+    d = {}
+    for name, (n, c, first_n, seed, th) in cases.LEARN_NMS_FPN_CASES.items():
+        cls_score, bbox_pred, rois, im_info, feat, p = cases.learn_nms_fpn_case(n, c, seed)
+        op = lnms.LearnNmsOperator(num_fg_classes=c, bbox_means=None, bbox_stds=None, first_n=first_n, class_agnostic=True,
+                                   num_thresh=5, class_thresh=th, nongt_dim=None, has_non_gt_index=False)
+        in_data = [mx.NDArray(x) for x in (cls_score, bbox_pred, rois, im_info, feat)]
+        in_data += [mx.NDArray(p[kk]) for kk in cases.LEARN_NMS_ARG_ORDER]
+        outs = [mx.nd.zeros((first_n, c, 5)), mx.nd.zeros((first_n, c, 4)), mx.nd.zeros((first_n, c))]
+        mx.TRACE.clear()
+        op.forward(False, ['write'] * 3, in_data, outs, [])
+        d[name + '/nms_multi_score'] = outs[0].asnumpy()
+        d[name + '/sorted_bbox'] = outs[1].asnumpy()
+        d[name + '/sorted_score'] = outs[2].asnumpy()
+        print('   ', name, 'done: classes with a non-zero score', int((outs[0].asnumpy().max(axis=(0, 2)) > 0).sum()), flush=True)
+    np.savez_compressed(os.path.join(out, 'learn_nms_fpn.npz'), **d)
+
+
 def gen_learn_nms(lnms, out):
     import mxnet as mx
     d = {}
@@ -413,8 +434,11 @@ def main():
     ap.add_argument('--out', default=HERE)
     ap.add_argument('--only-large', action='store_true', help='regenerate relation_large.npz only (minutes of numpy at N = 1000)')
     ap.add_argument('--skip-large', action='store_true')
+    ap.add_argument('--only-lnms-fpn', action='store_true', help='regenerate learn_nms_fpn.npz only')
     a = ap.parse_args()
     ga, bt, nm, rel, lnms = setup_reference(a.ref)
+    if a.only_lnms_fpn:
+        return gen_learn_nms_fpn(lnms, a.out)
     if not a.skip_large:
         gen_relation_large(rel, lnms, a.out)
     if a.only_large:
@@ -423,6 +447,7 @@ def main():
     gen_nms(nm, a.out)
     gen_relation(rel, a.out)
     gen_learn_nms(lnms, a.out)
+    gen_learn_nms_fpn(lnms, a.out)
     gen_targets(a.out)
     gen_fpn(a.out)
     gen_rpn_targets(a.ref, a.out)

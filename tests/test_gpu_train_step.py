@@ -186,14 +186,17 @@ def test_training_steps_reduce_the_loss_and_update_only_trainable():
         assert i == want, (name, i, want)
 
 
-def test_fpn_training_step_gradients_match_autograd():
+@pytest.mark.parametrize('N,first_n,ohem', [(60, 24, 128), (200, 150, 512)])
+def test_fpn_training_step_gradients_match_autograd(N, first_n, ohem):
     """BASELINE configs[4] graph: FPN neck, level-dispatched ROI pooling, relation head over the given proposals (+ gt rows),
-    learn-NMS head; every gradient vs float64 autograd of oracle/train_graph.py:total_loss_fpn."""
+    learn-NMS head; every gradient vs float64 autograd of oracle/train_graph.py:total_loss_fpn.  (200, 150, 512): the learn-NMS head
+    at the experiment file's FIRST_N 150 (the two-kernel relation backward, Mpad 160) and BATCH_ROIS_OHEM 512
+    (..._rcnn_fpn_relation_learn_nms_8epoch.yaml:92,141)."""
     import relnet_amd  # noqa: F401
     from relnet_amd import backbone, train
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_gpu_fpn import _proposals
-    H, W, N, G = 128, 160, 60, 4
+    H, W, G = 128, 160, 4
     p = backbone.init_params(seed=41, fpn=True)
     g = torch.Generator().manual_seed(42)
     for k in ('cls_score_weight', 'bbox_pred_weight'):
@@ -208,7 +211,7 @@ def test_fpn_training_step_gradients_match_autograd():
               'nms_linear_out_1_weight', 'nms_pair_pos_fc1_1_weight'):
         p[k] = torch.randn(p[k].shape, generator=g) * 0.05
     cfg = train.TrainConfig()
-    cfg.learn_nms, cfg.first_n = True, 24
+    cfg.learn_nms, cfg.first_n, cfg.batch_rois_ohem = True, first_n, ohem
     data = torch.randn(1, 3, H, W, generator=g)
     props = _proposals(N, 43, H, W)[None]
     gt = np.zeros((1, G, 5), np.float32)
@@ -224,7 +227,7 @@ def test_fpn_training_step_gradients_match_autograd():
     lnms = dict(rank_idx=out['nms_rank_idx'][0].cpu().numpy(), class_boxes=out['nms_class_boxes'][0].cpu().numpy(),
                 target=out['nms_multi_target'][0].cpu().numpy(), first_n=cfg.first_n)
     loss, parts = OT.total_loss_fpn(data.numpy(), pt, rois, level, out['label'][0].cpu().numpy(), out['bbox_target'][0].cpu().numpy(),
-                                    out['bbox_weight'][0].cpu().numpy(), N, lnms=lnms)
+                                    out['bbox_weight'][0].cpu().numpy(), N, batch_rois_ohem=ohem, lnms=lnms)
     loss.backward()
     e_cs = float((out['cls_score'][0].cpu().double() - parts['cls_score']).abs().max() / parts['cls_score'].abs().max())
     for l_, nm_ in enumerate((4, 8, 16, 32)):            # forward first: pyramid maps and pooled features (bf16, ~100 layers)
@@ -267,7 +270,9 @@ def test_fpn_training_step_gradients_match_autograd():
         cos = float((w * got).sum() / max(nw * ng, 1e-300))
         report.append('%-22s |want| %.3e |got| %.3e cos %.4f' % (name, nw, ng, cos))
         tight = not name.startswith('res') and 'pair_pos' not in name and 'fpn' not in name
-        cmin, nmax = (0.995, 0.03) if tight else (0.97, 0.08)      # trunk: four pyramid levels feed it (more bf16 paths than C4)
+        # trunk: four pyramid levels feed it (more bf16 paths than C4); with 204 pooled rois instead of 64 the bf16 noise of ~100 layers leaves
+        # single res3 tensors at 0.96 (the float32-trunk test below pins the trunk's wiring tightly instead)
+        cmin, nmax = (0.995, 0.03) if tight else ((0.97 if N <= 64 else 0.95), 0.08)
         if nw > 1e-9 and (cos < cmin or abs(ng / nw - 1) > nmax):
             bad.append(report[-1])
     assert not bad, '\n'.join(bad) + '\n--- all ---\n' + '\n'.join(report)

@@ -219,6 +219,25 @@ def test_learn_nms_benchmark_shape_matches_reference_operator():
         np.testing.assert_allclose(multi, g[name + '/nms_multi_score'], rtol=5e-5, atol=2e-7)
 
 
+def test_learn_nms_fpn_yaml_values_match_reference_operator():
+    """The learn-NMS head as the FPN experiment words it (..._rcnn_fpn_relation_learn_nms_8epoch.yaml:141,166-167: 1000 rois,
+    FIRST_N 150, LEARN_NMS_CLASS_SCORE_TH 0.05) through the reference's LearnNmsOperator.forward (learn_nms_fpn.npz)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'learn_nms_fpn.npz'))
+    for name, (n, c, first_n, seed, th) in cases.LEARN_NMS_FPN_CASES.items():
+        cls_score, bbox_pred, rois, im_info, feat, p = cases.learn_nms_fpn_case(n, c, seed)
+        multi, sbox, sscore, dbg = OL.learn_nms(cls_score, bbox_pred, rois, im_info, feat, p, num_fg_classes=c, first_n=first_n,
+                                                class_thresh=th, nongt_dim=None, return_intermediates=True)
+        want = g[name + '/nms_multi_score']
+        assert want.shape == (first_n, c, 5)
+        # the 0.05 rule drops 18 classes here, the default 0.01 would drop 9: the threshold is exercised
+        assert len(dbg['valid']) == 62 and np.array_equal(np.where(want.max(axis=(0, 2)) > 0)[0], dbg['valid'])
+        assert (sscore.max(axis=0) < 0.01).sum() == 9
+        np.testing.assert_allclose(sscore, g[name + '/sorted_score'], rtol=1e-6, atol=0)
+        np.testing.assert_allclose(sbox, g[name + '/sorted_bbox'], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(multi, want, rtol=5e-5, atol=2e-7)
+
+
 def test_assign_anchor_oracle_matches_reference_loader():
     """oracle/anchors.py (sampler='numpy') vs tests/golden/rpn_targets.npz = the output of the reference's own
     lib/rpn/rpn.py:assign_anchor with the same numpy seed: identical labels incl. the random fg / bg sub-sampling, identical

@@ -13,7 +13,7 @@
 #   probes     tools/llc_probe.py + tools/fill_probe.py
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 WHAT=$1; shift
-TAG=${TAG:-r05_$WHAT}
+TAG=${TAG:-r06_$WHAT}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 F="--no-cpu-baseline --no-train-line --no-other-configs --no-parity --no-batch-sweep --batch 54"
 line() { python -c "import json,sys; d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{\"metric')][-1]); print(sys.argv[2], round(d['value'],1), 'img/s', round(d['ms_per_step'],3), 'ms', d['config'].get('images_per_gpu_per_step'))" "$1" "$2" 2>/dev/null || echo "$2 FAILED"; }
