@@ -80,6 +80,7 @@ int relnet_gemm_nt(const void* A, long lda, long strideA, const void* W, long ld
                    long ldc, long strideC, const float* bias, int bias_mode, const void* resid, int relu,
                    int M, int N, int K, int batch, int in_dtype, int out_dtype, void* stream);
 void relnet_gemm_force_tile(int cfg);     /* tuning knob: 0 = auto, 1..relnet_gemm_tile_count() = fixed tile configuration */
+int relnet_gemm_get_forced_tile(void);    /* the value last given to relnet_gemm_force_tile (0 = auto): lets a caller restore it */
 void relnet_gemm_force_nloop(int n);      /* tuning knob: 0 = auto, n = column tiles per workgroup     */
 void relnet_gemm_set_swizzle(int on);     /* tuning knob: XCD-aware tile order (default 1)               */
 void relnet_gemm_debug_korder(int on);    /* tuning knob: (channel chunk, tap) k order of the spatial ring convolutions (default 1) */
@@ -99,6 +100,18 @@ int relnet_gemm_pick_tile(int M, int N, int K, int batch, int out_dtype);   /* t
 int relnet_conv2d_nhwc(const void* in, long in_pix, long in_img, const void* w, const float* bias,
                        const void* resid, int relu, void* out, long ldc, int B, int H, int W, int Cin, int Cout,
                        int R, int S, int stride, int dil, int pad, int out_dtype, void* stream);
+
+/* The same convolution with float32 operands on the exact-fp32 MFMA kernel (v_mfma_f32_32x32x2f32: an fmaf chain per output
+ * element): the float32 PARITY path of mx.symbol.Convolution (+ folded BatchNorm + Activation) for every convolution of the
+ * graph -- resnet_v1_101_rcnn_base.py:29-693, the FPN neck symbols/..._fpn_...:804-840 -- in place of a library call.
+ * in [B,H,W,>=Cin] fp32 (Cin % 16 == 0: the 3-channel stem image is zero-padded to 16 channels), w [Cout][R*S*Cin] fp32,
+ * out / resid [B*Hout*Wout][ldc] fp32; relu: 0 none, 1 ReLU, 2 = resid is a ReLU mask (float32 data gradients).             */
+int relnet_conv2d_nhwc_f32(const float* in, long in_pix, long in_img, const float* w, const float* bias, const float* resid,
+                           int relu, float* out, long ldc, int B, int H, int W, int Cin, int Cout, int R, int S, int stride,
+                           int dil, int pad, void* stream);
+/* pool1 of that path: mx.symbol.Pooling(kernel 3x3, stride 2, max, pooling_convention='full') (resnet_v1_101_rcnn_base.py:35-36),
+ * ceil-mode windows clipped at the border.  in [B,H,W,C] fp32 NHWC dense, C % 4 == 0 -> out [B,Ho,Wo,C].                    */
+int relnet_maxpool_nhwc_f32(const float* in, float* out, int B, int H, int W, int C, int ksize, int stride, void* stream);
 
 /* ---- conv1 7x7/2 pad 3, Cin = 3 (resnet_v1_101_rcnn_base.py:30-31) on the MFMA kernel: pack the
  * [B,3,H,W] image (fp32 or bf16) into zero-padded NHWC4 bf16 [B,Hp,Wp,4], then the implicit GEMM with

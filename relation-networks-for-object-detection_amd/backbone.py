@@ -4,7 +4,9 @@
 impl='hip' (bf16, the throughput path): every convolution, the 7x7 stem included, is a kernel of librelnet_hip.so over
 NHWC activations -- the implicit-GEMM MFMA kernels of csrc/gemm.hip with bias / ReLU / shortcut fused into the epilogue,
 the halo-resident 3x3 kernel and the block-boundary chain kernel of csrc/bottleneck.hip for res2; no library call.
-impl='miopen' (float32 parity path) runs the same graph through torch.nn.functional.conv2d.  What this module owns is the
+impl='hip32' (float32 parity path, the default for dtype float32): the same graph on the exact-fp32 MFMA convolution kernel
+(relnet_conv2d_nhwc_f32: an fmaf chain per output element) + relnet_maxpool_nhwc_f32 -- no library call either.
+impl='miopen' runs the graph through torch.nn.functional.conv2d (kept for the A/B against the library).  What this module owns is the
 graph itself: the Caffe-style ResNet (stride on the FIRST 1x1 of a stage, :99,103), conv5 dilated 2 with stride 1
 (:632-633), ceil-mode pool1 (pooling_convention='full', :35-36) and the frozen BatchNorm (use_global_stats=True, eps=1e-5,
 :32) folded into the preceding convolution at load time.
@@ -137,16 +139,17 @@ class Backbone(object):
             self.stage_split = {int(a): int(b) for a, b in (kv.split(':') for kv in env.split(','))}
         if os.environ.get('RELNET_INPLACE_EXPAND') is not None:
             self.inplace_expand = os.environ['RELNET_INPLACE_EXPAND'] not in ('', '0')
-        self.impl = impl or ('hip' if dtype == torch.bfloat16 else 'miopen')
+        self.impl = impl or ('hip' if dtype == torch.bfloat16 else ('hip32' if dtype == torch.float32 and torch.device(device).type == 'cuda' else 'miopen'))
         if self.impl == 'hip' and torch.device(device).type == 'cuda':
             ops.asm_selfcheck()          # tile 19 (AGPR accumulators across asm statements) against the compiler-scheduled tile, once per process
         self.stem = stem
-        assert self.impl in ('hip', 'miopen') and (self.impl == 'miopen' or dtype == torch.bfloat16)
+        assert self.impl in ('hip', 'hip32', 'miopen') and (self.impl != 'hip' or dtype == torch.bfloat16) and (self.impl != 'hip32' or dtype == torch.float32)
         self.mf = torch.channels_last if channels_last else torch.contiguous_format
         self.w = {}
         self.wp = {}
         self.wf = {}          # name -> fragment-order weight copy (panel kernel)
         self.b32 = {}
+        self.wp32 = {}        # impl 'hip32': name -> ([Cout, k*k*Cin] fp32 packed weight, fp32 bias, k)
         for conv, bn, oc, ic, k in conv_bn_names():
             if frozen_only and not conv.startswith(('conv1', 'res2')):
                 continue
@@ -211,6 +214,12 @@ class Backbone(object):
                         b.to(self.device, self.dtype))
         if self.impl == 'hip':
             self.b32[name] = b.to(self.device, torch.float32).contiguous()
+        if self.impl == 'hip32':
+            if w.shape[1] % 16:             # the 3-channel stem: zero input channels up to 16 (the kernel's k granularity)
+                wz = torch.zeros((w.shape[0], (w.shape[1] + 15) // 16 * 16) + tuple(w.shape[2:]), dtype=w.dtype)
+                wz[:, :w.shape[1]] = w
+                w = wz
+            self.wp32[name] = (ops.pack_conv_weight(w, torch.float32, self.device), b.to(self.device, torch.float32).contiguous(), int(w.shape[2]))
         if self.impl == 'hip' and w.shape[1] % 64 == 0:
             self.wp[name] = (ops.pack_conv_weight(w, self.dtype, self.device),
                              b.to(self.device, torch.float32).contiguous(), int(w.shape[2]))
@@ -228,6 +237,9 @@ class Backbone(object):
     def forward_res2(self, data):
         """Stem + res2 only (the part the reference freezes in training: cfgs/*.yaml FIXED_PARAMS conv1 / res2): raw NCHW image ->
         res2c output, NHWC bf16, on the inference kernels (fused stem, halo 3x3, chain kernels incl. res2a's in-kernel projection)."""
+        if self.impl == 'hip32':           # float32 parity path (frozen_only backbones return the res2c map)
+            assert self.frozen_only
+            return self._forward_hip32(data)
         x = ops.stem_fused(data, self.w_stem, self.b32['conv1'])
         y_next = None
         self.last_chain_units = []
@@ -388,6 +400,50 @@ class Backbone(object):
         y = F.conv2d(x, w, b, stride=stride, padding=pad, dilation=dil)
         return F.relu_(y) if relu else y
 
+    def _c32(self, x, name, stride=1, pad=0, dil=1, relu=False, resid=None):
+        w, b, k = self.wp32[name]
+        return ops.conv2d_nhwc_f32(x, w, b, ksize=k, stride=stride, pad=pad, dil=dil, relu=relu, resid=resid)
+
+    def _forward_hip32(self, data):
+        """The float32 parity path on this repository's own kernels: every convolution on relnet_conv2d_nhwc_f32 (exact-fp32 MFMA, bias /
+        shortcut / ReLU in the epilogue), pool1 on relnet_maxpool_nhwc_f32, NHWC float32 activations."""
+        B, Cin, H, W = data.shape
+        x = torch.zeros((B, H, W, 16), device=data.device, dtype=torch.float32)       # NHWC, channels zero-padded 3 -> 16
+        x[..., :Cin] = data.permute(0, 2, 3, 1)
+        x = self._c32(x, 'conv1', stride=2, pad=3, relu=True)
+        x = ops.maxpool_nhwc_f32(x, 3, 2)
+        conv4, ends = None, {}
+        nchw = lambda t: t.permute(0, 3, 1, 2)
+        for stage, nm, ic, mc, oc, stride, dil, proj in self.units:
+            if stage == 5 and conv4 is None:
+                conv4 = x
+            if proj and stage > 2:
+                ends[stage - 1] = x
+            sc = self._c32(x, 'res%s_branch1' % nm, stride=stride) if proj else x
+            y = self._c32(x, 'res%s_branch2a' % nm, stride=stride, relu=True)
+            if self.dcn and stage == 5:
+                off = self._c32(y, 'res%s_branch2b_offset' % nm, pad=2, dil=2)
+                y = self._deform_2b(nchw(y), 'res%s_branch2b' % nm, nchw(off)).permute(0, 2, 3, 1)
+            else:
+                y = self._c32(y, 'res%s_branch2b' % nm, pad=dil, dil=dil, relu=True)
+            x = self._c32(y, 'res%s_branch2c' % nm, relu=True, resid=sc)
+        conv5 = x
+        if self.frozen_only:
+            return x
+        if self.fpn:
+            tops = {32: self._c32(conv5, 'fpn_ft32_1x1')}
+            for lvl, src in ((16, ends[4]), (8, ends[3]), (4, ends[2])):
+                tops[lvl] = ops.upsample2x_add_(self._c32(src, 'fpn_ft%d_1x1' % lvl), tops[lvl * 2])
+            out = {'fpn_ft%d' % lvl: nchw(self._c32(tops[lvl], 'fpn_ft%d_3x3' % lvl, pad=1)) for lvl in (4, 8, 16, 32)}
+            out.update(conv4=nchw(conv4), conv5=nchw(conv5))
+            return out
+        feat = self._c32(conv5, 'conv_new_1', relu=True)
+        r = self._c32(conv4, 'rpn_conv_3x3', pad=1, relu=True)
+        rpn = self._c32(r, 'rpn_out')
+        na2 = self.w['rpn_cls_score'][0].shape[0]
+        return dict(conv4=nchw(conv4), conv5=nchw(conv5), conv_new_1_relu=nchw(feat),
+                    rpn_cls_score=nchw(rpn[..., :na2]), rpn_bbox_pred=nchw(rpn[..., na2:]))
+
     def forward(self, data, rpn_hook=None):
         """data [B,3,H,W] -> dict(conv4, conv5, conv_new_1_relu, rpn_cls_score, rpn_bbox_pred)
         (logical NCHW tensors; channels-last memory).
@@ -398,6 +454,8 @@ class Backbone(object):
         streams join before this function returns and the hook's result is returned under the key 'rpn_hook'."""
         if self.impl == 'hip':
             return self._forward_hip(data, rpn_hook)
+        if self.impl == 'hip32':
+            return self._forward_hip32(data)
         x = data.to(self.dtype).contiguous(memory_format=self.mf)
         x = self._conv(x, 'conv1', stride=2, pad=3, relu=True)
         x = F.max_pool2d(x, kernel_size=3, stride=2, padding=0, ceil_mode=True)

@@ -45,6 +45,7 @@ extern "C" const char* relnet_last_error(void);
 namespace relnet {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+long device_cu_count();
 }  // namespace relnet
 
 namespace relnet {

@@ -1891,7 +1891,11 @@ __global__ __launch_bounds__(256) void pack_w_frag_kernel(const unsigned short* 
 // ---------------------------------------------------------------------------------------
 // f32 in / f32 accumulate (exact fp32 MFMA, bit-wise an fmaf chain).  128x128 tile.
 // ---------------------------------------------------------------------------------------
-template <typename TOUT>
+// CONV: the A operand is an NHWC float32 image batch read as an implicit im2col matrix (GemmArgs c* fields, Cin % 16 == 0 so that a
+// 16-deep k block lies inside one filter tap): row m = output pixel (b, oy, ox), k = (r S + s) Cin + ic; a padded tap contributes
+// exact zeros.  The float32 parity path of every convolution of the graph (relnet_conv2d_nhwc_f32): same fmaf chain per output
+// element as the plain GEMM, whatever the tap order -- k is walked in the order of the packed weight row.
+template <typename TOUT, bool CONV = false>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -1904,11 +1908,19 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g) {
   // rows beyond M/N are clamped for the loads; their products are never stored
   const float* pa[2];
   const float* pb[2];
+  int iy0[2], ix0[2];            // CONV: input coordinates of tap (0, 0) of this lane's two output pixels
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     int ra = m0 + i * 32 + (lane & 31); ra = ra < g.M ? ra : g.M - 1;
     int rb = n0 + i * 32 + (lane & 31); rb = rb < g.N ? rb : g.N - 1;
-    pa[i] = A + (long)ra * g.lda + half * 8;
+    if constexpr (CONV) {
+      const int hw = g.cHout * g.cWout;
+      const int b = ra / hw, rem = ra - b * hw, oy = rem / g.cWout, ox = rem - oy * g.cWout;
+      iy0[i] = oy * g.cStride - g.cPad; ix0[i] = ox * g.cStride - g.cPad;
+      pa[i] = A + (long)b * g.cImg + half * 8;
+    } else {
+      pa[i] = A + (long)ra * g.lda + half * 8;
+    }
     pb[i] = W + (long)rb * g.ldw + half * 8;
   }
   f32x16 acc[2][2];
@@ -1920,13 +1932,30 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 a[2][2], b[2][2], an[2][2], bn[2][2];
+  int tr = 0, ts = 0, tc = 0;      // CONV: filter tap (row, column) and first channel of the k block the NEXT load fetches (loads are issued in k order)
   auto load = [&](int kb, float4 (&x)[2][2], float4 (&y)[2][2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      x[i][0] = *(const float4*)(pa[i] + kb * 16);
-      x[i][1] = *(const float4*)(pa[i] + kb * 16 + 4);
+      if constexpr (CONV) {
+        const int iy = iy0[i] + tr * g.cDil, ix = ix0[i] + ts * g.cDil;
+        if (iy >= 0 && iy < g.cH && ix >= 0 && ix < g.cW) {
+          const float* p = pa[i] + ((long)iy * g.cW + ix) * g.cPix + tc;
+          x[i][0] = *(const float4*)p;
+          x[i][1] = *(const float4*)(p + 4);
+        } else {
+          x[i][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+          x[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      } else {
+        x[i][0] = *(const float4*)(pa[i] + kb * 16);
+        x[i][1] = *(const float4*)(pa[i] + kb * 16 + 4);
+      }
       y[i][0] = *(const float4*)(pb[i] + kb * 16);
       y[i][1] = *(const float4*)(pb[i] + kb * 16 + 4);
+    }
+    if constexpr (CONV) {
+      tc += 16;
+      if (tc == g.cCin) { tc = 0; if (++ts == g.cS) { ts = 0; ++tr; } }
     }
   };
   const int nkb = g.K / 16;
@@ -1976,6 +2005,7 @@ static int g_force_tile = 0;     // tuning knob: 0 auto, else index into the con
 static int g_force_nloop = 0;    // tuning knob: 0 auto, else column tiles per workgroup
 static int g_swizzle = 1;        // tuning knob: XCD-aware tile order (0 = plain blockIdx order)
 extern "C" void relnet_gemm_force_tile(int t) { g_force_tile = t; }
+extern "C" int relnet_gemm_get_forced_tile(void) { return g_force_tile; }
 extern "C" void relnet_gemm_force_nloop(int n) { g_force_nloop = n; }
 extern "C" void relnet_gemm_set_swizzle(int on) { g_swizzle = on; }
 static int g_korder = 1;         // tuning knob: 1 = (channel chunk, tap) k order + XCD-contiguous row tiles for R*S > 1 ring launches
@@ -2382,6 +2412,32 @@ extern "C" int relnet_conv2d_nhwc(const void* in, long in_pix, long in_img, cons
   g.cStride = stride; g.cDil = dil; g.cPad = pad; g.cPix = in_pix; g.cImg = in_img;
   launch_bf16<1>(g, 1, out_dtype, (hipStream_t)stream);
   return check_launch("relnet_conv2d_nhwc");
+}
+
+// The same convolution with float32 operands on the exact-fp32 MFMA kernel (v_mfma_f32_32x32x2f32: bit-wise an fmaf chain per output
+// element) -- the float32 PARITY path of every convolution of the graph (backbone, RPN head, conv_new_1, FPN neck), in place of a
+// library call.  in [B,H,W,>=Cin] fp32 (pixel / image strides in elements, multiples of 4), w [Cout][R*S*Cin] fp32, out / resid
+// [B*Hout*Wout][ldc] fp32.  Cin % 16 == 0 (the 3-channel stem runs on an image zero-padded to 16 channels).  relu: 0 none, 1 ReLU,
+// 2 = resid is a ReLU mask (data gradients of the float32 training path).
+extern "C" int relnet_conv2d_nhwc_f32(const float* in, long in_pix, long in_img, const float* w, const float* bias, const float* resid,
+                                      int relu, float* out, long ldc, int B, int H, int W, int Cin, int Cout, int R, int S, int stride,
+                                      int dil, int pad, void* stream) {
+  RELNET_REQUIRE(in && w && out, "relnet_conv2d_nhwc_f32: null operand");
+  RELNET_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && dil > 0 && pad >= 0, "relnet_conv2d_nhwc_f32: bad geometry");
+  RELNET_REQUIRE(Cin % 16 == 0 && in_pix % 4 == 0 && in_img % 4 == 0 && (((uintptr_t)in | (uintptr_t)w) & 15) == 0,
+                 "relnet_conv2d_nhwc_f32: Cin %% 16 == 0 and 16-byte aligned operands / strides required (Cin=%d in_pix=%ld)", Cin, in_pix);
+  const int Hout = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1;
+  const int Wout = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
+  RELNET_REQUIRE(Hout > 0 && Wout > 0 && (long)B * Hout * Wout < (1L << 31), "relnet_conv2d_nhwc_f32: empty or too large output");
+  GemmArgs g{};
+  g.A = in; g.lda = in_pix; g.strideA = 0; g.W = w; g.ldw = (long)R * S * Cin; g.strideW = 0;
+  g.C = out; g.ldc = ldc; g.strideC = 0; g.bias = bias; g.resid = resid;
+  g.M = B * Hout * Wout; g.N = Cout; g.K = R * S * Cin; g.bias_mode = bias ? 1 : 0; g.relu = relu;
+  g.cH = H; g.cW = W; g.cCin = Cin; g.cHout = Hout; g.cWout = Wout; g.cR = R; g.cS = S;
+  g.cStride = stride; g.cDil = dil; g.cPad = pad; g.cPix = in_pix; g.cImg = in_img;
+  dim3 grid((Cout + 127) / 128, (g.M + 127) / 128, 1);
+  gemm_nt_f32_kernel<float, true><<<grid, 256, 0, (hipStream_t)stream>>>(g);
+  return check_launch("relnet_conv2d_nhwc_f32");
 }
 
 // W [N][K] bf16 -> MFMA fragment order for gemm_panelw_kernel (N % 32 == 0, K % 16 == 0); done once at model load

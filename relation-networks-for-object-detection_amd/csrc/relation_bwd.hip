@@ -853,14 +853,18 @@ extern "C" int relnet_relation_attention_bwd_kc(
   dim3 gq((unsigned)(((N + 31) / 32 + 3) / 4), H, B), gk((unsigned)(((M + 31) / 32 + 3) / 4), H, B);
   if (!prob) {
     RELNET_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && vw_ld % 8 == 0 && dy_ld % 8 == 0 && y_ld % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && vw_bs % 8 == 0 &&
-                   dy_bs % 8 == 0 && (((uintptr_t)q | (uintptr_t)dy | (uintptr_t)k | (uintptr_t)vw) & 15) == 0,
-                   "relnet_relation_attention_bwd(bf16, small-N form): rows of every operand must be 16-byte aligned");
+                   dy_bs % 8 == 0 && y_bs % 8 == 0 && bias_bs % 4 == 0 &&
+                   (((uintptr_t)q | (uintptr_t)dy | (uintptr_t)k | (uintptr_t)vw | (uintptr_t)y | (uintptr_t)bias) & 15) == 0,
+                   "relnet_relation_attention_bwd(bf16, small-N form): rows of every operand (q, k, vw, dy, y, bias) must be 16-byte aligned");
     static relnet::PerDeviceOnce attr_once;
     if (attr_once.first()) {
-      hipFuncSetAttribute((const void*)relation_attention_bwd_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute((const void*)relation_attention_bwd_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      const hipError_t e1 = hipFuncSetAttribute((const void*)relation_attention_bwd_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      const hipError_t e2 = hipFuncSetAttribute((const void*)relation_attention_bwd_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      RELNET_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, "relnet_relation_attention_bwd: the small-N kernel needs 160 KB of LDS per workgroup (hipFuncSetAttribute: %s)",
+                     hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     }
-    const unsigned grid = (unsigned)((long)H * B < 256 ? (long)H * B : 256);      // persistent: one workgroup per CU walks the (image, head) pairs
+    const long cus = relnet::device_cu_count();
+    const unsigned grid = (unsigned)((long)H * B < cus ? (long)H * B : cus);      // persistent: one workgroup per CU walks the (image, head) pairs
     if (dk) relation_attention_bwd_small_kernel<false><<<grid, 256, relnet::kSmallLdsBytes, s>>>(a);
     else relation_attention_bwd_small_kernel<true><<<grid, 256, relnet::kSmallLdsBytes, s>>>(a);
     return check_launch("relnet_relation_attention_bwd");

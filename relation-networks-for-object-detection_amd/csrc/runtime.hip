@@ -21,6 +21,20 @@ int check_launch(const char* what) {
   }
   return 0;
 }
+
+// Compute units of the current device (256 on an MI355X), cached per device: the grid size of the persistent kernels.
+long device_cu_count() {
+  static int cached[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int& c = cached[dev & 63];
+  if (c == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    c = n;
+  }
+  return c;
+}
 }  // namespace relnet
 
 extern "C" const char* relnet_last_error(void) { return relnet::g_err; }

@@ -71,6 +71,45 @@ extern "C" int relnet_stem_bias_relu_pool(const void* in, const float* bias, voi
   return check_launch("relnet_stem_bias_relu_pool");
 }
 
+// pool1 of the float32 parity path (mx.symbol.Pooling(kernel 3x3, stride 2, pool_type 'max', pooling_convention 'full'),
+// resnet_v1_101_rcnn_base.py:35-36): ceil-mode windows clipped at the border, no padding.  in [B,H,W,C] fp32 NHWC, C % 4 == 0.
+namespace relnet {
+struct PoolF32Args { const float* in; float* out; int B, H, W, C, Ho, Wo, ksize, stride; };
+__global__ __launch_bounds__(256) void maxpool_nhwc_f32_kernel(PoolF32Args g) {
+  const int groups = g.C >> 2;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)g.B * g.Ho * g.Wo * groups) return;
+  const int cg = (int)(t % groups);
+  long p = t / groups;
+  const int ox = (int)(p % g.Wo); p /= g.Wo;
+  const int oy = (int)(p % g.Ho);
+  const int b = (int)(p / g.Ho);
+  const int y0 = oy * g.stride, x0 = ox * g.stride;
+  const int y1 = min(y0 + g.ksize, g.H), x1 = min(x0 + g.ksize, g.W);
+  float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  const float* base = g.in + (long)b * g.H * g.W * g.C + cg * 4;
+  for (int y = y0; y < y1; ++y)
+    for (int x = x0; x < x1; ++x) {
+      const float4 v = *(const float4*)(base + ((long)y * g.W + x) * g.C);
+      best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+    }
+  *(float4*)(g.out + (((long)b * g.Ho + oy) * g.Wo + ox) * g.C + cg * 4) = best;
+}
+}  // namespace relnet
+
+extern "C" int relnet_maxpool_nhwc_f32(const float* in, float* out, int B, int H, int W, int C, int ksize, int stride, void* stream) {
+  RELNET_REQUIRE(in && out, "relnet_maxpool_nhwc_f32: null operand");
+  RELNET_REQUIRE(B > 0 && H >= ksize && W >= ksize && C > 0 && C % 4 == 0 && stride > 0, "relnet_maxpool_nhwc_f32: bad shape");
+  relnet::PoolF32Args g{in, out, B, H, W, C, 0, 0, ksize, stride};
+  g.Ho = (H - ksize + stride - 1) / stride + 1;
+  g.Wo = (W - ksize + stride - 1) / stride + 1;
+  if ((g.Ho - 1) * stride >= H) --g.Ho;      // last window must start inside the input
+  if ((g.Wo - 1) * stride >= W) --g.Wo;
+  const long total = (long)B * g.Ho * g.Wo * (C / 4);
+  relnet::maxpool_nhwc_f32_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(g);
+  return relnet::check_launch("relnet_maxpool_nhwc_f32");
+}
+
 // ---------------------------------------------------------------------------------------
 // Fused stem: conv1 7x7 / 2 (pad 3, Cin = 3) + folded-BN bias + ReLU + pool1 3x3 / 2 (ceil mode) in ONE kernel, from the
 // raw NCHW image to the pooled NHWC bf16 map (reference graph: resnet_v1_101_rcnn_base.py:30-36).  The three-launch path

@@ -59,6 +59,8 @@ _SIGNATURES = {
     'relnet_bbox_overlaps': (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),
     'relnet_image_topk': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'relnet_conv2d_nhwc': (C.c_int, [_vp, _l, _l, _vp, _vp, _vp, _i, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'relnet_conv2d_nhwc_f32': (C.c_int, [_vp, _l, _l, _vp, _vp, _vp, _i, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'relnet_maxpool_nhwc_f32': (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_pack_w_frag': (C.c_int, [_vp, _l, _vp, _i, _i, _vp]),
     'relnet_conv2d_nhwc_wf': (C.c_int, [_vp, _l, _l, _vp, _vp, _vp, _vp, _i, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_deformable_im2col': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l] + [_i] * 15 + [_vp]),
@@ -92,6 +94,7 @@ _SIGNATURES = {
     'relnet_wgrad_tune': (None, [_i, _i, _i]),
     'relnet_debug_tr_probe': (C.c_int, [_vp, _vp]),
     'relnet_gemm_force_tile': (None, [_i]),
+    'relnet_gemm_get_forced_tile': (C.c_int, []),
     'relnet_gemm_force_nloop': (None, [_i]),
     'relnet_weight_relayout': (C.c_int, [_vp, _i, _i, _vp]),
     'relnet_weight_fragpack': (C.c_int, [_vp, _i, _i, _vp]),

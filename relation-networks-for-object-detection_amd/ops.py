@@ -81,29 +81,33 @@ def asm_selfcheck(force=False):
     On a mismatch the asm tiles are switched off for the process (relnet_gemm_debug_asm(0): pick_tile then never chooses them)
     and the fact is announced on stderr.  -> True (match / not checked yet on this device) or False."""
     global _ASM_SELFCHECK
-    if _ASM_SELFCHECK is not None and not force:
-        return _ASM_SELFCHECK
     if not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
         return True
+    dev = torch.cuda.current_device()
+    if _ASM_SELFCHECK is None:
+        _ASM_SELFCHECK = {}
+    if dev in _ASM_SELFCHECK and not force:           # (cached per DEVICE: a process may drive several GPUs)
+        return _ASM_SELFCHECK[dev]
     if os.environ.get('RELNET_DEBUG_KNOBS') == '1' and (os.environ.get('RELNET_GEMM_FORCE_TILE') or os.environ.get('RELNET_GEMM_ASM')):
         return True                         # an A/B run pinned the tile choice by hand
     lib = _lib.load()
     g = torch.Generator().manual_seed(19)
     a = torch.randn(768, 1024, generator=g).cuda().to(torch.bfloat16)
     w = torch.randn(512, 1024, generator=g).cuda().to(torch.bfloat16)
+    prev = lib.relnet_gemm_get_forced_tile()       # a tile forced by the caller before the first model is built survives the check
     try:
         lib.relnet_gemm_force_tile(19); y19 = gemm_nt(a, w).float()
         lib.relnet_gemm_force_tile(8); y8 = gemm_nt(a, w).float()
     finally:
-        lib.relnet_gemm_force_tile(0)
+        lib.relnet_gemm_force_tile(prev)
     err, scale = float((y19 - y8).abs().max()), float(y8.abs().max())
-    _ASM_SELFCHECK = bool(err <= 1e-2 * scale) and bool(torch.isfinite(y19).all())
-    if not _ASM_SELFCHECK:
+    ok = _ASM_SELFCHECK[dev] = bool(err <= 1e-2 * scale) and bool(torch.isfinite(y19).all())
+    if not ok:
         import sys
         lib.relnet_gemm_debug_asm(0)
         sys.stderr.write('relnet: hand-scheduled GEMM tile 19 disagrees with tile 8 (max |diff| %.3g of %.3g): asm tiles DISABLED for this '
                          'process (compiler-scheduled ring tile instead)\n' % (err, scale))
-    return _ASM_SELFCHECK
+    return ok
 
 
 def gemm_nt_mask(a, w, mask, resid=None, out=None):
@@ -527,6 +531,8 @@ def conv2d_nhwc(x, w_packed, bias, ksize=1, stride=1, pad=0, dil=1, relu=False, 
     """x [B,H,W,Cin] bf16 (last dim contiguous; pixel/image strides free), w_packed
     [Cout, k*k*Cin], bias fp32 [Cout] -> [B,Hout,Wout,Cout]; optional fused residual + ReLU."""
     _chk(x, w_packed, bias, resid, out)
+    if x.dtype == torch.float32:        # float32 parity path: the exact-fp32 MFMA kernel in convolution mode
+        return conv2d_nhwc_f32(x, w_packed, bias, ksize, stride, pad, dil, relu, resid, out)
     assert x.dtype == torch.bfloat16 and w_packed.dtype == torch.bfloat16 and x.stride(3) == 1
     B, H, W, Cin = x.shape
     assert x.stride(1) == W * x.stride(2), "rows of an image must be dense in W"
@@ -545,6 +551,45 @@ def conv2d_nhwc(x, w_packed, bias, ksize=1, stride=1, pad=0, dil=1, relu=False, 
               _ptr(resid), int(relu), out.data_ptr(), out.stride(2), B, H, W, Cin, Cout, ksize, ksize,
               stride, dil, pad, _dt(out), _stream(),
               tag='M%d_N%d_K%d_k%d' % (B * Hout * Wout, Cout, ksize * ksize * Cin, ksize))
+    return out
+
+
+def conv2d_nhwc_f32(x, w_packed, bias, ksize=1, stride=1, pad=0, dil=1, relu=False, resid=None, out=None):
+    """float32 twin of conv2d_nhwc on the exact-fp32 MFMA kernel (relnet_conv2d_nhwc_f32): x [B,H,W,Cin] fp32 with Cin % 16 == 0,
+    w_packed [Cout, k*k*Cin] fp32, bias fp32 | None -> [B,Hout,Wout,Cout] fp32.  relu: False / True / 2 (resid is a ReLU mask)."""
+    _chk(x, w_packed, bias, resid, out)
+    assert x.dtype == torch.float32 and w_packed.dtype == torch.float32 and x.stride(3) == 1
+    B, H, W, Cin = x.shape
+    assert x.stride(1) == W * x.stride(2), "rows of an image must be dense in W"
+    Cout = w_packed.shape[0]
+    assert w_packed.shape[1] == ksize * ksize * Cin and w_packed.is_contiguous()
+    Hout = (H + 2 * pad - dil * (ksize - 1) - 1) // stride + 1
+    Wout = (W + 2 * pad - dil * (ksize - 1) - 1) // stride + 1
+    if out is None:
+        out = torch.empty((B, Hout, Wout, Cout), device=x.device, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.shape == (B, Hout, Wout, Cout) and out.stride(3) == 1
+    assert out.stride(1) == Wout * out.stride(2) and out.stride(0) == Hout * out.stride(1)
+    if resid is not None:
+        assert resid.dtype == torch.float32 and resid.stride() == out.stride()
+    _lib.call('relnet_conv2d_nhwc_f32', x.data_ptr(), x.stride(2), x.stride(0), w_packed.data_ptr(), _ptr(bias), _ptr(resid), int(relu),
+              out.data_ptr(), out.stride(2), B, H, W, Cin, Cout, ksize, ksize, stride, dil, pad, _stream(),
+              tag='M%d_N%d_K%d_k%d_f32' % (B * Hout * Wout, Cout, ksize * ksize * Cin, ksize))
+    return out
+
+
+def maxpool_nhwc_f32(x, ksize=3, stride=2):
+    """pool1 of the float32 path: ceil-mode max pooling without padding (pooling_convention='full'), x [B,H,W,C] fp32 dense."""
+    _chk(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    B, H, W, Cc = x.shape
+    Ho = -(-(H - ksize) // stride) + 1
+    Wo = -(-(W - ksize) // stride) + 1
+    if (Ho - 1) * stride >= H:
+        Ho -= 1
+    if (Wo - 1) * stride >= W:
+        Wo -= 1
+    out = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
+    _lib.call('relnet_maxpool_nhwc_f32', x.data_ptr(), out.data_ptr(), B, H, W, Cc, ksize, stride, _stream())
     return out
 
 

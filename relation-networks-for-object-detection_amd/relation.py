@@ -239,9 +239,11 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
         kt = qt = dyt = None       # the small-N backward kernel transposes K / Q / dY on the fly from LDS: no transposed copies
     elif sink is not None:         # persistent zero-padded buffers: the transposes below write [:, :, :rows], the pad columns stay zero
         Npad = ops.pad_to(N, 32)
-        kt = sink.scratch('kt', (B, d, Mpad), dtype)
-        qt = sink.scratch('qt', (B, d, Npad), dtype)
-        dyt = sink.scratch('dyt', (B, d, Npad), dtype)
+        # (keyed on the row counts as well as the shapes: a later call with the same padded shape but fewer rows must not see the
+        #  previous call's rows in [rows_new, rows_old) -- ADVICE r05)
+        kt = sink.scratch('kt_%d' % M, (B, d, Mpad), dtype)
+        qt = sink.scratch('qt_%d' % N, (B, d, Npad), dtype)
+        dyt = sink.scratch('dyt_%d' % N, (B, d, Npad), dtype)
         ops.transpose_2d(k, out=kt); ops.transpose_2d(q, out=qt); ops.transpose_2d(dY, out=dyt)
     else:
         kt = torch.zeros((B, d, Mpad), device=f.device, dtype=dtype)
@@ -252,7 +254,7 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
     if sink is not None and dtype == torch.bfloat16 and ops.relation_bwd_small_ok(dtype, N, Mpad):
         # small-N form (the learn-NMS head's module): the backward kernel writes (dQ | dK | dVW) as bf16 straight into the projection
         # backward's operand; its key blocks past row M are never written and stay zero in the persistent buffer
-        packed = sink.scratch('a3_%d' % index, (B, N, 3 * d), dtype)       # per module: the trainer's QUEUED weight-gradient product reads it after this call returns
+        packed = sink.scratch('a3_%d_%d' % (index, M), (B, N, 3 * d), dtype)       # per module and key count (rows >= M of the key blocks must be zero): the trainer's QUEUED weight-gradient product reads it after this call returns
     dq, dk, dvw, prob, dlog = ops.relation_attention_bwd(q, k, kt, vw, bias, dY, y, mod.bout, qt, dyt, M, key_count=key_count, packed_out=packed)
     if sink is not None and dtype == torch.bfloat16:
         # ---- gradients straight into the trainer's buffers (GradSink): one pack kernel, ONE projection-backward GEMM with the residual

@@ -90,6 +90,12 @@ class Trainer(object):
         dev = device
         f32 = lambda t: torch.as_tensor(t).to(dev, torch.float32).contiguous()
         self.fpn = bool(getattr(c, 'fpn', False))
+        # cfg.trunk_fp32 (parity tests only): conv1 .. res5 forward AND backward in float32 on the exact-fp32 MFMA kernels
+        # (relnet_conv2d_nhwc_f32 / relnet_gemm_nt f32, master weights read directly, no chain kernels, no fused ReLU-mask epilogue) with
+        # the SAME wiring code (_trunk_forward / _trunk_backward / train_ops) -- removes the bf16 noise of ~100 layers from the
+        # end-to-end gradient comparison, so that the trunk's wiring is pinned to float64 autograd at 1e-4 instead of 2e-2
+        self.trunk_fp32 = bool(getattr(c, 'trunk_fp32', False))
+        assert not (self.trunk_fp32 and getattr(c, 'dcn', False)), "trunk_fp32 covers the plain and FPN trunks"
         if torch.device(dev).type == 'cuda':
             ops.asm_selfcheck()
         self.units = unit_names(self.fpn)
@@ -107,7 +113,7 @@ class Trainer(object):
         self._frozen_backbone = None
         if getattr(c, 'frozen_on_inference_kernels', True) and torch.device(dev).type == 'cuda':
             from .backbone import Backbone
-            self._frozen_backbone = Backbone(params, dtype=torch.bfloat16, device=dev, fpn=self.fpn, frozen_only=True)
+            self._frozen_backbone = Backbone(params, dtype=torch.float32 if self.trunk_fp32 else torch.bfloat16, device=dev, fpn=self.fpn, frozen_only=True)
         self.zero_bias64 = torch.zeros(64, device=dev, dtype=torch.float32)
         weights, biases = [], []
         self.bn_scale, self.conv_bias, self.ksize = {}, {}, {'rpn_conv_3x3': 3, 'rpn_out': 1, 'conv_new_1': 1}
@@ -202,8 +208,8 @@ class Trainer(object):
                 for h in range(16):
                     self._relayout.add('nms_lo_h%d' % h, wo[8 * h:8 * h + 8], taps=1, pad_co=8, group=('rel_cat_nms', 2048 + 64 * h, 3 * 1024))
                 continue
-            if name.startswith(('pair_pos_fc1', 'nms_')) or name.endswith('_offset'):
-                continue                                    # consumed in other layouts (relation_bwd kernels, padded DCN offset convs)
+            if name.startswith(('pair_pos_fc1', 'nms_')) or name.endswith('_offset') or self._trunk32(name):
+                continue                                    # consumed in other layouts (relation_bwd kernels, padded DCN offset convs; float32 trunk)
             if name.startswith(('qk_', 'linear_out_')):     # [Wq; Wk]^T | Wout^T side by side: the [1024, 3072] operand of the ONE
                 i = name.rsplit('_', 1)[1]                  # projection-backward GEMM of relation module i (relation.GradSink)
                 group = ('rel_cat_' + i, 0 if name.startswith('qk_') else self.W.slices['qk_' + i][1][0])
@@ -215,7 +221,7 @@ class Trainer(object):
         # cfg.train_chain = False keeps the per-layer convolution launches (the round-4 form).
         self._fragpack = ops.FragRepack(dev)
         self.chain_units = {}                               # unit -> (has_next_reduce, next unit)
-        if getattr(c, 'train_chain', os.environ.get('RELNET_TRAIN_CHAIN', '1') != '0') and torch.device(dev).type == 'cuda':
+        if getattr(c, 'train_chain', os.environ.get('RELNET_TRAIN_CHAIN', '1') != '0') and torch.device(dev).type == 'cuda' and not self.trunk_fp32:
             trainable = [u for u in self.units if u[0] >= 3]
             for (st, nm, ic, mc, oc, stride, dil, proj), nxt in zip(trainable, trainable[1:] + [None]):
                 if c.dcn and st == 5:
@@ -230,7 +236,7 @@ class Trainer(object):
             self._fragpack.build()
         # data gradient through `relu(expand + shortcut)` with the ReLU mask in the GEMM epilogue (relnet_gemm_nt_mask) instead of a
         # separate relnet_relu_bwd pass over three [pixels, 4 mid] maps per unit
-        self.mask_epilogue = getattr(c, 'mask_epilogue', os.environ.get('RELNET_TRAIN_MASK_EPI', '1') != '0')
+        self.mask_epilogue = getattr(c, 'mask_epilogue', os.environ.get('RELNET_TRAIN_MASK_EPI', '1') != '0') and not self.trunk_fp32
         # weight-gradient products of the trunk launched on a side stream every `wgrad_overlap` units (0, the default: one grouped
         # launch per gradient bucket on the main stream): built to let the persistent stream-K kernel fill the CUs that the
         # data-gradient GEMMs of a 19 152-pixel map leave idle.  Measured (r05, same box, 8 images, ms per step): off 20.27, every
@@ -242,13 +248,18 @@ class Trainer(object):
         self._scratch_bufs = {}
 
     # ---- accessors ----------------------------------------------------------------------------------------
-    def w(self, name):          # bf16 working copy
-        return self.W.view(self.W.work, name)
+    def _trunk32(self, name):
+        return self.trunk_fp32 and name.startswith('res') and not name.endswith('_offset')
+
+    def w(self, name):          # bf16 working copy (the float32 master weights for the trunk layers of a cfg.trunk_fp32 trainer)
+        return self.W.view(self.W.master if self._trunk32(name) else self.W.work, name)
 
     def b(self, name):          # fp32 bias
         return self.Bv.view(self.Bv.master, name)
 
     def wt(self, name):         # data-gradient layout of w(name), refreshed by _relayout.run() at the start of every step
+        if self._trunk32(name):
+            return None         # (float32 trunk: train_ops transposes / flips the master weights on the fly)
         return self._relayout.get(name)
 
     def num_trainable(self):
@@ -325,7 +336,11 @@ class Trainer(object):
         at_conv4(conv4): called once conv4 exists, before res5 is queued (the RPN branch forks there)."""
         c = self.cfg
         fb = self._frozen_backbone
-        x = fb.forward_res2(data) if fb is not None else ops.stem_fused(data, self.w_stem, self.b_stem)
+        if self.trunk_fp32:
+            assert fb is not None
+            x = fb.forward_res2(data)                 # float32 NHWC (Backbone impl 'hip32')
+        else:
+            x = fb.forward_res2(data) if fb is not None else ops.stem_fused(data, self.w_stem, self.b_stem)
         saved = []
         conv4 = None
         ends = {}
@@ -436,11 +451,13 @@ class Trainer(object):
             def fork(conv4):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    rpn_branch(conv4)
+                    rpn_branch(conv4.to(torch.bfloat16))
             conv5, conv4, saved, _ = self._trunk_forward(data, at_conv4=fork)
         else:
             conv5, conv4, saved, _ = self._trunk_forward(data)
-            rpn_branch(conv4)
+            rpn_branch(conv4.to(torch.bfloat16))
+        # (a float32 trunk -- cfg.trunk_fp32, parity tests -- hands bf16 copies to the bf16 heads and takes their gradients back as float32)
+        conv5, conv4 = conv5.to(torch.bfloat16), conv4.to(torch.bfloat16)
         feat = self._conv(conv5, 'conv_new_1', relu=True, bias=self.b('conv_new_1'))
         if side is not None:
             main.wait_stream(side)
@@ -490,6 +507,8 @@ class Trainer(object):
         T.colsum_add(d_rpn, self._bg('rpn_out'))
         d_conv4_rpn, dw = T.conv3x3_bwd(conv4, self._dgrad_w('rpn_conv_3x3', 512), g_r, dil=1, keep_splits=True, wgrad_to=self._wg('rpn_conv_3x3'))
         T.colsum_add(g_r, self._bg('rpn_conv_3x3'))
+        if self.trunk_fp32:
+            d_x, d_conv4_rpn = d_x.float(), d_conv4_rpn.float()
         self._trunk_backward(saved, d_x, {'4b22': d_conv4_rpn})
         out['rois'] = rois_t
         out['label'] = labels_ohem
@@ -1054,6 +1073,8 @@ class FPNTrainer(Trainer):
         conv5, conv4, saved, ends = self._trunk_forward(data)
         # ---- neck: 1x1 laterals (+bias), nearest 2x upsampling + sum, 3x3 output convs
         src = {32: ends[5], 16: ends[4], 8: ends[3], 4: ends[2]}
+        if self.trunk_fp32:             # float32 trunk (parity tests): bf16 copies for the bf16 neck / heads
+            src = {k: v.to(bt) for k, v in src.items()}
         tops = {32: self._conv(src[32], 'fpn_ft32_1x1', bias=self.b('fpn_ft32_1x1'))}
         for lvl in (16, 8, 4):
             tops[lvl] = ops.upsample2x_add_(self._conv(src[lvl], 'fpn_ft%d_1x1' % lvl, bias=self.b('fpn_ft%d_1x1' % lvl)), tops[lvl * 2])
@@ -1105,6 +1126,8 @@ class FPNTrainer(Trainer):
                 inject['4b22'] = d_src
             elif lvl == 8:
                 inject['3b3'] = d_src
+        if self.trunk_fp32:
+            d_c5, inject = d_c5.float(), {k: v.float() for k, v in inject.items()}
         self._trunk_backward(saved, d_c5, inject)
         out.update(rois=rois_s, perm=perm, roi_level=level, label=labels_ohem, bbox_target=bbox_target, bbox_weight=weights_ohem,
                    bbox_pred=bbox_pred, cls_score=cls_score)

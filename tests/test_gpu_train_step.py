@@ -48,17 +48,23 @@ def _setup(H, W, G, seed, dcn=False):
     return p, cfg, data, gt, L, Tg, Wg, train
 
 
-@pytest.mark.parametrize('learn_nms,dcn,chain', [(False, False, False), (True, False, False), (True, True, False), (True, False, True)])
+@pytest.mark.parametrize('learn_nms,dcn,chain', [(False, False, False), (True, False, False), (True, True, False), (True, False, True), (True, False, 'trunk_fp32')])
 def test_training_step_gradients_match_autograd(learn_nms, dcn, chain, monkeypatch):
     """(True, False): BASELINE configs[2] (relation + learn-NMS end2end); (False, False): the relation end2end config;
     (True, True): configs[3], deformable res5 + deformable PSROI pooling on top.  chain: the res3 .. res5 block boundaries of the
-    forward on the chain kernels (what the benchmark's 19 152-pixel maps run; their pixel thresholds are lowered for this map)."""
+    forward on the chain kernels (what the benchmark's 19 152-pixel maps run; their pixel thresholds are lowered for this map).
+    'trunk_fp32': the same step with conv1 .. res5 in float32 (cfg.trunk_fp32, same wiring code, bf16 heads): what is left of the
+    trunk's error is the bf16 heads' error on d conv5 / d conv4, not ~100 layers of rounding -- the trunk tensors are then held to
+    the HEAD's bounds (cosine >= 0.995, norm within 3 %) instead of 0.98 / 8 %."""
+    trunk_fp32 = chain == 'trunk_fp32'
+    chain = chain is True
     H, W, G = 128, 160, 4
     p, cfg, data, gt, L, Tg, Wg, train = _setup(H, W, G, 31, dcn)
     if chain:
         from relnet_amd import ops as _ops
         monkeypatch.setattr(_ops, 'CHAIN_MIN_PIXELS', {k: 1 for k in _ops.CHAIN_MIN_PIXELS})
     cfg.learn_nms, cfg.first_n, cfg.dcn = learn_nms, 24, dcn
+    cfg.trunk_fp32 = trunk_fp32
     if learn_nms:          # un-saturate the duplicate classifier (init bias -3 -> sigmoid 0.05) so its gradients are not tiny
         g_ = torch.Generator().manual_seed(77)
         p['nms_logit_bias'] = torch.zeros(5)
@@ -136,7 +142,7 @@ def test_training_step_gradients_match_autograd(learn_nms, dcn, chain, monkeypat
         nw, ng = float(w.norm()), float(got.norm())
         cos = float((w * got).sum() / max(nw * ng, 1e-300))
         report.append('%-22s |want| %.3e |got| %.3e cos %.4f' % (name, nw, ng, cos))
-        tight = not name.startswith('res') and 'pair_pos' not in name
+        tight = (trunk_fp32 or not name.startswith('res')) and 'pair_pos' not in name
         cmin, nmax = (0.995, 0.03) if tight else (0.98, 0.08)
         if dcn:
             # the deformable graph's forward is 2.5x more sensitive to bf16 rounding (sampling positions move with the
@@ -186,8 +192,8 @@ def test_training_steps_reduce_the_loss_and_update_only_trainable():
         assert i == want, (name, i, want)
 
 
-@pytest.mark.parametrize('N,first_n,ohem', [(60, 24, 128), (200, 150, 512)])
-def test_fpn_training_step_gradients_match_autograd(N, first_n, ohem):
+@pytest.mark.parametrize('N,first_n,ohem,trunk_fp32', [(60, 24, 128, False), (200, 150, 512, False), (200, 150, 512, True)])
+def test_fpn_training_step_gradients_match_autograd(N, first_n, ohem, trunk_fp32):
     """BASELINE configs[4] graph: FPN neck, level-dispatched ROI pooling, relation head over the given proposals (+ gt rows),
     learn-NMS head; every gradient vs float64 autograd of oracle/train_graph.py:total_loss_fpn.  (200, 150, 512): the learn-NMS head
     at the experiment file's FIRST_N 150 (the two-kernel relation backward, Mpad 160) and BATCH_ROIS_OHEM 512
@@ -212,6 +218,7 @@ def test_fpn_training_step_gradients_match_autograd(N, first_n, ohem):
         p[k] = torch.randn(p[k].shape, generator=g) * 0.05
     cfg = train.TrainConfig()
     cfg.learn_nms, cfg.first_n, cfg.batch_rois_ohem = True, first_n, ohem
+    cfg.trunk_fp32 = trunk_fp32          # float32 conv1 .. res5 (same wiring code): the trunk tensors are then held to 0.99 / 4 %
     data = torch.randn(1, 3, H, W, generator=g)
     props = _proposals(N, 43, H, W)[None]
     gt = np.zeros((1, G, 5), np.float32)
@@ -273,6 +280,8 @@ def test_fpn_training_step_gradients_match_autograd(N, first_n, ohem):
         # trunk: four pyramid levels feed it (more bf16 paths than C4); with 204 pooled rois instead of 64 the bf16 noise of ~100 layers leaves
         # single res3 tensors at 0.96 (the float32-trunk test below pins the trunk's wiring tightly instead)
         cmin, nmax = (0.995, 0.03) if tight else ((0.97 if N <= 64 else 0.95), 0.08)
+        if trunk_fp32 and name.startswith('res'):
+            cmin, nmax = 0.99, 0.04        # (what is left: the bf16 neck's / heads' error on the gradients entering the trunk)
         if nw > 1e-9 and (cos < cmin or abs(ng / nw - 1) > nmax):
             bad.append(report[-1])
     assert not bad, '\n'.join(bad) + '\n--- all ---\n' + '\n'.join(report)
@@ -451,3 +460,71 @@ def test_round5_trunk_backward_forms_agree():
         if nb > 1e-12 and (cos < 0.99999 or abs(na / nb - 1) > 1e-3):
             bad.append('%s cos %.6f norm ratio %.5f' % (name, cos, na / nb))
     assert not bad, '\n'.join(bad)
+
+
+@pytest.mark.parametrize('fpn', [False, True])
+def test_float32_trunk_forward_and_gradients_match_float64_autograd_tightly(fpn):
+    """The trunk's WIRING pinned without the bf16 noise of ~100 layers (verdict r05 weak 3 / 4): a cfg.trunk_fp32 Trainer runs conv1 .. res5
+    forward and backward through the same code (_trunk_forward / _trunk_backward / train_ops) on the exact-fp32 MFMA kernels
+    (relnet_conv2d_nhwc_f32 in convolution mode, relnet_gemm_nt f32) and is compared with float64 torch autograd of oracle/network.py's
+    backbone under a random linear functional of conv5 and conv4 (the RPN / FPN-lateral injection point; FPN also res3b3): stage outputs
+    within 2e-5 of scale, EVERY res3 .. res5 weight gradient with cosine >= 0.9999 and norm within 0.5 %."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import backbone, train
+    from oracle import network as ON
+    H, W = 128, 160
+    p = backbone.init_params(seed=61, fpn=fpn)
+    cfg = train.TrainConfig()
+    cfg.trunk_fp32 = True
+    g = torch.Generator().manual_seed(62)
+    data = torch.randn(2, 3, H, W, generator=g)
+    tr = (train.FPNTrainer(p, cfg) if fpn else train.Trainer(p, cfg, im_hw=(H, W)))
+    assert tr.trunk_fp32 and not tr.chain_units and not tr.mask_epilogue and tr._frozen_backbone.impl == 'hip32'
+    conv5, conv4, saved, ends = tr._trunk_forward(data.cuda())
+    assert conv5.dtype == torch.float32 and saved[0][5].dtype == torch.float32
+    g5 = torch.randn(conv5.shape, generator=g) * 0.01
+    g4 = torch.randn(conv4.shape, generator=g) * 0.01
+    inject = {'4b22': g4.cuda()}
+    if fpn:
+        g3 = torch.randn(ends[3].shape, generator=g) * 0.01
+        inject['3b3'] = g3.cuda()
+    tr._grad_buckets().reset()
+    tr.W.grad.zero_(); tr.Bv.grad.zero_()
+    tr._trunk_backward(saved, g5.cuda(), inject)
+    tr._flush_wgrads()
+    torch.cuda.synchronize()
+    # ---- float64 autograd of the restated backbone
+    pt = {k: v.double().clone().requires_grad_(k.startswith(('res3', 'res4', 'res5')) and k.endswith('_weight')) for k, v in p.items()}
+    old = ON._t
+    ON._t = lambda x: x.double() if torch.is_tensor(x) else torch.as_tensor(np.asarray(x), dtype=torch.float64)
+    try:
+        if fpn:
+            c2, c3, c4, c5 = ON.backbone(data.double(), pt, fpn=True)
+        else:
+            c4, c5 = ON.backbone(data.double(), pt)
+    finally:
+        ON._t = old
+    nhwc = lambda t: t.permute(0, 2, 3, 1)
+    for name, got, want in (('conv4', conv4, c4), ('conv5', conv5, c5)) + ((('res3b3', ends[3], c3), ('res2c', ends[2], c2)) if fpn else ()):
+        err = float((got.double().cpu() - nhwc(want).detach()).abs().max() / want.detach().abs().max())
+        assert err <= 2e-5, (name, err)
+    loss = (nhwc(c5) * g5.double()).sum() + (nhwc(c4) * g4.double()).sum()
+    if fpn:
+        loss = loss + (nhwc(c3) * g3.double()).sum()
+    loss.backward()
+    bad, worst = [], 1.0
+    n_checked = 0
+    for name in tr.W.slices:
+        if not name.startswith('res'):
+            continue
+        gw = pt[name + '_weight'].grad
+        want = gw.permute(0, 2, 3, 1).reshape(gw.shape[0], -1) * tr.bn_scale[name].cpu().double().view(-1, 1)      # s * dL/dw = s^2 dL/dw'
+        got = tr.W.view(tr.W.grad, name).cpu().double().reshape(want.shape)
+        nw, ng = float(want.norm()), float(got.norm())
+        cos = float((want * got).sum() / max(nw * ng, 1e-300))
+        worst = min(worst, cos)
+        n_checked += 1
+        if nw > 1e-12 and (cos < 0.9999 or abs(ng / nw - 1) > 5e-3):
+            bad.append('%-20s |want| %.3e |got| %.3e cos %.6f' % (name, nw, ng, cos))
+    assert n_checked == 93 and not bad, '\n'.join(bad)
+    print('float32 trunk: %d tensors, worst cosine %.7f' % (n_checked, worst))
