@@ -11,11 +11,10 @@ Images are independent units: ranks share nothing on the data path (weak scaling
 collective); the barrier + max-over-ranks timing is the only communication.
 
 The JSON line also carries
-  roofline      the relation-attention kernel (north_star's named kernel): `frac` = algorithmic FLOPs of
-                the graph as written (3.13 GFLOP per module-image) / measured
-                launch duration (HIP events on the launching stream) / dense bf16 MFMA peak;
-                `frac_executed` = the same with the FLOPs the re-associated kernel really performs,
-                `hbm_frac` = bytes one launch must move / duration / 8 TB/s.
+  roofline      the relation-attention kernel (north_star's named kernel), stated on the roof that bounds it: HBM.  `achieved` =
+                algorithmic bytes per launch (SURVEY.md 8d with the geometry fused: 3.12 MB per image) / launch duration (HIP events on
+                the launching stream), `peak` 8000 GB/s, `traffic` = PMC bytes; `mfma_frac_as_written` (3.13 GFLOP per module-image as
+                the graph is written / 2.5 PFLOP/s) and `frac_executed` (the FLOPs the re-associated kernel performs) beside it.
   cpu_baseline  the CPU oracle (numpy + torch-CPU fp32 restatement of the same graph): 3 warm-up + 10 timed
                 images, median, on this host's cores (N = 1 only).
   parity        the timed detector, on images of the timed batch, checked stage by stage against the oracle
@@ -177,15 +176,25 @@ def _side_figure(fn, what):
     error, a diverged 5-step random-init run -- is recorded as {'error': ...} under the figure's key instead of losing the headline
     line.  Every rank calls the same sequence of side figures, so a failure that every rank sees (the reduced
     non-finite check) leaves them in step; a one-rank failure inside a collective cannot be repaired from here."""
+    res, err = None, None
     try:
-        return fn()
+        res = fn()
     except (Exception, SystemExit) as ex:          # noqa: BLE001 -- the line must survive any side figure
         sys.stderr.write('bench.py: side figure %s failed: %s: %s\n' % (what, type(ex).__name__, str(ex)[:300]))
         try:
             torch.cuda.empty_cache()
         except Exception:
             pass
-        return {'error': '%s: %s' % (type(ex).__name__, str(ex)[:300])}
+        err = {'error': '%s: %s' % (type(ex).__name__, str(ex)[:300])}
+    # every rank learns whether ALL ranks got through (ADVICE r05): a figure that failed on one rank only is dropped on every rank, so
+    # that they enter the next side figure's collectives together; a rank that died INSIDE a collective is caught by the process
+    # group's timeout (dist.init: 600 s) instead
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        from relnet_amd import dist as _D
+        n_ok = _D.sum_over_ranks(0.0 if err else 1.0, device='cuda')
+        if err is None and n_ok != float(torch.distributed.get_world_size()):
+            err = {'error': 'side figure %s failed on %d other rank(s)' % (what, int(torch.distributed.get_world_size() - n_ok))}
+    return err if err is not None else res
 
 
 def _fpn_proposals(batch, n_rois, im_h, im_w, g):
@@ -310,9 +319,8 @@ def bench_train(a, rank, world, D, emit=True, fatal=True):
             # all-reduce is issued between two graph launches and overlaps the rest of the backward pass; SGD stays eager
             graph = train.CapturedStep(tr, batch)
             out = graph.out
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
+        def one_step():
+            nonlocal out
             if graph is not None:
                 graph.replay()
             else:
@@ -320,8 +328,23 @@ def bench_train(a, rank, world, D, emit=True, fatal=True):
             tr.all_reduce(wait=False)      # launches the buckets the backward pass has not announced; update() waits bucket by bucket
             tr.update()
         fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            one_step()
+        fence()
         elapsed = time.perf_counter() - t0
+        comm = None
+        if world > 1:       # self-diagnosis of the N > 1 line (verdict r05 item 8), OUTSIDE the timed region: the same steps again with HIP
+            tr.comm_timing = []               # events around every bucket's wait -> exposed communication per step and per bucket
+            n_c = min(a.steps, 5)
+            for _ in range(n_c):
+                one_step()
+            fence()
+            comm = tr.comm_report(n_c)
+            tr.comm_timing = None
     elapsed = D.max_over_ranks(elapsed, device='cuda')
+    if comm is not None:
+        comm['exposed_comm_ms_per_step_max_over_ranks'] = D.max_over_ranks(comm['exposed_comm_ms_per_step'], device='cuda')
     ok = bool(torch.isfinite(tr.W.master).all())
     if not ok:
         sys.stderr.write('bench.py: rank %d: non-finite weights after the training steps\n' % rank)
@@ -360,6 +383,7 @@ def bench_train(a, rank, world, D, emit=True, fatal=True):
                        'images_per_gpu_per_step': B, 'launch': 'eager' if a.no_graph else 'hipGraph replay (forward+backward in %d segments cut at the gradient buckets)' % len(graph.segments),
                        'parallelism': 'dp%d (RCCL all-reduce SUM)' % world, 'lr': cfg.lr,
                        'lr_rule': 'yaml lr %g x min(1, 16 / images summed per step over all ranks)' % yaml_lr},
+            'communication': comm if comm is not None else 'single rank: no collective',
             'losses': {k: float(out[k]) for k in ('bbox_loss', 'rpn_bbox_loss', 'nms_pos_loss', 'nms_neg_loss') if k in out},
             'weights_finite_on_all_ranks': bool(ok)}
         if emit:
@@ -593,26 +617,36 @@ def main():
                 pmc = os.path.join(ROOT, 'profiles', 'attention_pmc.json')
                 if os.path.exists(pmc):
                     traffic = json.load(open(pmc)).get('hbm_bytes_per_launch_at_batch', {}).get(str(a.batch))
-                res['roofline'] = {
-                    'kernel': 'relation_attention_lds_kernel' if a.dtype == 'bf16' else 'relation_attention_kernel<float>', 'bound': 'mfma',
-                    'achieved': algo, 'peak': peak, 'unit': 'TFLOP/s', 'frac': algo / peak, 'traffic': traffic,
-                    'executed': EXEC_GFLOP_PER_MODULE_IMAGE * rs * a.batch / 1e3 / sec,
-                    'launch_ms': att['avg_ms'], 'launches': att['calls'],
-                    'algorithmic_gflop_per_launch': ALGO_GFLOP_PER_MODULE_IMAGE * rs * a.batch,
-                }
-                # honest utilisation figures next to the contract's `frac`: `frac` prices the graph AS WRITTEN (SURVEY 8d:
-                # softmax.V over 1024-d values, then the grouped linear_out); the kernel executes the re-associated form
-                # S.(F_K Wout^T) = 8.5x fewer FLOPs, so its MFMA pipes are `frac_executed` busy; `hbm_frac` = the bytes one
-                # launch must move (Q, K, VW^T, fp16 geometry bias, shortcut in, activation out) / duration / 8 TB/s
+                # The kernel is an HBM stream, not an MFMA-bound loop (PMC: MFMA-busy 9.6 %, 3.4 TB/s; profiles/attention_pmc.json), so the
+                # contract's roofline object is stated on the HBM roof: `achieved` = ALGORITHMIC bytes per launch (SURVEY 8d with the geometry
+                # fused: boxes + Q|K + VW^T + shortcut in + activation out = 3.12 MB per image at N = 300 -- NOT counting the materialised
+                # fp16 geometry bias the kernel also reads today) / launch duration; `traffic` = the bytes it really moves (PMC).  The MFMA
+                # pricing the earlier rounds led with stays beside it: `mfma_frac_as_written` prices the graph as written (softmax.V over
+                # 1024-d values, then the grouped linear_out: 3.13 GFLOP per module-image), `frac_executed` the FLOPs the re-associated
+                # kernel S.(F_K Wout^T) really performs (8.5x fewer).
                 mp = (n_rois + 31) // 32 * 32
-                hbm_bytes = a.batch * (n_rois * 2048 * 2 + 1024 * mp * 2 + 16 * n_rois * mp * 2 + 2 * n_rois * 1024 * 2)
-                res['roofline'].update(frac_executed=res['roofline']['executed'] / peak, hbm_algorithmic_bytes=hbm_bytes,
-                                       hbm_frac=hbm_bytes / sec / 8e12,
-                                       frac_basis='algorithmic FLOPs of the graph as written (SURVEY 8d); see frac_executed / hbm_frac',
-                                       traffic_source='profiles/attention_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of an earlier '
-                                                      'run of this kernel at this batch; not re-measured by this process)' if traffic else None)
+                algo_bytes = a.batch * (n_rois * 16 + n_rois * 2048 * 2 + 1024 * mp * 2 + 2 * n_rois * 1024 * 2)
+                bias_bytes = a.batch * 16 * n_rois * mp * 2
+                gbs = algo_bytes / sec / 1e9
+                res['roofline'] = {
+                    'kernel': 'relation_attention_lds_kernel' if a.dtype == 'bf16' else 'relation_attention_kernel<float>', 'bound': 'hbm',
+                    'achieved': gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs / 8000.0, 'traffic': traffic,
+                    'launch_ms': att['avg_ms'], 'launches': att['calls'],
+                    'algorithmic_bytes_per_launch': algo_bytes,
+                    'bytes_per_launch_with_the_materialised_geometry_bias': algo_bytes + bias_bytes,
+                    'hbm_frac_of_bytes_moved': (algo_bytes + bias_bytes) / sec / 8e12,
+                    'traffic_over_algorithmic': (traffic / algo_bytes) if traffic else None,
+                    'mfma_tflops_as_written': algo, 'mfma_peak_tflops': peak, 'mfma_frac_as_written': algo / peak,
+                    'executed_tflops': EXEC_GFLOP_PER_MODULE_IMAGE * rs * a.batch / 1e3 / sec,
+                    'frac_executed': EXEC_GFLOP_PER_MODULE_IMAGE * rs * a.batch / 1e3 / sec / peak,
+                    'algorithmic_gflop_per_launch': ALGO_GFLOP_PER_MODULE_IMAGE * rs * a.batch,
+                    'frac_basis': 'algorithmic HBM bytes with the geometry fused (SURVEY 8d) / launch time / 8 TB/s; the kernel reads a materialised fp16 '
+                                  'geometry bias on top (2x the algorithmic bytes): that is `traffic`, written by geometry_bias_mfma_kernel for both modules',
+                    'traffic_source': ('profiles/attention_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of an earlier run of this kernel at this '
+                                       'batch; not re-measured by this process)') if traffic else None,
+                }
                 iso = attention_isolated(a.batch, n_rois, tdt)           # kernel alone: median of 100 launches
-                res['roofline'].update(isolated_median_ms=iso, isolated_frac=ALGO_GFLOP_PER_MODULE_IMAGE * rs * a.batch / iso / peak)
+                res['roofline'].update(isolated_median_ms=iso, isolated_frac=algo_bytes / (iso * 1e-3) / 8e12)
         plain = not (a.dcn or a.fpn or a.learn_nms)
         if world == 1 and plain and not a.no_parity and a.dtype == 'bf16':
             # the timed configuration itself (same detector object, same batch) checked stage by stage against the oracle
@@ -634,14 +668,16 @@ def main():
         del det
         torch.cuda.empty_cache()
         ta = argparse.Namespace(**vars(a))
-        keys = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'n_gpus', 'config', 'losses', 'weights_finite_on_all_ranks')
-        sub = ('value', 'ms_per_step', 'steps')
+        keys = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'n_gpus', 'config', 'communication', 'losses', 'weights_finite_on_all_ranks')
+        sub = ('value', 'ms_per_step', 'steps', 'communication')
 
         def train_at(bsz, steps):
             ta.batch, ta.learn_nms, ta.steps, ta.warmup = bsz, True, steps, 2
             return _side_figure(lambda: bench_train(ta, rank, world, D, emit=False, fatal=False), 'train@%d' % bsz)
         tr_res = train_at(8, min(a.steps, 10))
-        tr16 = train_at(16, min(a.steps, 6))          # the same step at 16 images per GPU (larger GEMMs fill the chip better)
+        # the same step at 16 images per GPU (larger GEMMs fill the chip better): a single-GPU side figure -- an N > 1 run carries the
+        # scaling workload only (8 and 1 images per GPU), every extra collective-bearing figure is one more way to lose the line
+        tr16 = train_at(16, min(a.steps, 6)) if world == 1 else None
         # ... and at ONE image per GPU: the reference's own training protocol (BATCH_IMAGES: 1 per device,
         # cfgs/resnet_v1_101_coco_trainvalminus_rcnn_end2end_relation_learn_nms_8epoch.yaml:80, train_end2end.py:70-71)
         tr1 = train_at(1, min(a.steps, 10))
@@ -653,7 +689,9 @@ def main():
             if tr1 is not None and 'error' not in tr1:
                 res['train']['at_1_image_per_gpu']['note'] = ("the reference's own protocol: BATCH_IMAGES 1 per device (cfgs/..._rcnn_end2end_relation_"
                                                                "learn_nms_8epoch.yaml:80); ~700 launches of a few microseconds each, launch / latency bound")
-    if plain_graph and not a.no_other_configs:
+    if plain_graph and not a.no_other_configs and world > 1 and rank == 0:
+        res['other_configs'] = 'single-GPU side figures (configs[3] / configs[4] inference and training rates): run `python bench.py` with --gpus 1'
+    if plain_graph and not a.no_other_configs and world == 1:
         if 'det' in locals():
             del det
         torch.cuda.empty_cache()

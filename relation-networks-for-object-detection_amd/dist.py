@@ -23,7 +23,11 @@ def init(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        # a finite collective timeout: a rank that died (out of memory, an exception between two collectives) must turn the others'
+        # wait into an error after minutes, not into a hang that loses the whole run (RELNET_DIST_TIMEOUT_S overrides)
+        import datetime
+        dist.init_process_group(backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=int(os.environ.get('RELNET_DIST_TIMEOUT_S', '600'))))
     return rank, world, local
 
 
@@ -98,6 +102,7 @@ class BucketedAllReduce(object):
         self.cuda = flat.is_cuda
         self.stream = torch.cuda.Stream(device=flat.device) if self.cuda else None
         self.pending, self.done, self.launch_order = {}, set(), []
+        self.exchanged = False      # True from finish() / clear() until the next reset(): this pass's sums are in the flat buffer
 
     @staticmethod
     def active():
@@ -131,6 +136,7 @@ class BucketedAllReduce(object):
         for w in self.pending.values():
             w.wait()
         self.pending, self.done, self.launch_order = {}, set(), []
+        self.exchanged = False
 
     def launch_rest(self):
         """Launch the buckets nobody announced (in backward order) WITHOUT waiting; returns the launch order so far."""
@@ -159,6 +165,7 @@ class BucketedAllReduce(object):
         """End of a step whose buckets were waited for one by one."""
         assert not self.pending, sorted(self.pending)
         self.done, self.launch_order = set(), []
+        self.exchanged = True
 
     def finish(self):
         """Launch the buckets nobody announced (in backward order) and wait: after this the flat buffer holds the sums."""
@@ -173,6 +180,7 @@ class BucketedAllReduce(object):
             torch.cuda.synchronize()
         order = self.launch_order
         self.pending, self.done, self.launch_order = {}, set(), []
+        self.exchanged = True
         return order
 
 

@@ -936,24 +936,63 @@ class Trainer(object):
         W, Bv = self.W, self.Bv
         wo, bo, mult = self.lr_mult_tail if self.lr_mult_tail is not None else (W.size, Bv.size, 1.0)
         bk = self._grad_buckets()
-        pending = bk.pending_order() if bk.active() else []
+        pending = []
+        if bk.active():
+            # every bucket must have been exchanged before its slice is updated: a caller that skipped all_reduce() (or whose backward
+            # pass announced only some buckets) gets the missing collectives launched here instead of a silently local update
+            if not bk.exchanged:                    # (exchanged: all_reduce(wait=True) already summed this pass's gradients)
+                if len(bk.done) < bk.n:
+                    bk.launch_rest()
+                if getattr(self, '_bias_work', None) is None:
+                    self._bias_work = D.all_reduce_async(self.Bv.grad)
+                assert len(bk.done) == bk.n
+            pending = bk.pending_order()
         self.update_order = []                      # (bucket index, its collective had completed when SGD was queued) -- test hook
         ranges = [(self._bucket_cuts[i], self._bucket_cuts[i + 1], i) for i in pending] if pending else [(0, W.size, None)]
+        timing = getattr(self, 'comm_timing', None)   # list (bench.py --gpus N): per bucket, (name, event before the wait, event after it)
         for lo, hi, i in ranges:
             if i is not None:
                 self.update_order.append((i, bk.is_completed(i)))
+                if timing is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 bk.wait(i)
+                if timing is not None:
+                    e1.record()
+                    timing.append((self._bucket_names[i], e0, e1))
             # parameters with lr_mult != 1 (DCN `offset` FC) sit at the tail of both flat buffers
             self._sgd(W, lo, min(hi, wo), lr, c.wd)
             self._sgd(W, max(lo, wo), hi, lr * mult, c.wd)
         if pending:
             bk.clear()
         if getattr(self, '_bias_work', None) is not None:
+            if timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             D.wait_work(self._bias_work, self.Bv.grad)
+            if timing is not None:
+                e1.record()
+                timing.append(('biases', e0, e1))
             self._bias_work = None
         self._sgd(Bv, 0, bo, lr, 0.0, bf16=False)
         self._sgd(Bv, bo, Bv.size, lr * mult, 0.0, bf16=False)
         self.step_count += 1
+
+    def comm_report(self, steps):
+        """Exposed communication of the steps since `comm_timing = []` was set: per gradient bucket, the time the COMPUTE stream sat
+        in that bucket's wait (event before / after the wait, both on the compute stream: zero when the collective had finished under
+        the backward pass), averaged over `steps`; plus their sum per step.  Call after a device synchronisation."""
+        per = {}
+        for name, e0, e1 in (getattr(self, 'comm_timing', None) or []):
+            per[name] = per.get(name, 0.0) + e0.elapsed_time(e1)
+        per = {k: v / max(steps, 1) for k, v in per.items()}
+        mb = {n: 4e-6 * (self._bucket_cuts[i + 1] - self._bucket_cuts[i]) for i, n in enumerate(self._bucket_names)}
+        mb['biases'] = 4e-6 * self.Bv.size
+        return {'exposed_wait_ms_per_step': {k: round(v, 4) for k, v in per.items()},
+                'exposed_comm_ms_per_step': round(sum(per.values()), 4),
+                'bucket_megabytes': {k: round(v, 1) for k, v in mb.items()},
+                'how': 'HIP events on the compute stream around each bucket\'s wait in Trainer.update(): the time the optimizer was held up by a '
+                       'collective still in flight (0 = fully hidden under the backward pass)'}
 
     def step(self, *batch, **kw):
         out = self.forward_backward(*batch, **kw)
