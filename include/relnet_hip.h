@@ -63,6 +63,18 @@ int relnet_nms_greedy(const float* boxes5, const int* counts, float* rois, float
                       int* num_keep, int B, int n, int n_stride, int post, float thresh,
                       int batch_index_base, void* stream);
 
+/* ---- ROIAlign (named by BASELINE.json's north_star; the reference graphs pool with ROIPooling, SYM_REL:252-253, and ship no ROIAlign:
+ * this follows the published algorithm -- He et al., Mask R-CNN (2017), section 3, as in Detectron's RoIAlign / mx.contrib.sym.ROIAlign(data,
+ * rois, pooled_size, spatial_scale, sample_ratio) of MXNet >= 1.3): no coordinate rounding, sampling_ratio^2 bilinear samples per bin
+ * (<= 0: ceil(roi extent / pooled size)), averaged; `aligned` subtracts the half-pixel offset.  Strides as relnet_roi_pool_fwd.  Backward:
+ * grad_in fp32, pre-zeroed, strides (b, c, y, x) in elements; every sample scatters its four bilinear weights (atomics).              */
+int relnet_roi_align_fwd(const void* data, const long* data_strides4, const float* rois /*[R,5]*/, void* out, const long* out_strides4,
+                         int R, int C, int H, int W, int PH, int PW, float spatial_scale, int sampling_ratio, int aligned,
+                         int batch_index_base, int dtype, void* stream);
+int relnet_roi_align_bwd(const void* grad_out, const long* out_strides4, const float* rois, float* grad_in,
+                         const long* grad_in_strides4, int R, int C, int H, int W, int PH, int PW, float spatial_scale,
+                         int sampling_ratio, int aligned, int batch_index_base, int dtype, void* stream);
+
 /* ---- mx.symbol.ROIPooling(pooled_size=(7,7), spatial_scale=1/16), SYM_REL:252-253 ---------------
  * data/out described by element strides (b|r, c, y, x) so NCHW and channels-last both work.       */
 int relnet_roi_pool_fwd(const void* data, const long* data_strides4, const float* rois /*[R,5]*/, void* out,

@@ -83,31 +83,52 @@ def _compile(dig, verbose):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
     procs = []
+    hdr = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(CSRC, '*.h'))):
+        hdr.update(open(f, 'rb').read())
+    hdr.update(' '.join(FLAGS).encode())
+    fresh = {}
     for src in sorted(glob.glob(os.path.join(CSRC, '*.hip'))):
         obj = os.path.splitext(src)[0] + '.o'
+        objs.append(obj)
+        # per-object stamp (source + headers + flags): an edit of one kernel file recompiles that file only
+        od = hashlib.sha256(hdr.digest() + open(src, 'rb').read()).hexdigest()
+        ostamp = obj + '.stamp'
+        if os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read() == od:
+            continue
+        fresh[obj] = od
         cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
     # ISA guard of the hand-scheduled k-loops (gemm.hip, SCHED 5 / 6): their accumulators live in a[0:127] ACROSS separate asm
     # statements and the compiler only sees clobbers -- nothing in the language stops a future hipcc from parking a spill or an
     # AV-class temporary in those AGPRs between two slabs.  So the device assembly of gemm.hip is produced beside the object
     # (same flags, in parallel with the real compile) and checked: inside those kernels no instruction OUTSIDE the asm blocks may
     # touch an AGPR.  A violation fails the build instead of corrupting convolutions on some other toolchain.
-    guard_s = os.path.join('/tmp', 'relnet_gemm_guard_%d.s' % os.getpid())
-    guard = subprocess.Popen([hipcc] + FLAGS + ['--cuda-device-only', '-S', os.path.join(CSRC, 'gemm.hip'), '-o', guard_s],
-                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    import json
+    gemm_obj = os.path.join(CSRC, 'gemm.o')
+    need_guard = gemm_obj in fresh or not os.path.exists(GUARD)       # (gemm.hip unchanged: the report of the build that compiled it stands)
+    guard = None
+    if need_guard:
+        guard_s = os.path.join('/tmp', 'relnet_gemm_guard_%d.s' % os.getpid())
+        guard = subprocess.Popen([hipcc] + FLAGS + ['--cuda-device-only', '-S', os.path.join(CSRC, 'gemm.hip'), '-o', guard_s],
+                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode()))
-    gout, _ = guard.communicate()
-    if guard.returncode != 0:
-        raise RuntimeError("hipcc -S failed on gemm.hip (ISA guard):\n%s" % gout.decode())
-    report = asm_agpr_guard(guard_s)
-    os.remove(guard_s)
-    import json
+    for obj, od in fresh.items():
+        with open(obj + '.stamp', 'w') as f:
+            f.write(od)
+    if guard is not None:
+        gout, _ = guard.communicate()
+        if guard.returncode != 0:
+            raise RuntimeError("hipcc -S failed on gemm.hip (ISA guard):\n%s" % gout.decode())
+        report = asm_agpr_guard(guard_s)
+        os.remove(guard_s)
+    else:
+        report = {k: v for k, v in json.load(open(GUARD)).items() if k != 'digest'}
     with open(GUARD, 'w') as f:
         json.dump(dict(report, digest=dig), f)
     if report['offenders']:

@@ -39,6 +39,8 @@ class Config(object):
     dcn = False               # deformable res5 + DeformablePSROIPooling (symbols/..._dcn_...py)
     dcn_sample_per_part = 4
     dcn_trans_std = 0.1
+    roi_align = False         # True: ROIAlign (ops.roi_align, sampling_ratio 2) feeds fc_new_1 instead of the graphs' ROIPooling -- the operator
+    roi_align_sampling = 2    # north_star names; no reference graph uses it (SYM_REL:252-253 is ROIPooling), so it is off by default
 
     @classmethod
     def from_experiment(cls, name, train=False):
@@ -150,6 +152,9 @@ class Detector(object):
                                 out_dtype=torch.float32).view(B * N, 2, 7, 7)
             pooled = ops.deformable_psroi_pool(feat, r5, trans, sc, feat.shape[1], 1, 7, 7, c.dcn_sample_per_part,
                                                c.dcn_trans_std, False, channels_last_out=True)
+        elif c.roi_align:
+            pooled = ops.roi_align(f['conv_new_1_relu'], rois.view(B * N, 5), (7, 7), 1.0 / c.feat_stride, c.roi_align_sampling,
+                                   channels_last_out=True)
         else:
             pooled = ops.roi_pool(f['conv_new_1_relu'], rois.view(B * N, 5), (7, 7), 1.0 / c.feat_stride,
                                   channels_last_out=True)

@@ -47,6 +47,8 @@ _SIGNATURES = {
     'relnet_nms_scan': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     '_nms': (None, [_vp, _vp, _vp, _i, _i, _f, _i]),
     'relnet_roi_pool_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    'relnet_roi_align_fwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp]),
+    'relnet_roi_align_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp]),
     'relnet_roi_pool_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_roi_pool_bwd_ex': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_roi_pool_fpn_bwd_ex': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -58,7 +58,8 @@ sym = symbol = _make_namespace(__name__ + '.symbol_api')
 contrib = types.ModuleType(__name__ + '.contrib')
 contrib.sym = contrib.symbol = types.ModuleType(__name__ + '.contrib.symbol')
 for _pub, _op in (('DeformableConvolution', '_contrib_DeformableConvolution'),
-                  ('DeformablePSROIPooling', '_contrib_DeformablePSROIPooling'), ('Proposal', '_contrib_Proposal')):
+                  ('DeformablePSROIPooling', '_contrib_DeformablePSROIPooling'), ('Proposal', '_contrib_Proposal'),
+                  ('ROIAlign', '_contrib_ROIAlign')):
     setattr(contrib.sym, _pub, (lambda o: lambda *a, **k: _R.make(o, a, k))(_op))
 
 # mx.operator: the CustomOp protocol lives in relnet_amd.operator_py (same classes, same registry)

@@ -65,7 +65,7 @@ def infer_shapes(sym, known):
 # ---------------------------------------------------------------------------------------------------------
 # executor
 # ---------------------------------------------------------------------------------------------------------
-_LOWP_OK = {'Convolution', 'BatchNorm', 'Activation', 'broadcast_add', '_plus', 'elemwise_add', 'FullyConnected', 'ROIPooling',
+_LOWP_OK = {'Convolution', 'BatchNorm', 'Activation', 'broadcast_add', '_plus', 'elemwise_add', 'FullyConnected', 'ROIPooling', '_contrib_ROIAlign',
             'Pooling', 'slice_axis', '_contrib_DeformableConvolution', '_contrib_DeformablePSROIPooling', 'Flatten'}
 
 
@@ -477,6 +477,10 @@ class Executor(object):
             ps = a_tuple(a, 'pooled_size')
             return K.roi_pool(x if x.dtype in (torch.float32, torch.bfloat16) else x.float(), rois.float().contiguous(), ps,
                               a_float(a, 'spatial_scale'))
+        if n.op == '_contrib_ROIAlign':
+            x, rois = ins
+            return K.roi_align(x if x.dtype in (torch.float32, torch.bfloat16) else x.float(), rois.float().contiguous(), a_tuple(a, 'pooled_size'),
+                               a_float(a, 'spatial_scale'), a_int(a, 'sample_ratio', -1), a_bool(a, 'aligned'))
         if n.op == 'Pooling':
             x = ins[0]
             k, s, p = a_tuple(a, 'kernel'), a_tuple(a, 'stride', (1, 1)), a_tuple(a, 'pad', (0, 0))

@@ -557,6 +557,8 @@ def _roipool_meta(a, x, rois):
 
 
 defop('ROIPooling', ['data', 'rois'], _roipool_meta, heavy=True, hint='roipooling')
+# mx.contrib.sym.ROIAlign(data, rois, pooled_size, spatial_scale, sample_ratio) (MXNet >= 1.3; not used by the reference's symbols)
+defop('_contrib_ROIAlign', ['data', 'rois'], _roipool_meta, heavy=True, hint='roialign')
 
 
 def _dconv_inputs(a):

@@ -338,6 +338,41 @@ def roi_pool_bwd(grad_out, argmax, rois, in_shape, batch_index_base=0, channels_
     return gin
 
 
+def roi_align(data, rois, pooled=(7, 7), spatial_scale=0.0625, sampling_ratio=2, aligned=False, channels_last_out=False,
+              batch_index_base=0):
+    """ROIAlign (relnet_roi_align_fwd; Mask R-CNN section 3 / mx.contrib.sym.ROIAlign(data, rois, pooled_size, spatial_scale, sample_ratio)).
+    data: logical [B,C,H,W] of any strides, fp32 / bf16; rois [R,5] fp32.  Output logical [R,C,PH,PW] (memory (R,PH,PW,C) when
+    channels_last_out).  The reference graphs use ROIPooling (`roi_pool`); this is the operator north_star names next to it."""
+    _chk(data, rois)
+    assert rois.dtype == torch.float32 and rois.is_contiguous()
+    B, Cc, H, W = data.shape
+    R = rois.shape[0]
+    PH, PW = pooled
+    if channels_last_out:
+        out = torch.empty((R, PH, PW, Cc), device=data.device, dtype=data.dtype).permute(0, 3, 1, 2)
+    else:
+        out = torch.empty((R, Cc, PH, PW), device=data.device, dtype=data.dtype)
+    _lib.call('relnet_roi_align_fwd', data.data_ptr(), _strides4(data), rois.data_ptr(), out.data_ptr(), _strides4(out), R, Cc, H, W,
+              PH, PW, float(spatial_scale), int(sampling_ratio), int(bool(aligned)), batch_index_base, _dt(data), _stream())
+    return out
+
+
+def roi_align_bwd(grad_out, rois, in_shape, spatial_scale=0.0625, sampling_ratio=2, aligned=False, batch_index_base=0,
+                  channels_last=False):
+    """Adjoint of roi_align: grad_out logical [R,C,PH,PW] (any strides) -> fp32 gradient of the feature map, logical [B,C,H,W]
+    (memory NHWC with channels_last: coalesced atomics)."""
+    _chk(grad_out, rois)
+    B, Cc, H, W = in_shape
+    R, _, PH, PW = grad_out.shape
+    if channels_last:
+        gin = torch.zeros((B, H, W, Cc), device=grad_out.device, dtype=torch.float32).permute(0, 3, 1, 2)
+    else:
+        gin = torch.zeros((B, Cc, H, W), device=grad_out.device, dtype=torch.float32)
+    _lib.call('relnet_roi_align_bwd', grad_out.data_ptr(), _strides4(grad_out), rois.data_ptr(), gin.data_ptr(), _strides4(gin), R, Cc,
+              H, W, PH, PW, float(spatial_scale), int(sampling_ratio), int(bool(aligned)), batch_index_base, _dt(grad_out), _stream())
+    return gin
+
+
 # ---------------------------------------------------------------------------------------
 # detection post-processing
 # ---------------------------------------------------------------------------------------

@@ -258,3 +258,38 @@ def test_assign_anchor_oracle_matches_reference_loader():
     L2 = OA.assign_anchor((38, 63), g['crowded/gt'], (600, 1000), sampler='hash', seed=99)[0]
     L3 = OA.assign_anchor((38, 63), g['crowded/gt'], (600, 1000), sampler='hash', seed=100)[0]
     assert (L2 == 1).sum() == (L3 == 1).sum() == 128 and not np.array_equal(L2, L3)
+
+
+def test_roi_align_oracle_known_answers():
+    """oracle/roi_align.py has no reference code to be pinned by (the reference has no ROIAlign): what holds it are the answers that
+    follow from the published definition -- affine maps pool to their value at the bin centre, constants to the constant, a one-hot map to
+    the bilinear weight, float32 within rounding of float64."""
+    from oracle import roi_align as ORA
+    H, W, C = 20, 30, 5
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing='ij')
+    coef = np.random.default_rng(2).normal(0, 1, (C, 3))
+    data = (coef[:, 0, None, None] * yy + coef[:, 1, None, None] * xx + coef[:, 2, None, None])[None]
+    rois = np.array([[0, 40, 30, 200, 150], [0, 100.5, 60.25, 130.75, 99.5]], np.float32)
+    for aligned in (False, True):
+        for sr in (1, 2, 3, 0):
+            got = ORA.roi_align(data, rois, (7, 7), 1 / 16.0, sr, aligned, dtype=np.float64)
+            off = 0.5 if aligned else 0.0
+            for i, roi in enumerate(rois.astype(np.float64)):
+                sw, sh = roi[1] / 16 - off, roi[2] / 16 - off
+                rw, rh = roi[3] / 16 - off - sw, roi[4] / 16 - off - sh
+                if not aligned:
+                    rw, rh = max(rw, 1.0), max(rh, 1.0)
+                cy = sh + (np.arange(7) + 0.5) * rh / 7
+                cx = sw + (np.arange(7) + 0.5) * rw / 7
+                want = coef[:, 0, None, None] * cy[None, :, None] + coef[:, 1, None, None] * cx[None, None, :] + coef[:, 2, None, None]
+                assert np.abs(got[i] - want).max() <= 1e-10 * np.abs(want).max()
+            g32 = ORA.roi_align(data, rois, (7, 7), 1 / 16.0, sr, aligned)
+            assert g32.dtype == np.float32 and np.abs(g32 - got).max() <= 2e-5 * np.abs(got).max()
+    const = np.full((1, 2, H, W), 3.25)
+    assert np.array_equal(ORA.roi_align(const, rois, (3, 3), 1 / 16.0, 2), np.full((2, 2, 3, 3), 3.25, np.float32))
+    hot = np.zeros((1, 1, H, W)); hot[0, 0, 10, 20] = 1.0
+    roi = np.array([[0, 16 * 19.25, 16 * 9.5, 16 * 20.25, 16 * 10.5]], np.float32)
+    assert abs(float(ORA.roi_align(hot, roi, (1, 1), 1 / 16.0, 1)[0, 0, 0, 0]) - 0.75) < 1e-6
+    # a box hanging over the border: samples beyond (-1, H) x (-1, W) contribute zero, the divisor stays sr^2
+    out = ORA.roi_align(const, np.array([[0, -64, -64, 31, 31]], np.float32), (2, 2), 1 / 16.0, 2, dtype=np.float64)
+    assert out[0, 0, 0, 0] == 0.0 and 0 < out[0, 0, 1, 1] <= 3.25
