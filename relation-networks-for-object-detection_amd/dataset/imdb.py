@@ -82,57 +82,63 @@ class IMDB(object):
         rpn = self.load_rpn_roidb(gt_roidb, top_roi)
         return IMDB.merge_roidbs(rpn, gt_roidb) if append_gt else rpn
 
+    # per-roi fields of a roidb record and how two records of one image are joined (row-wise / element-wise)
+    _ROW_FIELDS = ('boxes', 'gt_overlaps')
+    _VEC_FIELDS = ('gt_classes', 'max_classes', 'max_overlaps', 'is_gt')
+
+    def _class_overlaps(self, boxes, gt, overlaps_fn):
+        """[n, num_classes] float32: for every box the IoU with its best ground-truth box, stored in that box's class
+        column (zero elsewhere, and zero rows for boxes that touch no ground truth)."""
+        table = np.zeros((len(boxes), self.num_classes), dtype=np.float32)
+        if gt is None or gt['boxes'].size == 0 or len(boxes) == 0:
+            return table
+        iou = np.asarray(overlaps_fn(boxes.astype(np.float64), gt['boxes'].astype(np.float64)))
+        best = iou.argmax(axis=1)
+        val = iou[np.arange(len(boxes)), best]
+        hit = val > 0
+        table[np.flatnonzero(hit), gt['gt_classes'][best[hit]]] = val[hit]
+        return table
+
     def create_roidb_from_box_list(self, box_list, gt_roidb, overlaps_fn=None):
-        """imdb.py:140-188.  `overlaps_fn(boxes f64 [N,4], gt f64 [K,4]) -> [N,K]` defaults to the device twin of
-        `bbox_overlaps_cython` (relnet_amd.bbox)."""
-        assert len(box_list) == self.num_images, 'number of boxes matrix must match number of images'
+        """Proposal records for `lib/dataset/imdb.py:140-188`'s consumers (same keys, dtypes and values).
+        `overlaps_fn(boxes f64 [N,4], gt f64 [K,4]) -> [N,K]` defaults to the device twin of `bbox_overlaps_cython`
+        (relnet_amd.bbox)."""
+        if len(box_list) != self.num_images:
+            raise AssertionError('number of boxes matrix must match number of images')
         if overlaps_fn is None:
             from ..bbox import bbox_overlaps as overlaps_fn
-        roidb = []
-        for i in range(self.num_images):
-            rec = dict(image=gt_roidb[i]['image'], height=gt_roidb[i]['height'], width=gt_roidb[i]['width'])
-            boxes = box_list[i]
-            if boxes.shape[1] == 5:
-                boxes = boxes[:, :4]
-            n = boxes.shape[0]
-            overlaps = np.zeros((n, self.num_classes), dtype=np.float32)
-            if gt_roidb is not None and gt_roidb[i]['boxes'].size > 0:
-                gt_boxes, gt_classes = gt_roidb[i]['boxes'], gt_roidb[i]['gt_classes']
-                gt_ov = np.asarray(overlaps_fn(boxes.astype(np.float64), gt_boxes.astype(np.float64)))
-                argmaxes, maxes = gt_ov.argmax(axis=1), gt_ov.max(axis=1)
-                idx = np.where(maxes > 0)[0]
-                overlaps[idx, gt_classes[argmaxes[idx]]] = maxes[idx]
-            rec.update(boxes=boxes, gt_classes=np.zeros((n,), dtype=np.int32), gt_overlaps=overlaps,
-                       max_classes=overlaps.argmax(axis=1), max_overlaps=overlaps.max(axis=1), flipped=False,
-                       is_gt=np.zeros(n))
-            roidb.append(rec)
-        return roidb
+
+        def record(dets, gt):
+            boxes = dets[:, :4]                                 # a fifth column is the proposal score
+            ov = self._class_overlaps(boxes, gt, overlaps_fn)
+            return {'image': gt['image'], 'height': gt['height'], 'width': gt['width'], 'boxes': boxes,
+                    'gt_classes': np.zeros(len(boxes), dtype=np.int32), 'gt_overlaps': ov,
+                    'max_classes': ov.argmax(axis=1), 'max_overlaps': ov.max(axis=1),
+                    'flipped': False, 'is_gt': np.zeros(len(boxes))}
+        return [record(d, g) for d, g in zip(box_list, gt_roidb)]
 
     def append_flipped_images(self, roidb):
-        """imdb.py:219-255: horizontally mirrored copy of every entry (the pixels are flipped when the image is loaded)."""
-        assert self.num_images == len(roidb)
-        for i in range(self.num_images):
-            r = roidb[i]
-            boxes = r['boxes'].copy()
-            oldx1, oldx2 = boxes[:, 0].copy(), boxes[:, 2].copy()
-            boxes[:, 0] = r['width'] - oldx2 - 1
-            boxes[:, 2] = r['width'] - oldx1 - 1
-            assert (boxes[:, 2] >= boxes[:, 0]).all()
-            roidb.append(dict(image=r['image'], height=r['height'], width=r['width'], boxes=boxes, gt_classes=r['gt_classes'],
-                              gt_overlaps=r['gt_overlaps'], max_classes=r['max_classes'], max_overlaps=r['max_overlaps'],
-                              flipped=True, is_gt=r['is_gt']))
-        self.image_set_index = self.image_set_index * 2
+        """Doubles the roidb with mirrored entries (`imdb.py:219-255`): x' = width - 1 - x with the two corners swapped;
+        the pixels themselves are mirrored when the image is loaded.  Every other field is shared with the original."""
+        if len(roidb) != self.num_images:
+            raise AssertionError('roidb does not cover the image set')
+
+        def mirrored(rec):
+            b = rec['boxes'].copy()
+            b[:, [0, 2]] = rec['width'] - 1 - rec['boxes'][:, [2, 0]]
+            if (b[:, 2] < b[:, 0]).any():
+                raise AssertionError('box with x2 < x1 in %s' % rec['image'])
+            return dict(rec, boxes=b, flipped=True)
+        roidb.extend([mirrored(r) for r in roidb[:self.num_images]])
+        self.image_set_index = list(self.image_set_index) + list(self.image_set_index)
         return roidb
 
     @staticmethod
     def merge_roidbs(a, b):
-        """imdb.py:382-400: concatenate the boxes of two roidbs of the same images (proposals + ground truth)."""
-        assert len(a) == len(b)
-        for i in range(len(a)):
-            a[i]['boxes'] = np.vstack((a[i]['boxes'], b[i]['boxes']))
-            a[i]['gt_classes'] = np.hstack((a[i]['gt_classes'], b[i]['gt_classes']))
-            a[i]['gt_overlaps'] = np.vstack((a[i]['gt_overlaps'], b[i]['gt_overlaps']))
-            a[i]['max_classes'] = np.hstack((a[i]['max_classes'], b[i]['max_classes']))
-            a[i]['max_overlaps'] = np.hstack((a[i]['max_overlaps'], b[i]['max_overlaps']))
-            a[i]['is_gt'] = np.hstack((a[i]['is_gt'], b[i]['is_gt']))
+        """Joins, image by image, the rois of `b` below those of `a` (proposals + ground truth, `imdb.py:382-400`);
+        `a` is updated in place and returned."""
+        if len(a) != len(b):
+            raise AssertionError('roidbs of different image sets')
+        for ra, rb in zip(a, b):
+            ra.update({k: np.concatenate((ra[k], rb[k]), axis=0) for k in IMDB._ROW_FIELDS + IMDB._VEC_FIELDS})
         return a
