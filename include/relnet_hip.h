@@ -103,6 +103,12 @@ void relnet_gemm_debug_phase_ts(void* buf); /* measurement knob: the ring kernel
 void relnet_gemm_debug_ablate(int a);     /* measurement knob for tile 8: 1 = fill path only, 2 = LDS + MFMA only (garbage results) */
 void relnet_chain_debug(int flags);        /* measurement knob for chain256_roles_kernel (garbage results while non-zero): 1 = half of the weight loads, 2 = none, 4 = no shortcut-slice loads, 8 = no global stores */
 int relnet_gemm_tile_count(void);         /* number of tile configurations (valid relnet_gemm_force_tile values 1..count) */
+/* Work area of the split-K tile (configuration 23, round 6: launches of at most one 64 x 64 workgroup per CU -- the one-image step of
+ * core/tester.py:219-295 / train_end2end.py with BATCH_IMAGES: 1 -- split their k-loop over 2..8 workgroups per tile; fp32 partial tiles and
+ * per-tile arrival counters live here).  `ws`: device memory, 256-byte aligned, ZERO-initialised by the caller, owned by the caller, registered per
+ * device; NULL unregisters.  Without a work area no launch is split.  Four equal slots, one per launching stream (capture-safe: nothing is allocated). */
+int relnet_gemm_set_workspace(void* ws, long bytes);
+void relnet_gemm_debug_splitk(int k);     /* tuning knob: 0 = auto, 1 = never split, k >= 2 = k ways wherever configuration 23 runs */
 int relnet_gemm_pick_tile(int M, int N, int K, int batch, int out_dtype);   /* the configuration `auto` selects */
 
 /* ---- mx.symbol.Convolution + BatchNorm(use_global_stats) + Activation of

@@ -37,6 +37,12 @@ struct GemmArgs {
   const void* mask;        // relu == 3 (relnet_gemm_nt_mask, MASK instantiations of gemm_nt_bf16_kernel only): C = (A W^T + resid) where mask > 0, else 0;
                            // same layout / dtype as C (bf16).  The backward of `x_next = relu(conv(..) + x)`: the shortcut gradient rides as
                            // `resid`, the saved forward activation as `mask` -- one launch instead of GEMM + relnet_relu_bwd
+  // split-K (gemm_nt_bf16_kernel, batch 1, n_loop 1): blockIdx.z = which of `ksplit` contiguous runs of k-slabs this workgroup multiplies.
+  // Every workgroup leaves its fp32 partial tile in kpart [ksplit][M][N]; the LAST one to arrive at a tile (kcnt, one counter per tile,
+  // left at zero again) sums the partials in split order -- the result does not depend on the arrival order -- and runs the epilogue.
+  int ksplit;
+  float* kpart;
+  unsigned int* kcnt;
 };
 
 template <typename TOUT> __device__ __forceinline__ void store_out(TOUT* p, float v);
@@ -176,10 +182,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
     by = t / gx; bx = t - by * gx;
   }
   const int m0 = by * BM;
-  const unsigned short* A = (const unsigned short*)g.A + (long)blockIdx.z * g.strideA;
-  const unsigned short* W = (const unsigned short*)g.W + (long)blockIdx.z * g.strideW;
-  TOUT* C = (TOUT*)g.C + (long)blockIdx.z * g.strideC;
-  const TOUT* R = g.resid ? (const TOUT*)g.resid + (long)blockIdx.z * g.strideC : nullptr;
+  const bool splitk = g.ksplit > 1;
+  const int zb = splitk ? 0 : blockIdx.z, ks = splitk ? (int)blockIdx.z : 0;
+  const unsigned short* A = (const unsigned short*)g.A + (long)zb * g.strideA;
+  const unsigned short* W = (const unsigned short*)g.W + (long)zb * g.strideW;
+  TOUT* C = (TOUT*)g.C + (long)zb * g.strideC;
+  const TOUT* R = g.resid ? (const TOUT*)g.resid + (long)zb * g.strideC : nullptr;
 
   // LDS-direct staging (global_load_lds, 16 B per lane): one instruction fills 8 rows x 128 B,
   // lane l -> LDS (row l>>3, slot l&7).  The bank-conflict swizzle slot = chunk ^ (row & 7) is
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
   // the main loop; fetched inside the epilogue it serialises one HBM round trip per copy pass,
   // which made the residual-add 1x1 convolutions run at 1.8-2.5 TB/s.
   uint4 rpre[TM][NP];
-  if (R && vec_ok) {
+  if (R && vec_ok && !splitk) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -294,13 +302,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
 
   // KU k-slabs per barrier: with less than one workgroup per CU (the 1-image step) a k-step costs one L2 round trip whatever it
   // carries, so two slabs per step halve the k-loop (res4 3x3 at 2 394 pixels: 36 round trips -> 18)
-  const int nk = g.K / BK;
+  int kbeg = 0, nk = g.K / BK;
+  if (splitk) {                                      // this workgroup's run of k-slabs: the first (nk % ksplit) runs are one slab longer
+    const int base = nk / g.ksplit, rem = nk - base * g.ksplit;
+    kbeg = ks * base + (ks < rem ? ks : rem);
+    nk = kbeg + base + (ks < rem ? 1 : 0);
+  }
 #pragma unroll
   for (int h = 0; h < KU; ++h)
-    if (h < nk) stage(h, h);
+    if (kbeg + h < nk) stage(kbeg + h, h);
   __syncthreads();                                   // (drains the LDS-direct loads: vmcnt(0))
-  for (int kt0 = 0; kt0 < nk; kt0 += KU) {
-    const int sb = (kt0 / KU) & 1;
+  for (int kt0 = kbeg; kt0 < nk; kt0 += KU) {
+    const int sb = ((kt0 - kbeg) / KU) & 1;
 #pragma unroll
     for (int h = 0; h < KU; ++h)
       if (kt0 + KU + h < nk) stage(kt0 + KU + h, (sb ^ 1) * KU + h);      // async: lands while this stage is multiplied
@@ -373,6 +386,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
         const float4 x = *(const float4*)(ct + brow_i * CLD + tcol + 4 * q);
         v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
       }
+      if (splitk) {                                    // fp32 partial tile (N % VEC == 0 is a launch condition)
+        // device-coherent (sc1, write-through) stores: the eight L2s of the chip are not coherent with each other, and a release FENCE
+        // here would write back and invalidate the whole L2 of this XCD (measured: +20 us per launch and split)
+        unsigned long long* pp = (unsigned long long*)(g.kpart + ((long)ks * g.M + m) * g.N + n);
+#pragma unroll
+        for (int q = 0; q < VEC / 2; ++q)
+          __hip_atomic_store(pp + q, ((unsigned long long)__float_as_uint(v[2 * q + 1]) << 32) | __float_as_uint(v[2 * q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+      }
       const float brow = (g.bias_mode == 2) ? g.bias[m] : 0.f;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) v[e] += bv[e] + brow;
@@ -420,6 +442,59 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_bf16_kernel(GemmArgs g) 
           }
         }
       }
+    }
+  }
+  if (splitk) {
+    // ---- split-K fix-up: the partial tile is complete in memory (sc1 stores + vmcnt(0)), count in, and let the last arriver finish the tile ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned int* flag = (unsigned int*)lds;           // (the epilogue band is dead after the barrier)
+    if (tid == 0) {
+      unsigned int* cnt = g.kcnt + (by * gridDim.x + bx);
+      const unsigned int old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool last = old == (unsigned)(g.ksplit - 1);
+      if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (nobody else touches this counter any more)
+      *flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*flag == 0u) return;
+    constexpr int ITEMS = BM * BN / 4;                 // float4 items of the tile
+    const long plane = (long)g.M * g.N;
+    for (int it = tid; it < ITEMS; it += NT) {
+      const int r = it / (BN / 4), cq = it - r * (BN / 4);
+      const int m = m0 + r, nn = n0 + 4 * cq;
+      if (m >= g.M || nn >= g.N) continue;
+      const unsigned long long* pp = (const unsigned long long*)(g.kpart + (long)m * g.N + nn);
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      // device-coherent loads (they bypass this XCD's L2), ALL requested before the first is used (one memory round trip per item instead of
+      // one per split), summed in split order
+      unsigned long long lo[8], hi[8];
+#pragma unroll
+      for (int sp = 0; sp < 8; ++sp) {
+        lo[sp] = hi[sp] = 0ull;                        // (+0.0f)
+        if (sp < g.ksplit) {
+          lo[sp] = __hip_atomic_load(pp + sp * (plane / 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          hi[sp] = __hip_atomic_load(pp + sp * (plane / 2) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+#pragma unroll
+      for (int sp = 0; sp < 8; ++sp) {
+        v[0] += __uint_as_float((unsigned)lo[sp]); v[1] += __uint_as_float((unsigned)(lo[sp] >> 32));
+        v[2] += __uint_as_float((unsigned)hi[sp]); v[3] += __uint_as_float((unsigned)(hi[sp] >> 32));
+      }
+      const float brow = (g.bias_mode == 2) ? g.bias[m] : 0.f;
+      TOUT* cp = C + (long)m * g.ldc + nn;
+      const TOUT* rp = R ? R + (long)m * g.ldc + nn : nullptr;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = v[e] + brow + (g.bias_mode == 1 ? g.bias[nn + e] : 0.f);
+        if (rp) x = res_apply(x, load_out<TOUT>(rp + e), g.relu);
+        if (g.relu == 1) x = fmaxf(x, 0.f);
+        if constexpr (MASK) x = load_out<TOUT>((const TOUT*)g.mask + (long)m * g.ldc + nn + e) > 0.f ? x : 0.f;
+        v[e] = x;
+      }
+      if constexpr (sizeof(TOUT) == 2) *(uint2*)cp = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      else *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
   }   // nt (row-panel loop)
@@ -2015,9 +2090,71 @@ extern "C" void relnet_gemm_debug_phase_ts(void* buf) { g_phase_ts = (long long*
 static int g_asm = 1;            // tuning knob: 0 = pick_tile never chooses tiles 18 / 19 (hand-scheduled k-loops)
 extern "C" void relnet_gemm_debug_asm(int on) { g_asm = on; }
 
+// ---- split-K work area (relnet_gemm_set_workspace): kSkSlots equal slots, each = 16 KB of tile counters (zero between launches) + fp32 partial
+// tiles.  Launches on one stream are ordered, so a stream owns one slot for the life of the process (first come, first served; a fifth
+// stream simply runs without split-K); under hipGraph capture the capturing streams are the owners, and the captured dependencies keep the
+// launches of one slot ordered at replay.
+constexpr int kSkSlots = 4;
+constexpr long kSkCounterBytes = 16384;
+struct SplitKArea { unsigned char* base = nullptr; long bytes = 0; hipStream_t owner[kSkSlots] = {}; int owners = 0; };
+static SplitKArea g_sk[64];
+static int g_splitk = 0;         // tuning knob: 0 auto, 1 = never split, k >= 2 = split by k wherever the split-K tile is chosen
+extern "C" void relnet_gemm_debug_splitk(int k) { g_splitk = k; }
+extern "C" int relnet_gemm_set_workspace(void* ws, long bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  RELNET_REQUIRE(ws == nullptr || (bytes >= kSkSlots * (kSkCounterBytes + (1L << 20)) && (((uintptr_t)ws) & 255) == 0),
+                 "relnet_gemm_set_workspace: need a 256-byte aligned area of at least %ld bytes", kSkSlots * (kSkCounterBytes + (1L << 20)));
+  SplitKArea& a = g_sk[dev & 63];
+  a.base = (unsigned char*)ws; a.bytes = ws ? bytes : 0; a.owners = 0;
+  return 0;
+}
+// the slot of stream `s` with room for `need` bytes of partial tiles and `tiles` counters, or false
+static bool splitk_slot(hipStream_t s, long need, long tiles, float** part, unsigned int** cnt) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  SplitKArea& a = g_sk[dev & 63];
+  if (!a.base) return false;
+  const long slot = (a.bytes / kSkSlots) & ~255L;
+  if (tiles * 4 > kSkCounterBytes || need > slot - kSkCounterBytes) return false;
+  int i = 0;
+  while (i < a.owners && a.owner[i] != s) ++i;
+  if (i == a.owners) {
+    if (a.owners == kSkSlots) return false;
+    a.owner[a.owners++] = s;
+  }
+  *cnt = (unsigned int*)(a.base + i * slot);
+  *part = (float*)(a.base + i * slot + kSkCounterBytes);
+  return true;
+}
+// how many ways the k-loop of a 64 x 64-tiled launch is split: only launches of at most one workgroup per CU (every k-step of such a launch is an
+// exposed L2 round trip, so the k-loop length IS the launch time), enough to put ~2 workgroups on every CU, at least 4 k-slabs per workgroup
+static int splitk_ways(long M, long N, long K, int batch, const GemmArgs& g) {
+  if (g_splitk == 1 || batch != 1 || (N & 7) || (g.ldc & 7) || g.mask || ((((uintptr_t)g.C) | ((uintptr_t)g.resid)) & 15)) return 1;
+  const long tiles = ((M + 63) / 64) * ((N + 63) / 64), nk = K / 64;
+  if (g_splitk >= 2) return (int)(nk / g_splitk >= 1 ? (g_splitk > 8 ? 8 : g_splitk) : 1);
+  // Measured on the one-image shapes (tools/splitk_probe.py, profiles/r06_notes/splitk_one_image.txt): the partial tiles cross XCDs, i.e. they travel
+  // through memory (sc1 stores, L2-bypassing loads), which costs the last arriver ~8 us -- as much as 4 - 5 k-steps.  The split pays only for the
+  // long k-loops: fc_new_1 (196 k-slabs, 80 tiles: 60.8 -> 36.7 us at 4 ways) and rpn_conv_3x3 (144 k-slabs, 304 tiles: 101 -> 79 us at 3 ways);
+  // res4 3x3 (36 k-slabs) stays at 21 us either way, res5 3x3 (72) at 52 us.
+  if (tiles > 320 || nk < 128) return 1;
+  return tiles <= 128 ? 4 : 3;
+}
+
 template <int BM, int BN, int WM, int WN, int CONV, int KU = 1>
-static void launch_cfg(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
+static void launch_cfg(GemmArgs g, int batch, int out_dtype, hipStream_t s, int ksplit = 1) {
   const int ntile = (g.N + BN - 1) / BN;
+  if (ksplit > 1) {
+    const long tiles = (long)ntile * ((g.M + BM - 1) / BM);
+    if (batch == 1 && splitk_slot(s, (long)ksplit * g.M * g.N * 4, tiles, &g.kpart, &g.kcnt)) {
+      g.ksplit = ksplit; g.n_loop = 1;
+      dim3 grid(ntile, (g.M + BM - 1) / BM, ksplit);
+      g.xcd_swizzle = (g_swizzle && ntile > 1 && tiles >= 16) ? 1 : 0;
+      if (out_dtype == RELNET_BF16) gemm_nt_bf16_kernel<BM, BN, WM, WN, unsigned short, CONV, KU><<<grid, 64 * WM * WN, 0, s>>>(g);
+      else gemm_nt_bf16_kernel<BM, BN, WM, WN, float, CONV, KU><<<grid, 64 * WM * WN, 0, s>>>(g);
+      return;
+    }
+  }
   int nloop = g_force_nloop > 0 ? g_force_nloop : g.n_loop;
   const bool swz = g_swizzle && batch == 1 && ntile > 1 && (long)ntile * ((g.M + BM - 1) / BM) >= 16;
   // with the XCD-aware order the column tiles of a row panel run side by side on one XCD and share the A rows through
@@ -2118,7 +2255,9 @@ static void launch_ring(GemmArgs g, int batch, int out_dtype, hipStream_t s) {
 //                                   19 = 18 with the asymmetric ring (activations three slots / two slabs ahead, filters two slots)
 //                                   20 = 5 with two k-slabs per barrier (launches of less than one workgroup per CU: the 1-image step)
 //                                   21 = 5 with four
-enum { GEMM_TILE_COUNT = 22 };
+//                                   22 = 192x128 (see launch_bf16)
+//                                   23 = 20 with the k-loop SPLIT over several workgroups per tile (round 6; needs relnet_gemm_set_workspace, else = 20)
+enum { GEMM_TILE_COUNT = 23 };
 
 template <int CONV>
 static bool launch_panel(const GemmArgs& g0, int batch, int out_dtype, hipStream_t s, bool use_wf = false, bool occ2 = false) {
@@ -2236,7 +2375,10 @@ extern "C" int relnet_gemm_pick_tile(int M, int N, int K, int batch, int out_dty
 template <int CONV>
 static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t s) {
   int cfg = g_force_tile;
-  if (cfg <= 0 || cfg > GEMM_TILE_COUNT) cfg = pick_tile(g.M, g.N, g.K, batch, out_dtype, g.resid != nullptr, CONV == 1 && g.Wf != nullptr);
+  if (cfg <= 0 || cfg > GEMM_TILE_COUNT) {
+    cfg = pick_tile(g.M, g.N, g.K, batch, out_dtype, g.resid != nullptr, CONV == 1 && g.Wf != nullptr);
+    if ((cfg == 5 || cfg == 20 || cfg == 21) && CONV != 2 && splitk_ways(g.M, g.N, g.K, batch, g) > 1) cfg = 23;
+  }
   switch (cfg) {
     case 1: launch_cfg<256, 256, 2, 4, CONV>(g, batch, out_dtype, s); break;
     case 2: launch_cfg<256, 128, 4, 2, CONV>(g, batch, out_dtype, s); break;
@@ -2250,6 +2392,19 @@ static void launch_bf16(const GemmArgs& g, int batch, int out_dtype, hipStream_t
     case 21:
       if constexpr (CONV == 2) launch_cfg<64, 64, 2, 2, CONV>(g, batch, out_dtype, s);
       else launch_cfg<64, 64, 2, 2, CONV, 4>(g, batch, out_dtype, s);
+      break;
+    // 23 (r06): split-K for the launches of at most one 64 x 64 workgroup per CU -- the one-image step (the reference's BATCH_IMAGES: 1
+    // protocol, inference and training): res4 3x3 = 152 tiles x 36 k-slabs, fc_new_1 = 80 tiles x 196 k-slabs.  With one resident workgroup per
+    // CU a k-step is one exposed L2 round trip whatever it carries (tiles 20 / 21 cut the steps by carrying 2 / 4 slabs); splitting the k-loop
+    // over 2 - 8 workgroups per tile cuts the steps AND fills the idle CUs.  Partials in fp32 through the work area, summed in split order by
+    // the last arriver, which also runs the bias / shortcut / ReLU epilogue: one launch, deterministic.
+    case 23:
+      if constexpr (CONV == 2) launch_cfg<64, 64, 2, 2, CONV>(g, batch, out_dtype, s);
+      else {
+        int ways = splitk_ways(g.M, g.N, g.K, batch, g);
+        if (cfg == g_force_tile && ways == 1 && g_splitk != 1 && batch == 1 && !(g.N & 7) && !(g.ldc & 7) && g.K >= 128 && !((((uintptr_t)g.C) | ((uintptr_t)g.resid)) & 15)) ways = 2;   // forced tile (tests): always split
+        launch_cfg<64, 64, 2, 2, CONV, 2>(g, batch, out_dtype, s, ways);
+      }
       break;
     // 22 (r05): 192 x 128 (2 x 2 waves, 96 x 64 outputs each) for the 128-column 3x3 layers of res3: one column tile, so a taller tile only cuts
     // the filter re-reads (fill bytes per output -17 % against 128 x 128).  us per launch, tile 3 / 22: 54 images 215.8 / 200.7, 8 images 47.8 / 40.3

@@ -111,6 +111,8 @@ _SIGNATURES = {
     'relnet_gemm_debug_ablate': (None, [_i]),
     'relnet_chain_debug': (None, [_i]),
     'relnet_gemm_tile_count': (C.c_int, []),
+    'relnet_gemm_set_workspace': (C.c_int, [_vp, _l]),
+    'relnet_gemm_debug_splitk': (None, [_i]),
     'relnet_gemm_pick_tile': (C.c_int, [_i, _i, _i, _i, _i]),
     'relnet_nms_greedy': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     'relnet_stem_bias_relu_pool': (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -167,14 +169,14 @@ def load():
         fn.argtypes = args
     # A/B knobs for whole-step measurements without editing code.  They change which kernels run, so they are honoured only
     # together with RELNET_DEBUG_KNOBS=1 and every use is announced on stderr (a forced tile is a measured-slower configuration)
-    knobs = [(k, os.environ[k]) for k in ('RELNET_GEMM_KORDER', 'RELNET_GEMM_FORCE_TILE', 'RELNET_GEMM_ASM') if os.environ.get(k)]
+    knobs = [(k, os.environ[k]) for k in ('RELNET_GEMM_KORDER', 'RELNET_GEMM_FORCE_TILE', 'RELNET_GEMM_ASM', 'RELNET_GEMM_SPLITK') if os.environ.get(k)]
     if knobs and os.environ.get('RELNET_DEBUG_KNOBS') != '1':
         sys.stderr.write('relnet: ignoring %s (set RELNET_DEBUG_KNOBS=1 to apply kernel-selection knobs)\n' % ', '.join(k for k, _ in knobs))
     elif knobs:
         sys.stderr.write('relnet: DEBUG kernel-selection knobs in effect: %s\n' % ', '.join('%s=%s' % kv for kv in knobs))
         for k, v in knobs:
             {'RELNET_GEMM_KORDER': lib.relnet_gemm_debug_korder, 'RELNET_GEMM_FORCE_TILE': lib.relnet_gemm_force_tile,
-             'RELNET_GEMM_ASM': lib.relnet_gemm_debug_asm}[k](int(v))
+             'RELNET_GEMM_ASM': lib.relnet_gemm_debug_asm, 'RELNET_GEMM_SPLITK': lib.relnet_gemm_debug_splitk}[k](int(v))
     _lib = lib
     return lib
 

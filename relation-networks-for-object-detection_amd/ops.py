@@ -39,6 +39,22 @@ def pad32(m):
     return (m + 31) // 32 * 32
 
 
+_GEMM_WS = {}
+
+
+def gemm_workspace():
+    """The split-K work area of the GEMM / convolution kernels (relnet_gemm_set_workspace, tile configuration 23): one zeroed
+    160 MB allocation per device, made on the first eager GEMM of the process (never inside a hipGraph capture) and kept for its
+    life.  The library only splits launches of at most one 64 x 64 workgroup per CU -- the one-image step."""
+    dev = torch.cuda.current_device()
+    if dev not in _GEMM_WS and not torch.cuda.is_current_stream_capturing():
+        ws = torch.zeros(4 * (16384 + (40 << 20)), device='cuda:%d' % dev, dtype=torch.uint8)
+        torch.cuda.synchronize(dev)
+        _lib.call('relnet_gemm_set_workspace', ws.data_ptr(), ws.numel())
+        _GEMM_WS[dev] = ws
+    return _GEMM_WS.get(dev)
+
+
 def gemm_nt(a, w, bias=None, bias_mode=1, resid=None, relu=False, out=None, out_dtype=None,
             n_cols=None):
     """out = a @ w^T (+bias) (+resid) (relu).  a [M,K] or [batch,M,K] (a 2-D `a` with a
@@ -64,6 +80,7 @@ def gemm_nt(a, w, bias=None, bias_mode=1, resid=None, relu=False, out=None, out_
     sc = out.stride(0) if out.dim() == 3 else 0
     if resid is not None:
         assert resid.dtype == out.dtype and resid.stride() == out.stride()
+    gemm_workspace()
     _lib.call('relnet_gemm_nt', a.data_ptr(), a.stride(-2), sa, w.data_ptr(), w.stride(-2), sw,
               out.data_ptr(), out.stride(-2), sc, _ptr(bias), bias_mode if bias is not None else 0,
               _ptr(resid), int(relu), M, N, K, batch, _dt(a), _dt(out), _stream(),
@@ -582,6 +599,7 @@ def conv2d_nhwc(x, w_packed, bias, ksize=1, stride=1, pad=0, dil=1, relu=False, 
     assert out.stride(1) == Wout * out.stride(2) and out.stride(0) == Hout * out.stride(1)
     if resid is not None:
         assert resid.dtype == out.dtype and resid.stride() == out.stride()
+    gemm_workspace()
     _lib.call('relnet_conv2d_nhwc_wf', x.data_ptr(), x.stride(2), x.stride(0), w_packed.data_ptr(), _ptr(w_frag), _ptr(bias),
               _ptr(resid), int(relu), out.data_ptr(), out.stride(2), B, H, W, Cin, Cout, ksize, ksize,
               stride, dil, pad, _dt(out), _stream(),

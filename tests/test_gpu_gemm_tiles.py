@@ -204,3 +204,72 @@ def test_gemm_nt_f16_matches_float64(tile):
              torch.cuda.current_stream().cuda_stream)
     err = (out.cpu().double() - want).abs().max().item() / want.abs().max().item()
     assert err <= 2e-5, err               # fp16 products are exact in fp32; only the fp32 accumulation order differs
+
+
+def test_split_k_tile_on_the_one_image_shapes(rn):
+    """Tile configuration 23 (round 6): the k-loop of a launch of <= 1 workgroup per CU split over 2..8 workgroups per tile, fp32 partials
+    summed in split order by the last arriver.  On the one-image shapes pick_tile's rule chooses it by itself (res4 3x3: 152 tiles x 36
+    k-slabs, fc_new_1: 80 tiles x 196 k-slabs, res5 3x3 dilated, rpn_out with a ragged N): against float64 from the definition; the result
+    must not depend on the arrival order (bit-identical over repeated launches, which also shows the tile counters return to zero), and two
+    streams launching at the same time use different slots of the work area."""
+    ops, L = rn
+    _set(L, 0, 1, 0)
+    g = torch.Generator().manual_seed(23)
+    rng = np.random.default_rng(23)
+    assert ops.gemm_workspace() is not None
+    # fc_new_1 at one image (300 rois) and its ways: auto (6), forced 2 .. 8, off
+    M, N, K = 300, 1024, 12544
+    a = torch.randn(M, K, generator=g).cuda().to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda().to(torch.bfloat16)
+    b = torch.randn(N, generator=g).cuda()
+    want64 = np.maximum(a.double().cpu().numpy() @ w.double().cpu().numpy().T + b.double().cpu().numpy(), 0)
+    outs = {}
+    for ways in (0, 2, 3, 5, 8, 1):
+        L.relnet_gemm_debug_splitk(ways)
+        for odt, tol in ((torch.bfloat16, 1e-2), (torch.float32, 2e-5 * K ** 0.5)):
+            got = [ops.gemm_nt(a, w, b, relu=True, out_dtype=odt) for _ in range(3)]
+            assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2]), ('not deterministic', ways, odt)
+            err = np.abs(got[0].double().cpu().numpy() - want64).max() / np.abs(want64).max()
+            assert err < tol, (ways, odt, err)
+            outs[(ways, odt)] = got[0]
+    L.relnet_gemm_debug_splitk(0)
+    # (the split changes the fp32 summation order only: bf16 outputs of the split and unsplit launches agree to an ulp of bf16)
+    d = (outs[(0, torch.bfloat16)].float() - outs[(1, torch.bfloat16)].float()).abs().max().item()
+    assert d <= 2 ** -7 * outs[(1, torch.bfloat16)].float().abs().max().item()
+    # convolutions of the one-image step, with shortcut / ReLU epilogues run by the last arriver
+    for (hw, cin, cout, k, dil, extras) in (((38, 63), 256, 256, 3, 1, 'relu'), ((38, 63), 512, 512, 3, 2, 'relu'),
+                                           ((38, 63), 1024, 256, 1, 1, 'resid+relu'), ((38, 63), 512, 72, 1, 1, '')):
+        x = torch.randn(1, hw[0], hw[1], cin, generator=g).cuda().to(torch.bfloat16)
+        wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(torch.bfloat16)
+        wp = wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda()
+        bias = torch.randn(cout, generator=g).cuda()
+        Mo = hw[0] * hw[1]
+        rows = _sample_rows(Mo, rng, 32)
+        w64 = _conv_rows64(x, wt.cuda(), bias, rows, hw[0], hw[1], 1, dil * (k // 2), dil)
+        for odt, tol in ((torch.bfloat16, 1e-2), (torch.float32, 3e-5 * (cin * k * k) ** 0.5)):
+            res = torch.randn(1, hw[0], hw[1], cout, generator=g).cuda().to(odt) if 'resid' in extras else None
+            want = w64 + (res.view(-1, cout)[torch.as_tensor(rows).cuda()].double().cpu().numpy() if res is not None else 0)
+            if 'relu' in extras:
+                want = np.maximum(want, 0)
+            runs = []
+            for ways in (0, 1):
+                L.relnet_gemm_debug_splitk(ways)
+                runs.append(ops.conv2d_nhwc(x, wp, bias, ksize=k, pad=dil * (k // 2), dil=dil, relu='relu' in extras, resid=res, out_dtype=odt))
+            L.relnet_gemm_debug_splitk(0)
+            again = ops.conv2d_nhwc(x, wp, bias, ksize=k, pad=dil * (k // 2), dil=dil, relu='relu' in extras, resid=res, out_dtype=odt)
+            assert torch.equal(runs[0], again)
+            for r_ in runs:
+                sub = r_.view(-1, cout)[torch.as_tensor(rows).cuda()].double().cpu().numpy()
+                assert np.abs(sub - want).max() / np.abs(want).max() < tol, (cin, cout, k, odt)
+            full = (runs[0].float() - runs[1].float()).abs().max().item() / runs[1].float().abs().max().item()
+            assert full < (1e-2 if odt == torch.bfloat16 else 1e-5), full
+    # two streams at once: each owns a slot, results equal the single-stream ones
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(4):
+        with torch.cuda.stream(s1):
+            o1 = ops.gemm_nt(a, w, b, relu=True, out_dtype=torch.bfloat16)
+        with torch.cuda.stream(s2):
+            o2 = ops.gemm_nt(a, w, b, relu=True, out_dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, outs[(0, torch.bfloat16)]) and torch.equal(o2, outs[(0, torch.bfloat16)])
