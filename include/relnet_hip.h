@@ -23,6 +23,8 @@ enum { RELNET_F32 = 0, RELNET_BF16 = 1 };
 
 int relnet_version(void);                 /* 100 = 0.1.0 */
 const char* relnet_last_error(void);
+/* 0 when `stream` is not being captured into a hipGraph, else the id of the capture sequence (hipStreamGetCaptureInfo) */
+unsigned long long relnet_stream_capture_id(void* stream);
 
 /* ---- lib/nms/gpu_nms.hpp:1-2 (the reference's own C prototype, bound by gpu_nms.pyx:15-16) -----
  * HOST pointers.  boxes_host: boxes_num rows [x1,y1,x2,y2,score] pre-sorted by score (descending);
@@ -103,12 +105,15 @@ void relnet_gemm_debug_phase_ts(void* buf); /* measurement knob: the ring kernel
 void relnet_gemm_debug_ablate(int a);     /* measurement knob for tile 8: 1 = fill path only, 2 = LDS + MFMA only (garbage results) */
 void relnet_chain_debug(int flags);        /* measurement knob for chain256_roles_kernel (garbage results while non-zero): 1 = half of the weight loads, 2 = none, 4 = no shortcut-slice loads, 8 = no global stores */
 int relnet_gemm_tile_count(void);         /* number of tile configurations (valid relnet_gemm_force_tile values 1..count) */
-/* Work area of the split-K tile (configuration 23, round 6: launches of at most one 64 x 64 workgroup per CU -- the one-image step of
- * core/tester.py:219-295 / train_end2end.py with BATCH_IMAGES: 1 -- split their k-loop over 2..8 workgroups per tile; fp32 partial tiles and
- * per-tile arrival counters live here).  `ws`: device memory, 256-byte aligned, ZERO-initialised by the caller, owned by the caller, registered per
- * device; NULL unregisters.  Without a work area no launch is split.  Four equal slots, one per launching stream (capture-safe: nothing is allocated). */
+/* Work area of the split-K tile (configuration 23, round 6: launches of at most one 64 x 64 workgroup per CU with a long k-loop -- fc_new_1 and
+ * rpn_conv_3x3 of the one-image step of core/tester.py:219-295 / train_end2end.py with BATCH_IMAGES: 1 -- split their k-loop over 3..4 workgroups per
+ * tile; fp32 partial tiles and per-tile arrival counters live here).  `ws`: device memory owned by the caller, 256-byte aligned, its first 16 KB
+ * ZERO when first handed over (the kernels leave them zero); NULL = none.  The pointer is remembered per HOST THREAD and used by the GEMM /
+ * convolution entry points called after it; launches that share an area must be ordered with respect to each other (same stream, or the
+ * dependencies of one captured graph): a caller that launches on several streams keeps one area per stream and names it before each call.
+ * Without an area no launch is split.  Nothing is allocated by the library (capture-safe). */
 int relnet_gemm_set_workspace(void* ws, long bytes);
-void relnet_gemm_debug_splitk(int k);     /* tuning knob: 0 = auto, 1 = never split, k >= 2 = k ways wherever configuration 23 runs */
+void relnet_gemm_debug_splitk(int k);     /* tuning knob: 0 = auto (launches of <= 128 tiles with >= 128 k-slabs), 1 = never split, k >= 2 = k ways wherever configuration 23 runs, -2 = auto incl. 129..320-tile launches */
 int relnet_gemm_pick_tile(int M, int N, int K, int batch, int out_dtype);   /* the configuration `auto` selects */
 
 /* ---- mx.symbol.Convolution + BatchNorm(use_global_stats) + Activation of
@@ -467,6 +472,28 @@ int relnet_relation_bwd_pack(const float* dq, const float* dk, const float* dvw,
  * d_prob[b][rank_idx[b][c][f]][c] += d_sorted[b][f][c]; d_prob [B][N][C] fp32 zeroed by the caller, rank_idx [B][C][F] int32
  * (negative = padding, skipped), d_sorted [B][F][C].                                                                               */
 int relnet_lnms_scatter_bwd(const float* d_sorted, const int* rank_idx, float* d_prob, int B, int N, int C, int F, void* stream);
+
+/* ---- element-wise chains of the learn-NMS head's train branch and of its adjoint as single kernels (csrc/lnms_train.hip, round 6) --------
+ * The reference spells them as chains of small operators (symbols/resnet_v1_101_rcnn_learn_nms_1024_attention_1024_pairwise_position_multi_head_16.py):
+ *   pad_params     nms_linear_out_1 [128,128] bf16 / bias [128] and nms_logit [T,128] bf16 / bias [T] into the zero-padded operands of the 64-wide
+ *                  tiles (wout_pad [1024,128]: row 64 h + j <- row 8 h + j; wl_pad [64,128]); the pad rows are the caller's zeros and stay untouched
+ *   residual_relu  :489-491  out [rows,128] = relu(x [rows,128] + att [rows,1024][:, 64 h + j], j < 8)   (bf16; the sum is rounded before the ReLU)
+ *   cond_multi     :497-505  cond [B,F,C,T] = sigmoid(logit [(b C + c) F + f][t]) (row stride ld), multi = sorted_score [B,F,C] x cond
+ *   cond_bwd       adjoint of cond_multi: d_sorted [B,F,C] = sum_t d_multi cond, d_logit bf16 [(b C + c) F + f][64] = d_multi score cond (1 - cond), 0 beyond T (T <= 8)
+ *   take_bwd       :447-452  d_emb fp32 [B N,128] (zeroed by the caller) += rows of d_x bf16 [B,C,F,128] at rank_idx [B,C,F] (negative = skipped)
+ *   softmax_bwd    :430-433  prob = softmax(cls_score)[:, 1:]: d_cls[b][n][0] += -(1 - sum prob) inner, d_cls[b][n][1 + c] += prob_c (d_prob_c - inner),
+ *                  inner = sum_c prob_c d_prob_c; d_cls rows ld_row apart, images ld_img apart (ACCUMULATES into the detector's own cls_score gradient) */
+/* out[0] = scale * sum(x[0..n))  (mode 0)  or  the count of entries >= 0 (mode 1): the scalar metrics of a training step (the MakeLoss outputs the
+ * reference's metric classes sum per image, core/metric.py; the OHEM keep count) -- one single-workgroup, deterministic launch each */
+int relnet_reduce_scalar(const float* x, long n, float scale, int mode, float* out, void* stream);
+int relnet_lnms_pad_params(const void* wo, const float* bo, const void* wl, const float* bl, void* wout_pad, float* bout_pad, void* wl_pad,
+                           float* bl_pad, int T, void* stream);
+int relnet_lnms_residual_relu(const void* att, const void* x, void* out, long rows, void* stream);
+int relnet_lnms_cond_multi(const float* logit, long ld, const float* sorted_score, float* cond, float* multi, int B, int C, int F, int T, void* stream);
+int relnet_lnms_cond_bwd(const float* d_multi, const float* cond, const float* sorted_score, float* d_sorted, void* d_logit, int B, int C, int F, int T,
+                         void* stream);
+int relnet_lnms_take_bwd(const void* d_x, const int* rank_idx, float* d_emb, int B, int N, int C, int F, void* stream);
+int relnet_lnms_softmax_bwd(const float* prob, const float* d_prob, float* d_cls, long ld_row, long ld_img, int B, int N, int C, void* stream);
 
 /* q [B][N][..], k [B][M][..] as in the forward; kt = K^T [B][H*64][>=Mpad] and qt = Q^T, dyt = dY^T
  * [B][H*64][>=Npad] zero padded; vw = F_K Wout^T [B][M][H*64] (not transposed); bias = fp32 log G of the forward;

@@ -2090,41 +2090,25 @@ extern "C" void relnet_gemm_debug_phase_ts(void* buf) { g_phase_ts = (long long*
 static int g_asm = 1;            // tuning knob: 0 = pick_tile never chooses tiles 18 / 19 (hand-scheduled k-loops)
 extern "C" void relnet_gemm_debug_asm(int on) { g_asm = on; }
 
-// ---- split-K work area (relnet_gemm_set_workspace): kSkSlots equal slots, each = 16 KB of tile counters (zero between launches) + fp32 partial
-// tiles.  Launches on one stream are ordered, so a stream owns one slot for the life of the process (first come, first served; a fifth
-// stream simply runs without split-K); under hipGraph capture the capturing streams are the owners, and the captured dependencies keep the
-// launches of one slot ordered at replay.
-constexpr int kSkSlots = 4;
+// ---- split-K work area (relnet_gemm_set_workspace): 16 KB of tile counters (zero between launches) + fp32 partial tiles.  The area is the CALLER's:
+// the launches that share one must be ordered (one stream, or the dependencies of one captured graph), so the host side (ops.py) keeps one area per
+// launching stream and names the current one before a GEMM call; the pointer is per host thread.  Nothing is allocated here (capture-safe).
 constexpr long kSkCounterBytes = 16384;
-struct SplitKArea { unsigned char* base = nullptr; long bytes = 0; hipStream_t owner[kSkSlots] = {}; int owners = 0; };
-static SplitKArea g_sk[64];
-static int g_splitk = 0;         // tuning knob: 0 auto, 1 = never split, k >= 2 = split by k wherever the split-K tile is chosen
+struct SplitKArea { unsigned char* base = nullptr; long bytes = 0; };
+static thread_local SplitKArea t_sk;
+static int g_splitk = 0;         // tuning knob: 0 auto, 1 = never split, k >= 2 = split by k wherever the split-K tile is chosen, -2 = auto incl. the 129..320-tile launches
 extern "C" void relnet_gemm_debug_splitk(int k) { g_splitk = k; }
 extern "C" int relnet_gemm_set_workspace(void* ws, long bytes) {
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  RELNET_REQUIRE(ws == nullptr || (bytes >= kSkSlots * (kSkCounterBytes + (1L << 20)) && (((uintptr_t)ws) & 255) == 0),
-                 "relnet_gemm_set_workspace: need a 256-byte aligned area of at least %ld bytes", kSkSlots * (kSkCounterBytes + (1L << 20)));
-  SplitKArea& a = g_sk[dev & 63];
-  a.base = (unsigned char*)ws; a.bytes = ws ? bytes : 0; a.owners = 0;
+  RELNET_REQUIRE(ws == nullptr || (bytes >= kSkCounterBytes + (1L << 20) && (((uintptr_t)ws) & 255) == 0),
+                 "relnet_gemm_set_workspace: need a 256-byte aligned area of at least %ld bytes", kSkCounterBytes + (1L << 20));
+  t_sk.base = (unsigned char*)ws; t_sk.bytes = ws ? bytes : 0;
   return 0;
 }
-// the slot of stream `s` with room for `need` bytes of partial tiles and `tiles` counters, or false
-static bool splitk_slot(hipStream_t s, long need, long tiles, float** part, unsigned int** cnt) {
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  SplitKArea& a = g_sk[dev & 63];
-  if (!a.base) return false;
-  const long slot = (a.bytes / kSkSlots) & ~255L;
-  if (tiles * 4 > kSkCounterBytes || need > slot - kSkCounterBytes) return false;
-  int i = 0;
-  while (i < a.owners && a.owner[i] != s) ++i;
-  if (i == a.owners) {
-    if (a.owners == kSkSlots) return false;
-    a.owner[a.owners++] = s;
-  }
-  *cnt = (unsigned int*)(a.base + i * slot);
-  *part = (float*)(a.base + i * slot + kSkCounterBytes);
+// room for `need` bytes of partial tiles and `tiles` counters in the current work area?
+static bool splitk_area(long need, long tiles, float** part, unsigned int** cnt) {
+  if (!t_sk.base || tiles * 4 > kSkCounterBytes || need > t_sk.bytes - kSkCounterBytes) return false;
+  *cnt = (unsigned int*)t_sk.base;
+  *part = (float*)(t_sk.base + kSkCounterBytes);
   return true;
 }
 // how many ways the k-loop of a 64 x 64-tiled launch is split: only launches of at most one workgroup per CU (every k-step of such a launch is an
@@ -2134,10 +2118,14 @@ static int splitk_ways(long M, long N, long K, int batch, const GemmArgs& g) {
   const long tiles = ((M + 63) / 64) * ((N + 63) / 64), nk = K / 64;
   if (g_splitk >= 2) return (int)(nk / g_splitk >= 1 ? (g_splitk > 8 ? 8 : g_splitk) : 1);
   // Measured on the one-image shapes (tools/splitk_probe.py, profiles/r06_notes/splitk_one_image.txt): the partial tiles cross XCDs, i.e. they travel
-  // through memory (sc1 stores, L2-bypassing loads), which costs the last arriver ~8 us -- as much as 4 - 5 k-steps.  The split pays only for the
-  // long k-loops: fc_new_1 (196 k-slabs, 80 tiles: 60.8 -> 36.7 us at 4 ways) and rpn_conv_3x3 (144 k-slabs, 304 tiles: 101 -> 79 us at 3 ways);
-  // res4 3x3 (36 k-slabs) stays at 21 us either way, res5 3x3 (72) at 52 us.
+  // through memory (sc1 stores, L2-bypassing loads), which costs the last arriver ~8 us -- as much as 4 - 5 k-steps.  In isolation the split pays only
+  // for the long k-loops: fc_new_1 (196 k-slabs, 80 tiles: 60.8 -> 34.7 us at 4 ways) and rpn_conv_3x3 (144 k-slabs, 304 tiles: 101 -> 78 us at 3 ways);
+  // res4 3x3 (36 k-slabs) stays at 21 us either way, res5 3x3 (72) at 52 us.  Inside the one-image step (same-box A/B, tools/scripts/r06_ab.sh,
+  // 2 000 replays each): unsplit 2.128 / 2.133 / 2.139 ms, fc_new_1 only 2.135 / 2.139 / 2.131 ms, both 2.192 / 2.202 / 2.167 ms -- the 912 workgroups
+  // of a split rpn_conv_3x3 on the side stream take CUs from res5 on the main one.  Default: the <= 128-tile launches only (neutral for inference,
+  // -0.04 ms on the one-image training step); g_splitk = -2 adds the <= 320-tile ones.
   if (tiles > 320 || nk < 128) return 1;
+  if (g_splitk != -2 && tiles > 128) return 1;
   return tiles <= 128 ? 4 : 3;
 }
 
@@ -2146,7 +2134,7 @@ static void launch_cfg(GemmArgs g, int batch, int out_dtype, hipStream_t s, int 
   const int ntile = (g.N + BN - 1) / BN;
   if (ksplit > 1) {
     const long tiles = (long)ntile * ((g.M + BM - 1) / BM);
-    if (batch == 1 && splitk_slot(s, (long)ksplit * g.M * g.N * 4, tiles, &g.kpart, &g.kcnt)) {
+    if (batch == 1 && splitk_area((long)ksplit * g.M * g.N * 4, tiles, &g.kpart, &g.kcnt)) {
       g.ksplit = ksplit; g.n_loop = 1;
       dim3 grid(ntile, (g.M + BM - 1) / BM, ksplit);
       g.xcd_swizzle = (g_swizzle && ntile > 1 && tiles >= 16) ? 1 : 0;

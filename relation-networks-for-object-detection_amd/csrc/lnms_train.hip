@@ -1,0 +1,175 @@
+// Element-wise pieces of the learn-NMS head's TRAIN branch (symbols/resnet_v1_101_rcnn_learn_nms_1024_attention_1024_pairwise_
+// position_multi_head_16.py:424-551) and of its adjoint that the graph spells as chains of small tensor operators (slice + add + relu;
+// sigmoid + transpose + multiply; the softmax Jacobian; take's adjoint ...).  Round 6: each chain is ONE kernel here -- at one image per
+// GPU (the reference's protocol) the step is launch bound and these chains were ~50 of its ~450 launches.
+//   relnet_lnms_pad_params     trained [128,128] / [T,128] matrices into the zero-padded operands of the 64-wide MFMA tiles
+//   relnet_lnms_residual_relu  all_feat = relu(x + linear_out)                    (:489-491; 8 real of 64 columns per head)
+//   relnet_lnms_cond_multi     conditional prob = sigmoid(logit), transposed to [B,F,C,T]; multi score = sorted score x cond  (:497-505)
+//   relnet_lnms_cond_bwd       adjoint of the two lines above -> d sorted score, d logit (bf16, padded to 64 columns)
+//   relnet_lnms_take_bwd       adjoint of take(roi_feat_embedding, rank indices)  (:447-452): fp32 atomic row sums
+//   relnet_lnms_softmax_bwd    adjoint of softmax + slice_axis(begin=1) (:430-433), accumulated into the detector's d cls_score
+#include "common.h"
+
+namespace relnet {
+
+__global__ __launch_bounds__(256) void lnms_pad_params_kernel(const unsigned short* wo, const float* bo, const unsigned short* wl, const float* bl,
+                                                              unsigned short* wout_pad, float* bout_pad, unsigned short* wl_pad, float* bl_pad, int T) {
+  // wo [16 heads x 8][128] -> rows h*64 + j of wout_pad [1024][128]; wl [T][128] -> rows 0..T-1 of wl_pad [64][128] (16-byte chunks)
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int nwo = 128 * 16, nwl = T * 16;
+  if (i < nwo) {
+    const int r = i >> 4, ch = i & 15;
+    *((uint4*)(wout_pad + (long)((r >> 3) * 64 + (r & 7)) * 128) + ch) = *((const uint4*)(wo + (long)r * 128) + ch);
+  } else if (i < nwo + nwl) {
+    const int k = i - nwo;
+    *((uint4*)wl_pad + k) = *((const uint4*)wl + k);
+  } else if (i < nwo + nwl + 128) {
+    const int r = i - nwo - nwl;
+    bout_pad[(r >> 3) * 64 + (r & 7)] = bo[r];
+  } else if (i < nwo + nwl + 128 + T) {
+    const int r = i - nwo - nwl - 128;
+    bl_pad[r] = bl[r];
+  }
+}
+
+// out[r][h*8 + j] = relu(x[r][h*8 + j] + att[r][h*64 + j]); one thread = one (row, head): 16 bytes of each operand
+__global__ __launch_bounds__(256) void lnms_residual_relu_kernel(const unsigned short* att, const unsigned short* x, unsigned short* out, long rows) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * 16) return;
+  const long r = i >> 4; const int h = (int)(i & 15);
+  const uint4 a = *(const uint4*)(att + r * 1024 + h * 64);
+  const uint4 b = *(const uint4*)(x + r * 128 + h * 8);
+  const unsigned int ua[4] = {a.x, a.y, a.z, a.w}, ub[4] = {b.x, b.y, b.z, b.w};
+  unsigned int o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // (the sum is rounded to bf16 BEFORE the ReLU, as the graph's broadcast_add + Activation do)
+    const float lo = bf2f(f2bf(bf2f(ua[k] & 0xffff) + bf2f(ub[k] & 0xffff))), hi = bf2f(f2bf(bf2f(ua[k] >> 16) + bf2f(ub[k] >> 16)));
+    o[k] = pack_bf16x2(fmaxf(lo, 0.f), fmaxf(hi, 0.f));
+  }
+  *(uint4*)(out + r * 128 + h * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// thread = (b, f, c): row (b*C + c)*F + f of the logits
+__global__ __launch_bounds__(256) void lnms_cond_multi_kernel(const float* logit, long ld, const float* score, float* cond, float* multi,
+                                                              int B, int C, int F, int T) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * F * C) return;
+  const int c = (int)(i % C); const int f = (int)((i / C) % F); const long b = i / ((long)C * F);
+  const float* lp = logit + ((b * C + c) * F + f) * ld;
+  const float s = score[i];
+  for (int t = 0; t < T; ++t) {
+    const float p = 1.f / (1.f + __expf(-lp[t]));
+    cond[i * T + t] = p;
+    multi[i * T + t] = s * p;
+  }
+}
+
+__global__ __launch_bounds__(256) void lnms_cond_bwd_kernel(const float* d_multi, const float* cond, const float* score, float* d_sorted,
+                                                            unsigned short* d_logit, int B, int C, int F, int T) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * F * C) return;
+  const int c = (int)(i % C); const int f = (int)((i / C) % F); const long b = i / ((long)C * F);
+  const float s = score[i];
+  float ds = 0.f;
+  unsigned int row[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t < T) {
+      const float dm = d_multi[i * T + t], p = cond[i * T + t];
+      ds += dm * p;
+      row[t] = f2bf(dm * s * p * (1.f - p));
+    }
+  }
+  d_sorted[i] = ds;
+  uint4* dp = (uint4*)(d_logit + ((b * C + c) * F + f) * 64);
+  dp[0] = make_uint4(row[0] | (row[1] << 16), row[2] | (row[3] << 16), row[4] | (row[5] << 16), row[6] | (row[7] << 16));
+#pragma unroll
+  for (int q = 1; q < 8; ++q) dp[q] = make_uint4(0, 0, 0, 0);
+}
+
+// d_emb[b*N + rank[b][c][f]][:] += d_x[b][c][f][:]   (thread = 4 columns of one (b, c, f) row; fp32 atomics: a roi is ranked by up to C classes)
+__global__ __launch_bounds__(256) void lnms_take_bwd_kernel(const unsigned short* d_x, const int* rank_idx, float* d_emb, long rows, int N, int CF) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * 32) return;
+  const long r = i >> 5; const int q = (int)(i & 31);
+  const int rk = rank_idx[r];
+  if (rk < 0 || rk >= N) return;
+  const long b = r / CF;
+  const uint2 v = *(const uint2*)(d_x + r * 128 + q * 4);
+  float* dst = d_emb + (b * N + rk) * 128 + q * 4;
+  atomicAdd(dst, bf2f(v.x & 0xffff)); atomicAdd(dst + 1, bf2f(v.x >> 16));
+  atomicAdd(dst + 2, bf2f(v.y & 0xffff)); atomicAdd(dst + 3, bf2f(v.y >> 16));
+}
+
+// one wavefront per (b, n): prob = softmax(cls_score)[1:], so with inner = sum_c prob_c d_prob_c and p_bg = 1 - sum_c prob_c:
+//   d cls_score[0] += -p_bg inner;   d cls_score[1 + c] += prob_c (d_prob_c - inner)
+__global__ __launch_bounds__(256) void lnms_softmax_bwd_kernel(const float* prob, const float* d_prob, float* d_cls, long ld_row, long ld_img,
+                                                               int B, int N, int C) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)B * N) return;
+  const long b = row / N, n = row - b * N;
+  const float* pp = prob + row * C;
+  const float* dp = d_prob + row * C;
+  float sp = 0.f, si = 0.f;
+  for (int c = lane; c < C; c += 64) { const float p = pp[c]; sp += p; si += p * dp[c]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sp += __shfl_xor(sp, o, 64); si += __shfl_xor(si, o, 64); }
+  float* out = d_cls + b * ld_img + n * ld_row;
+  if (lane == 0) out[0] += -(1.f - sp) * si;
+  for (int c = lane; c < C; c += 64) out[1 + c] += pp[c] * (dp[c] - si);
+}
+
+}  // namespace relnet
+
+using namespace relnet;
+
+extern "C" int relnet_lnms_pad_params(const void* wo, const float* bo, const void* wl, const float* bl, void* wout_pad, float* bout_pad,
+                                      void* wl_pad, float* bl_pad, int T, void* stream) {
+  RELNET_REQUIRE(wo && bo && wl && bl && wout_pad && bout_pad && wl_pad && bl_pad && T > 0 && T <= 64, "relnet_lnms_pad_params: bad arguments");
+  const int total = 128 * 16 + T * 16 + 128 + T;
+  lnms_pad_params_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>((const unsigned short*)wo, bo, (const unsigned short*)wl, bl,
+                                                                               (unsigned short*)wout_pad, bout_pad, (unsigned short*)wl_pad, bl_pad, T);
+  return check_launch("relnet_lnms_pad_params");
+}
+
+extern "C" int relnet_lnms_residual_relu(const void* att, const void* x, void* out, long rows, void* stream) {
+  RELNET_REQUIRE(att && x && out && rows > 0, "relnet_lnms_residual_relu: bad arguments");
+  RELNET_REQUIRE((((uintptr_t)att | (uintptr_t)x | (uintptr_t)out) & 15) == 0, "relnet_lnms_residual_relu: operands must be 16-byte aligned");
+  lnms_residual_relu_kernel<<<(unsigned)((rows * 16 + 255) / 256), 256, 0, (hipStream_t)stream>>>((const unsigned short*)att, (const unsigned short*)x,
+                                                                                                 (unsigned short*)out, rows);
+  return check_launch("relnet_lnms_residual_relu");
+}
+
+extern "C" int relnet_lnms_cond_multi(const float* logit, long ld, const float* sorted_score, float* cond, float* multi, int B, int C, int F, int T,
+                                      void* stream) {
+  RELNET_REQUIRE(logit && sorted_score && cond && multi && B > 0 && C > 0 && F > 0 && T > 0 && ld >= T, "relnet_lnms_cond_multi: bad arguments");
+  const long total = (long)B * F * C;
+  lnms_cond_multi_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(logit, ld, sorted_score, cond, multi, B, C, F, T);
+  return check_launch("relnet_lnms_cond_multi");
+}
+
+extern "C" int relnet_lnms_cond_bwd(const float* d_multi, const float* cond, const float* sorted_score, float* d_sorted, void* d_logit, int B, int C,
+                                    int F, int T, void* stream) {
+  RELNET_REQUIRE(d_multi && cond && sorted_score && d_sorted && d_logit && B > 0 && C > 0 && F > 0 && T > 0 && T <= 8, "relnet_lnms_cond_bwd: bad arguments (T <= 8)");
+  RELNET_REQUIRE((((uintptr_t)d_logit) & 15) == 0, "relnet_lnms_cond_bwd: d_logit must be 16-byte aligned");
+  const long total = (long)B * F * C;
+  lnms_cond_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_multi, cond, sorted_score, d_sorted, (unsigned short*)d_logit, B, C, F, T);
+  return check_launch("relnet_lnms_cond_bwd");
+}
+
+extern "C" int relnet_lnms_take_bwd(const void* d_x, const int* rank_idx, float* d_emb, int B, int N, int C, int F, void* stream) {
+  RELNET_REQUIRE(d_x && rank_idx && d_emb && B > 0 && N > 0 && C > 0 && F > 0, "relnet_lnms_take_bwd: bad arguments");
+  RELNET_REQUIRE((((uintptr_t)d_x) & 7) == 0, "relnet_lnms_take_bwd: d_x must be 8-byte aligned");
+  const long rows = (long)B * C * F;
+  lnms_take_bwd_kernel<<<(unsigned)((rows * 32 + 255) / 256), 256, 0, (hipStream_t)stream>>>((const unsigned short*)d_x, rank_idx, d_emb, rows, N, C * F);
+  return check_launch("relnet_lnms_take_bwd");
+}
+
+extern "C" int relnet_lnms_softmax_bwd(const float* prob, const float* d_prob, float* d_cls, long ld_row, long ld_img, int B, int N, int C, void* stream) {
+  RELNET_REQUIRE(prob && d_prob && d_cls && B > 0 && N > 0 && C > 0 && ld_row >= C + 1, "relnet_lnms_softmax_bwd: bad arguments");
+  const long rows = (long)B * N;
+  lnms_softmax_bwd_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(prob, d_prob, d_cls, ld_row, ld_img, B, N, C);
+  return check_launch("relnet_lnms_softmax_bwd");
+}

@@ -38,4 +38,12 @@ long device_cu_count() {
 }  // namespace relnet
 
 extern "C" const char* relnet_last_error(void) { return relnet::g_err; }
+// 0 when `stream` is not being captured into a hipGraph, else the id of that capture (unique per capture sequence, hipStreamGetCaptureInfo):
+// lets the host side tell two captures on one stream apart (per-capture scratch such as the split-K work area of relnet_gemm_set_workspace)
+extern "C" unsigned long long relnet_stream_capture_id(void* stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  if (hipStreamGetCaptureInfo((hipStream_t)stream, &st, &id) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return st == hipStreamCaptureStatusActive ? (id ? id : ~0ull) : 0;
+}
 extern "C" int relnet_version(void) { return 100; }   // 0.1.0

@@ -265,9 +265,32 @@ __global__ __launch_bounds__(256) void lnms_scatter_bwd_kernel(const float* d_so
   atomicAdd(d_prob + (b * N + r) * C + c, d_sorted[(b * F + f) * C + c]);
 }
 
+// out[0] = scale * sum(x)  (mode 0)  or  the number of entries >= 0 (mode 1): the scalar metrics of a training step (loss values =
+// MakeLoss outputs summed per image, the OHEM keep count) in ONE deterministic single-workgroup launch each instead of sum + div / ge + sum.
+__global__ __launch_bounds__(1024) void reduce_scalar_kernel(const float* x, long n, float scale, int mode, float* out) {
+  __shared__ float part[16];
+  float acc = 0.f;
+  for (long i = threadIdx.x; i < n; i += 1024) acc += mode ? (x[i] >= 0.f ? 1.f : 0.f) : x[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += part[w];
+    out[0] = (mode ? 1.f : scale) * t;
+  }
+}
+
 }  // namespace relnet
 
 using namespace relnet;
+
+extern "C" int relnet_reduce_scalar(const float* x, long n, float scale, int mode, float* out, void* stream) {
+  RELNET_REQUIRE(x && out && n > 0 && (mode == 0 || mode == 1), "relnet_reduce_scalar: bad arguments");
+  reduce_scalar_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(x, n, scale, mode, out);
+  return check_launch("relnet_reduce_scalar");
+}
 
 extern "C" int relnet_relu_bwd(const void* dy, const void* y, const void* add, void* dx, long n, int dtype, void* stream) {
   RELNET_REQUIRE(dy && y && dx && n > 0, "relnet_relu_bwd: bad operand");

@@ -102,6 +102,13 @@ _SIGNATURES = {
     'relnet_weight_fragpack': (C.c_int, [_vp, _i, _i, _vp]),
     'relnet_relation_bwd_pack': (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'relnet_lnms_scatter_bwd': (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'relnet_reduce_scalar': (C.c_int, [_vp, _l, _f, _i, _vp, _vp]),
+    'relnet_lnms_pad_params': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    'relnet_lnms_residual_relu': (C.c_int, [_vp, _vp, _vp, _l, _vp]),
+    'relnet_lnms_cond_multi': (C.c_int, [_vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'relnet_lnms_cond_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'relnet_lnms_take_bwd': (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'relnet_lnms_softmax_bwd': (C.c_int, [_vp, _vp, _vp, _l, _l, _i, _i, _i, _vp]),
     'relnet_gemm_nt_mask': (C.c_int, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _vp]),
     'relnet_gemm_nt_f16': (C.c_int, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _vp]),
     'relnet_gemm_set_swizzle': (None, [_i]),
@@ -112,6 +119,7 @@ _SIGNATURES = {
     'relnet_chain_debug': (None, [_i]),
     'relnet_gemm_tile_count': (C.c_int, []),
     'relnet_gemm_set_workspace': (C.c_int, [_vp, _l]),
+    'relnet_stream_capture_id': (C.c_ulonglong, [_vp]),
     'relnet_gemm_debug_splitk': (None, [_i]),
     'relnet_gemm_pick_tile': (C.c_int, [_i, _i, _i, _i, _i]),
     'relnet_nms_greedy': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),

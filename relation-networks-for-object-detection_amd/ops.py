@@ -40,19 +40,26 @@ def pad32(m):
 
 
 _GEMM_WS = {}
+_GEMM_WS_BYTES = 16384 + (40 << 20)
 
 
 def gemm_workspace():
-    """The split-K work area of the GEMM / convolution kernels (relnet_gemm_set_workspace, tile configuration 23): one zeroed
-    160 MB allocation per device, made on the first eager GEMM of the process (never inside a hipGraph capture) and kept for its
-    life.  The library only splits launches of at most one 64 x 64 workgroup per CU -- the one-image step."""
-    dev = torch.cuda.current_device()
-    if dev not in _GEMM_WS and not torch.cuda.is_current_stream_capturing():
-        ws = torch.zeros(4 * (16384 + (40 << 20)), device='cuda:%d' % dev, dtype=torch.uint8)
-        torch.cuda.synchronize(dev)
-        _lib.call('relnet_gemm_set_workspace', ws.data_ptr(), ws.numel())
-        _GEMM_WS[dev] = ws
-    return _GEMM_WS.get(dev)
+    """Names the split-K work area of the CURRENT stream to the library (relnet_gemm_set_workspace, tile configuration 23) before a
+    GEMM / convolution call: one 40 MB area per launching stream, made on the stream's first GEMM and kept for the life of the
+    process -- launches on one stream are ordered, which is what the area needs.  A stream that is being captured into a hipGraph
+    gets an area per CAPTURE (relnet_stream_capture_id): it comes from that capture's memory pool, the zeroing of its 16 KB of
+    counters is a node of the graph, and the reference held here keeps the block from being handed out again.  The library only
+    splits launches of at most one 64 x 64 workgroup per CU with k-loops of >= 128 slabs (the one-image step)."""
+    st = torch.cuda.current_stream().cuda_stream
+    cap = _lib.load().relnet_stream_capture_id(st) if torch.cuda.is_current_stream_capturing() else 0
+    key = (torch.cuda.current_device(), st, cap)
+    ws = _GEMM_WS.get(key)
+    if ws is None:
+        ws = torch.empty(_GEMM_WS_BYTES, device='cuda:%d' % key[0], dtype=torch.uint8)
+        ws[:16384].zero_()
+        _GEMM_WS[key] = ws
+    _lib.call('relnet_gemm_set_workspace', ws.data_ptr(), ws.numel())
+    return ws
 
 
 def gemm_nt(a, w, bias=None, bias_mode=1, resid=None, relu=False, out=None, out_dtype=None,

@@ -433,7 +433,7 @@ class Trainer(object):
             tgt = tgt_in.permute(0, 2, 3, 1).contiguous()
             wgt = wgt_in.permute(0, 2, 3, 1).contiguous()
             rpn_l1, d_delta = losses.smooth_l1_loss(delta, tgt, wgt, 3.0, 1.0 / c.rpn_batch_size)
-            out['rpn_bbox_loss'] = rpn_l1.sum() / B
+            out['rpn_bbox_loss'] = T.scalar_sum(rpn_l1, 1.0 / B)
             d_rpn = torch.cat([d_score.permute(0, 2, 3, 1), d_delta], 3).to(torch.bfloat16).contiguous()
             # -- proposals and their targets (no gradient: proposal.py:170-173, proposal_target.py:95-97)
             rois, _ = propose_batch(nchw(rpn[..., :na2]), nchw(rpn[..., na2:]), im_info, self.anchors, c.feat_stride,
@@ -616,13 +616,14 @@ class Trainer(object):
         _, d_cls = losses.softmax_output(cls_score.view(B * R, -1), labels_ohem.reshape(-1), use_ignore=True, ignore_label=-1.0, group=R)
         d_cls = d_cls.view(B, R, -1)
         l1, d_bbox = losses.smooth_l1_loss(bbox_pred, bbox_target, weights_ohem, 1.0, 1.0 / c.batch_rois_ohem)
-        out['bbox_loss'] = l1.sum() / B
-        out['num_ohem'] = (labels_ohem >= 0).sum()
+        out['bbox_loss'] = T.scalar_sum(l1, 1.0 / B)
+        out['num_ohem'] = T.scalar_sum(labels_ohem, count_nonneg=True)
         d_x2_lnms = None
         if c.learn_nms:     # the learn-NMS head sees the first N (non-gt) rows; its gradient joins cls_score and fc_all_2_relu
             d_cls_l, d_x2_lnms, lo = self._lnms_forward_backward(cls_score[:, :N], bbox_pred[:, :N], rois_t[:, :N].contiguous(),
-                                                                 im_info, x2[:, :N], gt_boxes, num_gt, n_valid=key_count)
-            d_cls[:, :N] += d_cls_l
+                                                                 im_info, x2[:, :N], gt_boxes, num_gt, n_valid=key_count, d_cls_out=d_cls)
+            if d_cls_l is not None:         # (None: already accumulated into d_cls[:, :N] by relnet_lnms_softmax_bwd)
+                d_cls[:, :N] += d_cls_l
             out.update(lo)
         # ================= backward =================
         d_cb = torch.cat([d_cls, d_bbox], 2).reshape(B * R, -1).to(bt)
@@ -639,13 +640,17 @@ class Trainer(object):
         self._add_bgrad('fc_new_1', db)
         return d_pool, (x2, f1, cls_score, bbox_pred, labels_ohem, weights_ohem)
 
-    def _lnms_forward_backward(self, cls_score, bbox_pred, rois, im_info, feat, gt_boxes, num_gt, n_valid=None):
+    def _lnms_forward_backward(self, cls_score, bbox_pred, rois, im_info, feat, gt_boxes, num_gt, n_valid=None, d_cls_out=None):
         """Train branch of the learn-NMS head (symbols/..._learn_nms.py:424-551) and its adjoint.
         cls_score [B,N,81] fp32, bbox_pred [B,N,8] (BlockGrad), rois [B,N,5], feat = fc_all_2_relu[:, :N] bf16.
-        Returns (d cls_score [B,N,81] fp32, d feat [B,N,1024] fp32, losses)."""
+        Returns (d cls_score [B,N,81] fp32, d feat [B,N,1024] (bf16, as the projection's backward GEMM leaves it), losses); with d_cls_out [B,R,81] fp32 (contiguous, R >= N) the
+        class-score gradient is accumulated into d_cls_out[:, :N] instead and None is returned in its place.
+        cfg.lnms_fused_glue (default on; RELNET_LNMS_GLUE=0 = the tensor-operator chains of rounds 3 - 5, kept for the equality test):
+        the element-wise chains of the branch run as single kernels (csrc/lnms_train.hip)."""
         import ctypes
         from . import lib as _lib
         c = self.cfg
+        fused = bool(getattr(c, 'lnms_fused_glue', os.environ.get('RELNET_LNMS_GLUE', '1') != '0'))
         B, N, C1 = cls_score.shape
         C, F, Tn = C1 - 1, c.first_n, len(c.nms_target_thresh)
         dev, bt, s_ = cls_score.device, torch.bfloat16, ops._stream()
@@ -677,9 +682,14 @@ class Trainer(object):
         mod.wqk, mod.bqk = self.w('nms_qk_1'), self.b('nms_qk_1')
         wo, bo = self.w('nms_linear_out_1'), self.b('nms_linear_out_1')
         mod.wout = self._scratch('nms_wout_pad', (1024, 128), bt)           # persistent: the 56 pad rows of every head stay zero
-        mod.wout.view(16, 64, 128)[:, :8] = wo.view(16, 8, 128)
         mod.bout = self._scratch('nms_bout_pad', (1024,), torch.float32)
-        mod.bout.view(16, 64)[:, :8] = bo.view(16, 8)
+        if fused:       # the four padded operands of the step (Wout / bout per head, the 64-row logit matrix) refreshed by one launch
+            w_logit, b_logit = self._scratch('nms_wlogit_pad', (64, 128), bt), self._scratch('nms_blogit_pad', (64,), torch.float32)
+            _lib.call('relnet_lnms_pad_params', wo.data_ptr(), bo.data_ptr(), self.w('nms_logit').data_ptr(), self.b('nms_logit').data_ptr(),
+                      mod.wout.data_ptr(), mod.bout.data_ptr(), w_logit.data_ptr(), b_logit.data_ptr(), Tn, s_)
+        else:
+            mod.wout.view(16, 64, 128)[:, :8] = wo.view(16, 8, 128)
+            mod.bout.view(16, 64)[:, :8] = bo.view(16, 8)
         mod.wp = self.W.view(self.W.master, 'nms_pair_pos_fc1_1')
         mod.bp = self.b('nms_pair_pos_fc1_1')
         wp_t, bp = pack_pair_pos([mod], dev)
@@ -688,21 +698,37 @@ class Trainer(object):
         lcache = {}
         att, _, _ = _module_forward(xr, mod, bias, F, True, False, False, vwt_buf=self._scratch('vwt_nms_%d' % F, (BC, 1024, bias.shape[-1]), bt),
                                     cache=lcache)                                               # [BC,F,1024]
-        att128 = att.view(BC, F, 16, 64)[..., :8].reshape(BC, F, 128)
-        allf = torch.relu(xr + att128).contiguous()
-        w_logit = torch.zeros((64, 128), device=dev, dtype=bt); w_logit[:Tn] = self.w('nms_logit')
-        b_logit = torch.zeros(64, device=dev, dtype=torch.float32); b_logit[:Tn] = self.b('nms_logit')
-        logit = ops.gemm_nt(allf.view(BC * F, 128), w_logit, b_logit, out_dtype=torch.float32)[:, :Tn]
-        cond = torch.sigmoid(logit).view(B, C, F, Tn).permute(0, 2, 1, 3).contiguous()          # [B,F,C,T]
-        multi = sorted_score.unsqueeze(3) * cond
+        if fused:
+            assert att.is_contiguous() and att.shape == (BC, F, 1024) and att.dtype == bt and xr.is_contiguous()
+            allf = torch.empty((BC, F, 128), device=dev, dtype=bt)
+            _lib.call('relnet_lnms_residual_relu', att.data_ptr(), xr.data_ptr(), allf.data_ptr(), BC * F, s_)
+            logit64 = ops.gemm_nt(allf.view(BC * F, 128), w_logit, b_logit, out_dtype=torch.float32)      # [BC*F, 64], T real columns
+            cond = torch.empty((B, F, C, Tn), device=dev, dtype=torch.float32)
+            multi = torch.empty_like(cond)
+            _lib.call('relnet_lnms_cond_multi', logit64.data_ptr(), logit64.stride(0), sorted_score.data_ptr(), cond.data_ptr(), multi.data_ptr(),
+                      B, C, F, Tn, s_)
+        else:
+            att128 = att.view(BC, F, 16, 64)[..., :8].reshape(BC, F, 128)
+            allf = torch.relu(xr + att128).contiguous()
+            w_logit = torch.zeros((64, 128), device=dev, dtype=bt); w_logit[:Tn] = self.w('nms_logit')
+            b_logit = torch.zeros(64, device=dev, dtype=torch.float32); b_logit[:Tn] = self.b('nms_logit')
+            logit = ops.gemm_nt(allf.view(BC * F, 128), w_logit, b_logit, out_dtype=torch.float32)[:, :Tn]
+            cond = torch.sigmoid(logit).view(B, C, F, Tn).permute(0, 2, 1, 3).contiguous()          # [B,F,C,T]
+            multi = sorted_score.unsqueeze(3) * cond
         target = ops.nms_multi_target(sorted_bbox, gt_boxes, sorted_score, num_gt, c.nms_target_thresh)
         pos, neg, d_multi = losses.nms_loss(multi, target, F, Tn, c.nms_loss_scale, c.nms_pos_scale, c.nms_eps)
-        lo = dict(nms_pos_loss=pos.sum() / B, nms_neg_loss=neg.sum() / B, nms_multi_score=multi, nms_multi_target=target,
+        lo = dict(nms_pos_loss=T.scalar_sum(pos, 1.0 / B), nms_neg_loss=T.scalar_sum(neg, 1.0 / B), nms_multi_score=multi, nms_multi_target=target,
                   sorted_score=sorted_score, nms_rank_idx=rank_idx, nms_class_boxes=class_boxes)
         # ---------------- adjoint ----------------
-        d_sorted = (d_multi * cond).sum(3)                                                      # [B,F,C]
-        d_logit = (d_multi * sorted_score.unsqueeze(3) * cond * (1.0 - cond)).permute(0, 2, 1, 3).reshape(BC * F, Tn)
-        d_logit_p = torch.zeros((BC * F, 64), device=dev, dtype=bt); d_logit_p[:, :Tn] = d_logit
+        if fused:
+            d_sorted = torch.empty((B, F, C), device=dev, dtype=torch.float32)
+            d_logit_p = torch.empty((BC * F, 64), device=dev, dtype=bt)
+            _lib.call('relnet_lnms_cond_bwd', d_multi.data_ptr(), cond.data_ptr(), sorted_score.data_ptr(), d_sorted.data_ptr(), d_logit_p.data_ptr(),
+                      B, C, F, Tn, s_)
+        else:
+            d_sorted = (d_multi * cond).sum(3)                                                      # [B,F,C]
+            d_logit = (d_multi * sorted_score.unsqueeze(3) * cond * (1.0 - cond)).permute(0, 2, 1, 3).reshape(BC * F, Tn)
+            d_logit_p = torch.zeros((BC * F, 64), device=dev, dtype=bt); d_logit_p[:, :Tn] = d_logit
         d_allf, dw, db = T.linear_bwd(allf.view(BC * F, 128), w_logit, d_logit_p, w_t=None, keep_splits=True)
         self._add_wgrad('nms_logit', dw.sum(0)[:Tn]); self._add_bgrad('nms_logit', db[:Tn])
         g = T.relu_bwd(d_allf, allf.view(BC * F, 128))                                          # [BC*F,128] bf16
@@ -736,17 +762,24 @@ class Trainer(object):
             d_x = (r['d_roi_feat'] + g.view(BC, F, 128).float()).view(B, C, F, 128)             # residual + module
         d_rank = d_x.sum((0, 1), dtype=torch.float32)                                           # [F,128] (fp32 accumulation whatever d_x's dtype)
         self._add_wgrad('nms_rank', T.wgrad(d_rank.to(bt), self.rank_emb)); self._add_bgrad('nms_rank', d_rank.sum(0))
-        flat = (rank_idx.long() + (torch.arange(B, device=dev) * N).view(B, 1, 1)).view(-1)
         d_emb = torch.zeros((B * N, 128), device=dev, dtype=torch.float32)
-        d_emb.index_add_(0, flat, d_x.reshape(-1, 128).float())                                 # take() backward (a roi is ranked in up to 80 classes: fp32 sums)
+        if fused and d_x.dtype == bt and d_x.is_contiguous():
+            _lib.call('relnet_lnms_take_bwd', d_x.data_ptr(), rank_idx.data_ptr(), d_emb.data_ptr(), B, N, C, F, s_)
+        else:
+            flat = (rank_idx.long() + (torch.arange(B, device=dev) * N).view(B, 1, 1)).view(-1)
+            d_emb.index_add_(0, flat, d_x.reshape(-1, 128).float())                             # take() backward (a roi is ranked in up to 80 classes: fp32 sums)
         d_feat, dw, db = T.linear_bwd(feat2, self.w('roi_feat_embedding'), d_emb.to(bt), w_t=self.wt('roi_feat_embedding'), keep_splits=True, wgrad_to=self._wg('roi_feat_embedding'), bgrad_to=self._bg('roi_feat_embedding'))
         self._add_bgrad('roi_feat_embedding', db)
         # sort / slice backward -> cls_prob -> softmax backward (background column has no direct gradient)
         d_prob = ops.lnms_scatter_bwd(d_sorted.contiguous(), rank_idx, N)      # d_prob[b, rank_idx[b,c,f], c] += d_sorted[b,f,c]
+        if fused and d_cls_out is not None and d_cls_out.is_contiguous() and d_cls_out.dtype == torch.float32 and d_cls_out.shape[2] == C1:
+            _lib.call('relnet_lnms_softmax_bwd', prob.data_ptr(), d_prob.data_ptr(), d_cls_out.data_ptr(), d_cls_out.stride(1), d_cls_out.stride(0),
+                      B, N, C, s_)
+            return None, d_feat.view(B, N, -1), lo
         p_bg = 1.0 - prob.sum(2, keepdim=True)
         inner = (prob * d_prob).sum(2, keepdim=True)
         d_cls = torch.cat([-p_bg * inner, prob * (d_prob - inner)], 2)
-        return d_cls, d_feat.float().view(B, N, -1), lo
+        return d_cls, d_feat.view(B, N, -1), lo
 
     def _dgrad_w(self, name, cout):
         """[Cout, 9*Cin] packed forward weights -> [Cin, 9*Cout] tap-flipped data-gradient weights."""

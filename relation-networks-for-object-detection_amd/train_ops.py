@@ -74,6 +74,17 @@ def wgrad(dy2d, x2d, keep_splits=False):
     return part.sum(0) if s > 1 else part[0]
 
 
+def scalar_sum(x, scale=1.0, count_nonneg=False):
+    """0-dim fp32 tensor = scale * x.sum() (or the number of entries >= 0): relnet_reduce_scalar, one launch (the loss values /
+    OHEM count a step reports; torch needs sum + div / ge + sum)."""
+    _chk(x)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        return (x >= 0).sum().float() if count_nonneg else x.sum() * scale
+    out = torch.empty((), device=x.device, dtype=torch.float32)
+    _lib.call('relnet_reduce_scalar', x.data_ptr(), x.numel(), float(scale), int(bool(count_nonneg)), out.data_ptr(), _stream())
+    return out
+
+
 def wgrad_accumulate(parts, grad, row_scale=None):
     """grad [rows, cols] (fp32 view of the flat gradient buffer) += row_scale^2 * parts.sum(0), one kernel."""
     _chk(parts, grad, row_scale)

@@ -226,19 +226,21 @@ def test_split_k_tile_on_the_one_image_shapes(rn):
     outs = {}
     for ways in (0, 2, 3, 5, 8, 1):
         L.relnet_gemm_debug_splitk(ways)
+        L.relnet_gemm_force_tile(23 if ways >= 2 else 0)
         for odt, tol in ((torch.bfloat16, 1e-2), (torch.float32, 2e-5 * K ** 0.5)):
             got = [ops.gemm_nt(a, w, b, relu=True, out_dtype=odt) for _ in range(3)]
             assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2]), ('not deterministic', ways, odt)
             err = np.abs(got[0].double().cpu().numpy() - want64).max() / np.abs(want64).max()
             assert err < tol, (ways, odt, err)
             outs[(ways, odt)] = got[0]
-    L.relnet_gemm_debug_splitk(0)
+    L.relnet_gemm_debug_splitk(0); L.relnet_gemm_force_tile(0)
     # (the split changes the fp32 summation order only: bf16 outputs of the split and unsplit launches agree to an ulp of bf16)
     d = (outs[(0, torch.bfloat16)].float() - outs[(1, torch.bfloat16)].float()).abs().max().item()
     assert d <= 2 ** -7 * outs[(1, torch.bfloat16)].float().abs().max().item()
     # convolutions of the one-image step, with shortcut / ReLU epilogues run by the last arriver
     for (hw, cin, cout, k, dil, extras) in (((38, 63), 256, 256, 3, 1, 'relu'), ((38, 63), 512, 512, 3, 2, 'relu'),
-                                           ((38, 63), 1024, 256, 1, 1, 'resid+relu'), ((38, 63), 512, 72, 1, 1, '')):
+                                           ((38, 63), 1024, 256, 1, 1, 'resid+relu'), ((38, 63), 512, 72, 1, 1, ''),
+                                           ((38, 63), 1024, 512, 3, 1, 'relu')):          # (the last: rpn_conv_3x3, split by the -2 rule itself)
         x = torch.randn(1, hw[0], hw[1], cin, generator=g).cuda().to(torch.bfloat16)
         wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(torch.bfloat16)
         wp = wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda()
@@ -252,12 +254,13 @@ def test_split_k_tile_on_the_one_image_shapes(rn):
             if 'relu' in extras:
                 want = np.maximum(want, 0)
             runs = []
-            for ways in (0, 1):
-                L.relnet_gemm_debug_splitk(ways)
+            for ways in (3, 1):               # three ways on tile 23 (forced) against unsplit
+                L.relnet_gemm_debug_splitk(ways); L.relnet_gemm_force_tile(23 if ways > 1 else 0)
                 runs.append(ops.conv2d_nhwc(x, wp, bias, ksize=k, pad=dil * (k // 2), dil=dil, relu='relu' in extras, resid=res, out_dtype=odt))
-            L.relnet_gemm_debug_splitk(0)
+            L.relnet_gemm_debug_splitk(-2 if cin * k * k >= 128 * 64 else 3); L.relnet_gemm_force_tile(0 if cin * k * k >= 128 * 64 else 23)
             again = ops.conv2d_nhwc(x, wp, bias, ksize=k, pad=dil * (k // 2), dil=dil, relu='relu' in extras, resid=res, out_dtype=odt)
-            assert torch.equal(runs[0], again)
+            L.relnet_gemm_debug_splitk(0); L.relnet_gemm_force_tile(0)
+            assert torch.equal(runs[0], again)            # (rpn_conv_3x3: the automatic -2 rule picks the same three ways)
             for r_ in runs:
                 sub = r_.view(-1, cout)[torch.as_tensor(rows).cuda()].double().cpu().numpy()
                 assert np.abs(sub - want).max() / np.abs(want).max() < tol, (cin, cout, k, odt)

@@ -92,3 +92,61 @@ def test_learn_nms_head_gradients_at_the_fpn_yaml_first_n(first_n):
             if float(w_.norm()) > 1e-9 and (cos < lim or abs(float(g.norm() / w_.norm()) - 1) > 0.04):
                 bad.append(report[-1])
     assert not bad, '\n'.join(bad) + '\n--- all ---\n' + '\n'.join(report)
+
+
+def test_fused_glue_kernels_equal_the_tensor_operator_chains():
+    """csrc/lnms_train.hip (round 6: pad_params, residual_relu, cond_multi, cond_bwd, take_bwd, softmax_bwd -- one kernel per
+    element-wise chain of the branch) against the torch-operator form it replaces (cfg.lnms_fused_glue = False), same inputs, same
+    trainer: losses, multi scores, both returned gradients (the class-score gradient ACCUMULATED into a non-zero [B, R, 81] buffer
+    with R > N) and every parameter gradient of the head."""
+    import relnet_amd  # noqa: F401
+    from relnet_amd import backbone, train
+    B, N, C, G, R = 2, 300, 80, 6, 308
+    p = backbone.init_params(seed=3)
+    g_ = torch.Generator().manual_seed(79)
+    p['nms_logit_bias'] = torch.zeros(5)
+    for k in ('nms_logit_weight', 'nms_rank_weight', 'roi_feat_embedding_weight', 'nms_query_1_weight', 'nms_key_1_weight',
+              'nms_linear_out_1_weight', 'nms_pair_pos_fc1_1_weight'):
+        p[k] = torch.randn(p[k].shape, generator=g_) * 0.05
+    cfg = train.TrainConfig()
+    cfg.learn_nms, cfg.first_n = True, 100
+    tr = train.Trainer(p, cfg, im_hw=(600, 1000))
+    ins = [cases.learn_nms_case(N, C, 190 + b) for b in range(B)]
+    d = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    cls_score, bbox_pred, rois = (d(np.stack([i[k] for i in ins])) for k in (0, 1, 2))
+    im_info = d(np.concatenate([i[3] for i in ins]))
+    feat = d(np.stack([i[4] for i in ins])).to(torch.bfloat16)
+    gt = np.zeros((B, G, 5), np.float32)
+    for b in range(B):
+        for j in range(G):
+            c = 1 + 7 * j
+            gt[b, j, :4] = ins[b][2][np.argmax(ins[b][0][:, c]), 1:]
+            gt[b, j, 4] = c
+    num_gt = torch.full((B,), G, dtype=torch.int32, device='cuda')
+    base = torch.randn(B, R, C + 1, generator=g_).cuda() * 1e-3
+    res = {}
+    for fused in (False, True):
+        cfg.lnms_fused_glue = fused
+        tr.W.grad.zero_(); tr.Bv.grad.zero_()
+        tr._relayout.run()
+        acc = base.clone()
+        d_cls, d_feat, lo = tr._lnms_forward_backward(cls_score, bbox_pred, rois, im_info, feat, d(gt), num_gt, d_cls_out=acc)
+        tr._flush_wgrads()
+        if d_cls is not None:
+            assert not fused
+            acc[:, :N] += d_cls
+        else:
+            assert fused
+        torch.cuda.synchronize()
+        res[fused] = dict(d_cls=acc.clone(), d_feat=d_feat.clone(), multi=lo['nms_multi_score'].clone(), pos=lo['nms_pos_loss'].clone(),
+                          neg=lo['nms_neg_loss'].clone(), wg=tr.W.grad.clone(), bg=tr.Bv.grad.clone())
+    a, b_ = res[False], res[True]
+    assert torch.equal(a['d_cls'][:, N:], base[:, N:]) and torch.equal(b_['d_cls'][:, N:], base[:, N:])       # rows past N untouched
+    for k in ('multi', 'pos', 'neg', 'd_cls', 'd_feat', 'wg', 'bg'):
+        x, y = a[k].double().reshape(-1), b_[k].double().reshape(-1)
+        cos = float((x * y).sum() / (x.norm() * y.norm()))
+        assert cos > 0.99999 and abs(float(y.norm() / x.norm()) - 1) < 1e-3, (k, cos, float(y.norm() / x.norm()))
+    for n in ('nms_rank', 'roi_feat_embedding', 'nms_pair_pos_fc1_1', 'nms_logit', 'nms_qk_1', 'nms_linear_out_1'):
+        x, y = tr.W.view(a['wg'], n).double().reshape(-1), tr.W.view(b_['wg'], n).double().reshape(-1)
+        cos = float((x * y).sum() / (x.norm() * y.norm()))
+        assert cos > 0.9999 and abs(float(y.norm() / x.norm()) - 1) < 2e-3, (n, cos)
