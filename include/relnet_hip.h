@@ -572,6 +572,10 @@ int relnet_sgd_update(float* w, float* mom, const float* grad, void* w_bf16, lon
  * (nn/deformable_im2col.cuh:313-351) + deformable_col2im_coord (:420-470) in one pass: grad_data (fp32, logical
  * [B,C,H,W], element strides) and grad_offset (fp32, logical [B,2*KH*KW*DG,Ho,Wo], may be NULL) are ACCUMULATED
  * into (atomics) -- zero them first.  dcol: [B*Ho*Wo][dcol_ld], column (i*KW + j)*C + c, fp32 or bf16.            */
+/* tuning / test knob of relnet_deformable_col2im: 0 = auto (round 6: on stride-1 channels-last bf16 layers the data gradient is GATHERED per feature cell
+ * from the (pixel, tap) pairs whose bilinear corners lie within 3 cells of their undeformed tap position, float atomics only for the others), 1 = the
+ * one-kernel atomic scatter everywhere, 2 = every pair treated as far (offset kernel + far-only scatter pass), 10 + D = window radius D */
+void relnet_deformable_col2im_debug(int mode);
 int relnet_deformable_col2im(const void* dcol, long dcol_ld, int dcol_dtype, const void* data,
                              const long* data_strides4, int data_dtype, const float* offset,
                              const long* offset_strides4, float* grad_data, const long* grad_data_strides4,

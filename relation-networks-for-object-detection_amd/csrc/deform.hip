@@ -379,7 +379,12 @@ struct DeformBwdArgs {
   float* grad_data; long gs_b, gs_c, gs_h, gs_w;      // fp32, += (atomics), logical [B,C,H,W]
   float* grad_offset; long os_b, os_c, os_h, os_w;    // fp32, += (atomics), logical [B, 2*KH*KW*DG, Ho, Wo]
   int dcol_f32;
+  int win;                         // gather form: window radius D (a pair is NEAR when its four corners lie within D cells of its undeformed tap position)
 };
+
+__device__ __forceinline__ bool pair_near(const Taps& t, int cy, int cx, int D) {
+  return abs(t.ya - cy) <= D && abs(t.yb - cy) <= D && abs(t.xa - cx) <= D && abs(t.xb - cx) <= D;
+}
 
 // one thread per (pixel, tap, channel), channel fastest: a wavefront covers 64 consecutive channels of one
 // (pixel, tap); when they share a deformable group the two offset gradients are reduced in-wave first.
@@ -442,6 +447,207 @@ __global__ __launch_bounds__(256) void deformable_col2im_kernel(DeformBwdArgs a)
 //  2.4 ms (16 waves) against 1.24 ms of the kernel above at 8 images: with one 128 KiB workgroup per CU the serial
 //  offset -> taps -> loads chain of each (pixel, tap) pair has nothing to hide behind, while the 64-channel-contiguous
 //  global_atomic_add_f32 of the plain kernel coalesce into two 128-byte requests per wavefront.)
+
+// ---- round 6: the data gradient as a GATHER ------------------------------------------------------------------------------------
+// The scatter above issues four memory-side float atomics per (pixel, tap, channel); a feature cell of res5 receives ~36 of them
+// (9 taps x 4 corner roles), and same-address atomics serialise: 353 M atomics = 1.24 ms per layer at 8 images, 13 % of the DCN
+// training step.  The offsets only say WHERE a (pixel, tap) pair lands: a pair whose four (clamped) corners lie within D cells of its
+// undeformed tap position (cy, cx) = (ho stride - pad + i dil, wo stride - pad + j dil) -- a NEAR pair, |offset| < D -- can only touch
+// the (2 D + 1)^2 cells around (cy, cx).  So a cell (Y, X) collects, per tap, from the pairs whose (cy, cx) lie in its (2 D + 1)^2
+// neighbourhood: 9 (2 D + 1)^2 candidate pairs (441 at the default D = 3), evaluated one per lane with exactly deform_taps() (same
+// border rules, same rounding); then lane = channel(s) adds weight x dcol over the ~36 candidates that hit -- no atomics, one coalesced
+// read-modify-write per cell.  FAR pairs (a corner further away: large learned offsets, clamped border taps) keep the atomic scatter in
+// deformable_col2im_far_kernel, which tests the same predicate; the offset gradients come from deformable_col2im_offset_kernel.
+// Stride 1, channels-last bf16 data / fp32 gradient, CPL = 1 or 2 channels per lane (64 CPL | channels per deformable group).
+// Measured (tools/col2im_probe.py, profiles/r06_notes/col2im_gather.txt, res5 at 8 images, bf16 column gradient): scatter 1.23 ms; gather form with
+// offsets of sigma 0.05 / 0.5 / 1.5 / 4 cells: D = 1 0.28 / 0.36 / 0.98 / 1.11 ms, D = 2 0.31 / 0.31 / 0.63 / 1.06 ms, D = 3 0.38 / 0.38 / 0.46 / 0.99 ms.
+// D = 3 is the default: 0.07 ms more than D = 2 on untrained (near-zero) offsets, but trained offsets of a few cells stay on the fast path.
+template <typename TCOL, int CPL>
+__global__ __launch_bounds__(256) void deformable_col2im_gather_kernel(DeformBwdArgs a) {
+  const DeformColArgs& g = a.f;
+  constexpr int CW = 64 * CPL;                       // channels per wavefront
+  const int lane = threadIdx.x & 63;
+  const int chunks = g.C / CW, cpg = g.C / g.DG;
+  const long nwave = (long)g.B * g.H * g.W * chunks;
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= nwave) return;
+  const int ch = (int)(wid % chunks);
+  long r = wid / chunks;
+  const int X = (int)(r % g.W); r /= g.W;
+  const int Y = (int)(r % g.H);
+  const int b = (int)(r / g.H);
+  const int dgi = (ch * CW) / cpg;
+  const int D = a.win, side = 2 * D + 1, nwin = side * side;
+  const int ntap = g.KH * g.KW, ncand = ntap * nwin;
+  float acc[CPL];
+#pragma unroll
+  for (int e = 0; e < CPL; ++e) acc[e] = 0.f;
+  const TCOL* dc = (const TCOL*)a.dcol + ch * CW + lane * CPL;
+  for (int k0 = 0; k0 < ncand; k0 += 64) {
+    // lane k evaluates candidate k: tap (i, j), undeformed tap position (Y + dy, X + dx)
+    const int k = k0 + lane;
+    float wgt = 0.f;
+    int prow = 0, tap = 0;
+    if (k < ncand) {
+      tap = k / nwin;
+      const int wv = k - tap * nwin, dy = wv / side - D, dx = wv - (wv / side) * side - D;
+      const int i = tap / g.KW, j = tap - i * g.KW;
+      const int cy = Y + dy, cx = X + dx;
+      const int ho = cy + g.pad_h - i * g.dil_h, wo = cx + g.pad_w - j * g.dil_w;       // (stride 1)
+      if (ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo) {
+        const Taps t = deform_taps(g, b, ho, wo, i, j, dgi);
+        if (t.inside && pair_near(t, cy, cx, D)) {
+          if (t.ya == Y && t.xa == X) wgt += t.w1;
+          if (t.ya == Y && t.xb == X) wgt += t.w2;
+          if (t.yb == Y && t.xa == X) wgt += t.w3;
+          if (t.yb == Y && t.xb == X) wgt += t.w4;
+        }
+        prow = (b * g.Ho + ho) * g.Wo + wo;
+      }
+    }
+    unsigned long long hit = __ballot(wgt != 0.f);
+    while (hit) {                    // four hits per trip: their loads are in flight together (a one-hit loop is one L2 round trip per hit)
+      float w[4];
+      const TCOL* src_p[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool any = hit != 0ull;
+        const int src = any ? __ffsll((long long)hit) - 1 : 0;
+        hit &= hit - 1;              // (0 stays 0)
+        w[u] = any ? __shfl(wgt, src, 64) : 0.f;
+        const long row = __shfl(prow, src, 64);
+        const int tp = __shfl(tap, src, 64);
+        src_p[u] = dc + row * a.dcol_ld + (long)tp * g.C;        // (an exhausted slot re-reads lane 0's candidate row with weight 0: a valid address)
+      }
+      float v[4][CPL];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if constexpr (CPL == 1) v[u][0] = dld<TCOL>(src_p[u]);
+        else if constexpr (sizeof(TCOL) == 4) { const float2 q = *(const float2*)src_p[u]; v[u][0] = q.x; v[u][1] = q.y; }
+        else { const unsigned int q = *(const unsigned int*)src_p[u]; v[u][0] = __uint_as_float(q << 16); v[u][1] = __uint_as_float(q & 0xffff0000u); }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) acc[e] += w[u] * v[u][e];
+    }
+  }
+  float* gd = a.grad_data + (long)b * a.gs_b + (long)Y * a.gs_h + (long)X * a.gs_w + (long)(ch * CW + lane * CPL);       // (gs_c == 1)
+#pragma unroll
+  for (int e = 0; e < CPL; ++e) gd[e] += acc[e];
+}
+
+// Offset gradients: one thread per (pixel, tap, 8-channel chunk) on channels-last bf16 data,
+// four 16-byte corner loads; the two offset gradients are reduced over the chunk's 8 channels in registers, over the deformable
+// group's chunks with lane shuffles (cpg / 8 consecutive lanes, a power of two <= 64), one atomic pair per group.
+template <typename TCOL>
+__global__ __launch_bounds__(256) void deformable_col2im_offset_kernel(DeformBwdArgs a) {
+  const DeformColArgs& g = a.f;
+  const int chunks = g.C / 8, cpg = g.C / g.DG, lpg = cpg / 8;      // lanes per deformable group
+  const long total = (long)g.B * g.Ho * g.Wo * g.KH * g.KW * chunks;
+  for (long base = (long)blockIdx.x * 256; base < total; base += (long)gridDim.x * 256) {
+    const long idx = base + threadIdx.x;
+    const bool live = idx < total;
+    const long id = live ? idx : total - 1;
+    const int cc = (int)(id % chunks);
+    long r = id / chunks;
+    const int tap = (int)(r % (g.KH * g.KW)); r /= (g.KH * g.KW);
+    const int wo = (int)(r % g.Wo); r /= g.Wo;
+    const int ho = (int)(r % g.Ho);
+    const int b = (int)(r / g.Ho);
+    const int c = cc * 8, dgi = c / cpg;
+    const int i = tap / g.KW, j = tap - i * g.KW;
+    const Taps t = deform_taps(g, b, ho, wo, i, j, dgi);
+    const long row = ((long)b * g.Ho + ho) * g.Wo + wo;
+    float doh = 0.f, dow = 0.f;
+    if (live && t.inside) {
+      float gv[8];
+      const TCOL* dp = (const TCOL*)a.dcol + row * a.dcol_ld + (long)tap * g.C + c;
+      if constexpr (sizeof(TCOL) == 4) {
+        const float4 g0 = *(const float4*)dp, g1 = *(const float4*)(dp + 4);
+        gv[0] = g0.x; gv[1] = g0.y; gv[2] = g0.z; gv[3] = g0.w; gv[4] = g1.x; gv[5] = g1.y; gv[6] = g1.z; gv[7] = g1.w;
+      } else {
+        const uint4 q = *(const uint4*)dp;
+        const unsigned int u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gv[2 * e] = __uint_as_float(u[e] << 16); gv[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
+      }
+      const unsigned short* p = (const unsigned short*)g.data + (long)b * g.ds_b + c;
+      const uint4 q1 = *(const uint4*)(p + (long)t.ya * g.ds_h + (long)t.xa * g.ds_w);
+      const uint4 q2 = *(const uint4*)(p + (long)t.ya * g.ds_h + (long)t.xb * g.ds_w);
+      const uint4 q3 = *(const uint4*)(p + (long)t.yb * g.ds_h + (long)t.xa * g.ds_w);
+      const uint4 q4 = *(const uint4*)(p + (long)t.yb * g.ds_h + (long)t.xb * g.ds_w);
+      const unsigned int* a1 = (const unsigned int*)&q1; const unsigned int* a2 = (const unsigned int*)&q2;
+      const unsigned int* a3 = (const unsigned int*)&q3; const unsigned int* a4 = (const unsigned int*)&q4;
+      const float hw = t.w1 + t.w3, lw = t.w2 + t.w4, hh = t.w1 + t.w2, lh = t.w3 + t.w4;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = e >> 1;
+        const float v1 = (e & 1) ? __uint_as_float(a1[k] & 0xffff0000u) : __uint_as_float(a1[k] << 16);
+        const float v2 = (e & 1) ? __uint_as_float(a2[k] & 0xffff0000u) : __uint_as_float(a2[k] << 16);
+        const float v3 = (e & 1) ? __uint_as_float(a3[k] & 0xffff0000u) : __uint_as_float(a3[k] << 16);
+        const float v4 = (e & 1) ? __uint_as_float(a4[k] & 0xffff0000u) : __uint_as_float(a4[k] << 16);
+        doh += gv[e] * (hw * (v3 - v1) + lw * (v4 - v2));
+        dow += gv[e] * (hh * (v2 - v1) + lh * (v4 - v3));
+      }
+    }
+    if (a.grad_offset) {
+      for (int o = lpg >> 1; o > 0; o >>= 1) { doh += __shfl_xor(doh, o, 64); dow += __shfl_xor(dow, o, 64); }
+      if (live && (cc % lpg) == 0) {
+        float* go = a.grad_offset + (long)b * a.os_b + (long)ho * a.os_h + (long)wo * a.os_w + (long)(dgi * 2 * g.KH * g.KW + 2 * tap) * a.os_c;
+        atomicAdd(go, doh); atomicAdd(go + a.os_c, dow);
+      }
+    }
+  }
+}
+
+// The FAR pairs' data gradient (companion of the two kernels above): lane = one (pixel, tap, deformable group) triple decides near / far with
+// the same deform_taps() + pair_near(); the wavefront then walks the far ones together, lane = channel (coalesced column-gradient loads and
+// float atomics).  While the learned offsets stay inside the window nothing is far and this is a pass over the offsets only.
+template <typename TCOL>
+__global__ __launch_bounds__(256) void deformable_col2im_far_kernel(DeformBwdArgs a) {
+  const DeformColArgs& g = a.f;
+  const int ntap = g.KH * g.KW, cpg = g.C / g.DG;
+  const long total = (long)g.B * g.Ho * g.Wo * ntap * g.DG;
+  const int lane = threadIdx.x & 63;
+  for (long base = (long)blockIdx.x * 256 + (threadIdx.x & ~63); base < total; base += (long)gridDim.x * 256) {
+    const long id = base + lane;
+    bool far = false;
+    Taps t{};
+    int b = 0, dgi = 0, tap = 0;
+    long row = 0;
+    if (id < total) {
+      dgi = (int)(id % g.DG);
+      long r = id / g.DG;
+      tap = (int)(r % ntap); r /= ntap;
+      const int wo = (int)(r % g.Wo); r /= g.Wo;
+      const int ho = (int)(r % g.Ho);
+      b = (int)(r / g.Ho);
+      const int i = tap / g.KW, j = tap - i * g.KW;
+      t = deform_taps(g, b, ho, wo, i, j, dgi);
+      const int cy = ho * g.stride_h - g.pad_h + i * g.dil_h, cx = wo * g.stride_w - g.pad_w + j * g.dil_w;
+      far = t.inside && !pair_near(t, cy, cx, a.win);
+      row = ((long)b * g.Ho + ho) * g.Wo + wo;
+    }
+    unsigned long long m = __ballot(far);
+    while (m) {
+      const int src = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int ya = __shfl(t.ya, src, 64), yb = __shfl(t.yb, src, 64), xa = __shfl(t.xa, src, 64), xb = __shfl(t.xb, src, 64);
+      const float w1 = __shfl(t.w1, src, 64), w2 = __shfl(t.w2, src, 64), w3 = __shfl(t.w3, src, 64), w4 = __shfl(t.w4, src, 64);
+      const int sb = __shfl(b, src, 64), sd = __shfl(dgi, src, 64), st = __shfl(tap, src, 64);
+      const long srow = __shfl(row, src, 64);
+      for (int c = sd * cpg + lane; c < (sd + 1) * cpg; c += 64) {
+        const float gv = dld<TCOL>((const TCOL*)a.dcol + srow * a.dcol_ld + (long)st * g.C + c);
+        float* gd = a.grad_data + (long)sb * a.gs_b + (long)c * a.gs_c;
+        atomicAdd(gd + (long)ya * a.gs_h + (long)xa * a.gs_w, w1 * gv);
+        atomicAdd(gd + (long)ya * a.gs_h + (long)xb * a.gs_w, w2 * gv);
+        atomicAdd(gd + (long)yb * a.gs_h + (long)xa * a.gs_w, w3 * gv);
+        atomicAdd(gd + (long)yb * a.gs_h + (long)xb * a.gs_w, w4 * gv);
+      }
+    }
+  }
+}
 
 struct PsroiBwdArgs {
   PsroiArgs f;                       // forward description (data values, rois, trans, shapes); f.out unused
@@ -611,6 +817,9 @@ __global__ __launch_bounds__(256) void deformable_psroi_pool_bwd_kernel(PsroiBwd
 
 }  // namespace relnet
 
+static int g_col2im_mode = 0;     // measurement / test knob: 0 auto (gather + offset + far-only kernels where they apply), 1 = the atomic scatter kernel, 2 = every pair treated as FAR, 10 + D = window radius D
+extern "C" void relnet_deformable_col2im_debug(int mode) { g_col2im_mode = mode; }
+
 extern "C" int relnet_deformable_col2im(const void* dcol, long dcol_ld, int dcol_dtype, const void* data,
                                         const long* data_strides4, int data_dtype, const float* offset,
                                         const long* offset_strides4, float* grad_data, const long* grad_data_strides4,
@@ -636,6 +845,34 @@ extern "C" int relnet_deformable_col2im(const void* dcol, long dcol_ld, int dcol
   a.grad_offset = grad_offset;
   if (grad_offset) { a.os_b = grad_offset_strides4[0]; a.os_c = grad_offset_strides4[1]; a.os_h = grad_offset_strides4[2]; a.os_w = grad_offset_strides4[3]; }
   hipStream_t s = (hipStream_t)stream;
+  // gather form (round 6): stride 1, channels-last bf16 data, dense channels-last fp32 gradient, whole 64-channel runs per deformable group,
+  // lanes-per-group a power of two, 16-byte aligned rows.  g_col2im_mode: 0 auto (window radius 3), 1 = scatter kernel only, 2 = every pair
+  // declared FAR (offset kernel + the scatter kernel's far-only pass: the consistency check of the two), 10 + D = window radius D
+  a.win = 0;
+  const int cpg = C / num_deformable_group, lpg = cpg / 8;
+  const bool gather_ok = g_col2im_mode != 1 && data_dtype == RELNET_BF16 && stride_h == 1 && stride_w == 1 && g.Ho == H && g.Wo == W &&
+                         g.ds_c == 1 && a.gs_c == 1 && cpg % 64 == 0 && lpg <= 64 && (lpg & (lpg - 1)) == 0 && (64 % lpg) == 0 &&
+                         g.ds_h % 8 == 0 && g.ds_w % 8 == 0 && g.ds_b % 8 == 0 && (((uintptr_t)data) & 15) == 0 &&
+                         dcol_ld % 8 == 0 && (((uintptr_t)dcol) & 15) == 0 && (long)B * g.Ho * g.Wo < (1L << 31);
+  if (gather_ok) {
+    const bool all_far = g_col2im_mode == 2;
+    a.win = all_far ? -1 : (g_col2im_mode >= 10 ? g_col2im_mode - 10 : 3);       // (-1: no pair is near)
+    const int cpl = (cpg % 128 == 0) ? 2 : 1;
+    const long nwave = (long)B * H * W * (C / (64 * cpl));
+    const unsigned ggrid = (unsigned)((nwave + 3) / 4), ogrid = grid_for((long)B * g.Ho * g.Wo * KH * KW * (C / 8));
+    if (a.dcol_f32) {
+      if (!all_far) { if (cpl == 2) deformable_col2im_gather_kernel<float, 2><<<ggrid, 256, 0, s>>>(a); else deformable_col2im_gather_kernel<float, 1><<<ggrid, 256, 0, s>>>(a); }
+      deformable_col2im_offset_kernel<float><<<ogrid, 256, 0, s>>>(a);
+    } else {
+      if (!all_far) { if (cpl == 2) deformable_col2im_gather_kernel<unsigned short, 2><<<ggrid, 256, 0, s>>>(a); else deformable_col2im_gather_kernel<unsigned short, 1><<<ggrid, 256, 0, s>>>(a); }
+      deformable_col2im_offset_kernel<unsigned short><<<ogrid, 256, 0, s>>>(a);
+    }
+    // the pairs beyond the window: atomic scatter (a pass over the offsets only while they stay below the window radius)
+    const unsigned fgrid = grid_for((long)B * g.Ho * g.Wo * KH * KW * num_deformable_group);
+    if (a.dcol_f32) deformable_col2im_far_kernel<float><<<fgrid, 256, 0, s>>>(a);
+    else deformable_col2im_far_kernel<unsigned short><<<fgrid, 256, 0, s>>>(a);
+    return check_launch("relnet_deformable_col2im");
+  }
   const unsigned grid = grid_for((long)B * g.Ho * g.Wo * KH * KW * C);
   if (data_dtype == RELNET_F32) deformable_col2im_kernel<float><<<grid, 256, 0, s>>>(a);
   else if (data_dtype == RELNET_BF16) deformable_col2im_kernel<unsigned short><<<grid, 256, 0, s>>>(a);

@@ -119,6 +119,7 @@ _SIGNATURES = {
     'relnet_chain_debug': (None, [_i]),
     'relnet_gemm_tile_count': (C.c_int, []),
     'relnet_gemm_set_workspace': (C.c_int, [_vp, _l]),
+    'relnet_deformable_col2im_debug': (None, [_i]),
     'relnet_stream_capture_id': (C.c_ulonglong, [_vp]),
     'relnet_gemm_debug_splitk': (None, [_i]),
     'relnet_gemm_pick_tile': (C.c_int, [_i, _i, _i, _i, _i]),

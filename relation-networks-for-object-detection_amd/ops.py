@@ -1287,10 +1287,12 @@ def deformable_conv_bwd(data, offset, w_packed, dy, kernel=(3, 3), stride=(1, 1)
     if Cout % gran:
         dyp = torch.zeros((dy2.shape[0], w_t.shape[1]), device=dy2.device, dtype=dy2.dtype)
         dyp[:, :Cout] = dy2
-    dcol = gemm_nt(dyp, w_t, out_dtype=torch.float32)
+    # (bf16 layers: the column gradient is rounded to bf16 like every other data gradient of the bf16 trunk -- the gather form of col2im reads
+    #  each of its rows ~4 times)
+    dcol = gemm_nt(dyp, w_t, out_dtype=torch.float32 if data.dtype == torch.float32 else torch.bfloat16)
     gdata = torch.zeros((B, H, W, Cc), device=data.device, dtype=torch.float32).permute(0, 3, 1, 2)
     goff = torch.zeros((B, offset.shape[2], offset.shape[3], offset.shape[1]), device=data.device, dtype=torch.float32).permute(0, 3, 1, 2)
-    _lib.call('relnet_deformable_col2im', dcol.data_ptr(), dcol.stride(0), F32, data.data_ptr(), _strides4(data), _dt(data),
+    _lib.call('relnet_deformable_col2im', dcol.data_ptr(), dcol.stride(0), _dt(dcol), data.data_ptr(), _strides4(data), _dt(data),
               offset.data_ptr(), _strides4(offset), gdata.data_ptr(), _strides4(gdata), goff.data_ptr(), _strides4(goff),
               B, Cc, H, W, kh, kw, ph, pw, sh, sw, dh, dw, num_deformable_group, _stream())
     col, _ = deformable_im2col(data, offset, kernel, stride, dilate, pad, num_deformable_group, col_dtype=dy2.dtype)

@@ -288,8 +288,8 @@ def _relerr(a, b):
 @pytest.mark.parametrize('dtype,C,dg', [('f32', 64, 4), ('bf16', 64, 4), ('f32', 256, 2), ('bf16', 256, 2), ('bf16', 256, 4)])
 def test_deformable_convolution_backward(dtype, C, dg):
     """C = 256, dg = 2: 128 channels per deformable group -> the in-wave reduction path of the offset gradient (res5 shape).
-    bf16 with >= 64 channels per group runs the LDS-aggregated col2im kernel: ragged 8 x 16 tiles, offsets (sigma 1.5) that leave
-    its window margin of 3 cells and take the direct-to-memory path; dg = 4 on a 19 x 37 map spans several tiles per image."""
+    bf16 with >= 64 channels per group runs the round-6 pair of kernels (data gradient GATHERED per feature cell from the pairs within one
+    cell of their undeformed tap position, atomics for the others): offsets of sigma 1.5 put about half of the pairs on each path."""
     ops, _ = _mods()
     from oracle import deform_torch as DT
     rng = np.random.default_rng(21)
@@ -317,6 +317,38 @@ def test_deformable_convolution_backward(dtype, C, dg):
     assert _relerr(go.permute(0, 3, 1, 2).cpu().numpy(), to.grad.numpy()) <= tol
     want_w = tw.grad.permute(0, 2, 3, 1).reshape(Co, -1).numpy()
     assert _relerr(gw.cpu().numpy(), want_w) <= (2e-4 if dtype == 'f32' else 5e-3)
+
+
+@pytest.mark.parametrize('sigma', [0.3, 1.5, 40.0])
+def test_col2im_gather_form_equals_the_atomic_scatter(sigma):
+    """relnet_deformable_col2im on a res5-sized layer (8 x 38 x 63 x 512, 4 deformable groups, dilation 2): the gather + offset kernels
+    (mode 0: window radius 3; modes 11 / 12: radius 1 / 2) against the one-kernel atomic scatter (mode 1) and against every pair treated as
+    FAR (mode 2).  sigma 0.3: every pair is NEAR (no data-gradient atomics at all); 1.5: a mix; 40: nearly all FAR or outside the map.  Same products, different fp32
+    summation order."""
+    ops, _ = _mods()
+    from relnet_amd import lib
+    L = lib.load()
+    g_ = torch.Generator().manual_seed(int(sigma * 10))
+    B, C, H, W, Co, dg = 8, 512, 38, 63, 512, 4
+    x = torch.randn(B, C, H, W, generator=g_).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    o = (torch.randn(B, 18 * dg, H, W, generator=g_) * sigma).cuda()
+    dy = torch.randn(B, Co, H, W, generator=g_).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wp = (torch.randn(Co, 9 * C, generator=g_) * 0.02).cuda().to(torch.bfloat16)
+    res = {}
+    try:
+        for mode in (1, 0, 2, 11, 12):
+            L.relnet_deformable_col2im_debug(mode)
+            gd, go, _ = ops.deformable_conv_bwd(x, o, wp, dy, 3, 1, 2, 2, dg)
+            torch.cuda.synchronize()
+            res[mode] = (gd.clone(), go.clone())
+    finally:
+        L.relnet_deformable_col2im_debug(0)
+    for mode in (0, 2, 11, 12):
+        for what, a, b_ in (('grad_data', res[mode][0], res[1][0]), ('grad_offset', res[mode][1], res[1][1])):
+            scale = b_.abs().max().item()
+            assert scale > 0
+            err = (a - b_).abs().max().item() / scale
+            assert err < 2e-5, (sigma, mode, what, err)
 
 
 @pytest.mark.parametrize("case", PSROI_CASES)
