@@ -248,16 +248,28 @@ def other_configs(a, rank, world, D):
         out[key] = r
         del det, step
         torch.cuda.empty_cache()
-    for key, dcn, fpn, bsz in (('configs3_dcn_relation_learn_nms_training', True, False, 8),
-                               ('configs4_fpn_relation_learn_nms_training', False, True, 2)):
-        ta = argparse.Namespace(**vars(a))
-        ta.batch, ta.learn_nms, ta.dcn, ta.fpn, ta.steps, ta.warmup, ta.no_graph = bsz, True, dcn, fpn, 5, 2, False
-        tr = _side_figure(lambda: bench_train(ta, rank, world, D, emit=False, fatal=False), key)
+    # training steps: 8 images per GPU and step like the headline training figure (configs[2]); round 6: also for the FPN graph, whose
+    # 2-image step of rounds 2-5 (6 400-pixel res4 maps: every convolution a launch of < 1 workgroup per CU) stays beside it as `at_2_images_per_gpu`
+    for key, dcn, fpn, bsz, also in (('configs3_dcn_relation_learn_nms_training', True, False, 8, ()),
+                                     ('configs4_fpn_relation_learn_nms_training', False, True, 8, (2,))):
+        def one(bsz_):
+            ta = argparse.Namespace(**vars(a))
+            ta.batch, ta.learn_nms, ta.dcn, ta.fpn, ta.steps, ta.warmup, ta.no_graph = bsz_, True, dcn, fpn, 5, 2, False
+            tr = _side_figure(lambda: bench_train(ta, rank, world, D, emit=False, fatal=False), key)
+            if rank != 0:
+                return None
+            r = tr if (tr is None or 'error' in tr) else dict({k: tr[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'n_gpus', 'weights_finite_on_all_ranks')},
+                                                               **{k: tr['config'][k] for k in ('experiment', 'first_n', 'ohem', 'lr', 'lr_rule', 'relation_bwd_of_the_learn_nms_head')})
+            if r is not None:
+                r['images_per_gpu_per_step'] = bsz_
+            return r
+        main = one(bsz)
+        extra = {'at_%d_images_per_gpu' % b_: one(b_) for b_ in also}
         if rank == 0:
-            out[key] = tr if (tr is None or 'error' in tr) else dict({k: tr[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'n_gpus', 'weights_finite_on_all_ranks')},
-                                                                     **{k: tr['config'][k] for k in ('experiment', 'first_n', 'ohem', 'lr', 'lr_rule', 'relation_bwd_of_the_learn_nms_head')})
-            if out[key] is not None:
-                out[key]['images_per_gpu_per_step'] = bsz
+            out[key] = main
+            if main is not None:
+                for k_, v_ in extra.items():
+                    main[k_] = v_ if (v_ is None or 'error' in v_) else {k: v_[k] for k in ('value', 'ms_per_step', 'steps', 'lr')}
     return out if rank == 0 else None
 
 
