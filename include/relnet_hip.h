@@ -484,7 +484,7 @@ int relnet_lnms_scatter_bwd(const float* d_sorted, const int* rank_idx, float* d
  *   softmax_bwd    :430-433  prob = softmax(cls_score)[:, 1:]: d_cls[b][n][0] += -(1 - sum prob) inner, d_cls[b][n][1 + c] += prob_c (d_prob_c - inner),
  *                  inner = sum_c prob_c d_prob_c; d_cls rows ld_row apart, images ld_img apart (ACCUMULATES into the detector's own cls_score gradient) */
 /* out[0] = scale * sum(x[0..n))  (mode 0)  or  the count of entries >= 0 (mode 1): the scalar metrics of a training step (the MakeLoss outputs the
- * reference's metric classes sum per image, core/metric.py; the OHEM keep count) -- one single-workgroup, deterministic launch each */
+ * reference's metric classes sum per image, core/metric.py; the OHEM keep count) -- a 4-byte memset + one launch of <= 64 workgroups each */
 int relnet_reduce_scalar(const float* x, long n, float scale, int mode, float* out, void* stream);
 int relnet_lnms_pad_params(const void* wo, const float* bo, const void* wl, const float* bl, void* wout_pad, float* bout_pad, void* wl_pad,
                            float* bl_pad, int T, void* stream);

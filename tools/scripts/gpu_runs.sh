@@ -47,8 +47,8 @@ case $WHAT in
     cp $(find /tmp/p54 -name "*kernel_stats.csv" | head -1) $O/bench_b54_kernel_stats.csv
     rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python $R/bench.py $P --batch 1 --steps 50 > /tmp/p1.log 2>&1
     cp $(find /tmp/p1 -name "*kernel_stats.csv" | head -1) $O/bench_b1_kernel_stats.csv
-    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -- python $R/bench.py --train --learn-nms --batch 8 --steps 10 --warmup 3 > /tmp/pt.log 2>&1
-    cp $(find /tmp/pt -name "*kernel_stats.csv" | head -1) $O/train_lnms_b8_kernel_stats.csv; ls -la $O ;;
+    rm -rf /tmp/pt_prof; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt_prof -- python $R/bench.py --train --learn-nms --batch 8 --steps 10 --warmup 3 > /tmp/pt.log 2>&1
+    cp $(find /tmp/pt_prof -name "*kernel_stats.csv" | head -1) $O/train_lnms_b8_kernel_stats.csv; ls -la $O ;;
   pmc_attn)
     cd /tmp && export TMPDIR=/tmp
     for NB in ${ATTN_BATCHES:-108 54}; do
@@ -69,8 +69,9 @@ case $WHAT in
   proftrain)
     cd /tmp && export TMPDIR=/tmp
     # EXTRA="--dcn" (configs[3]) / EXTRA="--fpn" BATCH=2 (configs[4]) profile the other training graphs: NAME=train_dcn_lnms ...
-    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -- python $R/bench.py --train --learn-nms $EXTRA --batch ${BATCH:-8} --steps 10 --warmup 3 > /tmp/pt.log 2>&1
-    cp $(find /tmp/pt -name "*kernel_stats.csv" | head -1) $O/${NAME:-train_lnms}_b${BATCH:-8}_kernel_stats.csv; tail -2 /tmp/pt.log; ls -la $O ;;
+    PD=/tmp/pt_${NAME:-train_lnms}_b${BATCH:-8}; rm -rf $PD      # (a fresh directory per run: `find | head -1` below must not pick up an earlier trace)
+    rocprofv3 --kernel-trace --stats --output-format csv -d $PD -- python $R/bench.py --train --learn-nms $EXTRA --batch ${BATCH:-8} --steps 10 --warmup 3 > /tmp/pt.log 2>&1
+    cp $(find $PD -name "*kernel_stats.csv" | head -1) $O/${NAME:-train_lnms}_b${BATCH:-8}_kernel_stats.csv; tail -2 /tmp/pt.log; ls -la $O ;;
   pmc_trunk)    # round 5: counters of the asm ring tile (res4 3x3, res5 3x3) and of chain256_roles_kernel, 54 images, separate passes per group
                 # (the training step's shapes: TAG=r05_pmc_trunk8 IMAGES=8 TILE=4 KERNELS="res4_3x3 chain256" ... pmc_trunk, folded with `pmc_trunk_fold.py trunk8`)
     cd /tmp && export TMPDIR=/tmp
