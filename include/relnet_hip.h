@@ -545,6 +545,10 @@ int relnet_wgrad_grouped(const relnet_wgrad_desc* descs, int n, void* table_work
  * relnet_debug_tr_probe dumps what ds_read_b64_tr_b16 returns for lane-linear addresses (256 values).                 */
 void relnet_wgrad_debug_plain(int on);
 void relnet_wgrad_tune(int workgroups, int mode, int wave_rows);
+/* share rule of relnet_wgrad_grouped: 0 / 1 = stream-K shares + float atomics (default), 2 = every workgroup owns WHOLE output tiles and flushes them by plain
+ * read-modify-write (bit-identical reruns; needs the layers of the group to accumulate into disjoint memory, which the entry point checks -- otherwise the atomics
+ * stay).  Round 6, measured slower at every batch size (one image: 7.16 -> 8.14 ms per training step): opt-in */
+void relnet_wgrad_debug_tiles(int mode);
 int relnet_debug_tr_probe(unsigned short* out256, void* stream);
 
 /* d pair_pos_fc1_{weight [16][64], bias [16]} += from dlog and the forward's fp32 bias (= log max(G,1e-6)):

@@ -39,6 +39,7 @@ struct WgradProblem {
   int Hout, Wout, Hin, Win;
   int tiles_m, tiles_n, slabs;                           // output tiles and 64-pixel slabs of this problem
   int unit_start;                                        // first work unit of this problem in the launch
+  int tile_start;                                        // first output tile of this problem in the launch (tile-aligned shares)
 };
 
 struct WgradTableChunk { WgradProblem p[16]; int n, offset; };
@@ -77,7 +78,7 @@ __device__ __forceinline__ bf16x8 frag_plain(const unsigned short* slab, int kk,
 // mode (measurement aids): 1 no flush, 4 no global loads; plain: fragments by scalar LDS reads (test aid).
 template <int WM, bool PLAIN>
 __global__ __launch_bounds__(128 * WM) void wgrad_streamk_kernel(const WgradProblem* __restrict__ table, int nprob, int total_units,
-                                                                 int mode) {
+                                                                 int mode, int total_tiles) {
   constexpr int kBM = 64 * WM, kLdA = kBM + 32, NT = 128 * WM;
   constexpr int kAchunks = kBM / 8, kArows = NT / kAchunks, kApass = kWgBP / kArows;     // dY slab: rows per pass, passes
   constexpr int kBchunks = kWgBN / 8, kBrows = NT / kBchunks, kBpass = kWgBP / kBrows;
@@ -88,9 +89,24 @@ __global__ __launch_bounds__(128 * WM) void wgrad_streamk_kernel(const WgradProb
   const int wm = wave % WM, wn = wave / WM;
   const int l31 = lane & 31, half = lane >> 5;
   // this workgroup's share of the work units
+  // total_tiles > 0 (round 6, opt-in): the shares are cut at TILE boundaries -- a workgroup owns whole output tiles, so the flush below is a plain
+  // read-modify-write instead of float atomics (deterministic; slower than the balanced shares: see relnet_wgrad_grouped).
   const long G = gridDim.x;
-  int u = (int)(((long)total_units * blockIdx.x) / G);
-  const int u_end = (int)(((long)total_units * (blockIdx.x + 1)) / G);
+  int u, u_end;
+  const bool whole_tiles = total_tiles > 0;
+  if (whole_tiles) {
+    auto tile_unit = [&](int t) {
+      if (t >= total_tiles) return total_units;
+      int lo = 0, hi = nprob - 1;
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (table[mid].tile_start <= t) lo = mid; else hi = mid - 1; }
+      return table[lo].unit_start + (t - table[lo].tile_start) * table[lo].slabs;
+    };
+    u = tile_unit((int)(((long)total_tiles * blockIdx.x) / G));
+    u_end = tile_unit((int)(((long)total_tiles * (blockIdx.x + 1)) / G));
+  } else {
+    u = (int)(((long)total_units * blockIdx.x) / G);
+    u_end = (int)(((long)total_units * (blockIdx.x + 1)) / G);
+  }
   const int ca = tid % kAchunks, ra0 = tid / kAchunks;
   const int cb = tid % kBchunks, rb0 = tid / kBchunks;
   const bool no_loads = (mode & 4) != 0;
@@ -242,7 +258,11 @@ __global__ __launch_bounds__(128 * WM) void wgrad_streamk_kernel(const WgradProb
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           const int col = n0 + 128 * wn + 32 * ni + l31;
-          if (col < a.Ktot) unsafeAtomicAdd(a.dw + (long)row * a.dw_ld + col, s2 * acc[mi][ni][r]);
+          if (col < a.Ktot) {
+            float* dst = a.dw + (long)row * a.dw_ld + col;
+            if (whole_tiles) *dst += s2 * acc[mi][ni][r];            // this workgroup is the tile's only writer in this launch
+            else unsafeAtomicAdd(dst, s2 * acc[mi][ni][r]);
+          }
         }
       }
   }
@@ -265,7 +285,8 @@ __global__ __launch_bounds__(64) void tr_probe_kernel(unsigned short* out) {
 
 using namespace relnet;
 
-static int g_wgrad_debug_plain = 0, g_wgrad_blocks = 0, g_wgrad_mode = 0, g_wgrad_wm = 0;
+static int g_wgrad_debug_plain = 0, g_wgrad_blocks = 0, g_wgrad_mode = 0, g_wgrad_wm = 0, g_wgrad_tiles = 0;
+extern "C" void relnet_wgrad_debug_tiles(int mode) { g_wgrad_tiles = mode; }
 extern "C" void relnet_wgrad_debug_plain(int on) { g_wgrad_debug_plain = on; }
 // measurement knobs (tools/bench_wgrad.py): persistent workgroups per launch (0 = one per CU), ablation mode bits, forced
 // wavefront rows (0 = by shape)
@@ -318,7 +339,8 @@ extern "C" int relnet_wgrad_grouped(const relnet_wgrad_desc* descs, int n, void*
   for (int i = 0; i < n; ++i) max_cout = descs[i].Cout > max_cout ? descs[i].Cout : max_cout;
   const int wm = g_wgrad_wm ? g_wgrad_wm : (max_cout > 128 ? 4 : 2);
   const int bm = 64 * wm;
-  long units = 0;
+  long units = 0, tiles = 0;
+  int max_slabs = 0;
   WgradTableChunk c;
   c.n = 0; c.offset = 0;
   for (int i = 0; i < n; ++i) {
@@ -326,7 +348,10 @@ extern "C" int relnet_wgrad_grouped(const relnet_wgrad_desc* descs, int n, void*
     if (wgrad_fill(descs[i], bm, &p) != 0) return -1;
     RELNET_REQUIRE(units + (long)p.tiles_m * p.tiles_n * p.slabs < (1L << 31), "relnet_wgrad_grouped: too many work units");
     p.unit_start = (int)units;
+    p.tile_start = (int)tiles;
     units += (long)p.tiles_m * p.tiles_n * p.slabs;
+    tiles += (long)p.tiles_m * p.tiles_n;
+    max_slabs = p.slabs > max_slabs ? p.slabs : max_slabs;
     if (++c.n == 16 || i == n - 1) {
       wgrad_fill_table_kernel<<<1, 64, 0, s>>>(c, (WgradProblem*)table_workspace);
       c.offset += c.n; c.n = 0;
@@ -334,6 +359,22 @@ extern "C" int relnet_wgrad_grouped(const relnet_wgrad_desc* descs, int n, void*
   }
   int blocks = g_wgrad_blocks > 0 ? g_wgrad_blocks : 256;
   if (units < blocks) blocks = (int)units;
+  // whole-tile shares (no atomics, bit-identical reruns): OPT-IN (g_wgrad_tiles = 2).  Built in round 6 on the estimate that the atomic flush was 0.5 of the
+  // 0.77 ms the seven launches of a one-image step take; measured, same box (tools/scripts/r06_ab3.sh): one image 7.16 ms with stream-K shares, 8.14 ms with
+  // whole tiles, two images 9.44 / 11.34 ms -- the fire-and-forget atomics overlap the next unit's loads, and what whole tiles add is up to one tile of
+  // imbalance per workgroup (400 tiles on 256 workgroups = two rounds) plus the read of the read-modify-write.  Needs the layers of the group to accumulate
+  // into disjoint memory (checked here; otherwise the atomics stay).  g_wgrad_tiles: 0 / 1 = stream-K shares, 2 = whole tiles whenever the writers are disjoint
+  bool disjoint = true;
+  for (int i = 0; i < n && disjoint; ++i)
+    for (int j = i + 1; j < n && disjoint; ++j) {
+      const float* a0 = descs[i].dw; const float* a1 = a0 + (long)(descs[i].Cout - 1) * descs[i].dw_ld + (long)descs[i].ks * descs[i].ks * descs[i].Cin;
+      const float* b0 = descs[j].dw; const float* b1 = b0 + (long)(descs[j].Cout - 1) * descs[j].dw_ld + (long)descs[j].ks * descs[j].ks * descs[j].Cin;
+      if (a0 < b1 && b0 < a1) disjoint = false;
+    }
+  const bool whole = disjoint && g_wgrad_tiles == 2;
+  (void)max_slabs;
+  if (whole && tiles < blocks) blocks = (int)tiles;
+  const int total_tiles = whole ? (int)tiles : 0;
   const size_t lds = (size_t)2 * kWgBP * ((bm + 32) + kWgLdB) * 2;
   static relnet::PerDeviceOnce attr_once;
   if (attr_once.first()) {
@@ -344,11 +385,11 @@ extern "C" int relnet_wgrad_grouped(const relnet_wgrad_desc* descs, int n, void*
   }
   const WgradProblem* tb = (const WgradProblem*)table_workspace;
   if (g_wgrad_debug_plain) {
-    if (wm == 4) wgrad_streamk_kernel<4, true><<<blocks, 512, lds, s>>>(tb, n, (int)units, g_wgrad_mode);
-    else wgrad_streamk_kernel<2, true><<<blocks, 256, lds, s>>>(tb, n, (int)units, g_wgrad_mode);
+    if (wm == 4) wgrad_streamk_kernel<4, true><<<blocks, 512, lds, s>>>(tb, n, (int)units, g_wgrad_mode, total_tiles);
+    else wgrad_streamk_kernel<2, true><<<blocks, 256, lds, s>>>(tb, n, (int)units, g_wgrad_mode, total_tiles);
   } else {
-    if (wm == 4) wgrad_streamk_kernel<4, false><<<blocks, 512, lds, s>>>(tb, n, (int)units, g_wgrad_mode);
-    else wgrad_streamk_kernel<2, false><<<blocks, 256, lds, s>>>(tb, n, (int)units, g_wgrad_mode);
+    if (wm == 4) wgrad_streamk_kernel<4, false><<<blocks, 512, lds, s>>>(tb, n, (int)units, g_wgrad_mode, total_tiles);
+    else wgrad_streamk_kernel<2, false><<<blocks, 256, lds, s>>>(tb, n, (int)units, g_wgrad_mode, total_tiles);
   }
   return check_launch("relnet_wgrad_grouped");
 }

@@ -94,6 +94,7 @@ _SIGNATURES = {
     'relnet_wgrad_workspace_bytes': (C.c_long, [_i]),
     'relnet_wgrad_debug_plain': (None, [_i]),
     'relnet_wgrad_tune': (None, [_i, _i, _i]),
+    'relnet_wgrad_debug_tiles': (None, [_i]),
     'relnet_debug_tr_probe': (C.c_int, [_vp, _vp]),
     'relnet_gemm_force_tile': (None, [_i]),
     'relnet_gemm_get_forced_tile': (C.c_int, []),
@@ -178,14 +179,14 @@ def load():
         fn.argtypes = args
     # A/B knobs for whole-step measurements without editing code.  They change which kernels run, so they are honoured only
     # together with RELNET_DEBUG_KNOBS=1 and every use is announced on stderr (a forced tile is a measured-slower configuration)
-    knobs = [(k, os.environ[k]) for k in ('RELNET_GEMM_KORDER', 'RELNET_GEMM_FORCE_TILE', 'RELNET_GEMM_ASM', 'RELNET_GEMM_SPLITK') if os.environ.get(k)]
+    knobs = [(k, os.environ[k]) for k in ('RELNET_GEMM_KORDER', 'RELNET_GEMM_FORCE_TILE', 'RELNET_GEMM_ASM', 'RELNET_GEMM_SPLITK', 'RELNET_WGRAD_TILES') if os.environ.get(k)]
     if knobs and os.environ.get('RELNET_DEBUG_KNOBS') != '1':
         sys.stderr.write('relnet: ignoring %s (set RELNET_DEBUG_KNOBS=1 to apply kernel-selection knobs)\n' % ', '.join(k for k, _ in knobs))
     elif knobs:
         sys.stderr.write('relnet: DEBUG kernel-selection knobs in effect: %s\n' % ', '.join('%s=%s' % kv for kv in knobs))
         for k, v in knobs:
             {'RELNET_GEMM_KORDER': lib.relnet_gemm_debug_korder, 'RELNET_GEMM_FORCE_TILE': lib.relnet_gemm_force_tile,
-             'RELNET_GEMM_ASM': lib.relnet_gemm_debug_asm, 'RELNET_GEMM_SPLITK': lib.relnet_gemm_debug_splitk}[k](int(v))
+             'RELNET_GEMM_ASM': lib.relnet_gemm_debug_asm, 'RELNET_GEMM_SPLITK': lib.relnet_gemm_debug_splitk, 'RELNET_WGRAD_TILES': lib.relnet_wgrad_debug_tiles}[k](int(v))
     _lib = lib
     return lib
 

@@ -174,23 +174,43 @@ def test_wgrad_tn_matches_float64(case):
     # more / fewer persistent workgroups than work units
     other = [(torch.randn(900, 64, generator=g).to(bf).cuda(), torch.randn(900, 96, generator=g).to(bf).cuda()),
              (torch.randn(130, 320, generator=g).to(bf).cuda(), torch.randn(130, 264, generator=g).to(bf).cuda())]
-    for blocks in (0, 7, 1000):
+    # share rule (round 6): 1 = stream-K shares + float atomics (the default), 2 = whole output tiles per workgroup + plain read-modify-write
+    # (opt-in: measured slower, but one writer per element = bit-identical reruns)
+    for tiles_mode, blocks in ((1, 0), (1, 7), (1, 1000), (2, 0), (2, 7), (2, 1000)):
         L.load().relnet_wgrad_tune(blocks, 0, 0)
+        L.load().relnet_wgrad_debug_tiles(tiles_mode)
+        runs = []
         try:
-            q = ops.WgradQueue()
-            o0 = torch.zeros(64, 96, device='cuda'); o1 = torch.zeros(320, 264, device='cuda')
-            om = torch.zeros(want.shape, device='cuda')
-            q.add(other[0][0], other[0][1], o0)
-            q.add(dyb, xk, om, scale, want.shape[0], conv)
-            q.add(other[1][0], other[1][1], o1)
-            assert len(q) == 3
-            q.flush()
+            for _ in range(2):
+                q = ops.WgradQueue()
+                o0 = torch.zeros(64, 96, device='cuda'); o1 = torch.zeros(320, 264, device='cuda')
+                om = torch.zeros(want.shape, device='cuda')
+                q.add(other[0][0], other[0][1], o0)
+                q.add(dyb, xk, om, scale, want.shape[0], conv)
+                q.add(other[1][0], other[1][1], o1)
+                assert len(q) == 3
+                q.flush()
+                runs.append(om.clone())
         finally:
             L.load().relnet_wgrad_tune(0, 0, 0)
-        assert (om.double().cpu() - want).abs().max().item() <= 2e-5 * want.abs().max().item(), (case, blocks)
+            L.load().relnet_wgrad_debug_tiles(0)
+        if tiles_mode == 2:
+            assert torch.equal(runs[0], runs[1]), (case, blocks)
+        assert (om.double().cpu() - want).abs().max().item() <= 2e-5 * want.abs().max().item(), (case, tiles_mode, blocks)
         for o, (dy_, x_) in ((o0, other[0]), (o1, other[1])):
             w_ = dy_.double().t().cpu() @ x_.double().cpu()
-            assert (o.double().cpu() - w_).abs().max().item() <= 2e-5 * w_.abs().max().item(), (case, blocks)
+            assert (o.double().cpu() - w_).abs().max().item() <= 2e-5 * w_.abs().max().item(), (case, tiles_mode, blocks)
+    # two layers of one group accumulating into the SAME memory: the entry point must see the overlap and keep the atomics
+    L.load().relnet_wgrad_debug_tiles(2)
+    try:
+        q = ops.WgradQueue()
+        om = torch.zeros(want.shape, device='cuda')
+        q.add(dyb, xk, om, scale, want.shape[0], conv)
+        q.add(dyb, xk, om, scale, want.shape[0], conv)
+        q.flush()
+    finally:
+        L.load().relnet_wgrad_debug_tiles(0)
+    assert (om.double().cpu() - 2 * want).abs().max().item() <= 4e-5 * want.abs().max().item(), case
 
 
 def test_weight_relayout_one_launch_for_all_layers():
