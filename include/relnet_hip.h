@@ -565,6 +565,9 @@ int relnet_relu_bwd(const void* dy, const void* y, const void* add /*or NULL*/, 
 /* out[c] += sum_r x[r, c]: the gradient of a bias (`FullyConnected` / `Convolution` bias, mx autograd) from the upstream gradient
  * [rows, cols] (dtype: 0 fp32, 1 bf16; row stride ld elements), accumulated in fp32 (atomic per column and row chunk).               */
 int relnet_colsum_add(const void* x, long ld, long rows, int cols, int dtype, float* out, void* stream);
+/* the same for up to 16 bf16 matrices in ONE launch (round 6: the 12 - 13 bias gradients of a training step's heads bucket): xs[i] [rows[i]][cols[i]]
+ * with row pitch lds[i] elements (8 | cols, 8 | ld, 16-byte aligned rows), outs[i] fp32 [cols[i]] += column sums.  The arrays are HOST arrays. */
+int relnet_colsum_add_grouped(const void* const* xs, const long* lds, const long* rows, const int* cols, float* const* outs, int n, void* stream);
 /* mx.optimizer.SGD as set up in relation_rcnn/train_end2end.py:163-168 (momentum, wd, rescale_grad 1.0, no
  * clipping): mom = momentum*mom - lr*(rescale*grad + wd*w); w += mom.  fp32 master weights; w_bf16 (may be
  * NULL) receives the rounded copy the MFMA kernels read.                                                    */

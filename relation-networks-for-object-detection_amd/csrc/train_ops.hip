@@ -98,6 +98,46 @@ __global__ __launch_bounds__(256) void colsum_add_bf16x8_kernel(const unsigned s
   }
 }
 
+// Grouped form (round 6): the bias gradients of a gradient bucket in ONE launch -- up to 16 (matrix, output) problems in the kernel argument
+// (no table in memory: capture safe), every workgroup finds its problem by a scan of the block prefix and then runs the body of
+// colsum_add_bf16x8_kernel.  A training step has 12 - 13 bias gradients (RPN head, conv_new_1, the FC layers, the relation modules' projections), all of
+// the heads bucket: 12 launches of 17 - 29 us (latency bound reductions) become one.
+struct ColsumProblem { const unsigned short* x; float* out; long ld, rows, rows_per_block; int cols, col_blocks, blk_start; };
+struct ColsumGroup { ColsumProblem p[16]; int n; };
+
+__global__ __launch_bounds__(256) void colsum_add_grouped_kernel(ColsumGroup g) {
+  __shared__ float part[8][32][9];
+  int pi = 0;
+  for (int i = 1; i < g.n; ++i) if ((int)blockIdx.x >= g.p[i].blk_start) pi = i;
+  const ColsumProblem& a = g.p[pi];
+  const int rel = blockIdx.x - a.blk_start;
+  const int bx = rel % a.col_blocks, by = rel / a.col_blocks;
+  const int gq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = (bx * 32 + gq) * 8;
+  const long r0 = (long)by * a.rows_per_block, r1 = min(r0 + a.rows_per_block, a.rows);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < a.cols) {
+    for (long r = r0 + rl; r < r1; r += 8) {
+      const uint4 v = *(const uint4*)(a.x + r * a.ld + c);
+      const unsigned int w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[2 * e] += __uint_as_float(w4[e] << 16); acc[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u); }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[rl][gq][e] = acc[e];
+  __syncthreads();
+  if (rl == 0 && c < a.cols) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += part[k][gq][e];
+      atomicAdd(a.out + c + e, t);
+    }
+  }
+}
+
 struct SgdArgs {
   float* w; float* mom; const float* grad; unsigned short* w_bf16;
   long n;
@@ -322,6 +362,28 @@ extern "C" int relnet_colsum_add(const void* x, long ld, long rows, int cols, in
   else if (dtype == RELNET_BF16) colsum_add_kernel<unsigned short><<<grid, 256, 0, s>>>((const unsigned short*)x, ld, rows, cols, rpb, out);
   else RELNET_REQUIRE(false, "relnet_colsum_add: unknown dtype %d", dtype);
   return check_launch("relnet_colsum_add");
+}
+
+// n <= 16 problems: xs[i] bf16 [rows[i]][cols[i]] with row pitch lds[i] (cols % 8 == 0, ld % 8 == 0, 16-byte aligned), outs[i] fp32 [cols[i]] += column sums
+extern "C" int relnet_colsum_add_grouped(const void* const* xs, const long* lds, const long* rows, const int* cols, float* const* outs, int n, void* stream) {
+  RELNET_REQUIRE(xs && lds && rows && cols && outs && n > 0 && n <= 16, "relnet_colsum_add_grouped: 1..16 problems, got %d", n);
+  ColsumGroup g;
+  g.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    RELNET_REQUIRE(xs[i] && outs[i] && rows[i] > 0 && cols[i] > 0 && cols[i] % 8 == 0 && lds[i] % 8 == 0 && lds[i] >= cols[i] && (((uintptr_t)xs[i]) & 15) == 0,
+                   "relnet_colsum_add_grouped: problem %d needs bf16 rows of 8 | cols, 8 | ld, 16-byte aligned", i);
+    long nchunk = (rows[i] + 511) / 512;
+    nchunk = nchunk < 1 ? 1 : (nchunk > 128 ? 128 : nchunk);
+    ColsumProblem& p = g.p[i];
+    p.x = (const unsigned short*)xs[i]; p.out = outs[i]; p.ld = lds[i]; p.rows = rows[i]; p.cols = cols[i];
+    p.rows_per_block = (rows[i] + nchunk - 1) / nchunk;
+    p.col_blocks = (cols[i] / 8 + 31) / 32;
+    p.blk_start = blocks;
+    blocks += p.col_blocks * (int)((rows[i] + p.rows_per_block - 1) / p.rows_per_block);
+  }
+  colsum_add_grouped_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(g);
+  return check_launch("relnet_colsum_add_grouped");
 }
 
 extern "C" int relnet_sgd_update(float* w, float* mom, const float* grad, void* w_bf16, long n, float lr, float momentum,

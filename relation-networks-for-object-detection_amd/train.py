@@ -192,6 +192,9 @@ class Trainer(object):
         self._anchor_step = torch.zeros(1, device=dev, dtype=torch.int64)
         self._side = torch.cuda.Stream(device=dev) if torch.cuda.is_available() and torch.device(dev).type == 'cuda' else None
         self._wq = ops.WgradQueue()
+        # bias-gradient column sums of a gradient bucket in one grouped launch (train_ops.ColsumQueue; cfg.colsum_grouped / RELNET_COLSUM_GROUP=0: one launch each)
+        self._cq = T.ColsumQueue()
+        self._colsum_grouped = bool(getattr(c, 'colsum_grouped', os.environ.get('RELNET_COLSUM_GROUP', '1') != '0'))
         # every data-parallel rank samples its own fg / bg anchor subsets (cfg.rank_in_anchor_seed = False: the same subsets on every
         # rank, what the two-rank gradient-sum check needs)
         self._rank, self._world = (0, 1) if not getattr(c, 'rank_in_anchor_seed', True) else ((torch.distributed.get_rank(), torch.distributed.get_world_size())
@@ -293,6 +296,7 @@ class Trainer(object):
         waits for every product launched on the side stream since the last join (a gradient bucket is complete only then).  The
         operand tensors stay referenced until the join: their blocks must not be handed out again on the main stream while the
         side stream still reads them."""
+        self._cq.flush()             # the queued bias-gradient column sums: one grouped launch
         side = self._wgrad_side
         if side is None:
             self._wq.flush()
@@ -397,7 +401,17 @@ class Trainer(object):
         self._anchor_step += 1
         return out
 
-    def forward_backward(self, data, im_info, gt_boxes, rpn_label=None, rpn_bbox_target=None, rpn_bbox_weight=None, num_gt=None):
+    def forward_backward(self, *args, **kwargs):
+        """One forward + backward pass (arguments: see `_forward_backward_impl` of the trainer class).  While it runs, bias-gradient column sums
+        are queued (train_ops.COLSUM_QUEUE) and launched grouped when a gradient bucket completes (`_flush_wgrads`)."""
+        T.COLSUM_QUEUE = self._cq if self._colsum_grouped else None
+        try:
+            return self._forward_backward_impl(*args, **kwargs)
+        finally:
+            self._cq.flush()            # (nothing is left unless a caller skipped the bucket announcements)
+            T.COLSUM_QUEUE = None
+
+    def _forward_backward_impl(self, data, im_info, gt_boxes, rpn_label=None, rpn_bbox_target=None, rpn_bbox_weight=None, num_gt=None):
         """data [B,3,H,W] fp32; gt_boxes [B,G,5]; rpn_label [B, A*h*w] ((a,y,x) order), rpn_bbox_target / weight
         [B, 4A, h, w] (lib/rpn/rpn.py:assign_anchor layouts) -- or None: computed on the device from gt_boxes
         (`rpn_targets`).  Accumulates gradients into the flat buffers and returns the loss values (reference metric names)."""
@@ -1126,7 +1140,7 @@ class FPNTrainer(Trainer):
         cfg.fpn = True
         Trainer.__init__(self, params, cfg, device, im_hw=None)
 
-    def forward_backward(self, data, im_info, gt_boxes, proposals, num_gt=None, num_proposals=None):
+    def _forward_backward_impl(self, data, im_info, gt_boxes, proposals, num_gt=None, num_proposals=None):
         """data [B,3,H,W] (H, W multiples of 32), proposals [B,N,4] fp32, gt_boxes [B,G,5]; num_proposals [B] int32
         (optional): real rows of `proposals` per image -- the reference hands every image its own roi count
         (core/rcnn.py:128-146, TOP_ROIS truncation only); a batched step pads to a common N and the padded rows are

@@ -28,12 +28,54 @@ def relu_bwd(dy, y, add=None, out=None):
     return out
 
 
+class ColsumQueue(object):
+    """Bias-gradient column sums collected for ONE grouped launch per gradient bucket (relnet_colsum_add_grouped, <= 16 problems per
+    launch).  `add` keeps the operand alive until `flush`; operands the grouped kernel does not take (fp32, ragged widths) are summed at once."""
+
+    def __init__(self):
+        self.items = []
+
+    def __len__(self):
+        return len(self.items)
+
+    def add(self, x2, out):
+        ok = (x2.dtype == torch.bfloat16 and x2.shape[1] % 8 == 0 and x2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0)
+        if not ok:
+            _lib.call('relnet_colsum_add', x2.data_ptr(), x2.stride(0), x2.shape[0], x2.shape[1], _dt(x2), out.data_ptr(), _stream())
+            return
+        self.items.append((x2, out))
+
+    def flush(self):
+        import ctypes as C
+        items, self.items = self.items, []
+        for i in range(0, len(items), 16):
+            grp = items[i:i + 16]
+            n = len(grp)
+            xs = (C.c_void_p * n)(*[x.data_ptr() for x, _ in grp])
+            lds = (C.c_long * n)(*[x.stride(0) for x, _ in grp])
+            rows = (C.c_long * n)(*[x.shape[0] for x, _ in grp])
+            cols = (C.c_int * n)(*[x.shape[1] for x, _ in grp])
+            outs = (C.c_void_p * n)(*[o.data_ptr() for _, o in grp])
+            _lib.call('relnet_colsum_add_grouped', xs, lds, rows, cols, outs, n, _stream())
+        return items            # (still referenced by the caller until the launch has been issued)
+
+
+#: the queue bias-gradient sums go to while a training step is being recorded (train.Trainer sets it around forward_backward and flushes it
+#: when a gradient bucket completes); None = every colsum_add launches at once
+COLSUM_QUEUE = None
+
+
 def colsum_add(x, out):
     """out[c] += sum over all leading dims of x[..., c]  (bias gradient accumulated in place; x bf16 / fp32 with a dense last dim,
-    out fp32 [C] -- a view of the flat gradient buffer)."""
+    out fp32 [C] -- a view of the flat gradient buffer).  With an active COLSUM_QUEUE the sum is deferred to the queue's grouped launch:
+    x must not be modified before that flush."""
     C = x.shape[-1]
     assert out.dtype == torch.float32 and out.numel() == C and out.is_contiguous() and x.stride(-1) == 1
     x2 = x.reshape(-1, C)
+    _chk(x2, out)
+    if COLSUM_QUEUE is not None:
+        COLSUM_QUEUE.add(x2, out)
+        return
     _lib.call('relnet_colsum_add', x2.data_ptr(), x2.stride(0), x2.shape[0], C, _dt(x2), out.data_ptr(), _stream())
 
 

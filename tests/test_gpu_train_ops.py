@@ -268,6 +268,37 @@ def test_colsum_add_accumulates_bias_gradients(shape, dt):
         assert (out2.double() - xs.double().sum(0)).abs().max().item() <= 2e-6 * scale + 1e-5
 
 
+def test_colsum_queue_one_grouped_launch_for_a_bucket():
+    """train_ops.ColsumQueue / relnet_colsum_add_grouped (round 6): the 12 - 13 bias gradients of a training step in one launch per <= 16
+    problems.  Mixed shapes (19 152 pixels x 128 / 256 channels, 2 464 rois x 1 024 / 2 048, a row-strided slice, a 100-row matrix), 20 problems
+    (two launches), accumulation on top of existing values; an fp32 and a ragged-width operand take the single-launch kernel at once."""
+    ops, T = _mods()
+    g = torch.Generator().manual_seed(5)
+    bf = torch.bfloat16
+    shapes = [(19152, 128), (19152, 256), (2464, 1024), (2464, 2048), (100, 64), (64000, 128)] * 3 + [(700, 512), (3, 8)]
+    xs = [torch.randn(r, c, generator=g).to(bf).cuda() for r, c in shapes]
+    xs[2] = torch.randn(2464, 1536, generator=g).to(bf).cuda()[:, 512:]           # row pitch 1536, 1024 columns
+    odd = [torch.randn(2464, 89, generator=g).cuda(), torch.randn(50, 12, generator=g).to(bf).cuda()]
+    outs = [torch.full((x.shape[1],), 0.25, device='cuda') for x in xs + odd]
+    q = T.ColsumQueue()
+    T.COLSUM_QUEUE = q
+    try:
+        for x, o in zip(xs + odd, outs):
+            T.colsum_add(x, o)
+        assert len(q) == len(xs)                    # the two odd operands were summed immediately
+        for x, o in zip(odd, outs[len(xs):]):
+            assert (o.double() - (x.double().sum(0) + 0.25)).abs().max().item() <= 1e-4 * max(x.double().abs().sum(0).max().item(), 1)
+        assert torch.equal(outs[0], torch.full_like(outs[0], 0.25))              # (queued: nothing launched yet)
+        q.flush()
+        assert len(q) == 0
+    finally:
+        T.COLSUM_QUEUE = None
+    for x, o in zip(xs, outs):
+        want = x.double().sum(0) + 0.25
+        scale = x.double().abs().sum(0).max().item()
+        assert (o.double() - want).abs().max().item() <= 2e-6 * scale + 1e-5, tuple(x.shape)
+
+
 @pytest.mark.parametrize('tile', [0, 1, 3, 4, 5, 22])
 def test_gemm_nt_mask_is_gemm_plus_shortcut_times_relu_mask(tile):
     """relnet_gemm_nt_mask: (A W^T + resid) where mask > 0, else 0, on every LDS-tiled configuration it may run on (tile 0 = the one
