@@ -177,12 +177,16 @@ class GradSink(object):
                grouped stream-K launch, straight into the flat gradient buffer)
       b_qk     fp32 view [2 d], b_out fp32 view [d] (or None: the caller sums it): bias gradients, accumulated by relnet_colsum_add
       dwp, dbp fp32 views [16, 64] / [16] of pair_pos_fc1's gradient: the geometry backward accumulates into them atomically
+      defer    optional callable(fn, keep): see __init__
       scratch  callable(name, shape, dtype) -> persistent ZERO-initialised buffer (pad columns of the transposed operands stay zero
                from step to step: no per-step fill)"""
 
-    def __init__(self, wcat_t, resid, wgrad, b_qk, b_out, dwp, dbp, scratch):
+    def __init__(self, wcat_t, resid, wgrad, b_qk, b_out, dwp, dbp, scratch, defer=None):
         self.wcat_t, self.resid, self.wgrad, self.b_qk, self.b_out, self.dwp, self.dbp, self.scratch = \
             wcat_t, resid, wgrad, b_qk, b_out, dwp, dbp, scratch
+        # defer: None, or callable(fn, keep) -- work that only produces PARAMETER gradients (the geometry backward) may be run by the trainer
+        # beside the data-gradient chain (a side stream joined before the gradient bucket is announced); `keep` = the tensors fn reads
+        self.defer = defer
 
 
 def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, index=1, dtype=None, packed=None, key_count=None,
@@ -259,7 +263,10 @@ def attention_module_backward(roi_feat, rois, params, d_out, nongt_dim=None, ind
     if sink is not None and dtype == torch.bfloat16:
         # ---- gradients straight into the trainer's buffers (GradSink): one pack kernel, ONE projection-backward GEMM with the residual
         # gradient in its epilogue, ONE queued weight-gradient product for [Wq; Wk; Wout], two column-sum kernels for the biases
-        ops.geometry_bias_bwd(bx, bias, dlog, M, fast=True, out=(sink.dwp, sink.dbp))
+        if sink.defer is not None:
+            sink.defer(lambda: ops.geometry_bias_bwd(bx, bias, dlog, M, fast=True, out=(sink.dwp, sink.dbp)), (bx, bias, dlog))
+        else:
+            ops.geometry_bias_bwd(bx, bias, dlog, M, fast=True, out=(sink.dwp, sink.dbp))
         a3 = packed if packed is not None else ops.relation_bwd_pack(dq, dk, dvw)   # [B, N, 3 d] bf16 = (dQ | dK | dVW), key blocks zero past M
         a3_2d = a3.view(B * N, 3 * d)
         d_f = ops.gemm_nt(a3_2d, sink.wcat_t, resid=None if sink.resid is None else sink.resid.reshape(B * N, Fd)).reshape(B, N, Fd)

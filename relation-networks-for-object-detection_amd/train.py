@@ -194,6 +194,11 @@ class Trainer(object):
         self._wq = ops.WgradQueue()
         # bias-gradient column sums of a gradient bucket in one grouped launch (train_ops.ColsumQueue; cfg.colsum_grouped / RELNET_COLSUM_GROUP=0: one launch each)
         self._cq = T.ColsumQueue()
+        # parameter-only gradient work (the relation modules' geometry backward) on a side stream beside the data-gradient chain, joined before the
+        # bucket is announced: OPT-IN (cfg.aux_stream / RELNET_AUX_STREAM=1).  Measured, same box, r06: 6.95 -> 7.16-7.67 ms at one image, 17.93 -> 18.02-18.12 ms
+        # at 8 -- like the weight-gradient side stream, every fork / join inside the captured step costs more than the overlap returns
+        self._aux = torch.cuda.Stream(device=dev) if (self._side is not None and getattr(c, 'aux_stream', os.environ.get('RELNET_AUX_STREAM', '0') != '0')) else None
+        self._aux_keep, self._aux_pending = [], False
         self._colsum_grouped = bool(getattr(c, 'colsum_grouped', os.environ.get('RELNET_COLSUM_GROUP', '1') != '0'))
         # every data-parallel rank samples its own fg / bg anchor subsets (cfg.rank_in_anchor_seed = False: the same subsets on every
         # rank, what the two-rank gradient-sum check needs)
@@ -297,6 +302,9 @@ class Trainer(object):
         operand tensors stay referenced until the join: their blocks must not be handed out again on the main stream while the
         side stream still reads them."""
         self._cq.flush()             # the queued bias-gradient column sums: one grouped launch
+        if self._aux_pending:        # deferred parameter-gradient work: the bucket is complete only once it has run
+            torch.cuda.current_stream().wait_stream(self._aux)
+            self._aux_pending, self._aux_keep = False, []
         side = self._wgrad_side
         if side is None:
             self._wq.flush()
@@ -312,6 +320,23 @@ class Trainer(object):
             main.wait_stream(side)
             self._wgrad_pending = False
             self._wgrad_keep = []
+
+    def _defer(self, fn, keep):
+        """Run fn() on the auxiliary stream after everything queued so far (GradSink.defer); joined in _flush_wgrads.  `keep`: the tensors fn
+        reads -- referenced until the join, and marked as used on that stream for the caching allocator (outside a capture)."""
+        if self._aux is None:
+            fn()
+            return
+        main = torch.cuda.current_stream()
+        self._aux.wait_stream(main)
+        with torch.cuda.stream(self._aux):
+            fn()
+        if not torch.cuda.is_current_stream_capturing():
+            for t in keep:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(self._aux)
+        self._aux_keep.append(keep)
+        self._aux_pending = True
 
     def _scratch(self, name, shape, dtype):
         """Persistent zero-initialised work buffer (created on first use, i.e. in the eager warm-up step, never inside a capture)."""
@@ -761,7 +786,7 @@ class Trainer(object):
                 ops.wgrad_tn(dy2d[:, :2048], x2d, out=gq.view(2048, 128))
                 ops.wgrad_tn(dy2d[:, 2048:], x2d, out=glo)
             sink = GradSink(wcat_t, g.view(BC, F, 128), wg, self._bg('nms_qk_1'), None,
-                            self.W.view(self.W.grad, 'nms_pair_pos_fc1_1'), self._bg('nms_pair_pos_fc1_1'), self._scratch)
+                            self.W.view(self.W.grad, 'nms_pair_pos_fc1_1'), self._bg('nms_pair_pos_fc1_1'), self._scratch, defer=self._defer)
             r = attention_module_backward(xr, cb, None, dY, nongt_dim=F, index=1, dtype=bt, packed=mod, cache=lcache, sink=sink)
             self.W.view(self.W.grad, 'nms_linear_out_1').view(16, 8, 128).add_(glo.view(16, 64, 128)[:, :8])
             T.colsum_add(g.view(BC * F, 128), self._bg('nms_linear_out_1'))    # (dY's real columns are g's columns)
@@ -828,7 +853,7 @@ class Trainer(object):
             g3 = self.W.grad[oq:oq + (sq[0] + so[0]) * sq[1]].view(sq[0] + so[0], sq[1])      # d[Wq; Wk; Wout], adjacent slices of the flat buffer
             sink = GradSink(wcat_t, g, lambda dy2d, x2d: T._wg_call((g3, None, self._wq), dy2d, x2d),
                             self._bg('qk_%d' % i), self._bg('linear_out_%d' % i),
-                            self.W.view(self.W.grad, 'pair_pos_fc1_%d' % i), self._bg('pair_pos_fc1_%d' % i), self._scratch)
+                            self.W.view(self.W.grad, 'pair_pos_fc1_%d' % i), self._bg('pair_pos_fc1_%d' % i), self._scratch, defer=self._defer)
             r = attention_module_backward(f, rois, None, g, nongt_dim=N, index=i, dtype=torch.bfloat16, packed=mod, key_count=key_count,
                                           cache=cache, sink=sink)
             return r['d_roi_feat']
