@@ -36,8 +36,12 @@ class RelationParams(object):
 
 def pack_pair_pos(mods, device):
     """[16,64] pair_pos_fc1 weights of the modules -> wp_t [64, nmod*16], bp [nmod*16]."""
-    wp_t = torch.cat([m.wp for m in mods], 0).t().contiguous().to(device)
-    bp = torch.cat([m.bp for m in mods], 0).contiguous().to(device)
+    # (one launch per output: the transposed views are concatenated straight into the contiguous result; a single module's bias is used as it is --
+    #  a training step packs these from the master weights every step)
+    if len(mods) == 1:
+        return mods[0].wp.t().contiguous().to(device), mods[0].bp.contiguous().to(device)
+    wp_t = torch.cat([m.wp.t() for m in mods], 1).contiguous().to(device)
+    bp = torch.cat([m.bp for m in mods], 0).to(device)
     return wp_t, bp
 
 
