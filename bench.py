@@ -392,7 +392,7 @@ def bench_train(a, rank, world, D, emit=True, fatal=True):
                                                              if cfg.first_n <= 128 else
                                                              'two-kernel form with fp32 S / dL maps in HBM (first_n %d -> Mpad %d is past the small kernel\'s 128)' % (cfg.first_n, (cfg.first_n + 31) // 32 * 32))
                                                             if a.learn_nms else None,
-                       'images_per_gpu_per_step': B, 'launch': 'eager' if a.no_graph else 'hipGraph replay (forward+backward in %d segments cut at the gradient buckets)' % len(graph.segments),
+                       'images_per_gpu_per_step': B, 'launch': 'eager' if a.no_graph else ('hipGraph replay (forward+backward in %d segments cut at the gradient buckets)' % len(graph.segments) if len(graph.segments) > 1 else 'hipGraph replay (forward+backward as one graph: one rank, no bucket exchange to cut for)'),
                        'parallelism': 'dp%d (RCCL all-reduce SUM)' % world, 'lr': cfg.lr,
                        'lr_rule': 'yaml lr %g x min(1, 16 / images summed per step over all ranks)' % yaml_lr},
             'communication': comm if comm is not None else 'single rank: no collective',

@@ -1085,8 +1085,12 @@ class CapturedStep(object):
         out = step.replay(); trainer.all_reduce(); trainer.update()
     """
 
-    def __init__(self, trainer, batch, kwargs=None):
+    def __init__(self, trainer, batch, kwargs=None, segments=None):
+        """segments: True = cut at every gradient bucket; None (default) = cut only when there is somebody to exchange the buckets with
+        (a process group of more than one rank) -- on one rank the whole pass is ONE hipGraph (round 6: five graph launches and their seams
+        less per step)."""
         self.tr = trainer
+        do_cut = trainer._grad_buckets().active() if segments is None else bool(segments)
         if trainer.step_count == 0:              # kernel attributes (hipFuncSetAttribute), allocator pools and caches must exist before a capture
             with torch.no_grad():
                 trainer.forward_backward(*batch, **(kwargs or {}))
@@ -1105,6 +1109,8 @@ class CapturedStep(object):
             cur[0].capture_begin(pool=pool, capture_error_mode='thread_local')
 
         def cut(idx):
+            if not do_cut:               # one rank: nothing is exchanged between the segments, keep capturing into the same graph
+                return
             cur[0].capture_end()
             self.segments.append((cur[0], idx))
             if idx == 0 or (isinstance(idx, tuple) and 0 in idx):   # bucket 0 (res3) is announced by the last kernel of the backward pass: nothing follows, so no

@@ -392,7 +392,10 @@ def test_captured_step_in_bucket_segments_equals_eager():
         eager = tr.forward_backward(*batch)                    # warm-up + reference (device anchor targets, step counter 0)
         g_eager = tr.W.grad.clone()
         tr._anchor_step.zero_()
-        step = train.CapturedStep(tr, batch)
+        one = train.CapturedStep(tr, batch)                    # one rank: no exchange between the buckets -> ONE graph
+        assert len(one.segments) == 1 and one.segments[0][1] is None
+        tr._anchor_step.zero_()
+        step = train.CapturedStep(tr, batch, segments=True)
         assert [i for _, i in step.segments][:5] == [4, 3, 2, 1, 0]         # heads | res5 | res4 hi | res4 lo | res3 (an empty tail is dropped)
         assert len(step.segments) <= 6
         tr._anchor_step.zero_()
