@@ -250,11 +250,14 @@ def other_configs(a, rank, world, D):
         torch.cuda.empty_cache()
     # training steps: 8 images per GPU and step like the headline training figure (configs[2]); round 6: also for the FPN graph, whose
     # 2-image step of rounds 2-5 (6 400-pixel res4 maps: every convolution a launch of < 1 workgroup per CU) stays beside it as `at_2_images_per_gpu`
+    # (round 6) + the reference README's fourth experiment: the learn-NMS-only step (detector fixed by FIXED_PARAMS, plain 2FC head, no OHEM)
     for key, dcn, fpn, bsz, also in (('configs3_dcn_relation_learn_nms_training', True, False, 8, ()),
-                                     ('configs4_fpn_relation_learn_nms_training', False, True, 8, (2,))):
+                                     ('configs4_fpn_relation_learn_nms_training', False, True, 8, (2,)),
+                                     ('rcnn_end2end_learn_nms_3epoch_training', False, False, 8, (1,))):
         def one(bsz_):
             ta = argparse.Namespace(**vars(a))
             ta.batch, ta.learn_nms, ta.dcn, ta.fpn, ta.steps, ta.warmup, ta.no_graph = bsz_, True, dcn, fpn, 5, 2, False
+            ta.experiment = 'rcnn_end2end_learn_nms_3epoch' if key.startswith('rcnn_end2end_learn_nms_3epoch') else None
             tr = _side_figure(lambda: bench_train(ta, rank, world, D, emit=False, fatal=False), key)
             if rank != 0:
                 return None
@@ -264,7 +267,7 @@ def other_configs(a, rank, world, D):
                 r['images_per_gpu_per_step'] = bsz_
             return r
         main = one(bsz)
-        extra = {'at_%d_images_per_gpu' % b_: one(b_) for b_ in also}
+        extra = {('at_%d_image%s_per_gpu' % (b_, '' if b_ == 1 else 's')): one(b_) for b_ in also}
         if rank == 0:
             out[key] = main
             if main is not None:
@@ -290,7 +293,10 @@ def bench_train(a, rank, world, D, emit=True, fatal=True):
     H, W, G = (800, 1024, 8) if a.fpn else (600, 1000, 8)
     B = a.batch
     params = backbone.init_params(seed=1, dcn_offset_std=0.005 if a.dcn else 0.0, fpn=a.fpn)
-    if a.learn_nms:     # the experiment file's own values: FPN = FIRST_N 150 / OHEM 512 / lr 0.00125, C4 and DCN = 100 / 128 / 0.0005
+    if getattr(a, 'experiment', None):     # any shipped experiment by its name (config.EXPERIMENTS), e.g. rcnn_end2end_learn_nms_3epoch = the learn-NMS-only step
+        cfg = train.TrainConfig.from_experiment(a.experiment, train=True)
+        assert cfg.dcn == bool(a.dcn) and cfg.fpn == bool(a.fpn), '--experiment %s needs --dcn %s --fpn %s' % (a.experiment, cfg.dcn, cfg.fpn)
+    elif a.learn_nms:     # the experiment file's own values: FPN = FIRST_N 150 / OHEM 512 / lr 0.00125, C4 and DCN = 100 / 128 / 0.0005
         cfg = train.TrainConfig.from_experiment(EXPERIMENT_OF[(bool(a.dcn), bool(a.fpn))], train=True)
         assert cfg.learn_nms and cfg.dcn == bool(a.dcn)
     else:
@@ -378,7 +384,8 @@ def bench_train(a, rank, world, D, emit=True, fatal=True):
             'metric': 'images/sec (1000x600, 300 ROIs)', 'value': images / elapsed, 'unit': 'images/s', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': ('BASELINE configs[4] (FPN, 800x1024 images, 1000 given proposals + 8 gt rows): ' if a.fpn else '') +
+            'config': {'workload': (('experiment %s (%s): ' % (a.experiment, 'learn-NMS head only: detector fixed by FIXED_PARAMS, JOINT_TRAINING false' if getattr(tr, 'lnms_only', False) else 'its own hyper-parameters')) if getattr(a, 'experiment', None) else '') +
+                                   ('BASELINE configs[4] (FPN, 800x1024 images, 1000 given proposals + 8 gt rows): ' if a.fpn else '') +
                                    ('BASELINE configs[3] (deformable res5 + deformable PSROI pooling): ' if a.dcn else '') +
                                    ('BASELINE configs[2]: TRAINING step of ResNet-101 Faster-RCNN + 2 relation modules + learn-NMS '
                                     'head end2end (..._rcnn_end2end_relation_learn_nms_8epoch.yaml)' if a.learn_nms else
@@ -391,7 +398,8 @@ def bench_train(a, rank, world, D, emit=True, fatal=True):
                        'relation_bwd_of_the_learn_nms_head': ('one workgroup per (image, class, head), S / dL in LDS (relation_attention_bwd_small_kernel: first_n <= 128)'
                                                              if cfg.first_n <= 128 else
                                                              'two-kernel form with fp32 S / dL maps in HBM (first_n %d -> Mpad %d is past the small kernel\'s 128)' % (cfg.first_n, (cfg.first_n + 31) // 32 * 32))
-                                                            if a.learn_nms else None,
+                                                            if cfg.learn_nms else None,
+                       'fixed_params': list(getattr(cfg, 'fixed_params', None) or []), 'learn_nms_only_step': bool(getattr(tr, 'lnms_only', False)),
                        'images_per_gpu_per_step': B, 'launch': 'eager' if a.no_graph else ('hipGraph replay (forward+backward in %d segments cut at the gradient buckets)' % len(graph.segments) if len(graph.segments) > 1 else 'hipGraph replay (forward+backward as one graph: one rank, no bucket exchange to cut for)'),
                        'parallelism': 'dp%d (RCCL all-reduce SUM)' % world, 'lr': cfg.lr,
                        'lr_rule': 'yaml lr %g x min(1, 16 / images summed per step over all ranks)' % yaml_lr},
@@ -419,6 +427,7 @@ def main():
     ap.add_argument('--dcn', action='store_true', help='deformable res5 + deformable PSROI pooling (config 4 graph, inference)')
     ap.add_argument('--fpn', action='store_true', help='FPN graph, 800x1024 images, 1000 given proposals (inference graph of config 5)')
     ap.add_argument('--train', action='store_true', help='training step (relation end2end graph): forward + backward + summed all-reduce + SGD')
+    ap.add_argument('--experiment', default=None, help='with --train: build the step from this shipped experiment (config.EXPERIMENTS key, e.g. rcnn_end2end_learn_nms_3epoch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=10)
     ap.add_argument('--parity-images', type=int, default=2, help='images of the batch checked stage by stage against the oracle')

@@ -68,14 +68,16 @@ def res5_dcn(conv4, pd):
 
 
 def _head_losses(pooled, rois, pd, labels_ohem, bbox_target, bbox_weight_ohem, nongt_dim, batch_rois_ohem=128,
-                 fc_names=('fc_new_1', 'fc_new_2')):
+                 fc_names=('fc_new_1', 'fc_new_2'), relation=True):
+    """relation=False: the plain 2FC head of symbols/resnet_v1_101_rcnn.py:96-174 / resnet_v1_101_rcnn_learn_nms_1024_...:176-216 (fc + ReLU twice);
+    without OHEM the caller passes the proposal_target labels / weights and batch_rois_ohem = 300 (the graphs' BATCH_ROIS < 0 normaliser)."""
     R = pooled.shape[0]
     n1, n2 = fc_names
     x = pooled.reshape(R, -1)
     f1 = x @ pd[n1 + '_weight'].t() + pd[n1 + '_bias']
-    x1 = torch.relu(f1 + ORT.relation_module(f1, rois[:, 1:5], pd, 1, nongt_dim))
+    x1 = torch.relu(f1 + ORT.relation_module(f1, rois[:, 1:5], pd, 1, nongt_dim)) if relation else torch.relu(f1)
     f2 = x1 @ pd[n2 + '_weight'].t() + pd[n2 + '_bias']
-    x2 = torch.relu(f2 + ORT.relation_module(f2, rois[:, 1:5], pd, 2, nongt_dim))
+    x2 = torch.relu(f2 + ORT.relation_module(f2, rois[:, 1:5], pd, 2, nongt_dim)) if relation else torch.relu(f2)
     cls_score = x2 @ pd['cls_score_weight'].t() + pd['cls_score_bias']
     bbox_pred = x2 @ pd['bbox_pred_weight'].t() + pd['bbox_pred_bias']
     lo = torch.as_tensor(np.asarray(labels_ohem, np.int64))
@@ -124,7 +126,7 @@ def total_loss_fpn(data, p, rois, level, labels_ohem, bbox_target, bbox_weight_o
 
 
 def total_loss(data, p, rois, labels_ohem, bbox_target, bbox_weight_ohem, rpn_label, rpn_bbox_target, rpn_bbox_weight,
-               nongt_dim, rpn_batch_size=256, batch_rois_ohem=128, lnms=None, dcn=False):
+               nongt_dim, rpn_batch_size=256, batch_rois_ohem=128, lnms=None, dcn=False, relation=True):
     """One image.  p: name -> torch float64 tensors (requires_grad on the trainable ones).  rois [R,5] numpy;
     labels_ohem [R]; bbox_target / bbox_weight_ohem [R,8]; rpn_label [A*h*w]; rpn_bbox_target / weight [4A,h,w]."""
     pd = {k: (v.double() if torch.is_tensor(v) else torch.as_tensor(np.asarray(v), dtype=torch.float64)) for k, v in p.items()}
@@ -164,7 +166,7 @@ def total_loss(data, p, rois, labels_ohem, bbox_target, bbox_weight_ohem, rpn_la
         g = torch.gather(flat, 1, idx.clamp(min=0).permute(1, 0, 2, 3).reshape(C, -1)).reshape(C, R, 7, 7).permute(1, 0, 2, 3)
         pooled = g * (idx >= 0).double()
     cls_score, bbox_pred, x2, f1, l_cls, l_box = _head_losses(pooled, rois, pd, labels_ohem, bbox_target, bbox_weight_ohem, nongt_dim,
-                                                              batch_rois_ohem)
+                                                              batch_rois_ohem, relation=relation)
     l_nms = 0.0
     multi = None
     if lnms is not None:       # dict(rank_idx, class_boxes, target, first_n)

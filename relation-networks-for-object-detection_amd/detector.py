@@ -67,6 +67,9 @@ class Config(object):
         c.learn_nms_class_thresh = te.LEARN_NMS_CLASS_SCORE_TH
         c.merge_method = te.MERGE_METHOD
         c.dcn = '_dcn' in e.symbol
+        # relation modules in the 2FC head: every `..._attention_...` symbol except the learn-NMS-only graph, whose name carries the attention
+        # suffix for its learn-NMS head's module (resnet_v1_101_rcnn_learn_nms_1024_attention_...: plain fc_new_1 / fc_new_2, symbols/...:176-216)
+        c.relation = ('_attention_' in e.symbol) and not e.symbol.startswith('resnet_v1_101_rcnn_learn_nms')
         c.fpn = '_fpn' in e.symbol
         c.top_rois = t.TOP_ROIS if train else te.TOP_ROIS          # proposals per image of the HAS_RPN: false (FPN) graphs
         c.scales = tuple(e.SCALES[0])

@@ -45,6 +45,9 @@ class TrainConfig(Config):
     nms_eps = 1e-8
     bbox_means = (0.0, 0.0, 0.0, 0.0)
     bbox_stds = (0.1, 0.1, 0.2, 0.2)
+    relation = True               # two relation modules in the 2FC head (False: the plain head of resnet_v1_101_rcnn_learn_nms_1024_...)
+    enable_ohem = True            # TRAIN.ENABLE_OHEM (False: SoftmaxOutput over all rois, bbox loss scaled by 1 / 300)
+    fixed_params = None           # network.FIXED_PARAMS of the experiment file (None: dist.FIXED_PARAMS, the end2end yamls' list)
 
 
 def all_reduce_sum(*buffers):
@@ -90,6 +93,7 @@ class Trainer(object):
         dev = device
         f32 = lambda t: torch.as_tensor(t).to(dev, torch.float32).contiguous()
         self.fpn = bool(getattr(c, 'fpn', False))
+        self.relation = bool(getattr(c, 'relation', True))
         # cfg.trunk_fp32 (parity tests only): conv1 .. res5 forward AND backward in float32 on the exact-fp32 MFMA kernels
         # (relnet_conv2d_nhwc_f32 / relnet_gemm_nt f32, master weights read directly, no chain kernels, no fused ReLU-mask epilogue) with
         # the SAME wiring code (_trunk_forward / _trunk_backward / train_ops) -- removes the bf16 noise of ~100 layers from the
@@ -154,7 +158,7 @@ class Trainer(object):
         self.num_classes = params['cls_score_weight'].shape[0]
         weights.append(('cls_bbox', torch.cat([params['cls_score_weight'], params['bbox_pred_weight']], 0)))
         biases.append(('cls_bbox', torch.cat([params['cls_score_bias'], params['bbox_pred_bias']], 0)))
-        for i in (1, 2):
+        for i in ((1, 2) if self.relation else ()):
             weights.append(('qk_%d' % i, torch.cat([params['query_%d_weight' % i], params['key_%d_weight' % i]], 0)))
             biases.append(('qk_%d' % i, torch.cat([params['query_%d_bias' % i], params['key_%d_bias' % i]], 0)))
             wo = params['linear_out_%d_weight' % i]
@@ -183,6 +187,22 @@ class Trainer(object):
         self.Bv = _Flat(biases, dev)          # biases: wd_mult 0 (MXNet's rule for names not ending in _weight / _gamma)
         if c.dcn:
             self.lr_mult_tail = (self.W.slices['offset'][0], self.Bv.slices['offset'][0], 0.01)
+        # network.FIXED_PARAMS (core/module.py:753-764: a parameter is fixed when ANY pattern is a substring of its name -- 'cls_score' also fixes
+        # rpn_cls_score).  The end2end experiments fix conv1 / res2 / the BatchNorm affine terms, which this class never registers as trainable; the
+        # learn-NMS-only experiment (..._rcnn_end2end_learn_nms_3epoch.yaml:23-40, JOINT_TRAINING false) fixes the whole detector: what is left are
+        # the learn-NMS head's parameters.  A fused slice (rpn_out = rpn_cls_score | rpn_bbox_pred, ...) is frozen when all its members are.
+        fixed = tuple(getattr(c, 'fixed_params', None) or D.FIXED_PARAMS)
+        members = {'rpn_out': ('rpn_cls_score', 'rpn_bbox_pred'), 'cls_bbox': ('cls_score', 'bbox_pred'), 'fc_new_1': (fc1n,), 'fc_new_2': (fc2n,),
+                   'qk_1': ('query_1', 'key_1'), 'qk_2': ('query_2', 'key_2'), 'nms_qk_1': ('nms_query_1', 'nms_key_1')}
+        def _frozen(flat_name):
+            fr = [not D.is_trainable(m + '_weight', fixed) for m in members.get(flat_name, (flat_name,))]
+            assert all(fr) or not any(fr), "FIXED_PARAMS splits the fused slice %s" % flat_name
+            return all(fr)
+        self.frozen_names = {n for n in self.W.slices if _frozen(n)}
+        lnms_names = {'nms_rank', 'roi_feat_embedding', 'nms_pair_pos_fc1_1', 'nms_logit', 'nms_qk_1', 'nms_linear_out_1'}
+        # the pruned step: every parameter outside the learn-NMS head is fixed -> no gradient leaves that head, nothing behind it is differentiated
+        self.lnms_only = bool(c.learn_nms) and bool(self.frozen_names) and all((n in self.frozen_names) != (n in lnms_names) for n in self.W.slices)
+        assert not self.frozen_names or self.lnms_only, "fixed parameter sets other than the end2end yamls' / the learn-NMS-only yaml's are not built: %s" % sorted(self.frozen_names)
         self.anchors_host = generate_anchors(c.feat_stride, c.anchor_ratios, c.anchor_scales)      # float64 [A,4], host (kernel argument)
         self.anchors = torch.as_tensor(self.anchors_host, dtype=torch.float64, device=dev)
         self.step_count = 0
@@ -524,6 +544,12 @@ class Trainer(object):
         d_pool, hs = self._head_forward_backward(pooled2, rois_t, N, label, bbox_target, bbox_weight, im_info, gt_boxes, num_gt, out)
         bt = torch.bfloat16
         x2, f1, cls_score, bbox_pred, labels_ohem, weights_ohem = hs
+        if self.lnms_only:          # JOINT_TRAINING false: the detector is fixed, the step ends with the learn-NMS head's parameter gradients
+            self._bucket_ready('heads')
+            out['rois'], out['label'] = rois_t, labels_ohem
+            out['bbox_target'], out['bbox_weight'] = bbox_target, weights_ohem
+            out['bbox_pred'], out['cls_score'], out['fc_all_2_relu'] = bbox_pred, cls_score, x2
+            return out
         # ROIPooling backward -> gradient of conv_new_1_relu
         if c.dcn:
             gp = d_pool.view(B * R, 7, 7, -1).permute(0, 3, 1, 2)
@@ -636,25 +662,35 @@ class Trainer(object):
         B, R = rois_t.shape[0], rois_t.shape[1]
         # keys of both relation modules = the first N rows of each image
         bt = torch.bfloat16
-        mods = [self._rel_params(i) for i in (1, 2)]
-        wp_t, bp = pack_pair_pos(mods, self.device)
-        # float32 ln G for the training forward (not the fp16 matrix-core bias of inference): the backward needs exactly this G
-        # and the outputs computed from it (relation.attention_module_backward), so they are produced once, here
-        bias = ops.geometry_bias(rois_t, wp_t, bp, N, fast32=True)
-        f1 = ops.gemm_nt(pooled2, self.w('fc_new_1'), self.b('fc_new_1')).reshape(B, R, -1)
-        caches = [{}, {}]           # Q|K and VW^T projections of the forward, reused by the backward
-        # (VW^T buffers: persistent -- only columns [:N] are written, the pad columns stay zero from step to step: no per-step fill)
-        vw_ = lambda i: self._scratch('vwt_%d_%d' % (i, N), (B, mods[0].wout.shape[0], bias.shape[-1]), bt)     # keyed on N: a smaller N in the same padded width would inherit stale columns
-        _, x1, _ = _module_forward(f1, mods[0], bias[0], N, True, True, False, vwt_buf=vw_(1), key_count=key_count, cache=caches[0])
-        f2 = ops.gemm_nt(x1.reshape(B * R, -1), self.w('fc_new_2'), self.b('fc_new_2')).reshape(B, R, -1)
-        _, x2, _ = _module_forward(f2, mods[1], bias[1], N, True, True, False, vwt_buf=vw_(2), key_count=key_count, cache=caches[1])
+        if self.relation:
+            mods = [self._rel_params(i) for i in (1, 2)]
+            wp_t, bp = pack_pair_pos(mods, self.device)
+            # float32 ln G for the training forward (not the fp16 matrix-core bias of inference): the backward needs exactly this G
+            # and the outputs computed from it (relation.attention_module_backward), so they are produced once, here
+            bias = ops.geometry_bias(rois_t, wp_t, bp, N, fast32=True)
+            f1 = ops.gemm_nt(pooled2, self.w('fc_new_1'), self.b('fc_new_1')).reshape(B, R, -1)
+            caches = [{}, {}]           # Q|K and VW^T projections of the forward, reused by the backward
+            # (VW^T buffers: persistent -- only columns [:N] are written, the pad columns stay zero from step to step: no per-step fill)
+            vw_ = lambda i: self._scratch('vwt_%d_%d' % (i, N), (B, mods[0].wout.shape[0], bias.shape[-1]), bt)     # keyed on N: a smaller N in the same padded width would inherit stale columns
+            _, x1, _ = _module_forward(f1, mods[0], bias[0], N, True, True, False, vwt_buf=vw_(1), key_count=key_count, cache=caches[0])
+            f2 = ops.gemm_nt(x1.reshape(B * R, -1), self.w('fc_new_2'), self.b('fc_new_2')).reshape(B, R, -1)
+            _, x2, _ = _module_forward(f2, mods[1], bias[1], N, True, True, False, vwt_buf=vw_(2), key_count=key_count, cache=caches[1])
+        else:       # plain 2FC head (resnet_v1_101_rcnn.py:96-174 / ..._learn_nms_1024_...:176-216): fc_new_i + ReLU in the GEMM epilogue
+            x1 = ops.gemm_nt(pooled2, self.w('fc_new_1'), self.b('fc_new_1'), relu=True).reshape(B, R, -1)
+            x2 = ops.gemm_nt(x1.reshape(B * R, -1), self.w('fc_new_2'), self.b('fc_new_2'), relu=True).reshape(B, R, -1)
+            f1 = x1
         cb = ops.gemm_nt(x2.reshape(B * R, -1), self.w('cls_bbox'), self.b('cls_bbox'), out_dtype=torch.float32).reshape(B, R, -1)
         nc = self.num_classes
         cls_score, bbox_pred = cb[:, :, :nc].contiguous(), cb[:, :, nc:].contiguous()
-        labels_ohem, weights_ohem = ops.box_annotator_ohem(cls_score, bbox_pred, label, bbox_target, bbox_weight, c.batch_rois_ohem)
+        if getattr(c, 'enable_ohem', True):
+            labels_ohem, weights_ohem = ops.box_annotator_ohem(cls_score, bbox_pred, label, bbox_target, bbox_weight, c.batch_rois_ohem)
+            box_norm = c.batch_rois_ohem
+        else:       # ENABLE_OHEM false (symbols/..._learn_nms_1024_...:232-241): every roi counts (padding rows of a short proposal list keep label -1
+            labels_ohem, weights_ohem = label, bbox_weight          # and are ignored), the box loss is scaled by 1 / 300 (BATCH_ROIS < 0)
+            box_norm = 300
         _, d_cls = losses.softmax_output(cls_score.view(B * R, -1), labels_ohem.reshape(-1), use_ignore=True, ignore_label=-1.0, group=R)
         d_cls = d_cls.view(B, R, -1)
-        l1, d_bbox = losses.smooth_l1_loss(bbox_pred, bbox_target, weights_ohem, 1.0, 1.0 / c.batch_rois_ohem)
+        l1, d_bbox = losses.smooth_l1_loss(bbox_pred, bbox_target, weights_ohem, 1.0, 1.0 / box_norm)
         out['bbox_loss'] = T.scalar_sum(l1, 1.0 / B)
         out['num_ohem'] = T.scalar_sum(labels_ohem, count_nonneg=True)
         d_x2_lnms = None
@@ -664,6 +700,8 @@ class Trainer(object):
             if d_cls_l is not None:         # (None: already accumulated into d_cls[:, :N] by relnet_lnms_softmax_bwd)
                 d_cls[:, :N] += d_cls_l
             out.update(lo)
+        if self.lnms_only:          # every parameter in front of the learn-NMS head is fixed: nothing is differentiated past this point
+            return None, (x2, f1, cls_score, bbox_pred, labels_ohem, weights_ohem)
         # ================= backward =================
         d_cb = torch.cat([d_cls, d_bbox], 2).reshape(B * R, -1).to(bt)
         d_x2, dw, db = T.linear_bwd(x2.reshape(B * R, -1), self.w('cls_bbox'), d_cb, w_t=self.wt('cls_bbox'), keep_splits=True, wgrad_to=self._wg('cls_bbox'), bgrad_to=self._bg('cls_bbox'))
@@ -671,10 +709,16 @@ class Trainer(object):
         if d_x2_lnms is not None:
             d_x2 = d_x2.reshape(B, R, -1)
             d_x2[:, :N] += d_x2_lnms.to(d_x2.dtype)
-        d_f2 = self._relation_bwd(2, mods[1], f2, x2, rois_t, d_x2.reshape(B, R, -1), N, key_count, caches[1])
+        if self.relation:
+            d_f2 = self._relation_bwd(2, mods[1], f2, x2, rois_t, d_x2.reshape(B, R, -1), N, key_count, caches[1])
+        else:
+            d_f2 = T.relu_bwd(d_x2.reshape(B, R, -1).contiguous(), x2)
         d_x1, dw, db = T.linear_bwd(x1.reshape(B * R, -1), self.w('fc_new_2'), d_f2.reshape(B * R, -1), w_t=self.wt('fc_new_2'), keep_splits=True, wgrad_to=self._wg('fc_new_2'), bgrad_to=self._bg('fc_new_2'))
         self._add_bgrad('fc_new_2', db)
-        d_f1 = self._relation_bwd(1, mods[0], f1, x1, rois_t, d_x1.reshape(B, R, -1), N, key_count, caches[0])
+        if self.relation:
+            d_f1 = self._relation_bwd(1, mods[0], f1, x1, rois_t, d_x1.reshape(B, R, -1), N, key_count, caches[0])
+        else:
+            d_f1 = T.relu_bwd(d_x1.reshape(B, R, -1).contiguous(), x1)
         d_pool, dw, db = T.linear_bwd(pooled2, self.w('fc_new_1'), d_f1.reshape(B * R, -1), w_t=self.wt('fc_new_1'), keep_splits=True, wgrad_to=self._wg('fc_new_1'), bgrad_to=self._bg('fc_new_1'))
         self._add_bgrad('fc_new_1', db)
         return d_pool, (x2, f1, cls_score, bbox_pred, labels_ohem, weights_ohem)
@@ -896,7 +940,7 @@ class Trainer(object):
         nc = self.num_classes
         out['cls_score_weight'], out['bbox_pred_weight'] = wv('cls_bbox')[:nc].clone(), wv('cls_bbox')[nc:].clone()
         out['cls_score_bias'], out['bbox_pred_bias'] = bv('cls_bbox')[:nc].clone(), bv('cls_bbox')[nc:].clone()
-        mods = [('', i) for i in (1, 2)] + ([('nms_', 1)] if self.cfg.learn_nms else [])
+        mods = ([('', i) for i in (1, 2)] if self.relation else []) + ([('nms_', 1)] if self.cfg.learn_nms else [])
         for pre, i in mods:
             qk, bq = wv('%sqk_%d' % (pre, i)), bv('%sqk_%d' % (pre, i))
             h = qk.shape[0] // 2
@@ -941,6 +985,10 @@ class Trainer(object):
         the trunk (RPN, conv_new_1 / FPN neck, 2FC + relation + learn-NMS heads).  The backward pass completes them last to first.
         res4's 104 MB are two buckets (cut at unit b11): its second half travels while the first half is still being differentiated,
         and what is left exposed after the last backward kernel is res3 (4.9 MB) plus the tail of a 47 MB message instead of 104 MB."""
+        if getattr(self, '_buckets', None) is None and self.lnms_only:
+            # (learn-NMS-only step: one bucket -- only the head's tail of the buffer ever holds a non-zero gradient)
+            self._bucket_cuts, self._bucket_names, self._unit_bucket = [0, self.W.size], ('heads',), {}
+            self._buckets = D.BucketedAllReduce(self.W.grad, self._bucket_cuts)
         if getattr(self, '_buckets', None) is None:
             trunk = [n for n in self.W.slices if n in self.bn_scale]            # BN-folded res3..res5 convolutions
             first = lambda pre: min(self.W.slices[n][0] for n in trunk if n.startswith(pre))
@@ -995,10 +1043,31 @@ class Trainer(object):
         self._bias_work = None
         return order
 
+    def _trainable_ranges(self, buf):
+        """Contiguous element ranges of a flat buffer that hold trainable slices (everything, unless network.FIXED_PARAMS fixes some)."""
+        if not self.frozen_names:
+            return [(0, buf.size)]
+        key = id(buf)
+        cache = self.__dict__.setdefault('_range_cache', {})
+        if key not in cache:
+            rs = []
+            for n, (off, shape) in sorted(buf.slices.items(), key=lambda kv: kv[1][0]):
+                if n in self.frozen_names:
+                    continue
+                end = off + (int(np.prod(shape)) + 63) // 64 * 64
+                if rs and rs[-1][1] == off:
+                    rs[-1] = (rs[-1][0], end)
+                else:
+                    rs.append((off, end))
+            cache[key] = rs
+        return cache[key]
+
     def _sgd(self, buf, lo, hi, lr, wd, bf16=True):
-        if hi > lo:
-            T.sgd_update(buf.master[lo:hi], buf.mom[lo:hi], buf.grad[lo:hi], lr, self.cfg.momentum, wd, 1.0,
-                         w_bf16=buf.work[lo:hi] if bf16 else None)
+        for a, b_ in self._trainable_ranges(buf):          # (fixed parameters: neither gradient step nor weight decay nor momentum)
+            l, h = max(lo, a), min(hi, b_)
+            if h > l:
+                T.sgd_update(buf.master[l:h], buf.mom[l:h], buf.grad[l:h], lr, self.cfg.momentum, wd, 1.0,
+                             w_bf16=buf.work[l:h] if bf16 else None)
 
     def update(self, lr=None):
         """mx.optimizer.SGD over the flat buffers.  One rank (or everything already waited for): one launch for the weights, one for

@@ -48,15 +48,19 @@ def _setup(H, W, G, seed, dcn=False):
     return p, cfg, data, gt, L, Tg, Wg, train
 
 
-@pytest.mark.parametrize('learn_nms,dcn,chain', [(False, False, False), (True, False, False), (True, True, False), (True, False, True), (True, False, 'trunk_fp32')])
+@pytest.mark.parametrize('learn_nms,dcn,chain', [(False, False, False), (True, False, False), (True, True, False), (True, False, True), (True, False, 'trunk_fp32'),
+                                                 (False, False, 'plain')])
 def test_training_step_gradients_match_autograd(learn_nms, dcn, chain, monkeypatch):
     """(True, False): BASELINE configs[2] (relation + learn-NMS end2end); (False, False): the relation end2end config;
     (True, True): configs[3], deformable res5 + deformable PSROI pooling on top.  chain: the res3 .. res5 block boundaries of the
     forward on the chain kernels (what the benchmark's 19 152-pixel maps run; their pixel thresholds are lowered for this map).
     'trunk_fp32': the same step with conv1 .. res5 in float32 (cfg.trunk_fp32, same wiring code, bf16 heads): what is left of the
     trunk's error is the bf16 heads' error on d conv5 / d conv4, not ~100 layers of rounding -- the trunk tensors are then held to
-    the HEAD's bounds (cosine >= 0.995, norm within 3 %) instead of 0.98 / 8 %."""
+    the HEAD's bounds (cosine >= 0.995, norm within 3 %) instead of 0.98 / 8 %.
+    'plain' (round 6): the plain Faster R-CNN training graph (resnet_v1_101_rcnn.py: 2FC head without relation modules, ENABLE_OHEM false ->
+    SoftmaxOutput over all rois, box loss / 300), the step the `rcnn_end2end_8epoch` / learn-NMS-only experiments build on."""
     trunk_fp32 = chain == 'trunk_fp32'
+    plain = chain == 'plain'
     chain = chain is True
     H, W, G = 128, 160, 4
     p, cfg, data, gt, L, Tg, Wg, train = _setup(H, W, G, 31, dcn)
@@ -65,6 +69,8 @@ def test_training_step_gradients_match_autograd(learn_nms, dcn, chain, monkeypat
         monkeypatch.setattr(_ops, 'CHAIN_MIN_PIXELS', {k: 1 for k in _ops.CHAIN_MIN_PIXELS})
     cfg.learn_nms, cfg.first_n, cfg.dcn = learn_nms, 24, dcn
     cfg.trunk_fp32 = trunk_fp32
+    if plain:
+        cfg.relation, cfg.enable_ohem = False, False
     if learn_nms:          # un-saturate the duplicate classifier (init bias -3 -> sigmoid 0.05) so its gradients are not tiny
         g_ = torch.Generator().manual_seed(77)
         p['nms_logit_bias'] = torch.zeros(5)
@@ -90,7 +96,8 @@ def test_training_step_gradients_match_autograd(learn_nms, dcn, chain, monkeypat
                     target=out['nms_multi_target'][0].cpu().numpy(), first_n=cfg.first_n)
         assert out['nms_multi_target'].sum() > 0                       # some duplicates-free positives exist
     loss, parts = OT.total_loss(data.numpy(), pt, rois, out['label'][0].cpu().numpy(), out['bbox_target'][0].cpu().numpy(),
-                                out['bbox_weight'][0].cpu().numpy(), L, Tg, Wg, N, lnms=lnms, dcn=dcn)
+                                out['bbox_weight'][0].cpu().numpy(), L, Tg, Wg, N, lnms=lnms, dcn=dcn, relation=not plain,
+                                batch_rois_ohem=300 if plain else 128)
     loss.backward()
     if learn_nms:
         ms = out['nms_multi_score'][0].cpu().double()
@@ -119,7 +126,7 @@ def test_training_step_gradients_match_autograd(learn_nms, dcn, chain, monkeypat
           'rpn_out': torch.cat([pt['rpn_cls_score_bias'].grad, pt['rpn_bbox_pred_bias'].grad]),
           'fc_new_1': pt['fc_new_1_bias'].grad, 'fc_new_2': pt['fc_new_2_bias'].grad,
           'cls_bbox': torch.cat([pt['cls_score_bias'].grad, pt['bbox_pred_bias'].grad])}
-    for i in (1, 2):
+    for i in (() if plain else (1, 2)):
         want['qk_%d' % i] = torch.cat([pt['query_%d_weight' % i].grad, pt['key_%d_weight' % i].grad], 0)
         want['linear_out_%d' % i] = pt['linear_out_%d_weight' % i].grad.reshape(1024, 1024)
         want['pair_pos_fc1_%d' % i] = pt['pair_pos_fc1_%d_weight' % i].grad
@@ -190,6 +197,80 @@ def test_training_steps_reduce_the_loss_and_update_only_trainable():
         else:
             want = 4
         assert i == want, (name, i, want)
+
+
+def test_learn_nms_only_experiment_trains_the_head_and_nothing_else():
+    """The learn-NMS-only experiment (..._rcnn_end2end_learn_nms_3epoch.yaml: JOINT_TRAINING false, ENABLE_OHEM false, FIXED_PARAMS = the whole
+    detector incl. -- by core/module.py:753-764's substring rule -- rpn_cls_score / rpn_bbox_pred; symbol resnet_v1_101_rcnn_learn_nms_1024_...:
+    plain 2FC head): Config.from_experiment gives the flags, the Trainer recognises the pruned step, only the learn-NMS head's slices of the flat
+    buffers receive a gradient, those gradients match float64 autograd of oracle/train_graph.py:learn_nms_loss on the run's own class scores and
+    fc_all_2_relu, and an optimizer step leaves every fixed weight bit-identical."""
+    from oracle import train_graph as OT
+    H, W, G = 128, 160, 4
+    p, _, data, gt, L, Tg, Wg, train = _setup(H, W, G, 57)
+    g_ = torch.Generator().manual_seed(58)
+    p['nms_logit_bias'] = torch.zeros(5)
+    for k in ('nms_logit_weight', 'nms_rank_weight', 'roi_feat_embedding_weight', 'nms_query_1_weight', 'nms_key_1_weight',
+              'nms_linear_out_1_weight', 'nms_pair_pos_fc1_1_weight'):
+        p[k] = torch.randn(p[k].shape, generator=g_) * 0.05
+    cfg = train.TrainConfig.from_experiment('rcnn_end2end_learn_nms_3epoch', train=True)
+    assert cfg.learn_nms and not cfg.relation and not cfg.enable_ohem and not cfg.joint_training and 'fc_new' in cfg.fixed_params
+    cfg.rpn_post_nms_top_n, cfg.first_n = 40, 24
+    tr = train.Trainer(p, cfg, im_hw=(H, W))
+    lnms = {'nms_rank', 'roi_feat_embedding', 'nms_pair_pos_fc1_1', 'nms_logit', 'nms_qk_1', 'nms_linear_out_1'}
+    assert tr.lnms_only and not tr.relation and set(tr.W.slices) - tr.frozen_names == lnms and 'rpn_out' in tr.frozen_names
+    assert 'qk_1' not in tr.W.slices
+    d = lambda a: torch.as_tensor(a).cuda()
+    batch = (data.cuda(), torch.tensor([[H, W, 1.0]]).cuda(), d(gt), d(L[None]), d(Tg[None]), d(Wg[None]))
+    w0, b0 = tr.W.master.clone(), tr.Bv.master.clone()
+    with torch.no_grad():
+        out = tr.forward_backward(*batch)
+    torch.cuda.synchronize()
+    for buf in (tr.W, tr.Bv):
+        for n, (off, shape) in buf.slices.items():
+            gnorm = float(buf.view(buf.grad, n).abs().max())
+            assert (gnorm > 0) == (n in lnms), (n, gnorm)
+    assert float(out['nms_multi_target'].sum()) >= 0 and torch.isfinite(out['nms_pos_loss'])
+    # float64 autograd of the learn-NMS branch on the run's own inputs (teacher forced on its ranks / boxes / targets)
+    N = tr.cfg.rpn_post_nms_top_n
+    names = ['nms_rank', 'roi_feat_embedding', 'nms_pair_pos_fc1_1', 'nms_logit', 'nms_query_1', 'nms_key_1', 'nms_linear_out_1']
+    pd = {k + s_: p[k + s_].double().clone().requires_grad_(True) for k in names for s_ in ('_weight', '_bias')}
+    cs64 = out['cls_score'][0, :N].double().cpu().requires_grad_(True)
+    ft64 = out['fc_all_2_relu'][0, :N].double().cpu().requires_grad_(True)
+    loss, multi = OT.learn_nms_loss(cs64, ft64, pd, out['nms_rank_idx'][0].cpu().numpy(), out['nms_class_boxes'][0].cpu().numpy(),
+                                    out['nms_multi_target'][0].cpu().numpy(), cfg.first_n)
+    loss.backward()
+    assert (out['nms_multi_score'][0].cpu().double() - multi.detach()).abs().max() <= 0.03 * multi.abs().max()
+    gw = lambda n: tr.W.view(tr.W.grad, n).cpu().double()
+    got = {'nms_rank': gw('nms_rank'), 'roi_feat_embedding': gw('roi_feat_embedding'), 'nms_pair_pos_fc1_1': gw('nms_pair_pos_fc1_1'),
+           'nms_logit': gw('nms_logit'), 'nms_query_1': gw('nms_qk_1')[:1024], 'nms_key_1': gw('nms_qk_1')[1024:], 'nms_linear_out_1': gw('nms_linear_out_1')}
+    bad = []
+    for n in names:
+        w_, g = pd[n + '_weight'].grad.reshape(-1), got[n].reshape(-1)
+        if float(w_.norm()) < 1e-9:
+            continue
+        cos = float((w_ * g).sum() / (w_.norm() * g.norm()))
+        if cos < (0.98 if 'pair_pos' in n else 0.995) or abs(float(g.norm() / w_.norm()) - 1) > 0.04:
+            bad.append((n, cos, float(g.norm() / w_.norm())))
+    assert not bad, bad
+    with torch.no_grad():
+        tr.all_reduce(); tr.update()
+    torch.cuda.synchronize()
+    for buf, before in ((tr.W, w0), (tr.Bv, b0)):
+        for n in buf.slices:
+            same = torch.equal(buf.view(buf.master, n), buf.view(before, n))
+            assert same == (n not in lnms) or (n in lnms and float(buf.view(buf.grad, n).abs().max()) == 0), (n, same)
+    ex = tr.export_params()
+    assert 'query_1_weight' not in ex and 'nms_query_1_weight' in ex and 'fc_new_1_weight' in ex
+    # the captured form of the same step: one graph, same gradients up to the order of the atomic sums
+    g_eager = tr.W.grad.clone()
+    with torch.no_grad():
+        step = train.CapturedStep(tr, batch)
+        step.replay()
+    torch.cuda.synchronize()
+    assert len(step.segments) == 1
+    assert torch.isfinite(tr.W.grad).all() and float(tr.W.grad.abs().max()) > 0
+    del g_eager
 
 
 @pytest.mark.parametrize('N,first_n,ohem,trunk_fp32', [(60, 24, 128, False), (200, 150, 512, False), (200, 150, 512, True)])
