@@ -40,12 +40,12 @@ def pad32(m):
 
 
 _GEMM_WS = {}
-_GEMM_WS_BYTES = 16384 + (40 << 20)
+_GEMM_WS_BYTES = 16384 + (16 << 20)        # counters + partial tiles: the default rule splits <= 128 tiles 4 ways = 8.4 MB at most; a launch that does not fit runs unsplit
 
 
 def gemm_workspace():
     """Names the split-K work area of the CURRENT stream to the library (relnet_gemm_set_workspace, tile configuration 23) before a
-    GEMM / convolution call: one 40 MB area per launching stream, made on the stream's first GEMM and kept for the life of the
+    GEMM / convolution call: one 16 MB area per launching stream, made on the stream's first GEMM and kept for the life of the
     process -- launches on one stream are ordered, which is what the area needs.  A stream that is being captured into a hipGraph
     gets an area per CAPTURE (relnet_stream_capture_id): it comes from that capture's memory pool, the zeroing of its 16 KB of
     counters is a node of the graph, and the reference held here keeps the block from being handed out again.  The library only

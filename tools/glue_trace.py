@@ -21,7 +21,7 @@ g = torch.Generator().manual_seed(1000)
 data = torch.randn(B, 3, H, W, generator=g).cuda()
 im_info = torch.tensor([[float(H), float(W), 1.0]] * B).cuda()
 if infer:
-    det = detector.Detector(params, detector.Config())
+    det = detector.Detector(params, cfg=detector.Config())
     step = lambda: det.forward(data, im_info)
 else:
     cfg = train.TrainConfig.from_experiment('rcnn_end2end_relation_learn_nms_8epoch', train=True)
