@@ -613,6 +613,13 @@ int relnet_roi_pool_fpn_bwd(const void* grad_out, const int* argmax, const long*
 int relnet_roi_pool_bwd_ex(const void* grad_out, const int* argmax, const long* out_strides4, const float* rois,
                            float* grad_in, long gs_b, long gs_c, long gs_p, int R, int C, int W, int PH, int PW,
                            int batch_index_base, int dtype, void* stream);
+/* The same adjoint for a channels-last gradient: grad_in fp32 [B][H][W][C] (dense, accumulated into).  Round 6: where the operands allow (channels contiguous
+ * in grad_out / argmax, 8 | C, H W <= 4608 cells) ONE workgroup owns (image, 4 or 8 channels): the H x W slab is accumulated in LDS over every (roi, bin) of the
+ * image and flushed once -- no global atomics (31 M contended float atomics = 0.44 ms per 8-image training step before); otherwise the scatter kernel.
+ * relnet_roi_pool_bwd_debug(1) forces the scatter kernel. */
+int relnet_roi_pool_bwd_cl(const void* grad_out, const int* argmax, const long* out_strides4, const float* rois, float* grad_in,
+                           int B, int H, int W, int R, int C, int PH, int PW, int batch_index_base, int dtype, void* stream);
+void relnet_roi_pool_bwd_debug(int mode);
 int relnet_roi_pool_fpn_bwd_ex(const void* grad_out, const int* argmax, const long* out_strides4, const float* rois,
                                const int* roi_level, float* const* grad_in_levels, const long* gs_b_levels,
                                const long* gs_c_levels, const long* gs_p_levels /* NULL = 1 */, int num_levels, int R, int C,

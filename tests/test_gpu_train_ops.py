@@ -376,3 +376,46 @@ def test_relation_bwd_pack_and_lnms_scatter():
                 if rank[b, c, f] >= 0:
                     ref[b, rank[b, c, f], c] += ds[b, f, c]
     assert torch.allclose(got, ref, atol=1e-6)
+
+
+@pytest.mark.parametrize('B,dt', [(8, torch.bfloat16), (1, torch.bfloat16), (3, torch.float32)])
+def test_roi_pool_backward_owner_form_equals_scatter_and_definition(B, dt):
+    """relnet_roi_pool_bwd_cl (round 6): one workgroup per (image, 4 / 8 channels) accumulates its H x W slab in LDS and flushes it once, against
+    the atomic scatter kernel (relnet_roi_pool_bwd_debug(1)) and against the definition grad_in[b, c, argmax[r, c, ph, pw]] += grad_out[r, c, ph, pw]
+    in float64.  Heavily overlapping rois (the contended case), rois of the images interleaved (the kernel selects by batch index, not by position),
+    accumulation on top of a non-zero buffer is the caller's zeros + add."""
+    ops, T = _mods()
+    from relnet_amd import lib as L
+    g = torch.Generator().manual_seed(40 + B)
+    H, W, C, Rpi = 38, 63, 256, 77
+    feat = torch.randn(B, H, W, C, generator=g).to(dt).cuda().permute(0, 3, 1, 2)
+    rois = []
+    for b in range(B):
+        x1 = torch.rand(Rpi, generator=g) * 500; y1 = torch.rand(Rpi, generator=g) * 300
+        w_ = 60 + torch.rand(Rpi, generator=g) * 400; h_ = 60 + torch.rand(Rpi, generator=g) * 250
+        rois.append(torch.stack([torch.full((Rpi,), float(b)), x1, y1, (x1 + w_).clamp(max=999), (y1 + h_).clamp(max=599)], 1))
+    rois = torch.cat(rois, 0)
+    rois = rois[torch.randperm(rois.shape[0], generator=g)].contiguous().cuda()
+    pooled, argmax = ops.roi_pool(feat, rois, (7, 7), 1.0 / 16, channels_last_out=True, want_argmax=True)
+    gout = torch.randn(pooled.shape, generator=g).to(dt).cuda().contiguous(memory_format=torch.channels_last)
+    assert gout.stride() == argmax.stride()
+    res = {}
+    for mode in (1, 0):
+        L.load().relnet_roi_pool_bwd_debug(mode)
+        try:
+            res[mode] = ops.roi_pool_bwd(gout, argmax, rois, (B, C, H, W), channels_last=True).clone()
+        finally:
+            L.load().relnet_roi_pool_bwd_debug(0)
+    torch.cuda.synchronize()
+    want = np.zeros((B, C, H * W))
+    am = argmax.cpu().numpy(); go = gout.double().cpu().numpy(); rb = rois[:, 0].long().cpu().numpy()
+    for r in range(rois.shape[0]):
+        a = am[r].reshape(C, -1); v = go[r].reshape(C, -1)
+        for k in range(49):
+            ok = a[:, k] >= 0
+            np.add.at(want[rb[r]], (np.nonzero(ok)[0], a[ok, k]), v[ok, k])
+    want = want.reshape(B, C, H, W)
+    scale = np.abs(want).max()
+    for mode in (0, 1):
+        got = res[mode].double().cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-5 * scale, (mode, np.abs(got - want).max() / scale)
