@@ -494,6 +494,11 @@ int relnet_lnms_cond_bwd(const float* d_multi, const float* cond, const float* s
                          void* stream);
 int relnet_lnms_take_bwd(const void* d_x, const int* rank_idx, float* d_emb, int B, int N, int C, int F, void* stream);
 int relnet_lnms_softmax_bwd(const float* prob, const float* d_prob, float* d_cls, long ld_row, long ld_img, int B, int N, int C, void* stream);
+/* the geometry bias ln G of the learn-NMS head's class-batched relation module from ONE per-image table: out [B C][16][F][Fpad] fp32 with
+ * out[b C + c][h][f1][f2] = img [B][16][N][Npad] at (rank_idx[b][c][f1], rank_idx[b][c][f2]) for f2 < F (pad columns unwritten); rank_idx [B][C][F] >= 0.
+ * The class's boxes are the image's boxes re-ordered by its ranks (operator_py/learn_nms.py:291-308), so this equals relnet_geometry_bias on the
+ * gathered boxes bit for bit at B N^2 instead of B C F^2 pair evaluations */
+int relnet_lnms_gather_bias(const float* img, const int* rank_idx, float* out, int B, int C, int N, int Npad, int F, int Fpad, void* stream);
 
 /* q [B][N][..], k [B][M][..] as in the forward; kt = K^T [B][H*64][>=Mpad] and qt = Q^T, dyt = dY^T
  * [B][H*64][>=Npad] zero padded; vw = F_K Wout^T [B][M][H*64] (not transposed); bias = fp32 log G of the forward;

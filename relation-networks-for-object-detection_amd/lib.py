@@ -111,6 +111,7 @@ _SIGNATURES = {
     'relnet_lnms_cond_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'relnet_lnms_take_bwd': (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'relnet_lnms_softmax_bwd': (C.c_int, [_vp, _vp, _vp, _l, _l, _i, _i, _i, _vp]),
+    'relnet_lnms_gather_bias': (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_gemm_nt_mask': (C.c_int, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _vp]),
     'relnet_gemm_nt_f16': (C.c_int, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _vp]),
     'relnet_gemm_set_swizzle': (None, [_i]),

@@ -140,6 +140,25 @@ def test_fused_glue_kernels_equal_the_tensor_operator_chains():
         torch.cuda.synchronize()
         res[fused] = dict(d_cls=acc.clone(), d_feat=d_feat.clone(), multi=lo['nms_multi_score'].clone(), pos=lo['nms_pos_loss'].clone(),
                           neg=lo['nms_neg_loss'].clone(), wg=tr.W.grad.clone(), bg=tr.Bv.grad.clone())
+    # the per-image geometry table gathered by the class ranks (relnet_lnms_gather_bias) IS the direct per-class evaluation, bit for bit
+    from relnet_amd import ops, lib as _lib
+    from relnet_amd.relation import pack_pair_pos
+    F_ = cfg.first_n
+    class M_(object):
+        pass
+    m_ = M_(); m_.wp = tr.W.view(tr.W.master, 'nms_pair_pos_fc1_1'); m_.bp = tr.b('nms_pair_pos_fc1_1')
+    wp_t, bp = pack_pair_pos([m_], 'cuda')
+    direct = ops.geometry_bias(lo['nms_class_boxes'].view(B * C, F_, 4), wp_t, bp, F_, fast32=True)[0]
+    boxes = torch.empty((B, N, 4), device='cuda')
+    for b in range(B):          # class_boxes[b, c, f] = boxes[b, rank_idx[b, c, f]]: recover the image's box list from any class that ranks the roi
+        ri = lo['nms_rank_idx'][b].long()
+        boxes[b].index_copy_(0, ri.reshape(-1), lo['nms_class_boxes'][b].reshape(-1, 4))
+    img = ops.geometry_bias(boxes, wp_t, bp, N, fast32=True)[0]
+    gathered = torch.empty_like(direct)
+    _lib.call('relnet_lnms_gather_bias', img.data_ptr(), lo['nms_rank_idx'].data_ptr(), gathered.data_ptr(), B, C, N, img.shape[-1], F_, gathered.shape[-1],
+              torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(gathered[..., :F_], direct[..., :F_])
     a, b_ = res[False], res[True]
     assert torch.equal(a['d_cls'][:, N:], base[:, N:]) and torch.equal(b_['d_cls'][:, N:], base[:, N:])       # rows past N untouched
     for k in ('multi', 'pos', 'neg', 'd_cls', 'd_feat', 'wg', 'bg'):
