@@ -223,36 +223,49 @@ extern "C" int relnet_roi_pool_fpn_fwd(const void* const* data_levels, const lon
 // [R][PH][PW][C], gradient [B][H W][C]), dense maps of <= kOwnerMaxCells cells; everything else (NCHW, FPN levels, large maps) keeps the scatter kernel.
 constexpr int kOwnerMaxCells = 4608;            // 4608 cells x 8 channels x 4 B = 147 KB of LDS
 
+constexpr int kOwnerList = 1024;                // rois per pass of the compact list (4 KB of LDS next to the slab)
+
 template <typename T, int CH>
 __global__ __launch_bounds__(256) void roi_pool_bwd_owner_kernel(RoiBwdArgs g, int cells) {
-  extern __shared__ float slab[];               // [cells][CH]
+  extern __shared__ float slab[];               // [cells][CH], then the roi list
+  int* list = (int*)(slab + (long)cells * CH);
+  __shared__ int cnt;
   const int chunks = g.C / CH;
   const int b = blockIdx.x / chunks, c0 = (blockIdx.x % chunks) * CH;
   for (int i = threadIdx.x; i < cells * CH; i += 256) slab[i] = 0.f;
+  if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
   const int bins = g.PH * g.PW;
-  const long pairs = (long)g.R * bins;
-  for (long p = threadIdx.x; p < pairs; p += 256) {
-    const int r = (int)(p / bins), bin = (int)(p - (long)r * bins);
-    if ((int)g.rois[(long)r * 5] - g.batch_index_base != b) continue;
-    const int ph = bin / g.PW, pw = bin - ph * g.PW;
-    const long o = (long)r * g.os_r + (long)ph * g.os_ph + (long)pw * g.os_pw + c0;           // (os_c == 1)
-    int a[CH];
-    float v[CH];
-    if constexpr (CH == 8) {
-      const int4 a0 = *(const int4*)(g.argmax + o), a1 = *(const int4*)(g.argmax + o + 4);
-      a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
-    } else {
-      const int4 a0 = *(const int4*)(g.argmax + o);
-      a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w;
+  // pass over the rois in segments of kOwnerList: the image's own rois go into a compact list (a scan over (roi, bin) PAIRS that skips 7 of 8 of them
+  // one dependent load at a time was the first form: latency bound), then the (listed roi, bin) pairs are walked at full occupancy
+  for (int base = 0; base < g.R; base += kOwnerList) {
+    for (int r = base + threadIdx.x; r < min(base + kOwnerList, g.R); r += 256)
+      if ((int)g.rois[(long)r * 5] - g.batch_index_base == b) list[atomicAdd(&cnt, 1)] = r;
+    __syncthreads();
+    const int n = cnt;
+    for (int p = threadIdx.x; p < n * bins; p += 256) {
+      const int r = list[p / bins], bin = p % bins;
+      const int ph = bin / g.PW, pw = bin - ph * g.PW;
+      const long o = (long)r * g.os_r + (long)ph * g.os_ph + (long)pw * g.os_pw + c0;           // (os_c == 1)
+      int a[CH];
+      float v[CH];
+      if constexpr (CH == 8) {
+        const int4 a0 = *(const int4*)(g.argmax + o), a1 = *(const int4*)(g.argmax + o + 4);
+        a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+      } else {
+        const int4 a0 = *(const int4*)(g.argmax + o);
+        a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w;
+      }
+#pragma unroll
+      for (int e = 0; e < CH; ++e) v[e] = ld<T>((const T*)g.grad_out + o + e);
+#pragma unroll
+      for (int e = 0; e < CH; ++e)
+        if (a[e] >= 0 && a[e] < cells) atomicAdd(&slab[a[e] * CH + e], v[e]);
     }
-#pragma unroll
-    for (int e = 0; e < CH; ++e) v[e] = ld<T>((const T*)g.grad_out + o + e);
-#pragma unroll
-    for (int e = 0; e < CH; ++e)
-      if (a[e] >= 0 && a[e] < cells) atomicAdd(&slab[a[e] * CH + e], v[e]);
+    __syncthreads();
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
   }
-  __syncthreads();
   float* gin = g.grad_in + (long)b * g.ds_b + c0;
   for (int i = threadIdx.x; i < cells; i += 256) {
     float* dst = gin + (long)i * g.ds_p;
@@ -279,27 +292,20 @@ extern "C" int relnet_roi_pool_bwd_cl(const void* grad_out, const int* argmax, c
   RoiBwdArgs g{grad_out, argmax, out_strides4[0], out_strides4[1], out_strides4[2], out_strides4[3],
                rois, grad_in, cells * C, 1, R, C, W, PH, PW, batch_index_base, nullptr, {}, (long)C};
   hipStream_t s = (hipStream_t)stream;
-  const bool owner = g_roi_bwd_mode != 1 && g.os_c == 1 && C % 8 == 0 && cells <= kOwnerMaxCells && g.os_r % 4 == 0 && g.os_ph % 4 == 0 &&
+  // (one workgroup per CU at least: B C / 8 >= 256.  Same box, r06: 8 images 18.03 -> 17.81 ms with the owner form, ONE image 6.91 -> 7.00 ms -- 32 - 64 workgroups
+  //  walking 308 rois lose to the 65 us scatter -- so small steps keep the scatter kernel)
+  const bool owner = g_roi_bwd_mode != 1 && (long)B * C / 8 >= 256 && g.os_c == 1 && C % 8 == 0 && cells <= kOwnerMaxCells && g.os_r % 4 == 0 && g.os_ph % 4 == 0 &&
                      g.os_pw % 4 == 0 && (((uintptr_t)argmax) & 15) == 0 && (((uintptr_t)grad_in) & 15) == 0;
   if (owner) {
-    // 8 channels per workgroup when that still gives every CU one (B C / 8 >= 256), else 4: the one- and two-image steps
-    const int ch = ((long)B * C / 8 >= 256) ? 8 : 4;
-    const unsigned grid = (unsigned)(B * (C / ch));
-    const size_t lds = (size_t)cells * ch * sizeof(float);
+    const unsigned grid = (unsigned)(B * (C / 8));
+    const size_t lds = (size_t)cells * 8 * sizeof(float) + kOwnerList * sizeof(int);
     static relnet::PerDeviceOnce attr_once;
     if (attr_once.first()) {
-      hipFuncSetAttribute((const void*)roi_pool_bwd_owner_kernel<float, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute((const void*)roi_pool_bwd_owner_kernel<float, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute((const void*)roi_pool_bwd_owner_kernel<unsigned short, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute((const void*)roi_pool_bwd_owner_kernel<unsigned short, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute((const void*)roi_pool_bwd_owner_kernel<float, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);      // (+ 4 B of static LDS: the list counter)
+      hipFuncSetAttribute((const void*)roi_pool_bwd_owner_kernel<unsigned short, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     }
-    if (dtype == RELNET_F32) {
-      if (ch == 8) roi_pool_bwd_owner_kernel<float, 8><<<grid, 256, lds, s>>>(g, (int)cells);
-      else roi_pool_bwd_owner_kernel<float, 4><<<grid, 256, lds, s>>>(g, (int)cells);
-    } else {
-      if (ch == 8) roi_pool_bwd_owner_kernel<unsigned short, 8><<<grid, 256, lds, s>>>(g, (int)cells);
-      else roi_pool_bwd_owner_kernel<unsigned short, 4><<<grid, 256, lds, s>>>(g, (int)cells);
-    }
+    if (dtype == RELNET_F32) roi_pool_bwd_owner_kernel<float, 8><<<grid, 256, lds, s>>>(g, (int)cells);
+    else roi_pool_bwd_owner_kernel<unsigned short, 8><<<grid, 256, lds, s>>>(g, (int)cells);
     return check_launch("relnet_roi_pool_bwd_cl");
   }
   dim3 grid((unsigned)((long)R * PH * PW));
@@ -353,6 +359,8 @@ extern "C" int relnet_roi_pool_fpn_bwd_ex(const void* grad_out, const int* argma
   return check_launch("relnet_roi_pool_fpn_bwd");
 }
 
+// (An FPN form of the owner kernel -- per level, the stride-4 map cut into 12 bands of whole rows -- was built and measured in round 6: 37.2 ms per 8-image
+//  FPN step with either kernel; the band workgroups re-read the level's argmax rows once per band, which costs what the contention did.  Removed.)
 extern "C" int relnet_roi_pool_fpn_bwd(const void* grad_out, const int* argmax, const long* out_strides4, const float* rois,
                                        const int* roi_level, float* const* grad_in_levels, const long* gs_b_levels,
                                        const long* gs_c_levels, int num_levels, int R, int C, int PH, int PW,

@@ -355,7 +355,7 @@ def roi_pool_bwd(grad_out, argmax, rois, in_shape, batch_index_base=0, channels_
     R, _, PH, PW = grad_out.shape
     if channels_last:
         gin = torch.zeros((B, H, W, Cc), device=grad_out.device, dtype=torch.float32).permute(0, 3, 1, 2)
-        # (relnet_roi_pool_bwd_cl: one workgroup per (image, 4 - 8 channels) accumulates its slab in LDS where the operands allow -- no global atomics)
+        # (relnet_roi_pool_bwd_cl: from 8 images x 256 channels up, one workgroup per (image, 8 channels) accumulates its slab in LDS -- no global atomics)
         _lib.call('relnet_roi_pool_bwd_cl', grad_out.data_ptr(), argmax.data_ptr(), _strides4(grad_out), rois.data_ptr(), gin.data_ptr(),
                   B, H, W, R, Cc, PH, PW, batch_index_base, _dt(grad_out), _stream())
         return gin

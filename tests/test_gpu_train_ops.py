@@ -378,9 +378,10 @@ def test_relation_bwd_pack_and_lnms_scatter():
     assert torch.allclose(got, ref, atol=1e-6)
 
 
-@pytest.mark.parametrize('B,dt', [(8, torch.bfloat16), (1, torch.bfloat16), (3, torch.float32)])
+@pytest.mark.parametrize('B,dt', [(8, torch.bfloat16), (1, torch.bfloat16), (9, torch.float32)])
 def test_roi_pool_backward_owner_form_equals_scatter_and_definition(B, dt):
-    """relnet_roi_pool_bwd_cl (round 6): one workgroup per (image, 4 / 8 channels) accumulates its H x W slab in LDS and flushes it once, against
+    """relnet_roi_pool_bwd_cl (round 6): one workgroup per (image, 8 channels) accumulates its H x W slab in LDS and flushes it once (steps of >= 8 images x 256
+    channels; the one-image case runs the scatter kernel on both sides), against
     the atomic scatter kernel (relnet_roi_pool_bwd_debug(1)) and against the definition grad_in[b, c, argmax[r, c, ph, pw]] += grad_out[r, c, ph, pw]
     in float64.  Heavily overlapping rois (the contended case), rois of the images interleaved (the kernel selects by batch index, not by position),
     accumulation on top of a non-zero buffer is the caller's zeros + add."""
