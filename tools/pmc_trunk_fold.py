@@ -84,7 +84,7 @@ def trunk(src, out, kernels=None, images=54):
 
 def attn(src, out):
     K = 'relnet::relation_attention_lds_kernel(relnet::AttnArgs, int, int)'
-    res = {'round': 5, 'kernel': K,
+    res = {'round': int(os.environ.get('RELNET_ROUND', '6')), 'kernel': K,
            'command': 'cd /tmp && export TMPDIR=/tmp; rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python tools/attn_only.py <108|54> 6   (one pass per '
                       'counter group: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE; `bash tools/scripts/gpu_runs.sh '
                       'pmc_attn`, folded by tools/pmc_collect.py + tools/pmc_trunk_fold.py; MI355X, ROCm 7.2, the round-5 binary)',
