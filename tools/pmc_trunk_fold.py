@@ -87,7 +87,7 @@ def attn(src, out):
     res = {'round': int(os.environ.get('RELNET_ROUND', '6')), 'kernel': K,
            'command': 'cd /tmp && export TMPDIR=/tmp; rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python tools/attn_only.py <108|54> 6   (one pass per '
                       'counter group: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE; `bash tools/scripts/gpu_runs.sh '
-                      'pmc_attn`, folded by tools/pmc_collect.py + tools/pmc_trunk_fold.py; MI355X, ROCm 7.2, the round-5 binary)',
+                      'pmc_attn`, folded by tools/pmc_collect.py + tools/pmc_trunk_fold.py; MI355X, ROCm 7.2, the binary of the round named above)',
            'note': 'FETCH_SIZE / WRITE_SIZE are in KiB. On gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section), so the '
                    'read side is doubled; WRITE_SIZE is taken as is. The launch is the pipeline\'s: one output, ReLU(out + shortcut). bench.py reads '
                    'hbm_bytes_per_launch_at_batch[<images per step>] as roofline.traffic.',
