@@ -604,6 +604,9 @@ int relnet_deformable_psroi_pool_bwd(const void* grad_out, const long* grad_out_
                                      int H, int W, int output_dim, int group_size, int pooled_size, int part_size,
                                      int sample_per_part, float spatial_scale, float trans_std, int num_classes,
                                      int batch_index_base, int dtype, void* stream);
+/* test / measurement knob of the entry above: 0 = auto (round 6: four channels per thread where the roi geometry / offsets / per-axis cell sums of a bin do not
+ * depend on the channel: group_size 1, one offset class or none, sample_per_part <= 4, 256 | output_dim), 1 = one channel per thread everywhere */
+void relnet_deformable_psroi_pool_bwd_debug(int mode);
 
 /* Adjoint of relnet_roi_pool_fpn_fwd (argmax from the forward, same strides as grad_out): roi r scatters into
  * grad_in_levels[roi_level[r]] (fp32 [B,C,H_l*W_l] with batch / channel strides gs_b / gs_c; host arrays).     */

@@ -125,6 +125,7 @@ _SIGNATURES = {
     'relnet_roi_pool_bwd_cl': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_roi_pool_bwd_debug': (None, [_i]),
     'relnet_deformable_col2im_debug': (None, [_i]),
+    'relnet_deformable_psroi_pool_bwd_debug': (None, [_i]),
     'relnet_stream_capture_id': (C.c_ulonglong, [_vp]),
     'relnet_gemm_debug_splitk': (None, [_i]),
     'relnet_gemm_pick_tile': (C.c_int, [_i, _i, _i, _i, _i]),

@@ -351,6 +351,49 @@ def test_col2im_gather_form_equals_the_atomic_scatter(sigma):
             assert err < 2e-5, (sigma, mode, what, err)
 
 
+@pytest.mark.parametrize('B,with_trans,chlast', [(8, True, True), (8, False, True), (2, True, False)])
+def test_psroi_backward_four_channels_per_thread_equals_one(B, with_trans, chlast):
+    """relnet_deformable_psroi_pool_bwd on the training step's shapes (features 38 x 63 x 256, 308 rois per image, 7 x 7 bins, 4 x 4 samples,
+    class-agnostic offsets): the four-channels-per-thread kernel (round 6: roi geometry / offsets / per-axis cell sums built once per four
+    channels) against the one-channel kernel (relnet_deformable_psroi_pool_bwd_debug(1)), channels-last bf16 and NCHW fp32 operands."""
+    ops, _ = _mods()
+    from relnet_amd import lib
+    L = lib.load()
+    g_ = torch.Generator().manual_seed(7 * B + int(with_trans))
+    C, H, W, Rpi = 256, 38, 63, 308
+    dt = torch.bfloat16 if chlast else torch.float32
+    feat = torch.randn(B, H, W, C, generator=g_).to(dt).cuda().permute(0, 3, 1, 2)
+    if not chlast:
+        feat = feat.contiguous()
+    rois = []
+    for b in range(B):
+        x1 = torch.rand(Rpi, generator=g_) * 700; y1 = torch.rand(Rpi, generator=g_) * 400
+        w_ = 30 + torch.rand(Rpi, generator=g_) * 500; h_ = 30 + torch.rand(Rpi, generator=g_) * 300
+        rois.append(torch.stack([torch.full((Rpi,), float(b)), x1, y1, (x1 + w_).clamp(max=999), (y1 + h_).clamp(max=599)], 1))
+    rois = torch.cat(rois, 0).contiguous().cuda()
+    R = rois.shape[0]
+    trans = (torch.randn(R, 2, 7, 7, generator=g_) * 2.0).cuda() if with_trans else None
+    gout = torch.randn(R, 7, 7, C, generator=g_).to(dt).cuda().permute(0, 3, 1, 2)
+    if not chlast:
+        gout = gout.contiguous()
+    res = {}
+    try:
+        for mode in (1, 0):
+            L.relnet_deformable_psroi_pool_bwd_debug(mode)
+            gd, gt = ops.deformable_psroi_pool_bwd(gout, feat, rois, trans, 0.0625, C, 1, 7, 7, 4, 0.1 if with_trans else 0.0, not with_trans)
+            torch.cuda.synchronize()
+            res[mode] = (gd.clone(), None if gt is None else gt.clone())
+    finally:
+        L.relnet_deformable_psroi_pool_bwd_debug(0)
+    scale = res[1][0].abs().max().item()
+    assert scale > 0
+    err = (res[0][0] - res[1][0]).abs().max().item() / scale
+    assert err < 2e-5, ('grad_data', err)
+    if with_trans:
+        ts = res[1][1].abs().max().item()
+        assert ts > 0 and (res[0][1] - res[1][1]).abs().max().item() / ts < 2e-5
+
+
 @pytest.mark.parametrize("case", PSROI_CASES)
 def test_psroi_backward(case):
     ops, _ = _mods()
