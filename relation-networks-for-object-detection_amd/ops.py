@@ -847,7 +847,7 @@ def deformable_im2col(data, offset, kernel=(3, 3), stride=(1, 1), dilate=(1, 1),
 
 
 def deformable_conv(data, offset, w_packed, bias=None, kernel=(3, 3), stride=(1, 1), dilate=(1, 1), pad=(0, 0),
-                    num_deformable_group=1, relu=False, out_dtype=None):
+                    num_deformable_group=1, relu=False, out_dtype=None, want_col=False):
     """DeformableConvolutionOp::Forward (deformable_convolution-inl.h:91-143) with the bias (or folded BatchNorm) and ReLU
     fused into the GEMM epilogue: sampling kernel (relnet_deformable_im2col, column matrix in (tap, channel) order) + NT GEMM
     (the res5 shape, K = 4608, runs on the hand-scheduled ring kernel).
@@ -855,7 +855,10 @@ def deformable_conv(data, offset, w_packed, bias=None, kernel=(3, 3), stride=(1,
     col, (Ho, Wo) = deformable_im2col(data, offset, kernel, stride, dilate, pad, num_deformable_group,
                                       col_dtype=w_packed.dtype)
     y = gemm_nt(col, w_packed, bias, relu=relu, out_dtype=out_dtype)
-    return y.view(data.shape[0], Ho, Wo, w_packed.shape[0]).permute(0, 3, 1, 2)
+    y = y.view(data.shape[0], Ho, Wo, w_packed.shape[0]).permute(0, 3, 1, 2)
+    # want_col (training): the sampled column matrix [B Ho Wo, kh kw C] is also the X operand of the weight gradient -- kept, it saves the backward a
+    # second sampling pass (deformable_conv_bwd(col=...))
+    return (y, col) if want_col else y
 
 
 def deformable_psroi_pool(data, rois, trans=None, spatial_scale=0.0625, output_dim=256, group_size=1,
@@ -1273,7 +1276,7 @@ def geometry_bias_bwd(boxes, bias, dlog, M, divisors=None, fast=False, out=None)
 
 
 def deformable_conv_bwd(data, offset, w_packed, dy, kernel=(3, 3), stride=(1, 1), dilate=(1, 1), pad=(0, 0),
-                        num_deformable_group=1):
+                        num_deformable_group=1, col=None):
     """Adjoint of deformable_conv.  data logical [B,C,H,W], offset fp32 logical [B,2*kh*kw*dg,Ho,Wo], dy logical
     [B,Cout,Ho,Wo] with channels-last memory ([B,Ho,Wo,Cout] contiguous).
     -> (grad_data fp32 [B,H,W,C] (NHWC), grad_offset fp32 [B,Ho,Wo,2*kh*kw*dg] (NHWC), grad_weight fp32 [Cout, kh*kw*C])."""
@@ -1299,7 +1302,8 @@ def deformable_conv_bwd(data, offset, w_packed, dy, kernel=(3, 3), stride=(1, 1)
     _lib.call('relnet_deformable_col2im', dcol.data_ptr(), dcol.stride(0), _dt(dcol), data.data_ptr(), _strides4(data), _dt(data),
               offset.data_ptr(), _strides4(offset), gdata.data_ptr(), _strides4(gdata), goff.data_ptr(), _strides4(goff),
               B, Cc, H, W, kh, kw, ph, pw, sh, sw, dh, dw, num_deformable_group, _stream())
-    col, _ = deformable_im2col(data, offset, kernel, stride, dilate, pad, num_deformable_group, col_dtype=dy2.dtype)
+    if col is None or col.dtype != dy2.dtype:       # (col: the forward's column matrix, deformable_conv(want_col=True))
+        col, _ = deformable_im2col(data, offset, kernel, stride, dilate, pad, num_deformable_group, col_dtype=dy2.dtype)
     gw = T.wgrad(dy2, col)
     return gdata.permute(0, 2, 3, 1), goff.permute(0, 2, 3, 1), gw
 

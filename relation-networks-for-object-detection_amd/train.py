@@ -417,8 +417,10 @@ class Trainer(object):
             off = None
             if c.dcn and stage == 5:       # 72-channel offset conv -> DeformableConvolution(num_deformable_group=4) + BN + ReLU
                 off = self._conv(y1, nb + '_offset', pad=2, dil=2, bias=self.b(nb + '_offset'), out_dtype=torch.float32)
-                y2 = ops.deformable_conv(y1.permute(0, 3, 1, 2), off.permute(0, 3, 1, 2), self.w(nb), self.conv_bias[nb],
-                                         3, 1, 2, 2, 4, relu=True).permute(0, 2, 3, 1)
+                y2, col = ops.deformable_conv(y1.permute(0, 3, 1, 2), off.permute(0, 3, 1, 2), self.w(nb), self.conv_bias[nb],
+                                              3, 1, 2, 2, 4, relu=True, want_col=True)
+                y2 = y2.permute(0, 2, 3, 1)
+                off = (off, col)           # (the sampled column matrix rides along to the backward: the weight gradient's X operand)
             else:
                 y2 = self._conv(y1, nb, pad=dil, dil=dil, relu=True)
             ch = self.chain_units.get(nm)
@@ -615,8 +617,9 @@ class Trainer(object):
             # (ReLU masks of the two inner activations ride in the data-gradient kernels' epilogues)
             g_y2, dw = T.conv1x1_bwd(y2, self.w(nc_), g_out, w_t=self.wt(nc_), keep_splits=True, wgrad_to=self._wg(nc_, self.bn_scale[nc_]), relu_mask=y2)
             if off is not None:            # deformable branch2b: data + offset gradients, then the offset conv's own backward
+                off, col = off
                 gd, goff, dw = ops.deformable_conv_bwd(y1.permute(0, 3, 1, 2), off.permute(0, 3, 1, 2), self.w(nb),
-                                                       g_y2.permute(0, 3, 1, 2), 3, 1, 2, 2, 4)
+                                                       g_y2.permute(0, 3, 1, 2), 3, 1, 2, 2, 4, col=col)
                 self._add_wgrad(nb, dw, self.bn_scale[nb])
                 no = nb + '_offset'
                 goff_p = torch.zeros((B, off.shape[1], off.shape[2], 128), device=off.device, dtype=bt)   # 72 -> 128 channels
