@@ -186,6 +186,9 @@ int relnet_relation_attention_kc(const void* q, long q_ld, long q_bs, const void
                                  long out_ld, long out_bs, void* out_act, long act_ld, long act_bs, float* logits,
                                  int B, int H, int N, int M, int Mpad, float scale, int in_dtype, int out_dtype,
                                  const int* key_count, void* stream);
+/* tuning / test knob: 1 (default, round 6) = a bf16 launch with a FLOAT32 bias (ln G: the training forward) runs on the LDS-resident kernel like the fp16-bias
+ * inference launches (no logits output); 0 = on the streaming kernel of rounds 1 - 5 */
+void relnet_relation_attention_debug_lds_f32(int on);
 
 /* Geometry + attention of ONE relation module in a single kernel (bf16 throughput path; csrc/relation.hip:
  * relation_fused_kernel): the position embedding (SYM_REL:29-83), pair_pos_fc1 + ReLU + log (:109-116, :139) and the

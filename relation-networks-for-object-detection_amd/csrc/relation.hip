@@ -437,6 +437,9 @@ constexpr int kOLD = 72;                    // epilogue row stride (bf16): 64 + 
 
 // lds layout: sK [kc_rows][64] bf16 (16-B chunks XOR-swizzled), sV [64][vld] bf16 (+ slack); the
 // epilogue reuses the start of the buffer as [nwave][32][kOLD] bf16.
+// BIAS_F32 (round 6): the bias is float32 ln G (the training forward's geometry, which its backward re-derives the softmax from) instead of fp16 log2 G:
+// 16-byte loads per four keys, multiplied by log2 e on the way into the log2-domain logits.
+template <bool BIAS_F32>
 __global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a, int kc_rows, int vld) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
@@ -453,7 +456,9 @@ __global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a
   const T* Q = (const T*)a.q + (long)b * a.q_bs + (long)qc * a.q_ld + h * 64;
   const T* Kb = (const T*)a.k + (long)b * a.k_bs + h * 64;
   const T* Vb = (const T*)a.vwt + (long)b * a.vwt_bs + (long)(h * 64) * a.vwt_ld;
-  const __half* Bq = (const __half*)a.bias + (long)b * a.bias_bs + ((long)h * a.N + qc) * a.Mpad;
+  typedef typename std::conditional<BIAS_F32, float, __half>::type TBIAS;
+  typedef typename std::conditional<BIAS_F32, float4, uint2>::type BV;      // four keys' bias values
+  const TBIAS* Bq = (const TBIAS*)a.bias + (long)b * a.bias_bs + ((long)h * a.N + qc) * a.Mpad;
 
   bf16x8 qf[4];
 #pragma unroll
@@ -471,9 +476,9 @@ __global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a
     if (kc0 > 0) __syncthreads();
     const int clen = min(a.M - kc0, kKC);             // valid keys of this chunk
     // bias of the first tile: issued before the staging so that its latency overlaps it
-    uint2 bcur[4];
+    BV bcur[4];
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) bcur[gq] = *(const uint2*)(Bq + kc0 + 8 * gq + 4 * half);
+    for (int gq = 0; gq < 4; ++gq) bcur[gq] = *(const BV*)(Bq + kc0 + 8 * gq + 4 * half);
     // ---- stage K rows [kc0, kc0+clen) and VW^T columns of this head --------------------------
     // (batches of 2 / 4 loads issued before their LDS writes -- more would spill at the 128 registers of a 1024-thread launch bound: a load -> write loop costs one L2 round trip per iteration, and with 124 VGPRs only ONE
     //  10-wave workgroup is resident per CU, so nothing else runs meanwhile -- r05: the staging was ~2/3 of a workgroup's 30 us)
@@ -518,11 +523,11 @@ __global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a
       for (int kt = 0; kt < ntile; ++kt) {
         const int key0 = kc0 + kt * 32;
         // prefetch the next tile's bias (clamped: the last prefetch re-reads a valid address)
-        uint2 bnext[4];
+        BV bnext[4];
         {
           const int kn = (kt + 1 < ntile) ? key0 + 32 : key0;
 #pragma unroll
-          for (int gq = 0; gq < 4; ++gq) bnext[gq] = *(const uint2*)(Bq + kn + 8 * gq + 4 * half);
+          for (int gq = 0; gq < 4; ++gq) bnext[gq] = *(const BV*)(Bq + kn + 8 * gq + 4 * half);
         }
         f32x16 s;
 #pragma unroll
@@ -540,8 +545,15 @@ __global__ __launch_bounds__(1024) void relation_attention_lds_kernel(AttnArgs a
         float tmax = -INFINITY;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-          const __half2 b01 = *(const __half2*)&bcur[gq].x, b23 = *(const __half2*)&bcur[gq].y;
-          const float bb[4] = {__low2float(b01), __high2float(b01), __low2float(b23), __high2float(b23)};
+          float bb[4];
+          if constexpr (BIAS_F32) {
+            const float4 bv = *(const float4*)&bcur[gq];
+            bb[0] = bv.x * 1.44269504088896340736f; bb[1] = bv.y * 1.44269504088896340736f; bb[2] = bv.z * 1.44269504088896340736f; bb[3] = bv.w * 1.44269504088896340736f;
+          } else {
+            const uint2 bu = *(const uint2*)&bcur[gq];
+            const __half2 b01 = *(const __half2*)&bu.x, b23 = *(const __half2*)&bu.y;
+            bb[0] = __low2float(b01); bb[1] = __high2float(b01); bb[2] = __low2float(b23); bb[3] = __high2float(b23);
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * gq + e;
@@ -943,6 +955,9 @@ extern "C" int relnet_geometry_bias(const float* boxes, int box_stride, int box_
   return check_launch("relnet_geometry_bias");
 }
 
+static int g_attn_lds_f32 = 1;     // tuning / test knob: 1 = bf16 attention with a float32 bias runs on the LDS kernel, 0 = on the streaming kernel (rounds 1 - 5)
+extern "C" void relnet_relation_attention_debug_lds_f32(int on) { g_attn_lds_f32 = on; }
+
 extern "C" int relnet_relation_attention_kc(
     const void* q, long q_ld, long q_bs, const void* k, long k_ld, long k_bs, const void* vwt,
     long vwt_ld, long vwt_bs, const void* bias, int bias_half, long bias_bs, const float* bout,
@@ -963,8 +978,10 @@ extern "C" int relnet_relation_attention_kc(
   a.scale = scale; a.key_count = key_count;
   dim3 grid((unsigned)(((N + 31) / 32 + 3) / 4), H, B);
   hipStream_t s = (hipStream_t)stream;
-  if (in_dtype == RELNET_BF16 && bias_half) {
-    // LDS kernel: fp16 bias, no logits output; one workgroup per (image, head, <=16 query tiles)
+  // round 6: the LDS kernel also takes the float32 ln G of the training forward (g_attn_lds_f32 = 0: the streaming kernel as before)
+  if (in_dtype == RELNET_BF16 && (bias_half || (g_attn_lds_f32 && !logits && Mpad % 4 == 0 && q_ld % 8 == 0 && k_ld % 8 == 0 && vwt_ld % 4 == 0 && out_ld % 8 == 0 &&
+                                                   act_ld % 8 == 0 && resid_ld % 8 == 0 && (((uintptr_t)bias) & 15) == 0 && bias_bs % 4 == 0))) {
+    // LDS kernel: fp16 log2 G (or float32 ln G) bias, no logits output; one workgroup per (image, head, <=16 query tiles)
     RELNET_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && vwt_ld % 4 == 0 && Mpad % 4 == 0, "relnet_relation_attention(bf16): row strides must be 16-byte (q,k) / 8-byte (vwt) aligned");
     RELNET_REQUIRE(!logits, "relnet_relation_attention: logits output needs the fp32-bias kernel (bias_half = 0)");
     RELNET_REQUIRE(out_ld % 8 == 0 && act_ld % 8 == 0 && resid_ld % 8 == 0, "relnet_relation_attention(bf16): output rows must be 16-byte aligned");
@@ -982,10 +999,12 @@ extern "C" int relnet_relation_attention_kc(
     const size_t lds = kv > ep ? kv : ep;
     static relnet::PerDeviceOnce attr_once;
     if (attr_once.first()) {
-      hipFuncSetAttribute((const void*)relation_attention_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute((const void*)relation_attention_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute((const void*)relation_attention_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     dim3 g2((unsigned)((qtiles + nwave - 1) / nwave), H, B);
-    relation_attention_lds_kernel<<<g2, nwave * 64, lds, s>>>(a, kc_rows, vld);
+    if (bias_half) relation_attention_lds_kernel<false><<<g2, nwave * 64, lds, s>>>(a, kc_rows, vld);
+    else relation_attention_lds_kernel<true><<<g2, nwave * 64, lds, s>>>(a, kc_rows, vld);
   } else if (in_dtype == RELNET_BF16) {
     RELNET_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && vwt_ld % 4 == 0, "relnet_relation_attention(bf16): row strides must be 16-byte (q,k) / 8-byte (vwt) aligned");
     relation_attention_kernel<unsigned short, unsigned short><<<grid, 256, 0, s>>>(a);

@@ -125,6 +125,7 @@ _SIGNATURES = {
     'relnet_roi_pool_bwd_cl': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_roi_pool_bwd_debug': (None, [_i]),
     'relnet_deformable_col2im_debug': (None, [_i]),
+    'relnet_relation_attention_debug_lds_f32': (None, [_i]),
     'relnet_deformable_psroi_pool_bwd_debug': (None, [_i]),
     'relnet_stream_capture_id': (C.c_ulonglong, [_vp]),
     'relnet_gemm_debug_splitk': (None, [_i]),
@@ -184,14 +185,14 @@ def load():
         fn.argtypes = args
     # A/B knobs for whole-step measurements without editing code.  They change which kernels run, so they are honoured only
     # together with RELNET_DEBUG_KNOBS=1 and every use is announced on stderr (a forced tile is a measured-slower configuration)
-    knobs = [(k, os.environ[k]) for k in ('RELNET_GEMM_KORDER', 'RELNET_GEMM_FORCE_TILE', 'RELNET_GEMM_ASM', 'RELNET_GEMM_SPLITK', 'RELNET_WGRAD_TILES', 'RELNET_ROI_BWD_SCATTER') if os.environ.get(k)]
+    knobs = [(k, os.environ[k]) for k in ('RELNET_GEMM_KORDER', 'RELNET_GEMM_FORCE_TILE', 'RELNET_GEMM_ASM', 'RELNET_GEMM_SPLITK', 'RELNET_WGRAD_TILES', 'RELNET_ROI_BWD_SCATTER', 'RELNET_ATTN_LDS_F32') if os.environ.get(k)]
     if knobs and os.environ.get('RELNET_DEBUG_KNOBS') != '1':
         sys.stderr.write('relnet: ignoring %s (set RELNET_DEBUG_KNOBS=1 to apply kernel-selection knobs)\n' % ', '.join(k for k, _ in knobs))
     elif knobs:
         sys.stderr.write('relnet: DEBUG kernel-selection knobs in effect: %s\n' % ', '.join('%s=%s' % kv for kv in knobs))
         for k, v in knobs:
             {'RELNET_GEMM_KORDER': lib.relnet_gemm_debug_korder, 'RELNET_GEMM_FORCE_TILE': lib.relnet_gemm_force_tile,
-             'RELNET_GEMM_ASM': lib.relnet_gemm_debug_asm, 'RELNET_GEMM_SPLITK': lib.relnet_gemm_debug_splitk, 'RELNET_WGRAD_TILES': lib.relnet_wgrad_debug_tiles, 'RELNET_ROI_BWD_SCATTER': lib.relnet_roi_pool_bwd_debug}[k](int(v))
+             'RELNET_GEMM_ASM': lib.relnet_gemm_debug_asm, 'RELNET_GEMM_SPLITK': lib.relnet_gemm_debug_splitk, 'RELNET_WGRAD_TILES': lib.relnet_wgrad_debug_tiles, 'RELNET_ROI_BWD_SCATTER': lib.relnet_roi_pool_bwd_debug, 'RELNET_ATTN_LDS_F32': lib.relnet_relation_attention_debug_lds_f32}[k](int(v))
     _lib = lib
     return lib
 
