@@ -483,7 +483,8 @@ int relnet_lnms_scatter_bwd(const float* d_sorted, const int* rank_idx, float* d
  *   residual_relu  :489-491  out [rows,128] = relu(x [rows,128] + att [rows,1024][:, 64 h + j], j < 8)   (bf16; the sum is rounded before the ReLU)
  *   cond_multi     :497-505  cond [B,F,C,T] = sigmoid(logit [(b C + c) F + f][t]) (row stride ld), multi = sorted_score [B,F,C] x cond
  *   cond_bwd       adjoint of cond_multi: d_sorted [B,F,C] = sum_t d_multi cond, d_logit bf16 [(b C + c) F + f][64] = d_multi score cond (1 - cond), 0 beyond T (T <= 8)
- *   take_bwd       :447-452  d_emb fp32 [B N,128] (zeroed by the caller) += rows of d_x bf16 [B,C,F,128] at rank_idx [B,C,F] (negative = skipped)
+ *   take_bwd       :447-452  d_emb bf16 [B N,128] = for every roi the fp32 sum of the rows of d_x bf16 [B,C,F,128] whose rank_idx [B,C,F] names it (every row written;
+ *                  negative ranks skipped; C <= 128)
  *   softmax_bwd    :430-433  prob = softmax(cls_score)[:, 1:]: d_cls[b][n][0] += -(1 - sum prob) inner, d_cls[b][n][1 + c] += prob_c (d_prob_c - inner),
  *                  inner = sum_c prob_c d_prob_c; d_cls rows ld_row apart, images ld_img apart (ACCUMULATES into the detector's own cls_score gradient) */
 /* out[0] = scale * sum(x[0..n))  (mode 0)  or  the count of entries >= 0 (mode 1): the scalar metrics of a training step (the MakeLoss outputs the
@@ -495,7 +496,7 @@ int relnet_lnms_residual_relu(const void* att, const void* x, void* out, long ro
 int relnet_lnms_cond_multi(const float* logit, long ld, const float* sorted_score, float* cond, float* multi, int B, int C, int F, int T, void* stream);
 int relnet_lnms_cond_bwd(const float* d_multi, const float* cond, const float* sorted_score, float* d_sorted, void* d_logit, int B, int C, int F, int T,
                          void* stream);
-int relnet_lnms_take_bwd(const void* d_x, const int* rank_idx, float* d_emb, int B, int N, int C, int F, void* stream);
+int relnet_lnms_take_bwd(const void* d_x, const int* rank_idx, void* d_emb, int B, int N, int C, int F, void* stream);
 int relnet_lnms_softmax_bwd(const float* prob, const float* d_prob, float* d_cls, long ld_row, long ld_img, int B, int N, int C, void* stream);
 /* the geometry bias ln G of the learn-NMS head's class-batched relation module from ONE per-image table: out [B C][16][F][Fpad] fp32 with
  * out[b C + c][h][f1][f2] = img [B][16][N][Npad] at (rank_idx[b][c][f1], rank_idx[b][c][f2]) for f2 < F (pad columns unwritten); rank_idx [B][C][F] >= 0.

@@ -6,7 +6,7 @@
 //   relnet_lnms_residual_relu  all_feat = relu(x + linear_out)                    (:489-491; 8 real of 64 columns per head)
 //   relnet_lnms_cond_multi     conditional prob = sigmoid(logit), transposed to [B,F,C,T]; multi score = sorted score x cond  (:497-505)
 //   relnet_lnms_cond_bwd       adjoint of the two lines above -> d sorted score, d logit (bf16, padded to 64 columns)
-//   relnet_lnms_take_bwd       adjoint of take(roi_feat_embedding, rank indices)  (:447-452): fp32 atomic row sums
+//   relnet_lnms_take_bwd       adjoint of take(roi_feat_embedding, rank indices)  (:447-452): gathered per roi over the classes that rank it, bf16 out
 //   relnet_lnms_softmax_bwd    adjoint of softmax + slice_axis(begin=1) (:430-433), accumulated into the detector's d cls_score
 //   relnet_lnms_gather_bias    the per-(image, class) geometry bias gathered from one per-image table by the class's ranks
 #include "common.h"
@@ -89,18 +89,36 @@ __global__ __launch_bounds__(256) void lnms_cond_bwd_kernel(const float* d_multi
   for (int q = 1; q < 8; ++q) dp[q] = make_uint4(0, 0, 0, 0);
 }
 
-// d_emb[b*N + rank[b][c][f]][:] += d_x[b][c][f][:]   (thread = 4 columns of one (b, c, f) row; fp32 atomics: a roi is ranked by up to C classes)
-__global__ __launch_bounds__(256) void lnms_take_bwd_kernel(const unsigned short* d_x, const int* rank_idx, float* d_emb, long rows, int N, int CF) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= rows * 32) return;
-  const long r = i >> 5; const int q = (int)(i & 31);
-  const int rk = rank_idx[r];
-  if (rk < 0 || rk >= N) return;
-  const long b = r / CF;
-  const uint2 v = *(const uint2*)(d_x + r * 128 + q * 4);
-  float* dst = d_emb + (b * N + rk) * 128 + q * 4;
-  atomicAdd(dst, bf2f(v.x & 0xffff)); atomicAdd(dst + 1, bf2f(v.x >> 16));
-  atomicAdd(dst + 2, bf2f(v.y & 0xffff)); atomicAdd(dst + 3, bf2f(v.y >> 16));
+// take's adjoint as a GATHER: d_emb[b N + n][:] = sum over the classes c that rank roi n (at position p) of d_x[b][c][p][:], written once as bf16.
+// (First form, round 6: thread = 4 columns of one (b, c, f) row, fp32 atomics into a zeroed table -- a roi is ranked by up to C classes, the adds of one row
+//  contend: 162 us at 8 images, plus the table's fill and its cast.)  One workgroup = 16 rois of one image: the image's C F ranks are scanned once for the
+// positions of those rois (LDS table pos[C][16], -1 = not ranked), then thread (roi, 8 columns) adds the hits in fp32.
+__global__ __launch_bounds__(256) void lnms_take_bwd_gather_kernel(const unsigned short* d_x, const int* rank_idx, unsigned short* d_emb, int N, int C, int F) {
+  __shared__ short pos[128 * 16];                 // [C <= 128][16]
+  const int chunks = (N + 15) / 16;
+  const int b = blockIdx.x / chunks, n0 = (blockIdx.x % chunks) * 16;
+  for (int i = threadIdx.x; i < C * 16; i += 256) pos[i] = -1;
+  __syncthreads();
+  const int* rk = rank_idx + (long)b * C * F;
+  for (int i = threadIdx.x; i < C * F; i += 256) {
+    const int r = rk[i] - n0;
+    if (r >= 0 && r < 16) pos[(i / F) * 16 + r] = (short)(i % F);
+  }
+  __syncthreads();
+  const int r = threadIdx.x >> 4, col = (threadIdx.x & 15) * 8;       // 16 rois x 16 column groups of 8
+  const int n = n0 + r;
+  if (n >= N) return;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const unsigned short* base = d_x + (long)b * C * F * 128 + col;
+  for (int c = 0; c < C; ++c) {
+    const int p = pos[c * 16 + r];
+    if (p < 0) continue;
+    const uint4 v = *(const uint4*)(base + ((long)c * F + p) * 128);
+    const unsigned int u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[2 * e] += __uint_as_float(u[e] << 16); acc[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u); }
+  }
+  *(uint4*)(d_emb + ((long)b * N + n) * 128 + col) = make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7]));
 }
 
 // one wavefront per (b, n): prob = softmax(cls_score)[1:], so with inner = sum_c prob_c d_prob_c and p_bg = 1 - sum_c prob_c:
@@ -198,11 +216,10 @@ extern "C" int relnet_lnms_cond_bwd(const float* d_multi, const float* cond, con
   return check_launch("relnet_lnms_cond_bwd");
 }
 
-extern "C" int relnet_lnms_take_bwd(const void* d_x, const int* rank_idx, float* d_emb, int B, int N, int C, int F, void* stream) {
-  RELNET_REQUIRE(d_x && rank_idx && d_emb && B > 0 && N > 0 && C > 0 && F > 0, "relnet_lnms_take_bwd: bad arguments");
-  RELNET_REQUIRE((((uintptr_t)d_x) & 7) == 0, "relnet_lnms_take_bwd: d_x must be 8-byte aligned");
-  const long rows = (long)B * C * F;
-  lnms_take_bwd_kernel<<<(unsigned)((rows * 32 + 255) / 256), 256, 0, (hipStream_t)stream>>>((const unsigned short*)d_x, rank_idx, d_emb, rows, N, C * F);
+extern "C" int relnet_lnms_take_bwd(const void* d_x, const int* rank_idx, void* d_emb, int B, int N, int C, int F, void* stream) {
+  RELNET_REQUIRE(d_x && rank_idx && d_emb && B > 0 && N > 0 && C > 0 && C <= 128 && F > 0 && F < 32768, "relnet_lnms_take_bwd: bad arguments (C <= 128)");
+  RELNET_REQUIRE((((uintptr_t)d_x | (uintptr_t)d_emb) & 15) == 0, "relnet_lnms_take_bwd: operands must be 16-byte aligned");
+  lnms_take_bwd_gather_kernel<<<(unsigned)(B * ((N + 15) / 16)), 256, 0, (hipStream_t)stream>>>((const unsigned short*)d_x, rank_idx, (unsigned short*)d_emb, N, C, F);
   return check_launch("relnet_lnms_take_bwd");
 }
 

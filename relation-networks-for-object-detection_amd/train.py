@@ -855,13 +855,15 @@ class Trainer(object):
             d_x = (r['d_roi_feat'] + g.view(BC, F, 128).float()).view(B, C, F, 128)             # residual + module
         d_rank = d_x.sum((0, 1), dtype=torch.float32)                                           # [F,128] (fp32 accumulation whatever d_x's dtype)
         self._add_wgrad('nms_rank', T.wgrad(d_rank.to(bt), self.rank_emb)); self._add_bgrad('nms_rank', d_rank.sum(0))
-        d_emb = torch.zeros((B * N, 128), device=dev, dtype=torch.float32)
-        if fused and d_x.dtype == bt and d_x.is_contiguous():
+        if fused and d_x.dtype == bt and d_x.is_contiguous() and C <= 128:
+            d_emb = torch.empty((B * N, 128), device=dev, dtype=bt)          # every row written: gathered per roi over the classes that rank it (fp32 sums)
             _lib.call('relnet_lnms_take_bwd', d_x.data_ptr(), rank_idx.data_ptr(), d_emb.data_ptr(), B, N, C, F, s_)
         else:
+            d_emb = torch.zeros((B * N, 128), device=dev, dtype=torch.float32)
             flat = (rank_idx.long() + (torch.arange(B, device=dev) * N).view(B, 1, 1)).view(-1)
             d_emb.index_add_(0, flat, d_x.reshape(-1, 128).float())                             # take() backward (a roi is ranked in up to 80 classes: fp32 sums)
-        d_feat, dw, db = T.linear_bwd(feat2, self.w('roi_feat_embedding'), d_emb.to(bt), w_t=self.wt('roi_feat_embedding'), keep_splits=True, wgrad_to=self._wg('roi_feat_embedding'), bgrad_to=self._bg('roi_feat_embedding'))
+            d_emb = d_emb.to(bt)
+        d_feat, dw, db = T.linear_bwd(feat2, self.w('roi_feat_embedding'), d_emb, w_t=self.wt('roi_feat_embedding'), keep_splits=True, wgrad_to=self._wg('roi_feat_embedding'), bgrad_to=self._bg('roi_feat_embedding'))
         self._add_bgrad('roi_feat_embedding', db)
         # sort / slice backward -> cls_prob -> softmax backward (background column has no direct gradient)
         d_prob = ops.lnms_scatter_bwd(d_sorted.contiguous(), rank_idx, N)      # d_prob[b, rank_idx[b,c,f], c] += d_sorted[b,f,c]
