@@ -476,13 +476,29 @@ class Trainer(object):
         main = torch.cuda.current_stream()
         nchw = lambda t: t.permute(0, 3, 1, 2)
 
+        def _conv4_hw(n):                  # spatial size of conv4 (stride 16): conv1 7x7 / 2 pad 3, pool1 3x3 / 2 (ceil), res3a and res4a stride 2
+            n = (n + 2 * 3 - 7) // 2 + 1
+            n = -(-(n - 3) // 2) + 1
+            n = (n - 1) // 2 + 1
+            return (n - 1) // 2 + 1
+        early = {}
+        if rpn_label is None and getattr(self, 'overlap_rpn', os.environ.get('RELNET_TRAIN_OVERLAP', '1') != '0') and self._side is not None:
+            # the anchor targets depend on the ground truth only (lib/rpn/rpn.py:assign_anchor runs in the LOADER in the reference): on the side stream
+            # from the very start of the step, beside the stem -- their 0.23 ms (8 images) used to sit between the RPN head and the proposals, on
+            # the longer of the two branches that meet at ROI pooling
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                early['t'] = self.rpn_targets(gt_boxes, num_gt, im_info, (_conv4_hw(data.shape[2]), _conv4_hw(data.shape[3])))
+
         def rpn_branch(conv4):
             r = self._conv(conv4, 'rpn_conv_3x3', pad=1, relu=True, bias=self.b('rpn_conv_3x3'))
             rpn = self._conv(r, 'rpn_out', bias=self.b('rpn_out'), out_dtype=torch.float32)             # [B,h,w,72]
             h, wd_ = rpn.shape[1], rpn.shape[2]
             na2 = self.na2
             lbl, tgt_in, wgt_in = rpn_label, rpn_bbox_target, rpn_bbox_weight
-            if lbl is None:
+            if lbl is None and early.get('t') is not None and tuple(early['t'][1].shape[2:]) == (h, wd_):
+                lbl, tgt_in, wgt_in = early['t']           # (computed on this stream at the start of the step)
+            elif lbl is None:
                 lbl, tgt_in, wgt_in = self.rpn_targets(gt_boxes, num_gt, im_info, (h, wd_))
             # -- RPN losses (per image, like one image per device in the reference)
             score_nchw = rpn[..., :na2].permute(0, 3, 1, 2).contiguous()                                 # [B,2A,h,w]
