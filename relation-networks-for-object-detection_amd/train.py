@@ -520,10 +520,23 @@ class Trainer(object):
             rois_t, label, bbox_target, bbox_weight = ops.proposal_target(rois, gt_boxes, num_gt)
             R = rois_t.shape[1]
             br.update(r=r, d_rpn=d_rpn, rois_t=rois_t, label=label, bbox_target=bbox_target, bbox_weight=bbox_weight, N=N, R=R)
+            if rpn_bwd_side:
+                br['ev'] = torch.cuda.Event()
+                br['ev'].record()               # main resumes here (rois and their targets exist); the RPN head's backward follows on this stream
+                rpn_backward(conv4, r, d_rpn)
 
+        def rpn_backward(conv4, r, d_rpn):
+            g_r, dw = T.conv1x1_bwd(r, self.w('rpn_out'), d_rpn, w_t=self.wt('rpn_out'), keep_splits=True, wgrad_to=self._wg('rpn_out'), relu_mask=r)
+            T.colsum_add(d_rpn, self._bg('rpn_out'))
+            d_conv4_rpn, dw = T.conv3x3_bwd(conv4, self._dgrad_w('rpn_conv_3x3', 512), g_r, dil=1, keep_splits=True, wgrad_to=self._wg('rpn_conv_3x3'))
+            T.colsum_add(g_r, self._bg('rpn_conv_3x3'))
+            br.update(g_r=g_r, d_conv4_rpn=d_conv4_rpn)
+
+        rpn_bwd_side = False
         side = None
         if getattr(self, 'overlap_rpn', os.environ.get('RELNET_TRAIN_OVERLAP', '1') != '0'):
             side = self._side
+            rpn_bwd_side = os.environ.get('RELNET_RPN_BWD_SIDE', '1') != '0' and not self.lnms_only
 
             def fork(conv4):
                 side.wait_stream(main)
@@ -537,7 +550,10 @@ class Trainer(object):
         conv5, conv4 = conv5.to(torch.bfloat16), conv4.to(torch.bfloat16)
         feat = self._conv(conv5, 'conv_new_1', relu=True, bias=self.b('conv_new_1'))
         if side is not None:
-            main.wait_stream(side)
+            if rpn_bwd_side:
+                main.wait_event(br['ev'])
+            else:
+                main.wait_stream(side)
             # the branch's tensors were allocated on the side stream and are consumed on the main one through the backward pass:
             # tell the caching allocator, so that their blocks are not handed out again on the side stream while main still reads them
             if not torch.cuda.is_current_stream_capturing():      # (a capture's private pool keeps its blocks for the graph's lifetime)
@@ -586,10 +602,11 @@ class Trainer(object):
         d_x, dw = T.conv1x1_bwd(conv5, self.w('conv_new_1'), g, w_t=self.wt('conv_new_1'), keep_splits=True, wgrad_to=self._wg('conv_new_1'))
         T.colsum_add(g, self._bg('conv_new_1'))
         # RPN head backward (joins the trunk at conv4)
-        g_r, dw = T.conv1x1_bwd(r, self.w('rpn_out'), d_rpn, w_t=self.wt('rpn_out'), keep_splits=True, wgrad_to=self._wg('rpn_out'), relu_mask=r)
-        T.colsum_add(d_rpn, self._bg('rpn_out'))
-        d_conv4_rpn, dw = T.conv3x3_bwd(conv4, self._dgrad_w('rpn_conv_3x3', 512), g_r, dil=1, keep_splits=True, wgrad_to=self._wg('rpn_conv_3x3'))
-        T.colsum_add(g_r, self._bg('rpn_conv_3x3'))
+        if rpn_bwd_side:
+            main.wait_stream(side)
+        else:
+            rpn_backward(conv4, r, d_rpn)
+        d_conv4_rpn = br['d_conv4_rpn']
         if self.trunk_fp32:
             d_x, d_conv4_rpn = d_x.float(), d_conv4_rpn.float()
         self._trunk_backward(saved, d_x, {'4b22': d_conv4_rpn})
