@@ -360,6 +360,18 @@ def bench_train(a, rank, world, D, emit=True, fatal=True):
             fence()
             comm = tr.comm_report(n_c)
             tr.comm_timing = None
+        nprobe = int(os.environ.get('RELNET_BENCH_RECAPTURE', '0'))
+        if nprobe and graph is not None:          # diagnostic, outside the timed region: does the replay time depend on the CAPTURE?
+            for i in range(nprobe):
+                g2 = train.CapturedStep(tr, batch)
+                for _ in range(3):
+                    g2.replay()
+                fence(); t1 = time.perf_counter()
+                for _ in range(20):
+                    g2.replay()
+                fence()
+                print('recapture %d: %.3f ms per forward+backward replay' % (i, (time.perf_counter() - t1) / 20 * 1e3), file=sys.stderr)
+                del g2
     elapsed = D.max_over_ranks(elapsed, device='cuda')
     if comm is not None:
         comm['exposed_comm_ms_per_step_max_over_ranks'] = D.max_over_ranks(comm['exposed_comm_ms_per_step'], device='cuda')

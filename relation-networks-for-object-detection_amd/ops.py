@@ -1180,7 +1180,9 @@ class WgradQueue(object):
     def __len__(self):
         return len(self.items)
 
-    def flush(self):
+    def flush(self, workgroups=0):
+        """One grouped launch of everything queued.  workgroups: size of the persistent grid (0 = one per CU) -- a launch that runs
+        BESIDE other work on another stream takes a part of the chip only."""
         n = len(self.items)
         if n == 0:
             return
@@ -1188,7 +1190,13 @@ class WgradQueue(object):
         lib = _lib.load()
         ws = torch.empty(int(lib.relnet_wgrad_workspace_bytes(n)), device=self.keep[0][0].device, dtype=torch.uint8)
         import ctypes
-        _lib.call('relnet_wgrad_grouped', ctypes.addressof(arr), n, ws.data_ptr(), _stream(), tag='n%d' % n)
+        if workgroups:
+            lib.relnet_wgrad_tune(int(workgroups), 0, 0)
+        try:
+            _lib.call('relnet_wgrad_grouped', ctypes.addressof(arr), n, ws.data_ptr(), _stream(), tag='n%d' % n)
+        finally:
+            if workgroups:
+                lib.relnet_wgrad_tune(0, 0, 0)
         self.items, self.keep = [], []
         return ws          # the caller may hold on to it; stream order already protects it from reuse on this stream
 

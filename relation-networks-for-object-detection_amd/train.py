@@ -526,11 +526,18 @@ class Trainer(object):
                 rpn_backward(conv4, r, d_rpn)
 
         def rpn_backward(conv4, r, d_rpn):
-            g_r, dw = T.conv1x1_bwd(r, self.w('rpn_out'), d_rpn, w_t=self.wt('rpn_out'), keep_splits=True, wgrad_to=self._wg('rpn_out'), relu_mask=r)
+            # ... and with them the two RPN weight gradients, as their own grouped launch on 64 workgroups (a quarter of the chip: the head's
+            # kernels beside it keep theirs); RELNET_RPN_WGRAD_SIDE=0 leaves them in the 'heads' bucket's launch on the main stream
+            nwg = int(os.environ.get('RELNET_RPN_WGRAD_SIDE', '64')) if rpn_bwd_side else 0
+            rq = ops.WgradQueue() if nwg else None
+            wg = (lambda n: self._wg(n)[:2] + (rq,)) if nwg else self._wg
+            g_r, dw = T.conv1x1_bwd(r, self.w('rpn_out'), d_rpn, w_t=self.wt('rpn_out'), keep_splits=True, wgrad_to=wg('rpn_out'), relu_mask=r)
             T.colsum_add(d_rpn, self._bg('rpn_out'))
-            d_conv4_rpn, dw = T.conv3x3_bwd(conv4, self._dgrad_w('rpn_conv_3x3', 512), g_r, dil=1, keep_splits=True, wgrad_to=self._wg('rpn_conv_3x3'))
+            d_conv4_rpn, dw = T.conv3x3_bwd(conv4, self._dgrad_w('rpn_conv_3x3', 512), g_r, dil=1, keep_splits=True, wgrad_to=wg('rpn_conv_3x3'))
             T.colsum_add(g_r, self._bg('rpn_conv_3x3'))
             br.update(g_r=g_r, d_conv4_rpn=d_conv4_rpn)
+            if nwg:
+                br['rq_keep'] = rq.flush(workgroups=nwg)
 
         rpn_bwd_side = False
         side = None
