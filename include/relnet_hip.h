@@ -571,6 +571,12 @@ int relnet_geometry_bias_bwd(const float* boxes, int box_stride, int box_off, co
 int relnet_relu_bwd(const void* dy, const void* y, const void* add /*or NULL*/, void* dx, long n, int dtype,
                     void* stream);
 
+/* Adjoint of the input sampling of a stride-s 1x1 convolution (symbols/resnet_v1_101_rcnn_base.py: res3a / res4a branch1 + branch2a, stride (2,2)):
+ * out [B,H,W,C] = low [B,Ho,Wo,C] at the pixels (s i, s j), zero elsewhere; mask (or NULL) [B,H,W,C] = the saved ReLU output that IS that map:
+ * the result is multiplied by (mask > 0) in the same pass.  Ho = (H - 1) / s + 1, Wo likewise; C a multiple of 8 (bf16) / 4 (fp32).            */
+int relnet_strided_scatter(const void* low, const void* mask /*or NULL*/, void* out, int B, int H, int W, int C, int Ho, int Wo, int stride,
+                           int dtype, void* stream);
+
 /* out[c] += sum_r x[r, c]: the gradient of a bias (`FullyConnected` / `Convolution` bias, mx autograd) from the upstream gradient
  * [rows, cols] (dtype: 0 fp32, 1 bf16; row stride ld elements), accumulated in fp32 (atomic per column and row chunk).               */
 int relnet_colsum_add(const void* x, long ld, long rows, int cols, int dtype, float* out, void* stream);

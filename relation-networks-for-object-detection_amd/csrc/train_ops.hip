@@ -321,6 +321,42 @@ __global__ __launch_bounds__(256) void reduce_scalar_kernel(const float* x, long
   if (threadIdx.x == 0) atomicAdd(out, (mode ? 1.f : scale) * (part[0] + part[1] + part[2] + part[3]));
 }
 
+
+// Adjoint of a stride-s 1x1 convolution's input sampling (x[:, ::s, ::s, :]): the low-resolution data gradient goes to the sampled pixels
+// of a full-resolution map, every other pixel is zero -- one pass that also applies the ReLU mask of the map's producer when that map has no
+// other consumer (zero fill + strided copy + relu_bwd otherwise: three passes over the full-resolution map).
+template <typename T>
+__global__ __launch_bounds__(256) void strided_scatter_kernel(const T* low, const T* mask, T* out, long nvec, int H, int W, int CV, int Ho, int Wo,
+                                                              int stride) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int w = (int)(p % W); p /= W;
+    const int h = (int)(p % H);
+    const long b = p / H;
+    uint4 r = make_uint4(0, 0, 0, 0);
+    const int ho = h / stride, wo = w / stride;
+    if (ho * stride == h && wo * stride == w && ho < Ho && wo < Wo) {
+      r = *((const uint4*)low + ((b * Ho + ho) * Wo + wo) * CV + cv);
+      if (mask) {
+        const uint4 o = *((const uint4*)mask + i);
+        const unsigned int* uo = (const unsigned int*)&o;
+        unsigned int* ur = (unsigned int*)&r;
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) ur[k] = __uint_as_float(uo[k]) > 0.f ? ur[k] : 0u;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float olo = __uint_as_float(uo[k] << 16), ohi = __uint_as_float(uo[k] & 0xffff0000u);
+            ur[k] = (olo > 0.f ? (ur[k] & 0xffffu) : 0u) | (ohi > 0.f ? (ur[k] & 0xffff0000u) : 0u);
+          }
+        }
+      }
+    }
+    *((uint4*)out + i) = r;
+  }
+}
 }  // namespace relnet
 
 using namespace relnet;
@@ -344,6 +380,22 @@ extern "C" int relnet_relu_bwd(const void* dy, const void* y, const void* add, v
   else if (dtype == RELNET_BF16) relu_bwd_kernel<unsigned short><<<(unsigned)blocks, 256, 0, s>>>((const unsigned short*)dy, (const unsigned short*)y, (const unsigned short*)add, (unsigned short*)dx, n);
   else RELNET_REQUIRE(false, "relnet_relu_bwd: unknown dtype %d", dtype);
   return check_launch("relnet_relu_bwd");
+}
+
+extern "C" int relnet_strided_scatter(const void* low, const void* mask, void* out, int B, int H, int W, int C, int Ho, int Wo, int stride, int dtype,
+                                      void* stream) {
+  RELNET_REQUIRE(low && out && B > 0 && H > 0 && W > 0 && C > 0 && stride >= 1, "relnet_strided_scatter: bad operand");
+  RELNET_REQUIRE(Ho == (H - 1) / stride + 1 && Wo == (W - 1) / stride + 1, "relnet_strided_scatter: [%d, %d] is not the stride-%d sampling of [%d, %d]", Ho, Wo, stride, H, W);
+  RELNET_REQUIRE(dtype == RELNET_F32 || dtype == RELNET_BF16, "relnet_strided_scatter: unknown dtype %d", dtype);
+  const int V = dtype == RELNET_F32 ? 4 : 8;
+  RELNET_REQUIRE(C % V == 0, "relnet_strided_scatter: channels (%d) must be a multiple of %d", C, V);
+  RELNET_REQUIRE((((uintptr_t)low | (uintptr_t)mask | (uintptr_t)out) & 15) == 0, "relnet_strided_scatter: operands must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const long nvec = (long)B * H * W * (C / V);
+  const long blocks = std::min<long>((nvec + 255) / 256, 65536);
+  if (dtype == RELNET_F32) strided_scatter_kernel<float><<<(unsigned)blocks, 256, 0, s>>>((const float*)low, (const float*)mask, (float*)out, nvec, H, W, C / V, Ho, Wo, stride);
+  else strided_scatter_kernel<unsigned short><<<(unsigned)blocks, 256, 0, s>>>((const unsigned short*)low, (const unsigned short*)mask, (unsigned short*)out, nvec, H, W, C / V, Ho, Wo, stride);
+  return check_launch("relnet_strided_scatter");
 }
 
 extern "C" int relnet_colsum_add(const void* x, long ld, long rows, int cols, int dtype, float* out, void* stream) {

@@ -84,6 +84,7 @@ _SIGNATURES = {
                                                    _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     'relnet_geometry_bias_bwd': (C.c_int, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'relnet_relu_bwd': (C.c_int, [_vp, _vp, _vp, _vp, _l, _i, _vp]),
+    'relnet_strided_scatter': (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'relnet_colsum_add': (C.c_int, [_vp, _l, _l, _i, _i, _vp, _vp]),
     'relnet_colsum_add_grouped': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'relnet_sgd_update': (C.c_int, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _vp]),

@@ -334,7 +334,7 @@ class Trainer(object):
             side.wait_stream(main)
             self._wgrad_keep.append(list(self._wq.keep))
             with torch.cuda.stream(side):
-                self._wgrad_keep.append(self._wq.flush())
+                self._wgrad_keep.append(self._wq.flush(workgroups=int(os.environ.get('RELNET_WGRAD_SIDE_WGS', '0'))))
             self._wgrad_pending = True
         if final and self._wgrad_pending:
             main.wait_stream(side)
@@ -676,10 +676,29 @@ class Trainer(object):
                 g_y1 = T.relu_bwd(d_y1, y1)
             first = (stage == 3 and proj)         # res3a: its input comes from the frozen res2 -> no data gradient
             if proj:
-                d_a, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, stride=stride, need_dx=not first, w_t=self.wt(na), keep_splits=True, wgrad_to=self._wg(na, self.bn_scale[na]))
+                # both branches read the same (sampled) input: their data gradients are summed in the second GEMM's epilogue -- at the SAMPLED
+                # resolution for a stride-2 unit, then scattered to the input's resolution once, with the previous unit's ReLU mask in the same
+                # pass when that output has no other consumer (was: 2 zero fills + 2 strided copies + a full-resolution add + relu_bwd)
+                prev_nm = order[pos + 1][1] if pos + 1 < len(order) else None
+                fold_on = os.environ.get('RELNET_TRAIN_FOLD', '1') != '0'          # (A/B switch: 0 = the separate passes)
+                lr = stride != 1 and fold_on
+                # a second consumer's gradient of this unit's INPUT (the RPN head at conv4, in front of the stride-1 res5a) rides in the first
+                # GEMM's epilogue; the input's ReLU mask can then ride in the second one's
+                inj = inject.get(prev_nm) if (fold_on and stride == 1 and not first and prev_nm is not None) else None
+                fold = inj is not None and inj.dtype == g_y1.dtype and tuple(inj.shape) == tuple(x_in.shape) and inj.is_contiguous()
+                d_a, dw = T.conv1x1_bwd(x_in, self.w(na), g_y1, stride=stride, need_dx=not first, w_t=self.wt(na), keep_splits=True, wgrad_to=self._wg(na, self.bn_scale[na]),
+                                        dx_add=inj if fold else None, low_res=lr)
+                if fold:
+                    inject = {k: v for k, v in inject.items() if k != prev_nm}
+                can_mask = self.mask_epilogue and not first and prev_nm is not None and inject.get(prev_nm) is None
                 d_s, dw = T.conv1x1_bwd(x_in, self.w(n1), g_out, stride=stride, need_dx=not first, w_t=self.wt(n1),
-                                        dx_add=d_a if (stride == 1 and not first) else None, keep_splits=True, wgrad_to=self._wg(n1, self.bn_scale[n1]))
-                d_x = None if first else (d_s if stride == 1 else d_s + d_a)
+                                        dx_add=d_a if (not first and (lr or stride == 1)) else None, keep_splits=True, wgrad_to=self._wg(n1, self.bn_scale[n1]), low_res=lr,
+                                        out_mask=x_in if (can_mask and fold_on and stride == 1) else None)
+                d_x = None if first else (d_s if (lr or stride == 1) else d_s + d_a)
+                masked = can_mask and fold_on and stride == 1
+                if lr and not first:
+                    d_x = T.strided_scatter(d_s, tuple(x_in.shape), stride, mask=x_in if can_mask else None)
+                    masked = can_mask
             else:
                 # identity shortcut: d x_in = g_y1 W1 + g_out; x_in is the previous unit's ReLU output, so its mask can ride in this GEMM's
                 # epilogue -- unless that output has a second consumer whose gradient must be added before the mask (inject)

@@ -28,6 +28,19 @@ def relu_bwd(dy, y, add=None, out=None):
     return out
 
 
+def strided_scatter(low, shape, stride, mask=None):
+    """Adjoint of x[:, ::stride, ::stride, :] (NHWC): low [B,Ho,Wo,C] -> [B,H,W,C] with zeros between the samples, times (mask > 0) when the
+    full-resolution map is a ReLU output with no other consumer (one pass: relnet_strided_scatter)."""
+    _chk(low, mask)
+    B, H, W, C = shape
+    assert low.is_contiguous() and low.shape[0] == B and low.shape[3] == C
+    if mask is not None:
+        assert mask.is_contiguous() and tuple(mask.shape) == tuple(shape) and mask.dtype == low.dtype
+    out = torch.empty(shape, device=low.device, dtype=low.dtype)
+    _lib.call('relnet_strided_scatter', low.data_ptr(), _ptr(mask), out.data_ptr(), B, H, W, C, low.shape[1], low.shape[2], int(stride), _dt(low), _stream())
+    return out
+
+
 class ColsumQueue(object):
     """Bias-gradient column sums collected for ONE grouped launch per gradient bucket (relnet_colsum_add_grouped, <= 16 problems per
     launch).  `add` keeps the operand alive until `flush`; operands the grouped kernel does not take (fp32, ragged widths) are summed at once."""
@@ -204,13 +217,14 @@ def pack_conv_dgrad_weight(w_oihw, dtype=torch.bfloat16, device='cuda'):
 
 
 def conv1x1_bwd(x, w_packed, dy, stride=1, need_dx=True, w_t=None, dx_add=None, keep_splits=False, wgrad_to=None, relu_mask=None,
-                out_mask=None):
+                out_mask=None, low_res=False):
     """x [B,H,W,Cin], dy [B,Ho,Wo,Cout] NHWC; w_packed [Cout,Cin].  -> (dx [B,H,W,Cin] | None, dW fp32).
     dx_add (stride 1 only): a second gradient of x's shape added in the GEMM epilogue (the shortcut branch).
     wgrad_to: see linear_bwd (the strided input rows are gathered inside relnet_wgrad: no sub-sampled copy of x).
     relu_mask (stride 1, instead of dx_add): x itself when x = relu(.) -- dx comes out already multiplied by (x > 0).
     out_mask (stride 1, WITH dx_add): dx = (dy W + dx_add) * (out_mask > 0) in one launch (relnet_gemm_nt_mask): the unit's input is the
-    previous unit's ReLU output, so the result is that unit's masked output gradient (no separate relu_bwd pass)."""
+    previous unit's ReLU output, so the result is that unit's masked output gradient (no separate relu_bwd pass).
+    low_res (stride > 1): dx is returned at dy's resolution [B,Ho,Wo,Cin] (+ dx_add of that shape), not scattered to x's."""
     B, H, W, Cin = x.shape
     Cout = w_packed.shape[0]
     P = dy.shape[0] * dy.shape[1] * dy.shape[2]
@@ -233,10 +247,11 @@ def conv1x1_bwd(x, w_packed, dy, stride=1, need_dx=True, w_t=None, dx_add=None, 
             dx = ops.gemm_nt(dyp, w_t, resid=relu_mask.reshape(P, Cin), relu=2).reshape(B, H, W, Cin)
         elif stride == 1:
             dx = ops.gemm_nt(dyp, w_t, resid=None if dx_add is None else dx_add.reshape(P, Cin)).reshape(B, H, W, Cin)
+        elif low_res:             # the caller sums both branches at the sampled resolution and scatters ONCE (strided_scatter)
+            dx = ops.gemm_nt(dyp, w_t, resid=None if dx_add is None else dx_add.reshape(P, Cin)).reshape(dy.shape[0], dy.shape[1], dy.shape[2], Cin)
         else:
             assert dx_add is None
-            dx = torch.zeros_like(x)
-            dx[:, ::stride, ::stride, :] = ops.gemm_nt(dyp, w_t).reshape(dy.shape[0], dy.shape[1], dy.shape[2], Cin)
+            dx = strided_scatter(ops.gemm_nt(dyp, w_t).reshape(dy.shape[0], dy.shape[1], dy.shape[2], Cin), (B, H, W, Cin), stride)
     if tn:
         if stride == 1:
             _wg_call(wgrad_to, dy2, x.reshape(P, Cin))

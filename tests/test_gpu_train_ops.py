@@ -48,6 +48,41 @@ def test_conv1x1_backward(stride):
         assert _rel(dx2.permute(0, 3, 1, 2), x.grad + add.permute(0, 3, 1, 2)) <= 1.5e-2
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('hw', [(38, 63), (75, 125), (8, 8)])
+def test_strided_scatter_is_the_adjoint_of_the_input_sampling(hw, dt):
+    """relnet_strided_scatter: zeros + out[:, ::2, ::2] = low (+ the ReLU mask of the full-resolution map), bit for bit; and the two-branch
+    stride-2 backward summed at the sampled resolution equals the sum of the two scattered gradients."""
+    ops, T = _mods()
+    g = torch.Generator().manual_seed(5)
+    B, (H, W), C = 2, hw, 64
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    low = torch.randn(B, Ho, Wo, C, generator=g).cuda().to(dt)
+    y = torch.relu(torch.randn(B, H, W, C, generator=g)).cuda().to(dt)
+    ref = torch.zeros(B, H, W, C, device='cuda', dtype=dt)
+    ref[:, ::2, ::2] = low
+    out = T.strided_scatter(low, (B, H, W, C), 2)
+    assert torch.equal(out, ref)
+    outm = T.strided_scatter(low, (B, H, W, C), 2, mask=y)
+    assert torch.equal(outm, ref * (y > 0))
+    with pytest.raises(RuntimeError):
+        T.strided_scatter(low[:, :-1].contiguous(), (B, H, W, C), 2)
+    if dt == torch.bfloat16:
+        Cout = 128
+        x = torch.randn(B, H, W, C, generator=g).cuda().to(dt)
+        w1 = (torch.randn(Cout, C, generator=g) * 0.05).cuda().to(dt)
+        w2 = (torch.randn(Cout, C, generator=g) * 0.05).cuda().to(dt)
+        dy1 = torch.randn(B, Ho, Wo, Cout, generator=g).cuda().to(dt)
+        dy2 = torch.randn(B, Ho, Wo, Cout, generator=g).cuda().to(dt)
+        a, _ = T.conv1x1_bwd(x, w1, dy1, stride=2)
+        b, _ = T.conv1x1_bwd(x, w2, dy2, stride=2)
+        la, _ = T.conv1x1_bwd(x, w1, dy1, stride=2, low_res=True)
+        ls, _ = T.conv1x1_bwd(x, w2, dy2, stride=2, low_res=True, dx_add=la)
+        s = T.strided_scatter(ls, (B, H, W, C), 2)
+        assert _rel(s, (a.float() + b.float()).cpu()) <= 1e-2
+        assert float(s[:, 1::2].abs().max()) == 0.0 and float(s[:, :, 1::2].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('dil', [1, 2])
 def test_conv3x3_backward(dil):
     ops, T = _mods()
