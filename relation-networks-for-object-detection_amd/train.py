@@ -236,6 +236,9 @@ class Trainer(object):
                 for h in range(16):
                     self._relayout.add('nms_lo_h%d' % h, wo[8 * h:8 * h + 8], taps=1, pad_co=8, group=('rel_cat_nms', 2048 + 64 * h, 3 * 1024))
                 continue
+            if name == 'nms_logit':                          # [T,128] -> [128, 64] (T real columns): data-gradient operand of the learn-NMS logit layer
+                self._relayout.add(name, self.w(name), taps=1, pad_co=64)
+                continue
             if name.startswith(('pair_pos_fc1', 'nms_')) or name.endswith('_offset') or self._trunk32(name):
                 continue                                    # consumed in other layouts (relation_bwd kernels, padded DCN offset convs; float32 trunk)
             if name.startswith(('qk_', 'linear_out_')):     # [Wq; Wk]^T | Wout^T side by side: the [1024, 3072] operand of the ONE
@@ -881,8 +884,16 @@ class Trainer(object):
             d_sorted = (d_multi * cond).sum(3)                                                      # [B,F,C]
             d_logit = (d_multi * sorted_score.unsqueeze(3) * cond * (1.0 - cond)).permute(0, 2, 1, 3).reshape(BC * F, Tn)
             d_logit_p = torch.zeros((BC * F, 64), device=dev, dtype=bt); d_logit_p[:, :Tn] = d_logit
-        d_allf, dw, db = T.linear_bwd(allf.view(BC * F, 128), w_logit, d_logit_p, w_t=None, keep_splits=True)
-        self._add_wgrad('nms_logit', dw.sum(0)[:Tn]); self._add_bgrad('nms_logit', db[:Tn])
+        wl_t = self.wt('nms_logit')
+        if fused and wl_t is not None:
+            # logit layer backward on the step's own machinery: W^T from the relayout table, the weight gradient in the bucket's grouped launch
+            # (Tn real of 64 padded output columns), the bias gradient in its grouped column sum (was 8 library launches: transpose, fills, casts, sums)
+            d_allf = ops.gemm_nt(d_logit_p, wl_t)
+            T._wg_call(self._wg('nms_logit'), d_logit_p, allf.view(BC * F, 128), cout=Tn)
+            T.colsum_add(d_logit_p[:, :Tn], self._bg('nms_logit'))
+        else:
+            d_allf, dw, db = T.linear_bwd(allf.view(BC * F, 128), w_logit, d_logit_p, w_t=None, keep_splits=True)
+            self._add_wgrad('nms_logit', dw.sum(0)[:Tn]); self._add_bgrad('nms_logit', db[:Tn])
         g = T.relu_bwd(d_allf, allf.view(BC * F, 128))                                          # [BC*F,128] bf16
         dY = self._scratch('nms_dy_pad', (BC, F, 1024), bt)                   # persistent: columns 8 .. 63 of every head stay zero
         dY.view(BC, F, 16, 64)[..., :8] = g.view(BC, F, 16, 8)
@@ -912,8 +923,14 @@ class Trainer(object):
             self._add_bgrad('nms_linear_out_1', r['linear_out_1_bias'].view(16, 64)[:, :8].reshape(128))
             self._add_wgrad('nms_pair_pos_fc1_1', r['pair_pos_fc1_1_weight']); self._add_bgrad('nms_pair_pos_fc1_1', r['pair_pos_fc1_1_bias'])
             d_x = (r['d_roi_feat'] + g.view(BC, F, 128).float()).view(B, C, F, 128)             # residual + module
-        d_rank = d_x.sum((0, 1), dtype=torch.float32)                                           # [F,128] (fp32 accumulation whatever d_x's dtype)
-        self._add_wgrad('nms_rank', T.wgrad(d_rank.to(bt), self.rank_emb)); self._add_bgrad('nms_rank', d_rank.sum(0))
+        if fused and d_x.is_contiguous():
+            d_rank = torch.zeros((F, 128), device=dev, dtype=torch.float32)                     # sum over (image, class): one column-sum launch (fp32 accumulation)
+            _lib.call('relnet_colsum_add', d_x.data_ptr(), F * 128, BC, F * 128, ops._dt(d_x), d_rank.data_ptr(), s_)
+            T._wg_call(self._wg('nms_rank'), d_rank.to(bt), self.rank_emb)
+            T.colsum_add(d_rank, self._bg('nms_rank'))
+        else:
+            d_rank = d_x.sum((0, 1), dtype=torch.float32)                                       # [F,128] (fp32 accumulation whatever d_x's dtype)
+            self._add_wgrad('nms_rank', T.wgrad(d_rank.to(bt), self.rank_emb)); self._add_bgrad('nms_rank', d_rank.sum(0))
         if fused and d_x.dtype == bt and d_x.is_contiguous() and C <= 128:
             d_emb = torch.empty((B * N, 128), device=dev, dtype=bt)          # every row written: gathered per roi over the classes that rank it (fp32 sums)
             _lib.call('relnet_lnms_take_bwd', d_x.data_ptr(), rank_idx.data_ptr(), d_emb.data_ptr(), B, N, C, F, s_)
