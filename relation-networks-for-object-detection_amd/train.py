@@ -1386,14 +1386,15 @@ class FPNTrainer(Trainer):
         for lvl in (4, 8, 16, 32):
             n3, n1 = 'fpn_ft%d_3x3' % lvl, 'fpn_ft%d_1x1' % lvl
             d_top, dw = T.conv3x3_bwd(tops[lvl], self._dgrad_w(n3, 256), d_feats[lvl], dil=1, keep_splits=True, wgrad_to=self._wg(n3))
-            self._add_bgrad(n3, d_feats[lvl].float().sum((0, 1, 2)))
-            if lvl in d_tops:                                    # + the gradient that came down from the finer level
-                d_top = (d_top.float() + d_tops[lvl]).to(bt)
-            if lvl < 32:       # tops[lvl] = lateral + up2x(tops[2 lvl]): adjoint of nearest upsampling = 2x2 block sums
+            T.colsum_add(d_feats[lvl], self._bg(n3))             # (bias gradients: the bucket's grouped column-sum launch)
+            if lvl in d_tops:                                    # + the gradient that came down from the finer level (fp32 block sums)
+                d_top = torch.add(d_top, d_tops[lvl]).to(bt)
+            if lvl < 32:       # tops[lvl] = lateral + up2x(tops[2 lvl]): adjoint of nearest upsampling = 2x2 block sums (fp32 accumulation, read as bf16)
                 Bh, Hh, Wh, Ch = d_top.shape
-                d_tops[lvl * 2] = d_top.float().view(Bh, Hh // 2, 2, Wh // 2, 2, Ch).sum((2, 4))
-            d_src, dw = T.conv1x1_bwd(src[lvl], self.w(n1), d_top.contiguous(), need_dx=(lvl != 4), w_t=self.wt(n1), keep_splits=True, wgrad_to=self._wg(n1))   # res2c is frozen
-            self._add_bgrad(n1, d_top.float().sum((0, 1, 2)))
+                d_tops[lvl * 2] = d_top.view(Bh, Hh // 2, 2, Wh // 2, 2, Ch).sum((2, 4), dtype=torch.float32)
+            d_top = d_top.contiguous()
+            d_src, dw = T.conv1x1_bwd(src[lvl], self.w(n1), d_top, need_dx=(lvl != 4), w_t=self.wt(n1), keep_splits=True, wgrad_to=self._wg(n1))   # res2c is frozen
+            T.colsum_add(d_top, self._bg(n1))
             if lvl == 32:
                 d_c5 = d_src
             elif lvl == 16:
