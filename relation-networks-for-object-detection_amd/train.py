@@ -469,8 +469,14 @@ class Trainer(object):
         B = data.shape[0]
         self._grad_buckets().reset()
         self.W.grad.zero_(); self.Bv.grad.zero_()
-        self._relayout.run()            # W^T / tap-flipped copies of the current weights for every data-gradient product
-        self._fragpack.run()            # ... and the fragment-order copies the chain kernels of the forward read
+        # W^T / tap-flipped copies of the current weights for every data-gradient product: only the BACKWARD reads them.  With the RPN branch on
+        # its side stream they are made after conv_new_1, where the main stream otherwise waits for the proposals (one image: the branch's
+        # single-workgroup sort / NMS kernels are the longer path and leave the chip idle); otherwise here
+        late_relayout = (self._side is not None and getattr(self, 'overlap_rpn', os.environ.get('RELNET_TRAIN_OVERLAP', '1') != '0')
+                         and os.environ.get('RELNET_LATE_RELAYOUT', '1') != '0')
+        if not late_relayout:
+            self._relayout.run()
+        self._fragpack.run()            # the fragment-order copies the chain kernels of the forward read
         # The RPN branch (head convolutions, anchor targets, losses, proposals, proposal targets: everything that hangs off conv4)
         # runs on a side stream BESIDE res5 / conv_new_1 -- its top-k / sort / NMS / target kernels are one workgroup per image and
         # leave the GPU idle on their own; fork when conv4 exists, join before ROI pooling (graph edges under capture).
@@ -526,7 +532,10 @@ class Trainer(object):
             if rpn_bwd_side:
                 br['ev'] = torch.cuda.Event()
                 br['ev'].record()               # main resumes here (rois and their targets exist); the RPN head's backward follows on this stream
-                rpn_backward(conv4, r, d_rpn)
+                if late_relayout:
+                    br['bwd'] = (conv4, r, d_rpn)     # ... once the main stream has made the weight copies it reads (enqueued below)
+                else:
+                    rpn_backward(conv4, r, d_rpn)
 
         def rpn_backward(conv4, r, d_rpn):
             # ... and with them the two RPN weight gradients, as their own grouped launch on 64 workgroups (a quarter of the chip: the head's
@@ -559,6 +568,12 @@ class Trainer(object):
         # (a float32 trunk -- cfg.trunk_fp32, parity tests -- hands bf16 copies to the bf16 heads and takes their gradients back as float32)
         conv5, conv4 = conv5.to(torch.bfloat16), conv4.to(torch.bfloat16)
         feat = self._conv(conv5, 'conv_new_1', relu=True, bias=self.b('conv_new_1'))
+        if late_relayout:
+            self._relayout.run()
+            if br.get('bwd') is not None:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    rpn_backward(*br.pop('bwd'))
         if side is not None:
             if rpn_bwd_side:
                 main.wait_event(br['ev'])
