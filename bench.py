@@ -721,7 +721,7 @@ def main():
             res['train']['at_1_image_per_gpu'] = pick(tr1, sub)
             if tr1 is not None and 'error' not in tr1:
                 res['train']['at_1_image_per_gpu']['note'] = ("the reference's own protocol: BATCH_IMAGES 1 per device (cfgs/..._rcnn_end2end_relation_"
-                                                               "learn_nms_8epoch.yaml:80); ~700 launches of a few microseconds each, launch / latency bound")
+                                                               "learn_nms_8epoch.yaml:80); ~380 launches of 4 - 37 us on 2 394-pixel maps, latency bound")
     if plain_graph and not a.no_other_configs and world > 1 and rank == 0:
         res['other_configs'] = 'single-GPU side figures (configs[3] / configs[4] inference and training rates): run `python bench.py` with --gpus 1'
     if plain_graph and not a.no_other_configs and world == 1:
