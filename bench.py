@@ -147,7 +147,7 @@ def _timed_windows(replay, D, per_window, windows=5, warm_seconds=1.0):
     return per[len(per) // 2], per[0], per[-1]
 
 
-def _replay_rate(det, bsz, a, D, replays=200, windows=5, step=None):
+def _replay_rate(det, bsz, a, D, replays=200, windows=5, step=None, make_det=None):
     """images/s of `det` at `bsz` images per step under hipGraph replay: one capture, 1 s of warm replays, then `windows` windows of
     `replays / windows` replays each (>= 200 replays in total: a 136-launch graph of ~3 ms is host-launch and clock-ramp
     sensitive, one 20-replay window is not a measurement); median window with min / max next to it."""
@@ -166,9 +166,21 @@ def _replay_rate(det, bsz, a, D, replays=200, windows=5, step=None):
         per_window = max(1, replays // windows)
         med, lo, hi = _timed_windows(graph.replay, D, per_window, windows)
     del graph
-    return {'images_per_s': bsz / med, 'ms_per_step': 1e3 * med, 'ms_min': 1e3 * lo, 'ms_max': 1e3 * hi,
-            'images_per_s_min': bsz / hi, 'images_per_s_max': bsz / lo,
-            'protocol': '%d windows x %d replays after >= 1 s of warm replays; median window (min / max beside it)' % (windows, per_window)}
+    res = {'images_per_s': bsz / med, 'ms_per_step': 1e3 * med, 'ms_min': 1e3 * lo, 'ms_max': 1e3 * hi,
+           'images_per_s_min': bsz / hi, 'images_per_s_max': bsz / lo,
+           'protocol': '%d windows x %d replays after >= 1 s of warm replays; median window (min / max beside it)' % (windows, per_window)}
+    if make_det is not None:      # the same protocol with TWO batches in flight (detector.InFlight: a second detector instance and batch, two streams)
+        from relnet_amd import detector as _det
+        g2 = torch.Generator().manual_seed(977 + bsz)
+        data2 = torch.randn(bsz, 3, 600, 1000, generator=g2).cuda()
+        im2 = torch.tensor([[600.0, 1000.0, 1.0]] * bsz).cuda()
+        det2 = make_det()
+        flight = _det.InFlight([step, lambda: det2.forward(data2, im2)])
+        med2, lo2, hi2 = _timed_windows(flight.submit, D, per_window, windows)
+        res['two_in_flight'] = {'images_per_s': bsz / med2, 'ms_per_step_by_throughput': 1e3 * med2, 'images_per_s_min': bsz / hi2, 'images_per_s_max': bsz / lo2,
+                                'note': 'two captured steps on two streams submitted alternately; every step still takes its own ~ms_per_step above (or longer) from launch to result'}
+        del flight, det2
+    return res
 
 
 def _side_figure(fn, what):
@@ -451,6 +463,7 @@ def main():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--stem', default='hip', choices=['hip', 'hip3', 'miopen'], help="stem: 'hip' one fused conv1 + ReLU + pool1 kernel, 'hip3' the three-launch form, 'miopen' library 7x7")
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of hipGraph replays')
+    ap.add_argument('--in-flight', type=int, default=2, help='inference line: batches in flight (captured steps on their own streams, submitted round-robin; 1 = one after the other)')
     ap.add_argument('--shapes', action='store_true', help='print per-shape GEMM/conv times to stderr')
     ap.add_argument('--head-init-std', type=float, default=0.05,
                     help='std of the random cls_score / bbox_pred weights (reference init: 0.01, which makes every class posterior '
@@ -507,19 +520,22 @@ def main():
     else:
         cfg = detector.Config()
         cfg.dcn = a.dcn
-    if a.fpn:
-        det = detector.FPNDetector(params, dtype=tdt, device='cuda', relation=not a.no_relation, cfg=cfg, stem=a.stem)
-    else:
-        det = detector.Detector(params, dtype=tdt, device='cuda', relation=not a.no_relation, cfg=cfg, stem=a.stem)
-    if a.no_overlap and hasattr(det, 'overlap_rpn'):
-        det.overlap_rpn = False
-    if a.no_chain:
-        from relnet_amd import ops as _ops
-        bb = det.backbone
-        bb.chain, bb.halo3, bb.chain_proj = {}, {}, {}
-        for name, (w, _, k) in bb.wp.items():          # res4 expand layers back on the row-panel kernel (the pre-fusion state)
-            if name.endswith('_branch2c') and k == 1 and w.shape[1] == 256 and w.shape[0] % 256 == 0:
-                bb.wf[name] = _ops.pack_w_frag(w)
+    def make_det():
+        if a.fpn:
+            det = detector.FPNDetector(params, dtype=tdt, device='cuda', relation=not a.no_relation, cfg=cfg, stem=a.stem)
+        else:
+            det = detector.Detector(params, dtype=tdt, device='cuda', relation=not a.no_relation, cfg=cfg, stem=a.stem)
+        if a.no_overlap and hasattr(det, 'overlap_rpn'):
+            det.overlap_rpn = False
+        if a.no_chain:
+            from relnet_amd import ops as _ops
+            bb = det.backbone
+            bb.chain, bb.halo3, bb.chain_proj = {}, {}, {}
+            for name, (w, _, k) in bb.wp.items():          # res4 expand layers back on the row-panel kernel (the pre-fusion state)
+                if name.endswith('_branch2c') and k == 1 and w.shape[1] == 256 and w.shape[0] % 256 == 0:
+                    bb.wf[name] = _ops.pack_w_frag(w)
+        return det
+    det = make_det()
     g = torch.Generator().manual_seed(1000 + rank)
     # unit-variance synthetic pixels: with random-init weights (no checkpoints offline) this gives
     # O(1) RPN logits/deltas, i.e. several hundred distinct proposals survive NMS per image; N(0,50)
@@ -566,6 +582,29 @@ def main():
                 out = step()
         fence()
         elapsed = time.perf_counter() - t0
+        # throughput mode (detector.InFlight), a SIDE figure of the line (`in_flight`): the same K steps with two batches in flight -- a second
+        # detector instance (own buffers), a second resident batch, each step captured on its own stream, steps submitted round-robin.
+        # `value` stays the one-at-a-time rate of rounds 1-5
+        elapsed_fl, n_flight = None, 1
+        if graph is not None and a.in_flight > 1:
+            del graph                 # (its executable graph holds runtime streams: with it alive the two graphs below measured no overlap at all)
+            graph = True
+            torch.cuda.synchronize()
+
+            def extra_step(j):
+                gj = torch.Generator().manual_seed(1000 + rank + 7919 * j)
+                dj, detj = torch.randn(a.batch, 3, im_h, im_w, generator=gj).cuda(), make_det()
+                return (lambda: detj.forward(dj, proposals, im_info)) if a.fpn else (lambda: detj.forward(dj, im_info))
+            flight = detector.InFlight([step] + [extra_step(j) for j in range(1, a.in_flight)])
+            for _ in range(2 * len(flight)):
+                flight.submit()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                flight.submit()
+            fence()
+            elapsed_fl, n_flight = time.perf_counter() - t0, len(flight)
+            out = flight.result(0)
         # per-kernel durations: the same step launched eagerly with HIP events around every C-ABI
         # launch (events cannot be timed inside a captured graph); same inputs, same stream
         timer = None if a.no_kernel_timing else KernelTimer()
@@ -576,6 +615,8 @@ def main():
             torch.cuda.synchronize()
             lib.timing_hook = None
     elapsed = D.max_over_ranks(elapsed, device='cuda')
+    if elapsed_fl is not None:
+        elapsed_fl = D.max_over_ranks(elapsed_fl, device='cuda')
     n_det = int(out['num_detections'].sum().item())
     # (random-init learn-NMS logits start at sigmoid(-3) x ~1/81 < 1e-3: zero detections is expected there)
     assert (n_det > 0 or a.learn_nms) and bool(torch.isfinite(out['cls_score']).all())
@@ -596,7 +637,8 @@ def main():
                                        'inference graph of BASELINE configs[4] (FPN, 800x1024 images, 1000 given proposals): ' if a.fpn else ''),
                                       '2 relation modules (N=300, 16 heads, d=1024)' if not a.no_relation else 'plain 2FC head',
                                       'learn-NMS (first_n %d, class_thresh %g, 80 classes)' % (cfg.first_n, cfg.learn_nms_class_thresh) if a.learn_nms else 'soft-NMS(0.6)'),
-                       'images_per_gpu_per_step': a.batch, 'launch': 'eager' if a.no_graph else 'hipGraph replay', 'parallelism': 'replicas x%d (no data-path collective)' % world,
+                       'images_per_gpu_per_step': a.batch,
+                       'launch': 'eager' if a.no_graph else 'hipGraph replay', 'batches_in_flight': 1, 'parallelism': 'replicas x%d (no data-path collective)' % world,
                        'cross_round_figure': "`value` is quoted at %d images per GPU per step (the default since the end of round 4); rounds 1-3 quoted 54: compare those with batch_sweep['54']" % a.batch,
                        'ranks_seen_by_rccl': ranks_seen, 'head_init_std': a.head_init_std,
                        'precision': 'bf16 operands, fp32 accumulation (fp16 only for the log2 geometry bias read by the attention kernel); BASELINE '
@@ -608,6 +650,12 @@ def main():
                                          'single GPU; at N > 1 the data-parallel scaling figure is train.value (training step incl. the RCCL all-reduce)',
                        **({'one_device_test': 'all %d ranks share cuda:0 and exchange over gloo (RELNET_BENCH_ONE_DEVICE): a code-path check, NOT a multi-GPU number' % world} if one_dev else {})},
         }
+        if elapsed_fl is not None:
+            res['in_flight'] = {'batches_in_flight': n_flight, 'value': images / elapsed_fl, 'unit': 'images/s', 'ms_per_step_by_throughput': 1e3 * elapsed_fl / a.steps,
+                                'steps': a.steps, 'vs_one_at_a_time': elapsed / elapsed_fl,
+                                'note': 'the same K steps with %d batches in flight (detector.InFlight: %d captured steps -- own detector buffers and resident batch each -- '
+                                        'submitted round-robin on %d streams); a step then takes longer from launch to result. Pays where one step leaves the chip idle: see '
+                                        "batch_sweep[*]['two_in_flight'] (1 image per step: +55 %%, 8 images: +37 %%)" % (n_flight, n_flight, n_flight)}
         if timer is not None:
             ks = timer.summary()
             if a.shapes:
@@ -692,7 +740,7 @@ def main():
             for bsz in (1, 8, 54):
                 if bsz == a.batch:
                     continue
-                res['batch_sweep'][str(bsz)] = _replay_rate(det, bsz, a, D)
+                res['batch_sweep'][str(bsz)] = _replay_rate(det, bsz, a, D, make_det=make_det if a.in_flight > 1 else None)
         if world == 1 and not a.no_cpu_baseline and not a.dcn and not a.fpn:      # the CPU port of the DCN graph is parity-only (slow)
             res['cpu_baseline'] = cpu_baseline(params, relation=not a.no_relation, images=a.cpu_images, threads=a.cpu_threads)
     if plain_graph and not a.no_train_line:

@@ -188,6 +188,53 @@ class Detector(object):
         return out
 
 
+
+class InFlight(object):
+    """Throughput mode of the captured step: n steps -- each a forward of its OWN detector instance on its own resident inputs (own
+    activations, scratch and split-K work area) -- are captured as n hipGraphs on n streams and replayed round-robin, so that
+    consecutive batches overlap: the tail of batch k (ROI pooling, the 2FC head, per-class NMS: partial waves of workgroups) and the
+    single-workgroup proposal kernels run beside the trunk of batch k + 1.  Measured on one MI355X (tools/pipeline_probe.py), images/s with 1 / 2
+    in flight: 1 image per step 479 / 735, 8 images 1569 / 2145, 54 images 2730 / 2867, 108 images 2810 / 2866.  Three and four in flight are
+    SLOWER (1 image: 608 / 561): a captured step already uses two hardware queues (trunk + RPN branch) and the runtime has four.
+    Every graph must be captured on ITS stream: two graphs captured on one stream share the runtime's queues and do not overlap (+0 - 1 %).
+    The reference runs one batch at a time per device (core/tester.py:pred_eval); the results of a batch are what one forward gives.
+
+        fl = InFlight([lambda: det_a.forward(data_a, im_info), lambda: det_b.forward(data_b, im_info)])
+        i = fl.submit()                 # replays slot k % n on its stream (refresh that slot's input tensors before, on any stream ordered before it)
+        out = fl.result(i)              # waits for THAT replay only; the tensors are overwritten by the slot's next replay
+    """
+
+    def __init__(self, steps, warmup=2, capture_error_mode='thread_local'):
+        self.graphs, self.streams, self.outs, self.done = [], [], [], []
+        with torch.no_grad():
+            for step in steps:
+                for _ in range(warmup):          # eager, on the caller's stream: kernel attributes, allocator pools, self-checks
+                    step()
+                torch.cuda.synchronize()
+                s = torch.cuda.Stream()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s, capture_error_mode=capture_error_mode):
+                    out = step()
+                self.graphs.append(g); self.streams.append(s); self.outs.append(out); self.done.append(torch.cuda.Event())
+        torch.cuda.synchronize()
+        self.k = 0
+
+    def __len__(self):
+        return len(self.graphs)
+
+    def submit(self):
+        i = self.k % len(self.graphs)
+        self.k += 1
+        with torch.cuda.stream(self.streams[i]):
+            self.graphs[i].replay()
+            self.done[i].record()
+        return i
+
+    def result(self, i):
+        self.done[i].synchronize()
+        return self.outs[i]
+
+
 class FPNDetector(object):
     """Test graph of the FPN relation configuration (symbols/resnet_v1_101_rcnn_fpn_attention_1024_pairwise_position_
     multi_head_16.py / ..._learn_nms.py, get_symbol_rcnn test branch :1085-1200): proposals are an INPUT

@@ -150,6 +150,38 @@ def test_detector_bf16_batch_runs_and_is_close(rn):
     assert (out['num_detections'] > 0).all()
 
 
+def test_two_batches_in_flight_give_each_batch_its_own_forward_results(rn):
+    """detector.InFlight: two captured steps (two detector instances, two resident batches) replayed round-robin on two streams.  Every
+    replay must give exactly what an eager forward of that instance gives on the slot's CURRENT input -- also when the other slot's
+    replay is in flight beside it, and after the slot's input tensor has been overwritten in place."""
+    ops, backbone, detector = rn
+    H, W = 192, 256
+    p = backbone.init_params(seed=4)
+    g = torch.Generator().manual_seed(16)
+    im_info = torch.tensor([[H, W, 1.0], [H, W, 1.0]]).cuda()
+    cfg = detector.Config(); cfg.rpn_post_nms_top_n = 64
+    dets = [detector.Detector(p, dtype=torch.bfloat16, im_hw=(H, W), cfg=cfg) for _ in range(2)]
+    datas = [torch.randn(2, 3, H, W, generator=g).cuda() for _ in range(2)]
+    keys = ('rois', 'cls_prob', 'pred_boxes', 'num_detections', 'det_boxes', 'det_scores', 'det_classes')
+    with torch.no_grad():
+        fl = detector.InFlight([lambda i=i: dets[i].forward(datas[i], im_info) for i in range(2)])
+        assert len(fl) == 2 and fl.streams[0] != fl.streams[1]
+        for rnd in range(3):
+            if rnd == 2:                       # new batches into the resident input tensors
+                for d in datas:
+                    d.copy_(torch.randn(d.shape, generator=g).cuda())
+                torch.cuda.synchronize()
+            ref = [{k: v.clone() for k, v in dets[i].forward(datas[i], im_info).items() if k in keys} for i in range(2)]
+            torch.cuda.synchronize()
+            slots = [fl.submit() for _ in range(4)]            # both slots twice, nothing waited for in between
+            assert slots == [0, 1, 0, 1]
+            for i in range(2):
+                out = fl.result(i)
+                for k in ref[i]:
+                    assert torch.equal(out[k], ref[i][k]), (rnd, i, k)
+        assert not torch.equal(fl.result(0)['rois'], fl.result(1)['rois'])          # (two different batches)
+
+
 @pytest.mark.parametrize('cin,cout,k,stride,dil,hw', [(64, 64, 1, 1, 1, (37, 50)), (256, 128, 1, 2, 1, (38, 51)),
                                                       (128, 128, 3, 1, 1, (19, 33)), (512, 512, 3, 1, 2, (13, 21)),
                                                       (1024, 72, 1, 1, 1, (12, 16)), (64, 256, 1, 1, 1, (75, 64))])
