@@ -147,7 +147,7 @@ def _timed_windows(replay, D, per_window, windows=5, warm_seconds=1.0):
     return per[len(per) // 2], per[0], per[-1]
 
 
-def _replay_rate(det, bsz, a, D, replays=200, windows=5, step=None, make_det=None):
+def _replay_rate(det, bsz, a, D, replays=200, windows=5, step=None, make_det=None, second=None):
     """images/s of `det` at `bsz` images per step under hipGraph replay: one capture, 1 s of warm replays, then `windows` windows of
     `replays / windows` replays each (>= 200 replays in total: a 136-launch graph of ~3 ms is host-launch and clock-ramp
     sensitive, one 20-replay window is not a measurement); median window with min / max next to it."""
@@ -169,17 +169,22 @@ def _replay_rate(det, bsz, a, D, replays=200, windows=5, step=None, make_det=Non
     res = {'images_per_s': bsz / med, 'ms_per_step': 1e3 * med, 'ms_min': 1e3 * lo, 'ms_max': 1e3 * hi,
            'images_per_s_min': bsz / hi, 'images_per_s_max': bsz / lo,
            'protocol': '%d windows x %d replays after >= 1 s of warm replays; median window (min / max beside it)' % (windows, per_window)}
-    if make_det is not None:      # the same protocol with TWO batches in flight (detector.InFlight: a second detector instance and batch, two streams)
+    if make_det is not None or second is not None:      # the same protocol with TWO batches in flight (detector.InFlight: a second detector instance and batch, two streams)
         from relnet_amd import detector as _det
-        g2 = torch.Generator().manual_seed(977 + bsz)
-        data2 = torch.randn(bsz, 3, 600, 1000, generator=g2).cuda()
-        im2 = torch.tensor([[600.0, 1000.0, 1.0]] * bsz).cuda()
-        det2 = make_det()
-        flight = _det.InFlight([step, lambda: det2.forward(data2, im2)])
+        if second is not None:        # (`second()` -> the second slot's step: its own detector instance on its own resident batch)
+            step2 = second()
+            det2 = None
+        else:
+            g2 = torch.Generator().manual_seed(977 + bsz)
+            data2 = torch.randn(bsz, 3, 600, 1000, generator=g2).cuda()
+            im2 = torch.tensor([[600.0, 1000.0, 1.0]] * bsz).cuda()
+            det2 = make_det()
+            step2 = lambda: det2.forward(data2, im2)
+        flight = _det.InFlight([step, step2])
         med2, lo2, hi2 = _timed_windows(flight.submit, D, per_window, windows)
         res['two_in_flight'] = {'images_per_s': bsz / med2, 'ms_per_step_by_throughput': 1e3 * med2, 'images_per_s_min': bsz / hi2, 'images_per_s_max': bsz / lo2,
                                 'note': 'two captured steps on two streams submitted alternately; every step still takes its own ~ms_per_step above (or longer) from launch to result'}
-        del flight, det2
+        del flight, det2, step2
     return res
 
 
@@ -242,18 +247,21 @@ def other_configs(a, rank, world, D):
         params = backbone.init_params(seed=1, dcn_offset_std=0.01 if dcn else 0.0, fpn=fpn)
         cfg = detector.Config.from_experiment(EXPERIMENT_OF[(dcn, fpn)])
         assert cfg.learn_nms and cfg.dcn == dcn
-        g = torch.Generator().manual_seed(77 + rank)
         im_h, im_w = (800, 1024) if fpn else (600, 1000)
-        data = torch.randn(bsz, 3, im_h, im_w, generator=g).cuda()
         im_info = torch.tensor([[float(im_h), float(im_w), 1.0]] * bsz).cuda()
-        if fpn:
-            det = detector.FPNDetector(params, dtype=torch.bfloat16, device='cuda', cfg=cfg)
-            props = _fpn_proposals(bsz, 1000, im_h, im_w, g)
-            step = lambda: det.forward(data, props, im_info)
-        else:
-            det = detector.Detector(params, dtype=torch.bfloat16, device='cuda', cfg=cfg)
-            step = lambda: det.forward(data, im_info)
-        r = _side_figure(lambda: _replay_rate(det, bsz, a, D, replays=30, windows=3, step=step), key)
+
+        def slot(seed):            # one detector instance + its resident batch -> (detector, step)
+            gs = torch.Generator().manual_seed(seed)
+            d_ = torch.randn(bsz, 3, im_h, im_w, generator=gs).cuda()
+            if fpn:
+                dt = detector.FPNDetector(params, dtype=torch.bfloat16, device='cuda', cfg=cfg)
+                pr = _fpn_proposals(bsz, 1000, im_h, im_w, gs)
+                return dt, (lambda: dt.forward(d_, pr, im_info))
+            dt = detector.Detector(params, dtype=torch.bfloat16, device='cuda', cfg=cfg)
+            return dt, (lambda: dt.forward(d_, im_info))
+        det, step = slot(77 + rank)
+        r = _side_figure(lambda: _replay_rate(det, bsz, a, D, replays=30, windows=3, step=step,
+                                              second=(lambda: slot(1077 + rank)[1]) if getattr(a, 'in_flight', 1) > 1 else None), key)
         if 'error' not in r:
             r.update(images_per_gpu_per_step=bsz, n_gpus=world, images_per_s_all_gpus=r['images_per_s'] * world,
                      experiment=cfg.experiment, first_n=cfg.first_n, class_thresh=cfg.learn_nms_class_thresh)
