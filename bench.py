@@ -147,7 +147,7 @@ def _timed_windows(replay, D, per_window, windows=5, warm_seconds=1.0):
     return per[len(per) // 2], per[0], per[-1]
 
 
-def _replay_rate(det, bsz, a, D, replays=200, windows=5, step=None, make_det=None, second=None):
+def _replay_rate(det, bsz, a, D, replays=200, windows=5, step=None, make_det=None, slot_step=None, n_flight=3):
     """images/s of `det` at `bsz` images per step under hipGraph replay: one capture, 1 s of warm replays, then `windows` windows of
     `replays / windows` replays each (>= 200 replays in total: a 136-launch graph of ~3 ms is host-launch and clock-ramp
     sensitive, one 20-replay window is not a measurement); median window with min / max next to it."""
@@ -169,22 +169,24 @@ def _replay_rate(det, bsz, a, D, replays=200, windows=5, step=None, make_det=Non
     res = {'images_per_s': bsz / med, 'ms_per_step': 1e3 * med, 'ms_min': 1e3 * lo, 'ms_max': 1e3 * hi,
            'images_per_s_min': bsz / hi, 'images_per_s_max': bsz / lo,
            'protocol': '%d windows x %d replays after >= 1 s of warm replays; median window (min / max beside it)' % (windows, per_window)}
-    if make_det is not None or second is not None:      # the same protocol with TWO batches in flight (detector.InFlight: a second detector instance and batch, two streams)
+    if make_det is not None or slot_step is not None:
+        # the same protocol with n_flight batches in flight (detector.InFlight): n_flight FRESH detector instances with the RPN branch in line
+        # (one hardware queue per captured step), each on its own resident batch and stream.  slot_step(j) -> the step of slot j.
         from relnet_amd import detector as _det
-        if second is not None:        # (`second()` -> the second slot's step: its own detector instance on its own resident batch)
-            step2 = second()
-            det2 = None
-        else:
-            g2 = torch.Generator().manual_seed(977 + bsz)
-            data2 = torch.randn(bsz, 3, 600, 1000, generator=g2).cuda()
-            im2 = torch.tensor([[600.0, 1000.0, 1.0]] * bsz).cuda()
-            det2 = make_det()
-            step2 = lambda: det2.forward(data2, im2)
-        flight = _det.InFlight([step, step2])
+        if slot_step is None:
+            def slot_step(j):
+                gj = torch.Generator().manual_seed(977 + bsz + 31 * j)
+                dj = torch.randn(bsz, 3, 600, 1000, generator=gj).cuda()
+                imj = torch.tensor([[600.0, 1000.0, 1.0]] * bsz).cuda()
+                detj = make_det(in_line=True)
+                return lambda: detj.forward(dj, imj)
+        flight = _det.InFlight([slot_step(j) for j in range(n_flight)])
         med2, lo2, hi2 = _timed_windows(flight.submit, D, per_window, windows)
-        res['two_in_flight'] = {'images_per_s': bsz / med2, 'ms_per_step_by_throughput': 1e3 * med2, 'images_per_s_min': bsz / hi2, 'images_per_s_max': bsz / lo2,
-                                'note': 'two captured steps on two streams submitted alternately; every step still takes its own ~ms_per_step above (or longer) from launch to result'}
-        del flight, det2, step2
+        res['in_flight'] = {'batches_in_flight': n_flight, 'images_per_s': bsz / med2, 'ms_per_step_by_throughput': 1e3 * med2, 'images_per_s_min': bsz / hi2,
+                            'images_per_s_max': bsz / lo2,
+                            'note': '%d captured steps (own detector instance and resident batch each, RPN branch in line) on %d streams, submitted round-robin; every step '
+                                    'still takes its own ~ms_per_step above (or longer) from launch to result' % (n_flight, n_flight)}
+        del flight
     return res
 
 
@@ -250,7 +252,7 @@ def other_configs(a, rank, world, D):
         im_h, im_w = (800, 1024) if fpn else (600, 1000)
         im_info = torch.tensor([[float(im_h), float(im_w), 1.0]] * bsz).cuda()
 
-        def slot(seed):            # one detector instance + its resident batch -> (detector, step)
+        def slot(seed, in_line=False):            # one detector instance + its resident batch -> (detector, step)
             gs = torch.Generator().manual_seed(seed)
             d_ = torch.randn(bsz, 3, im_h, im_w, generator=gs).cuda()
             if fpn:
@@ -258,10 +260,13 @@ def other_configs(a, rank, world, D):
                 pr = _fpn_proposals(bsz, 1000, im_h, im_w, gs)
                 return dt, (lambda: dt.forward(d_, pr, im_info))
             dt = detector.Detector(params, dtype=torch.bfloat16, device='cuda', cfg=cfg)
+            if in_line:
+                dt.overlap_rpn = False
             return dt, (lambda: dt.forward(d_, im_info))
         det, step = slot(77 + rank)
-        r = _side_figure(lambda: _replay_rate(det, bsz, a, D, replays=30, windows=3, step=step,
-                                              second=(lambda: slot(1077 + rank)[1]) if getattr(a, 'in_flight', 1) > 1 else None), key)
+        nfl = getattr(a, 'in_flight', 1)
+        r = _side_figure(lambda: _replay_rate(det, bsz, a, D, replays=30, windows=3, step=step, n_flight=nfl,
+                                              slot_step=(lambda j: slot(1077 + rank + 13 * j, True)[1]) if nfl > 1 else None), key)
         if 'error' not in r:
             r.update(images_per_gpu_per_step=bsz, n_gpus=world, images_per_s_all_gpus=r['images_per_s'] * world,
                      experiment=cfg.experiment, first_n=cfg.first_n, class_thresh=cfg.learn_nms_class_thresh)
@@ -471,7 +476,7 @@ def main():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--stem', default='hip', choices=['hip', 'hip3', 'miopen'], help="stem: 'hip' one fused conv1 + ReLU + pool1 kernel, 'hip3' the three-launch form, 'miopen' library 7x7")
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of hipGraph replays')
-    ap.add_argument('--in-flight', type=int, default=2, help='inference line: batches in flight (captured steps on their own streams, submitted round-robin; 1 = one after the other)')
+    ap.add_argument('--in-flight', type=int, default=3, help='side figures of the inference line: batches in flight (captured steps with the RPN branch in line, each on its own stream, submitted round-robin; 1 = none). `value` is always the one-at-a-time rate')
     ap.add_argument('--shapes', action='store_true', help='print per-shape GEMM/conv times to stderr')
     ap.add_argument('--head-init-std', type=float, default=0.05,
                     help='std of the random cls_score / bbox_pred weights (reference init: 0.01, which makes every class posterior '
@@ -528,13 +533,13 @@ def main():
     else:
         cfg = detector.Config()
         cfg.dcn = a.dcn
-    def make_det():
+    def make_det(in_line=False):
         if a.fpn:
             det = detector.FPNDetector(params, dtype=tdt, device='cuda', relation=not a.no_relation, cfg=cfg, stem=a.stem)
         else:
             det = detector.Detector(params, dtype=tdt, device='cuda', relation=not a.no_relation, cfg=cfg, stem=a.stem)
-        if a.no_overlap and hasattr(det, 'overlap_rpn'):
-            det.overlap_rpn = False
+        if (a.no_overlap or in_line) and hasattr(det, 'overlap_rpn'):
+            det.overlap_rpn = False          # (in_line: a step in flight beside others keeps to ONE hardware queue)
         if a.no_chain:
             from relnet_amd import ops as _ops
             bb = det.backbone
@@ -600,10 +605,10 @@ def main():
             torch.cuda.synchronize()
 
             def extra_step(j):
-                gj = torch.Generator().manual_seed(1000 + rank + 7919 * j)
-                dj, detj = torch.randn(a.batch, 3, im_h, im_w, generator=gj).cuda(), make_det()
+                gj = torch.Generator().manual_seed(1000 + rank + 7919 * (j + 1))
+                dj, detj = torch.randn(a.batch, 3, im_h, im_w, generator=gj).cuda(), make_det(in_line=True)
                 return (lambda: detj.forward(dj, proposals, im_info)) if a.fpn else (lambda: detj.forward(dj, im_info))
-            flight = detector.InFlight([step] + [extra_step(j) for j in range(1, a.in_flight)])
+            flight = detector.InFlight([extra_step(j) for j in range(a.in_flight)])
             for _ in range(2 * len(flight)):
                 flight.submit()
             fence()
@@ -661,9 +666,9 @@ def main():
         if elapsed_fl is not None:
             res['in_flight'] = {'batches_in_flight': n_flight, 'value': images / elapsed_fl, 'unit': 'images/s', 'ms_per_step_by_throughput': 1e3 * elapsed_fl / a.steps,
                                 'steps': a.steps, 'vs_one_at_a_time': elapsed / elapsed_fl,
-                                'note': 'the same K steps with %d batches in flight (detector.InFlight: %d captured steps -- own detector buffers and resident batch each -- '
-                                        'submitted round-robin on %d streams); a step then takes longer from launch to result. Pays where one step leaves the chip idle: see '
-                                        "batch_sweep[*]['two_in_flight'] (1 image per step: +55 %%, 8 images: +37 %%)" % (n_flight, n_flight, n_flight)}
+                                'note': 'the same K steps with %d batches in flight (detector.InFlight: %d captured steps -- own detector instance and resident batch each, RPN '
+                                        'branch in line = one hardware queue per step -- submitted round-robin on %d streams); a step then takes longer from launch to result. '
+                                        "Pays most where one step leaves the chip idle: see batch_sweep[*]['in_flight']" % (n_flight, n_flight, n_flight)}
         if timer is not None:
             ks = timer.summary()
             if a.shapes:
@@ -748,7 +753,7 @@ def main():
             for bsz in (1, 8, 54):
                 if bsz == a.batch:
                     continue
-                res['batch_sweep'][str(bsz)] = _replay_rate(det, bsz, a, D, make_det=make_det if a.in_flight > 1 else None)
+                res['batch_sweep'][str(bsz)] = _replay_rate(det, bsz, a, D, make_det=make_det if a.in_flight > 1 else None, n_flight=a.in_flight)
         if world == 1 and not a.no_cpu_baseline and not a.dcn and not a.fpn:      # the CPU port of the DCN graph is parity-only (slow)
             res['cpu_baseline'] = cpu_baseline(params, relation=not a.no_relation, images=a.cpu_images, threads=a.cpu_threads)
     if plain_graph and not a.no_train_line:

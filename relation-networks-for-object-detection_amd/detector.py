@@ -193,13 +193,18 @@ class InFlight(object):
     """Throughput mode of the captured step: n steps -- each a forward of its OWN detector instance on its own resident inputs (own
     activations, scratch and split-K work area) -- are captured as n hipGraphs on n streams and replayed round-robin, so that
     consecutive batches overlap: the tail of batch k (ROI pooling, the 2FC head, per-class NMS: partial waves of workgroups) and the
-    single-workgroup proposal kernels run beside the trunk of batch k + 1.  Measured on one MI355X (tools/pipeline_probe.py), images/s with 1 / 2
-    in flight: 1 image per step 479 / 735, 8 images 1569 / 2145, 54 images 2730 / 2867, 108 images 2810 / 2866.  Three and four in flight are
-    SLOWER (1 image: 608 / 561): a captured step already uses two hardware queues (trunk + RPN branch) and the runtime has four.
+    single-workgroup proposal kernels run beside the trunk of batch k + 1.  Measured on one MI355X (tools/pipeline_probe.py), images/s one at a
+    time -> in flight:
+      three steps with the RPN branch in line (`det.overlap_rpn = False`: one hardware queue per step):  1 image per step 440-466 -> 826-860,
+          2 images 637 -> 1228, 8 images 1494-1559 -> 2238-2269, 54 images 2723-2756 -> 2875-2878, 108 images 2813 -> 2901;
+      two steps that keep their RPN side stream (two queues each):  1 image 479 -> 735, 8 images 1569 -> 2145, 108 images 2810 -> 2866.
+    The runtime has four hardware queues: four single-queue steps (1 image: 675) or three two-queue steps (608) are SLOWER than these.
     Every graph must be captured on ITS stream: two graphs captured on one stream share the runtime's queues and do not overlap (+0 - 1 %).
-    The reference runs one batch at a time per device (core/tester.py:pred_eval); the results of a batch are what one forward gives.
+    The reference runs one batch at a time per device (core/tester.py:pred_eval); a replay gives exactly what one forward of that instance gives.
 
-        fl = InFlight([lambda: det_a.forward(data_a, im_info), lambda: det_b.forward(data_b, im_info)])
+        dets = [Detector(params, ...) for _ in range(3)]
+        for d in dets: d.overlap_rpn = False
+        fl = InFlight([lambda i=i: dets[i].forward(data[i], im_info) for i in range(3)])
         i = fl.submit()                 # replays slot k % n on its stream (refresh that slot's input tensors before, on any stream ordered before it)
         out = fl.result(i)              # waits for THAT replay only; the tensors are overwritten by the slot's next replay
     """

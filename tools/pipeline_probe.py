@@ -21,6 +21,8 @@ steps, keep = [], []
 with torch.no_grad():
     for i in range(NG):
         det = detector.Detector(params, dtype=torch.bfloat16, device='cuda', relation=True, cfg=detector.Config())
+        if os.environ.get('PROBE_NO_RPN_STREAM'):      # one queue per step: the RPN branch in line
+            det.overlap_rpn = False
         data = torch.randn(B, 3, 600, 1000, generator=g).cuda()
         keep.append((det, data))
         steps.append(lambda det=det, data=data: det.forward(data, im_info))
