@@ -150,8 +150,9 @@ def test_detector_bf16_batch_runs_and_is_close(rn):
     assert (out['num_detections'] > 0).all()
 
 
-def test_two_batches_in_flight_give_each_batch_its_own_forward_results(rn):
-    """detector.InFlight: two captured steps (two detector instances, two resident batches) replayed round-robin on two streams.  Every
+@pytest.mark.parametrize('n,in_line', [(2, False), (3, True)])
+def test_batches_in_flight_give_each_batch_its_own_forward_results(rn, n, in_line):
+    """detector.InFlight: n captured steps (n detector instances, n resident batches; in_line: RPN branch on the step's own stream) replayed round-robin on n streams.  Every
     replay must give exactly what an eager forward of that instance gives on the slot's CURRENT input -- also when the other slot's
     replay is in flight beside it, and after the slot's input tensor has been overwritten in place."""
     ops, backbone, detector = rn
@@ -160,22 +161,24 @@ def test_two_batches_in_flight_give_each_batch_its_own_forward_results(rn):
     g = torch.Generator().manual_seed(16)
     im_info = torch.tensor([[H, W, 1.0], [H, W, 1.0]]).cuda()
     cfg = detector.Config(); cfg.rpn_post_nms_top_n = 64
-    dets = [detector.Detector(p, dtype=torch.bfloat16, im_hw=(H, W), cfg=cfg) for _ in range(2)]
-    datas = [torch.randn(2, 3, H, W, generator=g).cuda() for _ in range(2)]
+    dets = [detector.Detector(p, dtype=torch.bfloat16, im_hw=(H, W), cfg=cfg) for _ in range(n)]
+    for d in dets:
+        d.overlap_rpn = not in_line
+    datas = [torch.randn(2, 3, H, W, generator=g).cuda() for _ in range(n)]
     keys = ('rois', 'cls_prob', 'pred_boxes', 'num_detections', 'det_boxes', 'det_scores', 'det_classes')
     with torch.no_grad():
-        fl = detector.InFlight([lambda i=i: dets[i].forward(datas[i], im_info) for i in range(2)])
-        assert len(fl) == 2 and fl.streams[0] != fl.streams[1]
+        fl = detector.InFlight([lambda i=i: dets[i].forward(datas[i], im_info) for i in range(n)])
+        assert len(fl) == n and fl.streams[0] != fl.streams[1]
         for rnd in range(3):
             if rnd == 2:                       # new batches into the resident input tensors
                 for d in datas:
                     d.copy_(torch.randn(d.shape, generator=g).cuda())
                 torch.cuda.synchronize()
-            ref = [{k: v.clone() for k, v in dets[i].forward(datas[i], im_info).items() if k in keys} for i in range(2)]
+            ref = [{k: v.clone() for k, v in dets[i].forward(datas[i], im_info).items() if k in keys} for i in range(n)]
             torch.cuda.synchronize()
-            slots = [fl.submit() for _ in range(4)]            # both slots twice, nothing waited for in between
-            assert slots == [0, 1, 0, 1]
-            for i in range(2):
+            slots = [fl.submit() for _ in range(2 * n)]        # every slot twice, nothing waited for in between
+            assert slots == list(range(n)) * 2
+            for i in range(n):
                 out = fl.result(i)
                 for k in ref[i]:
                     assert torch.equal(out[k], ref[i][k]), (rnd, i, k)
