@@ -634,7 +634,8 @@ int relnet_roi_pool_bwd_ex(const void* grad_out, const int* argmax, const long* 
 /* The same adjoint for a channels-last gradient: grad_in fp32 [B][H][W][C] (dense, accumulated into).  Round 6: where the operands allow (channels contiguous
  * in grad_out / argmax, 8 | C, H W <= 4608 cells) and the step is large enough to give every CU a workgroup (B C / 8 >= 256) ONE workgroup owns (image, 8
  * channels): the H x W slab is accumulated in LDS over every (roi, bin) of the image and flushed once -- no global atomics (31 M contended float atomics =
- * 0.44 ms per 8-image training step before); otherwise the scatter kernel.  relnet_roi_pool_bwd_debug(1) forces the scatter kernel. */
+ * 0.44 ms per 8-image training step before); otherwise the scatter kernel.  relnet_roi_pool_bwd_debug(1) forces the scatter kernel;
+ * 4 + bits = timing ablations of the owner kernel (results WRONG): 1 = no LDS adds, 2 = no scattered loads. */
 int relnet_roi_pool_bwd_cl(const void* grad_out, const int* argmax, const long* out_strides4, const float* rois, float* grad_in,
                            int B, int H, int W, int R, int C, int PH, int PW, int batch_index_base, int dtype, void* stream);
 void relnet_roi_pool_bwd_debug(int mode);

@@ -225,60 +225,92 @@ constexpr int kOwnerMaxCells = 4608;            // 4608 cells x 8 channels x 4 B
 
 constexpr int kOwnerList = 1024;                // rois per pass of the compact list (4 KB of LDS next to the slab)
 
+constexpr int kOwnerThreads = 1024;             // 16 wavefronts on the one workgroup a CU holds: the (roi, bin) walk is a chain of global loads -> LDS adds
+
 template <typename T, int CH>
-__global__ __launch_bounds__(256) void roi_pool_bwd_owner_kernel(RoiBwdArgs g, int cells) {
-  extern __shared__ float slab[];               // [cells][CH], then the roi list
+__global__ __launch_bounds__(kOwnerThreads) void roi_pool_bwd_owner_kernel(RoiBwdArgs g, int cells, int dbg) {
+  constexpr int NT = kOwnerThreads;
+  extern __shared__ float slab[];               // [CH][cells], then the roi list
   int* list = (int*)(slab + (long)cells * CH);
   __shared__ int cnt;
   const int chunks = g.C / CH;
-  const int b = blockIdx.x / chunks, c0 = (blockIdx.x % chunks) * CH;
-  for (int i = threadIdx.x; i < cells * CH; i += 256) slab[i] = 0.f;
+  // Workgroup i runs on XCD i % 8 (observed dispatch rule).  A 128-byte line of argmax holds 4 channel groups of a (roi, bin), a line of the bf16
+  // gradient 8: with group = i % chunks they sat on 4 / 8 different XCDs and every L2 fetched the line for 32 / 16 of its bytes (193 us per launch at
+  // 8 images: ~1 GB through the fabric for 185 MB of operands).  Each XCD now owns a contiguous run of chunks / 8 groups of an image.
+  int within = blockIdx.x % chunks;
+  if (chunks % 8 == 0) within = (within & 7) * (chunks >> 3) + (within >> 3);
+  const int b = blockIdx.x / chunks, c0 = within * CH;
+  for (int i = threadIdx.x; i < cells * CH; i += NT) slab[i] = 0.f;
   if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
   const int bins = g.PH * g.PW;
-  // pass over the rois in segments of kOwnerList: the image's own rois go into a compact list (a scan over (roi, bin) PAIRS that skips 7 of 8 of them
-  // one dependent load at a time was the first form: latency bound), then the (listed roi, bin) pairs are walked at full occupancy
-  for (int base = 0; base < g.R; base += kOwnerList) {
-    for (int r = base + threadIdx.x; r < min(base + kOwnerList, g.R); r += 256)
-      if ((int)g.rois[(long)r * 5] - g.batch_index_base == b) list[atomicAdd(&cnt, 1)] = r;
-    __syncthreads();
-    const int n = cnt;
-    for (int p = threadIdx.x; p < n * bins; p += 256) {
-      const int r = list[p / bins], bin = p % bins;
-      const int ph = bin / g.PW, pw = bin - ph * g.PW;
-      const long o = (long)r * g.os_r + (long)ph * g.os_ph + (long)pw * g.os_pw + c0;           // (os_c == 1)
-      int a[CH];
-      float v[CH];
-      if constexpr (CH == 8) {
-        const int4 a0 = *(const int4*)(g.argmax + o), a1 = *(const int4*)(g.argmax + o + 4);
-        a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
-      } else {
-        const int4 a0 = *(const int4*)(g.argmax + o);
-        a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w;
-      }
+  // argmax / gradient of one (listed roi, bin) pair for this workgroup's CH channels
+  auto fetch = [&](int p, int (&a)[CH], float (&v)[CH]) {
+    const int r = list[p / bins], bin = p % bins;
+    const int ph = bin / g.PW, pw = bin - ph * g.PW;
+    long o = (long)r * g.os_r + (long)ph * g.os_ph + (long)pw * g.os_pw + c0;           // (os_c == 1)
+    if (dbg & 2) o = (long)(threadIdx.x & 63) * 8 + c0;                                   // (timing ablation: every load hits the same few lines)
+    const int4 a0 = *(const int4*)(g.argmax + o);
+    a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w;
+    if constexpr (CH == 8) {
+      const int4 a1 = *(const int4*)(g.argmax + o + 4);
+      a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+    }
+    if constexpr (CH == 8 && sizeof(T) == 2) {             // bf16: the eight gradients are one 16-byte load (host: os_* % 8 == 0 for this path)
+      const uint4 w = *(const uint4*)((const unsigned short*)g.grad_out + o);
+      const unsigned int w4[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[2 * e] = bf2f(w4[e] & 0xffff); v[2 * e + 1] = bf2f(w4[e] >> 16); }
+    } else {
 #pragma unroll
       for (int e = 0; e < CH; ++e) v[e] = ld<T>((const T*)g.grad_out + o + e);
+    }
+  };
+  auto add = [&](const int (&a)[CH], const float (&v)[CH]) {
 #pragma unroll
-      for (int e = 0; e < CH; ++e)
-        if (a[e] >= 0 && a[e] < cells) atomicAdd(&slab[a[e] * CH + e], v[e]);
+    for (int e = 0; e < CH; ++e)
+      if (a[e] >= 0 && a[e] < cells && !(dbg & 1)) atomicAdd(&slab[e * cells + a[e]], v[e]);      // [CH][cells]: the lanes of one instruction (same e) spread over all banks
+                                                                                   // ([cells][CH] put them on 8 of 64: 178 us per launch at 8 images)
+  };
+  // pass over the rois in segments of kOwnerList: the image's own rois go into a compact list (a scan over (roi, bin) PAIRS that skips 7 of 8 of them
+  // one dependent load at a time was the first form: latency bound), then the (listed roi, bin) pairs are walked two at a time, loads first
+  for (int base = 0; base < g.R; base += kOwnerList) {
+    for (int r = base + threadIdx.x; r < min(base + kOwnerList, g.R); r += NT)
+      if ((int)g.rois[(long)r * 5] - g.batch_index_base == b) list[atomicAdd(&cnt, 1)] = r;
+    __syncthreads();
+    const int n = cnt, np = n * bins;
+    int p = threadIdx.x;
+    for (; p + NT < np; p += 2 * NT) {
+      int a0[CH], a1[CH];
+      float v0[CH], v1[CH];
+      fetch(p, a0, v0);
+      fetch(p + NT, a1, v1);
+      add(a0, v0);
+      add(a1, v1);
+    }
+    if (p < np) {
+      int a0[CH];
+      float v0[CH];
+      fetch(p, a0, v0);
+      add(a0, v0);
     }
     __syncthreads();
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
   }
   float* gin = g.grad_in + (long)b * g.ds_b + c0;
-  for (int i = threadIdx.x; i < cells; i += 256) {
+  for (int i = threadIdx.x; i < cells; i += NT) {
     float* dst = gin + (long)i * g.ds_p;
 #pragma unroll
     for (int q = 0; q < CH / 4; ++q) {
       float4 cur = *(float4*)(dst + 4 * q);
-      cur.x += slab[i * CH + 4 * q]; cur.y += slab[i * CH + 4 * q + 1]; cur.z += slab[i * CH + 4 * q + 2]; cur.w += slab[i * CH + 4 * q + 3];
+      cur.x += slab[(4 * q) * cells + i]; cur.y += slab[(4 * q + 1) * cells + i]; cur.z += slab[(4 * q + 2) * cells + i]; cur.w += slab[(4 * q + 3) * cells + i];
       *(float4*)(dst + 4 * q) = cur;
     }
   }
 }
 
-static int g_roi_bwd_mode = 0;       // test / measurement knob: 0 auto, 1 = scatter kernel only
+static int g_roi_bwd_mode = 0;       // test / measurement knob: 0 auto, 1 = scatter kernel only; 4 + bits = timing ablations of the owner kernel (results WRONG): 1 no LDS adds, 2 no scattered loads
 extern "C" void relnet_roi_pool_bwd_debug(int mode) { g_roi_bwd_mode = mode; }
 
 // Channels-last entry: grad_in fp32 [B][H][W][C] (dense, accumulated into), grad_out / argmax logical [R,C,PH,PW] with element strides out_strides4.
@@ -295,7 +327,8 @@ extern "C" int relnet_roi_pool_bwd_cl(const void* grad_out, const int* argmax, c
   // (one workgroup per CU at least: B C / 8 >= 256.  Same box, r06: 8 images 18.03 -> 17.81 ms with the owner form, ONE image 6.91 -> 7.00 ms -- 32 - 64 workgroups
   //  walking 308 rois lose to the 65 us scatter -- so small steps keep the scatter kernel)
   const bool owner = g_roi_bwd_mode != 1 && (long)B * C / 8 >= 256 && g.os_c == 1 && C % 8 == 0 && cells <= kOwnerMaxCells && g.os_r % 4 == 0 && g.os_ph % 4 == 0 &&
-                     g.os_pw % 4 == 0 && (((uintptr_t)argmax) & 15) == 0 && (((uintptr_t)grad_in) & 15) == 0;
+                     g.os_pw % 4 == 0 && (((uintptr_t)argmax) & 15) == 0 && (((uintptr_t)grad_in) & 15) == 0 &&
+                     (dtype != RELNET_BF16 || (g.os_r % 8 == 0 && g.os_ph % 8 == 0 && g.os_pw % 8 == 0 && (((uintptr_t)grad_out) & 15) == 0));
   if (owner) {
     const unsigned grid = (unsigned)(B * (C / 8));
     const size_t lds = (size_t)cells * 8 * sizeof(float) + kOwnerList * sizeof(int);
@@ -304,8 +337,8 @@ extern "C" int relnet_roi_pool_bwd_cl(const void* grad_out, const int* argmax, c
       hipFuncSetAttribute((const void*)roi_pool_bwd_owner_kernel<float, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);      // (+ 4 B of static LDS: the list counter)
       hipFuncSetAttribute((const void*)roi_pool_bwd_owner_kernel<unsigned short, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     }
-    if (dtype == RELNET_F32) roi_pool_bwd_owner_kernel<float, 8><<<grid, 256, lds, s>>>(g, (int)cells);
-    else roi_pool_bwd_owner_kernel<unsigned short, 8><<<grid, 256, lds, s>>>(g, (int)cells);
+    if (dtype == RELNET_F32) roi_pool_bwd_owner_kernel<float, 8><<<grid, kOwnerThreads, lds, s>>>(g, (int)cells, g_roi_bwd_mode >= 4 ? g_roi_bwd_mode - 4 : 0);
+    else roi_pool_bwd_owner_kernel<unsigned short, 8><<<grid, kOwnerThreads, lds, s>>>(g, (int)cells, g_roi_bwd_mode >= 4 ? g_roi_bwd_mode - 4 : 0);
     return check_launch("relnet_roi_pool_bwd_cl");
   }
   dim3 grid((unsigned)((long)R * PH * PW));
