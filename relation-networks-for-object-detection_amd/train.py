@@ -538,8 +538,10 @@ class Trainer(object):
                     rpn_backward(conv4, r, d_rpn)
 
         def rpn_backward(conv4, r, d_rpn):
-            # ... and with them the two RPN weight gradients, as their own grouped launch on 64 workgroups (a quarter of the chip: the head's
-            # kernels beside it keep theirs); RELNET_RPN_WGRAD_SIDE=0 leaves them in the 'heads' bucket's launch on the main stream
+            # RPN head backward (joins the trunk at conv4).  It depends on the RPN losses only: with the branch on its side stream it runs there,
+            # beside ROI pooling / the 2FC head / the learn-NMS branch (launches of <= 150 workgroups), and with it the two RPN weight gradients as
+            # their own grouped launch on 64 workgroups (a quarter of the chip: the head's kernels beside it keep theirs);
+            # RELNET_RPN_WGRAD_SIDE=0 leaves those in the 'heads' bucket's launch on the main stream
             nwg = int(os.environ.get('RELNET_RPN_WGRAD_SIDE', '64')) if rpn_bwd_side else 0
             rq = ops.WgradQueue() if nwg else None
             wg = (lambda n: self._wg(n)[:2] + (rq,)) if nwg else self._wg
