@@ -179,6 +179,10 @@ def load():
         raise RelnetError(
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no fallback path." % LIB_PATH)
+    # torch FIRST: its wheel ships its own libamdhip64 / librocm runtime, and this library must bind to THAT copy.  dlopen'ed before torch is
+    # imported (e.g. `build(); smoke()` in one process), it pulls in /opt/rocm's copy instead; torch then initialises a second HIP runtime and
+    # every launch from here fails with "no ROCm-capable device is detected" -- the device memory handed in belongs to the other runtime.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale -> loud

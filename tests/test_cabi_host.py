@@ -277,3 +277,24 @@ def test_asm_agpr_guard_ran_for_the_linked_library_and_flags_violations(tmp_path
     f.write_text(asm)
     r = b.asm_agpr_guard(str(f))
     assert r['kernels_checked'] == 1 and list(r['offenders']) == [k] and 'a5' in r['offenders'][k][0]
+
+
+def test_library_binds_to_the_hip_runtime_torch_ships():
+    """`build()` before `import torch` in one process (the driver's `build(); smoke()`): librelnet_hip.so must not pull /opt/rocm's libamdhip64 in
+    beside the copy the torch wheel ships -- with two HIP runtimes in the process every launch fails with "no ROCm-capable device is
+    detected" (round 6).  lib.load() imports torch first; exactly one libamdhip64 may be mapped afterwards."""
+    import subprocess
+    import sys
+    code = (
+        "import sys\n"
+        "assert 'torch' not in sys.modules\n"
+        "import __graft_entry__ as g\n"
+        "g.build()\n"
+        "import torch\n"
+        "paths = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l))\n"
+        "print('HIPLIBS', len(paths), paths)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('HIPLIBS')][-1]
+    assert line.split()[1] == '1', line
