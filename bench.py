@@ -180,13 +180,17 @@ def _replay_rate(det, bsz, a, D, replays=200, windows=5, step=None, make_det=Non
                 imj = torch.tensor([[600.0, 1000.0, 1.0]] * bsz).cuda()
                 detj = make_det(in_line=True)
                 return lambda: detj.forward(dj, imj)
-        flight = _det.InFlight([slot_step(j) for j in range(n_flight)])
-        med2, lo2, hi2 = _timed_windows(flight.submit, D, per_window, windows)
-        res['in_flight'] = {'batches_in_flight': n_flight, 'images_per_s': bsz / med2, 'ms_per_step_by_throughput': 1e3 * med2, 'images_per_s_min': bsz / hi2,
-                            'images_per_s_max': bsz / lo2,
-                            'note': '%d captured steps (own detector instance and resident batch each, RPN branch in line) on %d streams, submitted round-robin; every step '
-                                    'still takes its own ~ms_per_step above (or longer) from launch to result' % (n_flight, n_flight)}
-        del flight
+        try:          # (a figure beside the figure: its failure must not take the one-at-a-time rate above with it)
+            flight = _det.InFlight([slot_step(j) for j in range(n_flight)])
+            med2, lo2, hi2 = _timed_windows(flight.submit, D, per_window, windows)
+            res['in_flight'] = {'batches_in_flight': n_flight, 'images_per_s': bsz / med2, 'ms_per_step_by_throughput': 1e3 * med2, 'images_per_s_min': bsz / hi2,
+                                'images_per_s_max': bsz / lo2,
+                                'note': '%d captured steps (own detector instance and resident batch each, RPN branch in line) on %d streams, submitted round-robin; every step '
+                                        'still takes its own ~ms_per_step above (or longer) from launch to result' % (n_flight, n_flight)}
+            del flight
+        except Exception as ex:      # noqa: BLE001
+            res['in_flight'] = {'error': '%s: %s' % (type(ex).__name__, str(ex)[:300])}
+            torch.cuda.synchronize()
     return res
 
 
@@ -598,9 +602,9 @@ def main():
         # throughput mode (detector.InFlight), a SIDE figure of the line (`in_flight`): the same K steps with two batches in flight -- a second
         # detector instance (own buffers), a second resident batch, each step captured on its own stream, steps submitted round-robin.
         # `value` stays the one-at-a-time rate of rounds 1-5
-        elapsed_fl, n_flight = None, 1
-        if graph is not None and a.in_flight > 1:
-            del graph                 # (its executable graph holds runtime streams: with it alive the two graphs below measured no overlap at all)
+        elapsed_fl, n_flight, flight_err = None, 1, None
+        if graph is not None and a.in_flight > 1 and world == 1:      # (one rank only: a side figure must not be able to leave other ranks in a barrier)
+            del graph                 # (its executable graph holds runtime streams: with it alive the graphs below measured no overlap at all)
             graph = True
             torch.cuda.synchronize()
 
@@ -608,16 +612,23 @@ def main():
                 gj = torch.Generator().manual_seed(1000 + rank + 7919 * (j + 1))
                 dj, detj = torch.randn(a.batch, 3, im_h, im_w, generator=gj).cuda(), make_det(in_line=True)
                 return (lambda: detj.forward(dj, proposals, im_info)) if a.fpn else (lambda: detj.forward(dj, im_info))
-            flight = detector.InFlight([extra_step(j) for j in range(a.in_flight)])
-            for _ in range(2 * len(flight)):
-                flight.submit()
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(a.steps):
-                flight.submit()
-            fence()
-            elapsed_fl, n_flight = time.perf_counter() - t0, len(flight)
-            out = flight.result(0)
+            try:                      # a side figure: whatever happens here, the headline line above survives
+                flight = detector.InFlight([extra_step(j) for j in range(a.in_flight)])
+                for _ in range(2 * len(flight)):
+                    flight.submit()
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    flight.submit()
+                fence()
+                elapsed_fl, n_flight = time.perf_counter() - t0, len(flight)
+                n_fl = int(flight.result(0)['num_detections'].sum().item())
+                assert n_fl > 0 or a.learn_nms
+                del flight
+            except Exception as ex:   # noqa: BLE001
+                sys.stderr.write('bench.py: in-flight side figure failed: %s: %s\n' % (type(ex).__name__, str(ex)[:300]))
+                elapsed_fl, flight_err = None, '%s: %s' % (type(ex).__name__, str(ex)[:300])
+                torch.cuda.synchronize()
         # per-kernel durations: the same step launched eagerly with HIP events around every C-ABI
         # launch (events cannot be timed inside a captured graph); same inputs, same stream
         timer = None if a.no_kernel_timing else KernelTimer()
@@ -663,6 +674,8 @@ def main():
                                          'single GPU; at N > 1 the data-parallel scaling figure is train.value (training step incl. the RCCL all-reduce)',
                        **({'one_device_test': 'all %d ranks share cuda:0 and exchange over gloo (RELNET_BENCH_ONE_DEVICE): a code-path check, NOT a multi-GPU number' % world} if one_dev else {})},
         }
+        if flight_err is not None:
+            res['in_flight'] = {'error': flight_err}
         if elapsed_fl is not None:
             res['in_flight'] = {'batches_in_flight': n_flight, 'value': images / elapsed_fl, 'unit': 'images/s', 'ms_per_step_by_throughput': 1e3 * elapsed_fl / a.steps,
                                 'steps': a.steps, 'vs_one_at_a_time': elapsed / elapsed_fl,
